@@ -1,0 +1,194 @@
+"""TEST INFRASTRUCTURE ONLY. Generates tests/golden/*.pt by running the UNMODIFIED reference (/root/reference, via
+oracle/monai_stub.py) on CPU fp32 with fixed seeds. Only runnable in the build container; the fixtures are committed so
+the GPU box (no /root/reference) can pin both the oracle restatement and the HIP path against real reference outputs.
+
+    python oracle/make_golden.py            # rewrites every fixture
+
+Each fixture: dict(kind, cfg, state_dict, inputs{...}, outputs{...}, meta). Weights: reference default init under
+torch.manual_seed(seed), then derandomize_zeros(seed=1234, std=0.05).
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_loader import load_reference  # noqa: E402
+from restatement import derandomize_zeros, synthetic_state_dict  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def _randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+UNET_CASES = {
+    # the literal reference test configs, tests/test_diffusion_inferer.py:23-50 (C1a)
+    "unet2d_c1a": dict(cfg=dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=[8], norm_num_groups=8,
+                                attention_levels=[True], num_res_blocks=1, num_head_channels=8), shape=(2, 1, 8, 8)),
+    "unet3d_c1a": dict(cfg=dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=[8], norm_num_groups=8,
+                                attention_levels=[True], num_res_blocks=1, num_head_channels=8), shape=(2, 1, 8, 8, 8)),
+    # BASELINE.json configs[0] wording (C1b) at reduced resolution
+    "unet2d_c1b": dict(cfg=dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(32, 64),
+                                attention_levels=(False, True), num_res_blocks=1, num_head_channels=64),
+                       shape=(2, 1, 16, 16), synthetic=101),
+    # C2 topology (3 levels, 2 res blocks, attention only in the mid block, 1 head) at reduced width / resolution
+    "unet3d_c2mini": dict(cfg=dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(32, 64, 64),
+                                   attention_levels=(False, False, False), num_res_blocks=2,
+                                   num_head_channels=(0, 0, 64), norm_num_groups=32), shape=(1, 1, 16, 16, 16), synthetic=102),
+    # conditioned: cross-attention + class embedding + resblock_updown + concat-width groups
+    "unet2d_cond": dict(cfg=dict(spatial_dims=2, in_channels=2, out_channels=3, num_channels=(8, 16, 16),
+                                 attention_levels=(False, True, True), num_res_blocks=1, norm_num_groups=8,
+                                 num_head_channels=4, with_conditioning=True, cross_attention_dim=5,
+                                 transformer_num_layers=2, resblock_updown=True, num_class_embeds=4),
+                        shape=(2, 2, 8, 8), context=(2, 3, 5), class_labels=[1, 3]),
+    "unet3d_cond": dict(cfg=dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(8, 16),
+                                 attention_levels=(True, True), num_res_blocks=(1, 2), norm_num_groups=8,
+                                 num_head_channels=(8, 4), with_conditioning=True, cross_attention_dim=3,
+                                 upcast_attention=True), shape=(2, 1, 8, 8, 8), context=(2, 1, 3)),
+}
+
+AEKL_CASES = {
+    "aekl2d": dict(cfg=dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(8, 8, 16), latent_channels=4,
+                            attention_levels=(False, False, True), num_res_blocks=(1, 1, 2), norm_num_groups=4),
+                   shape=(2, 1, 16, 16)),
+    "aekl3d_brainlike": dict(cfg=dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4,
+                                      num_channels=(8, 16, 16), num_res_blocks=2, norm_num_groups=8,
+                                      attention_levels=(False, False, False), with_encoder_nonlocal_attn=False,
+                                      with_decoder_nonlocal_attn=False), shape=(1, 1, 16, 16, 16)),
+    "aekl3d_convT": dict(cfg=dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(8, 16),
+                                  latent_channels=3, attention_levels=(False, False), num_res_blocks=1,
+                                  norm_num_groups=8, use_convtranspose=True), shape=(2, 1, 8, 8, 8)),
+}
+
+VQVAE_CASES = {
+    "vqvae3d": dict(cfg=dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(8, 16), num_res_layers=1,
+                             num_res_channels=(8, 16), downsample_parameters=((2, 4, 1, 1),) * 2,
+                             upsample_parameters=((2, 4, 1, 1, 0),) * 2, num_embeddings=16, embedding_dim=8),
+                    shape=(2, 1, 16, 16, 16)),
+    "vqvae2d_odd": dict(cfg=dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(8, 16), num_res_layers=2,
+                                 num_res_channels=(4, 8), downsample_parameters=((2, 4, 1, 1), (1, 3, 1, 1)),
+                                 upsample_parameters=((1, 3, 1, 1, 0), (2, 3, 1, 1, 1)), num_embeddings=16,
+                                 embedding_dim=8, output_act="tanh"), shape=(2, 1, 16, 16)),
+}
+
+
+def main():
+    g = load_reference()
+    if g is None:
+        raise SystemExit("reference tree not found; golden fixtures can only be made in the build container")
+    from generative.inferers import DiffusionInferer
+    from generative.networks.nets import VQVAE, AutoencoderKL, DiffusionModelUNet
+    from generative.networks.schedulers import DDIMScheduler, DDPMScheduler
+
+    os.makedirs(OUT, exist_ok=True)
+    for name, case in UNET_CASES.items():
+        torch.manual_seed(0)
+        m = DiffusionModelUNet(**case["cfg"]).eval()
+        derandomize_zeros(m)
+        shapes = None
+        if case.get("synthetic"):  # weights too large to commit: regenerate from (shapes, seed) on both sides
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            m.load_state_dict(synthetic_state_dict(shapes, seed=case["synthetic"]))
+        x = _randn(case["shape"], 7)
+        n = case["shape"][0]
+        t = torch.tensor([980, 20][:n]) if n > 1 else torch.tensor([500])
+        ctx = _randn(case["context"], 8) if "context" in case else None
+        cl = torch.tensor(case["class_labels"]) if "class_labels" in case else None
+        with torch.no_grad():
+            y = m(x, t, context=ctx, class_labels=cl)
+        torch.save(dict(kind="unet", cfg=case["cfg"], state_dict=None if shapes else m.state_dict(), shapes=shapes,
+                        synthetic_seed=case.get("synthetic"),
+                        inputs=dict(x=x, timesteps=t, context=ctx, class_labels=cl), outputs=dict(y=y)),
+                   os.path.join(OUT, name + ".pt"))
+        print(name, tuple(y.shape), float(y.abs().max()))
+
+    for name, case in AEKL_CASES.items():
+        torch.manual_seed(0)
+        m = AutoencoderKL(**case["cfg"]).eval()
+        x = _randn(case["shape"], 7)
+        with torch.no_grad():
+            mu, sigma = m.encode(x)
+            rec = m.decode(mu)
+        torch.save(dict(kind="aekl", cfg=case["cfg"], state_dict=m.state_dict(), inputs=dict(x=x),
+                        outputs=dict(z_mu=mu, z_sigma=sigma, reconstruction=rec)), os.path.join(OUT, name + ".pt"))
+        print(name, tuple(mu.shape), tuple(rec.shape))
+
+    for name, case in VQVAE_CASES.items():
+        torch.manual_seed(0)
+        m = VQVAE(**case["cfg"]).eval()
+        x = _randn(case["shape"], 7)
+        with torch.no_grad():
+            z = m.encode(x)
+            idx = m.index_quantize(x)
+            q, loss = m.quantize(z)
+            rec = m.decode(q)
+        torch.save(dict(kind="vqvae", cfg=case["cfg"], state_dict=m.state_dict(), inputs=dict(x=x),
+                        outputs=dict(z=z, indices=idx, quantized=q, loss=loss, reconstruction=rec)),
+                   os.path.join(OUT, name + ".pt"))
+        print(name, tuple(z.shape), tuple(idx.shape))
+
+    # scheduler known-answer vectors: tables + single steps on fixed tensors (fp32, bit-exact targets)
+    sched = {}
+    mo, xs = _randn((2, 2, 4, 4, 4), 11), _randn((2, 2, 4, 4, 4), 12)
+    for sname, kw in [("linear_beta", {}), ("scaled_linear_beta", dict(beta_start=0.0005, beta_end=0.0195)),
+                      ("sigmoid_beta", {}), ("cosine", {})]:
+        ddim = DDIMScheduler(1000, schedule=sname, clip_sample=False, **kw)
+        ddim.set_timesteps(50)
+        entry = dict(kw=kw, betas=ddim.betas.clone(), alphas=ddim.alphas.clone(),
+                     alphas_cumprod=ddim.alphas_cumprod.clone(), timesteps50=ddim.timesteps.clone(), ddim={}, ddpm={})
+        for pt in ["epsilon", "sample", "v_prediction"]:
+            for clip in [False, True]:
+                ddim.prediction_type, ddim.clip_sample = pt, clip
+                for t in [980, 500, 20]:
+                    entry["ddim"][(pt, clip, t, 0.0)] = ddim.step(mo, t, xs)
+                gen = torch.Generator().manual_seed(5)
+                entry["ddim"][(pt, clip, 500, 0.5)] = ddim.step(mo, 500, xs, eta=0.5, generator=gen)
+        ddpm = DDPMScheduler(1000, schedule=sname, **kw)
+        for pt in ["epsilon", "sample", "v_prediction"]:
+            for vt in ["fixed_small", "fixed_large"]:
+                ddpm.prediction_type, ddpm.variance_type = pt, vt
+                for t in [999, 500, 1]:
+                    gen = torch.Generator().manual_seed(5)
+                    entry["ddpm"][(pt, vt, t)] = ddpm.step(mo, t, xs, generator=gen)
+        ts = torch.tensor([999, 3])
+        entry["add_noise"] = ddpm.add_noise(xs, mo, ts)
+        entry["get_velocity"] = DDPMScheduler(1000, schedule=sname, **kw).get_velocity(xs, mo, ts)
+        sched[sname] = entry
+    # learned variance (model predicts 2*C channels)
+    mo2 = _randn((2, 4, 4, 4, 4), 13)
+    for vt in ["learned", "learned_range"]:
+        d = DDPMScheduler(1000, variance_type=vt)
+        gen = torch.Generator().manual_seed(5)
+        sched["linear_beta"]["ddpm"][("epsilon", vt, 500)] = d.step(mo2, 500, xs, generator=gen)
+    torch.save(dict(kind="schedulers", model_output=mo, model_output2=mo2, sample=xs, noise_seed=5, tables=sched),
+               os.path.join(OUT, "schedulers.pt"))
+
+    # a full (free-running) DDIM-10 chain of the C1a 3D model, clip_sample=False, and a DDPM-10 chain with seeded noise
+    torch.manual_seed(0)
+    cfg = UNET_CASES["unet3d_c1a"]["cfg"]
+    m = DiffusionModelUNet(**cfg).eval()
+    derandomize_zeros(m)
+    noise = _randn((2, 1, 8, 8, 8), 21)
+    ddim = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    ddim.set_timesteps(10)
+    inf = DiffusionInferer(ddim)
+    out, inter = inf.sample(noise, m, ddim, save_intermediates=True, intermediate_steps=100, verbose=False)
+    ddpm = DDPMScheduler(num_train_timesteps=10)
+    ddpm.set_timesteps(10)
+    torch.manual_seed(99)  # DDPM draws its noise from the global CPU generator (ddpm.py:244-247)
+    out_p, inter_p = DiffusionInferer(ddpm).sample(noise, m, ddpm, save_intermediates=True, intermediate_steps=1,
+                                                   verbose=False)
+    xin = _randn((2, 1, 8, 8, 8), 22)
+    ts = torch.tensor([7, 2])
+    pred = DiffusionInferer(ddpm)(inputs=xin, diffusion_model=m, noise=noise, timesteps=ts)
+    torch.save(dict(kind="chain", cfg=cfg, state_dict=m.state_dict(), noise=noise, ddim_out=out, ddim_inter=inter,
+                    ddpm_out=out_p, ddpm_inter=inter_p, ddpm_global_seed=99, call_inputs=xin, call_timesteps=ts,
+                    call_prediction=pred), os.path.join(OUT, "chain_c1a3d.pt"))
+    print("chains", float(out.abs().max()), float(out_p.abs().max()), len(inter), len(inter_p))
+
+
+if __name__ == "__main__":
+    main()

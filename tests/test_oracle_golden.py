@@ -1,0 +1,93 @@
+"""CPU: pins the oracle restatement (oracle/restatement.py) against golden outputs of the UNMODIFIED reference
+(tests/golden/*.pt, made by oracle/make_golden.py in the build container). Tolerance 2e-5 abs on O(1) outputs = the
+reference's own fp32 op-order noise floor (fp32-vs-fp64 1.2e-5); scheduler arithmetic is bit-exact."""
+import pytest
+import torch
+
+import restatement as R
+from _util import assert_close, load_fixture
+
+UNETS = ["unet2d_c1a", "unet3d_c1a", "unet2d_c1b", "unet3d_c2mini", "unet2d_cond", "unet3d_cond"]
+
+
+@pytest.mark.parametrize("name", UNETS)
+def test_unet_forward_matches_reference(name):
+    fx = load_fixture(name)
+    i = fx["inputs"]
+    with torch.no_grad():
+        y = R.unet_forward(fx["state_dict"], fx["cfg"], i["x"], i["timesteps"], i["context"], i["class_labels"])
+    assert_close(y, fx["outputs"]["y"], atol=2e-5, what=name)
+
+
+@pytest.mark.parametrize("name", ["aekl2d", "aekl3d_brainlike", "aekl3d_convT"])
+def test_aekl_matches_reference(name):
+    fx = load_fixture(name)
+    sd, cfg, x = fx["state_dict"], fx["cfg"], fx["inputs"]["x"]
+    with torch.no_grad():
+        mu, sigma = R.aekl_encode(sd, cfg, x)
+        rec = R.aekl_decode(sd, cfg, fx["outputs"]["z_mu"])
+    assert_close(mu, fx["outputs"]["z_mu"], 2e-5, what="z_mu")
+    assert_close(sigma, fx["outputs"]["z_sigma"], 2e-5, what="z_sigma")
+    assert_close(rec, fx["outputs"]["reconstruction"], 2e-5, what="reconstruction")
+
+
+@pytest.mark.parametrize("name", ["vqvae3d", "vqvae2d_odd"])
+def test_vqvae_matches_reference(name):
+    fx = load_fixture(name)
+    sd, cfg, x, o = fx["state_dict"], fx["cfg"], fx["inputs"]["x"], fx["outputs"]
+    with torch.no_grad():
+        z = R.vqvae_encode(sd, cfg, x)
+        idx, _ = R.vq_index_quantize(sd, o["z"])
+        q, loss = R.vq_quantize(sd, cfg, o["z"])
+        rec = R.vqvae_decode(sd, cfg, o["quantized"])
+    assert_close(z, o["z"], 2e-5, what="z")
+    assert torch.equal(idx, o["indices"])  # integer work: bit-exact
+    assert_close(q, o["quantized"], 1e-6, what="quantized")
+    assert_close(loss, o["loss"], 1e-6, what="loss")
+    assert_close(rec, o["reconstruction"], 2e-5, what="reconstruction")
+    assert_close(R.vqvae_decode(sd, cfg, R.vq_embed(sd, o["indices"])), o["reconstruction"], 2e-5, what="decode_samples")
+
+
+def _eq(a, b):
+    return torch.allclose(a, b, rtol=0, atol=0, equal_nan=True)
+
+
+def test_scheduler_tables_and_steps_bit_exact():
+    fx = load_fixture("schedulers")
+    mo, xs = fx["model_output"], fx["sample"]
+    for sname, e in fx["tables"].items():
+        b, a, ac = R.noise_schedule(sname, 1000, **e["kw"])
+        assert torch.equal(b, e["betas"]) and torch.equal(a, e["alphas"]) and torch.equal(ac, e["alphas_cumprod"])
+        assert torch.equal(R.inference_timesteps(1000, 50), e["timesteps50"])
+        for (pt, clip, t, eta), (prev, x0) in e["ddim"].items():
+            noise = None
+            if eta > 0:
+                noise = torch.randn(mo.shape, dtype=mo.dtype, generator=torch.Generator().manual_seed(fx["noise_seed"]))
+            p2, x2 = R.ddim_step(ac, 1000, 50, mo, t, xs, eta=eta, prediction_type=pt, clip_sample=clip, noise=noise)
+            assert _eq(p2, prev) and _eq(x2, x0), (sname, pt, clip, t, eta)
+        for (pt, vt, t), (prev, x0) in e["ddpm"].items():
+            m = fx["model_output2"] if vt.startswith("learned") else mo
+            shape = list(m.shape)
+            if vt.startswith("learned"):
+                shape[1] //= 2
+            noise = torch.randn(shape, dtype=m.dtype, generator=torch.Generator().manual_seed(fx["noise_seed"]))
+            p2, x2 = R.ddpm_step(b, a, ac, m, t, xs, prediction_type=pt, variance_type=vt, noise=noise)
+            assert _eq(p2, prev) and _eq(x2, x0), (sname, pt, vt, t)
+        ts = torch.tensor([999, 3])
+        assert _eq(R.add_noise(ac, xs, mo, ts), e["add_noise"])
+        assert _eq(R.get_velocity(ac, xs, mo, ts), e["get_velocity"])
+
+
+def test_ddim_chain_matches_reference():
+    fx = load_fixture("chain_c1a3d")
+    _, _, ac = R.noise_schedule("scaled_linear_beta", 1000, beta_start=0.0005, beta_end=0.0195)
+    sched = dict(alphas_cumprod=ac, num_train_timesteps=1000, num_inference_steps=10,
+                 timesteps=R.inference_timesteps(1000, 10), clip_sample=False)
+    inter = []
+    with torch.no_grad():
+        out = R.ddim_sample(fx["state_dict"], fx["cfg"], fx["noise"], sched,
+                            on_step=lambda t, im: inter.append(im) if t % 100 == 0 else None)
+    # free-running clip_sample=False chain in fp32: reference self-noise 1.9e-4 on sigma~49
+    scale = fx["ddim_out"].abs().max().item()
+    assert_close(out, fx["ddim_out"], atol=2e-5 * max(1.0, scale), what="ddim chain")
+    assert len(inter) == len(fx["ddim_inter"])
