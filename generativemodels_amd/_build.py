@@ -1,0 +1,67 @@
+"""Builds the C-ABI HIP library (generativemodels_amd/lib/libgmamd.so) for gfx950 with hipcc. In-tree, no torch headers.
+
+`python -m generativemodels_amd._build` or `__graft_entry__.build()`; cross-compiles without a GPU."""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libgmamd.so")
+OBJDIR = os.path.join(HERE, "build")
+SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "attention.hip", "vq.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the gfx950 library cannot be built")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    srcp = os.path.join(CSRC, src)
+    deps = [srcp, os.path.join(CSRC, "gm_common.h")]
+    if _stale(obj, deps):
+        cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", srcp, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJDIR):
+            os.remove(os.path.join(OBJDIR, f))
+    with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if force or _stale(LIBPATH, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIBPATH]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print("built", LIBPATH, os.path.getsize(LIBPATH), "bytes")
+    return LIBPATH
+
+
+if __name__ == "__main__":
+    build_native(force="--force" in sys.argv, verbose=True)

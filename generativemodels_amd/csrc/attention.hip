@@ -1,0 +1,290 @@
+// Single-pass (flash-style) softmax attention on the CDNA4 matrix cores; the L x L score matrix never exists in HBM.
+//
+// Reference semantics (networks/nets/diffusion_model_unet.py:407-415 AttentionBlock, :143-153 CrossAttention,
+// networks/nets/autoencoderkl.py:261-269):  O = softmax(scale * Q K^T) V  per (batch, head), optionally + residual.
+// Scores and the softmax state are fp32 for every storage dtype (a superset of the reference's `upcast_attention`).
+//
+// Everything is kept in the *transposed* orientation so that a lane owns ONE query for the whole kernel:
+//   S^T[key][query] = K Q^T   (A = K tile from LDS, B = Q fragments held in registers)
+//   O^T[d][query]   = V^T P^T (A = V tile from LDS, B = P^T straight from the S^T accumulators -- no cross-lane moves)
+// The C/D layout of the 16x16 MFMAs (col = lane&15, row = 4*(lane>>4)+reg) then gives every lane 4 keys of its own query
+// after QK^T and 4 consecutive head channels of its own query after PV: running max / sum / rescale are lane-local, the
+// row max needs two xor-shuffles, and the output is stored as 8/16-byte NDHWC vectors.
+// bf16: v_mfma_f32_16x16x32_bf16, V is transposed (8x8 register blocks) while it is staged into LDS so the PV A-operand is
+// one ds_read_b128 per MFMA.  fp32: v_mfma_f32_16x16x4_f32 (exact fp32 products), V stays row-major.
+#include "gm_common.h"
+
+struct GmAttnDesc {
+  const void* q; long long q_ld;
+  const void* k; long long k_ld;
+  const void* v; long long v_ld;
+  const void* res; long long res_ld;  // optional residual, same geometry as o
+  void* o; long long o_ld;
+  int B, H, Lq, Lk, dh;
+  float scale;
+  int dtype;
+};
+
+template <typename T> struct AttnTraits;
+template <> struct AttnTraits<bf16_raw> { static constexpr int VECW = 8; static constexpr int KT = 64; };
+template <> struct AttnTraits<float> { static constexpr int VECW = 4; static constexpr int KT = 32; };
+
+__device__ __forceinline__ void unpack16(const uint4& v, float* o, bf16_raw) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+// load 16 bytes of row `row` at element offset c0 (zero fill outside [0, climit) / invalid rows)
+template <typename T>
+__device__ __forceinline__ uint4 load_row16(const T* base, long long ld, long long row, bool row_ok, int c0, int climit, bool vec_ok) {
+  constexpr int VECW = 16 / sizeof(T);
+  uint4 r = make_uint4(0, 0, 0, 0);
+  if (!row_ok || c0 >= climit) return r;
+  const T* p = base + row * ld + c0;
+  if (vec_ok) return *reinterpret_cast<const uint4*>(p);
+  T tmp[VECW];
+#pragma unroll
+  for (int i = 0; i < VECW; ++i) tmp[i] = (c0 + i < climit) ? p[i] : (T)0;
+  return *reinterpret_cast<uint4*>(tmp);
+}
+
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
+  constexpr int VECW = AttnTraits<T>::VECW;
+  constexpr int KT = AttnTraits<T>::KT;
+  constexpr int KF = KT / 16;                      // key fragments per tile
+  constexpr int ROWB_K = DH * (int)sizeof(T) + 16; // K tile row pitch (bytes)
+  constexpr int STEPS = DH * (int)sizeof(T) / 64;  // 64-byte k-steps over the head dim
+  constexpr int DF = DH / 16;                      // output channel fragments
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int ROWB_V = IS_BF16 ? (KT * 2 + 16) : (DH * 4 + 16);  // bf16: V^T rows of KT keys; fp32: V rows of DH
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;                              // [KT][ROWB_K]
+  char* ldsV = smem + (size_t)KT * ROWB_K;        // bf16: [DH][ROWB_V] (transposed), fp32: [KT][ROWB_V]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, qg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int my_q = q0 + l15;
+  const bool q_ok = my_q < p.Lq;
+
+  const T* Qb = reinterpret_cast<const T*>(p.q) + (long long)b * p.Lq * p.q_ld + h * p.dh;
+  const T* Kb = reinterpret_cast<const T*>(p.k) + (long long)b * p.Lk * p.k_ld + h * p.dh;
+  const T* Vb = reinterpret_cast<const T*>(p.v) + (long long)b * p.Lk * p.v_ld + h * p.dh;
+  const bool qvec = (p.dh % VECW == 0) && (p.q_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(Qb) & 15) == 0);
+  const bool kvec = (p.dh % VECW == 0) && (p.k_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(Kb) & 15) == 0);
+  const bool vvec = (p.dh % VECW == 0) && (p.v_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(Vb) & 15) == 0);
+
+  // Q fragments (B operand of S^T = K Q^T): lane (query l15, slot qg) holds channels step*BK + qg*VECW .. +VECW-1
+  uint4 qf[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) qf[s] = load_row16<T>(Qb, p.q_ld, my_q, q_ok, (s * 4 + qg) * VECW, p.dh, qvec);
+
+  f32x4_t oacc[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (p.Lk + KT - 1) / KT;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int key0 = tile * KT;
+    __syncthreads();  // the previous tile's LDS reads are complete
+    // ---- stage K: [KT][DH] row-major --------------------------------------------------------------------------------
+    {
+      constexpr int CH = DH * (int)sizeof(T) / 16;  // 16-byte chunks per row
+      for (int item = tid; item < KT * CH; item += 256) {
+        const int row = item / CH, ch = item % CH;
+        const uint4 v = load_row16<T>(Kb, p.k_ld, key0 + row, key0 + row < p.Lk, ch * VECW, p.dh, kvec);
+        *reinterpret_cast<uint4*>(ldsK + (size_t)row * ROWB_K + ch * 16) = v;
+      }
+    }
+    // ---- stage V ----------------------------------------------------------------------------------------------------
+    if constexpr (IS_BF16) {
+      // 8 keys x 8 channels per item, transposed in registers.  Key order inside a V^T row: position
+      // pos = s*32 + qq*8 + half*4 + r  <->  key = (2s+half)*16 + qq*4 + r, i.e. exactly the 8 keys lane-group qq
+      // feeds into k-step s of the PV MFMA are contiguous (one ds_read_b128).
+      constexpr int PB = KT / 8, DB = DH / 8;
+      for (int item = tid; item < PB * DB; item += 256) {
+        const int pb = item % PB, db = item / PB;
+        const int s = pb >> 2, qq = pb & 3;
+        uint4 rows[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int key = key0 + (2 * s + (j >> 2)) * 16 + qq * 4 + (j & 3);
+          rows[j] = load_row16<T>(Vb, p.v_ld, key, key < p.Lk, db * 8, p.dh, vvec);
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          uint32_t w[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const uint32_t a = reinterpret_cast<const uint32_t*>(&rows[2 * c])[d >> 1];
+            const uint32_t bq = reinterpret_cast<const uint32_t*>(&rows[2 * c + 1])[d >> 1];
+            w[c] = (d & 1) ? ((a >> 16) | (bq & 0xffff0000u)) : ((a & 0xffffu) | (bq << 16));
+          }
+          *reinterpret_cast<uint4*>(ldsV + (size_t)(db * 8 + d) * ROWB_V + pb * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
+    } else {
+      constexpr int CH = DH * 4 / 16;
+      for (int item = tid; item < KT * CH; item += 256) {
+        const int row = item / CH, ch = item % CH;
+        const uint4 v = load_row16<T>(Vb, p.v_ld, key0 + row, key0 + row < p.Lk, ch * VECW, p.dh, vvec);
+        *reinterpret_cast<uint4*>(ldsV + (size_t)row * ROWB_V + ch * 16) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T ------------------------------------------------------------------------------------------------
+    f32x4_t sacc[KF];
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf) sacc[kf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf) {
+        const uint4 kfrag = *reinterpret_cast<const uint4*>(ldsK + (size_t)(kf * 16 + l15) * ROWB_K + s * 64 + qg * 16);
+        if constexpr (IS_BF16) {
+          sacc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kfrag),
+                                                             __builtin_bit_cast(bf16x8_t, qf[s]), sacc[kf], 0, 0, 0);
+        } else {
+          sacc[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(kfrag.x), __uint_as_float(qf[s].x), sacc[kf], 0, 0, 0);
+          sacc[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(kfrag.y), __uint_as_float(qf[s].y), sacc[kf], 0, 0, 0);
+          sacc[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(kfrag.z), __uint_as_float(qf[s].z), sacc[kf], 0, 0, 0);
+          sacc[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(kfrag.w), __uint_as_float(qf[s].w), sacc[kf], 0, 0, 0);
+        }
+      }
+    }
+    // ---- online softmax: this lane's query, keys key0 + kf*16 + qg*4 + r ---------------------------------------------
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + kf * 16 + qg * 4 + r;
+        const float sv = key < p.Lk ? sacc[kf][r] * p.scale : -INFINITY;
+        sacc[kf][r] = sv;
+        tmax = fmaxf(tmax, sv);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = IS_BF16 ? __expf(m_run - m_new) : expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = IS_BF16 ? __expf(sacc[kf][r] - m_new) : expf(sacc[kf][r] - m_new);
+        sacc[kf][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DF; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha;
+
+    // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------
+    if constexpr (IS_BF16) {
+      uint4 pf[KF / 2];
+#pragma unroll
+      for (int s = 0; s < KF / 2; ++s) {
+        uint32_t w[4];
+        w[0] = (uint32_t)f32_to_bf16(sacc[2 * s][0]) | ((uint32_t)f32_to_bf16(sacc[2 * s][1]) << 16);
+        w[1] = (uint32_t)f32_to_bf16(sacc[2 * s][2]) | ((uint32_t)f32_to_bf16(sacc[2 * s][3]) << 16);
+        w[2] = (uint32_t)f32_to_bf16(sacc[2 * s + 1][0]) | ((uint32_t)f32_to_bf16(sacc[2 * s + 1][1]) << 16);
+        w[3] = (uint32_t)f32_to_bf16(sacc[2 * s + 1][2]) | ((uint32_t)f32_to_bf16(sacc[2 * s + 1][3]) << 16);
+        pf[s] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+#pragma unroll
+      for (int d = 0; d < DF; ++d)
+#pragma unroll
+        for (int s = 0; s < KF / 2; ++s) {
+          const uint4 vfrag = *reinterpret_cast<const uint4*>(ldsV + (size_t)(d * 16 + l15) * ROWB_V + s * 64 + qg * 16);
+          oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vfrag),
+                                                            __builtin_bit_cast(bf16x8_t, pf[s]), oacc[d], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DF; ++d)
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float vv = *reinterpret_cast<const float*>(ldsV + (size_t)(kf * 16 + qg * 4 + i) * ROWB_V + (d * 16 + l15) * 4);
+            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, sacc[kf][i], oacc[d], 0, 0, 0);
+          }
+    }
+  }
+
+  // ---- finish: 1/l, residual, store ------------------------------------------------------------------------------------
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (!q_ok) return;
+  T* orow = reinterpret_cast<T*>(p.o) + ((long long)b * p.Lq + my_q) * p.o_ld + h * p.dh;
+  const T* rrow = p.res ? reinterpret_cast<const T*>(p.res) + ((long long)b * p.Lq + my_q) * p.res_ld + h * p.dh : nullptr;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = d * 16 + qg * 4 + r;
+      if (c < p.dh) {
+        float v = oacc[d][r] * inv;
+        if (rrow) v += ElemIO<T>::ld(rrow + c);
+        ElemIO<T>::st(orow + c, v);
+      }
+    }
+  }
+}
+
+template <typename T, int DH>
+static int launch_attn(const GmAttnDesc& d, hipStream_t st) {
+  constexpr int KT = AttnTraits<T>::KT;
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr size_t smem = (size_t)KT * (DH * sizeof(T) + 16) + (IS_BF16 ? (size_t)DH * (KT * 2 + 16) : (size_t)KT * (DH * 4 + 16));
+  static bool attr_set = false;
+  auto kern = attn_kernel<T, DH>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();
+    attr_set = true;
+  }
+  dim3 grid((d.Lq + 63) / 64, d.B * d.H);
+  kern<<<grid, 256, smem, st>>>(d);
+  return 0;
+}
+
+template <typename T>
+static int dispatch_attn(const GmAttnDesc& d, hipStream_t st) {
+  if (d.dh <= 32) return launch_attn<T, 32>(d, st);
+  if (d.dh <= 64) return launch_attn<T, 64>(d, st);
+  if (d.dh <= 128) return launch_attn<T, 128>(d, st);
+  if (d.dh <= 256) return launch_attn<T, 256>(d, st);
+  return -1;
+}
+
+extern "C" int gm_attention_max_head_dim(void) { return 256; }
+
+extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream) {
+  GM_REQUIRE(dp, "null descriptor");
+  const GmAttnDesc& d = *dp;
+  GM_REQUIRE(d.q && d.k && d.v && d.o, "null tensor pointer");
+  GM_REQUIRE(d.B >= 0 && d.H > 0 && d.dh > 0, "bad batch / head geometry");
+  GM_REQUIRE(d.Lk > 0, "attention needs at least one key");
+  GM_REQUIRE(d.dh <= 256, "head dim > 256 is not supported by the gfx950 attention kernel");
+  GM_REQUIRE((long long)d.B * d.H <= 65535, "too many (batch, head) pairs for one launch");
+  if (d.B == 0 || d.Lq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (d.dtype == GM_F32) rc = dispatch_attn<float>(d, st);
+  else if (d.dtype == GM_BF16) rc = dispatch_attn<bf16_raw>(d, st);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_REQUIRE(rc == 0, "dispatch failed");
+  GM_LAUNCH_CHECK();
+}

@@ -1,0 +1,66 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of generativemodels_amd.
+// Everything here is wave64 / CDNA4 specific by design: no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GM_F32 0
+#define GM_BF16 1
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef uint16_t bf16_raw;  // storage type of a bf16 element in HBM / LDS
+
+// ---- error plumbing shared by every extern "C" entry point ---------------------------------------------------------
+extern "C" void gm_set_error(const char* where, int code, const char* msg);
+#define GM_FAIL(code, msg)                 \
+  do {                                     \
+    gm_set_error(__func__, (code), (msg)); \
+    return (code);                         \
+  } while (0)
+#define GM_REQUIRE(cond, msg) \
+  do {                        \
+    if (!(cond)) GM_FAIL(-1, msg); \
+  } while (0)
+#define GM_LAUNCH_CHECK()                                          \
+  do {                                                             \
+    hipError_t e__ = hipGetLastError();                            \
+    if (e__ != hipSuccess) GM_FAIL((int)e__, hipGetErrorString(e__)); \
+    return 0;                                                      \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_raw v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_raw)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_raw)(u >> 16);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemIO<bf16_raw> {
+  static __device__ __forceinline__ float ld(const bf16_raw* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_raw* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float gm_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gm_silu_precise(float x) { return x / (1.0f + expf(-x)); }
+
+// wave64 butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int gm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,260 @@
+// GroupNorm statistics for N[D]HWC activations + LayerNorm over token rows.
+//
+// Reference semantics: nn.GroupNorm(G, C, eps, affine=True) as used at networks/nets/diffusion_model_unet.py:623,643,
+// 275,377,1854 and networks/nets/autoencoderkl.py:146,156,227,433,579 -- biased variance over (C/G)*V elements of one
+// sample.  The normalisation itself is never a separate pass here: gm_gn_stats + gm_gn_finalize produce per-(n, c)
+// fp32 `scale = rstd*gamma`, `shift = beta - mean*rstd*gamma`, which the consumer (conv / linear prologue, conv.hip)
+// applies while it stages its input tile.  gm_gn_apply exists for callers without a fusable consumer.
+//
+// HBM-bound: one read of the tensor (C*V*elt bytes per sample).  Reductions: per-thread fp32 partials over <= 64 rows,
+// wave/LDS tree in fp64, block partials merged in fp64 in a fixed order -> deterministic and fp32-parity safe.
+#include "gm_common.h"
+
+#define GN_THREADS 256
+#define GN_ROWS_PER_THREAD 64
+
+template <typename T, int VEC> struct VecLd;
+template <> struct VecLd<float, 4> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+};
+template <> struct VecLd<float, 1> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) { o[0] = *p; }
+};
+template <> struct VecLd<bf16_raw, 8> {
+  static __device__ __forceinline__ void ld(const bf16_raw* p, float* o) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(w[i] << 16);
+      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+};
+template <> struct VecLd<bf16_raw, 1> {
+  static __device__ __forceinline__ void ld(const bf16_raw* p, float* o) { o[0] = bf16_to_f32(*p); }
+};
+
+// grid (nblk, N).  partial[(n*nblk + blk)*G + g] = {sum, sumsq} (fp64) over rows [blk*rpb, (blk+1)*rpb) of sample n.
+template <typename T, int VEC>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, long long ld, long long V, int C,
+                                                             int G, int rows_per_block, double2* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int CV = C / VEC;              // channel vectors per row (<= GN_THREADS, checked on the host)
+  const int R = GN_THREADS / CV;       // rows in flight
+  float* part_s = reinterpret_cast<float*>(smem_raw);           // [R][C]
+  float* part_q = part_s + (size_t)R * C;                       // [R][C]
+  double* ch_s = reinterpret_cast<double*>(part_q + (size_t)R * C);  // [C]
+  double* ch_q = ch_s + C;                                      // [C]
+
+  const int n = blockIdx.y, blk = blockIdx.x;
+  const int t = threadIdx.x;
+  const int cv = t % CV, r0 = t / CV;
+  const long long row_begin = (long long)blk * rows_per_block;
+  long long row_end = row_begin + rows_per_block;
+  if (row_end > V) row_end = V;
+
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q[i] = 0.f; }
+  if (r0 < R) {
+    const T* base = x + ((long long)n * V) * ld + (long long)cv * VEC;
+    for (long long r = row_begin + r0; r < row_end; r += R) {
+      float v[VEC];
+      VecLd<T, VEC>::ld(base + r * ld, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      part_s[(size_t)r0 * C + cv * VEC + i] = s[i];
+      part_q[(size_t)r0 * C + cv * VEC + i] = q[i];
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += GN_THREADS) {
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < R; ++r) { a += (double)part_s[(size_t)r * C + c]; b += (double)part_q[(size_t)r * C + c]; }
+    ch_s[c] = a; ch_q[c] = b;
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = t; g < G; g += GN_THREADS) {
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < cpg; ++j) { a += ch_s[g * cpg + j]; b += ch_q[g * cpg + j]; }
+    partial[((long long)n * gridDim.x + blk) * G + g] = make_double2(a, b);
+  }
+}
+
+// grid N*G blocks of one wave.  Merges the block partials, writes mean/rstd (optional) and per-channel scale/shift.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const double2* __restrict__ partial, int nblk, int C, int G,
+                                                        long long V, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ scale,
+                                                        float* __restrict__ shift, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out) {
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int lane = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int i = lane; i < nblk; i += 64) {
+    const double2 p = partial[((long long)n * nblk + i) * G + g];
+    a += p.x; b += p.y;
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  const int cpg = C / G;
+  const double cnt = (double)cpg * (double)V;
+  const double mean = a / cnt;
+  double var = b / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[n * G + g] = (float)mean;
+    if (rstd_out) rstd_out[n * G + g] = (float)rstd;
+  }
+  for (int j = lane; j < cpg; j += 64) {
+    const int c = g * cpg + j;
+    const double ga = gamma ? (double)gamma[c] : 1.0;
+    const double be = beta ? (double)beta[c] : 0.0;
+    scale[(long long)n * C + c] = (float)(rstd * ga);
+    shift[(long long)n * C + c] = (float)(be - mean * rstd * ga);
+  }
+}
+
+static long long gn_nblk(long long V, int C, int vec) {
+  const int CV = C / vec;
+  const int R = GN_THREADS / CV;
+  const long long rpb = (long long)R * GN_ROWS_PER_THREAD;
+  return (V + rpb - 1) / rpb;
+}
+
+// Upper bound over both load widths the dispatcher may pick (vector when C, ld and the base are 16-byte friendly).
+extern "C" long long gm_gn_workspace_bytes(int N, long long V, int C, int G, int dtype) {
+  const int vecmax = dtype == GM_F32 ? 4 : 8;
+  long long nblk = 0;
+  if (C % vecmax == 0 && C / vecmax <= GN_THREADS) nblk = gn_nblk(V, C, vecmax);
+  if (C <= GN_THREADS) {
+    const long long nb1 = gn_nblk(V, C, 1);
+    if (nb1 > nblk) nblk = nb1;
+  }
+  if (nblk == 0) return -1;
+  return (long long)N * nblk * G * (long long)sizeof(double2);
+}
+
+template <typename T, int VEC>
+static int launch_gn_stats(const void* x, long long ld, int N, long long V, int C, int G, double2* ws, int* nblk_out,
+                           hipStream_t st) {
+  const int CV = C / VEC;
+  const int R = GN_THREADS / CV;
+  const int rpb = R * GN_ROWS_PER_THREAD;
+  const int nblk = gm_cdiv(V, rpb);
+  const size_t smem = (size_t)R * C * 2 * sizeof(float) + (size_t)C * 2 * sizeof(double);
+  *nblk_out = nblk;
+  dim3 grid(nblk, N);
+  gn_stats_kernel<T, VEC><<<grid, GN_THREADS, smem, st>>>((const T*)x, ld, V, C, G, rpb, ws);
+  return 0;
+}
+
+// x: [N][V][ld] (C <= ld channels used), gamma/beta: fp32 [C] (nullable), scale/shift: fp32 [N][C] outputs,
+// mean/rstd: optional fp32 [N][G] outputs, workspace: >= gm_gn_workspace_bytes(...) bytes.
+extern "C" int gm_gn_scale_shift(const void* x, long long ld, int N, long long V, int C, int G, float eps,
+                                 const float* gamma, const float* beta, float* scale, float* shift, float* mean,
+                                 float* rstd, void* workspace, int dtype, void* stream) {
+  GM_REQUIRE(x && scale && shift && workspace, "null pointer");
+  GM_REQUIRE(G > 0 && C % G == 0, "channels must be divisible by groups");
+  GM_REQUIRE(N <= 65535, "batch too large");
+  if (N == 0 || V == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int vecmax = dtype == GM_F32 ? 4 : 8;
+  const bool vec_ok = (C % vecmax == 0) && (ld % vecmax == 0) && (((uintptr_t)x & 15) == 0);
+  const int CV = vec_ok ? C / vecmax : C;
+  GM_REQUIRE(CV <= GN_THREADS, "too many channels for gm_gn_scale_shift");
+  int nblk = 0;
+  double2* ws = (double2*)workspace;
+  if (dtype == GM_F32) {
+    if (vec_ok) launch_gn_stats<float, 4>(x, ld, N, V, C, G, ws, &nblk, st);
+    else launch_gn_stats<float, 1>(x, ld, N, V, C, G, ws, &nblk, st);
+  } else if (dtype == GM_BF16) {
+    if (vec_ok) launch_gn_stats<bf16_raw, 8>(x, ld, N, V, C, G, ws, &nblk, st);
+    else launch_gn_stats<bf16_raw, 1>(x, ld, N, V, C, G, ws, &nblk, st);
+  } else {
+    GM_FAIL(-2, "unsupported dtype");
+  }
+  {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) GM_FAIL((int)e, hipGetErrorString(e));
+  }
+  gn_finalize_kernel<<<N * G, 64, 0, st>>>(ws, nblk, C, G, V, eps, gamma, beta, scale, shift, mean, rstd);
+  GM_LAUNCH_CHECK();
+}
+
+// y[n, v, c] = act(x[n, v, c] * scale[n, c] + shift[n, c]);  act: 0 none, 1 SiLU
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y,
+                                                      long long y_ld, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, long long V, int C, long long total,
+                                                      int act) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / C;
+    const int c = (int)(i - row * C);
+    const long long n = row / V;
+    float v = ElemIO<T>::ld(x + row * x_ld + c) * scale[n * C + c] + shift[n * C + c];
+    if (act == 1) v = gm_silu_precise(v);
+    ElemIO<T>::st(y + row * y_ld + c, v);
+  }
+}
+
+extern "C" int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift,
+                           int N, long long V, int C, int act, int dtype, void* stream) {
+  GM_REQUIRE(x && y && scale && shift, "null pointer");
+  const long long total = (long long)N * V * C;
+  if (total == 0) return 0;
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32)
+    gn_apply_kernel<float><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, V, C, total, act);
+  else if (dtype == GM_BF16)
+    gn_apply_kernel<bf16_raw><<<(int)g, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, V, C, total, act);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim of [rows][ld] (transformer blocks: diffusion_model_unet.py:219-223): one wave per row.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y,
+                                                       long long y_ld, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * x_ld;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += ElemIO<T>::ld(xr + c);
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = ElemIO<T>::ld(xr + c) - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  T* yr = y + row * y_ld;
+  for (int c = lane; c < C; c += 64) {
+    const float v = (ElemIO<T>::ld(xr + c) - mean) * rstd;
+    ElemIO<T>::st(yr + c, v * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f));
+  }
+}
+
+extern "C" int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
+                            long long rows, int C, float eps, int dtype, void* stream) {
+  GM_REQUIRE(x && y, "null pointer");
+  if (rows == 0 || C == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = gm_cdiv(rows, 4);
+  if (dtype == GM_F32)
+    layernorm_kernel<float><<<grid, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, gamma, beta, rows, C, eps);
+  else if (dtype == GM_BF16)
+    layernorm_kernel<bf16_raw><<<grid, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, gamma, beta, rows, C, eps);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
