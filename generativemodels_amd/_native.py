@@ -1,0 +1,104 @@
+"""ctypes binding of the C-ABI kernel library (include/gm_amd.h -> generativemodels_amd/lib/libgmamd.so).
+
+There is no CPU or eager-PyTorch fallback behind this module: if the library is missing, or a tensor is not resident on an
+MI355X, every op raises. torch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgmamd.so")
+
+c_ll = C.c_longlong
+c_vp = C.c_void_p
+
+
+class GmStepParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("pred_type", C.c_int), ("c_sa", C.c_float), ("c_sb", C.c_float), ("clip", C.c_int),
+                ("clip_lo", C.c_float), ("clip_hi", C.c_float), ("c_prev", C.c_float), ("c_dir", C.c_float),
+                ("k0", C.c_float), ("k1", C.c_float), ("noise_mode", C.c_int), ("c_noise", C.c_float),
+                ("min_log", C.c_float), ("max_log", C.c_float)]
+
+
+class GmConvDesc(C.Structure):
+    _fields_ = [("x", c_vp), ("x_ld", c_ll), ("w", c_vp), ("bias", c_vp), ("pre_scale", c_vp), ("pre_shift", c_vp),
+                ("rowvec", c_vp), ("rowvec_bstride", c_ll), ("res", c_vp), ("res_ld", c_ll), ("y", c_vp), ("y_ld", c_ll),
+                ("N", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("Ds", C.c_int), ("Hs", C.c_int), ("Ws", C.c_int), ("Do", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+                ("kd", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("sd", C.c_int), ("sh", C.c_int), ("sw", C.c_int),
+                ("pd", C.c_int), ("ph", C.c_int), ("pw", C.c_int), ("dd", C.c_int), ("dh", C.c_int), ("dw", C.c_int),
+                ("in_mode", C.c_int), ("fd", C.c_int), ("fh", C.c_int), ("fw", C.c_int),
+                ("pre_act", C.c_int), ("post_act", C.c_int), ("dtype", C.c_int),
+                ("ltd", C.c_int), ("lth", C.c_int), ("ltw", C.c_int), ("cfg", C.c_int)]
+
+
+class GmAttnDesc(C.Structure):
+    _fields_ = [("q", c_vp), ("q_ld", c_ll), ("k", c_vp), ("k_ld", c_ll), ("v", c_vp), ("v_ld", c_ll),
+                ("res", c_vp), ("res_ld", c_ll), ("o", c_vp), ("o_ld", c_ll),
+                ("B", C.c_int), ("H", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int), ("dh", C.c_int),
+                ("scale", C.c_float), ("dtype", C.c_int)]
+
+
+# name -> (restype, argtypes); mirrors include/gm_amd.h one to one (tests/test_abi.py checks the export list)
+PROTOTYPES = {
+    "gm_abi_version": (C.c_int, []),
+    "gm_last_error": (C.c_char_p, []),
+    "gm_sched_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, C.c_int, C.POINTER(GmStepParams), c_vp]),
+    "gm_axpby_rows": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, C.c_int, c_vp]),
+    "gm_copy_channels": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp]),
+    "gm_nchw_to_nhwc": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_ll, c_vp]),
+    "gm_nhwc_to_nchw": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_vp]),
+    "gm_resample2x": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, c_vp]),
+    "gm_timestep_embedding": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_float, C.c_int, c_vp]),
+    "gm_geglu": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_ll, C.c_int, C.c_int, c_vp]),
+    "gm_aekl_sample": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, c_vp]),
+    "gm_addcmul": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, c_vp]),
+    "gm_scale": (C.c_int, [c_vp, c_vp, C.c_float, C.c_int, c_ll, C.c_int, c_vp]),
+    "gm_gn_workspace_bytes": (c_ll, [C.c_int, c_ll, C.c_int, C.c_int, C.c_int]),
+    "gm_gn_scale_shift": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                    c_vp, c_vp, C.c_int, c_vp]),
+    "gm_gn_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_layernorm": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_float, C.c_int, c_vp]),
+    "gm_conv_cfg_tile": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gm_conv_lds_bytes": (c_ll, [C.POINTER(GmConvDesc)]),
+    "gm_conv_forward": (C.c_int, [C.POINTER(GmConvDesc), c_vp]),
+    "gm_packed_conv_weight_elems": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      c_vp]),
+    "gm_attention_max_head_dim": (C.c_int, []),
+    "gm_attention_forward": (C.c_int, [C.POINTER(GmAttnDesc), c_vp]),
+    "gm_vq_argmin": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_vq_gather_workspace_bytes": (c_ll, []),
+    "gm_vq_gather": (C.c_int, [c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """The loaded C-ABI library. Raises NativeLibraryError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -m generativemodels_amd._build` (hipcc, gfx950). "
+                "generativemodels_amd has no CPU / eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().gm_last_error()
+        raise RuntimeError(f"libgmamd {what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -436,3 +436,44 @@ extern "C" int gm_aekl_sample(const void* mu, const void* logvar, const void* ep
   else GM_FAIL(-2, "unsupported dtype");
   GM_LAUNCH_CHECK();
 }
+
+// out = a + b * c (AutoencoderKL.sampling with an explicit sigma: autoencoderkl.py:751-752)
+template <typename T>
+__global__ __launch_bounds__(256) void addcmul_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                                     T* __restrict__ out, long long total) {
+#pragma clang fp contract(off)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const float m = ElemIO<T>::ld(b + i) * ElemIO<T>::ld(c + i);
+    ElemIO<T>::st(out + i, ElemIO<T>::ld(a + i) + m);
+  }
+}
+
+extern "C" int gm_addcmul(const void* a, const void* b, const void* c, void* out, long long total, int dtype, void* stream) {
+  GM_REQUIRE(a && b && c && out, "null pointer");
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32) addcmul_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)a, (const float*)b, (const float*)c, (float*)out, total);
+  else if (dtype == GM_BF16) addcmul_kernel<bf16_raw><<<ew_grid(total), 256, 0, st>>>((const bf16_raw*)a, (const bf16_raw*)b, (const bf16_raw*)c, (bf16_raw*)out, total);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+// out = x * s (mode 0) or x / s (mode 1): the latent scale factor of LatentDiffusionInferer (inferers/inferer.py:386,472)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, T* __restrict__ out, float s, int mode, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const float v = ElemIO<T>::ld(x + i);
+    ElemIO<T>::st(out + i, mode == 0 ? v * s : v / s);
+  }
+}
+
+extern "C" int gm_scale(const void* x, void* out, float s, int mode, long long total, int dtype, void* stream) {
+  GM_REQUIRE(x && out, "null pointer");
+  GM_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (multiply) or 1 (divide)");
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32) scale_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (float*)out, s, mode, total);
+  else if (dtype == GM_BF16) scale_kernel<bf16_raw><<<ew_grid(total), 256, 0, st>>>((const bf16_raw*)x, (bf16_raw*)out, s, mode, total);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}

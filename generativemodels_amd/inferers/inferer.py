@@ -1,0 +1,191 @@
+"""Inferers: the `__call__` (training forward) and `sample` (reverse sampling) contracts of the reference's
+generative/inferers/inferer.py:31-143 (DiffusionInferer) and :324-487 (LatentDiffusionInferer).
+
+MI355X-specific execution of `sample`:
+  * the timestep values live on the device for the whole chain (one upload instead of one H2D copy per step,
+    reference inferer.py:129,133), the host loop only computes the fp32 step scalars;
+  * per step: DiffusionModelUNet forward (fused HIP kernels) + ONE fused scheduler-step kernel;
+  * optional HIP-graph replay of the UNet forward (`use_hip_graph=True`): the ~200 kernel launches of one forward are
+    captured once on the first step and replayed for the remaining steps."""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..networks.nets import VQVAE, DiffusionModelUNet
+
+try:  # progress bar is optional, like in the reference (inferer.py:28)
+    from tqdm import tqdm
+
+    has_tqdm = True
+except Exception:  # pragma: no cover
+    has_tqdm = False
+
+
+class Inferer:
+    """Minimal stand-in for monai.inferers.Inferer (an ABC with `__call__`)."""
+
+    def __call__(self, *args, **kwargs):  # pragma: no cover
+        raise NotImplementedError
+
+
+def _check_mode(mode: str) -> None:
+    if mode not in ["crossattn", "concat"]:
+        raise NotImplementedError(f"{mode} condition is not supported")
+
+
+class _GraphedUNet:
+    """HIP-graph replay of `model(x, t, context)` for fixed shapes; falls back to nothing -- errors propagate."""
+
+    def __init__(self, model: DiffusionModelUNet, x: torch.Tensor, t: torch.Tensor, context: Optional[torch.Tensor]):
+        self.model = model
+        self.x = x.clone()
+        self.t = t.clone()
+        self.context = None if context is None else context.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up: packs weights, sets kernel attributes, sizes the allocator
+            model(self.x, self.t, self.context)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model(self.x, self.t, self.context)
+
+    def __call__(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        self.x.copy_(x)
+        self.t.copy_(t)
+        self.graph.replay()
+        return self.out
+
+
+class DiffusionInferer(Inferer):
+    """Drop-in for generative.inferers.DiffusionInferer. `diffusion_model` may be any callable `(x, timesteps=, context=)`."""
+
+    def __init__(self, scheduler: nn.Module, use_hip_graph: bool = False) -> None:
+        self.scheduler = scheduler
+        self.use_hip_graph = use_hip_graph
+
+    def __call__(self, inputs: torch.Tensor, diffusion_model: Callable[..., torch.Tensor], noise: torch.Tensor,
+                 timesteps: torch.Tensor, condition: torch.Tensor | None = None, mode: str = "crossattn",
+                 seg: torch.Tensor | None = None) -> torch.Tensor:
+        """Training forward: noise the inputs at `timesteps` (fused kernel) and predict (reference inferer.py:44-81)."""
+        _check_mode(mode)
+        noisy = self.scheduler.add_noise(original_samples=inputs, noise=noise, timesteps=timesteps)
+        if mode == "concat":
+            noisy = ops.concat_dim1([noisy, condition])
+            condition = None
+        return diffusion_model(x=noisy, timesteps=timesteps, context=condition)
+
+    @torch.no_grad()
+    def sample(self, input_noise: torch.Tensor, diffusion_model: Callable[..., torch.Tensor],
+               scheduler: Callable[..., torch.Tensor] | None = None, save_intermediates: bool | None = False,
+               intermediate_steps: int | None = 100, conditioning: torch.Tensor | None = None, mode: str = "crossattn",
+               verbose: bool = True, seg: torch.Tensor | None = None):
+        """Reverse chain over `scheduler.timesteps` (reference inferer.py:83-143). Returns the final image, or
+        (image, intermediates) with an intermediate kept whenever `t % intermediate_steps == 0`."""
+        _check_mode(mode)
+        if not scheduler:
+            scheduler = self.scheduler
+        ops.require_device(input_noise)
+        image = input_noise
+        steps = [int(t) for t in torch.as_tensor(scheduler.timesteps).cpu().tolist()]
+        t_dev = torch.tensor(steps, dtype=torch.float32).to(input_noise.device)  # whole chain, one upload
+        it = tqdm(range(len(steps))) if (verbose and has_tqdm) else range(len(steps))
+        graphed = None
+        intermediates = []
+        for i in it:
+            t, tt = steps[i], t_dev[i:i + 1]
+            if mode == "concat":
+                model_input, ctx = ops.concat_dim1([image, conditioning]), None
+            else:
+                model_input, ctx = image, conditioning
+            if self.use_hip_graph and isinstance(diffusion_model, DiffusionModelUNet):
+                if graphed is None:
+                    graphed = _GraphedUNet(diffusion_model, model_input, tt, ctx)
+                model_output = graphed(model_input, tt)
+            else:
+                model_output = diffusion_model(model_input, timesteps=tt, context=ctx)
+            image, _ = scheduler.step(model_output, t, image)
+            if save_intermediates and t % intermediate_steps == 0:
+                intermediates.append(image)
+        return (image, intermediates) if save_intermediates else image
+
+
+def _center_crop(x: torch.Tensor, roi) -> torch.Tensor:
+    """MONAI CenterSpatialCrop on a batch: roi entries <= 0 or >= size keep the axis (inferer.py:353,465)."""
+    sl = [slice(None), slice(None)]
+    for size, r in zip(x.shape[2:], roi):
+        if r <= 0 or r >= size:
+            sl.append(slice(None))
+        else:
+            start = size // 2 - r // 2
+            sl.append(slice(start, start + r))
+    return x[tuple(sl)].contiguous()
+
+
+def _spatial_pad(x: torch.Tensor, size) -> torch.Tensor:
+    """MONAI SpatialPad (symmetric, odd remainder on the high side) on a batch (inferer.py:352,389)."""
+    tgt = [max(int(s), int(cur)) for s, cur in zip(size, x.shape[2:])]
+    if tgt == list(x.shape[2:]):
+        return x
+    out = torch.zeros((x.shape[0], x.shape[1], *tgt), dtype=x.dtype, device=x.device)
+    sl = [slice(None), slice(None)]
+    for cur, t in zip(x.shape[2:], tgt):
+        lo = (t - cur) // 2
+        sl.append(slice(lo, lo + cur))
+    out[tuple(sl)].copy_(x)
+    return out
+
+
+class LatentDiffusionInferer(DiffusionInferer):
+    """Drop-in for generative.inferers.LatentDiffusionInferer: stage-1 autoencoder (AutoencoderKL / VQVAE) around the
+    diffusion chain, latent scaling, optional latent pad / crop."""
+
+    def __init__(self, scheduler: nn.Module, scale_factor: float = 1.0, ldm_latent_shape: list | None = None,
+                 autoencoder_latent_shape: list | None = None, use_hip_graph: bool = False) -> None:
+        super().__init__(scheduler=scheduler, use_hip_graph=use_hip_graph)
+        self.scale_factor = scale_factor
+        if (ldm_latent_shape is None) ^ (autoencoder_latent_shape is None):
+            raise ValueError("If ldm_latent_shape is None, autoencoder_latent_shape must be None and vice versa.")
+        self.ldm_latent_shape = ldm_latent_shape
+        self.autoencoder_latent_shape = autoencoder_latent_shape
+
+    def _scaled(self, x: torch.Tensor, divide: bool) -> torch.Tensor:
+        return x if self.scale_factor == 1.0 else ops.scale(x, self.scale_factor, divide)
+
+    def __call__(self, inputs: torch.Tensor, autoencoder_model: Callable[..., torch.Tensor],
+                 diffusion_model: Callable[..., torch.Tensor], noise: torch.Tensor, timesteps: torch.Tensor,
+                 condition: torch.Tensor | None = None, mode: str = "crossattn", seg: torch.Tensor | None = None,
+                 quantized: bool = True) -> torch.Tensor:
+        with torch.no_grad():
+            if isinstance(autoencoder_model, VQVAE):
+                latent = autoencoder_model.encode_stage_2_inputs(inputs, quantized=quantized)
+            else:
+                latent = autoencoder_model.encode_stage_2_inputs(inputs)
+            latent = self._scaled(latent, divide=False)
+        if self.ldm_latent_shape is not None:
+            latent = _spatial_pad(latent, self.ldm_latent_shape)
+        return super().__call__(inputs=latent, diffusion_model=diffusion_model, noise=noise, timesteps=timesteps,
+                                condition=condition, mode=mode)
+
+    @torch.no_grad()
+    def sample(self, input_noise: torch.Tensor, autoencoder_model: Callable[..., torch.Tensor],
+               diffusion_model: Callable[..., torch.Tensor], scheduler: Callable[..., torch.Tensor] | None = None,
+               save_intermediates: bool | None = False, intermediate_steps: int | None = 100,
+               conditioning: torch.Tensor | None = None, mode: str = "crossattn", verbose: bool = True,
+               seg: torch.Tensor | None = None):
+        outputs = super().sample(input_noise=input_noise, diffusion_model=diffusion_model, scheduler=scheduler,
+                                 save_intermediates=save_intermediates, intermediate_steps=intermediate_steps,
+                                 conditioning=conditioning, mode=mode, verbose=verbose)
+        latent, latent_intermediates = outputs if save_intermediates else (outputs, [])
+        if self.autoencoder_latent_shape is not None:
+            latent = _center_crop(latent, self.autoencoder_latent_shape)
+            latent_intermediates = [_center_crop(l, self.autoencoder_latent_shape) for l in latent_intermediates]
+        decode = autoencoder_model.decode_stage_2_outputs
+        image = decode(self._scaled(latent, divide=True))
+        if save_intermediates:
+            return image, [decode(self._scaled(l, divide=True)) for l in latent_intermediates]
+        return image

@@ -1,0 +1,200 @@
+"""AutoencoderKL for MI355X: constructor, state_dict names (`encoder.blocks.k.*`, `decoder.blocks.k.*`, `quant_conv_mu`, ...)
+and encode / decode / sampling / forward contract of the reference's generative/networks/nets/autoencoderkl.py:600-799,
+executed with the same fused HIP kernels as the diffusion UNet (N[D]HWC arena; GroupNorm+SiLU folded into the convolutions,
+nearest-2x folded into the up-sampling convolution, asymmetric-pad strided convolution for down-sampling)."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ._blocks import AttentionBlock, ConvP, ResnetBlock, ensure_tuple_rep, gn_prologue
+
+__all__ = ["AutoencoderKL"]
+
+
+class _Down(nn.Module):
+    """3^d stride-2 convolution with one zero voxel padded on the HIGH side of every axis only
+    (reference autoencoderkl.py:96-122); parameters live under `conv.conv.*`."""
+
+    def __init__(self, spatial_dims: int, channels: int) -> None:
+        super().__init__()
+        self.conv = ConvP(spatial_dims, channels, channels, 3, 2, 0, pad_hi=1)
+
+    def run(self, x):
+        return self.conv.run(x)
+
+
+class _Up(nn.Module):
+    """Nearest 2x + conv3 (folded) or ConvTranspose(k3, s2, p1, op1) (reference autoencoderkl.py:41-93)."""
+
+    def __init__(self, spatial_dims: int, channels: int, use_convtranspose: bool) -> None:
+        super().__init__()
+        self.use_convtranspose = use_convtranspose
+        if use_convtranspose:
+            self.conv = ConvP(spatial_dims, channels, channels, 3, 2, 1, transposed=True)
+        else:
+            self.conv = ConvP(spatial_dims, channels, channels, 3, 1, 1)
+
+    def run(self, x):
+        return self.conv.run(x) if self.use_convtranspose else self.conv.run(x, upsample=True)
+
+
+def _res(spatial_dims, cin, cout, groups, eps):
+    return ResnetBlock(spatial_dims, cin, cout, None, groups, eps, shortcut_name="nin_shortcut", zero_conv2=False)
+
+
+def _run_blocks(blocks: nn.ModuleList, h: torch.Tensor) -> torch.Tensor:
+    pre = None
+    for blk in blocks:
+        if isinstance(blk, nn.GroupNorm):
+            pre = gn_prologue(blk, h)  # consumed by the next convolution's prologue (no SiLU: autoencoderkl.py:433-446)
+        elif isinstance(blk, ConvP):
+            h = blk.run(h, pre=pre)
+            pre = None
+        else:
+            h = blk.run(h)
+    return h
+
+
+class Encoder(nn.Module):
+    """conv_in, per level [ResBlock (+Attention)] x r and an asymmetric-pad stride-2 conv, optional non-local
+    (ResBlock, Attention, ResBlock), GroupNorm, conv to the latent width (reference autoencoderkl.py:315-453)."""
+
+    def __init__(self, spatial_dims, in_channels, num_channels, out_channels, num_res_blocks, norm_num_groups, norm_eps,
+                 attention_levels, with_nonlocal_attn=True) -> None:
+        super().__init__()
+        g, eps = norm_num_groups, norm_eps
+        blocks: list[nn.Module] = [ConvP(spatial_dims, in_channels, num_channels[0], 3, 1, 1)]
+        out_c = num_channels[0]
+        for i in range(len(num_channels)):
+            in_c, out_c = out_c, num_channels[i]
+            for _ in range(num_res_blocks[i]):
+                blocks.append(_res(spatial_dims, in_c, out_c, g, eps))
+                in_c = out_c
+                if attention_levels[i]:
+                    blocks.append(AttentionBlock(spatial_dims, in_c, None, g, eps))
+            if i != len(num_channels) - 1:
+                blocks.append(_Down(spatial_dims, in_c))
+        if with_nonlocal_attn:
+            c = num_channels[-1]
+            blocks += [_res(spatial_dims, c, c, g, eps), AttentionBlock(spatial_dims, c, None, g, eps), _res(spatial_dims, c, c, g, eps)]
+        blocks.append(nn.GroupNorm(num_groups=g, num_channels=num_channels[-1], eps=eps, affine=True))
+        blocks.append(ConvP(spatial_dims, num_channels[-1], out_channels, 3, 1, 1))
+        self.blocks = nn.ModuleList(blocks)
+
+    def run(self, x):
+        return _run_blocks(self.blocks, x)
+
+
+class Decoder(nn.Module):
+    """Mirror of the encoder (reference autoencoderkl.py:455-597)."""
+
+    def __init__(self, spatial_dims, num_channels, in_channels, out_channels, num_res_blocks, norm_num_groups, norm_eps,
+                 attention_levels, with_nonlocal_attn=True, use_convtranspose=False) -> None:
+        super().__init__()
+        g, eps = norm_num_groups, norm_eps
+        rc = list(reversed(num_channels))
+        rr = list(reversed(num_res_blocks))
+        ra = list(reversed(attention_levels))
+        blocks: list[nn.Module] = [ConvP(spatial_dims, in_channels, rc[0], 3, 1, 1)]
+        if with_nonlocal_attn:
+            blocks += [_res(spatial_dims, rc[0], rc[0], g, eps), AttentionBlock(spatial_dims, rc[0], None, g, eps),
+                       _res(spatial_dims, rc[0], rc[0], g, eps)]
+        out_c = rc[0]
+        for i in range(len(rc)):
+            in_c, out_c = out_c, rc[i]
+            for _ in range(rr[i]):
+                blocks.append(_res(spatial_dims, in_c, out_c, g, eps))
+                in_c = out_c
+                if ra[i]:
+                    blocks.append(AttentionBlock(spatial_dims, in_c, None, g, eps))
+            if i != len(rc) - 1:
+                blocks.append(_Up(spatial_dims, in_c, use_convtranspose))
+        blocks.append(nn.GroupNorm(num_groups=g, num_channels=in_c, eps=eps, affine=True))
+        blocks.append(ConvP(spatial_dims, in_c, out_channels, 3, 1, 1))
+        self.blocks = nn.ModuleList(blocks)
+
+    def run(self, x):
+        return _run_blocks(self.blocks, x)
+
+
+class AutoencoderKL(nn.Module):
+    """Drop-in for generative.networks.nets.AutoencoderKL (same arguments, state_dict keys and methods)."""
+
+    def __init__(self, spatial_dims: int, in_channels: int = 1, out_channels: int = 1, num_res_blocks: Sequence[int] | int = (2, 2, 2, 2),
+                 num_channels: Sequence[int] = (32, 64, 64, 64), attention_levels: Sequence[bool] = (False, False, True, True),
+                 latent_channels: int = 3, norm_num_groups: int = 32, norm_eps: float = 1e-6, with_encoder_nonlocal_attn: bool = True,
+                 with_decoder_nonlocal_attn: bool = True, use_flash_attention: bool = False, use_checkpointing: bool = False,
+                 use_convtranspose: bool = False) -> None:
+        super().__init__()
+        if any((c % norm_num_groups) != 0 for c in num_channels):
+            raise ValueError("AutoencoderKL expects all num_channels being multiple of norm_num_groups")
+        if len(num_channels) != len(attention_levels):
+            raise ValueError("AutoencoderKL expects num_channels being same size of attention_levels")
+        if isinstance(num_res_blocks, int):
+            num_res_blocks = ensure_tuple_rep(num_res_blocks, len(num_channels))
+        if len(num_res_blocks) != len(num_channels):
+            raise ValueError("`num_res_blocks` should be a single integer or a tuple of integers with the same length as "
+                             "`num_channels`.")
+        self.spatial_dims = spatial_dims
+        self.encoder = Encoder(spatial_dims, in_channels, num_channels, latent_channels, num_res_blocks, norm_num_groups, norm_eps,
+                               attention_levels, with_encoder_nonlocal_attn)
+        self.decoder = Decoder(spatial_dims, num_channels, latent_channels, out_channels, num_res_blocks, norm_num_groups, norm_eps,
+                               attention_levels, with_decoder_nonlocal_attn, use_convtranspose)
+        self.quant_conv_mu = ConvP(spatial_dims, latent_channels, latent_channels, 1, 1, 0)
+        self.quant_conv_log_sigma = ConvP(spatial_dims, latent_channels, latent_channels, 1, 1, 0)
+        self.post_quant_conv = ConvP(spatial_dims, latent_channels, latent_channels, 1, 1, 0)
+        self.latent_channels = latent_channels
+        self.use_checkpointing = use_checkpointing  # accepted for API parity; inference path keeps no activations anyway
+
+    def _dtype(self):
+        return self.post_quant_conv.conv.weight.dtype
+
+    def _check(self, x: torch.Tensor) -> None:
+        ops.require_device(x)
+        if x.dtype != self._dtype():
+            raise TypeError(f"input dtype {x.dtype} does not match the model dtype {self._dtype()}")
+        if x.dim() != self.spatial_dims + 2:
+            raise ValueError(f"expected a (N, C, *{self.spatial_dims} spatial dims) tensor, got {tuple(x.shape)}")
+
+    def encode(self, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """-> (z_mu, z_sigma), sigma = exp(clamp(log_var, -30, 20) / 2) (reference autoencoderkl.py:718-736)."""
+        self._check(x)
+        with torch.no_grad():
+            h = self.encoder.run(ops.to_channels_last(x))
+            z_mu = ops.to_channels_first(self.quant_conv_mu.run(h))
+            z_log_var = ops.to_channels_first(self.quant_conv_log_sigma.run(h))
+            z_sigma, _ = ops.aekl_sample(None, z_log_var)
+        return z_mu, z_sigma
+
+    def sampling(self, z_mu: torch.Tensor, z_sigma: torch.Tensor) -> torch.Tensor:
+        """z = mu + eps * sigma, eps ~ N(0, I) from the device generator (reference autoencoderkl.py:738-753)."""
+        ops.require_device(z_mu, z_sigma)
+        eps = torch.randn_like(z_sigma)
+        return ops.addcmul(z_mu, eps, z_sigma)
+
+    def reconstruct(self, x: torch.Tensor) -> torch.Tensor:
+        z_mu, _ = self.encode(x)
+        return self.decode(z_mu)
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """post_quant_conv -> Decoder (reference autoencoderkl.py:769-784)."""
+        self._check(z)
+        with torch.no_grad():
+            h = self.post_quant_conv.run(ops.to_channels_last(z))
+            return ops.to_channels_first(self.decoder.run(h))
+
+    def forward(self, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        z_mu, z_sigma = self.encode(x)
+        z = self.sampling(z_mu, z_sigma)
+        return self.decode(z), z_mu, z_sigma
+
+    def encode_stage_2_inputs(self, x: torch.Tensor) -> torch.Tensor:
+        z_mu, z_sigma = self.encode(x)
+        return self.sampling(z_mu, z_sigma)
+
+    def decode_stage_2_outputs(self, z: torch.Tensor) -> torch.Tensor:
+        return self.decode(z)

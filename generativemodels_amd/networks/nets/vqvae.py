@@ -1,0 +1,192 @@
+"""VQVAE for MI355X: constructor, state_dict names and encode / quantize / decode / index_quantize / decode_samples /
+forward contract of the reference's generative/networks/nets/vqvae.py:274-455, on the fused HIP convolution kernel
+(strided conv / gather-form transposed conv with the activation and the residual add + ReLU in the epilogue)."""
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..layers.vector_quantizer import EMAQuantizer, VectorQuantizer
+from ._blocks import ConvP, ensure_tuple_rep
+
+__all__ = ["VQVAE"]
+
+
+def _act_name(act) -> str:
+    """MONAI `Act[...]` spec (name or (name, kwargs)) -> epilogue activation of the HIP convolution."""
+    if act is None:
+        return "none"
+    name = act[0] if isinstance(act, (tuple, list)) else act
+    if isinstance(act, (tuple, list)) and len(act) > 1 and act[1]:
+        raise ValueError(f"activation arguments {act[1]} are not supported by the fused HIP epilogue")
+    key = str(name).lower()
+    if key not in ops.POST_ACT or key == "none":
+        raise ValueError(f"activation '{name}' is not supported by the fused HIP epilogue (supported: "
+                         f"{sorted(k for k in ops.POST_ACT if k != 'none')})")
+    return key
+
+
+class _ConvAct(nn.Module):
+    """MONAI Convolution with adn_ordering="DA" (dropout, activation; the default instance norm is constructed by MONAI but
+    never inserted): parameters under `conv.*` (reference vqvae.py:127-163,220-260)."""
+
+    def __init__(self, spatial_dims, cin, cout, kernel, stride, padding, dilation=1, act="none", transposed=False, output_padding=0):
+        super().__init__()
+        self.spatial_dims = spatial_dims
+        self.kernel, self.stride, self.padding, self.dilation = kernel, stride, padding, dilation
+        self.transposed, self.output_padding, self.act = transposed, output_padding, act
+        holder = ConvP(spatial_dims, cin, cout, kernel, stride, padding, dilation, transposed, output_padding)
+        self.conv = holder.conv  # flat `conv.weight` naming, as MONAI's Convolution registers it
+
+    def run(self, x, **fusion):
+        return ops.conv(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding,
+                        dilation=self.dilation, transposed=self.transposed, output_padding=self.output_padding,
+                        post_act=fusion.pop("post_act", self.act), **fusion)
+
+
+class VQVAEResidualUnit(nn.Module):
+    """relu(x + conv2(act(conv1(x)))) (reference vqvae.py:27-80): two launches, add + ReLU in the second epilogue."""
+
+    def __init__(self, spatial_dims, num_channels, num_res_channels, act="relu", dropout=0.0) -> None:
+        super().__init__()
+        self.act = act
+        self.conv1 = ConvP(spatial_dims, num_channels, num_res_channels, 3, 1, 1)
+        self.conv2 = ConvP(spatial_dims, num_res_channels, num_channels, 3, 1, 1)
+
+    def run(self, x):
+        return self.conv2.run(self.conv1.run(x, post_act=self.act), res=x, post_act="relu")
+
+
+class Encoder(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels, num_channels, num_res_layers, num_res_channels,
+                 downsample_parameters, dropout, act) -> None:
+        super().__init__()
+        blocks: list[nn.Module] = []
+        for i, c in enumerate(num_channels):
+            s, k, d, p = downsample_parameters[i]
+            blocks.append(_ConvAct(spatial_dims, in_channels if i == 0 else num_channels[i - 1], c, k, s, p, d, act))
+            blocks += [VQVAEResidualUnit(spatial_dims, c, num_res_channels[i], act, dropout) for _ in range(num_res_layers)]
+        blocks.append(_ConvAct(spatial_dims, num_channels[-1], out_channels, 3, 1, 1))
+        self.blocks = nn.ModuleList(blocks)
+
+    def run(self, x):
+        for b in self.blocks:
+            x = b.run(x)
+        return x
+
+
+class Decoder(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels, num_channels, num_res_layers, num_res_channels,
+                 upsample_parameters, dropout, act, output_act) -> None:
+        super().__init__()
+        rc, rr = list(reversed(num_channels)), list(reversed(num_res_channels))
+        blocks: list[nn.Module] = [_ConvAct(spatial_dims, in_channels, rc[0], 3, 1, 1)]
+        n = len(rc)
+        for i in range(n):
+            blocks += [VQVAEResidualUnit(spatial_dims, rc[i], rr[i], act, dropout) for _ in range(num_res_layers)]
+            s, k, d, p, op = upsample_parameters[i]
+            last = i == n - 1
+            blocks.append(_ConvAct(spatial_dims, rc[i], out_channels if last else rc[i + 1], k, s, p, d,
+                                   (output_act or "none") if last else act, transposed=True, output_padding=op))
+        self.blocks = nn.ModuleList(blocks)
+
+    def run(self, x):
+        for b in self.blocks:
+            x = b.run(x)
+        return x
+
+
+class VQVAE(nn.Module):
+    """Drop-in for generative.networks.nets.VQVAE (same arguments, state_dict keys and methods; inference only)."""
+
+    def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, num_channels: Sequence[int] | int = (96, 96, 192),
+                 num_res_layers: int = 3, num_res_channels: Sequence[int] | int = (96, 96, 192),
+                 downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1), (2, 4, 1, 1)),
+                 upsample_parameters=((2, 4, 1, 1, 0), (2, 4, 1, 1, 0), (2, 4, 1, 1, 0)), num_embeddings: int = 32,
+                 embedding_dim: int = 64, embedding_init: str = "normal", commitment_cost: float = 0.25, decay: float = 0.5,
+                 epsilon: float = 1e-5, dropout: float = 0.0, act="RELU", output_act=None, ddp_sync: bool = True,
+                 use_checkpointing: bool = False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.spatial_dims = in_channels, out_channels, spatial_dims
+        self.num_channels = num_channels
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.use_checkpointing = use_checkpointing
+        if isinstance(num_res_channels, int):
+            num_res_channels = ensure_tuple_rep(num_res_channels, len(num_channels))
+        if len(num_res_channels) != len(num_channels):
+            raise ValueError("`num_res_channels` should be a single integer or a tuple of integers with the same length as "
+                             "`num_channels`.")
+        if not all(isinstance(v, (int, Sequence)) for v in downsample_parameters):
+            raise ValueError("`downsample_parameters` should be a single tuple of integer or a tuple of tuples.")
+        if not all(isinstance(v, (int, Sequence)) for v in upsample_parameters):
+            raise ValueError("`upsample_parameters` should be a single tuple of integer or a tuple of tuples.")
+        if all(isinstance(v, int) for v in upsample_parameters):
+            upsample_parameters = (upsample_parameters,) * len(num_channels)
+        if all(isinstance(v, int) for v in downsample_parameters):
+            downsample_parameters = (downsample_parameters,) * len(num_channels)
+        for p in downsample_parameters:
+            if len(p) != 4:
+                raise ValueError("`downsample_parameters` should be a tuple of tuples with 4 integers.")
+        for p in upsample_parameters:
+            if len(p) != 5:
+                raise ValueError("`upsample_parameters` should be a tuple of tuples with 5 integers.")
+        if len(downsample_parameters) != len(num_channels):
+            raise ValueError("`downsample_parameters` should be a tuple of tuples with the same length as `num_channels`.")
+        if len(upsample_parameters) != len(num_channels):
+            raise ValueError("`upsample_parameters` should be a tuple of tuples with the same length as `num_channels`.")
+        self.num_res_layers, self.num_res_channels = num_res_layers, num_res_channels
+        a = _act_name(act)
+        oa = _act_name(output_act) if output_act else None
+        self.encoder = Encoder(spatial_dims, in_channels, embedding_dim, num_channels, num_res_layers, num_res_channels,
+                               downsample_parameters, dropout, a)
+        self.decoder = Decoder(spatial_dims, embedding_dim, out_channels, num_channels, num_res_layers, num_res_channels,
+                               upsample_parameters, dropout, a, oa)
+        self.quantizer = VectorQuantizer(quantizer=EMAQuantizer(spatial_dims, num_embeddings, embedding_dim, commitment_cost,
+                                                                decay, epsilon, embedding_init, ddp_sync))
+
+    def _check(self, x: torch.Tensor) -> None:
+        ops.require_device(x)
+        want = self.encoder.blocks[0].conv.weight.dtype
+        if x.dtype != want:
+            raise TypeError(f"input dtype {x.dtype} does not match the model dtype {want}")
+
+    def encode(self, images: torch.Tensor) -> torch.Tensor:
+        self._check(images)
+        with torch.no_grad():
+            return ops.to_channels_first(self.encoder.run(ops.to_channels_last(images)))
+
+    def quantize(self, encodings: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        x_loss, x = self.quantizer(encodings)
+        return x, x_loss
+
+    def decode(self, quantizations: torch.Tensor) -> torch.Tensor:
+        self._check(quantizations)
+        with torch.no_grad():
+            return ops.to_channels_first(self.decoder.run(ops.to_channels_last(quantizations)))
+
+    def index_quantize(self, images: torch.Tensor) -> torch.Tensor:
+        self._check(images)
+        with torch.no_grad():  # encoder output stays in the arena: no layout round trip before the code search
+            return self.quantizer.quantizer.indices_of(self.encoder.run(ops.to_channels_last(images)))
+
+    def decode_samples(self, embedding_indices: torch.Tensor) -> torch.Tensor:
+        ops.require_device(embedding_indices)
+        with torch.no_grad():
+            q = self.quantizer.quantizer.lookup(embedding_indices, self.encoder.blocks[0].conv.weight.dtype)
+            return ops.to_channels_first(self.decoder.run(q))
+
+    def forward(self, images: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        quantizations, quantization_losses = self.quantize(self.encode(images))
+        return self.decode(quantizations), quantization_losses
+
+    def encode_stage_2_inputs(self, x: torch.Tensor, quantized: bool = True) -> torch.Tensor:
+        z = self.encode(x)
+        e, _ = self.quantize(z)
+        return e if quantized else z
+
+    def decode_stage_2_outputs(self, z: torch.Tensor) -> torch.Tensor:
+        e, _ = self.quantize(z)
+        return self.decode(e)

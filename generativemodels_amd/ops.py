@@ -1,0 +1,657 @@
+"""Tensor-level wrappers over the C-ABI kernels (include/gm_amd.h). torch supplies device memory and the current HIP stream;
+all arithmetic happens in libgmamd.so. Activations are "arena" tensors in channels-last layout: shape (N, *spatial, C) with
+unit stride on C and an arbitrary leading dimension (so a channel slice of a wider buffer is a valid operand).
+
+No fallback: a CPU tensor, a missing library or an unsupported geometry raises."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import weakref
+from typing import Optional, Sequence
+
+import torch
+
+from . import _native as nat
+from ._native import GmAttnDesc, GmConvDesc, GmStepParams, check, lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+ACT = {"none": 0, "silu": 1, "relu": 2}
+POST_ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "swish": 4, "leakyrelu": 5}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"generativemodels_amd kernels support float32 and bfloat16, got {dtype}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "generativemodels_amd runs on MI355X (HIP) tensors only: got a tensor on "
+                f"'{t.device}'. There is no CPU / eager fallback (move the module and its inputs to 'cuda').")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def arena_ld(t: torch.Tensor) -> int:
+    """Leading dimension (elements between consecutive voxels) of a channels-last arena tensor; validates the layout."""
+    if t.dim() < 2:
+        raise ValueError("arena tensors are (N, *spatial, C)")
+    c = t.shape[-1]
+    if c > 1 and t.stride(-1) != 1:
+        raise ValueError("arena tensor must have unit stride on the channel dim")
+    ld = expect = None
+    for sz, st in zip(reversed(t.shape[:-1]), reversed(t.stride()[:-1])):
+        if sz == 1:
+            continue
+        if expect is None:
+            ld = st
+        elif st != expect:
+            raise ValueError(f"arena tensor is not row-dense: shape {tuple(t.shape)}, strides {t.stride()}")
+        expect = st * sz
+    if ld is None:
+        ld = c
+    if ld < c:
+        raise ValueError("arena leading dim smaller than the channel count")
+    return int(ld)
+
+
+def rows_of(t: torch.Tensor) -> int:
+    return int(math.prod(t.shape[:-1]))
+
+
+def new_arena(n: int, spatial: Sequence[int], c: int, dtype, device) -> torch.Tensor:
+    return torch.empty((n, *spatial, c), dtype=dtype, device=device)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# parameter-derived caches (packed conv weights, fp32 copies of bias / norm affine)
+# ------------------------------------------------------------------------------------------------------------------------
+_param_cache: dict = {}
+
+
+def _cached(param: torch.Tensor, tag, make):
+    key = (id(param), tag)
+    ent = _param_cache.get(key)
+    ver = (param._version, param.data_ptr(), param.dtype, param.device)
+    if ent is not None and ent[0]() is param and ent[1] == ver:
+        return ent[2]
+    val = make()
+    _param_cache[key] = (weakref.ref(param), ver, val)
+    if len(_param_cache) > 65536:  # drop dead entries
+        for k in [k for k, e in _param_cache.items() if e[0]() is None]:
+            _param_cache.pop(k, None)
+    return val
+
+
+def as_f32(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """fp32 device copy of a small parameter vector (bias / gamma / beta); identity when it already is fp32."""
+    if param is None:
+        return None
+    require_device(param)
+    if param.dtype == torch.float32 and param.is_contiguous():
+        return param.detach()
+
+    def make():
+        out = torch.empty(param.shape, dtype=torch.float32, device=param.device)
+        src = param.detach().contiguous()
+        check(lib().gm_copy_channels(src.data_ptr(), src.numel(), dt_code(src.dtype), out.data_ptr(), out.numel(), 0, 1,
+                                     src.numel(), _stream()), "gm_copy_channels")
+        return out
+
+    return _cached(param, "f32", make)
+
+
+def packed_conv_weight(weight: torch.Tensor, dtype: torch.dtype, transposed: bool = False) -> torch.Tensor:
+    """weight: nn.Conv{1,2,3}d / nn.Linear layout [Cout, Cin, *k] (or nn.ConvTranspose [Cin, Cout, *k]) -> MFMA panel layout."""
+    require_device(weight)
+
+    def make():
+        w = weight.detach().contiguous()
+        k = list(w.shape[2:])
+        while len(k) < 3:
+            k.insert(0, 1)
+        cout, cin = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+        n = lib().gm_packed_conv_weight_elems(cout, cin, k[0], k[1], k[2], dt_code(dtype))
+        out = torch.empty(n, dtype=dtype, device=w.device)
+        check(lib().gm_pack_conv_weight(w.data_ptr(), dt_code(w.dtype), out.data_ptr(), dt_code(dtype), cout, cin, k[0], k[1],
+                                        k[2], int(transposed), _stream()), "gm_pack_conv_weight")
+        return out
+
+    return _cached(weight, ("pack", dtype, transposed), make)
+
+
+def packed_cat_weight(weights: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    """Linear weights [Cout_i, Cin] stacked along Cout and packed as one panel (fused q/k/v projections etc.)."""
+
+    def make():
+        w = torch.cat([x.detach() for x in weights], dim=0).contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        n = lib().gm_packed_conv_weight_elems(cout, cin, 1, 1, 1, dt_code(dtype))
+        out = torch.empty(n, dtype=dtype, device=w.device)
+        check(lib().gm_pack_conv_weight(w.data_ptr(), dt_code(w.dtype), out.data_ptr(), dt_code(dtype), cout, cin, 1, 1, 1, 0,
+                                        _stream()), "gm_pack_conv_weight")
+        return out
+
+    # validity is tied to the first weight's version; the others are folded into the tag
+    tag = ("packcat", dtype, tuple((id(x), x._version, x.data_ptr()) for x in weights[1:]))
+    return _cached(weights[0], tag, make)
+
+
+def cat_f32(params: Sequence[Optional[torch.Tensor]], sizes: Sequence[int], device) -> torch.Tensor:
+    """fp32 concatenation of bias vectors (None -> zeros)."""
+    key_param = next((p for p in params if p is not None), None)
+    build = lambda: torch.cat([torch.zeros(s, dtype=torch.float32, device=device) if p is None else p.detach().float()
+                               for p, s in zip(params, sizes)]).contiguous()
+    if key_param is None:
+        return build()
+    tag = ("catf32", tuple((id(p), None if p is None else (p._version, p.data_ptr())) for p in params))
+    return _cached(key_param, tag, build)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# layout
+# ------------------------------------------------------------------------------------------------------------------------
+def to_channels_last(x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Logical NC[D]HW tensor -> arena (N, *spatial, C) in `dtype` (default: x.dtype)."""
+    require_device(x)
+    dtype = dtype or x.dtype
+    x = x.contiguous()
+    n, c = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])
+    v = math.prod(sp)
+    if c == 1 and dtype == x.dtype:
+        return x.reshape(n, *sp, 1)
+    out = torch.empty((n, *sp, c), dtype=dtype, device=x.device)
+    check(lib().gm_nchw_to_nhwc(x.data_ptr(), dt_code(x.dtype), out.data_ptr(), dt_code(dtype), n, c, v, c, _stream()),
+          "gm_nchw_to_nhwc")
+    return out
+
+
+def to_channels_first(a: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Arena (N, *spatial, C) -> contiguous NC[D]HW tensor."""
+    require_device(a)
+    dtype = dtype or a.dtype
+    n, c = a.shape[0], a.shape[-1]
+    sp = tuple(a.shape[1:-1])
+    v = math.prod(sp)
+    ld = arena_ld(a)
+    if c == 1 and ld == 1 and dtype == a.dtype:
+        return a.reshape(n, 1, *sp)
+    out = torch.empty((n, c, *sp), dtype=dtype, device=a.device)
+    check(lib().gm_nhwc_to_nchw(a.data_ptr(), ld, dt_code(a.dtype), out.data_ptr(), dt_code(dtype), n, c, v, _stream()),
+          "gm_nhwc_to_nchw")
+    return out
+
+
+def copy_channels(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst[..., :C] = src (dst may be a channel slice of a wider arena buffer; dtypes may differ)."""
+    require_device(src, dst)
+    if src.shape != dst.shape:
+        raise ValueError(f"copy_channels shape mismatch {tuple(src.shape)} vs {tuple(dst.shape)}")
+    check(lib().gm_copy_channels(src.data_ptr(), arena_ld(src), dt_code(src.dtype), dst.data_ptr(), arena_ld(dst),
+                                 dt_code(dst.dtype), rows_of(src), src.shape[-1], _stream()), "gm_copy_channels")
+
+
+def concat_channels(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """torch.cat(dim=channel) in the arena (reference: diffusion_model_unet.py:1232,1340,1461; inferer.py:72,127)."""
+    c = sum(p.shape[-1] for p in parts)
+    out = torch.empty((*parts[0].shape[:-1], c), dtype=parts[0].dtype, device=parts[0].device)
+    off = 0
+    for p in parts:
+        copy_channels(p, out[..., off:off + p.shape[-1]])
+        off += p.shape[-1]
+    return out
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    require_device(x)
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    n = x.numel()
+    check(lib().gm_copy_channels(x.data_ptr(), n, dt_code(x.dtype), out.data_ptr(), n, dt_code(dtype), 1, n, _stream()),
+          "gm_copy_channels")
+    return out
+
+
+def resample2x(x: torch.Tensor, mode: str) -> torch.Tensor:
+    """mode 'up': nearest x2; 'down': 2x average pool, on every spatial axis of an arena tensor."""
+    require_device(x)
+    sp = list(x.shape[1:-1])
+    nd = len(sp)
+    d, h, w = ([1] * (3 - nd) + sp)
+    act_d = 1 if nd == 3 else 0
+    if nd == 1:
+        raise ValueError("resample2x needs 2-D or 3-D data")
+    if mode == "up":
+        osp = [s * 2 for s in sp]
+    else:
+        osp = [s // 2 for s in sp]
+    out = torch.empty((x.shape[0], *osp, x.shape[-1]), dtype=x.dtype, device=x.device)
+    check(lib().gm_resample2x(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), x.shape[0], x.shape[-1], d, h, w, act_d,
+                              0 if mode == "up" else 1, dt_code(x.dtype), _stream()), "gm_resample2x")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------------------------------------
+def gn_scale_shift(x: torch.Tensor, groups: int, eps: float, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
+                   want_stats: bool = False):
+    """GroupNorm statistics of an arena tensor -> fp32 (scale, shift) of shape [N, C] for a consumer's prologue."""
+    require_device(x)
+    n, c = x.shape[0], x.shape[-1]
+    v = rows_of(x) // max(n, 1)
+    if c % groups != 0:
+        raise ValueError("num_channels must be divisible by num_groups")
+    ws_bytes = lib().gm_gn_workspace_bytes(n, v, c, groups, dt_code(x.dtype))
+    if ws_bytes < 0:
+        raise ValueError(f"GroupNorm over {c} channels is not supported by the gfx950 kernel")
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    shift = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty((n, groups), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((n, groups), dtype=torch.float32, device=x.device)
+    check(lib().gm_gn_scale_shift(x.data_ptr(), arena_ld(x), n, v, c, groups, float(eps), _ptr(as_f32(gamma)), _ptr(as_f32(beta)),
+                                  scale.data_ptr(), shift.data_ptr(), _ptr(mean), _ptr(rstd), ws.data_ptr(), dt_code(x.dtype),
+                                  _stream()), "gm_gn_scale_shift")
+    if want_stats:
+        return scale, shift, mean, rstd
+    return scale, shift
+
+
+def gn_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act: str = "none") -> torch.Tensor:
+    require_device(x, scale, shift)
+    n, c = x.shape[0], x.shape[-1]
+    v = rows_of(x) // max(n, 1)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    check(lib().gm_gn_apply(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), scale.data_ptr(), shift.data_ptr(), n, v, c,
+                            ACT[act], dt_code(x.dtype), _stream()), "gm_gn_apply")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    require_device(x)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    check(lib().gm_layernorm(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), _ptr(as_f32(gamma)), _ptr(as_f32(beta)),
+                             rows_of(x), x.shape[-1], float(eps), dt_code(x.dtype), _stream()), "gm_layernorm")
+    return out
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    require_device(x)
+    inner = x.shape[-1] // 2
+    out = torch.empty((*x.shape[:-1], inner), dtype=x.dtype, device=x.device)
+    check(lib().gm_geglu(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), rows_of(x), inner, dt_code(x.dtype), _stream()),
+          "gm_geglu")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# convolution / linear
+# ------------------------------------------------------------------------------------------------------------------------
+def _clog2(v: int) -> int:
+    return max(0, (int(v) - 1).bit_length())
+
+
+def _tile_bits(total_bits: int, out_dims):
+    """Distribute log2(voxels per tile) over (d, h, w): grow the smallest tile extent first, never beyond the output."""
+    caps = [_clog2(d) for d in out_dims]
+    bits = [0, 0, 0]
+    for _ in range(total_bits):
+        cand = [i for i in (2, 1, 0) if bits[i] < caps[i]]
+        if not cand:
+            bits[2] += 1
+            continue
+        i = min(cand, key=lambda j: bits[j])
+        bits[i] += 1
+    return bits
+
+
+_CFG_TILES = {}
+
+
+def _cfg_tile(cfg: int):
+    if cfg not in _CFG_TILES:
+        bm, bn = C.c_int(), C.c_int()
+        check(lib().gm_conv_cfg_tile(cfg, C.byref(bm), C.byref(bn)), "gm_conv_cfg_tile")
+        _CFG_TILES[cfg] = (bm.value, bn.value)
+    return _CFG_TILES[cfg]
+
+
+LDS_SOFT_LIMIT = 80 * 1024   # two workgroups per CU
+LDS_HARD_LIMIT = 160 * 1024
+
+
+def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] = None):
+    cout = desc.Cout
+    if force_cfg is not None:
+        order = [force_cfg]
+    elif cout <= 16:
+        order = [3, 4, 2]
+    elif cout <= 64:
+        order = [0, 4, 2]
+    else:
+        order = [1, 4, 2]
+    if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
+        order = [c for c in order if _cfg_tile(c)[0] <= 64] + [c for c in order if _cfg_tile(c)[0] > 64]
+    best = None
+    for cfg in order:
+        bm, _ = _cfg_tile(cfg)
+        bits = _tile_bits(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
+        desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
+        lds = lib().gm_conv_lds_bytes(C.byref(desc))
+        if 0 < lds <= LDS_SOFT_LIMIT:
+            return
+        if 0 < lds <= LDS_HARD_LIMIT and best is None:
+            best = (cfg, bits)
+    if best is None:
+        raise ValueError("convolution geometry needs more than 160 KiB of LDS per tile (kernel/stride/dilation too large)")
+    desc.cfg, (desc.ltd, desc.lth, desc.ltw) = best[0], best[1]
+
+
+def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *, kernel, stride=1, padding=0, dilation=1,
+         pad_hi=None, upsample: bool = False, transposed: bool = False, output_padding=0,
+         pre: Optional[tuple] = None, pre_act: str = "none", rowvec: Optional[torch.Tensor] = None,
+         res: Optional[torch.Tensor] = None, post_act: str = "none", out: Optional[torch.Tensor] = None,
+         packed: Optional[torch.Tensor] = None, cout: Optional[int] = None, force_cfg: Optional[int] = None) -> torch.Tensor:
+    """Fused convolution over an arena tensor x = (N, *spatial, Cin).
+
+    kernel/stride/padding/dilation: int or per-axis tuples (len = number of spatial axes). `padding` is the low-side pad,
+    `pad_hi` the high side (default: same as low). upsample: nearest 2x folded into the input indexing.
+    transposed: nn.ConvTransposeNd semantics (weight [Cin, Cout, *k]). pre = (scale, shift) fp32 [N, Cin] GroupNorm affine;
+    pre_act in ACT; rowvec fp32 [B or 1, Cout]; res arena tensor in the output geometry; post_act in POST_ACT.
+    `packed`/`cout` override the weight panel (fused multi-head projections)."""
+    require_device(x, weight, bias, rowvec, res, out)
+    nsp = x.dim() - 2
+    if nsp < 1 or nsp > 3:
+        raise ValueError("conv expects (N, *spatial, C) with 1-3 spatial axes")
+
+    def tup(v):
+        v = tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * nsp
+        if len(v) != nsp:
+            raise ValueError("per-axis argument has the wrong length")
+        return v
+
+    def pad3(v, fill):
+        return (fill,) * (3 - nsp) + tuple(v)
+
+    k = pad3(tup(kernel), 1)
+    s = pad3(tup(stride), 1)
+    plo = pad3(tup(padding), 0)
+    phi = pad3(tup(pad_hi if pad_hi is not None else padding), 0)
+    dil = pad3(tup(dilation), 1)
+    opad = pad3(tup(output_padding), 0)
+    n, cin = x.shape[0], x.shape[-1]
+    src = pad3(tuple(x.shape[1:-1]), 1)
+    dtype = x.dtype
+    if packed is None:
+        packed = packed_conv_weight(weight, dtype, transposed)
+        cout = weight.shape[1] if transposed else weight.shape[0]
+        wcin = weight.shape[0] if transposed else weight.shape[1]
+        if wcin != cin:
+            raise ValueError(f"input has {cin} channels but the weight expects {wcin}")
+    d = GmConvDesc()
+    d.in_mode, d.fd, d.fh, d.fw = 0, 1, 1, 1
+    act_axes = (0,) * (3 - nsp) + (1,) * nsp
+    if transposed:
+        if upsample:
+            raise ValueError("upsample and transposed are exclusive")
+        d.in_mode = 2
+        d.fd, d.fh, d.fw = s
+        out_sp = tuple((src[i] - 1) * s[i] - plo[i] - phi[i] + dil[i] * (k[i] - 1) + opad[i] + 1 for i in range(3))
+        conv_pad = tuple(dil[i] * (k[i] - 1) - plo[i] for i in range(3))
+        conv_stride = (1, 1, 1)
+    else:
+        virt = src
+        if upsample:
+            d.in_mode = 1
+            d.fd, d.fh, d.fw = tuple(2 if a else 1 for a in act_axes)
+            virt = tuple(src[i] * (2 if act_axes[i] else 1) for i in range(3))
+        out_sp = tuple((virt[i] + plo[i] + phi[i] - dil[i] * (k[i] - 1) - 1) // s[i] + 1 for i in range(3))
+        conv_pad, conv_stride = plo, s
+    if min(out_sp) <= 0:
+        raise ValueError(f"convolution output would be empty: {out_sp}")
+    out_shape = (n, *out_sp[3 - nsp:], cout)
+    if out is None:
+        out = torch.empty(out_shape, dtype=dtype, device=x.device)
+    elif tuple(out.shape) != out_shape or out.dtype != dtype:
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {out_shape}")
+    d.x, d.x_ld = x.data_ptr(), arena_ld(x)
+    d.w = packed.data_ptr()
+    b32 = as_f32(bias) if bias is not None else None
+    d.bias = _ptr(b32)
+    if pre is not None:
+        sc, sh = pre
+        require_device(sc, sh)
+        if tuple(sc.shape) != (n, cin) or sc.dtype != torch.float32:
+            raise ValueError("pre scale/shift must be fp32 [N, Cin]")
+        d.pre_scale, d.pre_shift = sc.data_ptr(), sh.data_ptr()
+    else:
+        d.pre_scale = d.pre_shift = None
+    if rowvec is not None:
+        if rowvec.dtype != torch.float32 or rowvec.dim() != 2 or rowvec.shape[1] != cout or rowvec.shape[0] not in (1, n):
+            raise ValueError(f"rowvec must be fp32 [1 or N, Cout], got {tuple(rowvec.shape)} {rowvec.dtype}")
+        if rowvec.stride(1) != 1:
+            raise ValueError("rowvec must have unit stride on its last dim")
+        d.rowvec = rowvec.data_ptr()
+        d.rowvec_bstride = 0 if rowvec.shape[0] == 1 else rowvec.stride(0)
+    else:
+        d.rowvec, d.rowvec_bstride = None, 0
+    if res is not None:
+        if tuple(res.shape) != out_shape or res.dtype != dtype:
+            raise ValueError(f"residual has shape {tuple(res.shape)} / {res.dtype}, expected {out_shape} / {dtype}")
+        d.res, d.res_ld = res.data_ptr(), arena_ld(res)
+    else:
+        d.res, d.res_ld = None, 0
+    d.y, d.y_ld = out.data_ptr(), arena_ld(out)
+    d.N, d.Cin, d.Cout = n, cin, cout
+    d.Ds, d.Hs, d.Ws = src
+    d.Do, d.Ho, d.Wo = out_sp
+    d.kd, d.kh, d.kw = k
+    d.sd, d.sh, d.sw = conv_stride
+    d.pd, d.ph, d.pw = conv_pad
+    d.dd, d.dh, d.dw = dil
+    d.pre_act, d.post_act, d.dtype = ACT[pre_act], POST_ACT[post_act], dt_code(dtype)
+    _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
+    check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward")
+    return out
+
+
+def linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], **kw) -> torch.Tensor:
+    """nn.Linear over the last dim of x = (N, L, C) or (rows, C); same fusion hooks as conv."""
+    if x.dim() == 3:
+        return conv(x, weight, bias, kernel=1, **kw)
+    if x.dim() == 2:
+        for key in ("res", "out"):
+            if kw.get(key) is not None:
+                kw[key] = kw[key].unsqueeze(0)
+        return conv(x.unsqueeze(0), weight, bias, kernel=1, **kw).squeeze(0)
+    raise ValueError("linear expects (rows, C) or (N, L, C)")
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------------------------
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
+              res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(scale * Q K^T) V per (batch, head). q: (B, Lq, heads*dh) arena views (channel slices allowed), k/v: (B, Lk, ...)."""
+    require_device(q, k, v, res, out)
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    if c % heads != 0 or k.shape[2] != c or v.shape[2] != c or v.shape[1] != lk:
+        raise ValueError("attention operand shapes are inconsistent")
+    dh = c // heads
+    if dh > lib().gm_attention_max_head_dim():
+        raise ValueError(f"head dim {dh} exceeds the gfx950 attention kernel limit ({lib().gm_attention_max_head_dim()})")
+    if out is None:
+        out = torch.empty((b, lq, c), dtype=q.dtype, device=q.device)
+    d = GmAttnDesc()
+    d.q, d.q_ld = q.data_ptr(), arena_ld(q)
+    d.k, d.k_ld = k.data_ptr(), arena_ld(k)
+    d.v, d.v_ld = v.data_ptr(), arena_ld(v)
+    if res is not None:
+        if tuple(res.shape) != (b, lq, c) or res.dtype != q.dtype:
+            raise ValueError("attention residual shape/dtype mismatch")
+        d.res, d.res_ld = res.data_ptr(), arena_ld(res)
+    else:
+        d.res, d.res_ld = None, 0
+    d.o, d.o_ld = out.data_ptr(), arena_ld(out)
+    d.B, d.H, d.Lq, d.Lk, d.dh = b, heads, lq, lk, dh
+    d.scale, d.dtype = float(scale), dt_code(q.dtype)
+    # batch strides must equal L * ld (tokens of one sample are row-dense)
+    for t, L in ((q, lq), (k, lk), (v, lk), (out, lq)):
+        if t.shape[0] > 1 and t.stride(0) != L * arena_ld(t):
+            raise ValueError("attention operands must be row-dense over (batch, tokens)")
+    check(lib().gm_attention_forward(C.byref(d), _stream()), "gm_attention_forward")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# misc element-wise
+# ------------------------------------------------------------------------------------------------------------------------
+def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10000.0, dtype=torch.float32) -> torch.Tensor:
+    require_device(timesteps)
+    t = timesteps.to(torch.float32).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=dtype, device=t.device)
+    check(lib().gm_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, float(max_period), dt_code(dtype), _stream()),
+          "gm_timestep_embedding")
+    return out
+
+
+def sched_step(sample: torch.Tensor, model_output: torch.Tensor, params: GmStepParams, noise: Optional[torch.Tensor] = None,
+               want_x0: bool = True):
+    """Fused DDIM / DDPM step on logical NC[D]HW tensors (all contiguous, same dtype)."""
+    require_device(sample, model_output, noise)
+    if sample.dtype != model_output.dtype:
+        raise TypeError("sample and model_output must share a dtype")
+    sample = sample.contiguous()
+    model_output = model_output.contiguous()
+    batch = sample.shape[0]
+    inner = sample.numel() // max(batch, 1)
+    mo_bs = model_output.numel() // max(batch, 1)
+    if mo_bs not in (inner, 2 * inner):
+        raise ValueError("model_output shape does not match the sample")
+    if params.noise_mode in (2, 3) and mo_bs != 2 * inner:
+        raise ValueError("learned variance needs 2*C model output channels")
+    if noise is not None:
+        noise = noise.contiguous()
+        if noise.numel() != sample.numel() or noise.dtype != sample.dtype:
+            raise ValueError("noise must match the sample")
+    prev = torch.empty_like(sample)
+    x0 = torch.empty_like(sample) if want_x0 else None
+    check(lib().gm_sched_step(sample.data_ptr(), model_output.data_ptr(), _ptr(noise), prev.data_ptr(), _ptr(x0), batch, inner,
+                              mo_bs, dt_code(sample.dtype), C.byref(params), _stream()), "gm_sched_step")
+    return prev, x0
+
+
+def axpby_rows(x: torch.Tensor, y: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """out[n] = a[n] * x[n] + b[n] * y[n] with fp32 per-sample coefficients on the device."""
+    require_device(x, y, a, b)
+    if x.shape != y.shape or x.dtype != y.dtype:
+        raise ValueError("axpby_rows operands must match")
+    x, y = x.contiguous(), y.contiguous()
+    a = a.to(torch.float32).contiguous()
+    b = b.to(torch.float32).contiguous()
+    batch = x.shape[0]
+    if a.numel() != batch or b.numel() != batch:
+        raise ValueError("one coefficient per batch row expected")
+    out = torch.empty_like(x)
+    check(lib().gm_axpby_rows(x.data_ptr(), y.data_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(), batch,
+                              x.numel() // max(batch, 1), dt_code(x.dtype), _stream()), "gm_axpby_rows")
+    return out
+
+
+def aekl_sample(mu: Optional[torch.Tensor], logvar: torch.Tensor, eps: Optional[torch.Tensor] = None, want_sigma: bool = True):
+    """sigma = exp(clamp(logvar, -30, 20) / 2); z = mu + eps * sigma (if eps is given). Any matching dense layout."""
+    require_device(mu, logvar, eps)
+    logvar = logvar.contiguous()
+    sigma = torch.empty_like(logvar) if want_sigma else None
+    z = None
+    if eps is not None:
+        mu, eps = mu.contiguous(), eps.contiguous()
+        z = torch.empty_like(logvar)
+    check(lib().gm_aekl_sample(_ptr(mu), logvar.data_ptr(), _ptr(eps), _ptr(sigma), _ptr(z), logvar.numel(), dt_code(logvar.dtype),
+                               _stream()), "gm_aekl_sample")
+    return sigma, z
+
+
+def addcmul(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """a + b * c element-wise (same shape / dtype, any matching dense layout)."""
+    require_device(a, b, c)
+    if not (a.shape == b.shape == c.shape) or not (a.dtype == b.dtype == c.dtype):
+        raise ValueError("addcmul operands must match in shape and dtype")
+    a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+    out = torch.empty_like(a)
+    check(lib().gm_addcmul(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), a.numel(), dt_code(a.dtype), _stream()),
+          "gm_addcmul")
+    return out
+
+
+def scale(x: torch.Tensor, s: float, divide: bool = False) -> torch.Tensor:
+    """x * s or x / s element-wise."""
+    require_device(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(lib().gm_scale(x.data_ptr(), out.data_ptr(), float(s), int(divide), x.numel(), dt_code(x.dtype), _stream()), "gm_scale")
+    return out
+
+
+def concat_dim1(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """torch.cat(parts, dim=1) for contiguous NC[D]HW tensors (inferers/inferer.py:72,127 "concat" conditioning)."""
+    require_device(*parts)
+    parts = [p.contiguous() for p in parts]
+    n = parts[0].shape[0]
+    inner = [p.numel() // max(n, 1) for p in parts]
+    c = sum(p.shape[1] for p in parts)
+    out = torch.empty((n, c, *parts[0].shape[2:]), dtype=parts[0].dtype, device=parts[0].device)
+    tot, off = sum(inner), 0
+    flat = out.reshape(n, tot) if n else out
+    for p, k in zip(parts, inner):
+        if tuple(p.shape[2:]) != tuple(parts[0].shape[2:]) or p.shape[0] != n:
+            raise ValueError("concat_dim1 operands must agree outside dim 1")
+        if n and k:
+            check(lib().gm_copy_channels(p.data_ptr(), k, dt_code(p.dtype), flat.data_ptr() + off * flat.element_size(), tot,
+                                         dt_code(out.dtype), n, k, _stream()), "gm_copy_channels")
+        off += k
+    return out
+
+
+def vq_argmin(x: torch.Tensor, embedding: torch.Tensor) -> torch.Tensor:
+    """x: arena (N, *spatial, D) -> int64 indices (N, *spatial)."""
+    require_device(x, embedding)
+    emb = as_f32(embedding)
+    idx = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    check(lib().gm_vq_argmin(x.data_ptr(), arena_ld(x), emb.data_ptr(), idx.data_ptr(), rows_of(x), emb.shape[0], emb.shape[1],
+                             dt_code(x.dtype), _stream()), "gm_vq_argmin")
+    return idx
+
+
+def vq_gather(indices: torch.Tensor, embedding: torch.Tensor, dtype: torch.dtype, x: Optional[torch.Tensor] = None):
+    """indices (N, *spatial) -> arena (N, *spatial, D); with x also returns mean((q - x)^2) as a 0-dim fp32 tensor."""
+    require_device(indices, embedding, x)
+    emb = as_f32(embedding)
+    indices = indices.contiguous()
+    out = torch.empty((*indices.shape, emb.shape[1]), dtype=dtype, device=indices.device)
+    err = ws = None
+    if x is not None:
+        err = torch.empty((), dtype=torch.float32, device=indices.device)
+        ws = torch.empty(lib().gm_vq_gather_workspace_bytes(), dtype=torch.uint8, device=indices.device)
+    check(lib().gm_vq_gather(indices.data_ptr(), emb.data_ptr(), out.data_ptr(), arena_ld(out), _ptr(x), 0 if x is None else arena_ld(x),
+                             _ptr(err), _ptr(ws), indices.numel(), emb.shape[0], emb.shape[1], dt_code(dtype), _stream()),
+          "gm_vq_gather")
+    return (out, err) if x is not None else out

@@ -1,0 +1,151 @@
+/* gm_amd.h -- C ABI of libgmamd.so, the MI355X (gfx950) kernel library behind generativemodels_amd.
+ *
+ * The reference (Project-MONAI/GenerativeModels) has no native code and no FFI: its "kernels" are torch ops called from
+ * Python.  This header is therefore the boundary a maintainer would bind (ctypes / cffi) to replace
+ * those op sequences; every entry point names the reference lines it replaces (paths relative to generative/).
+ *
+ * Conventions
+ *   - plain pointers + sizes; device pointers unless stated; no torch / framework types.
+ *   - activations live in N[D]HWC ("channels last") layout: a tensor is (ptr, leading dim `ld` in ELEMENTS between
+ *     consecutive voxels, C used channels <= ld).  2-D data passes D = 1.
+ *   - dtype: GM_F32 (parity path, exact-fp32 MFMA) or GM_BF16 (bf16 storage, fp32 accumulation).
+ *   - every call enqueues on `stream` (a hipStream_t; NULL = default stream) and returns immediately.
+ *   - return value 0 = success; otherwise a negative argument error or a positive hipError_t, message via gm_last_error().
+ */
+#ifndef GM_AMD_H
+#define GM_AMD_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_F32 0
+#define GM_BF16 1
+
+int gm_abi_version(void);
+const char* gm_last_error(void);
+
+/* ---- scheduler (networks/schedulers/ddim.py:156-237, ddpm.py:191-252) ------------------------------------------------
+ * One fused element-wise kernel per reverse step.  The per-step scalars are computed by the host with the reference's
+ * own fp32 expressions (see generativemodels_amd/networks/schedulers). */
+typedef struct GmStepParams {
+  int mode;        /* 0 DDIM, 1 DDPM */
+  int pred_type;   /* 0 epsilon, 1 sample, 2 v_prediction */
+  float c_sa;      /* alpha_prod_t ** 0.5 */
+  float c_sb;      /* beta_prod_t ** 0.5 */
+  int clip;        /* clamp x0 to [clip_lo, clip_hi] */
+  float clip_lo, clip_hi;
+  float c_prev;    /* DDIM: alpha_prod_t_prev ** 0.5 */
+  float c_dir;     /* DDIM: (1 - alpha_prod_t_prev - std_dev_t**2) ** 0.5 */
+  float k0, k1;    /* DDPM: pred_original_sample_coeff, current_sample_coeff */
+  int noise_mode;  /* 0 none, 1 c_noise*noise, 2 learned variance, 3 learned_range */
+  float c_noise;
+  float min_log, max_log;
+} GmStepParams;
+/* sample/prev/x0/noise: [batch][inner]; model_output: [batch][mo_bstride] (mo_bstride = 2*inner for learned variance).
+ * x0 and noise may be NULL. */
+int gm_sched_step(const void* sample, const void* model_output, const void* noise, void* prev, void* x0,
+                  long long batch, long long inner, long long mo_bstride, int dtype, const GmStepParams* p, void* stream);
+/* out[n,i] = a[n]*x[n,i] + b[n]*y[n,i]: Scheduler.add_noise / get_velocity (networks/schedulers/scheduler.py:169-200) */
+int gm_axpby_rows(const void* x, const void* y, const float* a, const float* b, void* out, long long batch,
+                  long long inner, int dtype, void* stream);
+
+/* ---- layout plumbing of the NDHWC arena ------------------------------------------------------------------------------ */
+int gm_copy_channels(const void* src, long long src_ld, int src_dtype, void* dst, long long dst_ld, int dst_dtype,
+                     long long rows, int C, void* stream);            /* torch.cat / casts (diffusion_model_unet.py:1232) */
+int gm_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, long long V, long long dst_ld,
+                    void* stream);
+int gm_nhwc_to_nchw(const void* src, long long src_ld, int src_dtype, void* dst, int dst_dtype, int N, int C, long long V,
+                    void* stream);
+/* mode 0: nearest 2x up, mode 1: 2x average pool (ResnetBlock up/down path, diffusion_model_unet.py:635-639,674-682) */
+int gm_resample2x(const void* src, long long src_ld, void* dst, long long dst_ld, int N, int C, int Di, int Hi, int Wi,
+                  int act_d, int mode, int dtype, void* stream);
+/* get_timestep_embedding (diffusion_model_unet.py:461-485): [cos | sin], zero pad if dim is odd */
+int gm_timestep_embedding(const float* timesteps, void* out, int B, int dim, float max_period, int dtype, void* stream);
+/* MONAI MLPBlock(act="GEGLU") gate (diffusion_model_unet.py:211): out = x[:, :inner] * gelu(x[:, inner:]) */
+int gm_geglu(const void* x, long long x_ld, void* out, long long out_ld, long long rows, int inner, int dtype, void* stream);
+/* AutoencoderKL.encode/sampling tail (autoencoderkl.py:731-753); eps/z/mu may be NULL when only sigma is wanted */
+int gm_aekl_sample(const void* mu, const void* logvar, const void* eps, void* sigma, void* z, long long total, int dtype,
+                   void* stream);
+
+/* out = a + b*c element-wise: AutoencoderKL.sampling (autoencoderkl.py:751-752) */
+int gm_addcmul(const void* a, const void* b, const void* c, void* out, long long total, int dtype, void* stream);
+
+/* out = x*s (mode 0) or x/s (mode 1): latent scale factor of LatentDiffusionInferer (inferers/inferer.py:386,472) */
+int gm_scale(const void* x, void* out, float s, int mode, long long total, int dtype, void* stream);
+
+/* ---- GroupNorm / LayerNorm (diffusion_model_unet.py:623,643,275,377,1854; autoencoderkl.py:146,156,227,433,579) ------
+ * gm_gn_scale_shift reads x once and emits fp32 scale[n][c] = rstd*gamma, shift[n][c] = beta - mean*rstd*gamma that the
+ * consumer convolution applies in its prologue (no normalised tensor is ever written). */
+long long gm_gn_workspace_bytes(int N, long long V, int C, int G, int dtype);
+int gm_gn_scale_shift(const void* x, long long ld, int N, long long V, int C, int G, float eps, const float* gamma,
+                      const float* beta, float* scale, float* shift, float* mean, float* rstd, void* workspace, int dtype,
+                      void* stream);
+int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift, int N,
+                long long V, int C, int act, int dtype, void* stream);
+int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
+                 long long rows, int C, float eps, int dtype, void* stream);
+
+/* ---- convolution / linear as LDS-staged implicit GEMM on MFMA ---------------------------------------------------------
+ * Replaces MONAI Convolution(conv_only=True) (nn.ConvNd / nn.ConvTransposeNd) and nn.Linear, fused with
+ * GroupNorm-apply + SiLU (prologue), nearest-2x Upsample (diffusion_model_unet.py:572-585), bias, timestep-embedding add
+ * (:686-690), residual add (:692-696) and the output activation. */
+typedef struct GmConvDesc {
+  const void* x; long long x_ld;
+  const void* w;             /* packed by gm_pack_conv_weight */
+  const float* bias;         /* [Cout] or NULL */
+  const float* pre_scale;    /* [N][Cin] or NULL */
+  const float* pre_shift;    /* [N][Cin] or NULL */
+  const float* rowvec;       /* [B][Cout] fp32 or NULL: added per (n, cout) */
+  long long rowvec_bstride;  /* 0: one row broadcast over the batch */
+  const void* res; long long res_ld;
+  void* y; long long y_ld;
+  int N, Cin, Cout;
+  int Ds, Hs, Ws;
+  int Do, Ho, Wo;
+  int kd, kh, kw;
+  int sd, sh, sw;
+  int pd, ph, pw;            /* low-side padding */
+  int dd, dh, dw;            /* dilation */
+  int in_mode;               /* 0 direct, 1 nearest up-sample, 2 zero insertion (transposed conv) */
+  int fd, fh, fw;
+  int pre_act;               /* 0 none, 1 SiLU, 2 ReLU */
+  int post_act;              /* 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01) */
+  int dtype;
+  int ltd, lth, ltw;         /* log2 output tile dims; product must equal the configuration's voxel count */
+  int cfg;                   /* tile configuration, see gm_conv_cfg_tile */
+} GmConvDesc;
+int gm_conv_cfg_tile(int cfg, int* voxels, int* channels);
+long long gm_conv_lds_bytes(const GmConvDesc* d);
+int gm_conv_forward(const GmConvDesc* d, void* stream);
+long long gm_packed_conv_weight_elems(int Cout, int Cin, int kd, int kh, int kw, int dtype);
+/* src: [Cout][Cin][kd][kh][kw] (transposed = 0) or [Cin][Cout][kd][kh][kw] (transposed = 1, nn.ConvTransposeNd) */
+int gm_pack_conv_weight(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin, int kd, int kh, int kw,
+                        int transposed, void* stream);
+
+/* ---- attention (diffusion_model_unet.py:143-153,407-415; autoencoderkl.py:261-269) ------------------------------------
+ * O = softmax(scale * Q K^T) V (+ residual) per (batch, head); q/k/v/o rows are tokens, head h at element offset h*dh. */
+typedef struct GmAttnDesc {
+  const void* q; long long q_ld;
+  const void* k; long long k_ld;
+  const void* v; long long v_ld;
+  const void* res; long long res_ld;
+  void* o; long long o_ld;
+  int B, H, Lq, Lk, dh;
+  float scale;
+  int dtype;
+} GmAttnDesc;
+int gm_attention_max_head_dim(void);
+int gm_attention_forward(const GmAttnDesc* d, void* stream);
+
+/* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */
+int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long long* indices, long long tokens,
+                 int num_embeddings, int dim, int dtype, void* stream);
+long long gm_vq_gather_workspace_bytes(void);
+int gm_vq_gather(const long long* indices, const float* embedding, void* out, long long out_ld, const void* x,
+                 long long x_ld, float* sq_err_mean, void* workspace, long long tokens, int num_embeddings, int dim,
+                 int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GM_AMD_H */
