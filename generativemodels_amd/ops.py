@@ -39,6 +39,34 @@ def require_device(*ts: Optional[torch.Tensor]) -> None:
                 f"'{t.device}'. There is no CPU / eager fallback (move the module and its inputs to 'cuda').")
 
 
+# ---- optional per-launch timing (bench.py / profiling only): HIP events on the launch stream around selected kernels --------
+_PROFILE: Optional[list] = None
+
+
+def start_profile() -> None:
+    global _PROFILE
+    _PROFILE = []
+
+
+def stop_profile() -> list:
+    """-> [(kernel label, meta dict, elapsed ms)] for every launch since start_profile()."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE or [], None
+    torch.cuda.synchronize()
+    return [(name, meta, e0.elapsed_time(e1)) for name, meta, e0, e1 in rec]
+
+
+def _timed(name: str, meta: dict, fn):
+    if _PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    _PROFILE.append((name, meta, e0, e1))
+    return r
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -199,8 +227,9 @@ def copy_channels(src: torch.Tensor, dst: torch.Tensor) -> None:
     require_device(src, dst)
     if src.shape != dst.shape:
         raise ValueError(f"copy_channels shape mismatch {tuple(src.shape)} vs {tuple(dst.shape)}")
-    check(lib().gm_copy_channels(src.data_ptr(), arena_ld(src), dt_code(src.dtype), dst.data_ptr(), arena_ld(dst),
-                                 dt_code(dst.dtype), rows_of(src), src.shape[-1], _stream()), "gm_copy_channels")
+    _timed("copy_channels", dict(flops=0.0, bytes=float(src.numel() * (src.element_size() + dst.element_size())), shape=str(tuple(src.shape))),
+           lambda: check(lib().gm_copy_channels(src.data_ptr(), arena_ld(src), dt_code(src.dtype), dst.data_ptr(), arena_ld(dst),
+                                                dt_code(dst.dtype), rows_of(src), src.shape[-1], _stream()), "gm_copy_channels"))
 
 
 def concat_channels(parts: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -266,9 +295,11 @@ def gn_scale_shift(x: torch.Tensor, groups: int, eps: float, gamma: Optional[tor
     if want_stats:
         mean = torch.empty((n, groups), dtype=torch.float32, device=x.device)
         rstd = torch.empty((n, groups), dtype=torch.float32, device=x.device)
-    check(lib().gm_gn_scale_shift(x.data_ptr(), arena_ld(x), n, v, c, groups, float(eps), _ptr(as_f32(gamma)), _ptr(as_f32(beta)),
-                                  scale.data_ptr(), shift.data_ptr(), _ptr(mean), _ptr(rstd), ws.data_ptr(), dt_code(x.dtype),
-                                  _stream()), "gm_gn_scale_shift")
+    g32, b32 = as_f32(gamma), as_f32(beta)
+    _timed(f"gn_stats<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(x.element_size() * n * v * c), shape=f"N{n} V{v} C{c}"),
+           lambda: check(lib().gm_gn_scale_shift(x.data_ptr(), arena_ld(x), n, v, c, groups, float(eps), _ptr(g32), _ptr(b32),
+                                                 scale.data_ptr(), shift.data_ptr(), _ptr(mean), _ptr(rstd), ws.data_ptr(),
+                                                 dt_code(x.dtype), _stream()), "gm_gn_scale_shift"))
     if want_stats:
         return scale, shift, mean, rstd
     return scale, shift
@@ -468,7 +499,17 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     d.dd, d.dh, d.dw = dil
     d.pre_act, d.post_act, d.dtype = ACT[pre_act], POST_ACT[post_act], dt_code(dtype)
     _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
-    check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward")
+    if _PROFILE is None:
+        check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward")
+    else:
+        es = x.element_size()
+        taps = k[0] * k[1] * k[2]
+        nvo = n * math.prod(out_sp)
+        meta = dict(flops=2.0 * nvo * cout * cin * taps,
+                    bytes=float(es * (n * math.prod(src) * cin + nvo * cout * (2 if res is not None else 1) + cout * cin * taps)),
+                    shape=f"{cin}->{cout} k{k} s{conv_stride} out{tuple(out_sp)} mode{d.in_mode}")
+        _timed(f"conv_igemm<{str(dtype).split('.')[-1]},cfg{d.cfg}>", meta,
+               lambda: check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward"))
     return out
 
 
@@ -517,7 +558,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     for t, L in ((q, lq), (k, lk), (v, lk), (out, lq)):
         if t.shape[0] > 1 and t.stride(0) != L * arena_ld(t):
             raise ValueError("attention operands must be row-dense over (batch, tokens)")
-    check(lib().gm_attention_forward(C.byref(d), _stream()), "gm_attention_forward")
+    meta = dict(flops=4.0 * b * lq * lk * c, bytes=float(q.element_size() * b * (2 * lq + 2 * lk) * c), shape=f"B{b} H{heads} Lq{lq} Lk{lk} dh{dh}")
+    _timed(f"attention<{str(q.dtype).split('.')[-1]}>", meta,
+           lambda: check(lib().gm_attention_forward(C.byref(d), _stream()), "gm_attention_forward"))
     return out
 
 
@@ -554,8 +597,10 @@ def sched_step(sample: torch.Tensor, model_output: torch.Tensor, params: GmStepP
             raise ValueError("noise must match the sample")
     prev = torch.empty_like(sample)
     x0 = torch.empty_like(sample) if want_x0 else None
-    check(lib().gm_sched_step(sample.data_ptr(), model_output.data_ptr(), _ptr(noise), prev.data_ptr(), _ptr(x0), batch, inner,
-                              mo_bs, dt_code(sample.dtype), C.byref(params), _stream()), "gm_sched_step")
+    nb = sample.element_size() * sample.numel()
+    _timed("sched_step", dict(flops=0.0, bytes=float(nb * (3 + (x0 is not None) + (noise is not None))), shape=str(tuple(sample.shape))),
+           lambda: check(lib().gm_sched_step(sample.data_ptr(), model_output.data_ptr(), _ptr(noise), prev.data_ptr(), _ptr(x0), batch,
+                                             inner, mo_bs, dt_code(sample.dtype), C.byref(params), _stream()), "gm_sched_step"))
     return prev, x0
 
 

@@ -1,0 +1,351 @@
+"""GPU (-m gpu): every C-ABI kernel of libgmamd.so against the CPU oracle / a plain torch-CPU fp64 statement of the same op,
+called through the ctypes binding (generativemodels_amd.ops). Tolerances: fp32 path = exact-fp32 MFMA products with fp32
+accumulation, compared at 2e-5 * scale (the reference's own fp32 op-order noise); bf16 path = bf16 storage
+with fp32 accumulation, compared at 1.5e-2 * scale against the fp64 result of the bf16-rounded operands; scheduler
+arithmetic in fp32 is required to be BIT-EXACT."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import restatement as R
+from _util import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from generativemodels_amd import ops
+    return ops
+
+
+def _rand(shape, seed, dtype=torch.float32, scale=1.0):
+    return (torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale).to(dtype)
+
+
+def _cl(x):  # NC... -> arena on device
+    perm = [0] + list(range(2, x.dim())) + [1]
+    return x.permute(perm).contiguous().to(DEV)
+
+
+def _cf(a):  # arena -> NC... on cpu
+    perm = [0, a.dim() - 1] + list(range(1, a.dim() - 1))
+    return a.cpu().permute(perm).contiguous()
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.5e-2
+
+
+def _check(got, want, dtype, what, extra=1.0):
+    got, want = got.double().cpu(), want.double().cpu()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert math.isfinite(err) and err <= _tol(dtype) * scale * extra, f"{what}: max|err| {err:.3e} > {_tol(dtype) * scale * extra:.3e} (scale {scale:.3g})"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_library_loads_on_gpu():
+    from generativemodels_amd import _native
+    assert _native.lib().gm_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+def test_cpu_tensor_is_rejected():
+    ops = _ops()
+    with pytest.raises(RuntimeError):
+        ops.gn_scale_shift(torch.zeros(1, 4, 4, 8), 2, 1e-6, None, None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layout_roundtrip_and_cast(dtype):
+    ops = _ops()
+    x = _rand((2, 5, 3, 7, 6), 1).to(dtype)
+    a = ops.to_channels_last(x.to(DEV))
+    assert torch.equal(_cf(a), x)
+    assert torch.equal(ops.to_channels_first(a).cpu(), x)
+    wide = torch.zeros((2, 3, 7, 6, 9), dtype=dtype, device=DEV)
+    ops.copy_channels(a, wide[..., 2:7])
+    assert torch.equal(wide[..., 2:7].cpu(), a.cpu()) and float(wide[..., :2].abs().max()) == 0.0
+    assert torch.equal(ops.to_channels_first(wide[..., 2:7]).cpu(), x)
+    y = ops.cast(x.to(DEV), torch.float32)
+    assert torch.equal(y.cpu(), x.float())
+    c = ops.concat_channels([a, a[..., :2]])
+    assert torch.equal(c.cpu(), torch.cat([a.cpu(), a.cpu()[..., :2]], dim=-1))
+    d = ops.concat_dim1([x.to(DEV), x.to(DEV)[:, :2]])
+    assert torch.equal(d.cpu(), torch.cat([x, x[:, :2]], dim=1))
+
+
+def test_scheduler_steps_bit_exact_fp32():
+    """Every golden scheduler vector of the unmodified reference (tests/golden/schedulers.pt) through the fused HIP step."""
+    from generativemodels_amd.networks.schedulers import DDIMScheduler, DDPMScheduler
+    fx = load_fixture("schedulers")
+    mo, xs = fx["model_output"], fx["sample"]
+    n_cases = 0
+    for sname, e in fx["tables"].items():
+        ddim = DDIMScheduler(1000, schedule=sname, clip_sample=False, **e["kw"])
+        assert torch.equal(ddim.betas, e["betas"]) and torch.equal(ddim.alphas_cumprod, e["alphas_cumprod"])
+        ddim.set_timesteps(50)
+        assert torch.equal(ddim.timesteps, e["timesteps50"])
+        for (pt, clip, t, eta), (prev, x0) in e["ddim"].items():
+            ddim.prediction_type, ddim.clip_sample = pt, clip
+            gen = torch.Generator().manual_seed(fx["noise_seed"])
+            p2, x2 = ddim.step(mo.to(DEV), t, xs.to(DEV), eta=eta, generator=gen)
+            assert torch.equal(p2.cpu(), prev), ("ddim prev", sname, pt, clip, t, eta, (p2.cpu() - prev).abs().max().item())
+            assert torch.equal(x2.cpu(), x0), ("ddim x0", sname, pt, clip, t, eta)
+            n_cases += 1
+        ddpm = DDPMScheduler(1000, schedule=sname, **e["kw"])
+        for (pt, vt, t), (prev, x0) in e["ddpm"].items():
+            ddpm.prediction_type, ddpm.variance_type = pt, vt
+            m = fx["model_output2"] if vt.startswith("learned") else mo
+            gen = torch.Generator().manual_seed(fx["noise_seed"])
+            p2, x2 = ddpm.step(m.to(DEV), t, xs.to(DEV), generator=gen)
+            assert torch.equal(p2.cpu(), prev), ("ddpm prev", sname, pt, vt, t, (p2.cpu() - prev).abs().max().item())
+            assert torch.equal(x2.cpu(), x0), ("ddpm x0", sname, pt, vt, t)
+            n_cases += 1
+        ts = torch.tensor([999, 3])
+        assert torch.equal(ddpm.add_noise(xs.to(DEV), mo.to(DEV), ts).cpu(), e["add_noise"])
+        assert torch.equal(ddpm.get_velocity(xs.to(DEV), mo.to(DEV), ts.to(DEV)).cpu(), e["get_velocity"])
+    assert n_cases > 100
+
+
+def test_scheduler_step_bf16_close_to_fp32_oracle():
+    from generativemodels_amd.networks.schedulers import DDIMScheduler
+    d = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    d.set_timesteps(50)
+    mo, xs = _rand((1, 1, 16, 16, 16), 3), _rand((1, 1, 16, 16, 16), 4)
+    want, _ = R.ddim_step(d.alphas_cumprod, 1000, 50, mo.bfloat16().float(), 500, xs.bfloat16().float(), clip_sample=False)
+    got, _ = d.step(mo.bfloat16().to(DEV), 500, xs.bfloat16().to(DEV))
+    _check(got, want, torch.bfloat16, "ddim bf16")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,groups", [((2, 8, 8, 8, 8), 8), ((1, 64, 12, 10, 6), 32), ((2, 6, 9, 7), 3), ((1, 192, 5, 4, 3), 32),
+                                          ((1, 256, 33, 1, 1), 32), ((1, 40, 24, 24, 24), 8)])
+def test_groupnorm_scale_shift(dtype, shape, groups):
+    ops = _ops()
+    x = (_rand(shape, 5) * 1.7 + 0.4).to(dtype)
+    c = shape[1]
+    gamma, beta = _rand((c,), 6) * 0.3 + 1.0, _rand((c,), 7) * 0.2
+    a = _cl(x)
+    scale, shift, mean, rstd = ops.gn_scale_shift(a, groups, 1e-6, gamma.to(DEV), beta.to(DEV), want_stats=True)
+    xd = x.double()
+    want = F.group_norm(xd, groups, gamma.double(), beta.double(), 1e-6)
+    got = _cf(ops.gn_apply(a, scale, shift, "none"))
+    _check(got, want, dtype, "gn apply", extra=2.0)
+    got_silu = _cf(ops.gn_apply(a, scale, shift, "silu"))
+    _check(got_silu, F.silu(want), dtype, "gn+silu", extra=2.0)
+    grp = xd.reshape(shape[0], groups, -1)
+    assert (mean.cpu().double() - grp.mean(-1)).abs().max().item() < 1e-5
+    rel = ((rstd.cpu().double() - (grp.var(-1, unbiased=False) + 1e-6).rsqrt()) / rstd.cpu().double()).abs().max().item()
+    assert rel < 1e-5, rel
+    # sliced (ld > C) operand
+    wide = torch.zeros((*a.shape[:-1], c + 8), dtype=dtype, device=DEV)
+    ops.copy_channels(a, wide[..., 8:])
+    s2, h2 = ops.gn_scale_shift(wide[..., 8:], groups, 1e-6, gamma.to(DEV), beta.to(DEV))
+    assert torch.allclose(s2.cpu(), scale.cpu(), rtol=1e-6, atol=1e-7) and torch.allclose(h2.cpu(), shift.cpu(), rtol=1e-5, atol=1e-6)
+
+
+CONV_CASES = [
+    # name, N, Cin, Cout, spatial, kwargs (torch semantics)
+    ("3d_k3", 2, 8, 8, (8, 8, 8), dict(k=3, s=1, p=1)),
+    ("3d_k3_c64", 1, 64, 64, (6, 10, 12), dict(k=3, s=1, p=1)),
+    ("3d_k3_wide", 1, 48, 136, (5, 6, 9), dict(k=3, s=1, p=1)),
+    ("3d_cin1", 1, 1, 32, (9, 8, 7), dict(k=3, s=1, p=1)),
+    ("3d_cout1", 1, 32, 1, (9, 8, 7), dict(k=3, s=1, p=1)),
+    ("3d_s2", 1, 16, 24, (8, 10, 12), dict(k=3, s=2, p=1)),
+    ("3d_s2_asym", 2, 8, 8, (8, 8, 8), dict(k=3, s=2, p=0, pad_hi=1)),
+    ("3d_k1", 1, 40, 24, (4, 5, 6), dict(k=1, s=1, p=0)),
+    ("3d_up", 1, 16, 16, (4, 5, 6), dict(k=3, s=1, p=1, up=True)),
+    ("3d_k4s2", 1, 8, 16, (8, 8, 8), dict(k=4, s=2, p=1)),
+    ("3d_dil", 1, 8, 8, (9, 9, 9), dict(k=3, s=1, p=2, d=2)),
+    ("2d_k3", 2, 8, 16, (16, 16), dict(k=3, s=1, p=1)),
+    ("2d_s2", 2, 32, 32, (16, 12), dict(k=3, s=2, p=1)),
+    ("2d_up", 1, 8, 8, (7, 9), dict(k=3, s=1, p=1, up=True)),
+    ("2d_odd", 1, 3, 5, (11, 13), dict(k=3, s=1, p=1)),
+    ("3d_T_k4s2", 1, 8, 12, (4, 4, 4), dict(k=4, s=2, p=1, T=True, op=0)),
+    ("3d_T_k3s2", 2, 8, 8, (4, 4, 4), dict(k=3, s=2, p=1, T=True, op=1)),
+    ("2d_T_k3s1", 1, 8, 4, (8, 8), dict(k=3, s=1, p=1, T=True, op=0)),
+    ("2d_T_k3s2op1", 1, 16, 8, (8, 8), dict(k=3, s=2, p=1, T=True, op=1)),
+]
+
+
+def _conv_ref(x, w, b, nsp, kw):
+    x, w = x.double(), w.double()
+    b = None if b is None else b.double()
+    d = kw.get("d", 1)
+    if kw.get("up"):
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    if kw.get("T"):
+        fn = {2: F.conv_transpose2d, 3: F.conv_transpose3d}[nsp]
+        return fn(x, w, b, stride=kw["s"], padding=kw["p"], output_padding=kw.get("op", 0), dilation=d)
+    if kw.get("pad_hi") is not None:
+        x = F.pad(x, (kw["p"], kw["pad_hi"]) * nsp)
+        p = 0
+    else:
+        p = kw["p"]
+    fn = {2: F.conv2d, 3: F.conv3d}[nsp]
+    return fn(x, w, b, stride=kw["s"], padding=p, dilation=d)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_geometries(case, dtype):
+    ops = _ops()
+    name, n, cin, cout, sp, kw = case
+    nsp = len(sp)
+    x = _rand((n, cin, *sp), 11).to(dtype)
+    wshape = (cin, cout) if kw.get("T") else (cout, cin)
+    w = (_rand((*wshape, *([kw["k"]] * nsp)), 12) / math.sqrt(cin * kw["k"] ** nsp)).to(dtype)
+    b = _rand((cout,), 13) * 0.1
+    want = _conv_ref(x.float(), w.float(), b, nsp, kw)
+    got = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=kw["k"], stride=kw["s"], padding=kw["p"], dilation=kw.get("d", 1),
+                   pad_hi=kw.get("pad_hi"), upsample=bool(kw.get("up")), transposed=bool(kw.get("T")), output_padding=kw.get("op", 0))
+    _check(_cf(got), want, dtype, name)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+def test_conv_every_tile_configuration(cfg, dtype):
+    ops = _ops()
+    x = _rand((1, 24, 9, 10, 11), 21).to(dtype)
+    w = (_rand((40, 24, 3, 3, 3), 22) / math.sqrt(24 * 27)).to(dtype)
+    want = F.conv3d(x.double(), w.double(), None, padding=1)
+    got = ops.conv(_cl(x), w.to(DEV), None, kernel=3, padding=1, force_cfg=cfg)
+    _check(_cf(got), want, dtype, f"cfg{cfg}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_fused_resnet_prologue_epilogue(dtype):
+    """GN-apply + SiLU prologue, bias + timestep row + residual epilogue, channel-sliced input and output buffers."""
+    ops = _ops()
+    n, cin, cout, sp = 2, 16, 24, (6, 7, 8)
+    x = (_rand((n, cin, *sp), 31) * 1.3 + 0.2).to(dtype)
+    w = (_rand((cout, cin, 3, 3, 3), 32) / math.sqrt(cin * 27)).to(dtype)
+    b, gamma, beta = _rand((cout,), 33) * 0.1, _rand((cin,), 34) * 0.2 + 1.0, _rand((cin,), 35) * 0.1
+    temb = _rand((n, cout), 36) * 0.5
+    res = _rand((n, cout, *sp), 37).to(dtype)
+    xd = x.double()
+    want = F.conv3d(F.silu(F.group_norm(xd, 8, gamma.double(), beta.double(), 1e-6)), w.double(), b.double(), padding=1)
+    want = want + temb.double()[:, :, None, None, None] + res.double()
+    a = _cl(x)
+    wide_in = torch.zeros((*a.shape[:-1], cin + 8), dtype=dtype, device=DEV)
+    ops.copy_channels(a, wide_in[..., 8:])
+    xin = wide_in[..., 8:]
+    pre = ops.gn_scale_shift(xin, 8, 1e-6, gamma.to(DEV), beta.to(DEV))
+    wide_out = torch.zeros((n, *sp, cout + 8), dtype=dtype, device=DEV)
+    ops.conv(xin, w.to(DEV), b.to(DEV), kernel=3, padding=1, pre=pre, pre_act="silu", rowvec=temb.to(DEV), res=_cl(res),
+             out=wide_out[..., 4:4 + cout])
+    _check(_cf(wide_out[..., 4:4 + cout]), want, dtype, "fused resnet conv", extra=2.0)
+    assert float(wide_out[..., :4].abs().max()) == 0.0 and float(wide_out[..., 4 + cout:].abs().max()) == 0.0
+    # broadcast timestep row (B_t = 1, the `sample` case) + ReLU epilogue
+    got = ops.conv(xin, w.to(DEV), b.to(DEV), kernel=3, padding=1, rowvec=temb[:1].to(DEV), post_act="relu")
+    want2 = F.relu(F.conv3d(xd, w.double(), b.double(), padding=1) + temb.double()[:1, :, None, None, None])
+    _check(_cf(got), want2, dtype, "rowvec broadcast + relu")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_and_stacked_projection(dtype):
+    ops = _ops()
+    x = _rand((2, 37, 24), 41).to(dtype)
+    w1, w2 = (_rand((16, 24), 42) / 5).to(dtype), (_rand((8, 24), 43) / 5).to(dtype)
+    b1 = _rand((16,), 44)
+    got = ops.linear(x.to(DEV), w1.to(DEV), b1.to(DEV), pre_act="silu")
+    _check(got, F.linear(F.silu(x.double()), w1.double(), b1.double()), dtype, "linear")
+    wa, wb = w1.to(DEV), w2.to(DEV)
+    packed = ops.packed_cat_weight([wa, wb], dtype)
+    got2 = ops.conv(x.to(DEV), None, None, kernel=1, packed=packed, cout=24)
+    _check(got2, F.linear(x.double(), torch.cat([w1, w2]).double()), dtype, "stacked linear")
+    got3 = ops.linear(x[0].to(DEV), w1.to(DEV), None)
+    _check(got3, F.linear(x[0].double(), w1.double()), dtype, "2-D linear")
+
+
+ATTN_CASES = [  # B, heads, Lq, Lk, dh
+    (2, 1, 64, 64, 8), (1, 2, 100, 100, 16), (1, 1, 300, 300, 64), (2, 4, 50, 3, 4), (1, 1, 130, 77, 32),
+    (1, 1, 200, 200, 128), (1, 1, 96, 160, 256), (1, 3, 65, 65, 40),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[f"B{c[0]}H{c[1]}q{c[2]}k{c[3]}d{c[4]}" for c in ATTN_CASES])
+def test_attention(case, dtype):
+    ops = _ops()
+    b, h, lq, lk, dh = case
+    c = h * dh
+    q, k, v = _rand((b, lq, c), 51).to(dtype), _rand((b, lk, c), 52).to(dtype), _rand((b, lk, c), 53).to(dtype)
+    res = _rand((b, lq, c), 54).to(dtype)
+    scale = 1 / math.sqrt(dh)
+    want = R._mha(q.double(), k.double(), v.double(), h, scale) + res.double()
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), h, scale, res=res.to(DEV))
+    _check(got, want, dtype, "attention")
+    # q/k/v as channel slices of one stacked projection buffer (how the blocks call it)
+    if lq == lk:
+        qkv = torch.cat([q, k, v], dim=-1).to(DEV)
+        got2 = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], h, scale)
+        _check(got2, want - res.double(), dtype, "attention (sliced qkv)")
+
+
+def test_attention_softmax_is_stable_for_large_scores():
+    ops = _ops()
+    q = _rand((1, 70, 32), 61) * 30
+    k = _rand((1, 90, 32), 62) * 30
+    v = _rand((1, 90, 32), 63)
+    want = R._mha(q.double(), k.double(), v.double(), 1, 1.0)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 1, 1.0)
+    _check(got, want, torch.float32, "attention large scores", extra=5.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_elementwise_kernels(dtype):
+    ops = _ops()
+    x = _rand((2, 5, 6, 7, 12), 71).to(dtype)  # arena layout
+    up = ops.resample2x(x.to(DEV), "up").cpu()
+    xc = x.permute(0, 4, 1, 2, 3).float()
+    assert torch.equal(up.permute(0, 4, 1, 2, 3).float(), F.interpolate(xc, scale_factor=2.0, mode="nearest"))
+    x2 = _rand((2, 4, 6, 8, 12), 72).to(dtype)
+    dn = ops.resample2x(x2.to(DEV), "down").cpu().permute(0, 4, 1, 2, 3)
+    _check(dn, F.avg_pool3d(x2.permute(0, 4, 1, 2, 3).double(), 2), dtype, "avgpool")
+    x2d = _rand((2, 6, 8, 5), 73).to(dtype)
+    dn2 = ops.resample2x(x2d.to(DEV), "down").cpu().permute(0, 3, 1, 2)
+    _check(dn2, F.avg_pool2d(x2d.permute(0, 3, 1, 2).double(), 2), dtype, "avgpool2d")
+    g = _rand((3, 11, 16), 74).to(dtype)
+    a, gate = g.double().chunk(2, dim=-1)
+    _check(ops.geglu(g.to(DEV)), a * F.gelu(gate), dtype, "geglu")
+    ln_w, ln_b = _rand((16,), 75) * 0.1 + 1, _rand((16,), 76) * 0.1
+    _check(ops.layernorm(g.to(DEV), ln_w.to(DEV), ln_b.to(DEV), 1e-5), F.layer_norm(g.double(), (16,), ln_w.double(), ln_b.double(), 1e-5),
+           dtype, "layernorm", extra=2.0)
+    mu, lv, eps = _rand((2, 3, 4, 4), 77).to(dtype), (_rand((2, 3, 4, 4), 78) * 20).to(dtype), _rand((2, 3, 4, 4), 79).to(dtype)
+    sig, z = ops.aekl_sample(mu.to(DEV), lv.to(DEV), eps.to(DEV))
+    want_sig = torch.exp(torch.clamp(lv.double(), -30, 20) / 2)
+    assert ((sig.cpu().double() - want_sig).abs() / want_sig).max().item() < (1e-5 if dtype == torch.float32 else 1e-2)
+    if dtype == torch.float32:
+        assert torch.equal(ops.addcmul(mu.to(DEV), eps.to(DEV), sig).cpu(), mu + eps * sig.cpu())
+        assert torch.equal(ops.scale(mu.to(DEV), 0.7, divide=True).cpu(), mu / 0.7)
+        assert torch.equal(ops.scale(mu.to(DEV), 0.7).cpu(), mu * 0.7)
+
+
+def test_timestep_embedding_matches_oracle():
+    ops = _ops()
+    t = torch.tensor([980.0, 20.0, 0.0, 500.0])
+    for dim in (32, 33, 256):
+        got = ops.timestep_embedding(t.to(DEV), dim).cpu()
+        want = R.timestep_embedding(t, dim)
+        assert (got - want).abs().max().item() < 2e-4, dim  # fp32 sin/cos of arguments up to ~1e3: a few ulp of the argument
+
+
+def test_vq_argmin_and_gather():
+    ops = _ops()
+    fx = load_fixture("vqvae3d")
+    sd, o = fx["state_dict"], fx["outputs"]
+    emb = sd["quantizer.quantizer.embedding.weight"]
+    za = _cl(o["z"])
+    idx = ops.vq_argmin(za, emb.to(DEV))
+    assert torch.equal(idx.cpu(), o["indices"])  # integer work: bit-exact against the unmodified reference
+    q, mse = ops.vq_gather(idx, emb.to(DEV), torch.float32, za)
+    # the reference returns x + (q - x) (straight-through form): equal to the code vector up to one fp32 rounding
+    assert (_cf(q) - o["quantized"]).abs().max().item() <= 1e-6
+    assert abs(0.25 * mse.item() - o["loss"].item()) < 1e-6

@@ -1,0 +1,230 @@
+"""GPU (-m gpu): the drop-in modules (DiffusionModelUNet, AutoencoderKL, VQVAE, schedulers, inferers) against
+
+  (1) golden outputs of the UNMODIFIED reference (tests/golden/*.pt, produced by oracle/make_golden.py), and
+  (2) the CPU oracle (oracle/restatement.py) on fresh seeded inputs, incl. a free-running DDIM chain and a seeded DDPM chain.
+
+fp32 tolerance: max|err| <= 1e-4 * max(1, |ref|_inf) (the reference's own fp32-vs-fp64 noise is 1.2e-5).
+bf16 tolerance (vs the fp32 reference): mean|err| <= 2e-2 * sigma and max|err| <= 0.2 * sigma."""
+import pytest
+import torch
+
+import restatement as R
+from _util import cast_sd, load_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _nets():
+    from generativemodels_amd.networks import nets
+    return nets
+
+
+def _fp32_close(got, want, what, factor=1.0):
+    got, want = got.double().cpu(), want.double().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    tol = 1e-4 * max(1.0, want.abs().max().item()) * factor
+    err = (got - want).abs().max().item()
+    assert err <= tol, f"{what}: max|err| {err:.3e} > {tol:.3e}"
+
+
+def _bf16_close(got, want, what):
+    got, want = got.double().cpu(), want.double().cpu()
+    sigma = max(want.std().item(), 1e-3)
+    err = (got - want).abs()
+    assert err.mean().item() <= 2e-2 * sigma and err.max().item() <= 0.2 * sigma, \
+        f"{what}: mean|err| {err.mean().item():.3e}, max|err| {err.max().item():.3e}, sigma {sigma:.3e}"
+
+
+def _dev(x):
+    return None if x is None else x.to(DEV)
+
+
+UNETS = ["unet2d_c1a", "unet3d_c1a", "unet2d_c1b", "unet3d_c2mini", "unet2d_cond", "unet3d_cond"]
+
+
+def _build_unet(fx, dtype=torch.float32):
+    m = _nets().DiffusionModelUNet(**fx["cfg"]).eval()
+    m.load_state_dict(fx["state_dict"], strict=True)
+    return m.to(DEV, dtype)
+
+
+@pytest.mark.parametrize("name", UNETS)
+def test_unet_fp32_matches_reference_golden(name):
+    fx = load_fixture(name)
+    i = fx["inputs"]
+    m = _build_unet(fx)
+    y = m(_dev(i["x"]), _dev(i["timesteps"]), context=_dev(i["context"]), class_labels=_dev(i["class_labels"]))
+    _fp32_close(y, fx["outputs"]["y"], name)
+    # (1,)-shaped shared timestep broadcasts over the batch exactly like `sample` does (inferer.py:129,133)
+    if i["x"].shape[0] > 1 and i["class_labels"] is None:
+        t1 = i["timesteps"][:1]
+        with torch.no_grad():
+            want = R.unet_forward(fx["state_dict"], fx["cfg"], i["x"], t1, i["context"], None)
+        _fp32_close(m(_dev(i["x"]), _dev(t1), context=_dev(i["context"])), want, name + " shared timestep")
+
+
+@pytest.mark.parametrize("name", ["unet3d_c2mini", "unet2d_c1b", "unet3d_cond"])
+def test_unet_bf16_close_to_fp32_reference(name):
+    fx = load_fixture(name)
+    i = fx["inputs"]
+    m = _build_unet(fx, torch.bfloat16)
+    ctx = None if i["context"] is None else i["context"].bfloat16()
+    y = m(_dev(i["x"].bfloat16()), _dev(i["timesteps"]), context=_dev(ctx), class_labels=_dev(i["class_labels"]))
+    assert y.dtype == torch.bfloat16
+    _bf16_close(y, fx["outputs"]["y"], name)
+
+
+def test_unet_forward_errors_match_reference():
+    fx = load_fixture("unet2d_c1a")
+    m = _build_unet(fx)
+    x = _dev(fx["inputs"]["x"])
+    with pytest.raises(ValueError):
+        m(x, torch.zeros((2, 1), device=DEV))  # timesteps must be 1-D (diffusion_model_unet.py:471-472)
+    with pytest.raises(ValueError):
+        m(x, _dev(fx["inputs"]["timesteps"]), context=torch.zeros((2, 1, 3), device=DEV))  # context without conditioning
+    with pytest.raises(RuntimeError):
+        m(fx["inputs"]["x"], fx["inputs"]["timesteps"])  # CPU tensors: no fallback
+    fxc = load_fixture("unet2d_cond")
+    mc = _build_unet(fxc)
+    with pytest.raises(ValueError):
+        mc(_dev(fxc["inputs"]["x"]), _dev(fxc["inputs"]["timesteps"]), context=_dev(fxc["inputs"]["context"]))  # class_labels
+
+
+@pytest.mark.parametrize("name", ["aekl2d", "aekl3d_brainlike", "aekl3d_convT"])
+def test_autoencoderkl_matches_reference_golden(name):
+    fx = load_fixture(name)
+    m = _nets().AutoencoderKL(**fx["cfg"]).eval()
+    m.load_state_dict(fx["state_dict"], strict=True)
+    m = m.to(DEV)
+    x, o = fx["inputs"]["x"], fx["outputs"]
+    mu, sigma = m.encode(_dev(x))
+    _fp32_close(mu, o["z_mu"], "z_mu")
+    _fp32_close(sigma, o["z_sigma"], "z_sigma")
+    _fp32_close(m.decode(_dev(o["z_mu"])), o["reconstruction"], "reconstruction")
+    _fp32_close(m.reconstruct(_dev(x)), o["reconstruction"], "reconstruct", factor=2.0)
+    rec, mu2, sg2 = m(_dev(x))
+    assert rec.shape == o["reconstruction"].shape and torch.equal(mu2, mu) and torch.equal(sg2, sigma)
+    z = m.encode_stage_2_inputs(_dev(x))
+    assert z.shape == mu.shape and torch.isfinite(z).all()
+    # sampling() = mu + eps * sigma with eps ~ N(0, 1): with sigma = 0 it must return mu exactly
+    assert torch.equal(m.sampling(mu, torch.zeros_like(sigma)), mu)
+    mb = _nets().AutoencoderKL(**fx["cfg"]).eval()
+    mb.load_state_dict(fx["state_dict"])
+    mb = mb.to(DEV, torch.bfloat16)
+    _bf16_close(mb.decode(_dev(o["z_mu"].bfloat16())), o["reconstruction"], "bf16 reconstruction")
+
+
+@pytest.mark.parametrize("name", ["vqvae3d", "vqvae2d_odd"])
+def test_vqvae_matches_reference_golden(name):
+    fx = load_fixture(name)
+    m = _nets().VQVAE(**fx["cfg"]).eval()
+    m.load_state_dict(fx["state_dict"], strict=True)
+    m = m.to(DEV)
+    x, o = fx["inputs"]["x"], fx["outputs"]
+    _fp32_close(m.encode(_dev(x)), o["z"], "z")
+    q, loss = m.quantize(_dev(o["z"]))
+    _fp32_close(q, o["quantized"], "quantized")
+    assert abs(loss.item() - o["loss"].item()) <= 1e-6
+    assert torch.equal(m.quantizer.quantize(_dev(o["z"])).cpu(), o["indices"])
+    assert torch.equal(m.index_quantize(_dev(x)).cpu(), o["indices"])  # integer work: bit-exact
+    _fp32_close(m.decode(_dev(o["quantized"])), o["reconstruction"], "reconstruction")
+    _fp32_close(m.decode_samples(_dev(o["indices"])), o["reconstruction"], "decode_samples")
+    rec, l2 = m(_dev(x))
+    _fp32_close(rec, o["reconstruction"], "forward")
+    assert abs(l2.item() - o["loss"].item()) <= 1e-6
+    assert float(m.quantizer.perplexity) > 1.0
+
+
+def test_ddim_chain_free_running_matches_reference():
+    """10-step free-running DDIM chain (clip_sample=False) of the literal reference test model; the reference's own fp32
+    self-noise on this chain is ~2e-5 * scale (tests/test_oracle_golden.py)."""
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.schedulers import DDIMScheduler
+    fx = load_fixture("chain_c1a3d")
+    m = _build_unet(fx)
+    sched = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    sched.set_timesteps(10)
+    for graph in (False, True):
+        inf = DiffusionInferer(sched, use_hip_graph=graph)
+        out, inter = inf.sample(_dev(fx["noise"]), m, sched, save_intermediates=True, intermediate_steps=100, verbose=False)
+        _fp32_close(out, fx["ddim_out"], f"ddim chain (graph={graph})", factor=2.0)
+        assert len(inter) == len(fx["ddim_inter"])
+        for a, b in zip(inter, fx["ddim_inter"]):
+            _fp32_close(a, b, "ddim intermediate", factor=2.0)
+
+
+def test_ddpm_chain_with_seeded_cpu_noise_matches_reference():
+    """DDPM draws its noise from the global CPU generator (ddpm.py:244-247): same seed => same chain as the reference."""
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.schedulers import DDPMScheduler
+    fx = load_fixture("chain_c1a3d")
+    m = _build_unet(fx)
+    sched = DDPMScheduler(num_train_timesteps=10)
+    sched.set_timesteps(10)
+    torch.manual_seed(fx["ddpm_global_seed"])
+    out, inter = DiffusionInferer(sched).sample(_dev(fx["noise"]), m, sched, save_intermediates=True, intermediate_steps=1, verbose=False)
+    assert len(inter) == len(fx["ddpm_inter"]) == 10
+    _fp32_close(out, fx["ddpm_out"], "ddpm chain", factor=5.0)  # clip_sample=True chain: clamps amplify rounding at the knees
+    pred = DiffusionInferer(sched)(inputs=_dev(fx["call_inputs"]), diffusion_model=m, noise=_dev(fx["noise"]),
+                                   timesteps=_dev(fx["call_timesteps"]))
+    _fp32_close(pred, fx["call_prediction"], "inferer __call__")
+
+
+def test_inferer_concat_mode_and_errors():
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.schedulers import DDIMScheduler
+    cfg = dict(spatial_dims=2, in_channels=2, out_channels=1, num_channels=[8], norm_num_groups=8, attention_levels=[True],
+               num_res_blocks=1, num_head_channels=8)
+    torch.manual_seed(0)
+    m = _nets().DiffusionModelUNet(**cfg).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    R.derandomize_zeros(sd)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    sched = DDIMScheduler(1000, clip_sample=False)
+    sched.set_timesteps(4)
+    noise = torch.randn((2, 1, 8, 8), generator=torch.Generator().manual_seed(3))
+    cond = torch.randn((2, 1, 8, 8), generator=torch.Generator().manual_seed(4))
+    inf = DiffusionInferer(sched)
+    out = inf.sample(_dev(noise), m, sched, conditioning=_dev(cond), mode="concat", verbose=False)
+    want = R.ddim_sample(sd, cfg, noise, dict(alphas_cumprod=sched.alphas_cumprod, num_train_timesteps=1000, num_inference_steps=4,
+                                              timesteps=sched.timesteps, clip_sample=False), conditioning=cond, mode="concat")
+    _fp32_close(out, want, "concat-mode chain", factor=2.0)
+    with pytest.raises(NotImplementedError):
+        inf.sample(_dev(noise), m, sched, mode="film", verbose=False)
+    with pytest.raises(NotImplementedError):
+        inf(inputs=_dev(noise), diffusion_model=m, noise=_dev(noise), timesteps=torch.tensor([1, 2]), mode="film")
+
+
+def test_latent_diffusion_inferer_sample_and_call():
+    from generativemodels_amd.inferers import LatentDiffusionInferer
+    from generativemodels_amd.networks.schedulers import DDIMScheduler
+    fxa = load_fixture("aekl3d_brainlike")
+    ae = _nets().AutoencoderKL(**fxa["cfg"]).eval()
+    ae.load_state_dict(fxa["state_dict"])
+    ae = ae.to(DEV)
+    ucfg = dict(spatial_dims=3, in_channels=4, out_channels=4, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1,
+                norm_num_groups=8, num_head_channels=(0, 16))
+    torch.manual_seed(1)
+    un = _nets().DiffusionModelUNet(**ucfg).eval()
+    usd = {k: v.clone() for k, v in un.state_dict().items()}
+    R.derandomize_zeros(usd)
+    un.load_state_dict(usd)
+    un = un.to(DEV)
+    sched = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205, clip_sample=False)
+    sched.set_timesteps(3)
+    noise = torch.randn((1, 4, 4, 4, 4), generator=torch.Generator().manual_seed(9))
+    inf = LatentDiffusionInferer(sched, scale_factor=0.8)
+    img = inf.sample(_dev(noise), ae, un, sched, verbose=False)
+    lat = R.ddim_sample(usd, ucfg, noise, dict(alphas_cumprod=sched.alphas_cumprod, num_train_timesteps=1000, num_inference_steps=3,
+                                               timesteps=sched.timesteps, clip_sample=False))
+    with torch.no_grad():
+        want = R.aekl_decode(fxa["state_dict"], fxa["cfg"], lat / 0.8)
+    _fp32_close(img, want, "latent sample", factor=2.0)
+    x = fxa["inputs"]["x"]
+    pred = inf(inputs=_dev(x), autoencoder_model=ae, diffusion_model=un, noise=_dev(torch.randn_like(noise)),
+               timesteps=torch.tensor([5], device=DEV))
+    assert tuple(pred.shape) == (1, 4, 2, 2, 2) or pred.shape[1] == 4
+    with pytest.raises(ValueError):
+        LatentDiffusionInferer(sched, ldm_latent_shape=[4, 4, 4])

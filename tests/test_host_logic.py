@@ -1,0 +1,165 @@
+"""CPU (-m "not gpu"): host-side logic of the drop-in layer -- constructor contracts, state_dict key parity with the
+reference (via the committed golden fixtures), scheduler tables / timesteps (bit-exact vs the reference goldens), the
+ComponentStore plugin point, and the fail-loudly behaviour without a GPU. No kernel is launched here."""
+import pytest
+import torch
+
+from _util import load_fixture
+from generativemodels_amd.inferers import DiffusionInferer, LatentDiffusionInferer
+from generativemodels_amd.networks.nets import VQVAE, AutoencoderKL, DiffusionModelUNet
+from generativemodels_amd.networks.schedulers import DDIMScheduler, DDPMScheduler, NoiseSchedules
+from generativemodels_amd.utils import ComponentStore, unsqueeze_left, unsqueeze_right
+
+KINDS = {"unet": DiffusionModelUNet, "aekl": AutoencoderKL, "vqvae": VQVAE}
+FIXTURES = ["unet2d_c1a", "unet3d_c1a", "unet2d_c1b", "unet3d_c2mini", "unet2d_cond", "unet3d_cond", "aekl2d", "aekl3d_brainlike",
+            "aekl3d_convT", "vqvae3d", "vqvae2d_odd"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_state_dict_keys_and_shapes_match_reference(name):
+    fx = load_fixture(name)
+    m = KINDS[fx["kind"]](**fx["cfg"])
+    ours = m.state_dict()
+    ref = fx["state_dict"]
+    assert set(ours.keys()) == set(ref.keys())
+    for k in ref:
+        assert tuple(ours[k].shape) == tuple(ref[k].shape), k
+    m.load_state_dict(ref, strict=True)
+
+
+def test_fresh_unet_has_the_reference_zero_initialised_layers():
+    m = DiffusionModelUNet(2, 1, 1, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1, norm_num_groups=8,
+                           with_conditioning=True, cross_attention_dim=4)
+    sd = m.state_dict()
+    zeros = [k for k, v in sd.items() if v.is_floating_point() and v.abs().max() == 0]
+    assert "out.2.conv.weight" in zeros and "down_blocks.0.resnets.0.conv2.conv.weight" in zeros
+    assert "down_blocks.1.attentions.0.proj_out.conv.weight" in zeros
+    assert "down_blocks.0.resnets.0.conv1.conv.weight" not in zeros
+
+
+def test_unet_constructor_errors():
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, with_conditioning=True, cross_attention_dim=None)
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, with_conditioning=False, cross_attention_dim=3)
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, num_channels=(8, 12), attention_levels=(False, False), num_res_blocks=1, norm_num_groups=8)
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, num_channels=(8, 8, 8), attention_levels=(False, False), num_res_blocks=1, norm_num_groups=8)
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, num_channels=(8, 8), attention_levels=(False, False), num_res_blocks=(1, 1, 1), norm_num_groups=8)
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, num_channels=(8, 8), attention_levels=(False, True), num_res_blocks=1, norm_num_groups=8,
+                           num_head_channels=(4, 4, 4))
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, num_channels=(8, 8), attention_levels=(False, False), num_res_blocks=1, norm_num_groups=8,
+                           dropout_cattn=3.0)
+    with pytest.raises(ValueError):  # default 4-tuples do not fit a 2-level model
+        DiffusionModelUNet(2, 1, 1, num_channels=(8, 8), attention_levels=(False, False), norm_num_groups=8)
+
+
+def test_autoencoder_and_vqvae_constructor_errors():
+    with pytest.raises(ValueError):
+        AutoencoderKL(2, num_channels=(24, 24, 24), attention_levels=(False, False, False), num_res_blocks=1, norm_num_groups=16)
+    with pytest.raises(ValueError):
+        AutoencoderKL(2, num_channels=(8, 8, 8), attention_levels=(False, False), num_res_blocks=1, norm_num_groups=8)
+    with pytest.raises(ValueError):
+        AutoencoderKL(2, num_channels=(8, 8, 8), attention_levels=(False, False, False), num_res_blocks=(1, 1), norm_num_groups=8)
+    with pytest.raises(ValueError):
+        VQVAE(2, 1, 1, num_channels=(8, 16), num_res_channels=(8, 16, 16), downsample_parameters=((2, 4, 1, 1),) * 2,
+              upsample_parameters=((2, 4, 1, 1, 0),) * 2)
+    with pytest.raises(ValueError):
+        VQVAE(2, 1, 1, num_channels=(8, 16), num_res_channels=(8, 16), downsample_parameters=((2, 4, 1),) * 2,
+              upsample_parameters=((2, 4, 1, 1, 0),) * 2)
+    with pytest.raises(ValueError):
+        VQVAE(2, 1, 1, num_channels=(8, 16), num_res_channels=(8, 16), downsample_parameters=((2, 4, 1, 1),) * 2,
+              upsample_parameters=((2, 4, 1, 1),) * 2)
+    with pytest.raises(ValueError):
+        VQVAE(2, 1, 1, num_channels=(8, 16), num_res_channels=(8, 16), downsample_parameters=((2, 4, 1, 1),) * 3,
+              upsample_parameters=((2, 4, 1, 1, 0),) * 2)
+    v = VQVAE(3, 1, 1, num_channels=(8, 16), num_res_channels=8, downsample_parameters=(2, 4, 1, 1), upsample_parameters=(2, 4, 1, 1, 0),
+              num_res_layers=1, num_embeddings=16, embedding_dim=8)
+    assert "quantizer.quantizer.ema_w" in v.state_dict()
+
+
+def test_scheduler_tables_timesteps_and_errors():
+    fx = load_fixture("schedulers")
+    for sname, e in fx["tables"].items():
+        d = DDIMScheduler(1000, schedule=sname, **e["kw"])
+        assert torch.equal(d.betas, e["betas"]) and torch.equal(d.alphas, e["alphas"]) and torch.equal(d.alphas_cumprod, e["alphas_cumprod"])
+        d.set_timesteps(50)
+        assert torch.equal(d.timesteps, e["timesteps50"])
+        p = DDPMScheduler(1000, schedule=sname, **e["kw"])
+        assert torch.equal(p.alphas_cumprod, e["alphas_cumprod"])
+    d = DDIMScheduler(1000, steps_offset=1)
+    d.set_timesteps(100)
+    assert len(d.timesteps) == 100 and int(d.timesteps[-1]) == 1
+    p = DDPMScheduler(1000)
+    p.set_timesteps(100)
+    assert len(p.timesteps) == 100 and int(p.timesteps[0]) == 990
+    for cls in (DDIMScheduler, DDPMScheduler):
+        with pytest.raises(ValueError):
+            cls(10).set_timesteps(11)
+        with pytest.raises(ValueError):
+            cls(prediction_type="nope")
+        with pytest.raises(ValueError):
+            cls(clip_sample_min=1, clip_sample_max=1)
+    with pytest.raises(ValueError):
+        DDPMScheduler(variance_type="nope")
+    with pytest.raises(ValueError):
+        DDIMScheduler(schedule="not_registered")
+    assert float(DDIMScheduler(set_alpha_to_one=False).final_alpha_cumprod) == float(DDIMScheduler().alphas_cumprod[0])
+
+
+def test_user_registered_noise_schedule_feeds_the_scheduler():
+    name = "halfway_test_schedule"
+    if name not in NoiseSchedules:
+        @NoiseSchedules.add_def(name, "test schedule")
+        def _sched(num_train_timesteps, level=0.5):
+            """constant beta"""
+            return torch.full((num_train_timesteps,), level)
+    s = DDPMScheduler(20, schedule=name, level=0.25)
+    assert torch.allclose(s.alphas_cumprod, torch.cumprod(torch.full((20,), 0.75), 0))
+
+
+def test_component_store_contract():
+    st = ComponentStore("T", "desc")
+    st.add("a", "first", 1)
+    with pytest.raises(ValueError):
+        st.add("not valid!", "x", 2)
+    with pytest.raises(ValueError):
+        st["missing"]
+    assert "a" in st and len(st) == 1 and st.a == 1 and list(st) == [("a", 1)] and "Component Store 'T'" in str(st)
+    x = torch.zeros(3)
+    assert unsqueeze_right(x, 3).shape == (3, 1, 1) and unsqueeze_left(x, 3).shape == (1, 1, 3)
+
+
+def test_inferer_argument_checks_and_no_cpu_fallback():
+    s = DDIMScheduler(10)
+    with pytest.raises(ValueError):
+        LatentDiffusionInferer(s, ldm_latent_shape=[4, 4], autoencoder_latent_shape=None)
+    inf = DiffusionInferer(s)
+    x = torch.zeros(1, 1, 8, 8)
+    with pytest.raises(NotImplementedError):
+        inf.sample(x, lambda *a, **k: x, s, mode="bad", verbose=False)
+    m = DiffusionModelUNet(2, 1, 1, num_channels=[8], norm_num_groups=8, attention_levels=[True], num_res_blocks=1, num_head_channels=8)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(x, torch.tensor([1]))  # CPU tensors are refused: there is no eager fallback
+    with pytest.raises(RuntimeError, match="MI355X"):
+        s.step(x, 5, x)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        s.add_noise(x, x, torch.tensor([1]))
+
+
+def test_install_as_generative_aliases_the_reference_import_paths():
+    import subprocess
+    import sys
+    code = ("import generativemodels_amd as g; g.install_as_generative(); "
+            "from generative.networks.nets import DiffusionModelUNet, AutoencoderKL, VQVAE; "
+            "from generative.networks.schedulers import DDIMScheduler, DDPMScheduler; "
+            "from generative.inferers import DiffusionInferer, LatentDiffusionInferer; "
+            "from generative.networks.layers import VectorQuantizer; print('ok')")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr
