@@ -19,6 +19,25 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
 
+def hip_runtime_library() -> str:
+    """The HIP runtime the library is linked against. It MUST be the one the host framework uses: kernels are enqueued on the
+    caller's hipStream_t, which only means something inside the same runtime instance. PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (without a SONAME), so linking the system copy would silently put a second runtime -- with its own queues,
+    unordered against torch's -- into the process. Override with GM_HIP_RUNTIME=/path/to/libamdhip64.so for other hosts."""
+    env = os.environ.get("GM_HIP_RUNTIME")
+    if env:
+        return env
+    try:
+        import torch
+
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            return cand
+    except Exception:  # pragma: no cover
+        pass
+    return "/opt/rocm/lib/libamdhip64.so"
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -54,7 +73,9 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if force or _stale(LIBPATH, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIBPATH]
+        rt = hip_runtime_library()
+        linker = shutil.which("g++") or shutil.which("c++") or _hipcc()
+        cmd = [linker, "-shared", "-fPIC", *objs, "-o", LIBPATH, rt, f"-Wl,-rpath,{os.path.dirname(rt)}", "-Wl,--enable-new-dtags"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

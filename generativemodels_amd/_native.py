@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
     """The loaded C-ABI library. Raises NativeLibraryError (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  loads the HIP runtime the library shares with the host framework (see _build.hip_runtime_library)
+
         if not os.path.exists(LIB_PATH):
             raise NativeLibraryError(
                 f"{LIB_PATH} is missing: build it with `python -m generativemodels_amd._build` (hipcc, gfx950). "
