@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libgmamd.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "attention.hip", "vq.hip"]
+SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "conv_fast.hip", "attention.hip", "vq.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
@@ -55,7 +55,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 def _compile(src: str) -> str:
     obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
     srcp = os.path.join(CSRC, src)
-    deps = [srcp, os.path.join(CSRC, "gm_common.h")]
+    deps = [srcp] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     if _stale(obj, deps):
         cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -19,94 +19,7 @@
 // bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses v_mfma_f32_16x16x4_f32 (exact fp32 products; the parity path).
 #include "gm_common.h"
 
-struct GmConvDesc {
-  const void* x; long long x_ld;
-  const void* w;                  // packed by gm_pack_conv_weight: [chunk][tap][Cout_pad][BK]
-  const float* bias;              // [Cout] or null
-  const float* pre_scale;         // [N][Cin] or null
-  const float* pre_shift;         // [N][Cin] or null
-  const float* rowvec;            // [B][Cout] fp32 or null, added per (n, cout)
-  long long rowvec_bstride;       // 0 -> broadcast one row over the batch
-  const void* res; long long res_ld;  // residual in output geometry or null
-  void* y; long long y_ld;
-  int N, Cin, Cout;
-  int Ds, Hs, Ws;                 // stored input dims
-  int Do, Ho, Wo;
-  int kd, kh, kw;
-  int sd, sh, sw;
-  int pd, ph, pw;                 // low-side padding (high side is implied by the output size)
-  int dd, dh, dw;                 // dilation
-  int in_mode;                    // 0 direct, 1 nearest up-sample by (fd,fh,fw), 2 zero-insertion by (fd,fh,fw)
-  int fd, fh, fw;
-  int pre_act;                    // 0 none, 1 SiLU, 2 ReLU (applied after the optional affine)
-  int post_act;                   // 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01)
-  int dtype;
-  int ltd, lth, ltw;              // log2 of the output tile dims
-  int cfg;                        // tile configuration id (see dispatch)
-};
-
-#define CONV_ROWB 80  // LDS row pitch in bytes: 64 B of operands + 16 B pad
-
-template <typename T> struct ConvTraits;
-template <> struct ConvTraits<bf16_raw> { static constexpr int BK = 32; static constexpr int VECW = 8; };
-template <> struct ConvTraits<float> { static constexpr int BK = 16; static constexpr int VECW = 4; };
-
-__device__ __forceinline__ float conv_act(float v, int act, bool precise) {
-  switch (act) {
-    case 1: return precise ? gm_silu_precise(v) : gm_silu(v);
-    case 2: return fmaxf(v, 0.f);
-    default: return v;
-  }
-}
-__device__ __forceinline__ float conv_post_act(float v, int act) {
-  switch (act) {
-    case 1: return fmaxf(v, 0.f);
-    case 2: return tanhf(v);
-    case 3: return 1.0f / (1.0f + expf(-v));
-    case 4: return gm_silu_precise(v);
-    case 5: return v > 0.f ? v : 0.01f * v;
-    default: return v;
-  }
-}
-
-// 16-byte operand vector <-> 4/8 floats
-template <typename T> struct Vec16;
-template <> struct Vec16<float> {
-  static __device__ __forceinline__ void unpack(const uint4& v, float* o) {
-    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
-  }
-  static __device__ __forceinline__ uint4 pack(const float* o) {
-    return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
-  }
-};
-template <> struct Vec16<bf16_raw> {
-  static __device__ __forceinline__ void unpack(const uint4& v, float* o) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-  }
-  static __device__ __forceinline__ uint4 pack(const float* o) {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
-    return make_uint4(w[0], w[1], w[2], w[3]);
-  }
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_raw> {
-  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-  }
-};
+#include "conv_common.h"
 
 template <typename T, int WM, int WN, int MF, int NFR>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const GmConvDesc p) {
@@ -359,7 +272,25 @@ static const ConvCfg kCfgs[] = {
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
+// fast stride-1 path (conv_fast.hip): cfg 5 = 256 voxels x 64 channels, cfg 6 = 256 voxels x 128 channels
+extern "C" long long gm_conv_fast_lds_bytes(const GmConvDesc* d, int bn);
+extern "C" long long gm_conv_fast_max_patch(int wn);
+extern "C" int gm_conv_fast_launch(const GmConvDesc* dp, int wn, unsigned nblocks, void* stream);
+#define CONV_CFG_FAST64 5
+#define CONV_CFG_FAST128 6
+
+static bool conv_fast_eligible(const GmConvDesc& d) {
+  const int vecw = d.dtype == GM_F32 ? 4 : 8;
+  const long long td = 1 << d.ltd, th = 1 << d.lth, tw = 1 << d.ltw;
+  const long long P = (td + d.kd - 1) * (th + d.kh - 1) * (tw + d.kw - 1);
+  return d.sd == 1 && d.sh == 1 && d.sw == 1 && d.dd == 1 && d.dh == 1 && d.dw == 1 && (d.in_mode == 0 || d.in_mode == 1) &&
+         d.Cin % vecw == 0 && d.x_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d.x) & 15) == 0 &&
+         P <= gm_conv_fast_max_patch(d.cfg == CONV_CFG_FAST64 ? 1 : 2) &&
+         (long long)d.N * d.Ds * d.Hs * d.Ws < (1LL << 31);
+}
+
 extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
+  if (cfg == CONV_CFG_FAST64 || cfg == CONV_CFG_FAST128) { *bm = 256; *bn = cfg == CONV_CFG_FAST64 ? 64 : 128; return 0; }
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
   *bm = kCfgs[cfg].WM * kCfgs[cfg].MF * 16;
   *bn = kCfgs[cfg].WN * kCfgs[cfg].NFR * 16;
@@ -393,6 +324,10 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
+  if (d && (d->cfg == CONV_CFG_FAST64 || d->cfg == CONV_CFG_FAST128)) {
+    if (!conv_fast_eligible(*d)) return -1;
+    return gm_conv_fast_lds_bytes(d, d->cfg == CONV_CFG_FAST64 ? 64 : 128);
+  }
   if (!d || d->cfg < 0 || d->cfg >= kNumCfgs) return -1;
   const int td = 1 << d->ltd, th = 1 << d->lth, tw = 1 << d->ltw;
   const long long pD = (long long)(td - 1) * d->sd + (long long)(d->kd - 1) * d->dd + 1;
@@ -406,15 +341,17 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(dp, "null descriptor");
   const GmConvDesc& d = *dp;
   GM_REQUIRE(d.x && d.w && d.y, "null tensor pointer");
-  GM_REQUIRE(d.cfg >= 0 && d.cfg < kNumCfgs, "bad tile configuration");
+  const bool fast = d.cfg == CONV_CFG_FAST64 || d.cfg == CONV_CFG_FAST128;
+  GM_REQUIRE(fast || (d.cfg >= 0 && d.cfg < kNumCfgs), "bad tile configuration");
   GM_REQUIRE((d.pre_scale == nullptr) == (d.pre_shift == nullptr), "pre_scale and pre_shift go together");
   GM_REQUIRE(d.N >= 0 && d.Cin > 0 && d.Cout > 0, "bad channel / batch count");
   GM_REQUIRE(d.kd > 0 && d.kh > 0 && d.kw > 0 && d.sd > 0 && d.sh > 0 && d.sw > 0 && d.dd > 0 && d.dh > 0 && d.dw > 0, "bad kernel geometry");
   GM_REQUIRE(d.in_mode == 0 || (d.fd > 0 && d.fh > 0 && d.fw > 0), "bad input-mode factors");
   if (d.N == 0 || d.Do == 0 || d.Ho == 0 || d.Wo == 0) return 0;
-  const int bm = kCfgs[d.cfg].WM * kCfgs[d.cfg].MF * 16;
-  const int bn = kCfgs[d.cfg].WN * kCfgs[d.cfg].NFR * 16;
+  int bm = 0, bn = 0;
+  gm_conv_cfg_tile(d.cfg, &bm, &bn);
   GM_REQUIRE((1 << (d.ltd + d.lth + d.ltw)) == bm, "tile dims do not match the configuration");
+  GM_REQUIRE(!fast || conv_fast_eligible(d), "geometry is not eligible for the fast stride-1 kernel");
   const long long smem = gm_conv_lds_bytes(dp);
   GM_REQUIRE(smem > 0 && smem <= 160 * 1024, "tile needs more than 160 KiB of LDS");
   const long long ntd = (d.Do + (1 << d.ltd) - 1) >> d.ltd, nth = (d.Ho + (1 << d.lth) - 1) >> d.lth,
@@ -424,6 +361,11 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(nblocks < (1LL << 31), "grid too large");
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (fast) {
+    rc = gm_conv_fast_launch(dp, d.cfg == CONV_CFG_FAST64 ? 1 : 2, (unsigned)nblocks, stream);
+    GM_REQUIRE(rc == 0, "unsupported dtype");
+    GM_LAUNCH_CHECK();
+  }
   if (d.dtype == GM_F32) rc = dispatch_conv<float>(d, (size_t)smem, nblocks, st);
   else if (d.dtype == GM_BF16) rc = dispatch_conv<bf16_raw>(d, (size_t)smem, nblocks, st);
   else GM_FAIL(-2, "unsupported dtype");

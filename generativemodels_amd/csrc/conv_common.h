@@ -1,0 +1,93 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv.hip: generic geometry; conv_fast.hip: the stride-1 hot path).
+#pragma once
+#include "gm_common.h"
+
+struct GmConvDesc {
+  const void* x; long long x_ld;
+  const void* w;                  // packed by gm_pack_conv_weight: [chunk][tap][Cout_pad][BK]
+  const float* bias;              // [Cout] or null
+  const float* pre_scale;         // [N][Cin] or null
+  const float* pre_shift;         // [N][Cin] or null
+  const float* rowvec;            // [B][Cout] fp32 or null, added per (n, cout)
+  long long rowvec_bstride;       // 0 -> broadcast one row over the batch
+  const void* res; long long res_ld;  // residual in output geometry or null
+  void* y; long long y_ld;
+  int N, Cin, Cout;
+  int Ds, Hs, Ws;                 // stored input dims
+  int Do, Ho, Wo;
+  int kd, kh, kw;
+  int sd, sh, sw;
+  int pd, ph, pw;                 // low-side padding (high side is implied by the output size)
+  int dd, dh, dw;                 // dilation
+  int in_mode;                    // 0 direct, 1 nearest up-sample by (fd,fh,fw), 2 zero-insertion by (fd,fh,fw)
+  int fd, fh, fw;
+  int pre_act;                    // 0 none, 1 SiLU, 2 ReLU (applied after the optional affine)
+  int post_act;                   // 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01)
+  int dtype;
+  int ltd, lth, ltw;              // log2 of the output tile dims
+  int cfg;                        // tile configuration id (see dispatch)
+};
+
+#define CONV_ROWB 80  // LDS row pitch in bytes: 64 B of operands + 16 B pad
+
+template <typename T> struct ConvTraits;
+template <> struct ConvTraits<bf16_raw> { static constexpr int BK = 32; static constexpr int VECW = 8; };
+template <> struct ConvTraits<float> { static constexpr int BK = 16; static constexpr int VECW = 4; };
+
+__device__ __forceinline__ float conv_act(float v, int act, bool precise) {
+  switch (act) {
+    case 1: return precise ? gm_silu_precise(v) : gm_silu(v);
+    case 2: return fmaxf(v, 0.f);
+    default: return v;
+  }
+}
+__device__ __forceinline__ float conv_post_act(float v, int act) {
+  switch (act) {
+    case 1: return fmaxf(v, 0.f);
+    case 2: return tanhf(v);
+    case 3: return 1.0f / (1.0f + expf(-v));
+    case 4: return gm_silu_precise(v);
+    case 5: return v > 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+
+// 16-byte operand vector <-> 4/8 floats
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static __device__ __forceinline__ void unpack(const uint4& v, float* o) {
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* o) {
+    return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+  }
+};
+template <> struct Vec16<bf16_raw> {
+  static __device__ __forceinline__ void unpack(const uint4& v, float* o) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ uint4 pack(const float* o) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_raw> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+

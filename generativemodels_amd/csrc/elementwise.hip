@@ -32,55 +32,47 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const T* __restrict__ s
                                                         const T* __restrict__ noise, T* __restrict__ prev,
                                                         T* __restrict__ x0out, long long inner, long long mo_bstride,
                                                         long long total, GmStepParams p) {
-#pragma clang fp contract(off)
+  // every operation is an explicitly rounded, never-contracted IEEE fp32 op (__f*_rn) in the reference's order
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / inner, r = i - n * inner;
     const float s = ElemIO<T>::ld(sample + i);
     const float m = ElemIO<T>::ld(mo + n * mo_bstride + r);
     float x0, eps;
     if (p.pred_type == 0) {
-      const float t0 = p.c_sb * m;
-      x0 = (s - t0) / p.c_sa;
+      x0 = __fdiv_rn(__fsub_rn(s, __fmul_rn(p.c_sb, m)), p.c_sa);
       eps = m;
     } else if (p.pred_type == 1) {
       x0 = m;
-      const float t0 = p.c_sa * x0;
-      eps = (s - t0) / p.c_sb;
+      eps = __fdiv_rn(__fsub_rn(s, __fmul_rn(p.c_sa, x0)), p.c_sb);
     } else {
-      const float a = p.c_sa * s, b = p.c_sb * m;
-      x0 = a - b;
-      const float c = p.c_sa * m, d = p.c_sb * s;
-      eps = c + d;
+      x0 = __fsub_rn(__fmul_rn(p.c_sa, s), __fmul_rn(p.c_sb, m));
+      eps = __fadd_rn(__fmul_rn(p.c_sa, m), __fmul_rn(p.c_sb, s));
     }
     if (p.clip) x0 = fminf(fmaxf(x0, p.clip_lo), p.clip_hi);
     float out;
     if (p.mode == 0) {
-      const float dir = p.c_dir * eps;
-      const float a = p.c_prev * x0;
-      out = a + dir;
+      const float dir = __fmul_rn(p.c_dir, eps);
+      out = __fadd_rn(__fmul_rn(p.c_prev, x0), dir);
     } else {
-      const float a = p.k0 * x0, b = p.k1 * s;
-      out = a + b;
+      out = __fadd_rn(__fmul_rn(p.k0, x0), __fmul_rn(p.k1, s));
     }
     if (p.noise_mode != 0) {
       const float z = ElemIO<T>::ld(noise + i);
       float v;
       if (p.noise_mode == 1) {
-        v = p.c_noise * z;
+        v = __fmul_rn(p.c_noise, z);
       } else {
         const float pv = ElemIO<T>::ld(mo + n * mo_bstride + inner + r);
         float var;
         if (p.noise_mode == 2) {
           var = pv;
         } else {
-          const float frac = (pv + 1.0f) / 2.0f;
-          const float a = frac * p.max_log;
-          const float b = (1.0f - frac) * p.min_log;
-          var = a + b;
+          const float frac = __fdiv_rn(__fadd_rn(pv, 1.0f), 2.0f);
+          var = __fadd_rn(__fmul_rn(frac, p.max_log), __fmul_rn(__fsub_rn(1.0f, frac), p.min_log));
         }
-        v = sqrtf(var) * z;
+        v = __fmul_rn(__fsqrt_rn(var), z);
       }
-      out = out + v;
+      out = __fadd_rn(out, v);
     }
     ElemIO<T>::st(prev + i, out);
     if (x0out) ElemIO<T>::st(x0out + i, x0);
@@ -123,9 +115,9 @@ __global__ __launch_bounds__(256) void axpby_rows_kernel(const T* __restrict__ x
 #pragma clang fp contract(off)
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / inner;
-    const float u = a[n] * ElemIO<T>::ld(x + i);
-    const float v = b[n] * ElemIO<T>::ld(y + i);
-    ElemIO<T>::st(out + i, u + v);
+    const float u = __fmul_rn(a[n], ElemIO<T>::ld(x + i));
+    const float v = __fmul_rn(b[n], ElemIO<T>::ld(y + i));
+    ElemIO<T>::st(out + i, __fadd_rn(u, v));
   }
 }
 

@@ -375,9 +375,9 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
     elif cout <= 16:
         order = [3, 4, 2]
     elif cout <= 64:
-        order = [0, 4, 2]
+        order = [5, 0, 4, 2]
     else:
-        order = [1, 4, 2]
+        order = [6, 1, 4, 2]
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
         order = [c for c in order if _cfg_tile(c)[0] <= 64] + [c for c in order if _cfg_tile(c)[0] > 64]
     best = None
@@ -385,8 +385,9 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         bm, _ = _cfg_tile(cfg)
         bits = _tile_bits(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
-        lds = lib().gm_conv_lds_bytes(C.byref(desc))
-        if 0 < lds <= LDS_SOFT_LIMIT:
+        lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
+        soft = LDS_HARD_LIMIT if cfg in (5, 6) else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
+        if 0 < lds <= soft:
             return
         if 0 < lds <= LDS_HARD_LIMIT and best is None:
             best = (cfg, bits)
