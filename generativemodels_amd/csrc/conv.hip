@@ -278,6 +278,9 @@ extern "C" long long gm_conv_fast_max_patch(int wn);
 extern "C" int gm_conv_fast_launch(const GmConvDesc* dp, int wn, unsigned nblocks, void* stream);
 #define CONV_CFG_FAST64 5
 #define CONV_CFG_FAST128 6
+#define CONV_CFG_FAST512 7
+static inline bool conv_is_fast(int cfg) { return cfg >= CONV_CFG_FAST64 && cfg <= CONV_CFG_FAST512; }
+static inline int conv_fast_variant(int cfg) { return cfg - CONV_CFG_FAST64 + 1; }
 
 static bool conv_fast_eligible(const GmConvDesc& d) {
   const int vecw = d.dtype == GM_F32 ? 4 : 8;
@@ -285,12 +288,12 @@ static bool conv_fast_eligible(const GmConvDesc& d) {
   const long long P = (td + d.kd - 1) * (th + d.kh - 1) * (tw + d.kw - 1);
   return d.sd == 1 && d.sh == 1 && d.sw == 1 && d.dd == 1 && d.dh == 1 && d.dw == 1 && (d.in_mode == 0 || d.in_mode == 1) &&
          d.Cin % vecw == 0 && d.x_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d.x) & 15) == 0 &&
-         P <= gm_conv_fast_max_patch(d.cfg == CONV_CFG_FAST64 ? 1 : 2) &&
+         P <= gm_conv_fast_max_patch(conv_fast_variant(d.cfg)) &&
          (long long)d.N * d.Ds * d.Hs * d.Ws < (1LL << 31);
 }
 
 extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
-  if (cfg == CONV_CFG_FAST64 || cfg == CONV_CFG_FAST128) { *bm = 256; *bn = cfg == CONV_CFG_FAST64 ? 64 : 128; return 0; }
+  if (conv_is_fast(cfg)) { *bm = cfg == CONV_CFG_FAST512 ? 512 : 256; *bn = cfg == CONV_CFG_FAST128 ? 128 : 64; return 0; }
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
   *bm = kCfgs[cfg].WM * kCfgs[cfg].MF * 16;
   *bn = kCfgs[cfg].WN * kCfgs[cfg].NFR * 16;
@@ -324,9 +327,9 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
-  if (d && (d->cfg == CONV_CFG_FAST64 || d->cfg == CONV_CFG_FAST128)) {
+  if (d && conv_is_fast(d->cfg)) {
     if (!conv_fast_eligible(*d)) return -1;
-    return gm_conv_fast_lds_bytes(d, d->cfg == CONV_CFG_FAST64 ? 64 : 128);
+    return gm_conv_fast_lds_bytes(d, d->cfg == CONV_CFG_FAST128 ? 128 : 64);
   }
   if (!d || d->cfg < 0 || d->cfg >= kNumCfgs) return -1;
   const int td = 1 << d->ltd, th = 1 << d->lth, tw = 1 << d->ltw;
@@ -341,7 +344,7 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(dp, "null descriptor");
   const GmConvDesc& d = *dp;
   GM_REQUIRE(d.x && d.w && d.y, "null tensor pointer");
-  const bool fast = d.cfg == CONV_CFG_FAST64 || d.cfg == CONV_CFG_FAST128;
+  const bool fast = conv_is_fast(d.cfg);
   GM_REQUIRE(fast || (d.cfg >= 0 && d.cfg < kNumCfgs), "bad tile configuration");
   GM_REQUIRE((d.pre_scale == nullptr) == (d.pre_shift == nullptr), "pre_scale and pre_shift go together");
   GM_REQUIRE(d.N >= 0 && d.Cin > 0 && d.Cout > 0, "bad channel / batch count");
@@ -362,7 +365,7 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (fast) {
-    rc = gm_conv_fast_launch(dp, d.cfg == CONV_CFG_FAST64 ? 1 : 2, (unsigned)nblocks, stream);
+    rc = gm_conv_fast_launch(dp, conv_fast_variant(d.cfg), (unsigned)nblocks, stream);
     GM_REQUIRE(rc == 0, "unsupported dtype");
     GM_LAUNCH_CHECK();
   }

@@ -26,6 +26,7 @@ struct GmConvDesc {
   int dtype;
   int ltd, lth, ltw;              // log2 of the output tile dims
   int cfg;                        // tile configuration id (see dispatch)
+  int debug_flags;                // 0 in production; bench-only ablation switches of conv_fast.hip
 };
 
 #define CONV_ROWB 80  // LDS row pitch in bytes: 64 B of operands + 16 B pad
@@ -71,7 +72,7 @@ template <> struct Vec16<bf16_raw> {
   static __device__ __forceinline__ uint4 pack(const float* o) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
     return make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

@@ -75,3 +75,88 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
   const unsigned q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// Coalesced epilogue: each wave transposes its 64-voxel x (NFR*16)-channel accumulator tile through LDS so that every lane
+// ends up with 16 contiguous bytes of one voxel row and a wave-instruction writes eight complete 128-byte row segments
+// (the per-lane-4-channel store of conv_epilogue() wrote 32-byte fragments and cost ~half the kernel time on MI355X).
+// `lds` = this wave's private 64 x 144-byte scratch (the operand buffers are dead after the main loop's last barrier).
+// Requirements (checked by the caller): Cout, y_ld (and res_ld) multiples of 16/sizeof(T), 16-byte aligned bases.
+template <typename T, int MF, int NFR>
+__device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, int n, int m_base,
+                                                  int co_base, int od0, int oh0, int ow0, int lane) {
+  static_assert(MF == 4, "64 voxels per wave");
+  constexpr int VECW = 16 / (int)sizeof(T);
+  constexpr int ROWB_E = 144;                                   // 128 B of channels + 16 B pad
+  constexpr int NF_PER_PASS = 128 / (16 * (int)sizeof(T));      // 4 (bf16) or 2 (fp32) channel fragments per pass
+  constexpr int PASSES = (NFR + NF_PER_PASS - 1) / NF_PER_PASS;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int th = 1 << p.lth, tw = 1 << p.ltw;
+  T* yout = reinterpret_cast<T*>(p.y);
+  const T* res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+    // ---- accumulators (+ bias, + timestep row) -> LDS, row = voxel, 4 channels per lane ---------------------------------
+#pragma unroll
+    for (int nl = 0; nl < NF_PER_PASS; ++nl) {
+      const int nf = pass * NF_PER_PASS + nl;
+      if (nf >= NFR) break;
+      const int co = co_base + nf * 16 + q * 4;
+      float add[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = 0.f;
+        if (co + r < p.Cout) {
+          if (p.bias) a += p.bias[co + r];
+          if (p.rowvec) a += p.rowvec[(long long)n * p.rowvec_bstride + co + r];
+        }
+        add[r] = a;
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        char* dst = lds + (mf * 16 + l15) * ROWB_E + (nl * 16 + q * 4) * (int)sizeof(T);
+        const float o0 = acc[nf][mf][0] + add[0], o1 = acc[nf][mf][1] + add[1], o2 = acc[nf][mf][2] + add[2], o3 = acc[nf][mf][3] + add[3];
+        if (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = make_float4(o0, o1, o2, o3);
+        else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+      }
+    }
+    __syncthreads();
+    // ---- LDS -> global: lane = (voxel it*8 + lane/8, 16-byte segment lane%8) ---------------------------------------------
+    const int seg = lane & 7;
+    const int co = co_base + pass * NF_PER_PASS * 16 + seg * VECW;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int v = it * 8 + (lane >> 3);
+      const int m = m_base + v;
+      const int a = m >> (p.lth + p.ltw), bb = (m >> p.ltw) & (th - 1), c = m & (tw - 1);
+      const int od = od0 + a, oh = oh0 + bb, ow = ow0 + c;
+      if (od < p.Do && oh < p.Ho && ow < p.Wo && co < p.Cout) {
+        const long long vox = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+        uint4 raw = *reinterpret_cast<const uint4*>(lds + v * ROWB_E + seg * 16);
+        if (res || p.post_act) {
+          float o[VECW];
+          Vec16<T>::unpack(raw, o);
+          if (res) {
+            float rv[VECW];
+            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(res + vox * p.res_ld + co), rv);
+#pragma unroll
+            for (int i = 0; i < VECW; ++i) o[i] += rv[i];
+          }
+          if (p.post_act) {
+#pragma unroll
+            for (int i = 0; i < VECW; ++i) o[i] = conv_post_act(o[i], p.post_act);
+          }
+          raw = Vec16<T>::pack(o);
+        }
+        *reinterpret_cast<uint4*>(yout + vox * p.y_ld + co) = raw;
+      }
+    }
+    if (pass + 1 < PASSES) __syncthreads();
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ bool conv_epilogue_lds_ok(const GmConvDesc& p) {
+  constexpr int VECW = 16 / (int)sizeof(T);
+  return (p.Cout % VECW == 0) && (p.y_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
+         (!p.res || ((p.res_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
+}

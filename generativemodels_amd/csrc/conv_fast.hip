@@ -22,7 +22,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
   constexpr int ROWS_PER_PASS = NT / 4;
   constexpr int MAX_ITEMS = NT == 256 ? 12 : 8;  // patch rows per thread (host guarantees P <= MAX_ITEMS * ROWS_PER_PASS)
   constexpr bool PRECISE = sizeof(T) == 4;
-  static_assert(BN * 4 == NT, "one 16-byte weight item per thread per tap");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -94,31 +93,40 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // ---- weight panels: group of G taps, one 16-byte item per thread per tap ----------------------------------------------
+  // ---- weight panels: group of G taps = G*BN*4 16-byte items, spread over the NT threads; prefetched TWO groups ahead into
+  //      two register sets (a panel is consumed ~2 x 48 MFMAs after its loads were issued: covers an L2 round trip under load)
+  constexpr int B_ITEMS = G * BN * 4;
+  constexpr int B_PER_THREAD = (B_ITEMS + NT - 1) / NT;
   const char* wbase = reinterpret_cast<const char*>(p.w);
-  const int brow = tid >> 2;
-  const int bco = cb * BN + brow;
-  uint4 breg[G];
-  auto load_b = [&](int gstep) {
+  uint4 bregA[B_PER_THREAD], bregB[B_PER_THREAD];
+  auto load_b = [&](uint4 (&breg)[B_PER_THREAD], int gstep) __attribute__((always_inline)) {
     const int chunk = gstep / ngroups, grp = gstep - chunk * ngroups;
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-      const int t = grp * G + u;
+    for (int u = 0; u < B_PER_THREAD; ++u) {
+      const int item = tid + u * NT;
+      const int gi = item / (BN * 4), rem = item % (BN * 4);
+      const int row = rem >> 2, qq = rem & 3;
+      const int t = grp * G + gi, co = cb * BN + row;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (t < T_taps && bco < cout_pad)
-        v = *reinterpret_cast<const uint4*>(wbase + (((long long)(chunk * T_taps + t) * cout_pad + bco) * BK) * (long long)sizeof(T) + sq * 16);
+      if (item < B_ITEMS && t < T_taps && co < cout_pad)
+        v = *reinterpret_cast<const uint4*>(wbase + (((long long)(chunk * T_taps + t) * cout_pad + co) * BK) * (long long)sizeof(T) + qq * 16);
       breg[u] = v;
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](const uint4 (&breg)[B_PER_THREAD], int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < G; ++u)
-      *reinterpret_cast<uint4*>(ldsB + ((size_t)(buf * G + u) * BN + brow) * CONV_ROWB + sq * 16) = breg[u];
+    for (int u = 0; u < B_PER_THREAD; ++u) {
+      const int item = tid + u * NT;
+      const int gi = item / (BN * 4), rem = item % (BN * 4);
+      const int row = rem >> 2, qq = rem & 3;
+      if (item < B_ITEMS)
+        *reinterpret_cast<uint4*>(ldsB + ((size_t)(buf * G + gi) * BN + row) * CONV_ROWB + qq * 16) = breg[u];
+    }
   };
 
   // ---- patch staging with the fused prologue ---------------------------------------------------------------------------
   const T* xin = reinterpret_cast<const T*>(p.x);
-  auto stage_a = [&](int chunk) {
+  auto stage_a = [&](int chunk) __attribute__((always_inline)) {
     const int c0 = chunk * BK + sq * VECW;
     const bool cok = c0 < p.Cin;  // Cin % VECW == 0 (host-checked): a vector is entirely in or out of range
     float sc[VECW], sh[VECW];
@@ -162,43 +170,57 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
   };
 
   // ---- main loop --------------------------------------------------------------------------------------------------------
-  load_b(0);
+  load_b(bregA, 0);
   stage_a(0);
-  store_b(0);
+  store_b(bregA, 0);
+  if (total_gsteps > 1) load_b(bregB, 1);
   __syncthreads();
-  int gstep = 0;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    if (chunk > 0) {
-      stage_a(chunk);
+  int chunk = 0, grp = 0, kd_i = 0, kh_i = 0, kw_i = 0;
+  // one tap group; `r_next` holds the panel of gstep+1 (stored to LDS after the MFMAs), `r_far` receives the panel of gstep+2
+  auto group_body = [&](int gstep, uint4 (&r_next)[B_PER_THREAD], uint4 (&r_far)[B_PER_THREAD]) __attribute__((always_inline)) {
+    if (grp == 0 && chunk > 0) {
+      if (!(p.debug_flags & 1)) stage_a(chunk);  // every wave passed the barrier that ended the previous chunk
       __syncthreads();
     }
-    int kd_i = 0, kh_i = 0, kw_i = 0;
-    for (int grp = 0; grp < ngroups; ++grp, ++gstep) {
-      const bool more = gstep + 1 < total_gsteps;
-      if (more) load_b(gstep + 1);
-      const char* bsrc = ldsB + (size_t)((gstep & 1) * G) * BN * CONV_ROWB;
+    if (gstep + 2 < total_gsteps && !(p.debug_flags & 2)) load_b(r_far, gstep + 2);
+    const char* bsrc = ldsB + (size_t)((gstep & 1) * G) * BN * CONV_ROWB;
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        if (grp * G + u < T_taps) {
-          const int tap_off = ((kd_i * pH + kh_i) * pW + kw_i) * CONV_ROWB;
-          uint4 xf[MF], wf[NFR];
+    for (int u = 0; u < G; ++u) {
+      if (grp * G + u < T_taps && !(p.debug_flags & 8)) {
+        const int tap_off = ((kd_i * pH + kh_i) * pW + kw_i) * CONV_ROWB;
+        uint4 xf[MF], wf[NFR];
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(ldsA + aoff[mf] + tap_off);
+        for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(ldsA + aoff[mf] + tap_off);
 #pragma unroll
-          for (int nf = 0; nf < NFR; ++nf) wf[nf] = *reinterpret_cast<const uint4*>(bsrc + (size_t)u * BN * CONV_ROWB + boff[nf]);
+        for (int nf = 0; nf < NFR; ++nf) wf[nf] = *reinterpret_cast<const uint4*>(bsrc + (size_t)u * BN * CONV_ROWB + boff[nf]);
+        if (!(p.debug_flags & 4)) {
 #pragma unroll
           for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[nf][mf]);
-          if (++kw_i == p.kw) { kw_i = 0; if (++kh_i == p.kh) { kh_i = 0; ++kd_i; } }
+        } else {
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) asm volatile("" ::"v"(xf[mf].x), "v"(xf[mf].w), "v"(wf[mf].x), "v"(wf[mf].w));
         }
+        if (++kw_i == p.kw) { kw_i = 0; if (++kh_i == p.kh) { kh_i = 0; ++kd_i; } }
       }
-      if (more) store_b((gstep + 1) & 1);
-      __syncthreads();
     }
+    if (gstep + 1 < total_gsteps) store_b(r_next, (gstep + 1) & 1);
+    __syncthreads();
+    if (++grp == ngroups) { grp = 0; ++chunk; kd_i = kh_i = kw_i = 0; }
+  };
+  for (int gstep = 0; gstep < total_gsteps; gstep += 2) {
+    group_body(gstep, bregB, bregA);
+    if (gstep + 1 < total_gsteps) group_body(gstep + 1, bregA, bregB);
   }
 
-  conv_epilogue<T, MF, NFR>(p, acc, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, l15, q);
+  if (p.debug_flags & 16) return;
+  if (conv_epilogue_lds_ok<T>(p) && !(p.debug_flags & 32)) {
+    // every wave passed the main loop's final barrier: the operand buffers are free; one 64 x 144 B scratch per wave
+    conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * 64 * 144, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, lane);
+  } else {
+    conv_epilogue<T, MF, NFR>(p, acc, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, l15, q);
+  }
 }
 
 extern "C" long long gm_conv_fast_lds_bytes(const GmConvDesc* d, int bn) {
@@ -207,7 +229,8 @@ extern "C" long long gm_conv_fast_lds_bytes(const GmConvDesc* d, int bn) {
   return P * CONV_ROWB + 2LL * 3 * bn * CONV_ROWB;
 }
 
-extern "C" long long gm_conv_fast_max_patch(int wn) { return wn == 1 ? 12 * 64 : 8 * 128; }
+// variant: 1 = 256 voxels x 64 ch (4 waves), 2 = 256 voxels x 128 ch (8 waves), 3 = 512 voxels x 64 ch (8 waves)
+extern "C" long long gm_conv_fast_max_patch(int variant) { return variant == 1 ? 12 * 64 : 8 * 128; }
 
 template <typename T, int WM, int WN>
 static void launch_fast(const GmConvDesc& d, size_t smem, unsigned nblocks, hipStream_t st) {
@@ -221,15 +244,18 @@ static void launch_fast(const GmConvDesc& d, size_t smem, unsigned nblocks, hipS
   kern<<<dim3(nblocks), 64 * WM * WN, smem, st>>>(d);
 }
 
-// wn = 1: 256 voxels x 64 channels (4 waves); wn = 2: 256 voxels x 128 channels (8 waves).  Returns 0 or a negative code.
-extern "C" int gm_conv_fast_launch(const GmConvDesc* dp, int wn, unsigned nblocks, void* stream) {
+extern "C" int gm_conv_fast_launch(const GmConvDesc* dp, int variant, unsigned nblocks, void* stream) {
   const GmConvDesc& d = *dp;
-  const size_t smem = (size_t)gm_conv_fast_lds_bytes(dp, wn * 64);
+  const size_t smem = (size_t)gm_conv_fast_lds_bytes(dp, variant == 2 ? 128 : 64);
   hipStream_t st = (hipStream_t)stream;
   if (d.dtype == GM_F32) {
-    if (wn == 1) launch_fast<float, 4, 1>(d, smem, nblocks, st); else launch_fast<float, 4, 2>(d, smem, nblocks, st);
+    if (variant == 1) launch_fast<float, 4, 1>(d, smem, nblocks, st);
+    else if (variant == 2) launch_fast<float, 4, 2>(d, smem, nblocks, st);
+    else launch_fast<float, 8, 1>(d, smem, nblocks, st);
   } else if (d.dtype == GM_BF16) {
-    if (wn == 1) launch_fast<bf16_raw, 4, 1>(d, smem, nblocks, st); else launch_fast<bf16_raw, 4, 2>(d, smem, nblocks, st);
+    if (variant == 1) launch_fast<bf16_raw, 4, 1>(d, smem, nblocks, st);
+    else if (variant == 2) launch_fast<bf16_raw, 4, 2>(d, smem, nblocks, st);
+    else launch_fast<bf16_raw, 8, 1>(d, smem, nblocks, st);
   } else {
     return -2;
   }

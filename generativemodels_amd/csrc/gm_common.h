@@ -48,7 +48,14 @@ template <> struct ElemIO<bf16_raw> {
   static __device__ __forceinline__ void st(bf16_raw* p, float v) { *p = f32_to_bf16(v); }
 };
 
-__device__ __forceinline__ float gm_silu(float x) { return x / (1.0f + __expf(-x)); }
+// two fp32 -> packed bf16x2 (lo in bits 0..15) with the gfx950 hardware converter (round-to-nearest-even)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// fast SiLU for the bf16 path: v_exp_f32 + v_rcp_f32 (about 1 ulp each; far below bf16 resolution)
+__device__ __forceinline__ float gm_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float gm_silu_precise(float x) { return x / (1.0f + expf(-x)); }
 
 // wave64 butterfly reductions

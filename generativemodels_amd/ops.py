@@ -364,6 +364,8 @@ def _cfg_tile(cfg: int):
     return _CFG_TILES[cfg]
 
 
+_CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
+
 LDS_SOFT_LIMIT = 80 * 1024   # two workgroups per CU
 LDS_HARD_LIMIT = 160 * 1024
 
@@ -375,9 +377,9 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
     elif cout <= 16:
         order = [3, 4, 2]
     elif cout <= 64:
-        order = [5, 0, 4, 2]
+        order = [7, 5, 0, 4, 2] if n_vox_out * desc.N >= 512 * 512 else [5, 0, 4, 2]
     else:
-        order = [6, 1, 4, 2]
+        order = [7, 6, 1, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [6, 1, 4, 2]
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
         order = [c for c in order if _cfg_tile(c)[0] <= 64] + [c for c in order if _cfg_tile(c)[0] > 64]
     best = None
@@ -386,7 +388,7 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         bits = _tile_bits(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
-        soft = LDS_HARD_LIMIT if cfg in (5, 6) else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
+        soft = LDS_HARD_LIMIT if cfg in (5, 6, 7) else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
         if 0 < lds <= soft:
             return
         if 0 < lds <= LDS_HARD_LIMIT and best is None:
@@ -499,6 +501,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     d.pd, d.ph, d.pw = conv_pad
     d.dd, d.dh, d.dw = dil
     d.pre_act, d.post_act, d.dtype = ACT[pre_act], POST_ACT[post_act], dt_code(dtype)
+    d.debug_flags = _CONV_DEBUG_FLAGS
     _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
     if _PROFILE is None:
         check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward")

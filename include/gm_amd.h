@@ -113,6 +113,7 @@ typedef struct GmConvDesc {
   int dtype;
   int ltd, lth, ltw;         /* log2 output tile dims; product must equal the configuration's voxel count */
   int cfg;                   /* tile configuration, see gm_conv_cfg_tile */
+  int debug_flags;           /* must be 0 (bench-only ablation switches: results are wrong when set) */
 } GmConvDesc;
 int gm_conv_cfg_tile(int cfg, int* voxels, int* channels);
 long long gm_conv_lds_bytes(const GmConvDesc* d);
