@@ -31,7 +31,7 @@ if [[ $STAGES == *b* ]]; then
   echo "bench rc=$?" >> $OUT/round.log; tail -c 3000 $OUT/bench.log >> $OUT/round.log
 fi
 if [[ $STAGES == *p* ]]; then
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 0 --graph 0 --cpu-baseline off --inference-steps 5 > $OLDPWD/$OUT/prof.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 0 --graph 0 --cpu-baseline off --inference-steps 5 > $OLDPWD/$OUT/prof.log 2>&1)
   echo "prof rc=$?" >> $OUT/round.log
   find $OUT/prof -name "*kernel_stats*" | head -3 >> $OUT/round.log
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" >> $OUT/round.log
