@@ -12,6 +12,13 @@
 //   * tile = 256 voxels (4x8x8 in 3-D) x 64 channels with 4 waves (2 work-groups / CU), or x 128 channels with 8 waves.
 #include "conv_epilogue.h"
 
+// LDS operand rows are 64 bytes (one K chunk) with NO padding; the 16-byte slot a (row, slot) pair lives in is
+// slot ^ fast_swz(row).  With 16 consecutive rows per MFMA fragment (tile width 16, or the weight rows) every
+// ds_read_b128 lane group of gfx950 then touches 16 distinct 16-byte bank slots: conflict-free for any starting row
+// (exhaustively checked against the lane-group table of MI355X_MICROARCH.md, tools/lds_swizzle_search.py).
+#define FAST_ROWB 64
+__device__ __forceinline__ int fast_swz(int row) { return (row ^ (row >> 1)) & 3; }
+
 template <typename T, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
@@ -20,7 +27,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
   constexpr int MF = 4, NFR = 4, G = 3;
   constexpr int BN = WN * 64;
   constexpr int ROWS_PER_PASS = NT / 4;
-  constexpr int MAX_ITEMS = NT == 256 ? 12 : 8;  // patch rows per thread (host guarantees P <= MAX_ITEMS * ROWS_PER_PASS)
+  constexpr int MAX_ITEMS = NT == 256 ? 12 : 10;  // patch rows per thread (host guarantees P <= MAX_ITEMS * ROWS_PER_PASS)
+  constexpr int A_BATCH = NT == 256 ? 6 : 5;      // patch loads in flight per thread before the first is consumed
   constexpr bool PRECISE = sizeof(T) == 4;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -47,8 +55,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
   if (p.in_mode == 1) { Dv *= p.fd; Hv *= p.fh; Wv *= p.fw; }
   const int ud0 = od0 - p.pd, uh0 = oh0 - p.ph, uw0 = ow0 - p.pw;
 
-  char* ldsA = smem;                              // [P][CONV_ROWB]
-  char* ldsB = smem + (size_t)P * CONV_ROWB;      // [2][G][BN][CONV_ROWB]
+  char* ldsA = smem;                              // [P][FAST_ROWB], slots swizzled
+  char* ldsB = smem + (size_t)P * FAST_ROWB;      // [2][G][BN][FAST_ROWB], slots swizzled
 
   const int T_taps = p.kd * p.kh * p.kw;
   const int ngroups = (T_taps + G - 1) / G;
@@ -76,16 +84,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
   }
 
   // ---- per-lane LDS read offsets ---------------------------------------------------------------------------------------
-  int aoff[MF];
+  int arow[MF];  // patch row of this lane's voxel at tap (0,0,0)
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int m = (wm * MF + mf) * 16 + l15;
     const int a = m >> (p.lth + p.ltw), bb = (m >> p.ltw) & (th - 1), c = m & (tw - 1);
-    aoff[mf] = ((a * pH + bb) * pW + c) * CONV_ROWB + q * 16;
+    arow[mf] = (a * pH + bb) * pW + c;
   }
-  int boff[NFR];
+  int boff[NFR];  // weight rows: panel bases are multiples of 8 rows, so the swizzle term is a per-lane constant
 #pragma unroll
-  for (int nf = 0; nf < NFR; ++nf) boff[nf] = ((wn * NFR + nf) * 16 + l15) * CONV_ROWB + q * 16;
+  for (int nf = 0; nf < NFR; ++nf) {
+    const int r = (wn * NFR + nf) * 16 + l15;
+    boff[nf] = r * FAST_ROWB + ((q ^ fast_swz(r)) << 4);
+  }
 
   f32x4_t acc[NFR][MF];
 #pragma unroll
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
       const int gi = item / (BN * 4), rem = item % (BN * 4);
       const int row = rem >> 2, qq = rem & 3;
       if (item < B_ITEMS)
-        *reinterpret_cast<uint4*>(ldsB + ((size_t)(buf * G + gi) * BN + row) * CONV_ROWB + qq * 16) = breg[u];
+        *reinterpret_cast<uint4*>(ldsB + ((size_t)(buf * G + gi) * BN + row) * FAST_ROWB + ((qq ^ fast_swz(row)) << 4)) = breg[u];
     }
   };
 
@@ -138,16 +149,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
       }
     }
 #pragma unroll
-    for (int jb = 0; jb < MAX_ITEMS; jb += 4) {
-      uint4 raw[4];
+    for (int jb = 0; jb < MAX_ITEMS; jb += A_BATCH) {
+      uint4 raw[A_BATCH];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < A_BATCH; ++u) {
         raw[u] = make_uint4(0, 0, 0, 0);
-        if (vox[jb + u] >= 0 && cok) raw[u] = *reinterpret_cast<const uint4*>(xin + (long long)vox[jb + u] * p.x_ld + c0);
+        if (jb + u < MAX_ITEMS && vox[jb + u] >= 0 && cok)
+          raw[u] = *reinterpret_cast<const uint4*>(xin + (long long)vox[jb + u] * p.x_ld + c0);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < A_BATCH; ++u) {
         const int j = jb + u;
+        if (j >= MAX_ITEMS) break;
         if (vox[j] == -2) continue;
         uint4 outv = raw[u];
         if (vox[j] >= 0 && cok && (p.pre_scale || p.pre_act)) {
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
           outv = Vec16<T>::pack(v);
         }
         const int pv = (tid >> 2) + j * ROWS_PER_PASS;
-        *reinterpret_cast<uint4*>(ldsA + (size_t)pv * CONV_ROWB + sq * 16) = outv;
+        *reinterpret_cast<uint4*>(ldsA + (size_t)pv * FAST_ROWB + ((sq ^ fast_swz(pv)) << 4)) = outv;
       }
     }
   };
@@ -183,16 +196,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
       __syncthreads();
     }
     if (gstep + 2 < total_gsteps && !(p.debug_flags & 2)) load_b(r_far, gstep + 2);
-    const char* bsrc = ldsB + (size_t)((gstep & 1) * G) * BN * CONV_ROWB;
+    const char* bsrc = ldsB + (size_t)((gstep & 1) * G) * BN * FAST_ROWB;
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       if (grp * G + u < T_taps && !(p.debug_flags & 8)) {
-        const int tap_off = ((kd_i * pH + kh_i) * pW + kw_i) * CONV_ROWB;
+        const int tap_row = (kd_i * pH + kh_i) * pW + kw_i;
         uint4 xf[MF], wf[NFR];
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(ldsA + aoff[mf] + tap_off);
+        for (int mf = 0; mf < MF; ++mf) {
+          const int r = arow[mf] + tap_row;
+          xf[mf] = *reinterpret_cast<const uint4*>(ldsA + r * FAST_ROWB + ((q ^ fast_swz(r)) << 4));
+        }
 #pragma unroll
-        for (int nf = 0; nf < NFR; ++nf) wf[nf] = *reinterpret_cast<const uint4*>(bsrc + (size_t)u * BN * CONV_ROWB + boff[nf]);
+        for (int nf = 0; nf < NFR; ++nf) wf[nf] = *reinterpret_cast<const uint4*>(bsrc + (size_t)u * BN * FAST_ROWB + boff[nf]);
         if (!(p.debug_flags & 4)) {
 #pragma unroll
           for (int nf = 0; nf < NFR; ++nf)
@@ -226,11 +242,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
 extern "C" long long gm_conv_fast_lds_bytes(const GmConvDesc* d, int bn) {
   const long long td = 1 << d->ltd, th = 1 << d->lth, tw = 1 << d->ltw;
   const long long P = (td + d->kd - 1) * (th + d->kh - 1) * (tw + d->kw - 1);
-  return P * CONV_ROWB + 2LL * 3 * bn * CONV_ROWB;
+  const long long need = P * FAST_ROWB + 2LL * 3 * bn * FAST_ROWB;
+  const long long waves = (bn == 128 || (1 << (d->ltd + d->lth + d->ltw)) == 512) ? 8 : 4;
+  const long long scratch = waves * 64 * 144;  // epilogue transpose scratch re-uses the operand buffers
+  return need > scratch ? need : scratch;
 }
 
 // variant: 1 = 256 voxels x 64 ch (4 waves), 2 = 256 voxels x 128 ch (8 waves), 3 = 512 voxels x 64 ch (8 waves)
-extern "C" long long gm_conv_fast_max_patch(int variant) { return variant == 1 ? 12 * 64 : 8 * 128; }
+extern "C" long long gm_conv_fast_max_patch(int variant) { return variant == 1 ? 12 * 64 : 10 * 128; }
 
 template <typename T, int WM, int WN>
 static void launch_fast(const GmConvDesc& d, size_t smem, unsigned nblocks, hipStream_t st) {

@@ -353,6 +353,21 @@ def _tile_bits(total_bits: int, out_dims):
     return bits
 
 
+def _tile_bits_fast(total_bits: int, out_dims):
+    """Tiles of the fast kernels are 16 voxels wide (16 consecutive LDS rows per MFMA fragment = conflict-free reads);
+    the remaining bits go to h and d, smallest extent first."""
+    caps = [_clog2(d) for d in out_dims]
+    bits = [0, 0, min(4, caps[2], total_bits)]
+    for _ in range(total_bits - bits[2]):
+        cand = [i for i in (1, 0) if bits[i] < caps[i]]
+        if not cand:
+            bits[2] += 1
+            continue
+        i = min(cand, key=lambda j: bits[j])
+        bits[i] += 1
+    return bits
+
+
 _CFG_TILES = {}
 
 
@@ -385,7 +400,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
     best = None
     for cfg in order:
         bm, _ = _cfg_tile(cfg)
-        bits = _tile_bits(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
+        tb = _tile_bits_fast if cfg in (5, 6, 7) else _tile_bits
+        bits = tb(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg in (5, 6, 7) else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy

@@ -20,8 +20,8 @@ def run(cin, cout, sp, pro, flags, cfg):
     ops._CONV_DEBUG_FLAGS = 0
     return e0.elapsed_time(e1) / 3
 names = {0: "full", 1: "no A restage", 2: "no B loads", 4: "no MFMA (ds_reads kept)", 8: "no ds_read+MFMA", 16: "no epilogue",
-         1 | 2: "no A restage, no B loads", 1 | 2 | 8: "only barriers+epilogue", 1 | 2 | 8 | 16: "skeleton", 4 | 1: "no MFMA no A restage", 8 | 2: "A staging only"}
-for cin, cout, sp, cfg in [(64, 64, (128, 128, 128), 5), (128, 128, (64, 64, 64), 6), (192, 64, (128, 128, 128), 5)]:
+         1 | 2: "no A restage, no B loads", 1 | 2 | 8: "only barriers+epilogue", 1 | 2 | 8 | 16: "skeleton", 4 | 1: "no MFMA no A restage", 8 | 2: "A staging only", 32: "old scatter epilogue"}
+for cin, cout, sp, cfg in [(64, 64, (128, 128, 128), 7), (128, 128, (64, 64, 64), 6), (192, 64, (128, 128, 128), 7), (64, 64, (128, 128, 128), 5)]:
     for pro in (True, False):
         print(f"--- {cin}->{cout}@{sp} cfg{cfg} prologue={pro}")
         for f, nm in names.items():
