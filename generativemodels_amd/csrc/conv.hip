@@ -278,9 +278,11 @@ extern "C" long long gm_conv_fast_max_patch(int wn);
 extern "C" int gm_conv_fast_launch(const GmConvDesc* dp, int wn, unsigned nblocks, void* stream);
 #define CONV_CFG_FAST64 5
 #define CONV_CFG_FAST128 6
-#define CONV_CFG_FAST512 7
-static inline bool conv_is_fast(int cfg) { return cfg >= CONV_CFG_FAST64 && cfg <= CONV_CFG_FAST512; }
+#define CONV_CFG_FAST_LAST 9
+extern "C" int gm_conv_fast_variant_geometry(int variant, int* voxels, int* channels, int* threads);
+static inline bool conv_is_fast(int cfg) { return cfg >= CONV_CFG_FAST64 && cfg <= CONV_CFG_FAST_LAST; }
 static inline int conv_fast_variant(int cfg) { return cfg - CONV_CFG_FAST64 + 1; }
+static inline int conv_fast_bn(int cfg) { int v = 0, c = 0, t = 0; gm_conv_fast_variant_geometry(conv_fast_variant(cfg), &v, &c, &t); return c; }
 
 static bool conv_fast_eligible(const GmConvDesc& d) {
   const int vecw = d.dtype == GM_F32 ? 4 : 8;
@@ -293,7 +295,7 @@ static bool conv_fast_eligible(const GmConvDesc& d) {
 }
 
 extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
-  if (conv_is_fast(cfg)) { *bm = cfg == CONV_CFG_FAST512 ? 512 : 256; *bn = cfg == CONV_CFG_FAST128 ? 128 : 64; return 0; }
+  if (conv_is_fast(cfg)) { int t = 0; return gm_conv_fast_variant_geometry(conv_fast_variant(cfg), bm, bn, &t); }
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
   *bm = kCfgs[cfg].WM * kCfgs[cfg].MF * 16;
   *bn = kCfgs[cfg].WN * kCfgs[cfg].NFR * 16;
@@ -329,7 +331,7 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   if (d && conv_is_fast(d->cfg)) {
     if (!conv_fast_eligible(*d)) return -1;
-    return gm_conv_fast_lds_bytes(d, d->cfg == CONV_CFG_FAST128 ? 128 : 64);
+    return gm_conv_fast_lds_bytes(d, conv_fast_bn(d->cfg));
   }
   if (!d || d->cfg < 0 || d->cfg >= kNumCfgs) return -1;
   const int td = 1 << d->ltd, th = 1 << d->lth, tw = 1 << d->ltw;

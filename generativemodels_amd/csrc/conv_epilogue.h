@@ -84,7 +84,6 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
 template <typename T, int MF, int NFR>
 __device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, int n, int m_base,
                                                   int co_base, int od0, int oh0, int ow0, int lane) {
-  static_assert(MF == 4, "64 voxels per wave");
   constexpr int VECW = 16 / (int)sizeof(T);
   constexpr int ROWB_E = 144;                                   // 128 B of channels + 16 B pad
   constexpr int NF_PER_PASS = 128 / (16 * (int)sizeof(T));      // 4 (bf16) or 2 (fp32) channel fragments per pass
@@ -124,7 +123,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (
     const int seg = lane & 7;
     const int co = co_base + pass * NF_PER_PASS * 16 + seg * VECW;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < MF * 2; ++it) {
       const int v = it * 8 + (lane >> 3);
       const int m = m_base + v;
       const int a = m >> (p.lth + p.ltw), bb = (m >> p.ltw) & (th - 1), c = m & (tw - 1);

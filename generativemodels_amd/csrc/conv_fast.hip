@@ -19,16 +19,26 @@
 #define FAST_ROWB 64
 __device__ __forceinline__ int fast_swz(int row) { return (row ^ (row >> 1)) & 3; }
 
-template <typename T, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDesc p) {
+// bench-only ablation switches (tools/ablate_conv.py): compiled out of the production library
+#ifdef GM_CONV_ABLATE
+#define ABLATE(bit) (p.debug_flags & (bit))
+#else
+#define ABLATE(bit) false
+#endif
+
+// WM x WN waves, each owning MF voxel fragments (16 voxels) x 4 channel fragments; MINW = resident waves per SIMD the
+// register allocation must allow (work-groups per CU x waves per work-group / 4)
+template <typename T, int WM, int WN, int MF, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * WM * WN;
-  constexpr int MF = 4, NFR = 4, G = 3;
+  constexpr int NFR = 4, G = 3;
+  constexpr int BM = WM * MF * 16;
   constexpr int BN = WN * 64;
   constexpr int ROWS_PER_PASS = NT / 4;
-  constexpr int MAX_ITEMS = NT == 256 ? 12 : 10;  // patch rows per thread (host guarantees P <= MAX_ITEMS * ROWS_PER_PASS)
-  constexpr int A_BATCH = NT == 256 ? 6 : 5;      // patch loads in flight per thread before the first is consumed
+  constexpr int MAX_ITEMS = NT == 256 ? 12 : (NT == 512 ? (BM == 512 ? 10 : 6) : 3);  // patch rows per thread (host: P <= MAX_ITEMS * ROWS_PER_PASS)
+  constexpr int A_BATCH = MAX_ITEMS >= 10 ? (MAX_ITEMS + 1) / 2 : MAX_ITEMS;  // patch loads in flight per thread
   constexpr bool PRECISE = sizeof(T) == 4;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -84,12 +94,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
   }
 
   // ---- per-lane LDS read offsets ---------------------------------------------------------------------------------------
-  int arow[MF];  // patch row of this lane's voxel at tap (0,0,0)
+  int arow64[MF];  // 64 x patch row of this lane's voxel at tap (0,0,0)
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int m = (wm * MF + mf) * 16 + l15;
     const int a = m >> (p.lth + p.ltw), bb = (m >> p.ltw) & (th - 1), c = m & (tw - 1);
-    arow[mf] = (a * pH + bb) * pW + c;
+    arow64[mf] = ((a * pH + bb) * pW + c) * FAST_ROWB;
   }
   int boff[NFR];  // weight rows: panel bases are multiples of 8 rows, so the swizzle term is a per-lane constant
 #pragma unroll
@@ -192,24 +202,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
   // one tap group; `r_next` holds the panel of gstep+1 (stored to LDS after the MFMAs), `r_far` receives the panel of gstep+2
   auto group_body = [&](int gstep, uint4 (&r_next)[B_PER_THREAD], uint4 (&r_far)[B_PER_THREAD]) __attribute__((always_inline)) {
     if (grp == 0 && chunk > 0) {
-      if (!(p.debug_flags & 1)) stage_a(chunk);  // every wave passed the barrier that ended the previous chunk
+      if (!(ABLATE(1))) stage_a(chunk);  // every wave passed the barrier that ended the previous chunk
       __syncthreads();
     }
-    if (gstep + 2 < total_gsteps && !(p.debug_flags & 2)) load_b(r_far, gstep + 2);
+    if (gstep + 2 < total_gsteps && !(ABLATE(2))) load_b(r_far, gstep + 2);
     const char* bsrc = ldsB + (size_t)((gstep & 1) * G) * BN * FAST_ROWB;
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      if (grp * G + u < T_taps && !(p.debug_flags & 8)) {
+      if (grp * G + u < T_taps && !(ABLATE(8))) {
         const int tap_row = (kd_i * pH + kh_i) * pW + kw_i;
         uint4 xf[MF], wf[NFR];
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-          const int r = arow[mf] + tap_row;
-          xf[mf] = *reinterpret_cast<const uint4*>(ldsA + r * FAST_ROWB + ((q ^ fast_swz(r)) << 4));
+          const int rb = arow64[mf] + tap_row * FAST_ROWB;                 // row * 64
+          const int sw = (((rb ^ (rb >> 1)) >> 2) & 0x30) ^ (q << 4);      // (q ^ fast_swz(row)) << 4, computed on the byte offset
+          xf[mf] = *reinterpret_cast<const uint4*>(ldsA + rb + sw);
         }
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf) wf[nf] = *reinterpret_cast<const uint4*>(bsrc + (size_t)u * BN * FAST_ROWB + boff[nf]);
-        if (!(p.debug_flags & 4)) {
+        if (!(ABLATE(4))) {
 #pragma unroll
           for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
@@ -230,10 +241,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fast_kernel(const GmConvDes
     if (gstep + 1 < total_gsteps) group_body(gstep + 1, bregA, bregB);
   }
 
-  if (p.debug_flags & 16) return;
-  if (conv_epilogue_lds_ok<T>(p) && !(p.debug_flags & 32)) {
+  if (ABLATE(16)) return;
+  if (conv_epilogue_lds_ok<T>(p) && !ABLATE(32)) {
     // every wave passed the main loop's final barrier: the operand buffers are free; one 64 x 144 B scratch per wave
-    conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * 64 * 144, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, lane);
+    conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, lane);
   } else {
     conv_epilogue<T, MF, NFR>(p, acc, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, l15, q);
   }
@@ -243,18 +254,19 @@ extern "C" long long gm_conv_fast_lds_bytes(const GmConvDesc* d, int bn) {
   const long long td = 1 << d->ltd, th = 1 << d->lth, tw = 1 << d->ltw;
   const long long P = (td + d->kd - 1) * (th + d->kh - 1) * (tw + d->kw - 1);
   const long long need = P * FAST_ROWB + 2LL * 3 * bn * FAST_ROWB;
-  const long long waves = (bn == 128 || (1 << (d->ltd + d->lth + d->ltw)) == 512) ? 8 : 4;
-  const long long scratch = waves * 64 * 144;  // epilogue transpose scratch re-uses the operand buffers
+  const long long scratch = (1LL << (d->ltd + d->lth + d->ltw)) * (bn / 64) * 144;  // epilogue transpose scratch (64 x 144 B per 64x64 sub-tile) re-uses the operand buffers
   return need > scratch ? need : scratch;
 }
 
 // variant: 1 = 256 voxels x 64 ch (4 waves), 2 = 256 voxels x 128 ch (8 waves), 3 = 512 voxels x 64 ch (8 waves)
-extern "C" long long gm_conv_fast_max_patch(int variant) { return variant == 1 ? 12 * 64 : 10 * 128; }
+extern "C" long long gm_conv_fast_max_patch(int variant) {
+  switch (variant) { case 1: return 12 * 64; case 2: return 6 * 128; case 3: return 10 * 128; case 4: return 6 * 128; case 5: return 3 * 256; default: return 0; }
+}
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int MF, int MINW>
 static void launch_fast(const GmConvDesc& d, size_t smem, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_fast_kernel<T, WM, WN>;
+  auto kern = conv_fast_kernel<T, WM, WN, MF, MINW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
@@ -263,20 +275,32 @@ static void launch_fast(const GmConvDesc& d, size_t smem, unsigned nblocks, hipS
   kern<<<dim3(nblocks), 64 * WM * WN, smem, st>>>(d);
 }
 
+template <typename T>
+static int dispatch_fast(const GmConvDesc& d, int variant, size_t smem, unsigned nblocks, hipStream_t st) {
+  switch (variant) {
+    case 1: launch_fast<T, 4, 1, 4, 2>(d, smem, nblocks, st); return 0;   // 256 vox x  64 ch,  4 waves, 2 WG/CU
+    case 2: launch_fast<T, 4, 2, 4, 2>(d, smem, nblocks, st); return 0;   // 256 vox x 128 ch,  8 waves, 1 WG/CU
+    case 3: launch_fast<T, 8, 1, 4, 2>(d, smem, nblocks, st); return 0;   // 512 vox x  64 ch,  8 waves, 1 WG/CU
+    case 4: launch_fast<T, 8, 1, 2, 4>(d, smem, nblocks, st); return 0;   // 256 vox x  64 ch,  8 waves, 2 WG/CU (16 waves/CU)
+    case 5: launch_fast<T, 8, 2, 2, 4>(d, smem, nblocks, st); return 0;   // 256 vox x 128 ch, 16 waves, 1 WG/CU
+    default: return -3;
+  }
+}
+
+extern "C" int gm_conv_fast_variant_geometry(int variant, int* voxels, int* channels, int* threads) {
+  static const int g[6][3] = {{0, 0, 0}, {256, 64, 256}, {256, 128, 512}, {512, 64, 512}, {256, 64, 512}, {256, 128, 1024}};
+  if (variant < 1 || variant > 5) return -1;
+  *voxels = g[variant][0]; *channels = g[variant][1]; *threads = g[variant][2];
+  return 0;
+}
+
 extern "C" int gm_conv_fast_launch(const GmConvDesc* dp, int variant, unsigned nblocks, void* stream) {
   const GmConvDesc& d = *dp;
-  const size_t smem = (size_t)gm_conv_fast_lds_bytes(dp, variant == 2 ? 128 : 64);
+  int vox = 0, ch = 0, thr = 0;
+  if (gm_conv_fast_variant_geometry(variant, &vox, &ch, &thr) != 0) return -3;
+  const size_t smem = (size_t)gm_conv_fast_lds_bytes(dp, ch);
   hipStream_t st = (hipStream_t)stream;
-  if (d.dtype == GM_F32) {
-    if (variant == 1) launch_fast<float, 4, 1>(d, smem, nblocks, st);
-    else if (variant == 2) launch_fast<float, 4, 2>(d, smem, nblocks, st);
-    else launch_fast<float, 8, 1>(d, smem, nblocks, st);
-  } else if (d.dtype == GM_BF16) {
-    if (variant == 1) launch_fast<bf16_raw, 4, 1>(d, smem, nblocks, st);
-    else if (variant == 2) launch_fast<bf16_raw, 4, 2>(d, smem, nblocks, st);
-    else launch_fast<bf16_raw, 8, 1>(d, smem, nblocks, st);
-  } else {
-    return -2;
-  }
-  return 0;
+  if (d.dtype == GM_F32) return dispatch_fast<float>(d, variant, smem, nblocks, st);
+  if (d.dtype == GM_BF16) return dispatch_fast<bf16_raw>(d, variant, smem, nblocks, st);
+  return -2;
 }

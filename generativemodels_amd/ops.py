@@ -392,19 +392,19 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
     elif cout <= 16:
         order = [3, 4, 2]
     elif cout <= 64:
-        order = [7, 5, 0, 4, 2] if n_vox_out * desc.N >= 512 * 512 else [5, 0, 4, 2]
+        order = [8, 5, 0, 4, 2]   # 16 waves/CU on 256x64 tiles measured best at every C2 shape (tools/bench_conv.py)
     else:
-        order = [7, 6, 1, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [6, 1, 4, 2]
+        order = [9, 6, 1, 4, 2]
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
         order = [c for c in order if _cfg_tile(c)[0] <= 64] + [c for c in order if _cfg_tile(c)[0] > 64]
     best = None
     for cfg in order:
         bm, _ = _cfg_tile(cfg)
-        tb = _tile_bits_fast if cfg in (5, 6, 7) else _tile_bits
+        tb = _tile_bits_fast if cfg >= 5 else _tile_bits
         bits = tb(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
-        soft = LDS_HARD_LIMIT if cfg in (5, 6, 7) else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
+        soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
         if 0 < lds <= soft:
             return
         if 0 < lds <= LDS_HARD_LIMIT and best is None:

@@ -16,7 +16,7 @@ SHAPES = [  # name, Cin, Cout, spatial (input), upsample, prologue
     ("256->256@32^3 gn+silu", 256, 256, (32, 32, 32), False, True),
     ("64->64@128^3 plain", 64, 64, (128, 128, 128), False, False),
 ]
-cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 5, 6]
+cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [5, 6, 7, 8, 9]
 dtype = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
 for name, cin, cout, sp, up, pro in SHAPES:
     x = torch.randn((1, *sp, cin), device=dev).to(dtype)
