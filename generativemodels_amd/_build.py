@@ -52,12 +52,17 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# per-file extra flags: the scheduler / mixing kernels must reproduce the reference's fp32 op order bit for bit, so fused
+# multiply-add contraction is off for that translation unit (HIP's __fmul_rn/__fadd_rn are plain operators and DO contract)
+EXTRA_FLAGS = {"elementwise.hip": ["-ffp-contract=off"]}
+
+
 def _compile(src: str) -> str:
     obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
     srcp = os.path.join(CSRC, src)
-    deps = [srcp] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    deps = [srcp, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     if _stale(obj, deps):
-        cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", srcp, "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
