@@ -1,0 +1,27 @@
+#!/bin/bash
+# HBM traffic of the bench's kernels: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (counters only).
+cd "$(dirname "$0")/.."
+R=$PWD; OUT=$R/gpurun_out/pmc_traffic; rm -rf $OUT; mkdir -p $OUT
+export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -o c -- python $R/bench.py --steps 1 --warmup 0 --graph 0 --cpu-baseline off --inference-steps 1 > $OUT/$C.log 2>&1)
+done
+python - <<'PY'
+import csv, glob, collections, json
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob("gpurun_out/pmc_traffic/*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+rows = []
+for k, d in agg.items():
+    f, w = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
+    if not f and not w:
+        continue
+    rows.append((k, len(f), sum(f) / max(len(f), 1), sum(w) / max(len(w), 1)))
+rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
+out = [dict(kernel=k, launches=n, fetch_kib_per_launch=round(f, 1), write_kib_per_launch=round(w, 1),
+            hbm_mb_per_launch_corrected=round((2 * f + w) * 1024 / 1e6, 2)) for k, n, f, w in rows[:14]]
+json.dump(out, open("gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
+for o in out:
+    print(o)
+PY
