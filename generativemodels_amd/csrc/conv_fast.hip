@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
   constexpr int BN = WN * 64;
   constexpr int ROWS_PER_PASS = NT / 4;
   constexpr int MAX_ITEMS = NT == 256 ? 12 : (NT == 512 ? (BM == 512 ? 10 : 6) : 3);  // patch rows per thread (host: P <= MAX_ITEMS * ROWS_PER_PASS)
-  constexpr int A_BATCH = MAX_ITEMS >= 10 ? (MAX_ITEMS + 1) / 2 : MAX_ITEMS;  // patch loads in flight per thread
+  constexpr int A_BATCH = MINW >= 4 ? 2 : (MAX_ITEMS >= 10 ? (MAX_ITEMS + 1) / 2 : MAX_ITEMS);  // patch loads in flight per thread (128-VGPR variants: 3)
   constexpr bool PRECISE = sizeof(T) == 4;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
