@@ -128,20 +128,28 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
       const int gi = item / (BN * 4), rem = item % (BN * 4);
       const int row = rem >> 2, qq = rem & 3;
       const int t = grp * G + gi, co = cb * BN + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (item < B_ITEMS && t < T_taps && co < cout_pad)
-        v = *reinterpret_cast<const uint4*>(wbase + (((long long)(chunk * T_taps + t) * cout_pad + co) * BK) * (long long)sizeof(T) + qq * 16);
+      // branch-free: an `if (valid) load` makes hipcc branch around the load AND drain vmcnt(0) at the join, which killed the
+      // prefetch distance (the panel was waited for in the very next tap).  Load from a clamped in-range address instead and
+      // zero the result with a select at consumption time.
+      const bool ok = (item < B_ITEMS) & (t < T_taps) & (co < cout_pad);
+      const long long tt = ok ? (long long)(chunk * T_taps + t) : 0, cc = ok ? co : 0;
+      const uint4 v = *reinterpret_cast<const uint4*>(wbase + ((tt * cout_pad + cc) * BK) * (long long)sizeof(T) + qq * 16);
       breg[u] = v;
     }
   };
-  auto store_b = [&](const uint4 (&breg)[B_PER_THREAD], int buf) __attribute__((always_inline)) {
+  auto store_b = [&](const uint4 (&breg)[B_PER_THREAD], int gstep) __attribute__((always_inline)) {  // panel of group `gstep`
+    const int buf = gstep & 1;
+    const int grp = gstep % ngroups;
 #pragma unroll
     for (int u = 0; u < B_PER_THREAD; ++u) {
       const int item = tid + u * NT;
       const int gi = item / (BN * 4), rem = item % (BN * 4);
       const int row = rem >> 2, qq = rem & 3;
+      const bool ok = (grp * G + gi < T_taps) & (cb * BN + row < cout_pad);  // out-of-range rows / taps were loaded from a clamped address
+      uint4 v = breg[u];
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
       if (item < B_ITEMS)
-        *reinterpret_cast<uint4*>(ldsB + ((size_t)(buf * G + gi) * BN + row) * FAST_ROWB + ((qq ^ fast_swz(row)) << 4)) = breg[u];
+        *reinterpret_cast<uint4*>(ldsB + ((size_t)(buf * G + gi) * BN + row) * FAST_ROWB + ((qq ^ fast_swz(row)) << 4)) = v;
     }
   };
 
@@ -164,8 +172,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
 #pragma unroll
       for (int u = 0; u < A_BATCH; ++u) {
         raw[u] = make_uint4(0, 0, 0, 0);
-        if (jb + u < MAX_ITEMS && vox[jb + u] >= 0 && cok)
-          raw[u] = *reinterpret_cast<const uint4*>(xin + (long long)vox[jb + u] * p.x_ld + c0);
+        if (jb + u < MAX_ITEMS) {  // compile-time; the load itself is branch-free (clamped address + select, see load_b)
+          const bool ok = (vox[jb + u] >= 0) & cok;
+          const long long vv = ok ? vox[jb + u] : 0;
+          const uint4 v = *reinterpret_cast<const uint4*>(xin + vv * p.x_ld + (cok ? c0 : 0));
+          raw[u].x = ok ? v.x : 0u; raw[u].y = ok ? v.y : 0u; raw[u].z = ok ? v.z : 0u; raw[u].w = ok ? v.w : 0u;
+        }
       }
 #pragma unroll
       for (int u = 0; u < A_BATCH; ++u) {
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
         if (++kw_i == p.kw) { kw_i = 0; if (++kh_i == p.kh) { kh_i = 0; ++kd_i; } }
       }
     }
-    if (gstep + 1 < total_gsteps) store_b(r_next, (gstep + 1) & 1);
+    if (gstep + 1 < total_gsteps) store_b(r_next, gstep + 1);
     __syncthreads();
     if (++grp == ngroups) { grp = 0; ++chunk; kd_i = kh_i = kw_i = 0; }
   };

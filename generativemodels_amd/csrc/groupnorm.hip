@@ -205,14 +205,56 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// 16-byte vector variant: one lane = 8 bf16 / 4 fp32 consecutive channels of one voxel (HBM-bound: read + write once)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y,
+                                                          long long y_ld, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, long long V, int C, long long total_vec,
+                                                          int act) {
+  const int CV = C / VEC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / CV;
+    const int c = (int)(i - row * CV) * VEC;
+    const long long n = row / V;
+    float v[VEC];
+    VecLd<T, VEC>::ld(x + row * x_ld + c, v);
+    const float* sc = scale + n * C + c;
+    const float* sh = shift + n * C + c;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float t = v[k] * sc[k] + sh[k];
+      if (act == 1) t = sizeof(T) == 4 ? gm_silu_precise(t) : gm_silu(t);
+      v[k] = t;
+    }
+    if (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(y + row * y_ld + c) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      *reinterpret_cast<uint4*>(y + row * y_ld + c) =
+          make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4 % VEC], v[5 % VEC]), pack_bf16x2(v[6 % VEC], v[7 % VEC]));
+    }
+  }
+}
+
 extern "C" int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift,
                            int N, long long V, int C, int act, int dtype, void* stream) {
   GM_REQUIRE(x && y && scale && shift, "null pointer");
   const long long total = (long long)N * V * C;
   if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == GM_F32 ? 4 : 8;
+  const bool vec_ok = (C % vec == 0) && (x_ld % vec == 0) && (y_ld % vec == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0);
+  if (vec_ok && (dtype == GM_F32 || dtype == GM_BF16)) {
+    const long long tv = total / vec;
+    long long g = (tv + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (dtype == GM_F32)
+      gn_apply_vec_kernel<float, 4><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, V, C, tv, act);
+    else
+      gn_apply_vec_kernel<bf16_raw, 8><<<(int)g, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, V, C, tv, act);
+    GM_LAUNCH_CHECK();
+  }
   long long g = (total + 255) / 256;
   if (g > 4096) g = 4096;
-  hipStream_t st = (hipStream_t)stream;
   if (dtype == GM_F32)
     gn_apply_kernel<float><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, V, C, total, act);
   else if (dtype == GM_BF16)

@@ -153,9 +153,13 @@ class ResnetBlock(nn.Module):
             x = ops.resample2x(x, mode)
             h = ops.resample2x(h, mode)
             h = self.conv1.run(h, rowvec=temb_row)
-        else:
+        elif ops.fuse_gn_prologue(x):
             h = self.conv1.run(x, pre=pre1, pre_act="silu", rowvec=temb_row)
+        else:
+            h = self.conv1.run(ops.gn_apply(x, pre1[0], pre1[1], "silu"), rowvec=temb_row)
         pre2 = gn_prologue(self.norm2, h)
         shortcut = getattr(self, self.shortcut_name)
         skip = shortcut.run(x) if isinstance(shortcut, ConvP) else x
-        return self.conv2.run(h, pre=pre2, pre_act="silu", res=skip)
+        if ops.fuse_gn_prologue(h):
+            return self.conv2.run(h, pre=pre2, pre_act="silu", res=skip)
+        return self.conv2.run(ops.gn_apply(h, pre2[0], pre2[1], "silu"), res=skip)

@@ -310,9 +310,25 @@ def gn_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act: str
     n, c = x.shape[0], x.shape[-1]
     v = rows_of(x) // max(n, 1)
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    check(lib().gm_gn_apply(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), scale.data_ptr(), shift.data_ptr(), n, v, c,
-                            ACT[act], dt_code(x.dtype), _stream()), "gm_gn_apply")
+    _timed(f"gn_apply<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(2 * x.element_size() * x.numel()), shape=str(tuple(x.shape))),
+           lambda: check(lib().gm_gn_apply(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), scale.data_ptr(), shift.data_ptr(),
+                                           n, v, c, ACT[act], dt_code(x.dtype), _stream()), "gm_gn_apply"))
     return out
+
+
+# GroupNorm-apply + SiLU placement.  "prologue": inside the consumer convolution's patch staging (no normalised tensor in HBM).
+# "pass": one vectorised element-wise pass that writes the activated tensor, the convolution then runs without a prologue.
+# Measured on MI355X (tools/bench_conv.py): the in-kernel prologue is applied to every halo row (2.1-2.5x redundant) on the VALU
+# while the work-group's MFMAs wait, and costs ~3x the HBM-bound pass; "auto" therefore un-fuses for large bf16 tensors.
+GN_APPLY_POLICY = "auto"
+
+
+def fuse_gn_prologue(x: torch.Tensor) -> bool:
+    if GN_APPLY_POLICY == "prologue":
+        return True
+    if GN_APPLY_POLICY == "pass":
+        return False
+    return not (x.dtype == torch.bfloat16 and x.numel() >= (1 << 22) and x.shape[-1] % 8 == 0)
 
 
 def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
