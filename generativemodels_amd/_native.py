@@ -30,7 +30,7 @@ class GmConvDesc(C.Structure):
                 ("pd", C.c_int), ("ph", C.c_int), ("pw", C.c_int), ("dd", C.c_int), ("dh", C.c_int), ("dw", C.c_int),
                 ("in_mode", C.c_int), ("fd", C.c_int), ("fh", C.c_int), ("fw", C.c_int),
                 ("pre_act", C.c_int), ("post_act", C.c_int), ("dtype", C.c_int),
-                ("ltd", C.c_int), ("lth", C.c_int), ("ltw", C.c_int), ("cfg", C.c_int), ("debug_flags", C.c_int)]
+                ("ltd", C.c_int), ("lth", C.c_int), ("ltw", C.c_int), ("cfg", C.c_int), ("debug_flags", C.c_int), ("stats", c_vp)]
 
 
 class GmAttnDesc(C.Structure):
@@ -59,7 +59,9 @@ PROTOTYPES = {
     "gm_gn_workspace_bytes": (c_ll, [C.c_int, c_ll, C.c_int, C.c_int, C.c_int]),
     "gm_gn_scale_shift": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_vp, c_vp, C.c_int, c_vp]),
-    "gm_gn_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_gn_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_gn_channel_stats": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp, C.c_int, c_vp]),
+    "gm_gn_finalize_channels": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_ll, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gm_layernorm": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_float, C.c_int, c_vp]),
     "gm_conv_cfg_tile": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gm_conv_lds_bytes": (c_ll, [C.POINTER(GmConvDesc)]),

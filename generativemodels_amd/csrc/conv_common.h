@@ -27,7 +27,12 @@ struct GmConvDesc {
   int ltd, lth, ltw;              // log2 of the output tile dims
   int cfg;                        // tile configuration id (see dispatch)
   int debug_flags;                // 0 in production; bench-only ablation switches of conv_fast.hip
+  double* stats;                  // optional [GM_STAT_SLOTS][N][Cout][2] (sum, sum of squares) of the OUTPUT, fp64 atomics
 };
+
+// per-channel statistics are accumulated with fp64 atomics into GM_STAT_SLOTS copies (slot = tile index mod slots): with a
+// single copy every work-group of a launch hammers the same 2*C addresses and the L2 serialises them (~0.15 ms per launch)
+#define GM_STAT_SLOTS 64
 
 #define CONV_ROWB 80  // LDS row pitch in bytes: 64 B of operands + 16 B pad
 

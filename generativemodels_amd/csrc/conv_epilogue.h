@@ -81,9 +81,13 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
 // (the per-lane-4-channel store of conv_epilogue() wrote 32-byte fragments and cost ~half the kernel time on MI355X).
 // `lds` = this wave's private 64 x 144-byte scratch (the operand buffers are dead after the main loop's last barrier).
 // Requirements (checked by the caller): Cout, y_ld (and res_ld) multiples of 16/sizeof(T), 16-byte aligned bases.
+// Optionally accumulates, per lane, sum / sum of squares of the values it stores (st_s/st_q[pass][i] = channel
+// co_base + pass*NF_PER_PASS*16 + (lane&7)*VECW + i over this lane's rows) for the fused GroupNorm statistics.
 template <typename T, int MF, int NFR>
 __device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, int n, int m_base,
-                                                  int co_base, int od0, int oh0, int ow0, int lane) {
+                                                  int co_base, int od0, int oh0, int ow0, int lane,
+                                                  float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
+                                                  float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)]) {
   constexpr int VECW = 16 / (int)sizeof(T);
   constexpr int ROWB_E = 144;                                   // 128 B of channels + 16 B pad
   constexpr int NF_PER_PASS = 128 / (16 * (int)sizeof(T));      // 4 (bf16) or 2 (fp32) channel fragments per pass
@@ -147,6 +151,12 @@ __device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (
           raw = Vec16<T>::pack(o);
         }
         *reinterpret_cast<uint4*>(yout + vox * p.y_ld + co) = raw;
+        if (p.stats) {  // statistics of the values as stored (rounded to T), like a separate pass over the tensor would see them
+          float o[VECW];
+          Vec16<T>::unpack(raw, o);
+#pragma unroll
+          for (int i = 0; i < VECW; ++i) { st_s[pass][i] += o[i]; st_q[pass][i] += o[i] * o[i]; }
+        }
       }
     }
     if (pass + 1 < PASSES) __syncthreads();

@@ -256,7 +256,51 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
   if (ABLATE(16)) return;
   if (conv_epilogue_lds_ok<T>(p) && !ABLATE(32)) {
     // every wave passed the main loop's final barrier: the operand buffers are free; one 64 x 144 B scratch per wave
-    conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, lane);
+    constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
+    constexpr int CH_PER_PASS = 128 / (int)sizeof(T);
+    float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
+#pragma unroll
+    for (int e = 0; e < EPASSES; ++e)
+#pragma unroll
+      for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
+    conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, lane,
+                                  st_s, st_q);
+    if (p.stats) {
+      // fused GroupNorm statistics of the output: lanes sharing (lane & 7) hold the same channels for different rows
+      float* sst = reinterpret_cast<float*>(smem);  // [NWAVES][64 channels][2], after everyone left the transpose scratch
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < EPASSES; ++e)
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) {
+          float a = st_s[e][i], b2 = st_q[e][i];
+          a += __shfl_xor(a, 8, 64); b2 += __shfl_xor(b2, 8, 64);
+          a += __shfl_xor(a, 16, 64); b2 += __shfl_xor(b2, 16, 64);
+          a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64);
+          if (lane < 8) {
+            const int ch = e * CH_PER_PASS + lane * VECW + i;  // within this wave's 64 channels
+            sst[(wave * 64 + ch) * 2] = a;
+            sst[(wave * 64 + ch) * 2 + 1] = b2;
+          }
+        }
+      __syncthreads();
+      if (tid < BN) {
+        const int wn_c = tid >> 6, ch = tid & 63;
+        double a = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          a += (double)sst[((wn_c * WM + w) * 64 + ch) * 2];
+          b2 += (double)sst[((wn_c * WM + w) * 64 + ch) * 2 + 1];
+        }
+        const int co = cb * BN + tid;
+        if (co < p.Cout) {
+          const long long slot = (blockIdx.x / ncb) % GM_STAT_SLOTS;
+          double* dst = p.stats + ((slot * p.N + n) * p.Cout + co) * 2;
+          atomicAdd(dst, a);
+          atomicAdd(dst + 1, b2);
+        }
+      }
+    }
   } else {
     conv_epilogue<T, MF, NFR>(p, acc, n, wm * MF * 16, cb * BN + wn * NFR * 16, od0, oh0, ow0, l15, q);
   }

@@ -10,6 +10,7 @@
 // wave/LDS tree in fp64, block partials merged in fp64 in a fixed order -> deterministic and fp32-parity safe.
 #include "gm_common.h"
 
+#define GM_STAT_SLOTS 64  // see conv_common.h
 #define GN_THREADS 256
 #define GN_ROWS_PER_THREAD 64
 
@@ -41,7 +42,8 @@ template <> struct VecLd<bf16_raw, 1> {
 // grid (nblk, N).  partial[(n*nblk + blk)*G + g] = {sum, sumsq} (fp64) over rows [blk*rpb, (blk+1)*rpb) of sample n.
 template <typename T, int VEC>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, long long ld, long long V, int C,
-                                                             int G, int rows_per_block, double2* __restrict__ partial) {
+                                                             int G, int rows_per_block, double2* __restrict__ partial,
+                                                             double* __restrict__ chan_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int CV = C / VEC;              // channel vectors per row (<= GN_THREADS, checked on the host)
   const int R = GN_THREADS / CV;       // rows in flight
@@ -79,7 +81,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
     double a = 0.0, b = 0.0;
     for (int r = 0; r < R; ++r) { a += (double)part_s[(size_t)r * C + c]; b += (double)part_q[(size_t)r * C + c]; }
     ch_s[c] = a; ch_q[c] = b;
+    if (chan_out) {  // per-channel mode (fp64 atomics into [slots][N][C][2]): composable over channel concatenations
+      double* dst = chan_out + (((long long)(blk % GM_STAT_SLOTS) * gridDim.y + n) * C + c) * 2;
+      atomicAdd(dst, a);
+      atomicAdd(dst + 1, b);
+    }
   }
+  if (!partial) return;
   __syncthreads();
   const int cpg = C / G;
   for (int g = t; g < G; g += GN_THREADS) {
@@ -144,7 +152,7 @@ extern "C" long long gm_gn_workspace_bytes(int N, long long V, int C, int G, int
 
 template <typename T, int VEC>
 static int launch_gn_stats(const void* x, long long ld, int N, long long V, int C, int G, double2* ws, int* nblk_out,
-                           hipStream_t st) {
+                           hipStream_t st, double* chan_out = nullptr) {
   const int CV = C / VEC;
   const int R = GN_THREADS / CV;
   const int rpb = R * GN_ROWS_PER_THREAD;
@@ -152,7 +160,7 @@ static int launch_gn_stats(const void* x, long long ld, int N, long long V, int 
   const size_t smem = (size_t)R * C * 2 * sizeof(float) + (size_t)C * 2 * sizeof(double);
   *nblk_out = nblk;
   dim3 grid(nblk, N);
-  gn_stats_kernel<T, VEC><<<grid, GN_THREADS, smem, st>>>((const T*)x, ld, V, C, G, rpb, ws);
+  gn_stats_kernel<T, VEC><<<grid, GN_THREADS, smem, st>>>((const T*)x, ld, V, C, G, rpb, ws, chan_out);
   return 0;
 }
 
@@ -189,17 +197,78 @@ extern "C" int gm_gn_scale_shift(const void* x, long long ld, int N, long long V
   GM_LAUNCH_CHECK();
 }
 
+// Per-channel statistics: chan_out[n][c] += {sum, sum of squares} over the V voxels (zero-initialised by the caller).
+extern "C" int gm_gn_channel_stats(const void* x, long long ld, int N, long long V, int C, double* chan_out, int dtype, void* stream) {
+  GM_REQUIRE(x && chan_out, "null pointer");
+  GM_REQUIRE(N <= 65535, "batch too large");
+  if (N == 0 || V == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int vecmax = dtype == GM_F32 ? 4 : 8;
+  const bool vec_ok = (C % vecmax == 0) && (ld % vecmax == 0) && (((uintptr_t)x & 15) == 0);
+  GM_REQUIRE((vec_ok ? C / vecmax : C) <= GN_THREADS, "too many channels for gm_gn_channel_stats");
+  int nblk = 0;
+  if (dtype == GM_F32) {
+    if (vec_ok) launch_gn_stats<float, 4>(x, ld, N, V, C, 1, nullptr, &nblk, st, chan_out);
+    else launch_gn_stats<float, 1>(x, ld, N, V, C, 1, nullptr, &nblk, st, chan_out);
+  } else if (dtype == GM_BF16) {
+    if (vec_ok) launch_gn_stats<bf16_raw, 8>(x, ld, N, V, C, 1, nullptr, &nblk, st, chan_out);
+    else launch_gn_stats<bf16_raw, 1>(x, ld, N, V, C, 1, nullptr, &nblk, st, chan_out);
+  } else {
+    GM_FAIL(-2, "unsupported dtype");
+  }
+  GM_LAUNCH_CHECK();
+}
+
+// GroupNorm scale/shift from per-channel statistics of up to two channel-concatenated sources (C = C0 + C1).
+__global__ __launch_bounds__(64) void gn_finalize_channels_kernel(const double* __restrict__ s0, int C0, const double* __restrict__ s1,
+                                                                 int C1, int N, int G, long long V, float eps,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ scale, float* __restrict__ shift) {
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int lane = threadIdx.x;
+  const int C = C0 + C1, cpg = C / G;
+  double a = 0.0, b = 0.0;
+  for (int j = lane; j < cpg * GM_STAT_SLOTS; j += 64) {  // fixed summation order: deterministic given the slot contents
+    const int c = g * cpg + j % cpg, slot = j / cpg;
+    const double* src = c < C0 ? s0 + (((long long)slot * N + n) * C0 + c) * 2 : s1 + (((long long)slot * N + n) * C1 + (c - C0)) * 2;
+    a += src[0]; b += src[1];
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  const double cnt = (double)cpg * (double)V;
+  const double mean = a / cnt;
+  double var = b / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int j = lane; j < cpg; j += 64) {
+    const int c = g * cpg + j;
+    const double ga = gamma ? (double)gamma[c] : 1.0;
+    const double be = beta ? (double)beta[c] : 0.0;
+    scale[(long long)n * C + c] = (float)(rstd * ga);
+    shift[(long long)n * C + c] = (float)(be - mean * rstd * ga);
+  }
+}
+
+extern "C" int gm_gn_finalize_channels(const double* stats0, int C0, const double* stats1, int C1, int N, long long V, int G,
+                                       float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+  GM_REQUIRE(stats0 && scale && shift, "null pointer");
+  GM_REQUIRE(C1 == 0 || stats1, "second source without statistics");
+  GM_REQUIRE(G > 0 && (C0 + C1) % G == 0, "channels must be divisible by groups");
+  if (N == 0) return 0;
+  gn_finalize_channels_kernel<<<N * G, 64, 0, (hipStream_t)stream>>>(stats0, C0, stats1, C1, N, G, V, eps, gamma, beta, scale, shift);
+  GM_LAUNCH_CHECK();
+}
+
 // y[n, v, c] = act(x[n, v, c] * scale[n, c] + shift[n, c]);  act: 0 none, 1 SiLU
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y,
                                                       long long y_ld, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, long long V, int C, long long total,
-                                                      int act) {
+                                                      const float* __restrict__ shift, long long ss_ld, long long V, int C,
+                                                      long long total, int act) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long row = i / C;
     const int c = (int)(i - row * C);
     const long long n = row / V;
-    float v = ElemIO<T>::ld(x + row * x_ld + c) * scale[n * C + c] + shift[n * C + c];
+    float v = ElemIO<T>::ld(x + row * x_ld + c) * scale[n * ss_ld + c] + shift[n * ss_ld + c];
     if (act == 1) v = gm_silu_precise(v);
     ElemIO<T>::st(y + row * y_ld + c, v);
   }
@@ -209,8 +278,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y,
                                                           long long y_ld, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, long long V, int C, long long total_vec,
-                                                          int act) {
+                                                          const float* __restrict__ shift, long long ss_ld, long long V, int C,
+                                                          long long total_vec, int act) {
   const int CV = C / VEC;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (long long)gridDim.x * blockDim.x) {
     const long long row = i / CV;
@@ -218,8 +287,8 @@ __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__
     const long long n = row / V;
     float v[VEC];
     VecLd<T, VEC>::ld(x + row * x_ld + c, v);
-    const float* sc = scale + n * C + c;
-    const float* sh = shift + n * C + c;
+    const float* sc = scale + n * ss_ld + c;
+    const float* sh = shift + n * ss_ld + c;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       float t = v[k] * sc[k] + sh[k];
@@ -235,8 +304,9 @@ __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__
   }
 }
 
+// scale/shift rows are ss_ld floats apart (ss_ld >= C: a channel slice of a wider [N][C_total] table is a valid operand)
 extern "C" int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift,
-                           int N, long long V, int C, int act, int dtype, void* stream) {
+                           long long ss_ld, int N, long long V, int C, int act, int dtype, void* stream) {
   GM_REQUIRE(x && y && scale && shift, "null pointer");
   const long long total = (long long)N * V * C;
   if (total == 0) return 0;
@@ -248,17 +318,17 @@ extern "C" int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_l
     long long g = (tv + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
     if (dtype == GM_F32)
-      gn_apply_vec_kernel<float, 4><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, V, C, tv, act);
+      gn_apply_vec_kernel<float, 4><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, ss_ld, V, C, tv, act);
     else
-      gn_apply_vec_kernel<bf16_raw, 8><<<(int)g, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, V, C, tv, act);
+      gn_apply_vec_kernel<bf16_raw, 8><<<(int)g, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, ss_ld, V, C, tv, act);
     GM_LAUNCH_CHECK();
   }
   long long g = (total + 255) / 256;
   if (g > 4096) g = 4096;
   if (dtype == GM_F32)
-    gn_apply_kernel<float><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, V, C, total, act);
+    gn_apply_kernel<float><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, ss_ld, V, C, total, act);
   else if (dtype == GM_BF16)
-    gn_apply_kernel<bf16_raw><<<(int)g, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, V, C, total, act);
+    gn_apply_kernel<bf16_raw><<<(int)g, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, ss_ld, V, C, total, act);
   else GM_FAIL(-2, "unsupported dtype");
   GM_LAUNCH_CHECK();
 }

@@ -67,9 +67,10 @@ class ConvP(nn.Module):
         raise RuntimeError("ConvP is driven through the fused arena path (run), not called as a torch module")
 
 
-def gn_prologue(norm: nn.GroupNorm, x: torch.Tensor):
-    """(scale, shift) of a GroupNorm over arena tensor x, ready for a consumer's prologue."""
-    return ops.gn_scale_shift(x, norm.num_groups, norm.eps, norm.weight, norm.bias)
+def gn_prologue(norm: nn.GroupNorm, x):
+    """(scale, shift) of a GroupNorm over an arena tensor (or a VirtualCat of two), ready for a consumer's prologue. Built
+    from per-channel statistics: free when the producing convolution fused them into its epilogue."""
+    return ops.gn_scale_shift_composed(x, norm.num_groups, norm.eps, norm.weight, norm.bias)
 
 
 def lin(x: torch.Tensor, layer: nn.Linear, **fusion) -> torch.Tensor:
@@ -143,7 +144,11 @@ class ResnetBlock(nn.Module):
         else:
             setattr(self, shortcut_name, nn.Identity())
 
-    def run(self, x: torch.Tensor, temb_row: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def run(self, x, temb_row: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: arena tensor, or an ops.VirtualCat([h, skip]) (decoder half: the concatenation is never materialised)."""
+        cat = isinstance(x, ops.VirtualCat)
+        if cat and (self.up or self.down):
+            x, cat = x.materialise(), False
         pre1 = gn_prologue(self.norm1, x)
         if self.up or self.down:
             # resblock_updown variant: BOTH branches are resampled after norm1+SiLU (diffusion_model_unet.py:674-682);
@@ -152,14 +157,32 @@ class ResnetBlock(nn.Module):
             mode = "up" if self.up else "down"
             x = ops.resample2x(x, mode)
             h = ops.resample2x(h, mode)
-            h = self.conv1.run(h, rowvec=temb_row)
+            h = self.conv1.run(h, rowvec=temb_row, want_stats=True)
+        elif cat:
+            # the activated operand of conv1 is assembled by one GroupNorm-apply pass per part, straight into channel slices
+            xa = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            off = 0
+            for part in x.parts:
+                c = part.shape[-1]
+                ops.gn_apply(part, pre1[0][:, off:off + c], pre1[1][:, off:off + c], "silu", out=xa[..., off:off + c])
+                off += c
+            h = self.conv1.run(xa, rowvec=temb_row, want_stats=True)
         elif ops.fuse_gn_prologue(x):
-            h = self.conv1.run(x, pre=pre1, pre_act="silu", rowvec=temb_row)
+            h = self.conv1.run(x, pre=pre1, pre_act="silu", rowvec=temb_row, want_stats=True)
         else:
-            h = self.conv1.run(ops.gn_apply(x, pre1[0], pre1[1], "silu"), rowvec=temb_row)
+            h = self.conv1.run(ops.gn_apply(x, pre1[0], pre1[1], "silu"), rowvec=temb_row, want_stats=True)
         pre2 = gn_prologue(self.norm2, h)
         shortcut = getattr(self, self.shortcut_name)
-        skip = shortcut.run(x) if isinstance(shortcut, ConvP) else x
+        if not isinstance(shortcut, ConvP):
+            skip = x  # identity (never a VirtualCat: the decoder resnets always change width)
+        elif cat:
+            w, b = shortcut.conv.weight, shortcut.conv.bias
+            c0 = x.parts[0].shape[-1]
+            skip = ops.conv(x.parts[0], w, b, kernel=1, packed=ops.packed_conv_weight(w, x.dtype, cin_range=(0, c0)), cout=w.shape[0])
+            skip = ops.conv(x.parts[1], w, None, kernel=1, packed=ops.packed_conv_weight(w, x.dtype, cin_range=(c0, w.shape[1])),
+                            cout=w.shape[0], res=skip)
+        else:
+            skip = shortcut.run(x)
         if ops.fuse_gn_prologue(h):
-            return self.conv2.run(h, pre=pre2, pre_act="silu", res=skip)
-        return self.conv2.run(ops.gn_apply(h, pre2[0], pre2[1], "silu"), res=skip)
+            return self.conv2.run(h, pre=pre2, pre_act="silu", res=skip, want_stats=True)
+        return self.conv2.run(ops.gn_apply(h, pre2[0], pre2[1], "silu"), res=skip, want_stats=True)

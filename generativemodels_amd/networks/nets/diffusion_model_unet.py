@@ -136,7 +136,7 @@ class _Upsample(nn.Module):
         self.conv = ConvP(spatial_dims, num_channels, num_channels, 3, 1, 1)
 
     def run(self, x, temb_row=None):
-        return self.conv.run(x, upsample=True)
+        return self.conv.run(x, upsample=True, want_stats=True)
 
 
 class _Stage(nn.Module):
@@ -346,7 +346,7 @@ class DiffusionModelUNet(nn.Module):
 
             for st in self.up_blocks:
                 for j, rb in enumerate(st.resnets):
-                    h = rb.run(ops.concat_channels([h, skips.pop()]), temb(rb))
+                    h = rb.run(ops.VirtualCat([h, skips.pop()]), temb(rb))
                     h = st.attend(j, h, context)
                 if st.resampler_name == "upsampler":
                     us = st.upsampler

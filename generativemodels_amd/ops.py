@@ -140,12 +140,16 @@ def as_f32(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return _cached(param, "f32", make)
 
 
-def packed_conv_weight(weight: torch.Tensor, dtype: torch.dtype, transposed: bool = False) -> torch.Tensor:
-    """weight: nn.Conv{1,2,3}d / nn.Linear layout [Cout, Cin, *k] (or nn.ConvTranspose [Cin, Cout, *k]) -> MFMA panel layout."""
+def packed_conv_weight(weight: torch.Tensor, dtype: torch.dtype, transposed: bool = False, cin_range: Optional[tuple] = None) -> torch.Tensor:
+    """weight: nn.Conv{1,2,3}d / nn.Linear layout [Cout, Cin, *k] (or nn.ConvTranspose [Cin, Cout, *k]) -> MFMA panel layout.
+    cin_range = (lo, hi) packs only that slice of the input channels (a convolution over one part of a VirtualCat)."""
     require_device(weight)
 
     def make():
-        w = weight.detach().contiguous()
+        w = weight.detach()
+        if cin_range is not None:
+            w = w[:, cin_range[0]:cin_range[1]]
+        w = w.contiguous()
         k = list(w.shape[2:])
         while len(k) < 3:
             k.insert(0, 1)
@@ -156,7 +160,7 @@ def packed_conv_weight(weight: torch.Tensor, dtype: torch.dtype, transposed: boo
                                         k[2], int(transposed), _stream()), "gm_pack_conv_weight")
         return out
 
-    return _cached(weight, ("pack", dtype, transposed), make)
+    return _cached(weight, ("pack", dtype, transposed, cin_range), make)
 
 
 def packed_cat_weight(weights: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
@@ -305,15 +309,86 @@ def gn_scale_shift(x: torch.Tensor, groups: int, eps: float, gamma: Optional[tor
     return scale, shift
 
 
-def gn_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act: str = "none") -> torch.Tensor:
-    require_device(x, scale, shift)
+def gn_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act: str = "none", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x * scale[n, c] + shift[n, c]); scale/shift may be channel slices of a wider [N, C_total] table, `out` a channel
+    slice of a wider arena buffer (that is how a concatenated, activated operand is assembled without a copy pass)."""
+    require_device(x, scale, shift, out)
     n, c = x.shape[0], x.shape[-1]
     v = rows_of(x) // max(n, 1)
-    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    elif out.shape != x.shape or out.dtype != x.dtype:
+        raise ValueError("gn_apply: out must match x")
+    if scale.shape != (n, c) or shift.shape != (n, c) or scale.stride(1) != 1 or shift.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+        raise ValueError("gn_apply: scale/shift must be matching [N, C] (slices of) fp32 tables")
+    ss_ld = scale.stride(0) if n > 1 else max(scale.stride(0), c)
     _timed(f"gn_apply<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(2 * x.element_size() * x.numel()), shape=str(tuple(x.shape))),
            lambda: check(lib().gm_gn_apply(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), scale.data_ptr(), shift.data_ptr(),
-                                           n, v, c, ACT[act], dt_code(x.dtype), _stream()), "gm_gn_apply"))
+                                           ss_ld, n, v, c, ACT[act], dt_code(x.dtype), _stream()), "gm_gn_apply"))
     return out
+
+
+STAT_SLOTS = 64  # GM_STAT_SLOTS of include/gm_amd.h
+
+
+class VirtualCat:
+    """Channel concatenation that is never materialised (reference: torch.cat([h, skip], dim=1), diffusion_model_unet.py:1232,
+    1340,1461): its consumers read the parts directly."""
+
+    def __init__(self, parts: Sequence[torch.Tensor]):
+        self.parts = list(parts)
+        if len(self.parts) != 2:
+            raise ValueError("VirtualCat holds two parts")
+        a, b = self.parts
+        if a.shape[:-1] != b.shape[:-1] or a.dtype != b.dtype:
+            raise ValueError("VirtualCat parts must agree outside the channel dim")
+        self.shape = (*a.shape[:-1], a.shape[-1] + b.shape[-1])
+        self.dtype, self.device = a.dtype, a.device
+
+    def numel(self) -> int:
+        return math.prod(self.shape)
+
+    def materialise(self) -> torch.Tensor:
+        return concat_channels(self.parts)
+
+
+def channel_stats(x: torch.Tensor) -> torch.Tensor:
+    """fp64 [STAT_SLOTS, N, C, 2] per-channel (sum, sum of squares) partials of an arena tensor (sum over dim 0 = the statistics); cached on the tensor object (the fast convolution
+    kernels attach it to their outputs for free)."""
+    cached = getattr(x, "_gm_cstats", None)
+    if cached is not None:
+        return cached
+    require_device(x)
+    n, c = x.shape[0], x.shape[-1]
+    v = rows_of(x) // max(n, 1)
+    st = torch.zeros((STAT_SLOTS, n, c, 2), dtype=torch.float64, device=x.device)
+    _timed(f"gn_stats<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(x.element_size() * x.numel()), shape=f"N{n} V{v} C{c}"),
+           lambda: check(lib().gm_gn_channel_stats(x.data_ptr(), arena_ld(x), n, v, c, st.data_ptr(), dt_code(x.dtype), _stream()),
+                         "gm_gn_channel_stats"))
+    try:
+        x._gm_cstats = st
+    except Exception:  # pragma: no cover
+        pass
+    return st
+
+
+def gn_scale_shift_composed(x, groups: int, eps: float, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor]):
+    """GroupNorm (scale, shift) [N, C] of a tensor or a VirtualCat from per-channel statistics (fused into the producing
+    convolution's epilogue when available, else one stats pass per part)."""
+    parts = x.parts if isinstance(x, VirtualCat) else [x]
+    n = parts[0].shape[0]
+    v = rows_of(parts[0]) // max(n, 1)
+    cs = [p.shape[-1] for p in parts]
+    c = sum(cs)
+    if c % groups != 0:
+        raise ValueError("num_channels must be divisible by num_groups")
+    stats = [channel_stats(p) for p in parts]
+    scale = torch.empty((n, c), dtype=torch.float32, device=parts[0].device)
+    shift = torch.empty((n, c), dtype=torch.float32, device=parts[0].device)
+    check(lib().gm_gn_finalize_channels(stats[0].data_ptr(), cs[0], stats[1].data_ptr() if len(parts) > 1 else None,
+                                        cs[1] if len(parts) > 1 else 0, n, v, groups, float(eps), _ptr(as_f32(gamma)), _ptr(as_f32(beta)),
+                                        scale.data_ptr(), shift.data_ptr(), _stream()), "gm_gn_finalize_channels")
+    return scale, shift
 
 
 # GroupNorm-apply + SiLU placement.  "prologue": inside the consumer convolution's patch staging (no normalised tensor in HBM).
@@ -434,7 +509,8 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
          pad_hi=None, upsample: bool = False, transposed: bool = False, output_padding=0,
          pre: Optional[tuple] = None, pre_act: str = "none", rowvec: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, post_act: str = "none", out: Optional[torch.Tensor] = None,
-         packed: Optional[torch.Tensor] = None, cout: Optional[int] = None, force_cfg: Optional[int] = None) -> torch.Tensor:
+         packed: Optional[torch.Tensor] = None, cout: Optional[int] = None, force_cfg: Optional[int] = None,
+         want_stats: bool = False) -> torch.Tensor:
     """Fused convolution over an arena tensor x = (N, *spatial, Cin).
 
     kernel/stride/padding/dilation: int or per-axis tuples (len = number of spatial axes). `padding` is the low-side pad,
@@ -535,6 +611,11 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     d.pre_act, d.post_act, d.dtype = ACT[pre_act], POST_ACT[post_act], dt_code(dtype)
     d.debug_flags = _CONV_DEBUG_FLAGS
     _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
+    d.stats = None
+    if want_stats and d.cfg >= 5:  # only the fast stride-1 kernels fuse the output statistics into their epilogue
+        cst = torch.zeros((STAT_SLOTS, n, cout, 2), dtype=torch.float64, device=x.device)
+        d.stats = cst.data_ptr()
+        out._gm_cstats = cst
     if _PROFILE is None:
         check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward")
     else:

@@ -20,6 +20,7 @@ extern "C" {
 
 #define GM_F32 0
 #define GM_BF16 1
+#define GM_STAT_SLOTS 64   /* copies of a per-channel statistics table (spreads atomic contention); summed by the finaliser */
 
 int gm_abi_version(void);
 const char* gm_last_error(void);
@@ -80,8 +81,16 @@ long long gm_gn_workspace_bytes(int N, long long V, int C, int G, int dtype);
 int gm_gn_scale_shift(const void* x, long long ld, int N, long long V, int C, int G, float eps, const float* gamma,
                       const float* beta, float* scale, float* shift, float* mean, float* rstd, void* workspace, int dtype,
                       void* stream);
-int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift, int N,
-                long long V, int C, int act, int dtype, void* stream);
+/* scale/shift rows are ss_ld floats apart (a channel slice of a wider [N][C_total] table is a valid operand) */
+int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift, long long ss_ld,
+                int N, long long V, int C, int act, int dtype, void* stream);
+/* Composable form: per-channel {sum, sum of squares} in fp64 ([GM_STAT_SLOTS][N][C][2], zero-initialised by the caller; also produced by the
+ * fast convolution kernels' epilogue through GmConvDesc.stats), and the GroupNorm finalisation over up to two
+ * channel-concatenated sources -- torch.cat([h, skip]) followed by GroupNorm (diffusion_model_unet.py:1232 + 671) without ever
+ * materialising the concatenation. */
+int gm_gn_channel_stats(const void* x, long long ld, int N, long long V, int C, double* chan_out, int dtype, void* stream);
+int gm_gn_finalize_channels(const double* stats0, int C0, const double* stats1, int C1, int N, long long V, int G, float eps,
+                            const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
                  long long rows, int C, float eps, int dtype, void* stream);
 
@@ -114,6 +123,8 @@ typedef struct GmConvDesc {
   int ltd, lth, ltw;         /* log2 output tile dims; product must equal the configuration's voxel count */
   int cfg;                   /* tile configuration, see gm_conv_cfg_tile */
   int debug_flags;           /* must be 0 (bench-only ablation switches: results are wrong when set) */
+  double* stats;             /* optional, zero-initialised [GM_STAT_SLOTS][N][Cout][2]: per-channel sum / sum of squares of the
+                                stored output, accumulated by the fast stride-1 kernels (cfg >= 5) for the next GroupNorm */
 } GmConvDesc;
 int gm_conv_cfg_tile(int cfg, int* voxels, int* channels);
 long long gm_conv_lds_bytes(const GmConvDesc* d);

@@ -379,3 +379,43 @@ def test_vq_argmin_and_gather():
     # the reference returns x + (q - x) (straight-through form): equal to the code vector up to one fp32 rounding
     assert (_cf(q) - o["quantized"]).abs().max().item() <= 1e-6
     assert abs(0.25 * mse.item() - o["loss"].item()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_output_statistics_and_virtual_concat_groupnorm(dtype):
+    """GroupNorm over torch.cat([h, skip]) from per-channel statistics -- produced by the convolution epilogue for `h`, by a
+    stats pass for `skip` -- equals F.group_norm of the materialised concatenation; the activated operand is assembled by
+    per-part apply passes into channel slices (no concat copy)."""
+    ops = _ops()
+    n, cin, ch, cs, sp = 2, 16, 32, 16, (8, 8, 16)
+    x = _rand((n, cin, *sp), 91).to(dtype)
+    w = (_rand((ch, cin, 3, 3, 3), 92) / math.sqrt(cin * 27)).to(dtype)
+    b = _rand((ch,), 93) * 0.1
+    skip = (_rand((n, cs, *sp), 94) * 0.7 + 0.3).to(dtype)
+    h = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=3, padding=1, want_stats=True, force_cfg=8)
+    assert getattr(h, "_gm_cstats", None) is not None
+    fused = h._gm_cstats.sum(dim=0).cpu()
+    hd = _cf(h).double()
+    want = torch.stack([hd.sum(dim=(2, 3, 4)), (hd * hd).sum(dim=(2, 3, 4))], dim=-1)
+    assert torch.allclose(fused, want, rtol=1e-5, atol=1e-3), (fused - want).abs().max()
+    del h._gm_cstats
+    assert torch.allclose(ops.channel_stats(h).sum(dim=0).cpu(), want, rtol=1e-5, atol=1e-3)  # stand-alone per-channel pass agrees
+    sk = _cl(skip)
+    cat = ops.VirtualCat([h, sk])
+    groups = 8
+    gamma, beta = _rand((ch + cs,), 95) * 0.2 + 1.0, _rand((ch + cs,), 96) * 0.1
+    scale, shift = ops.gn_scale_shift_composed(cat, groups, 1e-6, gamma.to(DEV), beta.to(DEV))
+    xa = torch.empty(cat.shape, dtype=dtype, device=DEV)
+    ops.gn_apply(h, scale[:, :ch], shift[:, :ch], "silu", out=xa[..., :ch])
+    ops.gn_apply(sk, scale[:, ch:], shift[:, ch:], "silu", out=xa[..., ch:])
+    full = torch.cat([_cf(h), skip], dim=1).double()
+    want_act = F.silu(F.group_norm(full, groups, gamma.double(), beta.double(), 1e-6))
+    _check(_cf(xa), want_act, dtype, "virtual-concat GN+SiLU", extra=2.0)
+    assert torch.equal(cat.materialise().cpu(), torch.cat([h.cpu(), sk.cpu()], dim=-1))
+    # convolution over one part of the concatenation (split 1x1 skip path): W[:, :c0] h + W[:, c0:] s + b
+    w1 = (_rand((24, ch + cs), 97) / 7).to(dtype)
+    b1 = _rand((24,), 98) * 0.1
+    wd = w1.to(DEV)[:, :, None, None, None]
+    y = ops.conv(h, wd, b1.to(DEV), kernel=1, packed=ops.packed_conv_weight(wd, dtype, cin_range=(0, ch)), cout=24)
+    y = ops.conv(sk, wd, None, kernel=1, packed=ops.packed_conv_weight(wd, dtype, cin_range=(ch, ch + cs)), cout=24, res=y)
+    _check(_cf(y), F.conv3d(full, w1.double()[:, :, None, None, None], b1.double()), dtype, "split 1x1 conv over a virtual concat", extra=2.0)
