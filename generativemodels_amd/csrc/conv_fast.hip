@@ -217,7 +217,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
       if (!(ABLATE(1))) stage_a(chunk);  // every wave passed the barrier that ended the previous chunk
       __syncthreads();
     }
-    if (gstep + 2 < total_gsteps && !(ABLATE(2))) load_b(r_far, gstep + 2);
     const char* bsrc = ldsB + (size_t)((gstep & 1) * G) * BN * FAST_ROWB;
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -237,12 +236,22 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
           for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[nf][mf]);
+#ifndef GM_CONV_NO_SCHED
+          // issue ALL operand reads of the tap before its first MFMA: under the 128-VGPR cap the scheduler otherwise funnels the
+          // four weight fragments through one register quad (read -> wait -> 2 MFMAs, four times = four exposed LDS latencies)
+          __builtin_amdgcn_sched_group_barrier(0x100, MF + NFR, 0);                               // DS reads
+          __builtin_amdgcn_sched_group_barrier(0x008, MF * NFR * (sizeof(T) == 2 ? 1 : 4), 0);   // MFMAs
+#endif
         } else {
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) asm volatile("" ::"v"(xf[mf].x), "v"(xf[mf].w), "v"(wf[mf].x), "v"(wf[mf].w));
         }
         if (++kw_i == p.kw) { kw_i = 0; if (++kh_i == p.kh) { kh_i = 0; ++kd_i; } }
       }
+      // the weight-panel prefetch is issued AFTER the group's first tap: hipcc guards the first operand read of a group with a
+      // conservative `s_waitcnt vmcnt(0)` (register re-use after the patch-staging loads); issued before it, the prefetch was
+      // drained on the spot and its latency exposed
+      if (u == 0 && gstep + 2 < total_gsteps && !(ABLATE(2))) load_b(r_far, gstep + 2);
     }
     if (gstep + 1 < total_gsteps) store_b(r_next, gstep + 1);
     __syncthreads();
