@@ -278,7 +278,7 @@ extern "C" long long gm_conv_fast_max_patch(int wn);
 extern "C" int gm_conv_fast_launch(const GmConvDesc* dp, int wn, unsigned nblocks, void* stream);
 #define CONV_CFG_FAST64 5
 #define CONV_CFG_FAST128 6
-#define CONV_CFG_FAST_LAST 9
+#define CONV_CFG_FAST_LAST 10
 extern "C" int gm_conv_fast_variant_geometry(int variant, int* voxels, int* channels, int* threads);
 static inline bool conv_is_fast(int cfg) { return cfg >= CONV_CFG_FAST64 && cfg <= CONV_CFG_FAST_LAST; }
 static inline int conv_fast_variant(int cfg) { return cfg - CONV_CFG_FAST64 + 1; }

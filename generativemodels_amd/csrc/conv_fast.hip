@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
   constexpr int BM = WM * MF * 16;
   constexpr int BN = WN * 64;
   constexpr int ROWS_PER_PASS = NT / 4;
-  constexpr int MAX_ITEMS = NT == 256 ? 12 : (NT == 512 ? (BM == 512 ? 10 : 6) : 3);  // patch rows per thread (host: P <= MAX_ITEMS * ROWS_PER_PASS)
+  constexpr int MAX_ITEMS = NT == 256 ? 12 : (NT == 512 ? (BM == 512 ? 10 : 6) : (BM == 512 ? 5 : 3));  // patch rows per thread (host: P <= MAX_ITEMS * ROWS_PER_PASS)
   constexpr int A_BATCH = MINW >= 4 ? 2 : (MAX_ITEMS >= 10 ? (MAX_ITEMS + 1) / 2 : MAX_ITEMS);  // patch loads in flight per thread (128-VGPR variants: 3)
   constexpr bool PRECISE = sizeof(T) == 4;
 
@@ -325,7 +325,7 @@ extern "C" long long gm_conv_fast_lds_bytes(const GmConvDesc* d, int bn) {
 
 // variant: 1 = 256 voxels x 64 ch (4 waves), 2 = 256 voxels x 128 ch (8 waves), 3 = 512 voxels x 64 ch (8 waves)
 extern "C" long long gm_conv_fast_max_patch(int variant) {
-  switch (variant) { case 1: return 12 * 64; case 2: return 6 * 128; case 3: return 10 * 128; case 4: return 6 * 128; case 5: return 3 * 256; default: return 0; }
+  switch (variant) { case 1: return 12 * 64; case 2: return 6 * 128; case 3: return 10 * 128; case 4: return 6 * 128; case 5: return 3 * 256; case 6: return 5 * 256; default: return 0; }
 }
 
 template <typename T, int WM, int WN, int MF, int MINW>
@@ -348,13 +348,14 @@ static int dispatch_fast(const GmConvDesc& d, int variant, size_t smem, unsigned
     case 3: launch_fast<T, 8, 1, 4, 2>(d, smem, nblocks, st); return 0;   // 512 vox x  64 ch,  8 waves, 1 WG/CU
     case 4: launch_fast<T, 8, 1, 2, 4>(d, smem, nblocks, st); return 0;   // 256 vox x  64 ch,  8 waves, 2 WG/CU (16 waves/CU)
     case 5: launch_fast<T, 8, 2, 2, 4>(d, smem, nblocks, st); return 0;   // 256 vox x 128 ch, 16 waves, 1 WG/CU
+    case 6: launch_fast<T, 16, 1, 2, 4>(d, smem, nblocks, st); return 0;  // 512 vox x  64 ch, 16 waves, 1 WG/CU
     default: return -3;
   }
 }
 
 extern "C" int gm_conv_fast_variant_geometry(int variant, int* voxels, int* channels, int* threads) {
-  static const int g[6][3] = {{0, 0, 0}, {256, 64, 256}, {256, 128, 512}, {512, 64, 512}, {256, 64, 512}, {256, 128, 1024}};
-  if (variant < 1 || variant > 5) return -1;
+  static const int g[7][3] = {{0, 0, 0}, {256, 64, 256}, {256, 128, 512}, {512, 64, 512}, {256, 64, 512}, {256, 128, 1024}, {512, 64, 1024}};
+  if (variant < 1 || variant > 6) return -1;
   *voxels = g[variant][0]; *channels = g[variant][1]; *threads = g[variant][2];
   return 0;
 }

@@ -483,9 +483,10 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
     elif cout <= 16:
         order = [3, 4, 2]
     elif cout <= 64:
-        order = [8, 5, 0, 4, 2]   # 16 waves/CU on 256x64 tiles measured best at every C2 shape (tools/bench_conv.py)
+        # 16 waves per CU measured best at every C2 shape (tools/bench_conv.py); 512-voxel tiles once there are >= 8 tiles per CU
+        order = [10, 8, 5, 0, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [8, 5, 0, 4, 2]
     else:
-        order = [9, 6, 1, 4, 2]
+        order = [10, 9, 6, 1, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [9, 6, 1, 4, 2]
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
         order = [c for c in order if _cfg_tile(c)[0] <= 64] + [c for c in order if _cfg_tile(c)[0] > 64]
     best = None

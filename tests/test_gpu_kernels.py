@@ -239,7 +239,7 @@ def test_conv_geometries(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_conv_every_tile_configuration(cfg, dtype):
     ops = _ops()
     x = _rand((1, 24, 9, 10, 11), 21).to(dtype)
