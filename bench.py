@@ -46,6 +46,30 @@ def rerandomize_zero_params(state_dict, seed=1234, std=0.05):
     return state_dict
 
 
+# conv_fast_kernel<T, WM, WN, MF, MINW> instantiation behind each fast cfg (csrc/conv_fast.hip dispatch_fast)
+FAST_CFG_TEMPLATE = {5: "4, 1, 4, 2", 6: "4, 2, 4, 2", 7: "8, 1, 4, 2", 8: "8, 1, 2, 4", 9: "8, 2, 2, 4", 10: "16, 1, 2, 4"}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_per_kernel.json")
+
+
+def measured_hbm_traffic(label: str, dtype) -> dict:
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same bench command; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md, WRITE_SIZE calibrated 1:1 on the copy kernel).  Counters cannot be collected inside the timed run,
+    so the figure is read from profiles/; null when no committed pass covers this kernel."""
+    try:
+        cfg = int(label.split("cfg")[1].rstrip(">"))
+        rows = json.load(open(TRAFFIC_FILE))
+    except Exception:
+        return dict(traffic=None)
+    elem = "unsigned short" if dtype == torch.bfloat16 else "float"
+    sym = (f"conv_fast_kernel<{elem}, {FAST_CFG_TEMPLATE[cfg]}>" if cfg in FAST_CFG_TEMPLATE else None)
+    for r in rows:
+        if sym is not None and sym in r["kernel"]:
+            return dict(traffic=round(r["hbm_mb_per_launch_corrected"] * 1e6), traffic_unit="bytes/launch (avg over the same launches)",
+                        traffic_source=os.path.relpath(TRAFFIC_FILE, ROOT), traffic_launches_sampled=r["launches"])
+    return dict(traffic=None)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +167,9 @@ def main() -> None:
                         launches=b["launches"], avg_launch_ms=round(b["ms"] / b["launches"], 4),
                         algorithmic_gflop_per_launch=round(b["flops"] / b["launches"] / 1e9, 2),
                         algorithmic_mb_per_launch=round(b["bytes"] / b["launches"] / 1e6, 2))
+
+        if roof is not None:
+            roof.update(measured_hbm_traffic(roof["kernel"], dtype))
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----------------------------------------------------
     cpu = None

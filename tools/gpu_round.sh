@@ -25,13 +25,11 @@ fi
 if [[ $STAGES == *b* ]]; then
   timeout 300 python bench.py --size 32 --steps 1 --warmup 1 --inference-steps 4 --cpu-baseline small --graph 0 > $OUT/bench_small.log 2>&1
   echo "bench_small rc=$?" >> $OUT/round.log; tail -c 1500 $OUT/bench_small.log >> $OUT/round.log
-  true
-  echo "bench_nograph rc=$?" >> $OUT/round.log; tail -c 3000 $OUT/bench_nograph.log >> $OUT/round.log
-  timeout 1200 python bench.py --steps 2 --warmup 1 --graph 1 > $OUT/bench_graph.log 2>&1; timeout 1200 python bench.py --steps 2 --warmup 1 > $OUT/bench.log 2>&1
+  timeout 1200 python bench.py --steps 2 --warmup 1 > $OUT/bench.log 2>&1
   echo "bench rc=$?" >> $OUT/round.log; tail -c 3000 $OUT/bench.log >> $OUT/round.log
 fi
 if [[ $STAGES == *p* ]]; then
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 0 --graph 0 --cpu-baseline off --inference-steps 5 > $OLDPWD/$OUT/prof.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 0 --graph 0 --cpu-baseline off > $OLDPWD/$OUT/prof.log 2>&1)
   echo "prof rc=$?" >> $OUT/round.log
   find $OUT/prof -name "*kernel_stats*" | head -3 >> $OUT/round.log
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" >> $OUT/round.log
