@@ -21,6 +21,12 @@ class GmStepParams(C.Structure):
                 ("min_log", C.c_float), ("max_log", C.c_float)]
 
 
+class GmKlParams(C.Structure):
+    _fields_ = [("pred_type", C.c_int), ("c_sa", C.c_float), ("c_sb", C.c_float), ("clip", C.c_int), ("k0", C.c_float),
+                ("k1", C.c_float), ("m0", C.c_float), ("m1", C.c_float), ("t0", C.c_int), ("s", C.c_float), ("e", C.c_float),
+                ("half_bin", C.c_float)]
+
+
 class GmConvDesc(C.Structure):
     _fields_ = [("x", c_vp), ("x_ld", c_ll), ("w", c_vp), ("bias", c_vp), ("pre_scale", c_vp), ("pre_shift", c_vp),
                 ("rowvec", c_vp), ("rowvec_bstride", c_ll), ("res", c_vp), ("res_ld", c_ll), ("y", c_vp), ("y_ld", c_ll),
@@ -46,6 +52,8 @@ PROTOTYPES = {
     "gm_last_error": (C.c_char_p, []),
     "gm_sched_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, C.c_int, C.POINTER(GmStepParams), c_vp]),
     "gm_axpby_rows": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, C.c_int, c_vp]),
+    "gm_likelihood_term": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, C.c_int, C.POINTER(GmKlParams), c_vp]),
+    "gm_lincomb": (C.c_int, [C.POINTER(c_vp), C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, c_vp, c_ll, C.c_int, c_vp]),
     "gm_copy_channels": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp]),
     "gm_nchw_to_nhwc": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_ll, c_vp]),
     "gm_nhwc_to_nchw": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_vp]),

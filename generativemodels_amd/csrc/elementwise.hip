@@ -1,6 +1,8 @@
 // Element-wise / data-movement kernels of the sampling path (all HBM-bound; graded against the 8 TB/s roof).
 //   gm_sched_step      fused DDIM / DDPM reverse step      (reference: networks/schedulers/ddim.py:156-237, ddpm.py:191-252)
 //   gm_axpby_rows      add_noise / get_velocity            (reference: networks/schedulers/scheduler.py:169-200)
+//   gm_lincomb         PNDM multi-step combinations        (reference: networks/schedulers/pndm.py:186-195,241-250)
+//   gm_likelihood_term one term of get_likelihood's bound  (reference: inferers/inferer.py:203-256,281-321)
 //   gm_cast, gm_copy_channels, gm_nchw_to_nhwc, gm_nhwc_to_nchw, gm_resample2x   layout plumbing of the NDHWC arena
 //   gm_timestep_embedding                                   (reference: networks/nets/diffusion_model_unet.py:461-485)
 //   gm_geglu                                                (MONAI MLPBlock act="GEGLU" as used at diffusion_model_unet.py:211)
@@ -13,7 +15,7 @@
 // step is bit-identical to the reference CPU result.  bf16 tensors are computed in fp32 and rounded once.
 // ---------------------------------------------------------------------------------------------------------------------
 struct GmStepParams {
-  int mode;       // 0 = DDIM, 1 = DDPM
+  int mode;       // 0 = DDIM, 1 = DDPM, 2 = PNDM transfer (formula (9): k0*x - (k1*e)/c_prev, e = model output or its v-prediction transform)
   int pred_type;  // 0 epsilon, 1 sample, 2 v_prediction
   float c_sa;     // alpha_prod_t ** 0.5
   float c_sb;     // beta_prod_t ** 0.5
@@ -37,6 +39,11 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const T* __restrict__ s
     const long long n = i / inner, r = i - n * inner;
     const float s = ElemIO<T>::ld(sample + i);
     const float m = ElemIO<T>::ld(mo + n * mo_bstride + r);
+    if (p.mode == 2) {  // PNDMScheduler._get_prev_sample (pndm.py:276-316), same op order
+      const float e = (p.pred_type == 2) ? __fadd_rn(__fmul_rn(p.c_sa, m), __fmul_rn(p.c_sb, s)) : m;
+      ElemIO<T>::st(prev + i, __fsub_rn(__fmul_rn(p.k0, s), __fdiv_rn(__fmul_rn(p.k1, e), p.c_prev)));
+      continue;
+    }
     float x0, eps;
     if (p.pred_type == 0) {
       x0 = __fdiv_rn(__fsub_rn(s, __fmul_rn(p.c_sb, m)), p.c_sa);
@@ -104,6 +111,166 @@ extern "C" int gm_sched_step(const void* sample, const void* model_output, const
                                                                 inner, mo_bstride, total, *p);
   else
     GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+// out = post_mul * (((c0*x0 + c1*x1) + c2*x2) + c3*x3) / post_div, left to right, every op rounded (no contraction): the
+// linear multi-step / Runge-Kutta combinations of PNDMScheduler (pndm.py:186-195,241-250).  post_mul / post_div of 1 are skipped
+// (x*1 and x/1 are exact anyway).  x0 may be null (the reference's integer-0 accumulator: 0 + t == t exactly).
+struct GmLincomb {
+  const void* x[4];
+  float c[4];
+  int k;
+  float post_mul, post_div;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void lincomb_kernel(GmLincomb a, T* __restrict__ out, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float acc = 0.0f;
+    bool first = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < a.k && a.x[j]) {
+        const float t = __fmul_rn(a.c[j], ElemIO<T>::ld((const T*)a.x[j] + i));
+        acc = first ? t : __fadd_rn(acc, t);
+        first = false;
+      }
+    }
+    if (a.post_mul != 1.0f) acc = __fmul_rn(a.post_mul, acc);
+    if (a.post_div != 1.0f) acc = __fdiv_rn(acc, a.post_div);
+    ElemIO<T>::st(out + i, acc);
+  }
+}
+
+extern "C" int gm_lincomb(const void* const* x, const float* c, int k, float post_mul, float post_div, void* out, long long n,
+                          int dtype, void* stream) {
+  GM_REQUIRE(x && c && out, "null pointer");
+  GM_REQUIRE(k >= 1 && k <= 4, "1..4 terms");
+  if (n == 0) return 0;
+  GmLincomb a;
+  bool any = false;
+  for (int j = 0; j < 4; ++j) {
+    a.x[j] = j < k ? x[j] : nullptr;
+    a.c[j] = j < k ? c[j] : 0.0f;
+    any |= a.x[j] != nullptr;
+  }
+  GM_REQUIRE(any, "all terms are null");
+  a.k = k;
+  a.post_mul = post_mul;
+  a.post_div = post_div;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32)
+    lincomb_kernel<float><<<ew_grid(n), 256, 0, st>>>(a, (float*)out, n);
+  else if (dtype == GM_BF16)
+    lincomb_kernel<bf16_raw><<<ew_grid(n), 256, 0, st>>>(a, (bf16_raw*)out, n);
+  else
+    GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One term of the variational bound (DiffusionInferer.get_likelihood, inferer.py:203-256): per element the predicted mean
+// (DDPM formula (7) from the model output), the true posterior mean q(x_{t-1}|x_t,x_0), and either KL(q || p) between the two
+// Gaussians (t > 0) or the discretised-Gaussian decoder NLL (t == 0, inferer.py:281-321); per sample the mean over elements is
+// accumulated into total[n].  All scalar sub-expressions are evaluated on the host as the reference evaluates them (0-dim
+// fp32 torch-CPU tensors) and passed by value.
+// ---------------------------------------------------------------------------------------------------------------------
+struct GmKlParams {
+  int pred_type;      // 0 epsilon, 1 sample, 2 v_prediction
+  float c_sa, c_sb;   // alpha_prod_t ** 0.5, beta_prod_t ** 0.5
+  int clip;           // clamp predicted x0 to [-1, 1] (inferer.py:222-223)
+  float k0, k1;       // predicted mean = k0 * pred_x0 + k1 * x_t
+  float m0, m1;       // posterior mean = m0 * x_0 + m1 * x_t        (ddpm.py:151-154)
+  int t0;             // 1: decoder NLL, 0: KL between normals
+  float s;            // KL: (-1 + log_pred_var - log_post_var) + exp(log_post_var - log_pred_var)
+  float e;            // KL: exp(-log_pred_var);   NLL: inv_stdv = exp(-log_scales)
+  float half_bin;     // NLL: bin_width / 2
+};
+
+__device__ __forceinline__ float approx_std_normal_cdf(float x, float c) {
+  const float x3 = __fmul_rn(__fmul_rn(x, x), x);  // torch.pow(x, 3) is x*x*x
+  return __fmul_rn(0.5f, __fadd_rn(1.0f, tanhf(__fmul_rn(c, __fadd_rn(x, __fmul_rn(0.044715f, x3))))));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void likelihood_kl_kernel(const T* __restrict__ x0, const T* __restrict__ xt,
+                                                           const T* __restrict__ mo, T* __restrict__ kl_out,
+                                                           double* __restrict__ rowsum, long long inner,
+                                                           long long mo_bstride, GmKlParams p, float cdf_c) {
+  const long long n = blockIdx.y;
+  __shared__ double part[4];
+  double acc = 0.0;
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < inner; r += (long long)gridDim.x * blockDim.x) {
+    const long long i = n * inner + r;
+    const float x = ElemIO<T>::ld(x0 + i), s = ElemIO<T>::ld(xt + i), m = ElemIO<T>::ld(mo + n * mo_bstride + r);
+    float px0;
+    if (p.pred_type == 0)
+      px0 = __fdiv_rn(__fsub_rn(s, __fmul_rn(p.c_sb, m)), p.c_sa);
+    else if (p.pred_type == 1)
+      px0 = m;
+    else
+      px0 = __fsub_rn(__fmul_rn(p.c_sa, s), __fmul_rn(p.c_sb, m));
+    if (p.clip) px0 = fminf(fmaxf(px0, -1.0f), 1.0f);
+    const float pmean = __fadd_rn(__fmul_rn(p.k0, px0), __fmul_rn(p.k1, s));
+    float kl;
+    if (!p.t0) {
+      const float qmean = __fadd_rn(__fmul_rn(p.m0, x), __fmul_rn(p.m1, s));
+      const float d = __fsub_rn(qmean, pmean);
+      kl = __fmul_rn(0.5f, __fadd_rn(p.s, __fmul_rn(__fmul_rn(d, d), p.e)));
+    } else {
+      const float cx = __fsub_rn(x, pmean);
+      const float cdf_plus = approx_std_normal_cdf(__fmul_rn(p.e, __fadd_rn(cx, p.half_bin)), cdf_c);
+      const float cdf_min = approx_std_normal_cdf(__fmul_rn(p.e, __fsub_rn(cx, p.half_bin)), cdf_c);
+      float lp;
+      if (x < -0.999f)
+        lp = logf(fmaxf(cdf_plus, 1e-12f));
+      else if (x > 0.999f)
+        lp = logf(fmaxf(__fsub_rn(1.0f, cdf_min), 1e-12f));
+      else
+        lp = logf(fmaxf(__fsub_rn(cdf_plus, cdf_min), 1e-12f));
+      kl = -lp;
+    }
+    if (kl_out) {
+      ElemIO<T>::st(kl_out + i, kl);
+      kl = ElemIO<T>::ld(kl_out + i);  // the mean is taken over the stored (dtype-rounded) map, as the reference does
+    }
+    acc += (double)kl;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(rowsum + n, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void likelihood_fold_kernel(double* __restrict__ rowsum, float* __restrict__ total, long long batch, double inv_inner) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < batch) {
+    total[n] += (float)(rowsum[n] * inv_inner);
+    rowsum[n] = 0.0;  // ready for the next term
+  }
+}
+
+extern "C" int gm_likelihood_term(const void* x0, const void* xt, const void* model_output, void* kl, float* total,
+                                  double* workspace, long long batch, long long inner, long long mo_bstride, int dtype,
+                                  const GmKlParams* p, void* stream) {
+  GM_REQUIRE(x0 && xt && model_output && total && workspace && p, "null pointer");
+  if (batch * inner == 0) return 0;
+  GM_REQUIRE(batch <= 65535, "batch too large");
+  hipStream_t st = (hipStream_t)stream;
+  const float cdf_c = sqrtf((float)(2.0 / 3.14159265358979323846));  // torch.sqrt(torch.Tensor([2.0 / math.pi]))
+  long long gx = (inner + 255) / 256;
+  if (gx > 2048) gx = 2048;
+  dim3 grid((unsigned)gx, (unsigned)batch);
+  if (dtype == GM_F32)
+    likelihood_kl_kernel<float><<<grid, 256, 0, st>>>((const float*)x0, (const float*)xt, (const float*)model_output,
+                                                      (float*)kl, workspace, inner, mo_bstride, *p, cdf_c);
+  else if (dtype == GM_BF16)
+    likelihood_kl_kernel<bf16_raw><<<grid, 256, 0, st>>>((const bf16_raw*)x0, (const bf16_raw*)xt, (const bf16_raw*)model_output,
+                                                         (bf16_raw*)kl, workspace, inner, mo_bstride, *p, cdf_c);
+  else
+    GM_FAIL(-2, "unsupported dtype");
+  likelihood_fold_kernel<<<(unsigned)((batch + 63) / 64), 64, 0, st>>>(workspace, total, batch, 1.0 / (double)inner);
   GM_LAUNCH_CHECK();
 }
 

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .._native import GmKlParams
 from ..networks.nets import VQVAE, DiffusionModelUNet
 
 try:  # progress bar is optional, like in the reference (inferer.py:28)
@@ -106,12 +107,76 @@ class DiffusionInferer(Inferer):
                 if graphed is None:
                     graphed = _GraphedUNet(diffusion_model, model_input, tt, ctx)
                 model_output = graphed(model_input, tt)
+                if getattr(scheduler, "keeps_model_outputs", False):
+                    model_output = model_output.clone()  # the graph's static output buffer is overwritten by the next replay
             else:
                 model_output = diffusion_model(model_input, timesteps=tt, context=ctx)
             image, _ = scheduler.step(model_output, t, image)
             if save_intermediates and t % intermediate_steps == 0:
                 intermediates.append(image)
         return (image, intermediates) if save_intermediates else image
+
+    @torch.no_grad()
+    def get_likelihood(self, inputs: torch.Tensor, diffusion_model: Callable[..., torch.Tensor],
+                       scheduler: Callable[..., torch.Tensor] | None = None, save_intermediates: bool | None = False,
+                       conditioning: torch.Tensor | None = None, mode: str = "crossattn",
+                       original_input_range: tuple | None = (0, 255), scaled_input_range: tuple | None = (0, 1),
+                       verbose: bool = True, seg: torch.Tensor | None = None, _noise: torch.Tensor | None = None):
+        """Variational bound on -log p(x) per sample (reference inferer.py:145-256): for every t of the scheduler, noise the
+        inputs to t with ONE fixed noise draw, predict, and add KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) -- the discretised
+        decoder NLL at t = 0 -- averaged over elements.  Returns total_kl (N,) fp32, plus the per-step maps (CPU tensors, as
+        the reference) when `save_intermediates`.  Per step: add_noise kernel + UNet forward + ONE fused kernel
+        (gm_likelihood_term) instead of ~40 element-wise launches.  `_noise` (not in the reference) lets tests fix the draw."""
+        if not scheduler:
+            scheduler = self.scheduler
+        if scheduler._get_name() != "DDPMScheduler":
+            raise NotImplementedError(f"Likelihood computation is only compatible with DDPMScheduler, you are using {scheduler._get_name()}")
+        _check_mode(mode)
+        ops.require_device(inputs)
+        steps = [int(t) for t in torch.as_tensor(scheduler.timesteps).cpu().tolist()]
+        it = tqdm(steps) if (verbose and has_tqdm) else steps
+        noise = torch.randn_like(inputs) if _noise is None else _noise
+        n = inputs.shape[0]
+        total_kl = torch.zeros(n, dtype=torch.float32, device=inputs.device)
+        workspace = torch.zeros(n, dtype=torch.float64, device=inputs.device)
+        acp, betas, alphas = (scheduler._host_table(k) for k in ("alphas_cumprod", "betas", "alphas"))
+        one = scheduler.one.detach().to("cpu", torch.float32)
+        bin_width = (scaled_input_range[1] - scaled_input_range[0]) / (original_input_range[1] - original_input_range[0])
+        intermediates = []
+        for t in it:
+            timesteps = torch.full((n,), t, dtype=torch.long, device=inputs.device)
+            noisy = self.scheduler.add_noise(original_samples=inputs, noise=noise, timesteps=timesteps)
+            if mode == "concat":
+                model_output = diffusion_model(ops.concat_dim1([noisy, conditioning]), timesteps=timesteps, context=None)
+            else:
+                model_output = diffusion_model(x=noisy, timesteps=timesteps, context=conditioning)
+            if model_output.shape[1] == inputs.shape[1] * 2 and scheduler.variance_type in ["learned", "learned_range"]:
+                # the reference evaluates `if predicted_variance` on the whole tensor here (inferer.py:240) and raises
+                raise RuntimeError("Boolean value of Tensor with more than one value is ambiguous "
+                                   "(get_likelihood does not support learned variances, as in the reference)")
+            a_t = acp[t]
+            a_prev = acp[t - 1] if t > 0 else one
+            b_t, b_prev = 1 - a_t, 1 - a_prev
+            p = GmKlParams()
+            p.pred_type = {"epsilon": 0, "sample": 1, "v_prediction": 2}[str(scheduler.prediction_type)]
+            p.c_sa, p.c_sb = float(a_t**0.5), float(b_t**0.5)
+            p.clip = int(bool(scheduler.clip_sample))
+            p.k0 = float((a_prev**0.5 * betas[t]) / b_t)
+            p.k1 = float(alphas[t] ** 0.5 * b_prev / b_t)
+            p.m0 = float(a_prev.sqrt() * betas[t] / (1 - a_t))
+            p.m1 = float(alphas[t].sqrt() * (1 - a_prev) / (1 - a_t))
+            log_post = torch.log(scheduler._get_variance(timestep=t, predicted_variance=None))
+            log_pred = log_post
+            if t == 0:
+                p.t0, p.e, p.half_bin = 1, float(torch.exp(-(0.5 * log_pred))), float(torch.tensor(bin_width / 2, dtype=torch.float32))
+            else:
+                p.t0 = 0
+                p.s = float(-1.0 + log_pred - log_post + torch.exp(log_post - log_pred))
+                p.e = float(torch.exp(-log_pred))
+            kl = ops.likelihood_term(inputs, noisy, model_output, p, total_kl, workspace, want_map=bool(save_intermediates))
+            if save_intermediates:
+                intermediates.append(kl.cpu())
+        return (total_kl, intermediates) if save_intermediates else total_kl
 
 
 def _center_crop(x: torch.Tensor, roi) -> torch.Tensor:
@@ -189,3 +254,32 @@ class LatentDiffusionInferer(DiffusionInferer):
         if save_intermediates:
             return image, [decode(self._scaled(l, divide=True)) for l in latent_intermediates]
         return image
+
+    @torch.no_grad()
+    def get_likelihood(self, inputs: torch.Tensor, autoencoder_model: Callable[..., torch.Tensor],
+                       diffusion_model: Callable[..., torch.Tensor], scheduler: Callable[..., torch.Tensor] | None = None,
+                       save_intermediates: bool | None = False, conditioning: torch.Tensor | None = None, mode: str = "crossattn",
+                       original_input_range: tuple | None = (0, 255), scaled_input_range: tuple | None = (0, 1),
+                       verbose: bool = True, resample_latent_likelihoods: bool = False,
+                       resample_interpolation_mode: str = "nearest", seg: torch.Tensor | None = None, quantized: bool = True,
+                       _noise: torch.Tensor | None = None):
+        """Likelihood bound of the *latent* of `inputs` (reference inferer.py:489-562). The intermediate KL maps are CPU
+        tensors (as in the reference, which moves them with `.cpu()`), so the optional resampling to the image grid is the
+        reference's own host-side `nn.Upsample`."""
+        if resample_latent_likelihoods and resample_interpolation_mode not in ("nearest", "bilinear", "trilinear"):
+            raise ValueError(
+                f"resample_interpolation mode should be either nearest, bilinear, or trilinear, got {resample_interpolation_mode}")
+        if isinstance(autoencoder_model, VQVAE):
+            latents = autoencoder_model.encode_stage_2_inputs(inputs, quantized=quantized)
+        else:
+            latents = autoencoder_model.encode_stage_2_inputs(inputs)
+        latents = self._scaled(latents, divide=False)
+        if self.ldm_latent_shape is not None:
+            latents = _spatial_pad(latents, self.ldm_latent_shape)
+        outputs = super().get_likelihood(inputs=latents, diffusion_model=diffusion_model, scheduler=scheduler,
+                                         save_intermediates=save_intermediates, conditioning=conditioning, mode=mode,
+                                         verbose=verbose, _noise=_noise)
+        if save_intermediates and resample_latent_likelihoods:
+            resizer = nn.Upsample(size=inputs.shape[2:], mode=resample_interpolation_mode)
+            outputs = (outputs[0], [resizer(x) for x in outputs[1]])
+        return outputs

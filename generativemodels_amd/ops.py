@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _native as nat
-from ._native import GmAttnDesc, GmConvDesc, GmStepParams, check, lib
+from ._native import GmAttnDesc, GmConvDesc, GmKlParams, GmStepParams, check, lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 ACT = {"none": 0, "silu": 1, "relu": 2}
@@ -720,6 +720,50 @@ def sched_step(sample: torch.Tensor, model_output: torch.Tensor, params: GmStepP
            lambda: check(lib().gm_sched_step(sample.data_ptr(), model_output.data_ptr(), _ptr(noise), prev.data_ptr(), _ptr(x0), batch,
                                              inner, mo_bs, dt_code(sample.dtype), C.byref(params), _stream()), "gm_sched_step"))
     return prev, x0
+
+
+def likelihood_term(x0: torch.Tensor, xt: torch.Tensor, model_output: torch.Tensor, params: GmKlParams, total: torch.Tensor,
+                    workspace: torch.Tensor, want_map: bool = False) -> Optional[torch.Tensor]:
+    """One term of get_likelihood's bound: adds mean_over_elements(KL or decoder NLL) to total[n]; returns the map if asked."""
+    require_device(x0, xt, model_output, total, workspace)
+    if x0.shape != xt.shape or x0.dtype != xt.dtype or x0.dtype != model_output.dtype:
+        raise ValueError("inputs, noised inputs and model output must share dtype; inputs and noised inputs share shape")
+    if total.dtype != torch.float32 or workspace.dtype != torch.float64:
+        raise TypeError("total must be fp32 and workspace fp64")
+    x0, xt, model_output = x0.contiguous(), xt.contiguous(), model_output.contiguous()
+    batch = x0.shape[0]
+    inner = x0.numel() // max(batch, 1)
+    mo_bs = model_output.numel() // max(batch, 1)
+    if mo_bs < inner:
+        raise ValueError("model_output is smaller than the inputs")
+    kl = torch.empty_like(x0) if want_map else None
+    _timed("likelihood_term", dict(flops=0.0, bytes=float(x0.element_size() * x0.numel() * (3 + want_map)), shape=str(tuple(x0.shape))),
+           lambda: check(lib().gm_likelihood_term(x0.data_ptr(), xt.data_ptr(), model_output.data_ptr(), _ptr(kl), total.data_ptr(),
+                                                  workspace.data_ptr(), batch, inner, mo_bs, dt_code(x0.dtype), C.byref(params),
+                                                  _stream()), "gm_likelihood_term"))
+    return kl
+
+
+def lincomb(terms: Sequence[Optional[torch.Tensor]], coefs: Sequence[float], post_mul: float = 1.0, post_div: float = 1.0) -> torch.Tensor:
+    """post_mul * (c0*x0 + c1*x1 + ...) / post_div, left to right, each op rounded in fp32 (PNDM's history combinations,
+    reference pndm.py:186-195,241-250).  A None term is skipped (the reference's `0 + tensor`)."""
+    live = [t for t in terms if t is not None]
+    require_device(*live)
+    if not live or len(terms) > 4 or len(terms) != len(coefs):
+        raise ValueError("lincomb takes 1..4 (tensor, coefficient) pairs, at least one tensor")
+    ref = live[0]
+    for t in live:
+        if t.shape != ref.shape or t.dtype != ref.dtype:
+            raise ValueError("lincomb terms must share shape and dtype")
+    keep = [None if t is None else t.contiguous() for t in terms]
+    out = torch.empty_like(ref, memory_format=torch.contiguous_format)
+    ptrs = (C.c_void_p * len(keep))(*[None if t is None else t.data_ptr() for t in keep])
+    cs = (C.c_float * len(keep))(*[float(torch.tensor(c, dtype=torch.float32)) for c in coefs])
+    _timed("lincomb", dict(flops=0.0, bytes=float(ref.element_size() * ref.numel() * (len(live) + 1)), shape=str(tuple(ref.shape))),
+           lambda: check(lib().gm_lincomb(ptrs, cs, len(keep), float(torch.tensor(post_mul, dtype=torch.float32)),
+                                          float(torch.tensor(post_div, dtype=torch.float32)), out.data_ptr(), ref.numel(),
+                                          dt_code(ref.dtype), _stream()), "gm_lincomb"))
+    return out
 
 
 def axpby_rows(x: torch.Tensor, y: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -75,8 +75,98 @@ VQVAE_CASES = {
 }
 
 
+def bf16_reference_outputs():
+    """tests/golden/unet_bf16_ref.pt: the reference's OWN bf16 outputs (model.to(bfloat16) on CPU) for every UNet fixture, so the
+    GPU bf16 path can be held to SURVEY.md 8(c)(3): err(ours_bf16) <= 1.5 * err(ref_bf16), both against the fp32 golden."""
+    from generative.networks.nets import DiffusionModelUNet
+
+    res = {}
+    for name in UNET_CASES:
+        fx = torch.load(os.path.join(OUT, name + ".pt"))
+        m = DiffusionModelUNet(**fx["cfg"]).eval()
+        m.load_state_dict(fx["state_dict"] if fx["state_dict"] is not None else synthetic_state_dict(fx["shapes"], seed=fx["synthetic_seed"]))
+        m = m.to(torch.bfloat16)
+        i = fx["inputs"]
+        ctx = None if i["context"] is None else i["context"].bfloat16()
+        with torch.no_grad():
+            y = m(i["x"].bfloat16(), i["timesteps"], context=ctx, class_labels=i["class_labels"])
+        err = (y.float() - fx["outputs"]["y"]).abs()
+        res[name] = dict(y_bf16=y, mean_err=float(err.mean()), max_err=float(err.max()), sigma=float(fx["outputs"]["y"].std()))
+        print(name, "reference bf16 vs fp32: mean", res[name]["mean_err"], "max", res[name]["max_err"], "sigma", res[name]["sigma"])
+    torch.save(dict(kind="unet_bf16_ref", cases=res), os.path.join(OUT, "unet_bf16_ref.pt"))
+
+
+def extras():
+    """tests/golden/pndm_likelihood.pt: PNDMScheduler tables, a model-free step sequence and a UNet chain; DiffusionInferer.
+    get_likelihood totals + per-step maps.  Outputs of the unmodified reference."""
+    from generative.inferers import DiffusionInferer
+    from generative.networks.nets import DiffusionModelUNet
+    from generative.networks.schedulers import DDPMScheduler, PNDMScheduler
+
+    out = dict(kind="pndm_likelihood", tables={}, sequences={}, likelihood={})
+    for n in (10, 50, 100):
+        for skip in (False, True):
+            s = PNDMScheduler(1000, skip_prk_steps=skip)
+            s.set_timesteps(n)
+            out["tables"][(n, skip)] = dict(prk=torch.as_tensor(s.prk_timesteps.astype("int64")) if len(s.prk_timesteps) else torch.zeros(0, dtype=torch.long),
+                                            plms=torch.as_tensor(s.plms_timesteps.copy()), timesteps=s.timesteps.clone(),
+                                            num_inference_steps=s.num_inference_steps)
+    # model-free sequences: step() fed with fixed pseudo model outputs exercises every branch of the state machine
+    shape = (2, 2, 4, 4, 4)
+    for sname, kw in [("linear_beta", {}), ("scaled_linear_beta", dict(beta_start=0.0005, beta_end=0.0195))]:
+        for pt in ["epsilon", "v_prediction"]:
+            for skip in (False, True):
+                for one in (False, True):
+                    s = PNDMScheduler(1000, schedule=sname, skip_prk_steps=skip, set_alpha_to_one=one, prediction_type=pt, **kw)
+                    s.set_timesteps(20)
+                    x = _randn(shape, 31)
+                    seq = []
+                    for k, t in enumerate(s.timesteps):
+                        x, _ = s.step(_randn(shape, 100 + k), int(t), x)
+                        seq.append(x.clone())
+                    out["sequences"][(sname, pt, skip, one)] = dict(kw=kw, x0_seed=31, mo_seed0=100, shape=shape, steps=20, samples=seq)
+    # UNet chain (C1a 3D): PNDM sampling through the reference inferer
+    torch.manual_seed(0)
+    cfg = UNET_CASES["unet3d_c1a"]["cfg"]
+    m = DiffusionModelUNet(**cfg).eval()
+    derandomize_zeros(m)
+    noise = _randn((2, 1, 8, 8, 8), 21)
+    pndm = PNDMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195)
+    pndm.set_timesteps(10)
+    chain = DiffusionInferer(pndm).sample(noise, m, pndm, verbose=False)
+    out["chain"] = dict(cfg=cfg, state_dict=m.state_dict(), noise=noise, steps=10, out=chain)
+    # get_likelihood (C1a 2D), all fixed-variance / prediction-type combinations; inputs reach past +-0.999 (edge bins)
+    torch.manual_seed(0)
+    cfg2 = UNET_CASES["unet2d_c1a"]["cfg"]
+    m2 = DiffusionModelUNet(**cfg2).eval()
+    derandomize_zeros(m2)
+    inputs = (_randn((2, 1, 8, 8), 41) * 0.6).clamp(-1, 1)
+    out["likelihood"]["cfg"], out["likelihood"]["state_dict"], out["likelihood"]["inputs"] = cfg2, m2.state_dict(), inputs
+    out["likelihood"]["noise_seed"] = 123
+    out["likelihood"]["cases"] = {}
+    for vt in ["fixed_small", "fixed_large"]:
+        for pt in ["epsilon", "v_prediction", "sample"]:
+            for clip in (True, False):
+                d = DDPMScheduler(num_train_timesteps=10, variance_type=vt, prediction_type=pt, clip_sample=clip)
+                inf = DiffusionInferer(d)
+                torch.manual_seed(123)
+                total, maps = inf.get_likelihood(inputs, m2, d, save_intermediates=True, verbose=False)
+                out["likelihood"]["cases"][(vt, pt, clip)] = dict(total=total, maps=maps)
+    torch.save(out, os.path.join(OUT, "pndm_likelihood.pt"))
+    print("pndm tables", {k: int(v["num_inference_steps"]) for k, v in out["tables"].items()})
+    print("chain", float(chain.abs().max()), "likelihood", {k: v["total"].tolist() for k, v in list(out["likelihood"]["cases"].items())[:3]})
+
+
 def main():
     g = load_reference()
+    if g is None:
+        raise SystemExit("reference tree not found; golden fixtures can only be made in the build container")
+    if "--extras-only" in sys.argv:  # PNDM + get_likelihood fixtures only
+        extras()
+        return
+    if "--bf16-only" in sys.argv:  # adds the bf16 reference outputs without rewriting the fp32 fixtures
+        bf16_reference_outputs()
+        return
     if g is None:
         raise SystemExit("reference tree not found; golden fixtures can only be made in the build container")
     from generative.inferers import DiffusionInferer

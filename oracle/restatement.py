@@ -569,6 +569,159 @@ def get_velocity(alphas_cumprod, sample, noise, timesteps):
     return sa * noise - sb * sample
 
 
+def pndm_timesteps(num_train_timesteps, num_inference_steps, skip_prk_steps=False, steps_offset=0, order=4):
+    """PNDMScheduler.set_timesteps, schedulers/pndm.py:119-163 -> (prk_timesteps, plms_timesteps, timesteps) as int64 arrays."""
+    if num_inference_steps > num_train_timesteps:
+        raise ValueError("num_inference_steps cannot be larger than num_train_timesteps")
+    ratio = num_train_timesteps // num_inference_steps
+    base = (np.arange(0, num_inference_steps) * ratio).round().astype(np.int64) + steps_offset
+    if skip_prk_steps:
+        prk, plms = np.array([]), base[::-1]
+    else:
+        pairs = np.array(base[-order:]).repeat(2) + np.tile(np.array([0, num_train_timesteps // num_inference_steps // 2]), order)
+        prk = (pairs[:-1].repeat(2)[1:-1])[::-1].copy()
+        plms = base[:-3][::-1].copy()
+    return prk, plms, np.concatenate([prk, plms]).astype(np.int64)
+
+
+class PNDM:
+    """Functional-state restatement of PNDMScheduler.step / step_prk / step_plms / _get_prev_sample (schedulers/pndm.py:165-316).
+    Quirk kept: after set_timesteps, `num_inference_steps` is the number of *model evaluations* (pndm.py:158-159), and the
+    step ratio used by the step functions is derived from that number."""
+
+    def __init__(self, alphas_cumprod, num_train_timesteps, num_inference_steps, skip_prk_steps=False, set_alpha_to_one=False,
+                 prediction_type="epsilon", steps_offset=0):
+        self.ac = alphas_cumprod
+        self.T = num_train_timesteps
+        self.skip = skip_prk_steps
+        self.final = torch.tensor(1.0) if set_alpha_to_one else alphas_cumprod[0]
+        self.prediction_type = prediction_type
+        self.prk, self.plms, ts = pndm_timesteps(num_train_timesteps, num_inference_steps, skip_prk_steps, steps_offset)
+        self.timesteps = torch.from_numpy(ts)
+        self.n = len(ts)
+        self.acc, self.counter, self.cur_sample, self.ets = 0, 0, None, []
+
+    def transfer(self, sample, t, prev_t, e):  # :276-316
+        a_t = self.ac[t]
+        a_prev = self.ac[prev_t] if prev_t >= 0 else self.final
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        if self.prediction_type == "v_prediction":
+            e = (a_t**0.5) * e + (b_t**0.5) * sample
+        coeff = (a_prev / a_t) ** (0.5)
+        denom = a_t * b_prev ** (0.5) + (a_t * b_t * a_prev) ** (0.5)
+        return coeff * sample - (a_prev - a_t) * e / denom
+
+    def step(self, model_output, timestep, sample):
+        if self.counter < len(self.prk) and not self.skip:
+            return self._prk(model_output, timestep, sample)
+        return self._plms(model_output, timestep, sample)
+
+    def _prk(self, mo, t, sample):  # :188-229
+        half = 0 if self.counter % 2 else self.T // self.n // 2
+        prev_t = t - half
+        t = int(self.prk[self.counter // 4 * 4])
+        phase = self.counter % 4
+        if phase == 0:
+            self.acc = self.acc + 1 / 6 * mo
+            self.ets.append(mo)
+            self.cur_sample = sample
+        elif phase in (1, 2):
+            self.acc = self.acc + 1 / 3 * mo
+        else:
+            mo = self.acc + 1 / 6 * mo
+            self.acc = 0
+        cur = self.cur_sample if self.cur_sample is not None else sample
+        out = self.transfer(cur, t, prev_t, mo)
+        self.counter += 1
+        return out
+
+    def _plms(self, mo, t, sample):  # :231-274
+        if not self.skip and len(self.ets) < 3:
+            raise ValueError("plms steps need 12 prk iterations first")
+        prev_t = t - self.T // self.n
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(mo)
+        else:
+            prev_t = t
+            t = t + self.T // self.n
+        e = self.ets
+        if len(e) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(e) == 1 and self.counter == 1:
+            mo = (mo + e[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(e) == 2:
+            mo = (3 * e[-1] - e[-2]) / 2
+        elif len(e) == 3:
+            mo = (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12
+        else:
+            mo = (1 / 24) * (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4])
+        out = self.transfer(sample, t, prev_t, mo)
+        self.counter += 1
+        return out
+
+
+def approx_standard_normal_cdf(x):
+    """DiffusionInferer._approx_standard_normal_cdf, inferers/inferer.py:258-267 (tanh approximation)."""
+    return 0.5 * (1.0 + torch.tanh(torch.sqrt(torch.Tensor([2.0 / math.pi])) * (x + 0.044715 * torch.pow(x, 3))))
+
+
+def decoder_log_likelihood(inputs, means, log_scales, original_input_range=(0, 255), scaled_input_range=(0, 1)):
+    """DiffusionInferer._get_decoder_log_likelihood, inferers/inferer.py:269-321."""
+    bin_width = (scaled_input_range[1] - scaled_input_range[0]) / (original_input_range[1] - original_input_range[0])
+    centered = inputs - means
+    inv_std = torch.exp(-log_scales)
+    cdf_hi = approx_standard_normal_cdf(inv_std * (centered + bin_width / 2))
+    cdf_lo = approx_standard_normal_cdf(inv_std * (centered - bin_width / 2))
+    log_hi = torch.log(cdf_hi.clamp(min=1e-12))
+    log_one_minus_lo = torch.log((1.0 - cdf_lo).clamp(min=1e-12))
+    log_mid = torch.log((cdf_hi - cdf_lo).clamp(min=1e-12))
+    return torch.where(inputs < -0.999, log_hi, torch.where(inputs > 0.999, log_one_minus_lo, log_mid))
+
+
+def get_likelihood(model_fn, inputs, noise, betas, alphas, alphas_cumprod, timesteps, prediction_type="epsilon",
+                   variance_type="fixed_small", clip_sample=True, conditioning=None, mode="crossattn",
+                   original_input_range=(0, 255), scaled_input_range=(0, 1)):
+    """DiffusionInferer.get_likelihood, inferers/inferer.py:145-256, for fixed variances (the reference's learned-variance branch
+    raises at :240). model_fn(x, timesteps, context) -> prediction; `noise` = the single randn_like draw of :189.
+    Returns (total_kl (N,), [kl map per timestep])."""
+    one = torch.tensor(1.0)
+    total = torch.zeros(inputs.shape[0])
+    maps = []
+    for t in [int(v) for v in timesteps]:
+        ts = torch.full(inputs.shape[:1], t).long()
+        noisy = add_noise(alphas_cumprod, inputs, noise, ts)
+        if mode == "concat":
+            mo = model_fn(torch.cat([noisy, conditioning], dim=1), ts, None)
+        else:
+            mo = model_fn(noisy, ts, conditioning)
+        a_t = alphas_cumprod[t]
+        a_prev = alphas_cumprod[t - 1] if t > 0 else one
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        x0, _ = _x0_eps(prediction_type, a_t, mo, noisy)
+        if clip_sample:
+            x0 = torch.clamp(x0, -1, 1)
+        pred_mean = (a_prev ** (0.5) * betas[t]) / b_t * x0 + alphas[t] ** (0.5) * b_prev / b_t * noisy
+        post_mean = a_prev.sqrt() * betas[t] / (1 - a_t) * inputs + alphas[t].sqrt() * (1 - a_prev) / (1 - a_t) * noisy  # ddpm.py:133-156
+        var = (1 - a_prev) / (1 - a_t) * betas[t]  # ddpm.py:158-189
+        if variance_type == "fixed_small":
+            var = torch.clamp(var, min=1e-20)
+        elif variance_type == "fixed_large":
+            var = betas[t]
+        log_post = torch.log(var)
+        log_pred = log_post
+        if t == 0:
+            kl = -decoder_log_likelihood(inputs, pred_mean, 0.5 * log_pred, original_input_range, scaled_input_range)
+        else:
+            kl = 0.5 * (-1.0 + log_pred - log_post + torch.exp(log_post - log_pred)
+                        + ((post_mean - pred_mean) ** 2) * torch.exp(-log_pred))
+        total += kl.view(kl.shape[0], -1).mean(axis=1)
+        maps.append(kl)
+    return total, maps
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # Inferer loops (inferers/inferer.py)
 # --------------------------------------------------------------------------------------------------------------------

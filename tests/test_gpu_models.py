@@ -64,8 +64,10 @@ def test_unet_fp32_matches_reference_golden(name):
         _fp32_close(m(_dev(i["x"]), _dev(t1), context=_dev(i["context"])), want, name + " shared timestep")
 
 
-@pytest.mark.parametrize("name", ["unet3d_c2mini", "unet2d_c1b", "unet3d_cond"])
+@pytest.mark.parametrize("name", UNETS)
 def test_unet_bf16_close_to_fp32_reference(name):
+    """bf16 bar of SURVEY.md 8(c)(3): absolute (vs the fp32 golden) AND relative to the reference's own bf16 run
+    (tests/golden/unet_bf16_ref.pt, oracle/make_golden.py --bf16-only): mean|err| <= 1.5 x the reference's bf16 mean|err|."""
     fx = load_fixture(name)
     i = fx["inputs"]
     m = _build_unet(fx, torch.bfloat16)
@@ -73,6 +75,10 @@ def test_unet_bf16_close_to_fp32_reference(name):
     y = m(_dev(i["x"].bfloat16()), _dev(i["timesteps"]), context=_dev(ctx), class_labels=_dev(i["class_labels"]))
     assert y.dtype == torch.bfloat16
     _bf16_close(y, fx["outputs"]["y"], name)
+    ref = load_fixture("unet_bf16_ref")["cases"][name]
+    err = (y.float().cpu() - fx["outputs"]["y"]).abs()
+    assert err.mean().item() <= 1.5 * ref["mean_err"], f"{name}: ours bf16 mean|err| {err.mean().item():.3e} vs reference bf16 {ref['mean_err']:.3e}"
+    assert err.max().item() <= 2.0 * ref["max_err"], f"{name}: ours bf16 max|err| {err.max().item():.3e} vs reference bf16 {ref['max_err']:.3e}"
 
 
 def test_unet_forward_errors_match_reference():
@@ -228,3 +234,75 @@ def test_latent_diffusion_inferer_sample_and_call():
     assert tuple(pred.shape) == (1, 4, 2, 2, 2) or pred.shape[1] == 4
     with pytest.raises(ValueError):
         LatentDiffusionInferer(sched, ldm_latent_shape=[4, 4, 4])
+
+
+def test_pndm_step_sequences_bit_exact_and_chain_matches_reference():
+    """PNDMScheduler on the device: a model-free sequence through every branch of the RK / multi-step state machine is BIT-EXACT
+    against the oracle run on this host (and within a few ulp-of-operand of the committed reference outputs, see the DDIM test for
+    why golden vectors from another CPU are not bit-comparable); the UNet chain matches the reference's PNDM sample."""
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.schedulers import PNDMScheduler
+    fx = load_fixture("pndm_likelihood")
+    for (sname, pt, skip, one), e in fx["sequences"].items():
+        s = PNDMScheduler(1000, schedule=sname, skip_prk_steps=skip, set_alpha_to_one=one, prediction_type=pt, **e["kw"])
+        s.set_timesteps(e["steps"])
+        o = R.PNDM(s.alphas_cumprod, 1000, e["steps"], skip_prk_steps=skip, set_alpha_to_one=one, prediction_type=pt)
+        x0 = torch.randn(e["shape"], generator=torch.Generator().manual_seed(e["x0_seed"]))
+        x, xo = _dev(x0), x0
+        assert torch.equal(s.timesteps, o.timesteps)
+        for k, t in enumerate(s.timesteps):
+            mo = torch.randn(e["shape"], generator=torch.Generator().manual_seed(e["mo_seed0"] + k))
+            x, none = s.step(_dev(mo), int(t), x)
+            xo = o.step(mo, int(t), xo)
+            assert none is None
+            assert torch.equal(x.cpu(), xo), (sname, pt, skip, one, k, (x.cpu() - xo).abs().max().item())
+            gold = e["samples"][k]
+            assert (x.cpu() - gold).abs().max().item() <= 1e-5 * max(1.0, gold.abs().max().item()), (sname, pt, skip, one, k)
+    c = fx["chain"]
+    m = _nets().DiffusionModelUNet(**c["cfg"]).eval()
+    m.load_state_dict(c["state_dict"])
+    m = m.to(DEV)
+    for graph in (False, True):
+        s = PNDMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195)
+        s.set_timesteps(c["steps"])
+        out = DiffusionInferer(s, use_hip_graph=graph).sample(_dev(c["noise"]), m, s, verbose=False)
+        _fp32_close(out, c["out"], f"pndm chain (graph={graph})", factor=2.0)
+    # bf16 tensors: fp32 arithmetic, one rounding per fused op
+    s = PNDMScheduler(1000)
+    s.set_timesteps(20)
+    o = R.PNDM(s.alphas_cumprod, 1000, 20)
+    x0 = torch.randn((2, 2, 4, 4, 4), generator=torch.Generator().manual_seed(5))
+    x, xo = _dev(x0.bfloat16()), x0.bfloat16().float()
+    for k, t in enumerate(s.timesteps[:16]):
+        mo = torch.randn((2, 2, 4, 4, 4), generator=torch.Generator().manual_seed(200 + k)).bfloat16()
+        x, _ = s.step(_dev(mo), int(t), x)
+        xo = o.step(mo.float(), int(t), xo)
+        assert x.dtype == torch.bfloat16
+    assert (x.float().cpu() - xo).abs().max().item() <= 0.05 * max(1.0, xo.abs().max().item())
+
+
+def test_get_likelihood_matches_reference():
+    """DiffusionInferer.get_likelihood (inferer.py:145-321): totals and per-step KL / decoder-NLL maps against the reference's
+    outputs for every fixed-variance x prediction-type x clip combination, with the reference's seeded noise draw."""
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.schedulers import DDIMScheduler, DDPMScheduler
+    lk = load_fixture("pndm_likelihood")["likelihood"]
+    m = _nets().DiffusionModelUNet(**lk["cfg"]).eval()
+    m.load_state_dict(lk["state_dict"])
+    m = m.to(DEV)
+    torch.manual_seed(lk["noise_seed"])
+    noise = torch.randn_like(lk["inputs"])
+    for (vt, pt, clip), e in lk["cases"].items():
+        d = DDPMScheduler(num_train_timesteps=10, variance_type=vt, prediction_type=pt, clip_sample=clip)
+        total, maps = DiffusionInferer(d).get_likelihood(_dev(lk["inputs"]), m, d, save_intermediates=True, verbose=False,
+                                                         _noise=_dev(noise))
+        assert total.shape == (2,) and total.dtype == torch.float32 and len(maps) == 10 and not maps[0].is_cuda
+        tol = 1e-4 * e["total"].abs().max().item()
+        assert (total.cpu() - e["total"]).abs().max().item() <= tol, (vt, pt, clip, total.cpu(), e["total"])
+        for k, (got, want) in enumerate(zip(maps, e["maps"])):
+            assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()), (vt, pt, clip, k)
+        only_total = DiffusionInferer(d).get_likelihood(_dev(lk["inputs"]), m, d, verbose=False, _noise=_dev(noise))
+        assert torch.allclose(only_total, total, rtol=1e-6, atol=0)
+    with pytest.raises(NotImplementedError):
+        s = DDIMScheduler(10)
+        DiffusionInferer(s).get_likelihood(_dev(lk["inputs"]), m, s, verbose=False)

@@ -111,6 +111,34 @@ def test_scheduler_tables_timesteps_and_errors():
     assert float(DDIMScheduler(set_alpha_to_one=False).final_alpha_cumprod) == float(DDIMScheduler().alphas_cumprod[0])
 
 
+def test_pndm_tables_state_and_errors():
+    """PNDMScheduler host logic (reference pndm.py:80-163 and the shape pins of tests/test_scheduler_pndm.py): timestep tables,
+    the evaluation count (100 requested -> 109), constructor / set_timesteps errors, no CPU fallback."""
+    from generativemodels_amd.networks.schedulers import PNDMScheduler
+
+    fx = load_fixture("pndm_likelihood")
+    for (n, skip), e in fx["tables"].items():
+        s = PNDMScheduler(1000, skip_prk_steps=skip)
+        s.set_timesteps(n)
+        assert torch.equal(s.timesteps, e["timesteps"]) and s.num_inference_steps == e["num_inference_steps"], (n, skip)
+        assert len(s.prk_timesteps) == len(e["prk"]) and torch.equal(torch.as_tensor(s.plms_timesteps.copy()), e["plms"])
+        assert s.counter == 0 and s.ets == []
+    s = PNDMScheduler(1000)
+    s.set_timesteps(100)
+    assert s.num_inference_steps == 109 and len(s.timesteps) == 109
+    assert float(PNDMScheduler().final_alpha_cumprod) == float(PNDMScheduler().alphas_cumprod[0])
+    assert float(PNDMScheduler(set_alpha_to_one=True).final_alpha_cumprod) == 1.0
+    with pytest.raises(ValueError):
+        PNDMScheduler(10).set_timesteps(11)
+    with pytest.raises(ValueError):
+        PNDMScheduler(prediction_type="sample")  # PNDM knows epsilon and v_prediction only (pndm.py:43-53)
+    x = torch.zeros(1, 1, 8, 8)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        PNDMScheduler(10).step(x, 5, x)
+    with pytest.raises(NotImplementedError):
+        DiffusionInferer(PNDMScheduler(10)).get_likelihood(x, lambda *a, **k: x, verbose=False)  # DDPM only (inferer.py:176-180)
+
+
 def test_user_registered_noise_schedule_feeds_the_scheduler():
     name = "halfway_test_schedule"
     if name not in NoiseSchedules:

@@ -91,3 +91,47 @@ def test_ddim_chain_matches_reference():
     scale = fx["ddim_out"].abs().max().item()
     assert_close(out, fx["ddim_out"], atol=2e-5 * max(1.0, scale), what="ddim chain")
     assert len(inter) == len(fx["ddim_inter"])
+
+
+def test_pndm_tables_and_sequences_match_reference():
+    """PNDMScheduler (pndm.py): timestep tables (50 -> 59, 100 -> 109 evaluations) and a model-free step sequence through every
+    branch of the Runge-Kutta / multi-step state machine, bit-exact against the reference's outputs."""
+    fx = load_fixture("pndm_likelihood")
+    for (n, skip), e in fx["tables"].items():
+        prk, plms, ts = R.pndm_timesteps(1000, n, skip_prk_steps=skip)
+        assert torch.equal(torch.from_numpy(ts), e["timesteps"]) and len(ts) == e["num_inference_steps"], (n, skip)
+        assert torch.equal(torch.from_numpy(plms.copy()), e["plms"]) and len(prk) == len(e["prk"])
+    assert fx["tables"][(100, False)]["num_inference_steps"] == 109  # the reference's structural pin (test_scheduler_pndm.py:58-62)
+    for (sname, pt, skip, one), e in fx["sequences"].items():
+        _, _, ac = R.noise_schedule(sname, 1000, **e["kw"])
+        s = R.PNDM(ac, 1000, e["steps"], skip_prk_steps=skip, set_alpha_to_one=one, prediction_type=pt)
+        x = torch.randn(e["shape"], generator=torch.Generator().manual_seed(e["x0_seed"]))
+        assert len(s.timesteps) == len(e["samples"])
+        for k, t in enumerate(s.timesteps):
+            mo = torch.randn(e["shape"], generator=torch.Generator().manual_seed(e["mo_seed0"] + k))
+            x = s.step(mo, int(t), x)
+            assert _eq(x, e["samples"][k]), (sname, pt, skip, one, k)
+
+
+def test_pndm_chain_and_likelihood_match_reference():
+    fx = load_fixture("pndm_likelihood")
+    c = fx["chain"]
+    _, _, ac = R.noise_schedule("scaled_linear_beta", 1000, beta_start=0.0005, beta_end=0.0195)
+    s = R.PNDM(ac, 1000, c["steps"])
+    x = c["noise"]
+    with torch.no_grad():
+        for t in s.timesteps:
+            x = s.step(R.unet_forward(c["state_dict"], c["cfg"], x, torch.Tensor((int(t),))), int(t), x)
+    assert_close(x, c["out"], atol=2e-5 * max(1.0, c["out"].abs().max().item()), what="pndm chain")
+    lk = fx["likelihood"]
+    b, a, ac = R.noise_schedule("linear_beta", 10)
+    torch.manual_seed(lk["noise_seed"])
+    noise = torch.randn_like(lk["inputs"])
+    model = lambda xx, ts, ctx: R.unet_forward(lk["state_dict"], lk["cfg"], xx, ts, ctx)  # noqa: E731
+    for (vt, pt, clip), e in lk["cases"].items():
+        with torch.no_grad():
+            total, maps = R.get_likelihood(model, lk["inputs"], noise, b, a, ac, torch.arange(9, -1, -1), prediction_type=pt,
+                                           variance_type=vt, clip_sample=clip)
+        assert_close(total, e["total"], atol=1e-5 * e["total"].abs().max().item(), what=f"likelihood total {vt} {pt} {clip}")
+        for got, want in zip(maps, e["maps"]):
+            assert_close(got, want, atol=2e-5 * max(1.0, want.abs().max().item()), what=f"kl map {vt} {pt} {clip}")
