@@ -284,6 +284,13 @@ static inline bool conv_is_fast(int cfg) { return cfg >= CONV_CFG_FAST64 && cfg 
 static inline int conv_fast_variant(int cfg) { return cfg - CONV_CFG_FAST64 + 1; }
 static inline int conv_fast_bn(int cfg) { int v = 0, c = 0, t = 0; gm_conv_fast_variant_geometry(conv_fast_variant(cfg), &v, &c, &t); return c; }
 
+// LDS-DMA 3x3x3 kernel (conv_dma.hip): cfg 11 = 256 voxels (4x4x16) x 64 channels, no fused prologue
+#define CONV_CFG_DMA 11
+extern "C" long long gm_conv_dma_lds_bytes();
+extern "C" int gm_conv_dma_eligible(const GmConvDesc* d);
+extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
+static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA; }
+
 static bool conv_fast_eligible(const GmConvDesc& d) {
   const int vecw = d.dtype == GM_F32 ? 4 : 8;
   const long long td = 1 << d.ltd, th = 1 << d.lth, tw = 1 << d.ltw;
@@ -295,6 +302,7 @@ static bool conv_fast_eligible(const GmConvDesc& d) {
 }
 
 extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
+  if (conv_is_dma(cfg)) { *bm = 256; *bn = 64; return 0; }
   if (conv_is_fast(cfg)) { int t = 0; return gm_conv_fast_variant_geometry(conv_fast_variant(cfg), bm, bn, &t); }
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
   *bm = kCfgs[cfg].WM * kCfgs[cfg].MF * 16;
@@ -329,6 +337,7 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
+  if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes() : -1;
   if (d && conv_is_fast(d->cfg)) {
     if (!conv_fast_eligible(*d)) return -1;
     return gm_conv_fast_lds_bytes(d, conv_fast_bn(d->cfg));
@@ -347,7 +356,8 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   const GmConvDesc& d = *dp;
   GM_REQUIRE(d.x && d.w && d.y, "null tensor pointer");
   const bool fast = conv_is_fast(d.cfg);
-  GM_REQUIRE(fast || (d.cfg >= 0 && d.cfg < kNumCfgs), "bad tile configuration");
+  const bool dma = conv_is_dma(d.cfg);
+  GM_REQUIRE(fast || dma || (d.cfg >= 0 && d.cfg < kNumCfgs), "bad tile configuration");
   GM_REQUIRE((d.pre_scale == nullptr) == (d.pre_shift == nullptr), "pre_scale and pre_shift go together");
   GM_REQUIRE(d.N >= 0 && d.Cin > 0 && d.Cout > 0, "bad channel / batch count");
   GM_REQUIRE(d.kd > 0 && d.kh > 0 && d.kw > 0 && d.sd > 0 && d.sh > 0 && d.sw > 0 && d.dd > 0 && d.dh > 0 && d.dw > 0, "bad kernel geometry");
@@ -357,6 +367,7 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   gm_conv_cfg_tile(d.cfg, &bm, &bn);
   GM_REQUIRE((1 << (d.ltd + d.lth + d.ltw)) == bm, "tile dims do not match the configuration");
   GM_REQUIRE(!fast || conv_fast_eligible(d), "geometry is not eligible for the fast stride-1 kernel");
+  GM_REQUIRE(!dma || gm_conv_dma_eligible(dp), "geometry is not eligible for the LDS-DMA 3x3x3 kernel");
   const long long smem = gm_conv_lds_bytes(dp);
   GM_REQUIRE(smem > 0 && smem <= 160 * 1024, "tile needs more than 160 KiB of LDS");
   const long long ntd = (d.Do + (1 << d.ltd) - 1) >> d.ltd, nth = (d.Ho + (1 << d.lth) - 1) >> d.lth,
@@ -366,6 +377,11 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(nblocks < (1LL << 31), "grid too large");
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (dma) {
+    rc = gm_conv_dma_launch(dp, (unsigned)nblocks, stream);
+    GM_REQUIRE(rc == 0, "unsupported dtype");
+    GM_LAUNCH_CHECK();
+  }
   if (fast) {
     rc = gm_conv_fast_launch(dp, conv_fast_variant(d.cfg), (unsigned)nblocks, stream);
     GM_REQUIRE(rc == 0, "unsupported dtype");

@@ -1,0 +1,279 @@
+// 3x3x3 stride-1 convolution with BOTH operands streamed global -> LDS by the LDS-DMA engine (global_load_lds_dwordx4): the
+// prologue-free ResnetBlock / Upsample convolutions of the 3-D UNet and auto-encoders (conv_fast.hip keeps the fused-prologue,
+// 1^d and 2-D cases).  What rocprof / the ISA of conv_fast showed on MI355X and what this kernel changes:
+//   * register-staged prefetch does not survive hipcc: every ds_read after a prefetch `global_load` is guarded by
+//     `s_waitcnt vmcnt(0)` (register re-use hazard), so the weight panel's L2 latency was exposed once per tap group and the
+//     halo patch was fetched in serialised batches of two.  LDS-DMA has no destination register: all pieces of a patch are in
+//     flight at once, weight panels are issued two tap groups ahead into a 3-deep ring, and the only waits are the counted
+//     `s_waitcnt vmcnt(N)` written here (hipcc does not see inline-asm memory operations);
+//   * 4.4 VALU + 4.4 SALU instructions per MFMA (swizzle address arithmetic, tap counters): the tile geometry is a template
+//     constant, the 27 taps are fully unrolled, the patch plane pitch is padded to a multiple of 16 rows so the XOR swizzle is
+//     invariant under the depth offset -- a tap's operand reads are `ds_read_b128 v, vaddr offset:imm` from 9 precomputed
+//     per-lane addresses per voxel fragment: zero address arithmetic in the loop.
+// LDS-DMA writes lane-linear (M0 base + lane*16), so the swizzle is applied on the SOURCE side: LDS (row, slot s) receives the
+// 16-byte channel slot s ^ swz(row) of that row; out-of-volume rows (zero padding) read a zero page.
+// Tile: 4x4x16 = 256 voxels x 64 channels, 8 waves (32 voxels x 64 channels each), 78 KiB LDS -> two work-groups per CU, one
+// staging its patch while the other computes.
+#include "conv_epilogue.h"
+
+#define DMA_ROWB 64
+__device__ __forceinline__ int dma_swz(int row) { return (row ^ (row >> 1)) & 3; }  // period 8 rows
+
+__device__ __attribute__((aligned(64))) unsigned int gm_zero_row[16] = {0};  // the source of every padding row
+
+// one LDS-DMA piece: 64 lanes x 16 bytes -> LDS [lds_dst, lds_dst + 1 KiB), lane i from gsrc(i).  M0 is compiler-reserved: saved
+// and restored inside the statement (cdna_hip_programming.md 5.7).  Not counted by hipcc: callers wait with dma_wait<N>().
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
+  constexpr int BK = ConvTraits<T>::BK;
+  constexpr int VECW = ConvTraits<T>::VECW;
+  constexpr int NW = 8, NT = 64 * NW;
+  constexpr int MF = 2, NFR = 4, G = 3;
+  constexpr int TD = 4, TH = 4, TW = 16;
+  constexpr int PD = TD + 2, PH = TH + 2, PW = TW + 2;
+  constexpr int PLANE = ((PH * PW + 15) / 16) * 16;        // 112 rows: depth offsets keep (row mod 16)
+  constexpr int PROWS = PD * PLANE;                        // 672 rows = 42 DMA pieces
+  constexpr int PPIECES = PROWS / 16;
+  constexpr int PPW = (PPIECES + NW - 1) / NW;             // patch pieces per wave (6; the last round is partial)
+  constexpr int BN = 64;
+  constexpr int WROWS = G * BN;                            // 192 rows per weight panel = 12 KiB = 1.5 pieces per wave
+  constexpr int PATCH_BYTES = PROWS * DMA_ROWB;
+  constexpr int WBUF_BYTES = WROWS * DMA_ROWB;
+  constexpr int NGROUPS = 9;                               // 27 taps / G
+  static_assert(WROWS == NW * 16 + NW * 8, "each wave moves one full and one half piece of a weight panel");
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB]
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+
+  const int ntd = (p.Do + TD - 1) / TD, nth = (p.Ho + TH - 1) / TH, ntw = (p.Wo + TW - 1) / TW;
+  const int ncb = (p.Cout + BN - 1) / BN;
+  unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+  const int cb = b % ncb; b /= ncb;
+  const int tw_i = b % ntw; b /= ntw;
+  const int th_i = b % nth; b /= nth;
+  const int td_i = b % ntd; b /= ntd;
+  const int n = b;
+  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
+  int Dv = p.Ds, Hv = p.Hs, Wv = p.Ws;
+  if (p.in_mode == 1) { Dv *= p.fd; Hv *= p.fh; Wv *= p.fw; }
+  const int ud0 = od0 - p.pd, uh0 = oh0 - p.ph, uw0 = ow0 - p.pw;
+  const int nchunks = p.Cin / BK;                          // host-checked: Cin % BK == 0
+  const int cout_pad = (p.Cout + 15) & ~15;
+  const int total = nchunks * NGROUPS;
+
+  // ---- per-lane DMA sources ---------------------------------------------------------------------------------------------
+  // patch piece j of this wave covers LDS rows 16*(wave + NW*j) .. +15; lane -> (row, LDS slot lane&3) <- channel slot swizzled
+  const char* zero = reinterpret_cast<const char*>(gm_zero_row);
+  const char* xbase = reinterpret_cast<const char*>(p.x);
+  long long psrc[PPW];  // byte offset of this lane's 16 bytes in chunk 0, or -1 for a padding row
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int row = 16 * (wave + NW * j) + (lane >> 2);
+    const int pa = row / PLANE, rr = row - pa * PLANE;
+    const int pb = rr / PW, pc = rr - pb * PW;
+    int ud = ud0 + pa, uh = uh0 + pb, uw = uw0 + pc;
+    const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv);
+    if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
+    const long long vox = (((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw;
+    psrc[j] = ok ? (vox * p.x_ld * (long long)sizeof(T) + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
+  }
+  auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (wave + NW * j < PPIECES) {  // wave-uniform
+        const char* src = psrc[j] >= 0 ? xbase + psrc[j] + (long long)chunk * (BK * (int)sizeof(T)) : zero + ((lane & 3) << 4);
+        dma16(src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
+      }
+    }
+  };
+  // weight panel of global tap group t (chunk = t / 9, taps 3*(t%9) ..): rows r = u*64 + co_local.  Wave w moves rows
+  // 16w .. 16w+15 (full piece) and rows 128 + 8w .. +7 (half piece, lanes 0..31).
+  const char* wbase = reinterpret_cast<const char*>(p.w);
+  int wrow[2];
+  long long wsrc[2];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2);
+    const int u = row >> 6, col = row & 63;
+    const int co = cb * BN + col;
+    wrow[h] = row;
+    wsrc[h] = co < cout_pad ? (((long long)u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
+  }
+  auto issue_w = [&](int t, int buf) __attribute__((always_inline)) {  // 2 pieces per wave, every wave
+    const long long panel = (long long)t * G * cout_pad * DMA_ROWB;     // (chunk*27 + 3*grp) * cout_pad rows
+    const unsigned dst = lds0 + PATCH_BYTES + (unsigned)buf * WBUF_BYTES;
+    const char* s0 = wsrc[0] >= 0 ? wbase + panel + wsrc[0] : zero + ((lane & 3) << 4);
+    dma16(s0, dst + (unsigned)(16 * wave) * DMA_ROWB);
+    const char* s1 = wsrc[1] >= 0 ? wbase + panel + wsrc[1] : zero + ((lane & 3) << 4);
+    if (lane < 32) dma16(s1, dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
+  };
+
+  // ---- per-lane operand read addresses (bytes from smem) ------------------------------------------------------------------
+  int xaddr[MF][3][3];  // voxel fragment mf at tap (0, kh, kw); depth taps add kd * PLANE * 64 as an immediate
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = (wave * MF + mf) * 16 + l15;
+    const int a = m >> 6, bb = (m >> 4) & 3, c = m & 15;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int row = a * PLANE + (bb + kh) * PW + c + kw;
+        xaddr[mf][kh][kw] = row * DMA_ROWB + ((q ^ dma_swz(row)) << 4);
+      }
+  }
+  int waddr[NFR];
+#pragma unroll
+  for (int nf = 0; nf < NFR; ++nf) {
+    const int r = nf * 16 + l15;
+    waddr[nf] = PATCH_BYTES + r * DMA_ROWB + ((q ^ dma_swz(r)) << 4);
+  }
+
+  f32x4_t acc[NFR][MF];
+#pragma unroll
+  for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // ---- main loop ----------------------------------------------------------------------------------------------------------
+  issue_patch(0);
+  issue_w(0, 0);
+  if (total > 1) issue_w(1, 1);
+  dma_wait<0>();
+  __builtin_amdgcn_s_barrier();
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const bool last_chunk = chunk + 1 == nchunks;
+#pragma unroll
+    for (int g = 0; g < NGROUPS; ++g) {
+      const int t = chunk * NGROUPS + g;
+      // panel t+2 goes into the ring slot group t-1 read from (every wave is past the barrier that ended it)
+      if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % 3);
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int tap = g * G + u;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        uint4 xf[MF], wf[NFR];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+          xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[mf][kh][kw] + kd * (PLANE * DMA_ROWB));
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf)
+          wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + (g % 3) * WBUF_BYTES + u * (BN * DMA_ROWB));
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[nf][mf]);
+        __builtin_amdgcn_sched_group_barrier(0x100, MF + NFR, 0);                              // the tap's DS reads first
+        __builtin_amdgcn_sched_group_barrier(0x008, MF * NFR * (sizeof(T) == 2 ? 1 : 4), 0);  // then its MFMAs
+      }
+      if (g == NGROUPS - 1) {
+        if (!last_chunk) {
+          __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
+          issue_patch(chunk + 1);
+          dma_wait<0>();                 // patch + the two panels in flight
+          __builtin_amdgcn_s_barrier();
+        }
+      } else {
+        // panel t+1 (issued a group ago) must have landed; panel t+2 (2 pieces, just issued) may stay in flight
+        if (g < NGROUPS - 2 || !last_chunk) dma_wait<2>(); else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+
+  // ---- epilogue (shared with conv_fast): LDS transpose -> 16-byte row stores, fused GroupNorm statistics -------------------
+  __syncthreads();
+  constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
+  constexpr int CH_PER_PASS = 128 / (int)sizeof(T);
+  float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
+#pragma unroll
+  for (int e = 0; e < EPASSES; ++e)
+#pragma unroll
+    for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
+  conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wave * MF * 16, cb * BN, od0, oh0, ow0, lane, st_s, st_q);
+  if (p.stats) {
+    float* sst = reinterpret_cast<float*>(smem);  // [NW][64 channels][2]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPASSES; ++e)
+#pragma unroll
+      for (int i = 0; i < VECW; ++i) {
+        float a = st_s[e][i], b2 = st_q[e][i];
+        a += __shfl_xor(a, 8, 64); b2 += __shfl_xor(b2, 8, 64);
+        a += __shfl_xor(a, 16, 64); b2 += __shfl_xor(b2, 16, 64);
+        a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64);
+        if (lane < 8) {
+          const int ch = e * CH_PER_PASS + lane * VECW + i;
+          sst[(wave * 64 + ch) * 2] = a;
+          sst[(wave * 64 + ch) * 2 + 1] = b2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN) {
+      double a = 0.0, b2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        a += (double)sst[(w * 64 + tid) * 2];
+        b2 += (double)sst[(w * 64 + tid) * 2 + 1];
+      }
+      const int co = cb * BN + tid;
+      if (co < p.Cout) {
+        const long long slot = (blockIdx.x / ncb) % GM_STAT_SLOTS;
+        double* dst = p.stats + ((slot * p.N + n) * p.Cout + co) * 2;
+        atomicAdd(dst, a);
+        atomicAdd(dst + 1, b2);
+      }
+    }
+  }
+}
+
+extern "C" long long gm_conv_dma_lds_bytes() { return 672LL * DMA_ROWB + 3LL * 192 * DMA_ROWB; }
+
+// geometry this kernel covers (the caller has already checked stride 1 / dilation 1 / alignment like for conv_fast)
+extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
+  const int bk = d->dtype == GM_F32 ? 16 : 32;
+  const int vecw = d->dtype == GM_F32 ? 4 : 8;
+  return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
+         (d->in_mode == 0 || d->in_mode == 1) && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
+         (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->ltd == 2 && d->lth == 2 &&
+         d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
+         (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) &&
+         (long long)d->N * d->Ds * d->Hs * d->Ws * d->x_ld < (1LL << 40);
+}
+
+template <typename T>
+static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_dma_kernel<T>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();
+    attr_set = true;
+  }
+  kern<<<dim3(nblocks), 512, (size_t)gm_conv_dma_lds_bytes(), st>>>(d);
+}
+
+extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dp->dtype == GM_F32) { launch_dma<float>(*dp, nblocks, st); return 0; }
+  if (dp->dtype == GM_BF16) { launch_dma<bf16_raw>(*dp, nblocks, st); return 0; }
+  return -2;
+}

@@ -472,6 +472,8 @@ def _cfg_tile(cfg: int):
 
 _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
 
+DMA_CONV = True              # route eligible 3x3x3 convolutions through conv_dma.hip (cfg 11)
+DMA_CONV_MIN_VOXELS = 1 << 12
 LDS_SOFT_LIMIT = 80 * 1024   # two workgroups per CU
 LDS_HARD_LIMIT = 160 * 1024
 
@@ -487,6 +489,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         order = [10, 8, 5, 0, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [8, 5, 0, 4, 2]
     else:
         order = [10, 9, 6, 1, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [9, 6, 1, 4, 2]
+    if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
+        order = [11] + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
         order = [c for c in order if _cfg_tile(c)[0] <= 64] + [c for c in order if _cfg_tile(c)[0] > 64]
     best = None

@@ -18,7 +18,12 @@ SHAPES = [  # name, Cin, Cout, spatial (input), upsample, prologue
 ]
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [5, 6, 7, 8, 9]
 dtype = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
+PLAIN = bool(int(os.environ.get("BENCH_PLAIN", "0")))  # drop the fused prologue from every shape (the LDS-DMA kernel's domain)
 for name, cin, cout, sp, up, pro in SHAPES:
+    if PLAIN:
+        if not pro:
+            continue
+        name, pro = name.replace("gn+silu", "plain"), False
     x = torch.randn((1, *sp, cin), device=dev).to(dtype)
     w = (torch.randn((cout, cin, 3, 3, 3), device=dev) / math.sqrt(cin * 27)).to(dtype)
     b = torch.randn((cout,), device=dev)
