@@ -28,6 +28,10 @@ if [[ $STAGES == *b* ]]; then
   timeout 1200 python bench.py --steps 2 --warmup 1 > $OUT/bench.log 2>&1
   echo "bench rc=$?" >> $OUT/round.log; tail -c 3000 $OUT/bench.log >> $OUT/round.log
 fi
+if [[ $STAGES == *l* ]]; then
+  timeout 600 python tools/layer_times.py > $OUT/layer_times.log 2>&1
+  echo "layer_times rc=$?" >> $OUT/round.log; tail -1 $OUT/layer_times.log >> $OUT/round.log
+fi
 if [[ $STAGES == *p* ]]; then
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 0 --graph 0 --cpu-baseline off > $OLDPWD/$OUT/prof.log 2>&1)
   echo "prof rc=$?" >> $OUT/round.log
