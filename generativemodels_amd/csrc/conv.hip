@@ -290,6 +290,16 @@ extern "C" long long gm_conv_dma_lds_bytes();
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA; }
+// HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
+#define CONV_CFG_CIN 12
+#define CONV_CFG_COUT1 13
+extern "C" int gm_conv_cin_eligible(const GmConvDesc* d);
+extern "C" long long gm_conv_cin_lds_bytes(const GmConvDesc* d);
+extern "C" int gm_conv_cin_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
+extern "C" int gm_conv_cout1_eligible(const GmConvDesc* d);
+extern "C" long long gm_conv_cout1_lds_bytes();
+extern "C" int gm_conv_cout1_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
+static inline bool conv_is_edge(int cfg) { return cfg == CONV_CFG_CIN || cfg == CONV_CFG_COUT1; }
 
 static bool conv_fast_eligible(const GmConvDesc& d) {
   const int vecw = d.dtype == GM_F32 ? 4 : 8;
@@ -302,7 +312,8 @@ static bool conv_fast_eligible(const GmConvDesc& d) {
 }
 
 extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
-  if (conv_is_dma(cfg)) { *bm = 256; *bn = 64; return 0; }
+  if (conv_is_dma(cfg) || cfg == CONV_CFG_CIN) { *bm = 256; *bn = 64; return 0; }
+  if (cfg == CONV_CFG_COUT1) { *bm = 256; *bn = 16; return 0; }
   if (conv_is_fast(cfg)) { int t = 0; return gm_conv_fast_variant_geometry(conv_fast_variant(cfg), bm, bn, &t); }
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
   *bm = kCfgs[cfg].WM * kCfgs[cfg].MF * 16;
@@ -338,6 +349,8 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes() : -1;
+  if (d && d->cfg == CONV_CFG_CIN) return gm_conv_cin_eligible(d) ? gm_conv_cin_lds_bytes(d) : -1;
+  if (d && d->cfg == CONV_CFG_COUT1) return gm_conv_cout1_eligible(d) ? gm_conv_cout1_lds_bytes() : -1;
   if (d && conv_is_fast(d->cfg)) {
     if (!conv_fast_eligible(*d)) return -1;
     return gm_conv_fast_lds_bytes(d, conv_fast_bn(d->cfg));
@@ -357,7 +370,8 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(d.x && d.w && d.y, "null tensor pointer");
   const bool fast = conv_is_fast(d.cfg);
   const bool dma = conv_is_dma(d.cfg);
-  GM_REQUIRE(fast || dma || (d.cfg >= 0 && d.cfg < kNumCfgs), "bad tile configuration");
+  const bool edge = conv_is_edge(d.cfg);
+  GM_REQUIRE(fast || dma || edge || (d.cfg >= 0 && d.cfg < kNumCfgs), "bad tile configuration");
   GM_REQUIRE((d.pre_scale == nullptr) == (d.pre_shift == nullptr), "pre_scale and pre_shift go together");
   GM_REQUIRE(d.N >= 0 && d.Cin > 0 && d.Cout > 0, "bad channel / batch count");
   GM_REQUIRE(d.kd > 0 && d.kh > 0 && d.kw > 0 && d.sd > 0 && d.sh > 0 && d.sw > 0 && d.dd > 0 && d.dh > 0 && d.dw > 0, "bad kernel geometry");
@@ -368,6 +382,8 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE((1 << (d.ltd + d.lth + d.ltw)) == bm, "tile dims do not match the configuration");
   GM_REQUIRE(!fast || conv_fast_eligible(d), "geometry is not eligible for the fast stride-1 kernel");
   GM_REQUIRE(!dma || gm_conv_dma_eligible(dp), "geometry is not eligible for the LDS-DMA 3x3x3 kernel");
+  GM_REQUIRE(!edge || (d.cfg == CONV_CFG_CIN ? gm_conv_cin_eligible(dp) : gm_conv_cout1_eligible(dp)),
+             "geometry is not eligible for the C_in<=4 / C_out==1 kernels");
   const long long smem = gm_conv_lds_bytes(dp);
   GM_REQUIRE(smem > 0 && smem <= 160 * 1024, "tile needs more than 160 KiB of LDS");
   const long long ntd = (d.Do + (1 << d.ltd) - 1) >> d.ltd, nth = (d.Ho + (1 << d.lth) - 1) >> d.lth,
@@ -377,6 +393,11 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(nblocks < (1LL << 31), "grid too large");
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (edge) {
+    rc = d.cfg == CONV_CFG_CIN ? gm_conv_cin_launch(dp, (unsigned)nblocks, stream) : gm_conv_cout1_launch(dp, (unsigned)nblocks, stream);
+    GM_REQUIRE(rc == 0, "unsupported dtype");
+    GM_LAUNCH_CHECK();
+  }
   if (dma) {
     rc = gm_conv_dma_launch(dp, (unsigned)nblocks, stream);
     GM_REQUIRE(rc == 0, "unsupported dtype");

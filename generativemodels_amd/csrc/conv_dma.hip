@@ -30,9 +30,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
 }
+// wait until at most N of this wave's DMA pieces are in flight AND all of its LDS reads have returned: the barrier that follows
+// releases other waves to overwrite the ring slot / patch this wave has been reading
 template <int N>
 __device__ __forceinline__ void dma_wait() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
 template <typename T>
@@ -82,7 +84,8 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
   // patch piece j of this wave covers LDS rows 16*(wave + NW*j) .. +15; lane -> (row, LDS slot lane&3) <- channel slot swizzled
   const char* zero = reinterpret_cast<const char*>(gm_zero_row);
   const char* xbase = reinterpret_cast<const char*>(p.x);
-  long long psrc[PPW];  // byte offset of this lane's 16 bytes in chunk 0, or -1 for a padding row
+  int pvox[PPW];  // source voxel of this lane's patch row per piece, or -1 for a padding row (32-bit: host checks N*V < 2^31)
+  const int pswz = ((lane & 3) ^ dma_swz(lane >> 2)) << 4;  // piece bases are multiples of 16 rows: the swizzle term is per lane
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
     const int row = 16 * (wave + NW * j) + (lane >> 2);
@@ -91,14 +94,15 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
     int ud = ud0 + pa, uh = uh0 + pb, uw = uw0 + pc;
     const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv);
     if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
-    const long long vox = (((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw;
-    psrc[j] = ok ? (vox * p.x_ld * (long long)sizeof(T) + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
+    pvox[j] = ok ? ((n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
   }
+  const long long xrowb = p.x_ld * (long long)sizeof(T);
   auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
+    const char* cbase = xbase + (long long)chunk * (BK * (int)sizeof(T)) + pswz;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       if (wave + NW * j < PPIECES) {  // wave-uniform
-        const char* src = psrc[j] >= 0 ? xbase + psrc[j] + (long long)chunk * (BK * (int)sizeof(T)) : zero + ((lane & 3) << 4);
+        const char* src = pvox[j] >= 0 ? cbase + pvox[j] * xrowb : zero + ((lane & 3) << 4);
         dma16(src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
       }
     }
@@ -106,22 +110,20 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
   // weight panel of global tap group t (chunk = t / 9, taps 3*(t%9) ..): rows r = u*64 + co_local.  Wave w moves rows
   // 16w .. 16w+15 (full piece) and rows 128 + 8w .. +7 (half piece, lanes 0..31).
   const char* wbase = reinterpret_cast<const char*>(p.w);
-  int wrow[2];
-  long long wsrc[2];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
+  int wsrc[2];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2);
     const int u = row >> 6, col = row & 63;
     const int co = cb * BN + col;
-    wrow[h] = row;
-    wsrc[h] = co < cout_pad ? (((long long)u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
+    wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
   }
   auto issue_w = [&](int t, int buf) __attribute__((always_inline)) {  // 2 pieces per wave, every wave
-    const long long panel = (long long)t * G * cout_pad * DMA_ROWB;     // (chunk*27 + 3*grp) * cout_pad rows
+    const char* panel = wbase + (long long)t * G * cout_pad * DMA_ROWB;  // (chunk*27 + 3*grp) * cout_pad rows
     const unsigned dst = lds0 + PATCH_BYTES + (unsigned)buf * WBUF_BYTES;
-    const char* s0 = wsrc[0] >= 0 ? wbase + panel + wsrc[0] : zero + ((lane & 3) << 4);
+    const char* s0 = wsrc[0] >= 0 ? panel + wsrc[0] : zero + ((lane & 3) << 4);
     dma16(s0, dst + (unsigned)(16 * wave) * DMA_ROWB);
-    const char* s1 = wsrc[1] >= 0 ? wbase + panel + wsrc[1] : zero + ((lane & 3) << 4);
+    const char* s1 = wsrc[1] >= 0 ? panel + wsrc[1] : zero + ((lane & 3) << 4);
     if (lane < 32) dma16(s1, dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
   };
 
@@ -166,26 +168,38 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
       const int t = chunk * NGROUPS + g;
       // panel t+2 goes into the ring slot group t-1 read from (every wave is past the barrier that ended it)
       if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % 3);
-#pragma unroll
-      for (int u = 0; u < G; ++u) {
+      // The last tap's operand reads are issued before the end-of-group wait and its MFMAs after the barrier.  The wait retires
+      // every LDS read of the group (lgkmcnt(0)): the barrier releases other waves to DMA into the ring slot this group read.
+      // (Measured against an ordering that keeps the two patch reads of the last tap in flight across the barrier: 2-3 % slower.)
+      uint4 xf[MF], wf[NFR];
+      auto read_tap = [&](int u) __attribute__((always_inline)) {
         const int tap = g * G + u;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-        uint4 xf[MF], wf[NFR];
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-          xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[mf][kh][kw] + kd * (PLANE * DMA_ROWB));
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf)
           wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + (g % 3) * WBUF_BYTES + u * (BN * DMA_ROWB));
 #pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+          xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[mf][kh][kw] + kd * (PLANE * DMA_ROWB));
+      };
+      auto mma_tap = [&]() __attribute__((always_inline)) {
+#pragma unroll
         for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[nf][mf]);
-        __builtin_amdgcn_sched_group_barrier(0x100, MF + NFR, 0);                              // the tap's DS reads first
-        __builtin_amdgcn_sched_group_barrier(0x008, MF * NFR * (sizeof(T) == 2 ? 1 : 4), 0);  // then its MFMAs
+      };
+      constexpr int NMMA = MF * NFR * (sizeof(T) == 2 ? 1 : 4);
+#pragma unroll
+      for (int u = 0; u < G - 1; ++u) {
+        read_tap(u);
+        mma_tap();
+        __builtin_amdgcn_sched_group_barrier(0x100, MF + NFR, 0);  // all operand reads of a tap before its MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
       }
+      read_tap(G - 1);
       if (g == NGROUPS - 1) {
         if (!last_chunk) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
           issue_patch(chunk + 1);
           dma_wait<0>();                 // patch + the two panels in flight
@@ -196,6 +210,7 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
         if (g < NGROUPS - 2 || !last_chunk) dma_wait<2>(); else dma_wait<0>();
         __builtin_amdgcn_s_barrier();
       }
+      mma_tap();
     }
   }
 
@@ -256,7 +271,7 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
          (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->ltd == 2 && d->lth == 2 &&
          d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
          (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) &&
-         (long long)d->N * d->Ds * d->Hs * d->Ws * d->x_ld < (1LL << 40);
+         (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31);
 }
 
 template <typename T>

@@ -489,6 +489,11 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         order = [10, 8, 5, 0, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [8, 5, 0, 4, 2]
     else:
         order = [10, 9, 6, 1, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [9, 6, 1, 4, 2]
+    if force_cfg is None and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
+        if cout == 1:
+            order = [13] + order  # taps-as-N kernel of the single-channel output heads (conv_edge.hip)
+        if desc.Cin <= 4:
+            order = [12] + order  # taps-as-K kernel of the 1..4-channel input convolutions
     if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
         order = [11] + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
@@ -617,7 +622,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     d.debug_flags = _CONV_DEBUG_FLAGS
     _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
     d.stats = None
-    if want_stats and d.cfg >= 5:  # only the fast stride-1 kernels fuse the output statistics into their epilogue
+    if want_stats and d.cfg >= 5 and d.cfg != 13:  # the fast stride-1 kernels fuse the output statistics into their epilogue
         cst = torch.zeros((STAT_SLOTS, n, cout, 2), dtype=torch.float64, device=x.device)
         d.stats = cst.data_ptr()
         out._gm_cstats = cst

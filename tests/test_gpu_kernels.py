@@ -283,6 +283,55 @@ def test_conv_lds_dma_kernel(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,sp", [(1, 64, (8, 8, 16)), (1, 40, (5, 7, 19)), (3, 96, (4, 6, 18)), (4, 64, (6, 5, 17))])
+def test_conv_few_input_channels_kernel(cin, cout, sp, dtype):
+    """cfg 12 (conv_edge.hip, taps x C_in as the GEMM K): conv_in shapes, ragged volumes, channel-sliced output, bias + residual,
+    fused GroupNorm statistics; and the automatic choice routes C_in <= 4 there."""
+    ops = _ops()
+    n = 2
+    x = _rand((n, cin, *sp), 81).to(dtype)
+    w = (_rand((cout, cin, 3, 3, 3), 82) / math.sqrt(cin * 27)).to(dtype)
+    b = _rand((cout,), 83) * 0.1
+    res = _rand((n, cout, *sp), 84).to(dtype)
+    want = F.conv3d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    wide_out = torch.full((n, *sp, cout + 8), 3.0, dtype=dtype, device=DEV)
+    got = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=3, padding=1, res=_cl(res), out=wide_out[..., 8:], force_cfg=12, want_stats=True)
+    _check(_cf(got), want, dtype, f"cin{cin}")
+    assert torch.all(wide_out[..., :8] == 3.0)
+    st = got._gm_cstats.sum(0).cpu()
+    v = got.float().cpu().double().reshape(n, -1, cout)
+    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1], (v * v).sum(1), rtol=1e-4, atol=1e-2)
+    auto = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=3, padding=1, res=_cl(res))  # whatever kernel the chooser picks agrees
+    _check(_cf(auto), want, dtype, f"cin{cin} auto")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,sp,pro", [(64, (8, 8, 16), True), (64, (5, 7, 19), True), (128, (4, 6, 18), False), (32, (6, 5, 17), True)])
+def test_conv_single_output_channel_kernel(cin, sp, pro, dtype):
+    """cfg 13 (conv_edge.hip, taps as the GEMM N + 27-point gather): the `out` head GN -> SiLU -> conv C->1 with the fused prologue,
+    ragged volumes, channel-sliced input."""
+    ops = _ops()
+    if dtype == torch.bfloat16 and cin == 32:
+        pytest.skip("bf16 channel steps are 32 wide: 64 / 128 input channels")
+    n = 2
+    x = (_rand((n, cin, *sp), 91) * 1.2 + 0.1).to(dtype)
+    w = (_rand((1, cin, 3, 3, 3), 92) / math.sqrt(cin * 27)).to(dtype)
+    b = _rand((1,), 93) * 0.1
+    scale, shift = _rand((n, cin), 94) * 0.2 + 1.0, _rand((n, cin), 95) * 0.1
+    xin = x.double()
+    if pro:
+        xin = F.silu(xin * scale.double().reshape(n, cin, 1, 1, 1) + shift.double().reshape(n, cin, 1, 1, 1))
+    want = F.conv3d(xin, w.double(), b.double(), padding=1)
+    wide_in = torch.zeros((n, *sp, cin + 8), dtype=dtype, device=DEV)
+    wide_in[..., 8:] = _cl(x)
+    kw = dict(kernel=3, padding=1, pre=(scale.to(DEV), shift.to(DEV)) if pro else None, pre_act="silu" if pro else "none")
+    got = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), force_cfg=13, **kw)
+    _check(_cf(got), want, dtype, f"cout1 cin{cin}")
+    auto = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), **kw)
+    _check(_cf(auto), want, dtype, f"cout1 cin{cin} auto")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_fused_resnet_prologue_epilogue(dtype):
     """GN-apply + SiLU prologue, bias + timestep row + residual epilogue, channel-sliced input and output buffers."""
     ops = _ops()

@@ -18,6 +18,7 @@ SHAPES = [  # name, Cin, Cout, spatial (input), upsample, prologue
 ]
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [5, 6, 7, 8, 9]
 dtype = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
+ops._CONV_DEBUG_FLAGS = int(os.environ.get("CONV_FLAGS", "0"))
 PLAIN = bool(int(os.environ.get("BENCH_PLAIN", "0")))  # drop the fused prologue from every shape (the LDS-DMA kernel's domain)
 for name, cin, cout, sp, up, pro in SHAPES:
     if PLAIN:
@@ -44,11 +45,11 @@ for name, cin, cout, sp, up, pro in SHAPES:
                 assert err < 0.1, (name, cfg, err)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(3):
+            for _ in range(20):
                 ops.conv(x, w, b, **kw)
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 3
+            ms = e0.elapsed_time(e1) / 20
             line += f" | cfg{cfg}: {ms:7.3f} ms {flops / ms / 1e9:7.1f} TF/s"
         except Exception as ex:  # noqa
             line += f" | cfg{cfg}: n/a ({str(ex)[:40]})"

@@ -16,7 +16,7 @@ import csv, glob, collections
 tot = collections.OrderedDict()
 for f in sorted(glob.glob("gpurun_out/pmc_conv/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "conv_fast" not in r.get("Kernel_Name", "") and "conv_igemm" not in r.get("Kernel_Name", ""):
+        if not any(k in r.get("Kernel_Name", "") for k in ("conv_fast", "conv_igemm", "conv_dma")):
             continue
         tot.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for k, v in tot.items():
