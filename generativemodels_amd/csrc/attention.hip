@@ -14,16 +14,7 @@
 // one ds_read_b128 per MFMA.  fp32: v_mfma_f32_16x16x4_f32 (exact fp32 products), V stays row-major.
 #include "gm_common.h"
 
-struct GmAttnDesc {
-  const void* q; long long q_ld;
-  const void* k; long long k_ld;
-  const void* v; long long v_ld;
-  const void* res; long long res_ld;  // optional residual, same geometry as o
-  void* o; long long o_ld;
-  int B, H, Lq, Lk, dh;
-  float scale;
-  int dtype;
-};
+#include "attn_common.h"
 
 template <typename T> struct AttnTraits;
 template <> struct AttnTraits<bf16_raw> { static constexpr int VECW = 8; static constexpr int KT = 64; };
@@ -270,6 +261,7 @@ static int dispatch_attn(const GmAttnDesc& d, hipStream_t st) {
 }
 
 extern "C" int gm_attention_max_head_dim(void) { return 256; }
+extern "C" int gm_attention_dma_try(const GmAttnDesc* dp, void* stream);  // attention_dma.hip
 
 extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream) {
   GM_REQUIRE(dp, "null descriptor");
@@ -281,6 +273,7 @@ extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream) {
   GM_REQUIRE((long long)d.B * d.H <= 65535, "too many (batch, head) pairs for one launch");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (gm_attention_dma_try(dp, stream)) GM_LAUNCH_CHECK();  // bf16, d in {64,128,256}, workspace given: LDS-DMA kernel
   int rc;
   if (d.dtype == GM_F32) rc = dispatch_attn<float>(d, st);
   else if (d.dtype == GM_BF16) rc = dispatch_attn<bf16_raw>(d, st);

@@ -1,0 +1,16 @@
+// Attention descriptor shared by attention.hip (register-staged, any dtype / head dim) and attention_dma.hip (bf16, LDS-DMA).
+#pragma once
+#include "gm_common.h"
+
+struct GmAttnDesc {
+  const void* q; long long q_ld;
+  const void* k; long long k_ld;
+  const void* v; long long v_ld;
+  const void* res; long long res_ld;  // optional residual, same geometry as o
+  void* o; long long o_ld;
+  int B, H, Lq, Lk, dh;
+  float scale;
+  int dtype;
+  void* workspace;             // optional scratch (gm_attention_workspace_bytes): enables the LDS-DMA kernel
+  long long workspace_bytes;
+};

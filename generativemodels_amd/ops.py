@@ -685,6 +685,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     for t, L in ((q, lq), (k, lk), (v, lk), (out, lq)):
         if t.shape[0] > 1 and t.stride(0) != L * arena_ld(t):
             raise ValueError("attention operands must be row-dense over (batch, tokens)")
+    d.workspace, d.workspace_bytes = None, 0
+    ws_bytes = lib().gm_attention_workspace_bytes(C.byref(d))
+    if ws_bytes > 0:  # scratch for the transposed V image of the LDS-DMA kernel; stream-ordered, freed on return
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
     meta = dict(flops=4.0 * b * lq * lk * c, bytes=float(q.element_size() * b * (2 * lq + 2 * lk) * c), shape=f"B{b} H{heads} Lq{lq} Lk{lk} dh{dh}")
     _timed(f"attention<{str(q.dtype).split('.')[-1]}>", meta,
            lambda: check(lib().gm_attention_forward(C.byref(d), _stream()), "gm_attention_forward"))

@@ -167,8 +167,12 @@ typedef struct GmAttnDesc {
   int B, H, Lq, Lk, dh;
   float scale;
   int dtype;
+  void* workspace;            /* optional scratch of gm_attention_workspace_bytes(): enables the LDS-DMA kernel (bf16, dh 64/128/256) */
+  long long workspace_bytes;
 } GmAttnDesc;
 int gm_attention_max_head_dim(void);
+/* bytes of scratch the fastest kernel for this geometry wants (0: none; the descriptor's workspace fields are not read) */
+long long gm_attention_workspace_bytes(const GmAttnDesc* d);
 int gm_attention_forward(const GmAttnDesc* d, void* stream);
 
 /* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */

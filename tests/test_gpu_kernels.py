@@ -401,6 +401,34 @@ def test_attention(case, dtype):
         _check(got2, want - res.double(), dtype, "attention (sliced qkv)")
 
 
+@pytest.mark.parametrize("case", [(1, 1, 256, 256, 256), (2, 2, 200, 333, 64), (1, 2, 130, 129, 128), (1, 1, 1000, 700, 256),
+                                  (2, 4, 128, 192, 64)], ids=lambda c: f"B{c[0]}H{c[1]}q{c[2]}k{c[3]}d{c[4]}")
+def test_attention_lds_dma_kernel(case):
+    """attention_dma.hip (bf16, head dims 64/128/256, >= 128 tokens): V transposed once into the scratch image, K / V^T tiles by
+    LDS-DMA with source-side swizzle, ragged query / key counts (zero page + masking), heads as channel slices, residual."""
+    ops = _ops()
+    b, h, lq, lk, dh = case
+    c = h * dh
+    dtype = torch.bfloat16
+    q, k, v = _rand((b, lq, c), 151).to(dtype), _rand((b, lk, c), 152).to(dtype), _rand((b, lk, c), 153).to(dtype)
+    res = _rand((b, lq, c), 154).to(dtype)
+    scale = 1 / math.sqrt(dh)
+    want = R._mha(q.double(), k.double(), v.double(), h, scale) + res.double()
+    from generativemodels_amd import _native
+    d = _native.GmAttnDesc()
+    d.dtype, d.dh, d.Lq, d.Lk, d.B, d.H = 1, dh, lq, lk, b, h
+    qd = q.to(DEV)
+    d.q = d.k = d.v = d.o = qd.data_ptr()
+    d.q_ld = d.k_ld = d.v_ld = d.o_ld = c
+    assert _native.lib().gm_attention_workspace_bytes(d) == b * h * dh * ((lk + 63) // 64 * 64) * 2  # this geometry takes the DMA path
+    got = ops.attention(qd, k.to(DEV), v.to(DEV), h, scale, res=res.to(DEV))
+    _check(got, want, dtype, "attention (LDS-DMA)")
+    if lq == lk:
+        qkv = torch.cat([q, k, v], dim=-1).to(DEV)
+        got2 = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], h, scale)
+        _check(got2, want - res.double(), dtype, "attention (LDS-DMA, sliced qkv)")
+
+
 def test_attention_softmax_is_stable_for_large_scores():
     ops = _ops()
     q = _rand((1, 70, 32), 61) * 30
