@@ -36,7 +36,8 @@ class GmConvDesc(C.Structure):
                 ("pd", C.c_int), ("ph", C.c_int), ("pw", C.c_int), ("dd", C.c_int), ("dh", C.c_int), ("dw", C.c_int),
                 ("in_mode", C.c_int), ("fd", C.c_int), ("fh", C.c_int), ("fw", C.c_int),
                 ("pre_act", C.c_int), ("post_act", C.c_int), ("dtype", C.c_int),
-                ("ltd", C.c_int), ("lth", C.c_int), ("ltw", C.c_int), ("cfg", C.c_int), ("debug_flags", C.c_int), ("stats", c_vp)]
+                ("ltd", C.c_int), ("lth", C.c_int), ("ltw", C.c_int), ("cfg", C.c_int), ("debug_flags", C.c_int), ("stats", c_vp),
+                ("skip_x", c_vp * 2), ("skip_ld", c_ll * 2), ("skip_cin", C.c_int * 2), ("skip_w", c_vp), ("skip_bias", c_vp)]
 
 
 class GmAttnDesc(C.Structure):

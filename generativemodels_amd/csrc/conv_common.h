@@ -28,6 +28,11 @@ struct GmConvDesc {
   int cfg;                        // tile configuration id (see dispatch)
   int debug_flags;                // 0 in production; bench-only ablation switches of conv_fast.hip
   double* stats;                  // optional [GM_STAT_SLOTS][N][Cout][2] (sum, sum of squares) of the OUTPUT, fp64 atomics
+  // optional fused 1x1 "skip" convolution (ResnetBlock shortcut): y += W_skip * cat(skip_x[0], skip_x[1]) + skip_bias, sources in
+  // the OUTPUT geometry; only the LDS-DMA kernel (cfg 11) implements it
+  const void* skip_x[2]; long long skip_ld[2]; int skip_cin[2];
+  const void* skip_w;             // gm_pack_conv_weight of the [Cout][skip_cin[0] + skip_cin[1]] 1x1 kernel
+  const float* skip_bias;         // [Cout] or null
 };
 
 // per-channel statistics are accumulated with fp64 atomics into GM_STAT_SLOTS copies (slot = tile index mod slots): with a

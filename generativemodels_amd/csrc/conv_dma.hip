@@ -214,6 +214,68 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
     }
   }
 
+  // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
+  // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
+  // and one piece of the two 4 KiB weight panels into the ring, one wait + barrier, then 2 x 8 MFMAs.
+  if (p.skip_x[0]) {
+    const int nsc0 = p.skip_cin[0] / BK, nsc = nsc0 + (p.skip_x[1] ? p.skip_cin[1] / BK : 0);
+    int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
+#pragma unroll
+    for (int h = 0; h < MF; ++h) {
+      const int m = wave * 32 + h * 16 + (lane >> 2);
+      const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+      svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
+    }
+    const int wcol = (wave & 3) * 16 + (lane >> 2);     // weight row of this lane's panel piece
+    const int wco = cb * BN + wcol;
+    const int wswz = ((lane & 3) ^ dma_swz(wcol)) << 4;
+    int caddr[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int m = (wave * MF + mf) * 16 + l15;
+      caddr[mf] = m * DMA_ROWB + ((q ^ dma_swz(m)) << 4);
+    }
+    const char* wsk = reinterpret_cast<const char*>(p.skip_w);
+    for (int sc0 = 0; sc0 < nsc; sc0 += 2) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // patch buffer and ring are free
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int sc = sc0 + j;
+        if (sc < nsc) {  // wave-uniform
+          const int part = sc >= nsc0 ? 1 : 0, cip = sc - (part ? nsc0 : 0);
+          const char* xb = reinterpret_cast<const char*>(p.skip_x[part]) + (long long)cip * (BK * (int)sizeof(T)) + pswz;
+          const long long rowb = p.skip_ld[part] * (long long)sizeof(T);
+#pragma unroll
+          for (int h = 0; h < MF; ++h) {
+            const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
+            dma16(src, lds0 + (unsigned)(j * 256 + wave * 32 + h * 16) * DMA_ROWB);
+          }
+          if ((wave >> 2) == j) {
+            const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane & 3) << 4);
+            dma16(src, lds0 + PATCH_BYTES + (unsigned)(j * BN + (wave & 3) * 16) * DMA_ROWB);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (sc0 + j < nsc) {
+          uint4 xf[MF], wf[NFR];
+#pragma unroll
+          for (int nf = 0; nf < NFR; ++nf) wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + j * (BN * DMA_ROWB));
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(smem + caddr[mf] + j * (256 * DMA_ROWB));
+#pragma unroll
+          for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[nf][mf]);
+        }
+      }
+    }
+  }
+
   // ---- epilogue (shared with conv_fast): LDS transpose -> 16-byte row stores, fused GroupNorm statistics -------------------
   __syncthreads();
   constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
@@ -271,7 +333,12 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
          (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->ltd == 2 && d->lth == 2 &&
          d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
          (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) &&
-         (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31);
+         (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31) && (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31) &&
+         (!d->skip_x[0] ||
+          (d->skip_w && d->skip_cin[0] > 0 && d->skip_cin[0] % bk == 0 && d->skip_ld[0] % vecw == 0 &&
+           (reinterpret_cast<uintptr_t>(d->skip_x[0]) & 15) == 0 &&
+           (!d->skip_x[1] || (d->skip_cin[1] > 0 && d->skip_cin[1] % bk == 0 && d->skip_ld[1] % vecw == 0 &&
+                              (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
 }
 
 template <typename T>

@@ -110,6 +110,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (
         float a = 0.f;
         if (co + r < p.Cout) {
           if (p.bias) a += p.bias[co + r];
+          if (p.skip_bias) a += p.skip_bias[co + r];
           if (p.rowvec) a += p.rowvec[(long long)n * p.rowvec_bstride + co + r];
         }
         add[r] = a;

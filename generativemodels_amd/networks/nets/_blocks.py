@@ -120,8 +120,9 @@ class ResnetBlock(nn.Module):
     """GN -> SiLU -> conv3 (+ timestep row) -> GN -> SiLU -> conv3 -> + skip(x).
 
     Covers the UNet block (reference diffusion_model_unet.py:589-696; `temb_channels` given) and the AutoencoderKL block
-    (autoencoderkl.py:125-193; no timestep path, shortcut named `nin_shortcut`).  Two fused conv launches + two GN-stat
-    passes replace the reference's 2 GN + 2 SiLU + 2-3 conv + 2 add launches; the normalised tensors never reach HBM."""
+    (autoencoderkl.py:125-193; no timestep path, shortcut named `nin_shortcut`).  Two fused conv launches (GroupNorm statistics
+    in their epilogues, the 1x1 shortcut inside the second one) + at most two GroupNorm-apply passes replace the reference's
+    2 GN + 2 SiLU + 2-3 conv + 2 add launches."""
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: Optional[int] = None, temb_channels: Optional[int] = None,
                  norm_num_groups: int = 32, norm_eps: float = 1e-6, up: bool = False, down: bool = False,
@@ -173,16 +174,12 @@ class ResnetBlock(nn.Module):
             h = self.conv1.run(ops.gn_apply(x, pre1[0], pre1[1], "silu"), rowvec=temb_row, want_stats=True)
         pre2 = gn_prologue(self.norm2, h)
         shortcut = getattr(self, self.shortcut_name)
+        fusion = dict(want_stats=True)
         if not isinstance(shortcut, ConvP):
-            skip = x  # identity (never a VirtualCat: the decoder resnets always change width)
-        elif cat:
-            w, b = shortcut.conv.weight, shortcut.conv.bias
-            c0 = x.parts[0].shape[-1]
-            skip = ops.conv(x.parts[0], w, b, kernel=1, packed=ops.packed_conv_weight(w, x.dtype, cin_range=(0, c0)), cout=w.shape[0])
-            skip = ops.conv(x.parts[1], w, None, kernel=1, packed=ops.packed_conv_weight(w, x.dtype, cin_range=(c0, w.shape[1])),
-                            cout=w.shape[0], res=skip)
+            fusion["res"] = x  # identity (never a VirtualCat: the decoder resnets always change width)
         else:
-            skip = shortcut.run(x)
+            # the 1x1 shortcut over x -- or over the two halves of the virtual concat -- rides along in conv2 as extra K chunks
+            fusion["skip"] = (list(x.parts) if cat else [x], shortcut.conv.weight, shortcut.conv.bias)
         if ops.fuse_gn_prologue(h):
-            return self.conv2.run(h, pre=pre2, pre_act="silu", res=skip, want_stats=True)
-        return self.conv2.run(ops.gn_apply(h, pre2[0], pre2[1], "silu"), res=skip, want_stats=True)
+            return self.conv2.run(h, pre=pre2, pre_act="silu", **fusion)
+        return self.conv2.run(ops.gn_apply(h, pre2[0], pre2[1], "silu"), **fusion)

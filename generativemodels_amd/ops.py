@@ -520,14 +520,17 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
          pre: Optional[tuple] = None, pre_act: str = "none", rowvec: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, post_act: str = "none", out: Optional[torch.Tensor] = None,
          packed: Optional[torch.Tensor] = None, cout: Optional[int] = None, force_cfg: Optional[int] = None,
-         want_stats: bool = False) -> torch.Tensor:
+         want_stats: bool = False, skip: Optional[tuple] = None) -> torch.Tensor:
     """Fused convolution over an arena tensor x = (N, *spatial, Cin).
 
     kernel/stride/padding/dilation: int or per-axis tuples (len = number of spatial axes). `padding` is the low-side pad,
     `pad_hi` the high side (default: same as low). upsample: nearest 2x folded into the input indexing.
     transposed: nn.ConvTransposeNd semantics (weight [Cin, Cout, *k]). pre = (scale, shift) fp32 [N, Cin] GroupNorm affine;
     pre_act in ACT; rowvec fp32 [B or 1, Cout]; res arena tensor in the output geometry; post_act in POST_ACT.
-    `packed`/`cout` override the weight panel (fused multi-head projections)."""
+    `packed`/`cout` override the weight panel (fused multi-head projections).
+    skip = (parts, weight, bias): a ResnetBlock's 1x1 shortcut convolution over cat(parts) (1 or 2 arena tensors in the output
+    geometry), added to the result.  Fused into the LDS-DMA kernel as extra K chunks when it covers the geometry; otherwise
+    computed by 1x1 launches first and added as the residual (`res` must then be None)."""
     require_device(x, weight, bias, rowvec, res, out)
     nsp = x.dim() - 2
     if nsp < 1 or nsp > 3:
@@ -611,6 +614,23 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     else:
         d.res, d.res_ld = None, 0
     d.y, d.y_ld = out.data_ptr(), arena_ld(out)
+    d.skip_w = d.skip_bias = None
+    d.skip_x[0] = d.skip_x[1] = None
+    skip_keep = None
+    if skip is not None:
+        parts, sw, sb = skip
+        parts = list(parts)
+        require_device(sw, sb, *parts)
+        if res is not None:
+            raise ValueError("skip and res are exclusive (the shortcut IS the residual)")
+        if not 1 <= len(parts) <= 2 or sw.shape[0] != cout or sw.shape[1] != sum(t.shape[-1] for t in parts) or math.prod(sw.shape[2:]) != 1:
+            raise ValueError("skip = (1 or 2 parts, [Cout, sum(C_part), 1...] weight, bias)")
+        for i, t in enumerate(parts):
+            if tuple(t.shape[:-1]) != out_shape[:-1] or t.dtype != dtype:
+                raise ValueError("skip parts must have the output geometry and dtype")
+            d.skip_x[i], d.skip_ld[i], d.skip_cin[i] = t.data_ptr(), arena_ld(t), t.shape[-1]
+        skip_keep = (packed_conv_weight(sw, dtype), as_f32(sb) if sb is not None else None)
+        d.skip_w, d.skip_bias = skip_keep[0].data_ptr(), _ptr(skip_keep[1])
     d.N, d.Cin, d.Cout = n, cin, cout
     d.Ds, d.Hs, d.Ws = src
     d.Do, d.Ho, d.Wo = out_sp
@@ -620,7 +640,25 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     d.dd, d.dh, d.dw = dil
     d.pre_act, d.post_act, d.dtype = ACT[pre_act], POST_ACT[post_act], dt_code(dtype)
     d.debug_flags = _CONV_DEBUG_FLAGS
-    _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
+    if skip is not None:
+        try:
+            _choose_conv_cfg(d, math.prod(out_sp), 11)  # only the LDS-DMA kernel fuses the shortcut
+        except ValueError:
+            # not covered (fused prologue, 2-D, small / ragged channel counts ...): 1x1 launches over the parts, then a residual
+            parts, sw, sb = skip
+            parts = list(parts)
+            acc_t, off = None, 0
+            for t in parts:
+                c_t = t.shape[-1]
+                acc_t = conv(t, sw, sb if acc_t is None else None, kernel=1,
+                             packed=packed_conv_weight(sw, dtype, cin_range=(off, off + c_t)), cout=cout, res=acc_t)
+                off += c_t
+            return conv(x, weight, bias, kernel=kernel, stride=stride, padding=padding, dilation=dilation, pad_hi=pad_hi,
+                        upsample=upsample, transposed=transposed, output_padding=output_padding, pre=pre, pre_act=pre_act,
+                        rowvec=rowvec, res=acc_t, post_act=post_act, out=out, packed=packed, cout=cout, force_cfg=force_cfg,
+                        want_stats=want_stats)
+    else:
+        _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
     d.stats = None
     if want_stats and d.cfg >= 5 and d.cfg != 13:  # the fast stride-1 kernels fuse the output statistics into their epilogue
         cst = torch.zeros((STAT_SLOTS, n, cout, 2), dtype=torch.float64, device=x.device)
@@ -632,8 +670,9 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
         es = x.element_size()
         taps = k[0] * k[1] * k[2]
         nvo = n * math.prod(out_sp)
-        meta = dict(flops=2.0 * nvo * cout * cin * taps,
-                    bytes=float(es * (n * math.prod(src) * cin + nvo * cout * (2 if res is not None else 1) + cout * cin * taps)),
+        scin = 0 if skip is None else sum(t.shape[-1] for t in skip[0])
+        meta = dict(flops=2.0 * nvo * cout * (cin * taps + scin),
+                    bytes=float(es * (n * math.prod(src) * cin + nvo * (cout * (2 if res is not None else 1) + scin) + cout * (cin * taps + scin))),
                     shape=f"{cin}->{cout} k{k} s{conv_stride} out{tuple(out_sp)} mode{d.in_mode}")
         _timed(f"conv_igemm<{str(dtype).split('.')[-1]},cfg{d.cfg}>", meta,
                lambda: check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward"))

@@ -147,6 +147,12 @@ typedef struct GmConvDesc {
   int debug_flags;           /* must be 0 (bench-only ablation switches: results are wrong when set) */
   double* stats;             /* optional, zero-initialised [GM_STAT_SLOTS][N][Cout][2]: per-channel sum / sum of squares of the
                                 stored output, accumulated by the fast stride-1 kernels (cfg >= 5) for the next GroupNorm */
+  /* optional fused 1x1 shortcut convolution of a ResnetBlock (diffusion_model_unet.py:684-696, autoencoderkl.py:188-193):
+   * y += W_skip * cat(skip_x[0], skip_x[1]) + skip_bias with the sources in the output geometry (skip_x[1] may be NULL).
+   * Implemented by cfg 11 only: gm_conv_lds_bytes() returns -1 for any other configuration when skip_x[0] is set. */
+  const void* skip_x[2]; long long skip_ld[2]; int skip_cin[2];
+  const void* skip_w;        /* gm_pack_conv_weight image of the [Cout][skip_cin[0]+skip_cin[1]] 1x1 kernel */
+  const float* skip_bias;    /* [Cout] or NULL */
 } GmConvDesc;
 int gm_conv_cfg_tile(int cfg, int* voxels, int* channels);
 long long gm_conv_lds_bytes(const GmConvDesc* d);

@@ -283,6 +283,37 @@ def test_conv_lds_dma_kernel(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("one", 64, 64, (32,), (8, 8, 16)), ("cat", 32, 40, (64, 32), (5, 7, 19)), ("cat3", 64, 136, (32, 96), (4, 6, 18)),
+                                  ("fallback2d", 16, 24, (8, 16), (9, 20))], ids=lambda c: c[0])
+def test_conv_fused_shortcut(case, dtype):
+    """ResnetBlock tail: conv3(h) + bias + conv1x1(cat(parts)) + bias_s (diffusion_model_unet.py:684-696) as ONE launch of the
+    LDS-DMA kernel (skip = extra K chunks, centre tap), including two-part virtual concats with channel-sliced sources and ragged
+    volumes; geometries the kernel does not cover (2-D here) take the 1x1-launch fallback with the same result."""
+    ops = _ops()
+    name, cin, cout, pcs, sp = case
+    n, nsp = 2, len(sp)
+    h = _rand((n, cin, *sp), 161).to(dtype)
+    w = (_rand((cout, cin, *([3] * nsp)), 162) / math.sqrt(cin * 3 ** nsp)).to(dtype)
+    b = _rand((cout,), 163) * 0.1
+    parts = [_rand((n, c, *sp), 170 + i).to(dtype) for i, c in enumerate(pcs)]
+    ws = (_rand((cout, sum(pcs), *([1] * nsp)), 164) / math.sqrt(sum(pcs))).to(dtype)
+    bs = _rand((cout,), 165) * 0.1
+    convf = {2: F.conv2d, 3: F.conv3d}[nsp]
+    want = convf(h.double(), w.double(), b.double(), padding=1) + convf(torch.cat([p.double() for p in parts], 1), ws.double(), bs.double())
+    dparts = []
+    for p in parts:  # sources are channel slices of wider arenas, like the skips of a decoder
+        wide = torch.zeros((n, *sp, p.shape[1] + 8), dtype=dtype, device=DEV)
+        wide[..., 8:] = _cl(p)
+        dparts.append(wide[..., 8:])
+    got = ops.conv(_cl(h), w.to(DEV), b.to(DEV), kernel=3, padding=1, skip=(dparts, ws.to(DEV), bs.to(DEV)), want_stats=True)
+    _check(_cf(got), want, dtype, f"fused shortcut {name}", extra=1.5)
+    if name != "fallback2d":
+        st = got._gm_cstats.sum(0).cpu()
+        v = got.float().cpu().double().reshape(n, -1, cout)
+        assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,sp", [(1, 64, (8, 8, 16)), (1, 40, (5, 7, 19)), (3, 96, (4, 6, 18)), (4, 64, (6, 5, 17))])
 def test_conv_few_input_channels_kernel(cin, cout, sp, dtype):
     """cfg 12 (conv_edge.hip, taps x C_in as the GEMM K): conv_in shapes, ragged volumes, channel-sliced output, bias + residual,
