@@ -289,7 +289,7 @@ static inline int conv_fast_bn(int cfg) { int v = 0, c = 0, t = 0; gm_conv_fast_
 extern "C" long long gm_conv_dma_lds_bytes();
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
-static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA; }
+static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || cfg == 14; }  // 14: the 4-wave x 64-voxel variant
 // HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
 #define CONV_CFG_CIN 12
 #define CONV_CFG_COUT1 13

@@ -37,12 +37,16 @@ __device__ __forceinline__ void dma_wait() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <typename T>
-__global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
+// NW waves per work-group, each owning MF voxel fragments (16 voxels) x 64 channels of the 256-voxel tile: <8, 2> = 16 waves / CU,
+// 0.75 LDS operand reads per MFMA; <4, 4> = 8 waves / CU with 256 VGPRs each, 0.5 reads per MFMA (the LDS port is the next limit
+// after latency: 16 waves x 6 KiB per tap = 768 LDS clocks against 512 MFMA clocks per SIMD)
+template <typename T, int NW, int MF>
+__global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
-  constexpr int NW = 8, NT = 64 * NW;
-  constexpr int MF = 2, NFR = 4, G = 3;
+  constexpr int NT = 64 * NW;
+  constexpr int NFR = 4, G = 3;
+  static_assert(NW * MF == 16, "256-voxel tile");
   constexpr int TD = 4, TH = 4, TW = 16;
   constexpr int PD = TD + 2, PH = TH + 2, PW = TW + 2;
   constexpr int PLANE = ((PH * PW + 15) / 16) * 16;        // 112 rows: depth offsets keep (row mod 16)
@@ -54,7 +58,8 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
   constexpr int PATCH_BYTES = PROWS * DMA_ROWB;
   constexpr int WBUF_BYTES = WROWS * DMA_ROWB;
   constexpr int NGROUPS = 9;                               // 27 taps / G
-  static_assert(WROWS == NW * 16 + NW * 8, "each wave moves one full and one half piece of a weight panel");
+  constexpr int WPW = NW == 8 ? 2 : 3;  // DMA instructions per wave per weight panel: 8 waves x (1 full + 1 half piece) or 4 x 3 full
+  static_assert(WROWS == 192, "12 pieces per weight panel");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB]
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -110,21 +115,27 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
   // weight panel of global tap group t (chunk = t / 9, taps 3*(t%9) ..): rows r = u*64 + co_local.  Wave w moves rows
   // 16w .. 16w+15 (full piece) and rows 128 + 8w .. +7 (half piece, lanes 0..31).
   const char* wbase = reinterpret_cast<const char*>(p.w);
-  int wsrc[2];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
+  int wsrc[WPW];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int row = h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2);
+  for (int h = 0; h < WPW; ++h) {
+    const int row = NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2)) : 16 * (wave + NW * h) + (lane >> 2);
     const int u = row >> 6, col = row & 63;
     const int co = cb * BN + col;
     wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
   }
-  auto issue_w = [&](int t, int buf) __attribute__((always_inline)) {  // 2 pieces per wave, every wave
+  auto issue_w = [&](int t, int buf) __attribute__((always_inline)) {  // WPW instructions per wave, every wave
     const char* panel = wbase + (long long)t * G * cout_pad * DMA_ROWB;  // (chunk*27 + 3*grp) * cout_pad rows
     const unsigned dst = lds0 + PATCH_BYTES + (unsigned)buf * WBUF_BYTES;
-    const char* s0 = wsrc[0] >= 0 ? panel + wsrc[0] : zero + ((lane & 3) << 4);
-    dma16(s0, dst + (unsigned)(16 * wave) * DMA_ROWB);
-    const char* s1 = wsrc[1] >= 0 ? panel + wsrc[1] : zero + ((lane & 3) << 4);
-    if (lane < 32) dma16(s1, dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
+#pragma unroll
+    for (int h = 0; h < WPW; ++h) {
+      const char* src = wsrc[h] >= 0 ? panel + wsrc[h] : zero + ((lane & 3) << 4);
+      if (NW == 8) {
+        if (h == 0) dma16(src, dst + (unsigned)(16 * wave) * DMA_ROWB);
+        else if (lane < 32) dma16(src, dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
+      } else {
+        dma16(src, dst + (unsigned)(16 * (wave + NW * h)) * DMA_ROWB);
+      }
+    }
   };
 
   // ---- per-lane operand read addresses (bytes from smem) ------------------------------------------------------------------
@@ -206,8 +217,8 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
           __builtin_amdgcn_s_barrier();
         }
       } else {
-        // panel t+1 (issued a group ago) must have landed; panel t+2 (2 pieces, just issued) may stay in flight
-        if (g < NGROUPS - 2 || !last_chunk) dma_wait<2>(); else dma_wait<0>();
+        // panel t+1 (issued a group ago) must have landed; panel t+2 (WPW instructions, just issued) may stay in flight
+        if (g < NGROUPS - 2 || !last_chunk) dma_wait<WPW>(); else dma_wait<0>();
         __builtin_amdgcn_s_barrier();
       }
       mma_tap();
@@ -222,11 +233,11 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
     int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
 #pragma unroll
     for (int h = 0; h < MF; ++h) {
-      const int m = wave * 32 + h * 16 + (lane >> 2);
+      const int m = wave * (MF * 16) + h * 16 + (lane >> 2);
       const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
       svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
     }
-    const int wcol = (wave & 3) * 16 + (lane >> 2);     // weight row of this lane's panel piece
+    const int wcol = (wave & 3) * 16 + (lane >> 2);     // weight row of this lane's panel piece (piece wave&3 of a 4-piece panel)
     const int wco = cb * BN + wcol;
     const int wswz = ((lane & 3) ^ dma_swz(wcol)) << 4;
     int caddr[MF];
@@ -249,9 +260,9 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(const GmConvDesc p) {
 #pragma unroll
           for (int h = 0; h < MF; ++h) {
             const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
-            dma16(src, lds0 + (unsigned)(j * 256 + wave * 32 + h * 16) * DMA_ROWB);
+            dma16(src, lds0 + (unsigned)(j * 256 + wave * (MF * 16) + h * 16) * DMA_ROWB);
           }
-          if ((wave >> 2) == j) {
+          if (NW == 4 || (wave >> 2) == j) {  // 8 waves: waves 0-3 move panel 0, waves 4-7 panel 1; 4 waves: every wave moves both
             const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane & 3) << 4);
             dma16(src, lds0 + PATCH_BYTES + (unsigned)(j * BN + (wave & 3) * 16) * DMA_ROWB);
           }
@@ -341,21 +352,22 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
                               (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
 }
 
-template <typename T>
+template <typename T, int NW, int MF>
 static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_dma_kernel<T>;
+  auto kern = conv_dma_kernel<T, NW, MF>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  kern<<<dim3(nblocks), 512, (size_t)gm_conv_dma_lds_bytes(), st>>>(d);
+  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(), st>>>(d);
 }
 
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (dp->dtype == GM_F32) { launch_dma<float>(*dp, nblocks, st); return 0; }
-  if (dp->dtype == GM_BF16) { launch_dma<bf16_raw>(*dp, nblocks, st); return 0; }
+  const bool four = dp->cfg == 14;  // cfg 11: 8 waves x 32 voxels, cfg 14: 4 waves x 64 voxels
+  if (dp->dtype == GM_F32) { if (four) launch_dma<float, 4, 4>(*dp, nblocks, st); else launch_dma<float, 8, 2>(*dp, nblocks, st); return 0; }
+  if (dp->dtype == GM_BF16) { if (four) launch_dma<bf16_raw, 4, 4>(*dp, nblocks, st); else launch_dma<bf16_raw, 8, 2>(*dp, nblocks, st); return 0; }
   return -2;
 }

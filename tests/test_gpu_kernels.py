@@ -252,7 +252,8 @@ def test_conv_every_tile_configuration(cfg, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [("plain", 32, 64, (8, 8, 16), False), ("ragged", 64, 40, (5, 7, 19), False),
                                   ("wide", 96, 136, (4, 6, 18), False), ("up", 32, 64, (3, 5, 9), True)], ids=lambda c: c[0])
-def test_conv_lds_dma_kernel(case, dtype):
+@pytest.mark.parametrize("cfg", [11, 14])
+def test_conv_lds_dma_kernel(case, dtype, cfg):
     """cfg 11 (conv_dma.hip): both operands through the LDS-DMA engine, source-side swizzle, zero page for the halo; ragged
     volumes, channel counts that are not tile multiples, folded 2x up-sampling, bias + timestep row + residual epilogue into a
     channel slice of a wider buffer, fused GroupNorm statistics."""
@@ -270,7 +271,7 @@ def test_conv_lds_dma_kernel(case, dtype):
     wide_in[..., 8:] = _cl(x)
     wide_out = torch.full((n, *osp, cout + 16), 7.0, dtype=dtype, device=DEV)
     got = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), kernel=3, padding=1, upsample=up, rowvec=temb.to(DEV), res=_cl(res),
-                   out=wide_out[..., 16:], force_cfg=11, want_stats=True)
+                   out=wide_out[..., 16:], force_cfg=cfg, want_stats=True)
     _check(_cf(got), want, dtype, f"dma {name}")
     assert torch.all(wide_out[..., :16] == 7.0)  # nothing written outside the slice
     st = got._gm_cstats.sum(0).cpu()             # [N][C][2] after folding the slots
