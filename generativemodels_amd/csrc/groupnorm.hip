@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
-// 16-byte vector variant: one lane = 8 bf16 / 4 fp32 consecutive channels of one voxel (HBM-bound: read + write once)
+// 16-byte vector variant: one lane = 8 bf16 / 4 fp32 consecutive channels of one voxel (HBM-bound: read + write once).
+// Measured 5.0 TB/s on 268 MB tensors; a 4x-unrolled variant with four loads in flight per lane measured the same, i.e. the mixed
+// read + write stream is at what HBM sustains, not latency-bound.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y,
                                                           long long y_ld, const float* __restrict__ scale,

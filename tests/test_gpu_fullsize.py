@@ -1,0 +1,114 @@
+"""GPU (-m gpu): the hot kernels at the FULL sizes of the headline configuration C2 (BASELINE.json: 1x1x128^3, channels 64/128/256,
+mid-block attention over 32^3 = 32768 tokens with one 256-wide head).  The CPU oracle cannot run whole tensors of this size
+inside a test, so parity is established through properties that do not depend on size:
+  * spot checks: for randomly drawn output positions the reference arithmetic (a direct fp64 dot product over the 3x3x3xC_in input
+    window / a full softmax row over all 32768 keys) is evaluated on the host from the SAME device inputs and compared;
+  * linearity of the convolution, conv(a + b) = conv(a) + conv(b) - bias, over the whole volume;
+  * the fused GroupNorm statistics against an independent reduction of the stored output;
+  * the whole sampling chain: finite, deterministic in its inputs, and identical volumes for identical noise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from generativemodels_amd import ops
+    return ops
+
+
+def _randn(shape, seed, dtype=torch.bfloat16, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=DEV) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("cin,cout,size,up", [(64, 64, 128, False), (192, 64, 128, False), (128, 128, 64, True), (256, 256, 32, False)])
+def test_conv_full_size_spot_checks_and_linearity(cin, cout, size, up):
+    ops = _ops()
+    x = _randn((1, size, size, size, cin), 1)
+    w = _randn((cout, cin, 3, 3, 3), 2, scale=1 / math.sqrt(cin * 27))
+    b = _randn((cout,), 3, torch.float32, 0.1)
+    osz = size * 2 if up else size
+    res = _randn((1, osz, osz, osz, cout), 4)
+    y = ops.conv(x, w, b, kernel=3, padding=1, upsample=up, res=res, want_stats=True)
+    assert y.shape == (1, osz, osz, osz, cout) and torch.isfinite(y.float()).all()
+    # ---- spot checks: 48 random output voxels + the 8 corners, all channels, fp64 reference from the same inputs ---------------
+    g = torch.Generator().manual_seed(5)
+    pts = torch.randint(0, osz, (48, 3), generator=g).tolist() + [[a, b_, c] for a in (0, osz - 1) for b_ in (0, osz - 1) for c in (0, osz - 1)]
+    w64 = w.double().cpu()
+    worst = 0.0
+    for d, h, ww in pts:
+        acc = b.double().cpu().clone()
+        for kd in range(3):
+            for kh in range(3):
+                for kw in range(3):
+                    ud, uh, uw = d + kd - 1, h + kh - 1, ww + kw - 1
+                    if min(ud, uh, uw) < 0 or max(ud, uh, uw) >= osz:
+                        continue
+                    src = x[0, ud // 2, uh // 2, uw // 2] if up else x[0, ud, uh, uw]
+                    acc += w64[:, :, kd, kh, kw] @ src.double().cpu()
+        want = acc + res[0, d, h, ww].double().cpu()
+        got = y[0, d, h, ww].double().cpu()
+        worst = max(worst, (got - want).abs().max().item() / max(1.0, want.abs().max().item()))
+    assert worst <= 1.5e-2, f"spot-check error {worst:.3e}"  # bf16 storage of the result: 2^-8 relative
+    # ---- fused statistics vs an independent reduction of the stored tensor -------------------------------------------------------
+    st = y._gm_cstats.sum(0)[0]  # [C][2]
+    v = y.double().reshape(-1, cout)
+    assert torch.allclose(st[:, 0], v.sum(0), rtol=1e-6, atol=1e-3) and torch.allclose(st[:, 1], (v * v).sum(0), rtol=1e-6, atol=1e-3)
+    # ---- linearity over the whole volume -----------------------------------------------------------------------------------------
+    x2 = _randn((1, size, size, size, cin), 6)
+    ya = ops.conv(x, w, b, kernel=3, padding=1, upsample=up).float()
+    yb = ops.conv(x2, w, b, kernel=3, padding=1, upsample=up).float()
+    yab = ops.conv((x.float() + x2.float()).to(torch.bfloat16), w, b, kernel=3, padding=1, upsample=up).float()
+    lin = (yab - (ya + yb - b)).abs()
+    scale = yab.abs().max().item()
+    assert lin.max().item() <= 4e-2 * scale and lin.mean().item() <= 4e-3 * scale, (lin.max().item(), lin.mean().item(), scale)
+
+
+def test_attention_full_size_rows_match_a_host_softmax():
+    ops = _ops()
+    L, dh = 32768, 256
+    qkv = _randn((1, L, 3 * dh), 11)
+    res = _randn((1, L, dh), 12)
+    scale = 1 / math.sqrt(dh)
+    out = ops.attention(qkv[..., :dh], qkv[..., dh:2 * dh], qkv[..., 2 * dh:], 1, scale, res=res)
+    assert torch.isfinite(out.float()).all()
+    rows = torch.randint(0, L, (24,), generator=torch.Generator().manual_seed(13)).tolist() + [0, L - 1]
+    k, v = qkv[0, :, dh:2 * dh].double().cpu(), qkv[0, :, 2 * dh:].double().cpu()
+    for r in rows:
+        p = torch.softmax(scale * (k @ qkv[0, r, :dh].double().cpu()), dim=0)
+        want = p @ v + res[0, r].double().cpu()
+        got = out[0, r].double().cpu()
+        assert (got - want).abs().max().item() <= 1.5e-2 * max(1.0, want.abs().max().item()), r
+
+
+def test_c2_sampling_chain_full_size_is_finite_and_reproducible():
+    """Three DDIM steps of the headline configuration at full size: finite, the same volume for the same noise (the only
+    run-to-run freedom is the summation order of the fp64 statistic atomics, far below bf16 resolution), different for different
+    noise, and an eps-prediction of unit scale for unit-variance input (random-init network)."""
+    from bench import C2, rerandomize_zero_params
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    from generativemodels_amd.networks.schedulers import DDIMScheduler
+
+    torch.manual_seed(0)
+    model = DiffusionModelUNet(**C2).eval()
+    model.load_state_dict(rerandomize_zero_params({k: v.clone() for k, v in model.state_dict().items()}))
+    model = model.to(DEV, torch.bfloat16)
+    sched = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    sched.set_timesteps(3)
+    inf = DiffusionInferer(sched)
+    noise = _randn((1, 1, 128, 128, 128), 21)
+    a = inf.sample(noise, model, sched, verbose=False)
+    b = inf.sample(noise, model, sched, verbose=False)
+    c = inf.sample(_randn((1, 1, 128, 128, 128), 22), model, sched, verbose=False)
+    assert a.shape == (1, 1, 128, 128, 128) and torch.isfinite(a.float()).all()
+    assert (a.float() - b.float()).abs().max().item() <= 2e-2 * a.float().abs().max().item()
+    assert (a.float() - c.float()).abs().mean().item() > 1e-2
+    eps = model(noise, torch.tensor([500.0], device=DEV))
+    assert torch.isfinite(eps.float()).all() and 1e-3 < eps.float().std().item() < 1e3
