@@ -52,6 +52,7 @@ PROTOTYPES = {
     "gm_abi_version": (C.c_int, []),
     "gm_last_error": (C.c_char_p, []),
     "gm_sched_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, C.c_int, C.POINTER(GmStepParams), c_vp]),
+    "gm_nearest_resize": (C.c_int, [c_vp, c_ll, c_vp, c_ll] + [C.c_int] * 9 + [c_vp]),
     "gm_axpby_rows": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, C.c_int, c_vp]),
     "gm_likelihood_term": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, C.c_int, C.POINTER(GmKlParams), c_vp]),
     "gm_lincomb": (C.c_int, [C.POINTER(c_vp), C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, c_vp, c_ll, C.c_int, c_vp]),

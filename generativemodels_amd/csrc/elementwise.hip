@@ -636,3 +636,44 @@ extern "C" int gm_scale(const void* x, void* out, float s, int mode, long long t
   else GM_FAIL(-2, "unsupported dtype");
   GM_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// F.interpolate(x, size, mode="nearest") on an arena tensor (N, D, H, W, C): the ControlNet latent inferers resize the conditioning
+// image to the latent grid (reference: inferers/inferer.py:926-927, 989-990, 1096-1097).  Source index = min(floor(dst * (in/out)),
+// in - 1) with the scale evaluated in fp32, exactly torch's nearest_neighbor_compute_source_index.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nearest_resize_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y, long long y_ld,
+                                                            int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
+                                                            float sd, float sh, float sw) {
+  const long long total = (long long)N * Do * Ho * Wo * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int ow = (int)(r % Wo); r /= Wo;
+    const int oh = (int)(r % Ho); r /= Ho;
+    const int od = (int)(r % Do);
+    const int n = (int)(r / Do);
+    const int id = min((int)floorf(od * sd), Di - 1), ih = min((int)floorf(oh * sh), Hi - 1), iw = min((int)floorf(ow * sw), Wi - 1);
+    const long long src = (((long long)n * Di + id) * Hi + ih) * Wi + iw;
+    const long long dst = (((long long)n * Do + od) * Ho + oh) * Wo + ow;
+    y[dst * y_ld + c] = x[src * x_ld + c];
+  }
+}
+
+extern "C" int gm_nearest_resize(const void* x, long long x_ld, void* y, long long y_ld, int N, int Di, int Hi, int Wi, int Do, int Ho,
+                                 int Wo, int C, int dtype, void* stream) {
+  GM_REQUIRE(x && y, "null pointer");
+  GM_REQUIRE(Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "empty spatial extent");
+  const long long total = (long long)N * Do * Ho * Wo * C;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const float sd = (float)Di / (float)Do, sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  if (dtype == GM_F32)
+    nearest_resize_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, N, Di, Hi, Wi, Do, Ho, Wo, C, sd, sh, sw);
+  else if (dtype == GM_BF16)
+    nearest_resize_kernel<bf16_raw><<<ew_grid(total), 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, N, Di, Hi, Wi, Do, Ho, Wo, C, sd, sh, sw);
+  else
+    GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}

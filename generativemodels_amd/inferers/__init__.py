@@ -1,3 +1,3 @@
-from .inferer import DiffusionInferer, LatentDiffusionInferer
+from .inferer import (ControlNetDiffusionInferer, ControlNetLatentDiffusionInferer, DiffusionInferer, LatentDiffusionInferer)
 
-__all__ = ["DiffusionInferer", "LatentDiffusionInferer"]
+__all__ = ["DiffusionInferer", "LatentDiffusionInferer", "ControlNetDiffusionInferer", "ControlNetLatentDiffusionInferer"]

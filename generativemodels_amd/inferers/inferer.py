@@ -283,3 +283,104 @@ class LatentDiffusionInferer(DiffusionInferer):
             resizer = nn.Upsample(size=inputs.shape[2:], mode=resample_interpolation_mode)
             outputs = (outputs[0], [resizer(x) for x in outputs[1]])
         return outputs
+
+
+class _Controlled:
+    """`diffusion_model(x, timesteps, context)` with the ControlNet evaluated first and its residuals injected -- the body the
+    reference repeats in every ControlNet inferer method (inferer.py:610-626, 676-694, 778-793)."""
+
+    def __init__(self, diffusion_model, controlnet, cn_cond) -> None:
+        self.diffusion_model, self.controlnet, self.cn_cond = diffusion_model, controlnet, cn_cond
+
+    def __call__(self, x, timesteps, context=None):
+        down, mid = self.controlnet(x=x, timesteps=timesteps, controlnet_cond=self.cn_cond, context=context)
+        return self.diffusion_model(x=x, timesteps=timesteps, context=context, down_block_additional_residuals=down,
+                                    mid_block_additional_residual=mid)
+
+
+class ControlNetDiffusionInferer(DiffusionInferer):
+    """Drop-in for generative.inferers.ControlNetDiffusionInferer (inferer.py:565-868): DiffusionInferer with a ControlNet
+    evaluated on every model call."""
+
+    def __init__(self, scheduler: nn.Module) -> None:
+        super().__init__(scheduler)
+
+    def __call__(self, inputs: torch.Tensor, diffusion_model: Callable[..., torch.Tensor], controlnet: Callable[..., torch.Tensor],
+                 noise: torch.Tensor, timesteps: torch.Tensor, cn_cond: torch.Tensor, condition: torch.Tensor | None = None,
+                 mode: str = "crossattn", seg: torch.Tensor | None = None) -> torch.Tensor:
+        return super().__call__(inputs=inputs, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond), noise=noise,
+                                timesteps=timesteps, condition=condition, mode=mode)
+
+    @torch.no_grad()
+    def sample(self, input_noise: torch.Tensor, diffusion_model: Callable[..., torch.Tensor], controlnet: Callable[..., torch.Tensor],
+               cn_cond: torch.Tensor, scheduler: Callable[..., torch.Tensor] | None = None, save_intermediates: bool | None = False,
+               intermediate_steps: int | None = 100, conditioning: torch.Tensor | None = None, mode: str = "crossattn",
+               verbose: bool = True, seg: torch.Tensor | None = None):
+        return super().sample(input_noise=input_noise, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond),
+                              scheduler=scheduler, save_intermediates=save_intermediates, intermediate_steps=intermediate_steps,
+                              conditioning=conditioning, mode=mode, verbose=verbose)
+
+    @torch.no_grad()
+    def get_likelihood(self, inputs: torch.Tensor, diffusion_model: Callable[..., torch.Tensor], controlnet: Callable[..., torch.Tensor],
+                       cn_cond: torch.Tensor, scheduler: Callable[..., torch.Tensor] | None = None,
+                       save_intermediates: bool | None = False, conditioning: torch.Tensor | None = None, mode: str = "crossattn",
+                       original_input_range: tuple | None = (0, 255), scaled_input_range: tuple | None = (0, 1), verbose: bool = True,
+                       seg: torch.Tensor | None = None, _noise: torch.Tensor | None = None):
+        return super().get_likelihood(inputs=inputs, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond), scheduler=scheduler,
+                                      save_intermediates=save_intermediates, conditioning=conditioning, mode=mode,
+                                      original_input_range=original_input_range, scaled_input_range=scaled_input_range,
+                                      verbose=verbose, _noise=_noise)
+
+
+def _resize_like(cn_cond: torch.Tensor, spatial) -> torch.Tensor:
+    """F.interpolate(cn_cond, size) with the default nearest mode (inferer.py:926-927): the conditioning image on the latent grid."""
+    if tuple(cn_cond.shape[2:]) == tuple(spatial):
+        return cn_cond
+    ops.require_device(cn_cond)
+    return ops.to_channels_first(ops.nearest_resize(ops.to_channels_last(cn_cond), tuple(spatial)))
+
+
+class ControlNetLatentDiffusionInferer(LatentDiffusionInferer):
+    """Drop-in for generative.inferers.ControlNetLatentDiffusionInferer (inferer.py:871-1123)."""
+
+    def __call__(self, inputs: torch.Tensor, autoencoder_model: Callable[..., torch.Tensor], diffusion_model: Callable[..., torch.Tensor],
+                 controlnet: Callable[..., torch.Tensor], noise: torch.Tensor, timesteps: torch.Tensor, cn_cond: torch.Tensor,
+                 condition: torch.Tensor | None = None, mode: str = "crossattn", seg: torch.Tensor | None = None,
+                 quantized: bool = True) -> torch.Tensor:
+        model = _Controlled(diffusion_model, controlnet, _resize_like(cn_cond, noise.shape[2:]))  # noise has the latent's shape
+        return super().__call__(inputs=inputs, autoencoder_model=autoencoder_model, diffusion_model=model, noise=noise,
+                                timesteps=timesteps, condition=condition, mode=mode, quantized=quantized)
+
+    @torch.no_grad()
+    def sample(self, input_noise: torch.Tensor, autoencoder_model: Callable[..., torch.Tensor],
+               diffusion_model: Callable[..., torch.Tensor], controlnet: Callable[..., torch.Tensor], cn_cond: torch.Tensor,
+               scheduler: Callable[..., torch.Tensor] | None = None, save_intermediates: bool | None = False,
+               intermediate_steps: int | None = 100, conditioning: torch.Tensor | None = None, mode: str = "crossattn",
+               verbose: bool = True, seg: torch.Tensor | None = None):
+        model = _Controlled(diffusion_model, controlnet, _resize_like(cn_cond, input_noise.shape[2:]))
+        return super().sample(input_noise=input_noise, autoencoder_model=autoencoder_model, diffusion_model=model, scheduler=scheduler,
+                              save_intermediates=save_intermediates, intermediate_steps=intermediate_steps, conditioning=conditioning,
+                              mode=mode, verbose=verbose)
+
+    @torch.no_grad()
+    def get_likelihood(self, inputs: torch.Tensor, autoencoder_model: Callable[..., torch.Tensor],
+                       diffusion_model: Callable[..., torch.Tensor], controlnet: Callable[..., torch.Tensor], cn_cond: torch.Tensor,
+                       scheduler: Callable[..., torch.Tensor] | None = None, save_intermediates: bool | None = False,
+                       conditioning: torch.Tensor | None = None, mode: str = "crossattn", original_input_range: tuple | None = (0, 255),
+                       scaled_input_range: tuple | None = (0, 1), verbose: bool = True, resample_latent_likelihoods: bool = False,
+                       resample_interpolation_mode: str = "nearest", seg: torch.Tensor | None = None, quantized: bool = True,
+                       _noise: torch.Tensor | None = None):
+        # the latent grid is only known after encoding; resize lazily on the first model call
+        inferer = self
+
+        class _Lazy(_Controlled):
+            def __call__(self, x, timesteps, context=None):
+                self.cn_cond = _resize_like(self.cn_cond, x.shape[2:])
+                return super().__call__(x, timesteps, context)
+
+        return LatentDiffusionInferer.get_likelihood(inferer, inputs=inputs, autoencoder_model=autoencoder_model,
+                                                     diffusion_model=_Lazy(diffusion_model, controlnet, cn_cond), scheduler=scheduler,
+                                                     save_intermediates=save_intermediates, conditioning=conditioning, mode=mode,
+                                                     original_input_range=original_input_range, scaled_input_range=scaled_input_range,
+                                                     verbose=verbose, resample_latent_likelihoods=resample_latent_likelihoods,
+                                                     resample_interpolation_mode=resample_interpolation_mode, quantized=quantized, _noise=_noise)

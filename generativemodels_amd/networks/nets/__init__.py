@@ -1,5 +1,6 @@
 from .autoencoderkl import AutoencoderKL
+from .controlnet import ControlNet, ControlNetConditioningEmbedding, copy_weights_to_controlnet
 from .diffusion_model_unet import DiffusionModelUNet
 from .vqvae import VQVAE
 
-__all__ = ["AutoencoderKL", "DiffusionModelUNet", "VQVAE"]
+__all__ = ["AutoencoderKL", "ControlNet", "ControlNetConditioningEmbedding", "DiffusionModelUNet", "VQVAE", "copy_weights_to_controlnet"]

@@ -185,7 +185,43 @@ class _MidBlock(nn.Module):
         self.resnet_2 = ResnetBlock(spatial_dims, channels, channels, temb_channels, groups, eps)
 
 
-class DiffusionModelUNet(nn.Module):
+class _TimestepPath:
+    """Timestep (+ class) embedding path shared by DiffusionModelUNet and ControlNet: needs `time_embed`, `block_out_channels`,
+    `num_class_embeds` (+ `class_embedding`) on the host class."""
+
+    # ---- fused timestep path -------------------------------------------------------------------------------------------
+    def _resnets_in_order(self):
+        return [m for m in self.modules() if isinstance(m, ResnetBlock) and hasattr(m, "time_emb_proj")]
+
+    def _temb_rows(self, timesteps: torch.Tensor, class_labels: Optional[torch.Tensor]):
+        """fp32 [B_t, C_out] additive rows for every ResnetBlock from ONE stacked GEMM (reference: one Linear per block,
+        diffusion_model_unet.py:686-690).  The whole timestep path runs in fp32 regardless of the model dtype."""
+        f32 = torch.float32
+        t_emb = ops.timestep_embedding(timesteps, self.block_out_channels[0], dtype=f32)
+        l0, l2 = self.time_embed[0], self.time_embed[2]
+        h = ops.linear(t_emb, l0.weight, l0.bias)
+        class_emb = None
+        if self.num_class_embeds is not None:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            class_emb = ops.vq_gather(class_labels.to(h.device), self.class_embedding.weight, f32)
+            if class_emb.shape[0] != h.shape[0]:
+                raise ValueError("class_labels and timesteps must have the same batch size")
+        emb = ops.linear(h, l2.weight, l2.bias, pre_act="silu", res=class_emb)
+        blocks = self._resnets_in_order()
+        w = ops.packed_cat_weight([b.time_emb_proj.weight for b in blocks], f32)
+        sizes = [b.out_channels for b in blocks]
+        bias = ops.cat_f32([b.time_emb_proj.bias for b in blocks], sizes, emb.device)
+        rows = ops.conv(emb.unsqueeze(0), None, bias, kernel=1, pre_act="silu", packed=w, cout=sum(sizes)).squeeze(0)
+        out, off = {}, 0
+        for b, s in zip(blocks, sizes):
+            out[id(b)] = rows[:, off:off + s]
+            off += s
+        return out
+
+
+
+class DiffusionModelUNet(_TimestepPath, nn.Module):
     """Drop-in for generative.networks.nets.DiffusionModelUNet (same arguments, same state_dict keys, same forward)."""
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, num_res_blocks: Sequence[int] | int = (2, 2, 2, 2),
@@ -268,36 +304,6 @@ class DiffusionModelUNet(nn.Module):
 
         self.out = nn.Sequential(nn.GroupNorm(num_groups=g, num_channels=num_channels[0], eps=eps, affine=True), nn.SiLU(),
                                  zero_module(ConvP(spatial_dims, num_channels[0], out_channels, 3, 1, 1)))
-
-    # ---- fused timestep path -------------------------------------------------------------------------------------------
-    def _resnets_in_order(self):
-        return [m for m in self.modules() if isinstance(m, ResnetBlock) and hasattr(m, "time_emb_proj")]
-
-    def _temb_rows(self, timesteps: torch.Tensor, class_labels: Optional[torch.Tensor]):
-        """fp32 [B_t, C_out] additive rows for every ResnetBlock from ONE stacked GEMM (reference: one Linear per block,
-        diffusion_model_unet.py:686-690).  The whole timestep path runs in fp32 regardless of the model dtype."""
-        f32 = torch.float32
-        t_emb = ops.timestep_embedding(timesteps, self.block_out_channels[0], dtype=f32)
-        l0, l2 = self.time_embed[0], self.time_embed[2]
-        h = ops.linear(t_emb, l0.weight, l0.bias)
-        class_emb = None
-        if self.num_class_embeds is not None:
-            if class_labels is None:
-                raise ValueError("class_labels should be provided when num_class_embeds > 0")
-            class_emb = ops.vq_gather(class_labels.to(h.device), self.class_embedding.weight, f32)
-            if class_emb.shape[0] != h.shape[0]:
-                raise ValueError("class_labels and timesteps must have the same batch size")
-        emb = ops.linear(h, l2.weight, l2.bias, pre_act="silu", res=class_emb)
-        blocks = self._resnets_in_order()
-        w = ops.packed_cat_weight([b.time_emb_proj.weight for b in blocks], f32)
-        sizes = [b.out_channels for b in blocks]
-        bias = ops.cat_f32([b.time_emb_proj.bias for b in blocks], sizes, emb.device)
-        rows = ops.conv(emb.unsqueeze(0), None, bias, kernel=1, pre_act="silu", packed=w, cout=sum(sizes)).squeeze(0)
-        out, off = {}, 0
-        for b, s in zip(blocks, sizes):
-            out[id(b)] = rows[:, off:off + s]
-            off += s
-        return out
 
     # ---- forward -------------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor | None = None,

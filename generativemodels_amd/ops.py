@@ -281,6 +281,21 @@ def resample2x(x: torch.Tensor, mode: str) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------------------------------
 # normalisation
 # ------------------------------------------------------------------------------------------------------------------------
+def nearest_resize(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
+    """F.interpolate(mode="nearest") of an arena tensor (N, *spatial, C) to the spatial `size`."""
+    require_device(x)
+    nsp = x.dim() - 2
+    if len(size) != nsp or nsp < 1 or nsp > 3:
+        raise ValueError("size must have one entry per spatial axis (1-3 axes)")
+    x = x.contiguous()
+    si = (1,) * (3 - nsp) + tuple(x.shape[1:-1])
+    so = (1,) * (3 - nsp) + tuple(int(v) for v in size)
+    out = torch.empty((x.shape[0], *[int(v) for v in size], x.shape[-1]), dtype=x.dtype, device=x.device)
+    check(lib().gm_nearest_resize(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), x.shape[0], *si, *so, x.shape[-1],
+                                  dt_code(x.dtype), _stream()), "gm_nearest_resize")
+    return out
+
+
 def gn_scale_shift(x: torch.Tensor, groups: int, eps: float, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
                    want_stats: bool = False):
     """GroupNorm statistics of an arena tensor -> fp32 (scale, shift) of shape [N, C] for a consumer's prologue."""

@@ -79,6 +79,10 @@ int gm_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, in
                     void* stream);
 int gm_nhwc_to_nchw(const void* src, long long src_ld, int src_dtype, void* dst, int dst_dtype, int N, int C, long long V,
                     void* stream);
+/* F.interpolate(x, size, mode="nearest") on an arena tensor (N, Di, Hi, Wi, C) -> (N, Do, Ho, Wo, C): the ControlNet latent inferers
+ * resize the conditioning image to the latent grid (inferers/inferer.py:926-927). */
+int gm_nearest_resize(const void* x, long long x_ld, void* y, long long y_ld, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                      int C, int dtype, void* stream);
 /* mode 0: nearest 2x up, mode 1: 2x average pool (ResnetBlock up/down path, diffusion_model_unet.py:635-639,674-682) */
 int gm_resample2x(const void* src, long long src_ld, void* dst, long long dst_ld, int N, int C, int Di, int Hi, int Wi,
                   int act_d, int mode, int dtype, void* stream);

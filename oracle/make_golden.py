@@ -157,10 +157,86 @@ def extras():
     print("chain", float(chain.abs().max()), "likelihood", {k: v["total"].tolist() for k, v in list(out["likelihood"]["cases"].items())[:3]})
 
 
+def controlnet_fixtures():
+    """tests/golden/controlnet.pt: ControlNet forwards (2-D with class embedding + attention, 3-D with cross-attention), the
+    ControlNet-conditioned inferer (__call__ + a DDIM-4 chain) and its latent variant with a conditioning image that the reference
+    resizes with F.interpolate(nearest).  Outputs of the unmodified reference."""
+    from generative.inferers import ControlNetDiffusionInferer, ControlNetLatentDiffusionInferer
+    from generative.networks.nets import AutoencoderKL, ControlNet, DiffusionModelUNet
+    from generative.networks.schedulers import DDIMScheduler
+
+    out = dict(kind="controlnet", forwards={})
+    cases = {
+        "cn2d": dict(cfg=dict(spatial_dims=2, in_channels=1, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1,
+                              norm_num_groups=8, num_head_channels=8, num_class_embeds=3, conditioning_embedding_in_channels=2,
+                              conditioning_embedding_num_channels=(8, 16)), x=(2, 1, 8, 8), cond=(2, 2, 16, 16), class_labels=[0, 2]),
+        "cn3d_cross": dict(cfg=dict(spatial_dims=3, in_channels=1, num_channels=(8, 8), attention_levels=(True, True), num_res_blocks=(1, 2),
+                                    norm_num_groups=8, num_head_channels=4, with_conditioning=True, cross_attention_dim=3,
+                                    conditioning_embedding_in_channels=1, conditioning_embedding_num_channels=(8,)),
+                           x=(2, 1, 8, 8, 8), cond=(2, 1, 8, 8, 8), context=(2, 2, 3)),
+    }
+    for name, case in cases.items():
+        torch.manual_seed(0)
+        m = ControlNet(**case["cfg"]).eval()
+        derandomize_zeros(m)
+        x, cond = _randn(case["x"], 7), _randn(case["cond"], 9)
+        t = torch.tensor([980, 20])
+        ctx = _randn(case["context"], 8) if "context" in case else None
+        cl = torch.tensor(case["class_labels"]) if "class_labels" in case else None
+        with torch.no_grad():
+            down, mid = m(x, t, cond, conditioning_scale=0.7, context=ctx, class_labels=cl)
+        out["forwards"][name] = dict(cfg=case["cfg"], state_dict=m.state_dict(), x=x, timesteps=t, cond=cond, context=ctx, class_labels=cl,
+                                     scale=0.7, down=[d.clone() for d in down], mid=mid.clone())
+        print(name, len(down), float(mid.abs().max()))
+    # conditioned sampling: 2-D UNet + ControlNet
+    ucfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1,
+                norm_num_groups=8, num_head_channels=8)
+    ccfg = dict(spatial_dims=2, in_channels=1, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1, norm_num_groups=8,
+                num_head_channels=8, conditioning_embedding_in_channels=1, conditioning_embedding_num_channels=(8, 16))
+    torch.manual_seed(0)
+    unet = DiffusionModelUNet(**ucfg).eval()
+    derandomize_zeros(unet)
+    torch.manual_seed(1)
+    cn = ControlNet(**ccfg).eval()
+    derandomize_zeros(cn)
+    noise, cond = _randn((2, 1, 8, 8), 21), _randn((2, 1, 16, 16), 23)
+    sch = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    sch.set_timesteps(4)
+    inf = ControlNetDiffusionInferer(sch)
+    chain = inf.sample(noise, unet, cn, cond, sch, verbose=False)
+    xin, ts = _randn((2, 1, 8, 8), 22), torch.tensor([700, 30])
+    pred = inf(inputs=xin, diffusion_model=unet, controlnet=cn, noise=noise, timesteps=ts, cn_cond=cond)
+    out["inferer"] = dict(unet_cfg=ucfg, unet_sd=unet.state_dict(), cn_cfg=ccfg, cn_sd=cn.state_dict(), noise=noise, cond=cond, steps=4,
+                          chain=chain, call_inputs=xin, call_timesteps=ts, call_prediction=pred)
+    # latent variant: AutoencoderKL 16x16 -> 4x4 latent of 4 channels; cond given at image size 20x20 is resized to 8x8 = 2 x latent
+    acfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(8, 8, 16), latent_channels=4, attention_levels=(False, False, False),
+                num_res_blocks=1, norm_num_groups=4, with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False)
+    lucfg = dict(ucfg, in_channels=4, out_channels=4)
+    lccfg = dict(ccfg, in_channels=4, conditioning_embedding_num_channels=(8,))
+    torch.manual_seed(2)
+    ae = AutoencoderKL(**acfg).eval()
+    torch.manual_seed(3)
+    lunet = DiffusionModelUNet(**lucfg).eval()
+    derandomize_zeros(lunet)
+    torch.manual_seed(4)
+    lcn = ControlNet(**lccfg).eval()
+    derandomize_zeros(lcn)
+    lnoise, lcond = _randn((2, 4, 4, 4), 31), _randn((2, 1, 10, 6), 32)
+    linf = ControlNetLatentDiffusionInferer(sch, scale_factor=0.9)
+    limg = linf.sample(lnoise, ae, lunet, lcn, lcond, sch, verbose=False)
+    out["latent"] = dict(ae_cfg=acfg, ae_sd=ae.state_dict(), unet_cfg=lucfg, unet_sd=lunet.state_dict(), cn_cfg=lccfg, cn_sd=lcn.state_dict(),
+                         noise=lnoise, cond=lcond, steps=4, scale_factor=0.9, image=limg)
+    torch.save(out, os.path.join(OUT, "controlnet.pt"))
+    print("inferer chain", float(chain.abs().max()), "latent image", tuple(limg.shape), float(limg.abs().max()))
+
+
 def main():
     g = load_reference()
     if g is None:
         raise SystemExit("reference tree not found; golden fixtures can only be made in the build container")
+    if "--controlnet-only" in sys.argv:
+        controlnet_fixtures()
+        return
     if "--extras-only" in sys.argv:  # PNDM + get_likelihood fixtures only
         extras()
         return

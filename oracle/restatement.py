@@ -262,6 +262,77 @@ def unet_forward(sd, cfg, x, timesteps, context=None, class_labels=None, down_bl
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# ControlNet (networks/nets/controlnet.py)
+# --------------------------------------------------------------------------------------------------------------------
+
+CONTROLNET_DEFAULTS = dict(UNET_DEFAULTS, conditioning_embedding_in_channels=1, conditioning_embedding_num_channels=(16, 32, 96, 256))
+
+
+def controlnet_cond_embedding(sd, p, cond, num_channels):
+    """ControlNetConditioningEmbedding.forward, nets/controlnet.py:103-114: conv_in, (conv, stride-2 conv) per level, SiLU after each,
+    zero-initialised conv_out."""
+    e = F.silu(_conv(sd, f"{p}.conv_in", cond))
+    for i in range(len(num_channels) - 1):
+        e = F.silu(_conv(sd, f"{p}.blocks.{2 * i}", e))
+        e = F.silu(_conv(sd, f"{p}.blocks.{2 * i + 1}", e, stride=2, padding=1))
+    return _conv(sd, f"{p}.conv_out", e)
+
+
+def controlnet_forward(sd, cfg, x, timesteps, controlnet_cond, conditioning_scale=1.0, context=None, class_labels=None):
+    """ControlNet.forward, nets/controlnet.py:367-436: the UNet's encoder + mid block on x + embed(cond), every skip and the mid
+    output through its own zero-initialised 1x1 conv, all scaled.  -> (tuple of down residuals, mid residual)."""
+    c = dict(CONTROLNET_DEFAULTS, **cfg)
+    chans = tuple(c["num_channels"])
+    nlev = len(chans)
+    att = tuple(c["attention_levels"])
+    nres = _rep(c["num_res_blocks"], nlev)
+    nhc = _rep(c["num_head_channels"], nlev)
+    groups, eps = c["norm_num_groups"], c["norm_eps"]
+    cond, updown = c["with_conditioning"], c["resblock_updown"]
+    nlayers, upcast = c["transformer_num_layers"], c["upcast_attention"]
+    t_emb = timestep_embedding(timesteps, chans[0]).to(dtype=x.dtype)
+    emb = _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", t_emb)))
+    if c["num_class_embeds"] is not None:
+        if class_labels is None:
+            raise ValueError("class_labels should be provided when num_class_embeds > 0")
+        emb = emb + F.embedding(class_labels, sd["class_embedding.weight"]).to(dtype=x.dtype)
+    if context is not None and not cond:
+        raise ValueError("model should have with_conditioning = True if context is provided")
+
+    def attend(p, h, level_nhc):
+        if cond:
+            return spatial_transformer(sd, p, h, context, groups, eps, level_nhc, nlayers, upcast)
+        return attention_block(sd, p, h, groups, eps, level_nhc)
+
+    h = _conv(sd, "conv_in", x) + controlnet_cond_embedding(sd, "controlnet_cond_embedding", controlnet_cond,
+                                                              c["conditioning_embedding_num_channels"])
+    skips = [h]
+    for i in range(nlev):
+        p = f"down_blocks.{i}"
+        for j in range(nres[i]):
+            h = unet_resnet(sd, f"{p}.resnets.{j}", h, emb, groups, eps)
+            if att[i]:
+                h = attend(f"{p}.attentions.{j}", h, nhc[i])
+            skips.append(h)
+        if i != nlev - 1:
+            if updown:
+                h = unet_resnet(sd, f"{p}.downsampler", h, emb, groups, eps, down=True)
+            else:
+                h = _conv(sd, f"{p}.downsampler.op", h, stride=2, padding=1)
+            skips.append(h)
+    h = unet_resnet(sd, "middle_block.resnet_1", h, emb, groups, eps)
+    h = attend("middle_block.attention", h, nhc[-1])
+    h = unet_resnet(sd, "middle_block.resnet_2", h, emb, groups, eps)
+    outs = []
+    for k, s_ in enumerate(skips):
+        # the first zero conv is registered as the bare nn.Conv (controlnet.py:277-287), the others as Convolution wrappers
+        name = f"controlnet_down_blocks.{k}" if k == 0 else f"controlnet_down_blocks.{k}.conv"
+        outs.append(_convnd(s_, sd[name + ".weight"], sd[name + ".bias"]) * conditioning_scale)
+    mid = _conv(sd, "controlnet_mid_block", h, padding=0) * conditioning_scale
+    return tuple(outs), mid
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # AutoencoderKL (networks/nets/autoencoderkl.py)
 # --------------------------------------------------------------------------------------------------------------------
 

@@ -45,7 +45,13 @@ def test_struct_layouts_match_the_header_field_order():
             first = names[0].split()
             fields.append(first[-1])
             fields += [n.strip() for n in names[1:]]
+        # `name[2]` in the header is a 2-element ctypes array field `name`
+        arrays = {f.split("[")[0]: int(f.split("[")[1].rstrip("]")) for f in fields if "[" in f}
+        fields = [f.split("[")[0] for f in fields]
         assert fields == [f[0] for f in cls._fields_], cname
+        for fname, ftype in cls._fields_:
+            if fname in arrays:
+                assert getattr(ftype, "_length_", None) == arrays[fname], (cname, fname)
 
 
 def test_pure_host_entry_points_run_without_a_gpu():

@@ -306,3 +306,54 @@ def test_get_likelihood_matches_reference():
     with pytest.raises(NotImplementedError):
         s = DDIMScheduler(10)
         DiffusionInferer(s).get_likelihood(_dev(lk["inputs"]), m, s, verbose=False)
+
+
+def test_controlnet_matches_reference():
+    """ControlNet forward (down / mid residuals) and the ControlNet-conditioned inferers against the reference's outputs:
+    2-D with class embedding + attention, 3-D with cross-attention, conditioned __call__ and DDIM chain, latent variant with the
+    conditioning image resized (nearest) to the latent grid."""
+    from generativemodels_amd.inferers import ControlNetDiffusionInferer, ControlNetLatentDiffusionInferer
+    from generativemodels_amd.networks.nets import ControlNet
+    from generativemodels_amd.networks.schedulers import DDIMScheduler
+    fx = load_fixture("controlnet")
+    for name, e in fx["forwards"].items():
+        m = ControlNet(**e["cfg"]).eval()
+        m.load_state_dict(e["state_dict"])
+        m = m.to(DEV)
+        down, mid = m(_dev(e["x"]), _dev(e["timesteps"]), _dev(e["cond"]), conditioning_scale=e["scale"], context=_dev(e["context"]),
+                      class_labels=_dev(e["class_labels"]))
+        assert len(down) == len(e["down"])
+        for a, b in zip(down, e["down"]):
+            _fp32_close(a, b, f"{name} down residual")
+        _fp32_close(mid, e["mid"], f"{name} mid residual")
+        mb = ControlNet(**e["cfg"]).eval()
+        mb.load_state_dict(e["state_dict"])
+        mb = mb.to(DEV, torch.bfloat16)
+        ctx = None if e["context"] is None else e["context"].bfloat16()
+        dn, md = mb(_dev(e["x"].bfloat16()), _dev(e["timesteps"]), _dev(e["cond"].bfloat16()), conditioning_scale=e["scale"], context=_dev(ctx),
+                    class_labels=_dev(e["class_labels"]))
+        _bf16_close(md, e["mid"], f"{name} bf16 mid residual")
+    i = fx["inferer"]
+    unet = _nets().DiffusionModelUNet(**i["unet_cfg"]).eval()
+    unet.load_state_dict(i["unet_sd"])
+    cn = ControlNet(**i["cn_cfg"]).eval()
+    cn.load_state_dict(i["cn_sd"])
+    unet, cn = unet.to(DEV), cn.to(DEV)
+    sch = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    sch.set_timesteps(i["steps"])
+    inf = ControlNetDiffusionInferer(sch)
+    _fp32_close(inf.sample(_dev(i["noise"]), unet, cn, _dev(i["cond"]), sch, verbose=False), i["chain"], "controlnet chain", factor=2.0)
+    pred = inf(inputs=_dev(i["call_inputs"]), diffusion_model=unet, controlnet=cn, noise=_dev(i["noise"]), timesteps=_dev(i["call_timesteps"]),
+               cn_cond=_dev(i["cond"]))
+    _fp32_close(pred, i["call_prediction"], "controlnet inferer __call__")
+    l = fx["latent"]
+    ae = _nets().AutoencoderKL(**l["ae_cfg"]).eval()
+    ae.load_state_dict(l["ae_sd"])
+    lunet = _nets().DiffusionModelUNet(**l["unet_cfg"]).eval()
+    lunet.load_state_dict(l["unet_sd"])
+    lcn = ControlNet(**l["cn_cfg"]).eval()
+    lcn.load_state_dict(l["cn_sd"])
+    ae, lunet, lcn = ae.to(DEV), lunet.to(DEV), lcn.to(DEV)
+    linf = ControlNetLatentDiffusionInferer(sch, scale_factor=l["scale_factor"])
+    img = linf.sample(_dev(l["noise"]), ae, lunet, lcn, _dev(l["cond"]), sch, verbose=False)
+    _fp32_close(img, l["image"], "controlnet latent chain", factor=2.0)

@@ -191,3 +191,38 @@ def test_install_as_generative_aliases_the_reference_import_paths():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+def test_controlnet_state_dict_and_constructor_errors():
+    """ControlNet host logic (reference controlnet.py:190-365): strict state_dict compatibility incl. the bare first zero conv,
+    zero-initialised control convolutions, constructor errors, copy_weights_to_controlnet, no CPU fallback."""
+    from generativemodels_amd.networks.nets import ControlNet, copy_weights_to_controlnet
+
+    fx = load_fixture("controlnet")
+    for name, e in fx["forwards"].items():
+        m = ControlNet(**e["cfg"])
+        assert set(m.state_dict()) == set(e["state_dict"]), name
+        for k, v in m.state_dict().items():
+            assert tuple(v.shape) == tuple(e["state_dict"][k].shape), (name, k)
+        m.load_state_dict(e["state_dict"], strict=True)
+    m = ControlNet(2, 1, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1, norm_num_groups=8, num_head_channels=8)
+    assert "controlnet_down_blocks.0.weight" in m.state_dict() and "controlnet_down_blocks.1.conv.weight" in m.state_dict()
+    for k, v in m.state_dict().items():
+        if k.startswith("controlnet_down_blocks") or k.startswith("controlnet_mid_block") or k.startswith("controlnet_cond_embedding.conv_out"):
+            assert float(v.abs().max()) == 0.0, k
+    unet = DiffusionModelUNet(2, 1, 1, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1, norm_num_groups=8, num_head_channels=8)
+    copy_weights_to_controlnet(m, unet, verbose=False)
+    assert torch.equal(m.down_blocks[0].resnets[0].conv1.conv.weight, unet.down_blocks[0].resnets[0].conv1.conv.weight)
+    with pytest.raises(ValueError):
+        ControlNet(2, 1, with_conditioning=True)
+    with pytest.raises(ValueError):
+        ControlNet(2, 1, cross_attention_dim=3)
+    with pytest.raises(ValueError):
+        ControlNet(2, 1, num_channels=(8, 12), norm_num_groups=8, attention_levels=(False, False))
+    with pytest.raises(ValueError):
+        ControlNet(2, 1, num_channels=(8, 8), norm_num_groups=8, attention_levels=(False,))
+    with pytest.raises(ValueError):
+        ControlNet(2, 1, num_channels=(8, 8), norm_num_groups=8, attention_levels=(False, False), num_res_blocks=(1, 1, 1))
+    x = torch.zeros(1, 1, 8, 8)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(x, torch.tensor([1]), x)

@@ -135,3 +135,29 @@ def test_pndm_chain_and_likelihood_match_reference():
         assert_close(total, e["total"], atol=1e-5 * e["total"].abs().max().item(), what=f"likelihood total {vt} {pt} {clip}")
         for got, want in zip(maps, e["maps"]):
             assert_close(got, want, atol=2e-5 * max(1.0, want.abs().max().item()), what=f"kl map {vt} {pt} {clip}")
+
+
+def test_controlnet_forward_and_conditioned_chain_match_reference():
+    """ControlNet (controlnet.py:367-436) and the ControlNet-conditioned DDIM chain (inferer.py:565-707) restated vs the reference."""
+    fx = load_fixture("controlnet")
+    for name, e in fx["forwards"].items():
+        with torch.no_grad():
+            down, mid = R.controlnet_forward(e["state_dict"], e["cfg"], e["x"], e["timesteps"], e["cond"], e["scale"], e["context"], e["class_labels"])
+        assert len(down) == len(e["down"])
+        for a, b in zip(down, e["down"]):
+            assert_close(a, b, atol=2e-5, what=f"{name} down residual")
+        assert_close(mid, e["mid"], atol=2e-5, what=f"{name} mid residual")
+    i = fx["inferer"]
+    _, _, ac = R.noise_schedule("scaled_linear_beta", 1000, beta_start=0.0005, beta_end=0.0195)
+    img = i["noise"]
+    with torch.no_grad():
+        for t in R.inference_timesteps(1000, i["steps"]):
+            ts = torch.Tensor((int(t),))
+            down, mid = R.controlnet_forward(i["cn_sd"], i["cn_cfg"], img, ts, i["cond"])
+            eps = R.unet_forward(i["unet_sd"], i["unet_cfg"], img, ts, None, None, down, mid)
+            img, _ = R.ddim_step(ac, 1000, i["steps"], eps, int(t), img, clip_sample=False)
+        assert_close(img, i["chain"], atol=2e-5 * max(1.0, i["chain"].abs().max().item()), what="controlnet chain")
+        noisy = R.add_noise(ac, i["call_inputs"], i["noise"], i["call_timesteps"])
+        down, mid = R.controlnet_forward(i["cn_sd"], i["cn_cfg"], noisy, i["call_timesteps"], i["cond"])
+        pred = R.unet_forward(i["unet_sd"], i["unet_cfg"], noisy, i["call_timesteps"], None, None, down, mid)
+    assert_close(pred, i["call_prediction"], atol=2e-5, what="controlnet inferer __call__")
