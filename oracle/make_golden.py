@@ -230,10 +230,73 @@ def controlnet_fixtures():
     print("inferer chain", float(chain.abs().max()), "latent image", tuple(limg.shape), float(limg.abs().max()))
 
 
+def transformer_fixtures():
+    """tests/golden/transformer.pt: DecoderOnlyTransformer forwards (with / without cross-attention), Ordering permutations,
+    VQVAETransformerInferer __call__ / get_likelihood / greedy (top_k = 1) sample with a small 2-D VQVAE."""
+    from generative.inferers import VQVAETransformerInferer
+    from generative.networks.nets import VQVAE, DecoderOnlyTransformer
+    from generative.utils.ordering import Ordering
+
+    out = dict(kind="transformer", forwards={}, orderings={})
+    for name, cfg, ctx in [("plain", dict(num_tokens=17, max_seq_len=24, attn_layers_dim=32, attn_layers_depth=2, attn_layers_heads=4), None),
+                           ("cross", dict(num_tokens=10, max_seq_len=12, attn_layers_dim=16, attn_layers_depth=1, attn_layers_heads=2,
+                                          with_cross_attention=True), (2, 3, 16))]:
+        torch.manual_seed(0)
+        m = DecoderOnlyTransformer(**cfg).eval()
+        tok = torch.randint(0, cfg["num_tokens"], (2, cfg["max_seq_len"] - 3), generator=torch.Generator().manual_seed(5))
+        context = _randn(ctx, 6) if ctx else None
+        with torch.no_grad():
+            y = m(tok, context=context)
+        out["forwards"][name] = dict(cfg=cfg, state_dict=m.state_dict(), tokens=tok, context=context, logits=y)
+        print(name, tuple(y.shape), float(y.abs().max()))
+    for key, kw in {"raster2d": dict(ordering_type="raster_scan", spatial_dims=2, dimensions=(1, 4, 6)),
+                    "scurve3d": dict(ordering_type="s_curve", spatial_dims=3, dimensions=(1, 3, 4, 2)),
+                    "scurve2d_tf": dict(ordering_type="s_curve", spatial_dims=2, dimensions=(1, 4, 4), reflected_spatial_dims=(True, False),
+                                        transpositions_axes=((1, 0),), rot90_axes=((0, 1),))}.items():
+        o = Ordering(**kw)
+        out["orderings"][key] = dict(kw=kw, order=torch.as_tensor(o.get_sequence_ordering().copy()),
+                                     revert=torch.as_tensor(o.get_revert_sequence_ordering().copy()))
+    vcfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(8, 8), num_res_layers=1, num_res_channels=(8, 8),
+                downsample_parameters=((2, 4, 1, 1),) * 2, upsample_parameters=((2, 4, 1, 1, 0),) * 2, num_embeddings=16, embedding_dim=8)
+    tcfg = dict(num_tokens=17, max_seq_len=16, attn_layers_dim=32, attn_layers_depth=2, attn_layers_heads=4)
+    torch.manual_seed(1)
+    vq = VQVAE(**vcfg).eval()
+    torch.manual_seed(2)
+    tr = DecoderOnlyTransformer(**tcfg).eval()
+    x = _randn((2, 1, 16, 16), 7)  # -> 4 x 4 latent = 16 tokens = max_seq_len
+    order = Ordering(ordering_type="s_curve", spatial_dims=2, dimensions=(1, 4, 4))
+    inf = VQVAETransformerInferer()
+    with torch.no_grad():
+        pred, target, lsd = inf(x, vq, tr, order, return_latent=True)
+        lik = inf.get_likelihood(x, vq, tr, order)
+        start = torch.full((2, 1), 16)
+        greedy = inf.sample((4, 4), start, vq, tr, order, top_k=1, verbose=False)
+        # teacher-forced sampling-head probabilities along the greedy path for temperature / top-k variants
+        idx = vq.index_quantize(x).reshape(2, -1)[:, order.get_sequence_ordering()]
+        seq = torch.cat([start, idx], 1).long()
+        logits = tr(seq[:, :16])
+    out["inferer"] = dict(vq_cfg=vcfg, vq_sd=vq.state_dict(), tr_cfg=tcfg, tr_sd=tr.state_dict(), x=x, ordering=dict(ordering_type="s_curve", spatial_dims=2, dimensions=(1, 4, 4)),
+                          prediction=pred, target=target, latent_spatial_dim=lsd, likelihood=lik, greedy_image=greedy, seq=seq, logits=logits)
+    # a longer-than-context case for get_likelihood's sliding window: 8 x 8 input -> 2 x 2 ... use max_seq_len 3 < 4 tokens
+    tcfg2 = dict(num_tokens=17, max_seq_len=3, attn_layers_dim=16, attn_layers_depth=1, attn_layers_heads=2)
+    torch.manual_seed(3)
+    tr2 = DecoderOnlyTransformer(**tcfg2).eval()
+    x2 = _randn((2, 1, 8, 8), 8)
+    order2 = Ordering(ordering_type="raster_scan", spatial_dims=2, dimensions=(1, 2, 2))
+    with torch.no_grad():
+        lik2 = inf.get_likelihood(x2, vq, tr2, order2)
+    out["window"] = dict(tr_cfg=tcfg2, tr_sd=tr2.state_dict(), x=x2, likelihood=lik2)
+    torch.save(out, os.path.join(OUT, "transformer.pt"))
+    print("likelihood", tuple(lik.shape), float(lik.min()), "greedy", tuple(greedy.shape))
+
+
 def main():
     g = load_reference()
     if g is None:
         raise SystemExit("reference tree not found; golden fixtures can only be made in the build container")
+    if "--transformer-only" in sys.argv:
+        transformer_fixtures()
+        return
     if "--controlnet-only" in sys.argv:
         controlnet_fixtures()
         return

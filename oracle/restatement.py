@@ -794,6 +794,109 @@ def get_likelihood(model_fn, inputs, noise, betas, alphas, alphas_cumprod, times
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# DecoderOnlyTransformer (networks/nets/transformer.py, blocks/transformerblock.py, blocks/selfattention.py) + Ordering
+# --------------------------------------------------------------------------------------------------------------------
+
+
+def sa_block(sd, p, x, heads, context=None, causal=False):
+    """SABlock.forward, blocks/selfattention.py:98-147 (non-flash path): q from x, k/v from context or x, scaled scores, optional
+    lower-triangular mask, softmax, out_proj."""
+    b, t, c = x.shape
+    kv = context if context is not None else x
+    kt = kv.shape[1]
+    hd = c // heads
+    q = _lin(sd, f"{p}.to_q", x).view(b, t, heads, hd).transpose(1, 2) * (1.0 / math.sqrt(hd))
+    k = _lin(sd, f"{p}.to_k", kv).view(b, kt, heads, hd).transpose(1, 2)
+    v = _lin(sd, f"{p}.to_v", kv).view(b, kt, heads, hd).transpose(1, 2)
+    scores = q @ k.transpose(-2, -1)
+    if causal:
+        scores = scores.masked_fill(torch.tril(torch.ones(t, kt)).view(1, 1, t, kt) == 0, float("-inf"))
+    y = (F.softmax(scores, dim=-1) @ v).transpose(1, 2).contiguous().view(b, t, c)
+    return _lin(sd, f"{p}.out_proj", y)
+
+
+def transformer_forward(sd, cfg, tokens, context=None):
+    """DecoderOnlyTransformer.forward, nets/transformer.py:98-106: token + absolute position embeddings, pre-norm blocks
+    (causal self-attention [+ cross-attention] + GELU MLP, blocks/transformerblock.py:86-91), to_logits.
+    cfg: num_tokens, max_seq_len, attn_layers_dim, attn_layers_depth, attn_layers_heads, with_cross_attention."""
+    heads, cross = cfg["attn_layers_heads"], cfg.get("with_cross_attention", False)
+    b, t = tokens.shape
+    x = F.embedding(tokens, sd["token_embeddings.weight"]) + F.embedding(torch.arange(t).repeat(b, 1), sd["position_embeddings.embedding.weight"])
+    for i in range(cfg["attn_layers_depth"]):
+        p = f"blocks.{i}"
+        ln = lambda name, h: F.layer_norm(h, (h.shape[-1],), sd[f"{p}.{name}.weight"], sd[f"{p}.{name}.bias"], 1e-5)  # noqa: E731
+        x = x + sa_block(sd, f"{p}.attn", ln("norm1", x), heads, causal=True)
+        if cross:
+            x = x + sa_block(sd, f"{p}.cross_attn", ln("norm2", x), heads, context=context)
+        h = ln("norm3", x)
+        x = x + _lin(sd, f"{p}.mlp.linear2", F.gelu(_lin(sd, f"{p}.mlp.linear1", h)))
+    return _lin(sd, "to_logits", x)
+
+
+def raster_scan_ordering(dimensions):
+    """Ordering('raster_scan', ...) without transformations (utils/ordering.py:113-166): the identity permutation."""
+    n = int(np.prod(dimensions[1:]))
+    return np.arange(n), np.arange(n)
+
+
+def ordering_indices(ordering_type, spatial_dims, dimensions, reflected_spatial_dims=(), transpositions_axes=(), rot90_axes=(),
+                     transformation_order=("transpose", "rotate_90", "reflect")):
+    """utils/ordering.py:52-205 -> (sequence_ordering, revert_sequence_ordering). 'random' is not restated (np.random state)."""
+    tmpl = np.arange(int(np.prod(dimensions[1:]))).reshape(*dimensions[1:])
+    for tr in transformation_order:
+        if tr == "transpose":
+            for axes in transpositions_axes:
+                tmpl = np.transpose(tmpl, axes=axes)
+        elif tr == "rotate_90":
+            for axes in rot90_axes:
+                tmpl = np.rot90(tmpl, axes=axes)
+        elif tr == "reflect":
+            for axis, flag in enumerate(reflected_spatial_dims):
+                tmpl = np.flip(tmpl, axis=axis) if flag else tmpl
+    shape = tmpl.shape
+    seq = []
+    for r in range(shape[0]):
+        cols = range(shape[1]) if (ordering_type == "raster_scan" or r % 2 == 0) else range(shape[1] - 1, -1, -1)
+        for c in cols:
+            if spatial_dims == 3:
+                deps = range(shape[2]) if (ordering_type == "raster_scan" or c % 2 == 0) else range(shape[2] - 1, -1, -1)
+                for d in deps:
+                    seq.append(tmpl[r, c, d])
+            else:
+                seq.append(tmpl[r, c])
+    order = np.array(seq)
+    return order, np.argsort(order)
+
+
+def transformer_sample_probs(logits_last, temperature, top_k, bos):
+    """The sampling head of VQVAETransformerInferer.sample, inferers/inferer.py:1221-1232: temperature, top-k crop, softmax, BOS
+    probability zeroed (NOT renormalised)."""
+    logits = logits_last / temperature
+    if top_k is not None:
+        v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+        logits = logits.masked_fill(logits < v[:, [-1]], -float("Inf"))
+    probs = F.softmax(logits, dim=-1).clone()
+    probs[:, bos] = 0
+    return probs
+
+
+def transformer_likelihood(sd, cfg, latent_idx, ordering, revert, bos, context=None):
+    """VQVAETransformerInferer.get_likelihood, inferers/inferer.py:1248-1330, from the VQ indices (B, *spatial) on: log-probability
+    of every latent token given its predecessors, re-arranged to the latent grid."""
+    shape = latent_idx.shape
+    lat = latent_idx.reshape(shape[0], -1)[:, ordering]
+    lat = F.pad(lat, (1, 0), "constant", bos).long()
+    msl = cfg["max_seq_len"]
+    probs = F.softmax(transformer_forward(sd, cfg, lat[:, :msl], context), dim=-1)
+    target = lat[:, 1:]
+    probs = torch.gather(probs, 2, target[:, :msl].unsqueeze(2)).squeeze(2)
+    for i in range(msl, target.shape[1]):
+        p = F.softmax(transformer_forward(sd, cfg, lat[:, i + 1 - msl:i + 1], context)[:, -1, :], dim=-1)
+        probs = torch.cat((probs, torch.gather(p, 1, target[:, i].unsqueeze(1))), dim=1)
+    return torch.log(probs)[:, revert].reshape(shape)
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # Inferer loops (inferers/inferer.py)
 # --------------------------------------------------------------------------------------------------------------------
 

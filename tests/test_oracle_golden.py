@@ -161,3 +161,37 @@ def test_controlnet_forward_and_conditioned_chain_match_reference():
         down, mid = R.controlnet_forward(i["cn_sd"], i["cn_cfg"], noisy, i["call_timesteps"], i["cond"])
         pred = R.unet_forward(i["unet_sd"], i["unet_cfg"], noisy, i["call_timesteps"], None, None, down, mid)
     assert_close(pred, i["call_prediction"], atol=2e-5, what="controlnet inferer __call__")
+
+
+def test_transformer_ordering_and_vqvae_transformer_inferer_match_reference():
+    """DecoderOnlyTransformer (transformer.py:98-106), Ordering (ordering.py), VQVAETransformerInferer __call__ / get_likelihood /
+    greedy sample (inferer.py:1126-1330) restated vs the reference's outputs."""
+    fx = load_fixture("transformer")
+    for name, e in fx["forwards"].items():
+        with torch.no_grad():
+            y = R.transformer_forward(e["state_dict"], e["cfg"], e["tokens"], e["context"])
+        assert_close(y, e["logits"], atol=2e-5, what=f"transformer {name}")
+    for key, e in fx["orderings"].items():
+        order, revert = R.ordering_indices(**e["kw"])
+        assert torch.equal(torch.as_tensor(order.copy()), e["order"]) and torch.equal(torch.as_tensor(revert.copy()), e["revert"]), key
+    i = fx["inferer"]
+    order, revert = R.ordering_indices(**i["ordering"])
+    with torch.no_grad():
+        idx = R.vq_index_quantize(i["vq_sd"], R.vqvae_encode(i["vq_sd"], i["vq_cfg"], i["x"]))[0]
+        lat = idx.reshape(2, -1)[:, order]
+        assert torch.equal(lat, i["target"])
+        seq = torch.nn.functional.pad(lat, (1, 0), "constant", 16)[:, :-1].long()
+        assert_close(R.transformer_forward(i["tr_sd"], i["tr_cfg"], seq), i["prediction"], atol=2e-5, what="inferer __call__")
+        lik = R.transformer_likelihood(i["tr_sd"], i["tr_cfg"], idx, order, revert, 16)
+        assert_close(lik, i["likelihood"], atol=2e-5, what="transformer likelihood")
+        # greedy sampling (top_k = 1): the argmax path of the restated sampling head reproduces the reference's image
+        s = torch.full((2, 1), 16).long()
+        for _ in range(16):
+            logits = R.transformer_forward(i["tr_sd"], i["tr_cfg"], s[:, -16:])[:, -1, :]
+            s = torch.cat([s, R.transformer_sample_probs(logits, 1.0, 1, 16).argmax(-1, keepdim=True)], 1)
+        img = R.vqvae_decode(i["vq_sd"], i["vq_cfg"], R.vq_embed(i["vq_sd"], s[:, 1:][:, revert].reshape(2, 4, 4)))
+        assert_close(img, i["greedy_image"], atol=2e-5, what="greedy sample")
+        w = fx["window"]
+        idx2 = R.vq_index_quantize(i["vq_sd"], R.vqvae_encode(i["vq_sd"], i["vq_cfg"], w["x"]))[0]
+        o2, r2 = R.ordering_indices("raster_scan", 2, (1, 2, 2))
+        assert_close(R.transformer_likelihood(w["tr_sd"], w["tr_cfg"], idx2, o2, r2, 16), w["likelihood"], atol=2e-5, what="windowed likelihood")
