@@ -44,7 +44,8 @@ class GmAttnDesc(C.Structure):
     _fields_ = [("q", c_vp), ("q_ld", c_ll), ("k", c_vp), ("k_ld", c_ll), ("v", c_vp), ("v_ld", c_ll),
                 ("res", c_vp), ("res_ld", c_ll), ("o", c_vp), ("o_ld", c_ll),
                 ("B", C.c_int), ("H", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int), ("dh", C.c_int),
-                ("scale", C.c_float), ("dtype", C.c_int), ("workspace", c_vp), ("workspace_bytes", c_ll)]
+                ("scale", C.c_float), ("dtype", C.c_int), ("workspace", c_vp), ("workspace_bytes", c_ll),
+                ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll)]
 
 
 # name -> (restype, argtypes); mirrors include/gm_amd.h one to one (tests/test_abi.py checks the export list)
@@ -80,6 +81,9 @@ PROTOTYPES = {
     "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       c_vp]),
     "gm_attention_max_head_dim": (C.c_int, []),
+    "gm_embed_tokens": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_sample_probs": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_token_log_prob": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, c_vp]),
     "gm_attention_workspace_bytes": (c_ll, [C.POINTER(GmAttnDesc)]),
     "gm_attention_forward": (C.c_int, [C.POINTER(GmAttnDesc), c_vp]),
     "gm_vq_argmin": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),

@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
   const bool q_ok = my_q < p.Lq;
 
   const T* Qb = reinterpret_cast<const T*>(p.q) + (long long)b * p.Lq * p.q_ld + h * p.dh;
-  const T* Kb = reinterpret_cast<const T*>(p.k) + (long long)b * p.Lk * p.k_ld + h * p.dh;
-  const T* Vb = reinterpret_cast<const T*>(p.v) + (long long)b * p.Lk * p.v_ld + h * p.dh;
+  const T* Kb = reinterpret_cast<const T*>(p.k) + (long long)b * (p.k_bs ? p.k_bs : p.Lk * p.k_ld) + h * p.dh;
+  const T* Vb = reinterpret_cast<const T*>(p.v) + (long long)b * (p.v_bs ? p.v_bs : p.Lk * p.v_ld) + h * p.dh;
   const bool qvec = (p.dh % VECW == 0) && (p.q_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(Qb) & 15) == 0);
   const bool kvec = (p.dh % VECW == 0) && (p.k_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(Kb) & 15) == 0);
   const bool vvec = (p.dh % VECW == 0) && (p.v_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(Vb) & 15) == 0);
@@ -79,7 +79,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
   for (int d = 0; d < DF; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (p.Lk + KT - 1) / KT;
+  // causal: this lane's query sees keys <= my_q + (Lk - Lq); the work-group stops after the tile holding its last visible key
+  const int kmax = p.causal ? my_q + (p.Lk - p.Lq) : p.Lk;
+  int ntiles = (p.Lk + KT - 1) / KT;
+  if (p.causal) {
+    const int last = min(p.Lk - 1, (int)blockIdx.x * 64 + 63 + (p.Lk - p.Lq));
+    ntiles = max(1, min(ntiles, last / KT + 1));
+  }
   for (int tile = 0; tile < ntiles; ++tile) {
     const int key0 = tile * KT;
     __syncthreads();  // the previous tile's LDS reads are complete
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + kf * 16 + qg * 4 + r;
-        const float sv = key < p.Lk ? sacc[kf][r] * p.scale : -INFINITY;
+        const float sv = (key < p.Lk) & (key <= kmax) ? sacc[kf][r] * p.scale : -INFINITY;
         sacc[kf][r] = sv;
         tmax = fmaxf(tmax, sv);
       }

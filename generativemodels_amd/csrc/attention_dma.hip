@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void attn_dma_kernel(const GmAttnDesc p, co
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static bool attn_dma_eligible(const GmAttnDesc& d) {
   auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-  return d.dtype == GM_BF16 && (d.dh == 64 || d.dh == 128 || d.dh == 256) && d.Lq >= 128 && d.Lk >= 128 &&
+  return d.dtype == GM_BF16 && !d.causal && d.k_bs == 0 && d.v_bs == 0 && (d.dh == 64 || d.dh == 128 || d.dh == 256) && d.Lq >= 128 && d.Lk >= 128 &&
          d.q_ld % 8 == 0 && d.k_ld % 8 == 0 && d.v_ld % 8 == 0 && al(d.q, 16) && al(d.k, 16) && al(d.v, 16) &&
          d.o_ld % 4 == 0 && al(d.o, 8) && (!d.res || (d.res_ld % 4 == 0 && al(d.res, 8)));
 }

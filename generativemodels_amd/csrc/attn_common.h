@@ -13,4 +13,6 @@ struct GmAttnDesc {
   int dtype;
   void* workspace;             // optional scratch (gm_attention_workspace_bytes): enables the LDS-DMA kernel
   long long workspace_bytes;
+  int causal;                  // 1: query i attends keys j <= i + (Lk - Lq) only (SABlock causal mask, blocks/selfattention.py:133-134)
+  long long k_bs, v_bs;        // batch strides of k / v in elements; 0 = dense (Lk * ld).  A KV cache is [B][max_len][C] read up to Lk.
 };

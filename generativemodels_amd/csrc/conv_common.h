@@ -22,7 +22,7 @@ struct GmConvDesc {
   int in_mode;                    // 0 direct, 1 nearest up-sample by (fd,fh,fw), 2 zero-insertion by (fd,fh,fw)
   int fd, fh, fw;
   int pre_act;                    // 0 none, 1 SiLU, 2 ReLU (applied after the optional affine)
-  int post_act;                   // 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01)
+  int post_act;                   // 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01), 6 GELU (erf)
   int dtype;
   int ltd, lth, ltw;              // log2 of the output tile dims
   int cfg;                        // tile configuration id (see dispatch)
@@ -59,6 +59,7 @@ __device__ __forceinline__ float conv_post_act(float v, int act) {
     case 3: return 1.0f / (1.0f + expf(-v));
     case 4: return gm_silu_precise(v);
     case 5: return v > 0.f ? v : 0.01f * v;
+    case 6: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact), MONAI MLPBlock
     default: return v;
   }
 }

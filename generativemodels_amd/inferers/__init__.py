@@ -1,3 +1,5 @@
-from .inferer import (ControlNetDiffusionInferer, ControlNetLatentDiffusionInferer, DiffusionInferer, LatentDiffusionInferer)
+from .inferer import (ControlNetDiffusionInferer, ControlNetLatentDiffusionInferer, DiffusionInferer, LatentDiffusionInferer,
+                      VQVAETransformerInferer)
 
-__all__ = ["DiffusionInferer", "LatentDiffusionInferer", "ControlNetDiffusionInferer", "ControlNetLatentDiffusionInferer"]
+__all__ = ["DiffusionInferer", "LatentDiffusionInferer", "ControlNetDiffusionInferer", "ControlNetLatentDiffusionInferer",
+           "VQVAETransformerInferer"]

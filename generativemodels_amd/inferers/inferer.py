@@ -9,6 +9,7 @@ MI355X-specific execution of `sample`:
     captured once on the first step and replayed for the remaining steps."""
 from __future__ import annotations
 
+import math
 from typing import Callable, Optional
 
 import torch
@@ -16,7 +17,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._native import GmKlParams
-from ..networks.nets import VQVAE, DiffusionModelUNet
+from ..networks.nets import VQVAE, DecoderOnlyTransformer, DiffusionModelUNet
 
 try:  # progress bar is optional, like in the reference (inferer.py:28)
     from tqdm import tqdm
@@ -384,3 +385,103 @@ class ControlNetLatentDiffusionInferer(LatentDiffusionInferer):
                                                      original_input_range=original_input_range, scaled_input_range=scaled_input_range,
                                                      verbose=verbose, resample_latent_likelihoods=resample_latent_likelihoods,
                                                      resample_interpolation_mode=resample_interpolation_mode, quantized=quantized, _noise=_noise)
+
+
+class VQVAETransformerInferer(Inferer):
+    """Drop-in for generative.inferers.VQVAETransformerInferer (inferer.py:1126-1330): training forward, autoregressive sampling
+    and per-token likelihoods of a VQ-VAE + decoder-only transformer pair.
+
+    `sample` decodes incrementally over a KV cache when the transformer is this package's DecoderOnlyTransformer: the reference
+    re-runs the whole prefix for every new token; here a token is one row through each GEMM + one 1 x t attention per block, and
+    the sampling head (temperature, top-k, softmax, BOS mask) is one fused kernel.  When the prefix outgrows `max_seq_len` the
+    reference's window slides and the absolute positions restart, so those (few) steps recompute the cropped window like the
+    reference does.  The categorical draw itself is torch.multinomial on the device, as in the reference."""
+
+    def __init__(self) -> None:
+        pass
+
+    @staticmethod
+    def _sequence(latent: torch.Tensor, ordering) -> torch.Tensor:
+        lat = latent.reshape(latent.shape[0], -1)
+        order = torch.as_tensor(ordering.get_sequence_ordering().copy(), device=lat.device)
+        return lat[:, order]
+
+    def __call__(self, inputs: torch.Tensor, vqvae_model, transformer_model, ordering, condition: torch.Tensor | None = None,
+                 return_latent: bool = False):
+        """Next-token logits for the (BOS-shifted) latent sequence of `inputs` (reference inferer.py:1134-1181)."""
+        with torch.no_grad():
+            latent = vqvae_model.index_quantize(inputs)
+        latent_spatial_dim = tuple(latent.shape[1:])
+        latent = self._sequence(latent, ordering)
+        target = latent.clone()
+        bos = torch.full((latent.shape[0], 1), vqvae_model.num_embeddings, dtype=latent.dtype, device=latent.device)
+        latent = torch.cat([bos, latent], dim=1)[:, :-1].long()
+        seq_len, max_seq_len = latent.shape[1], transformer_model.max_seq_len
+        start = int(torch.randint(low=0, high=seq_len + 1 - max_seq_len, size=(1,)).item()) if max_seq_len < seq_len else 0
+        prediction = transformer_model(x=latent[:, start:start + max_seq_len].contiguous(), context=condition)
+        if return_latent:
+            return prediction, target[:, start:start + max_seq_len], latent_spatial_dim
+        return prediction
+
+    @torch.no_grad()
+    def sample(self, latent_spatial_dim, starting_tokens: torch.Tensor, vqvae_model, transformer_model, ordering,
+               conditioning: torch.Tensor | None = None, temperature: float = 1.0, top_k: int | None = None, verbose: bool = True):
+        """Autoregressive sampling of prod(latent_spatial_dim) tokens after the BOS token(s), decoded to an image
+        (reference inferer.py:1183-1245)."""
+        ops.require_device(starting_tokens)
+        seq_len = math.prod(latent_spatial_dim)
+        it = tqdm(range(seq_len)) if (verbose and has_tqdm) else range(seq_len)
+        latent_seq = starting_tokens.long()
+        bos = vqvae_model.num_embeddings
+        cached = isinstance(transformer_model, DecoderOnlyTransformer)
+        cache, filled = None, 0
+        for _ in it:
+            n = latent_seq.size(1)
+            if cached and n <= transformer_model.max_seq_len:
+                if cache is None:
+                    cache = transformer_model.new_cache(latent_seq.shape[0], latent_seq.device)
+                while filled < n:  # feeds the starting tokens on the first iteration, one new token afterwards
+                    logits = transformer_model.step(latent_seq[:, filled:filled + 1].contiguous(), filled, cache, conditioning)
+                    filled += 1
+            else:
+                idx_cond = latent_seq if n <= transformer_model.max_seq_len else latent_seq[:, -transformer_model.max_seq_len:]
+                logits = transformer_model(x=idx_cond.contiguous(), context=conditioning)[:, -1, :]
+            probs = ops.sample_probs(logits, temperature, top_k, bos)
+            idx_next = torch.multinomial(probs, num_samples=1)
+            latent_seq = torch.cat((latent_seq, idx_next), dim=1)
+        latent_seq = latent_seq[:, 1:]
+        revert = torch.as_tensor(ordering.get_revert_sequence_ordering().copy(), device=latent_seq.device)
+        latent = latent_seq[:, revert].reshape((starting_tokens.shape[0],) + tuple(latent_spatial_dim))
+        return vqvae_model.decode_samples(latent)
+
+    @torch.no_grad()
+    def get_likelihood(self, inputs: torch.Tensor, vqvae_model, transformer_model, ordering, condition: torch.Tensor | None = None,
+                       resample_latent_likelihoods: bool = False, resample_interpolation_mode: str = "nearest", verbose: bool = False):
+        """log p(token | predecessors) for every latent token, on the latent grid (reference inferer.py:1247-1330)."""
+        if resample_latent_likelihoods and resample_interpolation_mode not in ("nearest", "bilinear", "trilinear"):
+            raise ValueError(
+                f"resample_interpolation mode should be either nearest, bilinear, or trilinear, got {resample_interpolation_mode}")
+        latent = vqvae_model.index_quantize(inputs)
+        latent_spatial_dim = tuple(latent.shape[1:])
+        latent = self._sequence(latent, ordering)
+        seq_len = math.prod(latent_spatial_dim)
+        bos = torch.full((latent.shape[0], 1), vqvae_model.num_embeddings, dtype=latent.dtype, device=latent.device)
+        latent = torch.cat([bos, latent], dim=1).long()
+        msl = transformer_model.max_seq_len
+        target = latent[:, 1:]
+        logits = transformer_model(x=latent[:, :msl].contiguous(), context=condition)
+        t0 = logits.shape[1] if target.shape[1] >= logits.shape[1] else target.shape[1]
+        lp = ops.token_log_prob(logits[:, :t0].reshape(-1, logits.shape[-1]), target[:, :t0].reshape(-1)).reshape(latent.shape[0], t0)
+        if lp.shape[1] < target.shape[1]:
+            it = tqdm(range(msl, seq_len)) if (verbose and has_tqdm) else range(msl, seq_len)
+            cols = [lp]
+            for i in it:
+                lg = transformer_model(x=latent[:, i + 1 - msl:i + 1].contiguous(), context=condition)[:, -1, :]
+                cols.append(ops.token_log_prob(lg, target[:, i]).unsqueeze(1))
+            lp = torch.cat(cols, dim=1)
+        revert = torch.as_tensor(ordering.get_revert_sequence_ordering().copy(), device=lp.device)
+        out = lp[:, revert].reshape((inputs.shape[0],) + latent_spatial_dim)
+        if resample_latent_likelihoods:
+            # like the reference, on whatever device the values live: nn.Upsample is host-framework resampling of a result map
+            out = nn.Upsample(size=inputs.shape[2:], mode=resample_interpolation_mode)(out[:, None, ...].cpu()).to(out.device)
+        return out

@@ -17,7 +17,7 @@ from ._native import GmAttnDesc, GmConvDesc, GmKlParams, GmStepParams, check, li
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 ACT = {"none": 0, "silu": 1, "relu": 2}
-POST_ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "swish": 4, "leakyrelu": 5}
+POST_ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "swish": 4, "leakyrelu": 5, "gelu": 6}
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -709,9 +709,17 @@ def linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch
 # ------------------------------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------------------------------
+def _kv_ld(t: torch.Tensor) -> int:
+    """Row pitch of a (B, L, C) key / value operand whose batch stride is free (the first L rows of a per-sample KV cache)."""
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError("attention keys / values must be (B, L, C) with unit channel stride")
+    return t.stride(1) if t.shape[1] > 1 else max(t.stride(1), t.shape[2])
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
-              res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """softmax(scale * Q K^T) V per (batch, head). q: (B, Lq, heads*dh) arena views (channel slices allowed), k/v: (B, Lk, ...)."""
+              res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, causal: bool = False) -> torch.Tensor:
+    """softmax(scale * Q K^T) V per (batch, head). q: (B, Lq, heads*dh) arena views (channel slices allowed), k/v: (B, Lk, ...);
+    k / v may be the first Lk rows of a longer per-sample buffer (a KV cache). causal: query i sees keys j <= i + (Lk - Lq)."""
     require_device(q, k, v, res, out)
     b, lq, c = q.shape
     lk = k.shape[1]
@@ -724,8 +732,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
         out = torch.empty((b, lq, c), dtype=q.dtype, device=q.device)
     d = GmAttnDesc()
     d.q, d.q_ld = q.data_ptr(), arena_ld(q)
-    d.k, d.k_ld = k.data_ptr(), arena_ld(k)
-    d.v, d.v_ld = v.data_ptr(), arena_ld(v)
+    d.k, d.k_ld = k.data_ptr(), _kv_ld(k)
+    d.v, d.v_ld = v.data_ptr(), _kv_ld(v)
     if res is not None:
         if tuple(res.shape) != (b, lq, c) or res.dtype != q.dtype:
             raise ValueError("attention residual shape/dtype mismatch")
@@ -735,10 +743,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     d.o, d.o_ld = out.data_ptr(), arena_ld(out)
     d.B, d.H, d.Lq, d.Lk, d.dh = b, heads, lq, lk, dh
     d.scale, d.dtype = float(scale), dt_code(q.dtype)
-    # batch strides must equal L * ld (tokens of one sample are row-dense)
-    for t, L in ((q, lq), (k, lk), (v, lk), (out, lq)):
+    # q / out / res: batch strides must equal L * ld (tokens of one sample are row-dense); k / v may carry their own batch stride
+    for t, L in ((q, lq), (out, lq)) + (((res, lq),) if res is not None else ()):
         if t.shape[0] > 1 and t.stride(0) != L * arena_ld(t):
-            raise ValueError("attention operands must be row-dense over (batch, tokens)")
+            raise ValueError("attention queries / outputs must be row-dense over (batch, tokens)")
+    d.causal = int(bool(causal))
+    d.k_bs = k.stride(0) if (b > 1 and k.stride(0) != lk * _kv_ld(k)) else 0
+    d.v_bs = v.stride(0) if (b > 1 and v.stride(0) != lk * _kv_ld(v)) else 0
+    if causal and lk < lq:
+        raise ValueError("causal attention needs at least as many keys as queries")
     d.workspace, d.workspace_bytes = None, 0
     ws_bytes = lib().gm_attention_workspace_bytes(C.byref(d))
     if ws_bytes > 0:  # scratch for the transposed V image of the LDS-DMA kernel; stream-ordered, freed on return
@@ -753,6 +766,46 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
 # ------------------------------------------------------------------------------------------------------------------------
 # misc element-wise
 # ------------------------------------------------------------------------------------------------------------------------
+def embed_tokens(indices: torch.Tensor, token_weight: torch.Tensor, position_weight: torch.Tensor, pos0: int = 0) -> torch.Tensor:
+    """token_weight[indices] + position_weight[pos0 + arange(T)] for (B, T) int64 indices -> (B, T, C)."""
+    require_device(indices, token_weight, position_weight)
+    if indices.dim() != 2 or indices.dtype != torch.long or token_weight.dtype != position_weight.dtype or token_weight.shape[1] != position_weight.shape[1]:
+        raise ValueError("embed_tokens expects (B, T) int64 indices and two embedding tables of one dtype / width")
+    b, t = indices.shape
+    if pos0 + t > position_weight.shape[0]:
+        raise ValueError("sequence is longer than the position embedding table")
+    indices = indices.contiguous()
+    tw, pw = token_weight.detach().contiguous(), position_weight.detach().contiguous()
+    out = torch.empty((b, t, tw.shape[1]), dtype=tw.dtype, device=indices.device)
+    check(lib().gm_embed_tokens(indices.data_ptr(), tw.data_ptr(), pw.data_ptr(), out.data_ptr(), b, t, tw.shape[1], int(pos0), tw.shape[0],
+                                pw.shape[0], dt_code(tw.dtype), _stream()), "gm_embed_tokens")
+    return out
+
+
+def sample_probs(logits: torch.Tensor, temperature: float, top_k: Optional[int], bos_index: int) -> torch.Tensor:
+    """The transformer sampling head on (rows, V) logits -> fp32 probabilities (temperature, top-k crop, softmax, BOS zeroed)."""
+    require_device(logits)
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError("sample_probs expects (rows, V) logits with unit stride over V")
+    rows, v = logits.shape
+    probs = torch.empty((rows, v), dtype=torch.float32, device=logits.device)
+    check(lib().gm_sample_probs(logits.data_ptr(), logits.stride(0), probs.data_ptr(), rows, v, float(temperature),
+                                0 if top_k is None else int(min(top_k, v)), int(bos_index), dt_code(logits.dtype), _stream()), "gm_sample_probs")
+    return probs
+
+
+def token_log_prob(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """log(softmax(logits)[target]) for (rows, V) logits and (rows,) int64 targets -> fp32 (rows,)."""
+    require_device(logits, target)
+    if logits.dim() != 2 or logits.stride(1) != 1 or target.dtype != torch.long or target.numel() != logits.shape[0]:
+        raise ValueError("token_log_prob expects (rows, V) logits and (rows,) int64 targets")
+    target = target.contiguous()
+    out = torch.empty((logits.shape[0],), dtype=torch.float32, device=logits.device)
+    check(lib().gm_token_log_prob(logits.data_ptr(), logits.stride(0), target.data_ptr(), out.data_ptr(), logits.shape[0], logits.shape[1],
+                                  dt_code(logits.dtype), _stream()), "gm_token_log_prob")
+    return out
+
+
 def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10000.0, dtype=torch.float32) -> torch.Tensor:
     require_device(timesteps)
     t = timesteps.to(torch.float32).contiguous()

@@ -144,7 +144,7 @@ typedef struct GmConvDesc {
   int in_mode;               /* 0 direct, 1 nearest up-sample, 2 zero insertion (transposed conv) */
   int fd, fh, fw;
   int pre_act;               /* 0 none, 1 SiLU, 2 ReLU */
-  int post_act;              /* 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01) */
+  int post_act;              /* 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01), 6 GELU (erf) */
   int dtype;
   int ltd, lth, ltw;         /* log2 output tile dims; product must equal the configuration's voxel count */
   int cfg;                   /* tile configuration, see gm_conv_cfg_tile */
@@ -179,11 +179,25 @@ typedef struct GmAttnDesc {
   int dtype;
   void* workspace;            /* optional scratch of gm_attention_workspace_bytes(): enables the LDS-DMA kernel (bf16, dh 64/128/256) */
   long long workspace_bytes;
+  int causal;                 /* 1: query i sees keys j <= i + (Lk - Lq) (causal SABlock, blocks/selfattention.py:133-134) */
+  long long k_bs, v_bs;       /* batch strides of k / v in elements, 0 = dense (Lk * ld): a KV cache [B][max_len][C] read up to Lk */
 } GmAttnDesc;
 int gm_attention_max_head_dim(void);
 /* bytes of scratch the fastest kernel for this geometry wants (0: none; the descriptor's workspace fields are not read) */
 long long gm_attention_workspace_bytes(const GmAttnDesc* d);
 int gm_attention_forward(const GmAttnDesc* d, void* stream);
+
+/* ---- autoregressive transformer helpers (networks/nets/transformer.py, inferers/inferer.py:1126-1330) ------------------------ */
+/* out[b][t][:] = token_weight[indices[b][t]] + position_weight[pos0 + t]  (transformer.py:99-101) */
+int gm_embed_tokens(const long long* indices, const void* token_weight, const void* position_weight, void* out, long long batch,
+                    int seq_len, int C, int pos0, int num_tokens, int max_positions, int dtype, void* stream);
+/* sampling head (inferer.py:1221-1232): probs = softmax(crop_topk(logits / temperature)), probs[:, bos_index] = 0; top_k <= 0: no crop.
+ * logits: [rows][ld >= V] in dtype, probs: fp32 [rows][V] */
+int gm_sample_probs(const void* logits, long long ld, float* probs, long long rows, int V, float temperature, int top_k, int bos_index,
+                    int dtype, void* stream);
+/* out[row] = log(softmax(logits[row])[target[row]])  (inferer.py:1290-1296, 1316) */
+int gm_token_log_prob(const void* logits, long long ld, const long long* target, float* out, long long rows, int V, int dtype,
+                      void* stream);
 
 /* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */
 int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long long* indices, long long tokens,

@@ -357,3 +357,61 @@ def test_controlnet_matches_reference():
     linf = ControlNetLatentDiffusionInferer(sch, scale_factor=l["scale_factor"])
     img = linf.sample(_dev(l["noise"]), ae, lunet, lcn, _dev(l["cond"]), sch, verbose=False)
     _fp32_close(img, l["image"], "controlnet latent chain", factor=2.0)
+
+
+def test_transformer_and_vqvae_transformer_inferer_match_reference():
+    """DecoderOnlyTransformer (full-sequence forward and the KV-cache step API), the causal flag of the attention kernel, the fused
+    sampling head and VQVAETransformerInferer (__call__, get_likelihood incl. the sliding window, greedy sample) against the
+    reference's outputs / the oracle."""
+    from generativemodels_amd import ops
+    from generativemodels_amd.inferers import VQVAETransformerInferer
+    from generativemodels_amd.networks.nets import DecoderOnlyTransformer
+    from generativemodels_amd.utils import Ordering
+    fx = load_fixture("transformer")
+    for name, e in fx["forwards"].items():
+        m = DecoderOnlyTransformer(**e["cfg"]).eval()
+        m.load_state_dict(e["state_dict"])
+        m = m.to(DEV)
+        y = m(_dev(e["tokens"]), context=_dev(e["context"]))
+        _fp32_close(y, e["logits"], f"transformer {name}")
+        # incremental decoding reproduces the full forward, position by position
+        cache = m.new_cache(2, DEV)
+        for t in range(e["tokens"].shape[1]):
+            lg = m.step(_dev(e["tokens"][:, t:t + 1].contiguous()), t, cache, _dev(e["context"]))
+            _fp32_close(lg, e["logits"][:, t], f"transformer {name} step {t}")
+        mb = DecoderOnlyTransformer(**e["cfg"]).eval()
+        mb.load_state_dict(e["state_dict"])
+        mb = mb.to(DEV, torch.bfloat16)
+        ctx = None if e["context"] is None else e["context"].bfloat16()
+        _bf16_close(mb(_dev(e["tokens"]), context=_dev(ctx)), e["logits"], f"transformer {name} bf16")
+    i = fx["inferer"]
+    vq = _nets().VQVAE(**i["vq_cfg"]).eval()
+    vq.load_state_dict(i["vq_sd"])
+    tr = DecoderOnlyTransformer(**i["tr_cfg"]).eval()
+    tr.load_state_dict(i["tr_sd"])
+    vq, tr = vq.to(DEV), tr.to(DEV)
+    order = Ordering(**i["ordering"])
+    inf = VQVAETransformerInferer()
+    pred, target, lsd = inf(_dev(i["x"]), vq, tr, order, return_latent=True)
+    assert lsd == tuple(i["latent_spatial_dim"]) and torch.equal(target.cpu(), i["target"])
+    _fp32_close(pred, i["prediction"], "transformer inferer __call__")
+    _fp32_close(inf.get_likelihood(_dev(i["x"]), vq, tr, order), i["likelihood"], "transformer likelihood")
+    img = inf.sample((4, 4), torch.full((2, 1), 16, device=DEV), vq, tr, order, top_k=1, verbose=False)
+    _fp32_close(img, i["greedy_image"], "greedy sample (KV cache)")
+    # the sampling head against the oracle on the teacher-forced logits: temperature / top-k variants incl. ties and k >= V
+    logits = i["logits"].reshape(-1, i["logits"].shape[-1])
+    for temp, k in [(1.0, None), (0.7, 5), (1.3, 1), (1.0, 17), (2.0, 40)]:
+        want = R.transformer_sample_probs(logits.clone(), temp, k, 16)
+        got = ops.sample_probs(_dev(logits), temp, k, 16).cpu()
+        assert (got - want).abs().max().item() <= 1e-6, (temp, k)
+        assert torch.equal(got == 0, want == 0)
+    tied = torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0, -1.0]])
+    assert torch.equal(ops.sample_probs(_dev(tied), 1.0, 2, 5).cpu() > 0, R.transformer_sample_probs(tied.clone(), 1.0, 2, 5) > 0)
+    w = fx["window"]
+    tr2 = DecoderOnlyTransformer(**w["tr_cfg"]).eval()
+    tr2.load_state_dict(w["tr_sd"])
+    tr2 = tr2.to(DEV)
+    o2 = Ordering("raster_scan", 2, (1, 2, 2))
+    _fp32_close(inf.get_likelihood(_dev(w["x"]), vq, tr2, o2), w["likelihood"], "windowed likelihood")
+    s = inf.sample((2, 2), torch.full((2, 1), 16, device=DEV), vq, tr2, o2, top_k=3, verbose=False)  # window slides: recompute path
+    assert s.shape == (2, 1, 8, 8) and torch.isfinite(s).all()

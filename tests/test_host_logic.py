@@ -226,3 +226,50 @@ def test_controlnet_state_dict_and_constructor_errors():
     x = torch.zeros(1, 1, 8, 8)
     with pytest.raises(RuntimeError, match="MI355X"):
         m(x, torch.tensor([1]), x)
+
+
+def test_transformer_state_dict_ordering_and_errors():
+    """DecoderOnlyTransformer / SABlock / Ordering host logic: reference state_dict keys (incl. the causal_mask buffer key, emitted on
+    save and ignored on load), ordering permutations, constructor errors, no CPU fallback."""
+    import numpy as np
+
+    from generativemodels_amd.networks.blocks import SABlock, TransformerBlock
+    from generativemodels_amd.networks.nets import DecoderOnlyTransformer
+    from generativemodels_amd.utils import Ordering
+
+    fx = load_fixture("transformer")
+    for name, e in fx["forwards"].items():
+        m = DecoderOnlyTransformer(**e["cfg"])
+        sd = m.state_dict()
+        assert set(sd) == set(e["state_dict"]), name
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(e["state_dict"][k].shape), (name, k)
+        assert torch.equal(sd["blocks.0.attn.causal_mask"], e["state_dict"]["blocks.0.attn.causal_mask"])
+        m.load_state_dict(e["state_dict"], strict=True)
+    for key, e in fx["orderings"].items():
+        o = Ordering(**e["kw"])
+        assert np.array_equal(o.get_sequence_ordering(), e["order"].numpy()) and np.array_equal(o.get_revert_sequence_ordering(), e["revert"].numpy())
+        x = torch.arange(len(e["order"]))
+        assert torch.equal(o(x)[torch.as_tensor(o.get_revert_sequence_ordering().copy())], x)
+    np.random.seed(0)
+    r = Ordering("random", 2, (1, 3, 3))
+    assert sorted(r.get_sequence_ordering().tolist()) == list(range(9))
+    with pytest.raises(ValueError):
+        Ordering("hilbert", 2, (1, 2, 2))
+    with pytest.raises(ValueError):
+        Ordering("raster_scan", 2, (1, 2, 2, 2))
+    with pytest.raises(ValueError):
+        Ordering("raster_scan", 2, (1, 2, 2), transformation_order=("reflect", "reflect"))
+    with pytest.raises(ValueError):
+        Ordering("raster_scan", 2, (1, 2, 2), transformation_order=("shear",))
+    with pytest.raises(ValueError):
+        SABlock(16, 3)
+    with pytest.raises(ValueError):
+        SABlock(16, 4, causal=True)
+    with pytest.raises(ValueError):
+        SABlock(16, 4, dropout_rate=1.5)
+    with pytest.raises(ValueError):
+        TransformerBlock(16, 64, 3)
+    m = DecoderOnlyTransformer(num_tokens=10, max_seq_len=8, attn_layers_dim=16, attn_layers_depth=1, attn_layers_heads=2)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros((1, 4), dtype=torch.long))
