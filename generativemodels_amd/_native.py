@@ -40,6 +40,18 @@ class GmConvDesc(C.Structure):
                 ("skip_x", c_vp * 2), ("skip_ld", c_ll * 2), ("skip_cin", C.c_int * 2), ("skip_w", c_vp), ("skip_bias", c_vp)]
 
 
+class GmDecodeBlock(C.Structure):
+    _fields_ = [("ln1_g", c_vp), ("ln1_b", c_vp), ("w_qkv", c_vp), ("b_qkv", c_vp), ("w_o", c_vp), ("b_o", c_vp), ("ln3_g", c_vp),
+                ("ln3_b", c_vp), ("w_1", c_vp), ("b_1", c_vp), ("w_2", c_vp), ("b_2", c_vp), ("k_cache", c_vp), ("v_cache", c_vp)]
+
+
+class GmDecodeDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("M", C.c_int), ("heads", C.c_int), ("depth", C.c_int), ("max_len", C.c_int),
+                ("num_tokens", C.c_int), ("dtype", C.c_int), ("ln_eps", C.c_float), ("pos", C.c_int), ("tokens", c_vp),
+                ("tok_emb", c_vp), ("pos_emb", c_vp), ("blocks", C.POINTER(GmDecodeBlock)), ("w_logits", c_vp), ("b_logits", c_vp),
+                ("logits", c_vp), ("scratch", c_vp), ("scratch_bytes", c_ll)]
+
+
 class GmAttnDesc(C.Structure):
     _fields_ = [("q", c_vp), ("q_ld", c_ll), ("k", c_vp), ("k_ld", c_ll), ("v", c_vp), ("v_ld", c_ll),
                 ("res", c_vp), ("res_ld", c_ll), ("o", c_vp), ("o_ld", c_ll),
@@ -81,6 +93,8 @@ PROTOTYPES = {
     "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       c_vp]),
     "gm_attention_max_head_dim": (C.c_int, []),
+    "gm_decode_scratch_bytes": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gm_transformer_decode_step": (C.c_int, [C.POINTER(GmDecodeDesc), c_vp]),
     "gm_embed_tokens": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_sample_probs": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_token_log_prob": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, c_vp]),

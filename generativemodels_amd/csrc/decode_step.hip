@@ -1,0 +1,109 @@
+// One autoregressive decoding step of the decoder-only transformer, issued from native code.
+//
+// A token step is ~110 tiny launches (per block: LayerNorm, stacked q|k|v GEMM, two KV-cache row copies, 1 x t attention, out_proj +
+// residual, LayerNorm, MLP up + GELU, MLP down + residual).  Issued one by one through the Python binding it cost 2.7 ms per token
+// (20 us of interpreter + descriptor work per launch) -- no faster than the reference's recompute-the-prefix loop on this model
+// size.  This entry point walks the block table in C++ and enqueues the same kernels back to back
+// (reference semantics: networks/nets/transformer.py:98-106, blocks/transformerblock.py:86-91, blocks/selfattention.py:98-147).
+#include "attn_common.h"
+#include "conv_common.h"
+
+extern "C" int gm_embed_tokens(const long long* indices, const void* token_weight, const void* position_weight, void* out, long long batch,
+                               int seq_len, int C, int pos0, int num_tokens, int max_positions, int dtype, void* stream);
+extern "C" int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta, long long rows,
+                            int C, float eps, int dtype, void* stream);
+extern "C" int gm_copy_channels(const void* src, long long src_ld, int src_dtype, void* dst, long long dst_ld, int dst_dtype,
+                                long long rows, int C, void* stream);
+extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream);
+extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream);
+
+struct GmDecodeBlock {
+  const float *ln1_g, *ln1_b;
+  const void* w_qkv; const float* b_qkv;  // packed [3C][C] (gm_pack_conv_weight), bias or null
+  const void* w_o; const float* b_o;
+  const float *ln3_g, *ln3_b;
+  const void* w_1; const float* b_1;      // C -> M
+  const void* w_2; const float* b_2;      // M -> C
+  void* k_cache; void* v_cache;           // [B][max_len][C]
+};
+
+struct GmDecodeDesc {
+  int B, C, M, heads, depth, max_len, num_tokens, dtype;
+  float ln_eps;
+  int pos;                                // position of the token being fed (its K/V land in cache row `pos`)
+  const long long* tokens;                // [B] token ids on the device
+  const void* tok_emb; const void* pos_emb;
+  const GmDecodeBlock* blocks;            // host array of `depth` entries
+  const void* w_logits; const float* b_logits;
+  void* logits;                           // [B][num_tokens] in dtype
+  void* scratch; long long scratch_bytes; // gm_decode_scratch_bytes(B, C, M, dtype)
+};
+
+static long long elt(int dtype) { return dtype == GM_F32 ? 4 : 2; }
+
+extern "C" long long gm_decode_scratch_bytes(int B, int C, int M, int dtype) {
+  // x0, x1, h, y: B*C each; qkv: 3*B*C; a: B*M; every buffer rounded up to 256 bytes
+  auto r = [](long long v) { return (v + 255) / 256 * 256; };
+  return 4 * r((long long)B * C * elt(dtype)) + r(3LL * B * C * elt(dtype)) + r((long long)B * M * elt(dtype));
+}
+
+// y[rows][cout] = act(x[rows][cin] W^T + b) (+ res): the 1-tap form of the implicit-GEMM convolution over `rows` "voxels"
+static int linear_rows(const void* x, long long x_ld, const void* w, const float* b, const void* res, long long res_ld, void* y, long long y_ld,
+                       int rows, int cin, int cout, int post_act, int dtype, void* stream) {
+  GmConvDesc d = {};
+  d.x = x; d.x_ld = x_ld; d.w = w; d.bias = b;
+  d.res = res; d.res_ld = res_ld; d.y = y; d.y_ld = y_ld;
+  d.N = 1; d.Cin = cin; d.Cout = cout;
+  d.Ds = d.Hs = 1; d.Ws = rows; d.Do = d.Ho = 1; d.Wo = rows;
+  d.kd = d.kh = d.kw = 1; d.sd = d.sh = d.sw = 1; d.dd = d.dh = d.dw = 1;
+  d.fd = d.fh = d.fw = 1;
+  d.post_act = post_act; d.dtype = dtype;
+  d.cfg = 4; d.ltd = 0; d.lth = 0; d.ltw = 6;  // 64 rows x 64 channels per work-group
+  return gm_conv_forward(&d, stream);
+}
+
+extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) {
+  GM_REQUIRE(dp, "null descriptor");
+  const GmDecodeDesc& d = *dp;
+  GM_REQUIRE(d.tokens && d.tok_emb && d.pos_emb && d.blocks && d.w_logits && d.logits && d.scratch, "null pointer");
+  GM_REQUIRE(d.B > 0 && d.C > 0 && d.M > 0 && d.heads > 0 && d.C % d.heads == 0 && d.depth > 0, "bad geometry");
+  GM_REQUIRE(d.pos >= 0 && d.pos < d.max_len, "position outside the context window");
+  GM_REQUIRE(d.scratch_bytes >= gm_decode_scratch_bytes(d.B, d.C, d.M, d.dtype), "scratch too small");
+  const long long es = elt(d.dtype);
+  auto r = [](long long v) { return (v + 255) / 256 * 256; };
+  char* s = reinterpret_cast<char*>(d.scratch);
+  char* x0 = s;  s += r((long long)d.B * d.C * es);
+  char* x1 = s;  s += r((long long)d.B * d.C * es);
+  char* h = s;   s += r((long long)d.B * d.C * es);
+  char* y = s;   s += r((long long)d.B * d.C * es);
+  char* qkv = s; s += r(3LL * d.B * d.C * es);
+  char* a = s;
+  const int C = d.C;
+  int rc = gm_embed_tokens(d.tokens, d.tok_emb, d.pos_emb, x0, d.B, 1, C, d.pos, d.num_tokens, d.max_len, d.dtype, stream);
+  if (rc) return rc;
+  const float scale = 1.0f / sqrtf((float)(C / d.heads));
+  for (int i = 0; i < d.depth; ++i) {
+    const GmDecodeBlock& b = d.blocks[i];
+    GM_REQUIRE(b.w_qkv && b.w_o && b.w_1 && b.w_2 && b.k_cache && b.v_cache, "null block parameter");
+    if ((rc = gm_layernorm(x0, C, h, C, b.ln1_g, b.ln1_b, d.B, C, d.ln_eps, d.dtype, stream))) return rc;
+    if ((rc = linear_rows(h, C, b.w_qkv, b.b_qkv, nullptr, 0, qkv, 3 * C, d.B, C, 3 * C, 0, d.dtype, stream))) return rc;
+    // this token's key / value rows -> cache row `pos` of every sequence (row r of the copy = sequence r)
+    if ((rc = gm_copy_channels(qkv + (long long)C * es, 3 * C, d.dtype, reinterpret_cast<char*>(b.k_cache) + (long long)d.pos * C * es,
+                               (long long)d.max_len * C, d.dtype, d.B, C, stream))) return rc;
+    if ((rc = gm_copy_channels(qkv + 2LL * C * es, 3 * C, d.dtype, reinterpret_cast<char*>(b.v_cache) + (long long)d.pos * C * es,
+                               (long long)d.max_len * C, d.dtype, d.B, C, stream))) return rc;
+    GmAttnDesc at = {};
+    at.q = qkv; at.q_ld = 3 * C;
+    at.k = b.k_cache; at.k_ld = C; at.k_bs = (long long)d.max_len * C;
+    at.v = b.v_cache; at.v_ld = C; at.v_bs = (long long)d.max_len * C;
+    at.o = y; at.o_ld = C;
+    at.B = d.B; at.H = d.heads; at.Lq = 1; at.Lk = d.pos + 1; at.dh = C / d.heads;
+    at.scale = scale; at.dtype = d.dtype;
+    if ((rc = gm_attention_forward(&at, stream))) return rc;
+    if ((rc = linear_rows(y, C, b.w_o, b.b_o, x0, C, x1, C, d.B, C, C, 0, d.dtype, stream))) return rc;
+    if ((rc = gm_layernorm(x1, C, h, C, b.ln3_g, b.ln3_b, d.B, C, d.ln_eps, d.dtype, stream))) return rc;
+    if ((rc = linear_rows(h, C, b.w_1, b.b_1, nullptr, 0, a, d.M, d.B, C, d.M, 6, d.dtype, stream))) return rc;
+    if ((rc = linear_rows(a, d.M, b.w_2, b.b_2, x1, C, x0, C, d.B, d.M, C, 0, d.dtype, stream))) return rc;
+  }
+  return linear_rows(x0, C, d.w_logits, d.b_logits, nullptr, 0, d.logits, d.num_tokens, d.B, C, d.num_tokens, 0, d.dtype, stream);
+}

@@ -199,6 +199,33 @@ int gm_sample_probs(const void* logits, long long ld, float* probs, long long ro
 int gm_token_log_prob(const void* logits, long long ld, const long long* target, float* out, long long rows, int V, int dtype,
                       void* stream);
 
+/* One KV-cache decoding step of the decoder-only transformer issued natively (~110 launches back to back): embed the fed token at
+ * `pos`, per block LayerNorm -> q|k|v -> append k, v to the caches -> 1 x (pos+1) attention -> out_proj + x -> LayerNorm -> MLP(GELU) + x,
+ * then to_logits (networks/nets/transformer.py:98-106, blocks/transformerblock.py:86-91, blocks/selfattention.py:98-147; no cross
+ * attention).  Weights are gm_pack_conv_weight images of the nn.Linear matrices (q, k, v stacked along the output dim). */
+typedef struct GmDecodeBlock {
+  const float *ln1_g, *ln1_b;
+  const void* w_qkv; const float* b_qkv;
+  const void* w_o; const float* b_o;
+  const float *ln3_g, *ln3_b;
+  const void* w_1; const float* b_1;
+  const void* w_2; const float* b_2;
+  void* k_cache; void* v_cache;      /* [B][max_len][C] */
+} GmDecodeBlock;
+typedef struct GmDecodeDesc {
+  int B, C, M, heads, depth, max_len, num_tokens, dtype;
+  float ln_eps;
+  int pos;
+  const long long* tokens;           /* [B] device */
+  const void* tok_emb; const void* pos_emb;
+  const GmDecodeBlock* blocks;       /* host array, `depth` entries */
+  const void* w_logits; const float* b_logits;
+  void* logits;                      /* [B][num_tokens], dtype */
+  void* scratch; long long scratch_bytes;
+} GmDecodeDesc;
+long long gm_decode_scratch_bytes(int B, int C, int M, int dtype);
+int gm_transformer_decode_step(const GmDecodeDesc* d, void* stream);
+
 /* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */
 int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long long* indices, long long tokens,
                  int num_embeddings, int dim, int dtype, void* stream);

@@ -374,11 +374,15 @@ def test_transformer_and_vqvae_transformer_inferer_match_reference():
         m = m.to(DEV)
         y = m(_dev(e["tokens"]), context=_dev(e["context"]))
         _fp32_close(y, e["logits"], f"transformer {name}")
-        # incremental decoding reproduces the full forward, position by position
-        cache = m.new_cache(2, DEV)
-        for t in range(e["tokens"].shape[1]):
-            lg = m.step(_dev(e["tokens"][:, t:t + 1].contiguous()), t, cache, _dev(e["context"]))
-            _fp32_close(lg, e["logits"][:, t], f"transformer {name} step {t}")
+        # incremental decoding reproduces the full forward, position by position: native step (one C call per token; models
+        # without cross attention) and the op-by-op step issue the same kernels
+        for native in (True, False):
+            m.native_step = native
+            cache = m.new_cache(2, DEV)
+            for t in range(e["tokens"].shape[1]):
+                lg = m.step(_dev(e["tokens"][:, t:t + 1].contiguous()), t, cache, _dev(e["context"]))
+                _fp32_close(lg, e["logits"][:, t], f"transformer {name} step {t} native={native}")
+        m.native_step = True
         mb = DecoderOnlyTransformer(**e["cfg"]).eval()
         mb.load_state_dict(e["state_dict"])
         mb = mb.to(DEV, torch.bfloat16)
