@@ -40,15 +40,19 @@ __device__ __forceinline__ void dma_wait() {
 // NW waves per work-group, each owning MF voxel fragments (16 voxels) x 64 channels of the 256-voxel tile: <8, 2> = 16 waves / CU,
 // 0.75 LDS operand reads per MFMA; <4, 4> = 8 waves / CU with 256 VGPRs each, 0.5 reads per MFMA (the LDS port is the next limit
 // after latency: 16 waves x 6 KiB per tap = 768 LDS clocks against 512 MFMA clocks per SIMD)
-template <typename T, int NW, int MF>
-__global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvDesc p) {
+// S = 1: stride 1 (optionally over a 2x nearest-upsampled input), 4x4x16 output tile.  S = 2: stride 2 (the Downsample convolutions),
+// 2x4x16 output tile whose 5 x 9 x 33 input patch is stored with even and odd W columns in separate row runs, so that the 16 voxels of
+// a fragment still read 16 consecutive LDS rows for every tap (the DMA source address is free per lane: any layout costs nothing).
+template <typename T, int NW, int MF, int S, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * NW;
   constexpr int NFR = 4, G = 3;
-  static_assert(NW * MF == 16, "256-voxel tile");
-  constexpr int TD = 4, TH = 4, TW = 16;
-  constexpr int PD = TD + 2, PH = TH + 2, PW = TW + 2;
+  static_assert(NW * MF * 16 == (S == 1 ? 256 : 128), "waves x fragments cover the tile");
+  constexpr int TD = S == 1 ? 4 : 2, TH = 4, TW = 16, BM = TD * TH * TW;
+  constexpr int PD = S * (TD - 1) + 3, PH = S * (TH - 1) + 3, PW = S * (TW - 1) + 3;  // LDS rows per W line (33 for S = 2: 17 even + 16 odd)
+  constexpr int EW = TW + 1;                                                            // S = 2: rows of the even-column run
   constexpr int PLANE = ((PH * PW + 15) / 16) * 16;        // 112 rows: depth offsets keep (row mod 16)
   constexpr int PROWS = PD * PLANE;                        // 672 rows = 42 DMA pieces
   constexpr int PPIECES = PROWS / 16;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvD
   const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
   int Dv = p.Ds, Hv = p.Hs, Wv = p.Ws;
   if (p.in_mode == 1) { Dv *= p.fd; Hv *= p.fh; Wv *= p.fw; }
-  const int ud0 = od0 - p.pd, uh0 = oh0 - p.ph, uw0 = ow0 - p.pw;
+  const int ud0 = od0 * S - p.pd, uh0 = oh0 * S - p.ph, uw0 = ow0 * S - p.pw;
   const int nchunks = p.Cin / BK;                          // host-checked: Cin % BK == 0
   const int cout_pad = (p.Cout + 15) & ~15;
   const int total = nchunks * NGROUPS;
@@ -95,7 +99,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvD
   for (int j = 0; j < PPW; ++j) {
     const int row = 16 * (wave + NW * j) + (lane >> 2);
     const int pa = row / PLANE, rr = row - pa * PLANE;
-    const int pb = rr / PW, pc = rr - pb * PW;
+    const int pb = rr / PW, lc = rr - pb * PW;
+    const int pc = S == 1 ? lc : (lc < EW ? 2 * lc : 2 * (lc - EW) + 1);  // S = 2: even columns first, then the odd ones
     int ud = ud0 + pa, uh = uh0 + pb, uw = uw0 + pc;
     const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv);
     if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
@@ -148,7 +153,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvD
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const int row = a * PLANE + (bb + kh) * PW + c + kw;
+        const int col = S == 1 ? c + kw : (kw == 1 ? EW + c : c + (kw >> 1));  // patch column S*c + kw in the split layout
+        const int row = S * a * PLANE + (S * bb + kh) * PW + col;
         xaddr[mf][kh][kw] = row * DMA_ROWB + ((q ^ dma_swz(row)) << 4);
       }
   }
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvD
     int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
 #pragma unroll
     for (int h = 0; h < MF; ++h) {
-      const int m = wave * (MF * 16) + h * 16 + (lane >> 2);
+      const int m = wave * (MF * 16) + h * 16 + (lane >> 2);  // (a, bb, c) below assume TH = 4, TW = 16
       const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
       svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
     }
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvD
 #pragma unroll
           for (int h = 0; h < MF; ++h) {
             const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
-            dma16(src, lds0 + (unsigned)(j * 256 + wave * (MF * 16) + h * 16) * DMA_ROWB);
+            dma16(src, lds0 + (unsigned)(j * BM + wave * (MF * 16) + h * 16) * DMA_ROWB);
           }
           if (NW == 4 || (wave >> 2) == j) {  // 8 waves: waves 0-3 move panel 0, waves 4-7 panel 1; 4 waves: every wave moves both
             const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane & 3) << 4);
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvD
 #pragma unroll
           for (int nf = 0; nf < NFR; ++nf) wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + j * (BN * DMA_ROWB));
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(smem + caddr[mf] + j * (256 * DMA_ROWB));
+          for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(smem + caddr[mf] + j * (BM * DMA_ROWB));
 #pragma unroll
           for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
@@ -333,15 +339,19 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_dma_kernel(const GmConvD
   }
 }
 
-extern "C" long long gm_conv_dma_lds_bytes() { return 672LL * DMA_ROWB + 3LL * 192 * DMA_ROWB; }
+extern "C" long long gm_conv_dma_lds_bytes(int stride) {
+  const long long plane = stride == 1 ? 112 : 304, planes = stride == 1 ? 6 : 5;
+  return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB;
+}
 
-// geometry this kernel covers (the caller has already checked stride 1 / dilation 1 / alignment like for conv_fast)
+// geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
-  return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
-         (d->in_mode == 0 || d->in_mode == 1) && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
-         (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->ltd == 2 && d->lth == 2 &&
+  const int s = d->cfg == 15 ? 2 : 1;
+  return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == s && d->sh == s && d->sw == s && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
+         (d->in_mode == 0 || (d->in_mode == 1 && s == 1)) && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
+         (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->ltd == (s == 1 ? 2 : 1) && d->lth == 2 &&
          d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
          (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) &&
          (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31) && (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31) &&
@@ -352,22 +362,28 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
                               (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
 }
 
-template <typename T, int NW, int MF>
+template <typename T, int NW, int MF, int S, int MINW>
 static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_dma_kernel<T, NW, MF>;
+  auto kern = conv_dma_kernel<T, NW, MF, S, MINW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(), st>>>(d);
+  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(S), st>>>(d);
+}
+
+template <typename T>
+static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
+  if (d.cfg == 15) launch_dma<T, 8, 1, 2, 2>(d, nblocks, st);        // stride 2: 8 waves x 16 voxels, one work-group per CU
+  else if (d.cfg == 14) launch_dma<T, 4, 4, 1, 2>(d, nblocks, st);   // 4 waves x 64 voxels
+  else launch_dma<T, 8, 2, 1, 4>(d, nblocks, st);                    // cfg 11: 8 waves x 32 voxels, two work-groups per CU
 }
 
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const bool four = dp->cfg == 14;  // cfg 11: 8 waves x 32 voxels, cfg 14: 4 waves x 64 voxels
-  if (dp->dtype == GM_F32) { if (four) launch_dma<float, 4, 4>(*dp, nblocks, st); else launch_dma<float, 8, 2>(*dp, nblocks, st); return 0; }
-  if (dp->dtype == GM_BF16) { if (four) launch_dma<bf16_raw, 4, 4>(*dp, nblocks, st); else launch_dma<bf16_raw, 8, 2>(*dp, nblocks, st); return 0; }
+  if (dp->dtype == GM_F32) { dispatch_dma<float>(*dp, nblocks, st); return 0; }
+  if (dp->dtype == GM_BF16) { dispatch_dma<bf16_raw>(*dp, nblocks, st); return 0; }
   return -2;
 }

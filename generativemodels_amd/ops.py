@@ -531,7 +531,7 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         if desc.Cin <= 4:
             order = [12] + order  # taps-as-K kernel of the 1..4-channel input convolutions
     if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
-        order = [11] + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
+        order = ([15] if desc.sd == 2 else [11]) + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
         order = [c for c in order if _cfg_tile(c)[0] <= 64] + [c for c in order if _cfg_tile(c)[0] > 64]
     best = None

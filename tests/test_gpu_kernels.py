@@ -284,6 +284,26 @@ def test_conv_lds_dma_kernel(case, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("even", 32, 64, (8, 16, 32), 1, 1), ("odd", 64, 40, (9, 11, 37), 1, 1), ("asym", 32, 72, (8, 10, 34), 0, 1)],
+                         ids=lambda c: c[0])
+def test_conv_lds_dma_stride2_kernel(case, dtype):
+    """cfg 15 (conv_dma.hip, S = 2): the Downsample convolutions -- stride 2 with symmetric padding (diffusion_model_unet.py:510-518)
+    and with the AutoencoderKL's pad-high-only form (autoencoderkl.py:107-121); even / odd W columns live in separate LDS row runs."""
+    ops = _ops()
+    name, cin, cout, sp, plo, phi = case
+    n = 2
+    x = _rand((n, cin, *sp), 181).to(dtype)
+    w = (_rand((cout, cin, 3, 3, 3), 182) / math.sqrt(cin * 27)).to(dtype)
+    b = _rand((cout,), 183) * 0.1
+    want = F.conv3d(F.pad(x.double(), (plo, phi) * 3), w.double(), b.double(), stride=2)
+    got = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=3, stride=2, padding=plo, pad_hi=phi, force_cfg=15, want_stats=True)
+    _check(_cf(got), want, dtype, f"dma stride 2 {name}")
+    st = got._gm_cstats.sum(0).cpu()
+    v = got.float().cpu().double().reshape(n, -1, cout)
+    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [("one", 64, 64, (32,), (8, 8, 16)), ("cat", 32, 40, (64, 32), (5, 7, 19)), ("cat3", 64, 136, (32, 96), (4, 6, 18)),
                                   ("fallback2d", 16, 24, (8, 16), (9, 20))], ids=lambda c: c[0])
 def test_conv_fused_shortcut(case, dtype):
