@@ -202,43 +202,68 @@ __global__ __launch_bounds__(256, 2) void conv_cout1_kernel(const GmConvDesc p) 
       }
   }
 
-  // ---- phase 1: Z[tap][v] for every patch voxel; one 16-voxel fragment at a time per wave, operands straight from global ----------
+  // ---- phase 1: Z[tap][v] for every patch voxel; 16-voxel fragments, operands straight from global memory.  A wave owns fragments
+  // wave, wave + 4, ...; their loads are issued in batches of FB fragments, batch b + 1 in flight while batch b is multiplied (one
+  // fragment per round trip left 8 waves per CU waiting on HBM latency: 0.33 ms for the 64 -> 1 head at 128^3) -------------------
   const T* xin = reinterpret_cast<const T*>(p.x);
-  for (int f = wave; f < NFRAG; f += 4) {
+  constexpr int FB = KS <= 2 ? 4 : 2;                       // fragments per batch (register budget: 2 x FB x KS x 4 VGPRs)
+  constexpr int FPW = (NFRAG + 3) / 4;                      // fragments per wave (11)
+  constexpr int NBATCH = (FPW + FB - 1) / FB;
+  auto frag_vox = [&](int f, bool& ok) __attribute__((always_inline)) -> long long {
     const int row = f * 16 + l15;
     const int pa = row / (PH * PW), rr = row - pa * (PH * PW), pb = rr / PW, pc = rr - pb * PW;
     const int ud = od0 - p.pd + pa, uh = oh0 - p.ph + pb, uw = ow0 - p.pw + pc;
-    const bool ok = (row < PROWS) & (ud >= 0) & (ud < p.Ds) & (uh >= 0) & (uh < p.Hs) & (uw >= 0) & (uw < p.Ws);
-    const long long vox = ok ? (((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : 0;
-    uint4 raw[KS];
+    ok = (f < NFRAG) & (row < PROWS) & (ud >= 0) & (ud < p.Ds) & (uh >= 0) & (uh < p.Hs) & (uw >= 0) & (uw < p.Ws);
+    return ok ? (((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : 0;
+  };
+  uint4 raw[2][FB][KS];
+  auto load_batch = [&](int bi, int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) raw[s] = *reinterpret_cast<const uint4*>(xin + vox * p.x_ld + s * BK + q * VECW);  // branch-free
-    f32x4_t z0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, z1 = z0;
+    for (int u = 0; u < FB; ++u) {
+      bool ok;
+      const long long vox = frag_vox(wave + 4 * (bi * FB + u), ok);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      uint4 xf = raw[s];
-      if (p.pre_scale || p.pre_act) {
-        float v[VECW];
-        Vec16<T>::unpack(raw[s], v);
-        if (p.pre_scale) {
-#pragma unroll
-          for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[s][i] + sh[s][i];
-        }
-        if (p.pre_act) {
-#pragma unroll
-          for (int i = 0; i < VECW; ++i) v[i] = conv_act(v[i], p.pre_act, PRECISE);
-        }
-        xf = Vec16<T>::pack(v);
-      }
-      xf = make_uint4(ok ? xf.x : 0u, ok ? xf.y : 0u, ok ? xf.z : 0u, ok ? xf.w : 0u);  // zero padding of the ACTIVATED tensor
-      Mma<T>::run(wf[0][s], xf, z0);
-      Mma<T>::run(wf[1][s], xf, z1);
+      for (int s = 0; s < KS; ++s) raw[slot][u][s] = *reinterpret_cast<const uint4*>(xin + vox * p.x_ld + s * BK + q * VECW);  // branch-free
     }
-    // D layout: column = voxel l15, rows = taps 4q + r (fragment 0) and 16 + 4q + r (fragment 1)
+  };
+  load_batch(0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      Z[(4 * q + r) * ZP + row] = z0[r];
-      if (16 + 4 * q + r < NTAP) Z[(16 + 4 * q + r) * ZP + row] = z1[r];
+  for (int bi = 0; bi < NBATCH; ++bi) {
+    if (bi + 1 < NBATCH) load_batch(bi + 1, (bi + 1) & 1);
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+      const int f = wave + 4 * (bi * FB + u);
+      if (f >= NFRAG) continue;  // wave-uniform
+      bool ok;
+      (void)frag_vox(f, ok);
+      const int row = f * 16 + l15;
+      f32x4_t z0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, z1 = z0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        uint4 xf = raw[bi & 1][u][s];
+        if (p.pre_scale || p.pre_act) {
+          float v[VECW];
+          Vec16<T>::unpack(xf, v);
+          if (p.pre_scale) {
+#pragma unroll
+            for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[s][i] + sh[s][i];
+          }
+          if (p.pre_act) {
+#pragma unroll
+            for (int i = 0; i < VECW; ++i) v[i] = conv_act(v[i], p.pre_act, PRECISE);
+          }
+          xf = Vec16<T>::pack(v);
+        }
+        xf = make_uint4(ok ? xf.x : 0u, ok ? xf.y : 0u, ok ? xf.z : 0u, ok ? xf.w : 0u);  // zero padding of the ACTIVATED tensor
+        Mma<T>::run(wf[0][s], xf, z0);
+        Mma<T>::run(wf[1][s], xf, z1);
+      }
+      // D layout: column = voxel l15, rows = taps 4q + r (fragment 0) and 16 + 4q + r (fragment 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Z[(4 * q + r) * ZP + row] = z0[r];
+        if (16 + 4 * q + r < NTAP) Z[(16 + 4 * q + r) * ZP + row] = z1[r];
+      }
     }
   }
   __syncthreads();
