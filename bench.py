@@ -63,7 +63,8 @@ def measured_hbm_traffic(label: str, dtype) -> dict:
         return dict(traffic=None)
     elem = "unsigned short" if dtype == torch.bfloat16 else "float"
     sym = (f"conv_fast_kernel<{elem}, {FAST_CFG_TEMPLATE[cfg]}>" if cfg in FAST_CFG_TEMPLATE else
-           f"conv_dma_kernel<{elem}, 8, 2>" if cfg == 11 else f"conv_dma_kernel<{elem}, 4, 4>" if cfg == 14 else None)
+           f"conv_dma_kernel<{elem}, 8, 2, 1, 4>" if cfg == 11 else f"conv_dma_kernel<{elem}, 4, 4, 1, 2>" if cfg == 14 else
+           f"conv_dma_kernel<{elem}, 8, 1, 2, 2>" if cfg == 15 else None)
     for r in rows:
         if sym is not None and sym in r["kernel"]:
             return dict(traffic=round(r["hbm_mb_per_launch_corrected"] * 1e6), traffic_unit="bytes/launch (avg over the same launches)",
