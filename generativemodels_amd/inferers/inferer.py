@@ -66,7 +66,11 @@ class _GraphedUNet:
 class DiffusionInferer(Inferer):
     """Drop-in for generative.inferers.DiffusionInferer. `diffusion_model` may be any callable `(x, timesteps=, context=)`."""
 
-    def __init__(self, scheduler: nn.Module, use_hip_graph: bool = False) -> None:
+    GRAPH_AUTO_MAX_ELEMENTS = 1 << 19  # use_hip_graph=None: replay a HIP graph when the model input is at most this many elements
+
+    def __init__(self, scheduler: nn.Module, use_hip_graph: bool | None = None) -> None:
+        """use_hip_graph: True / False, or None = decide per call: small problems are host-launch-bound and replaying the forward from
+        a HIP graph is 1.4-3x faster (C1b, tools/bench_c1b.py), large ones are GPU-bound and eager launches are faster (C2)."""
         self.scheduler = scheduler
         self.use_hip_graph = use_hip_graph
 
@@ -104,7 +108,8 @@ class DiffusionInferer(Inferer):
                 model_input, ctx = ops.concat_dim1([image, conditioning]), None
             else:
                 model_input, ctx = image, conditioning
-            if self.use_hip_graph and isinstance(diffusion_model, DiffusionModelUNet):
+            use_graph = self.use_hip_graph if self.use_hip_graph is not None else model_input.numel() <= self.GRAPH_AUTO_MAX_ELEMENTS
+            if use_graph and isinstance(diffusion_model, DiffusionModelUNet):
                 if graphed is None:
                     graphed = _GraphedUNet(diffusion_model, model_input, tt, ctx)
                 model_output = graphed(model_input, tt)
@@ -211,7 +216,7 @@ class LatentDiffusionInferer(DiffusionInferer):
     diffusion chain, latent scaling, optional latent pad / crop."""
 
     def __init__(self, scheduler: nn.Module, scale_factor: float = 1.0, ldm_latent_shape: list | None = None,
-                 autoencoder_latent_shape: list | None = None, use_hip_graph: bool = False) -> None:
+                 autoencoder_latent_shape: list | None = None, use_hip_graph: bool | None = None) -> None:
         super().__init__(scheduler=scheduler, use_hip_graph=use_hip_graph)
         self.scale_factor = scale_factor
         if (ldm_latent_shape is None) ^ (autoencoder_latent_shape is None):
