@@ -290,10 +290,97 @@ def transformer_fixtures():
     print("likelihood", tuple(lik.shape), float(lik.min()), "greedy", tuple(greedy.shape))
 
 
+def grid_cases():
+    """Constructor-argument grid in the spirit of the reference's own shape tests (tests/test_diffusion_model_unet.py:23-232,
+    tests/test_autoencoderkl.py:22-160, tests/test_vqvae.py:22-90): per-level res-block tuples, resblock_updown, attention placements and
+    head widths, cross-attention with several transformer layers, class embeddings, encoder / decoder non-local attention switches,
+    ConvTranspose up-sampling, scalar-vs-tuple VQ-VAE parameters -- in 2-D and 3-D."""
+    unet = []
+    for sd in (2, 3):
+        base = dict(spatial_dims=sd, in_channels=1, out_channels=1, num_channels=(8, 8, 8), norm_num_groups=8)
+        unet += [
+            dict(base, num_res_blocks=1, attention_levels=(False, False, False)),
+            dict(base, num_res_blocks=(1, 1, 2), attention_levels=(False, False, False)),
+            dict(base, num_res_blocks=1, attention_levels=(False, False, False), resblock_updown=True),
+            dict(base, num_res_blocks=1, attention_levels=(False, False, True), num_head_channels=8),
+            dict(base, num_res_blocks=1, attention_levels=(False, False, True), num_head_channels=4, resblock_updown=True),
+            dict(base, num_res_blocks=1, attention_levels=(False, True, True), num_head_channels=(0, 2, 4)),
+            dict(base, num_res_blocks=1, attention_levels=(False, False, True), num_head_channels=4, with_conditioning=True,
+                 cross_attention_dim=3, transformer_num_layers=2),
+            dict(base, in_channels=2, out_channels=3, num_res_blocks=(2, 1, 1), attention_levels=(True, False, True), num_head_channels=8,
+                 num_class_embeds=5, upcast_attention=True),
+        ]
+    aekl = []
+    for sd in (2, 3):
+        base = dict(spatial_dims=sd, in_channels=1, out_channels=1, num_channels=(4, 4, 4), latent_channels=4, norm_num_groups=4)
+        aekl += [
+            dict(base, attention_levels=(False, False, False), num_res_blocks=1),
+            dict(base, attention_levels=(False, False, False), num_res_blocks=(1, 1, 2)),
+            dict(base, attention_levels=(False, False, True), num_res_blocks=1),
+            dict(base, attention_levels=(False, False, False), num_res_blocks=1, with_encoder_nonlocal_attn=False),
+            dict(base, attention_levels=(False, True, False), num_res_blocks=1, with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False,
+                 use_convtranspose=True),
+        ]
+    vq = []
+    for sd in (2, 3):
+        base = dict(spatial_dims=sd, in_channels=1, out_channels=1, num_channels=(4, 4), num_res_layers=1, num_embeddings=8, embedding_dim=8)
+        vq += [
+            dict(base, num_res_channels=(4, 4), downsample_parameters=((2, 4, 1, 1),) * 2, upsample_parameters=((2, 4, 1, 1, 0),) * 2),
+            dict(base, num_res_channels=4, downsample_parameters=(2, 4, 1, 1), upsample_parameters=(2, 4, 1, 1, 0)),
+            dict(base, num_res_layers=2, num_res_channels=(4, 8), downsample_parameters=((2, 4, 1, 1), (1, 3, 1, 1)),
+                 upsample_parameters=((1, 3, 1, 1, 0), (2, 4, 1, 1, 0)), act="LEAKYRELU", output_act="sigmoid"),
+        ]
+    return unet, aekl, vq
+
+
+def grid_fixture():
+    """tests/golden/config_grid.pt: reference outputs over grid_cases(); weights are synthetic_state_dict(shapes, seed) on both sides."""
+    from generative.networks.nets import VQVAE, AutoencoderKL, DiffusionModelUNet
+
+    unet, aekl, vq = grid_cases()
+    out = dict(kind="config_grid", unet=[], aekl=[], vqvae=[])
+    for i, cfg in enumerate(unet):
+        m = DiffusionModelUNet(**cfg).eval()
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(synthetic_state_dict(shapes, seed=300 + i))
+        sp = (16,) * cfg["spatial_dims"]
+        x = _randn((2, cfg["in_channels"], *sp), 7)
+        ctx = _randn((2, 2, cfg["cross_attention_dim"]), 8) if cfg.get("with_conditioning") else None
+        cl = torch.tensor([1, 4]) if cfg.get("num_class_embeds") else None
+        t = torch.tensor([600, 30])
+        with torch.no_grad():
+            y = m(x, t, context=ctx, class_labels=cl)
+        out["unet"].append(dict(cfg=cfg, shapes=shapes, seed=300 + i, x=x, timesteps=t, context=ctx, class_labels=cl, y=y))
+    for i, cfg in enumerate(aekl):
+        m = AutoencoderKL(**cfg).eval()
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(synthetic_state_dict(shapes, seed=400 + i))
+        x = _randn((1, 1, *((16,) * cfg["spatial_dims"])), 7)
+        with torch.no_grad():
+            mu, sigma = m.encode(x)
+            rec = m.decode(mu)
+        out["aekl"].append(dict(cfg=cfg, shapes=shapes, seed=400 + i, x=x, z_mu=mu, z_sigma=sigma, reconstruction=rec))
+    for i, cfg in enumerate(vq):
+        m = VQVAE(**cfg).eval()
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(synthetic_state_dict(shapes, seed=500 + i))
+        x = _randn((1, 1, *((8,) * cfg["spatial_dims"])), 7)
+        with torch.no_grad():
+            z = m.encode(x)
+            idx = m.index_quantize(x)
+            rec = m.decode_samples(idx)
+        out["vqvae"].append(dict(cfg=cfg, shapes=shapes, seed=500 + i, x=x, z=z, indices=idx, reconstruction=rec))
+    torch.save(out, os.path.join(OUT, "config_grid.pt"))
+    print("grid", len(out["unet"]), len(out["aekl"]), len(out["vqvae"]))
+
+
 def main():
     g = load_reference()
     if g is None:
         raise SystemExit("reference tree not found; golden fixtures can only be made in the build container")
+    if "--grid-only" in sys.argv:
+        grid_fixture()
+        return
     if "--transformer-only" in sys.argv:
         transformer_fixtures()
         return

@@ -195,3 +195,33 @@ def test_transformer_ordering_and_vqvae_transformer_inferer_match_reference():
         idx2 = R.vq_index_quantize(i["vq_sd"], R.vqvae_encode(i["vq_sd"], i["vq_cfg"], w["x"]))[0]
         o2, r2 = R.ordering_indices("raster_scan", 2, (1, 2, 2))
         assert_close(R.transformer_likelihood(w["tr_sd"], w["tr_cfg"], idx2, o2, r2, 16), w["likelihood"], atol=2e-5, what="windowed likelihood")
+
+
+def _grid_sd(e):
+    return R.synthetic_state_dict(e["shapes"], seed=e["seed"])
+
+
+def test_constructor_argument_grid_matches_reference():
+    """The restatement over a grid of constructor arguments in the spirit of the reference's shape tests (res-block tuples,
+    resblock_updown, attention placements / head widths, cross-attention depth, class embeddings, non-local attention switches,
+    ConvTranspose up-sampling, scalar-vs-tuple VQ-VAE parameters; 2-D and 3-D) against reference outputs (oracle/make_golden.py
+    --grid-only)."""
+    fx = load_fixture("config_grid")
+    with torch.no_grad():
+        for e in fx["unet"]:
+            y = R.unet_forward(_grid_sd(e), e["cfg"], e["x"], e["timesteps"], e["context"], e["class_labels"])
+            assert_close(y, e["y"], atol=2e-5 * max(1.0, e["y"].abs().max().item()), what=f"unet {e['cfg']}")
+        for e in fx["aekl"]:
+            sd = _grid_sd(e)
+            mu, sigma = R.aekl_encode(sd, e["cfg"], e["x"])
+            assert_close(mu, e["z_mu"], atol=2e-5 * max(1.0, e["z_mu"].abs().max().item()), what=f"aekl mu {e['cfg']}")
+            assert_close(sigma, e["z_sigma"], atol=2e-5 * max(1.0, e["z_sigma"].abs().max().item()), what=f"aekl sigma {e['cfg']}")
+            assert_close(R.aekl_decode(sd, e["cfg"], e["z_mu"]), e["reconstruction"], atol=2e-5 * max(1.0, e["reconstruction"].abs().max().item()),
+                         what=f"aekl decode {e['cfg']}")
+        for e in fx["vqvae"]:
+            sd = _grid_sd(e)
+            z = R.vqvae_encode(sd, e["cfg"], e["x"])
+            assert_close(z, e["z"], atol=2e-5 * max(1.0, e["z"].abs().max().item()), what=f"vqvae z {e['cfg']}")
+            assert torch.equal(R.vq_index_quantize(sd, e["z"])[0], e["indices"])
+            assert_close(R.vqvae_decode(sd, e["cfg"], R.vq_embed(sd, e["indices"])), e["reconstruction"],
+                         atol=2e-5 * max(1.0, e["reconstruction"].abs().max().item()), what=f"vqvae decode {e['cfg']}")
