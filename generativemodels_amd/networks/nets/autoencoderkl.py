@@ -24,7 +24,7 @@ class _Down(nn.Module):
         self.conv = ConvP(spatial_dims, channels, channels, 3, 2, 0, pad_hi=1)
 
     def run(self, x):
-        return self.conv.run(x)
+        return self.conv.run(x, want_stats=True)  # a ResBlock's GroupNorm follows: statistics ride in the epilogue
 
 
 class _Up(nn.Module):
@@ -39,7 +39,7 @@ class _Up(nn.Module):
             self.conv = ConvP(spatial_dims, channels, channels, 3, 1, 1)
 
     def run(self, x):
-        return self.conv.run(x) if self.use_convtranspose else self.conv.run(x, upsample=True)
+        return self.conv.run(x, want_stats=True) if self.use_convtranspose else self.conv.run(x, upsample=True, want_stats=True)
 
 
 def _res(spatial_dims, cin, cout, groups, eps):
@@ -52,7 +52,7 @@ def _run_blocks(blocks: nn.ModuleList, h: torch.Tensor) -> torch.Tensor:
         if isinstance(blk, nn.GroupNorm):
             pre = gn_prologue(blk, h)  # consumed by the next convolution's prologue (no SiLU: autoencoderkl.py:433-446)
         elif isinstance(blk, ConvP):
-            h = blk.run(h, pre=pre)
+            h = blk.run(h, pre=pre, want_stats=True)
             pre = None
         else:
             h = blk.run(h)

@@ -140,7 +140,7 @@ class ControlNet(_TimestepPath, nn.Module):
                 context = ops.cast(context.contiguous(), dtype)
             temb = lambda blk: rows[id(blk)]
             emb = self.controlnet_cond_embedding.run(ops.to_channels_last(controlnet_cond))
-            h = self.conv_in.run(ops.to_channels_last(x), res=emb)
+            h = self.conv_in.run(ops.to_channels_last(x), res=emb, want_stats=True)
             skips = [h]
             for st in self.down_blocks:
                 for j, rb in enumerate(st.resnets):

@@ -124,7 +124,7 @@ class _Downsample(nn.Module):
         self.op = ConvP(spatial_dims, num_channels, num_channels, 3, 2, padding)
 
     def run(self, x, temb_row=None):
-        return self.op.run(x)
+        return self.op.run(x, want_stats=True)  # the next ResnetBlock's GroupNorm statistics ride in the epilogue
 
 
 class _Upsample(nn.Module):
@@ -329,7 +329,7 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
                 context = ops.cast(context.contiguous(), dtype)
             temb = lambda blk: rows[id(blk)]
 
-            h = self.conv_in.run(ops.to_channels_last(x))
+            h = self.conv_in.run(ops.to_channels_last(x), want_stats=True)
             skips = [h]
             for st in self.down_blocks:
                 for j, rb in enumerate(st.resnets):
