@@ -62,7 +62,8 @@ def _compile(src: str) -> str:
     srcp = os.path.join(CSRC, src)
     deps = [srcp, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     if _stale(obj, deps):
-        cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", srcp, "-o", obj]
+        extra = os.environ.get("GM_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DGM_CONV_ABLATE for tools/ablate_conv.py (bench-only builds)
+        cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), *extra, "-x", "hip", "-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

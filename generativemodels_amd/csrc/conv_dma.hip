@@ -294,6 +294,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   }
 
   // ---- epilogue (shared with conv_fast): LDS transpose -> 16-byte row stores, fused GroupNorm statistics -------------------
+#ifdef GM_CONV_ABLATE
+  if (p.debug_flags & 256) return;  // bench-only: main loop without the epilogue
+#endif
   __syncthreads();
   constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
   constexpr int CH_PER_PASS = 128 / (int)sizeof(T);
