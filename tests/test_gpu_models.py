@@ -452,3 +452,24 @@ def test_constructor_argument_grid_matches_reference():
         idx = m.index_quantize(_dev(e["x"])).cpu()
         # indices are an argmin over fp32 distances: a near-tie may flip under a different summation order; demand >= 99 % agreement
         assert (idx == e["indices"]).float().mean().item() >= 0.99, f"vqvae indices {e['cfg']}"
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 20, 24, 28), (2, 1, 12, 36, 20)])
+def test_unet3d_ragged_volume_matches_oracle(shape):
+    """Volumes whose extents are not multiples of the 4x4x16 / 2x4x16 tiles of the LDS-DMA kernels (partial tiles on every axis, at
+    every resolution level, through the stride-2 and up-sampling convolutions and the fused shortcut), fp32, against the CPU oracle."""
+    cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(32, 64, 64), attention_levels=(False, False, True),
+               num_res_blocks=(1, 2, 1), num_head_channels=(0, 0, 32), norm_num_groups=16)
+    torch.manual_seed(0)
+    m = _nets().DiffusionModelUNet(**cfg).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    R.derandomize_zeros(sd)
+    m.load_state_dict(sd)
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(3))
+    t = torch.tensor([700, 40][:shape[0]])
+    with torch.no_grad():
+        want = R.unet_forward(sd, cfg, x, t)
+    got = m.to(DEV)(_dev(x), _dev(t))
+    _fp32_close(got, want, f"ragged unet {shape}")
+    yb = m.to(DEV, torch.bfloat16)(_dev(x.bfloat16()), _dev(t))
+    _bf16_close(yb, want, f"ragged unet bf16 {shape}")
