@@ -49,8 +49,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * NW;
   constexpr int NFR = 4, G = 3;
-  static_assert(NW * MF * 16 == (S == 1 ? 256 : 128), "waves x fragments cover the tile");
-  constexpr int TD = S == 1 ? 4 : 2, TH = 4, TW = 16, BM = TD * TH * TW;
+  static_assert(NW * MF * 16 == 512 || NW * MF * 16 == (S == 1 ? 256 : 128), "waves x fragments cover the tile");
+  constexpr int TH = 4, TW = 16, BM = NW * MF * 16, TD = BM / (TH * TW);  // 4x4x16 (8x4x16 for the 16-wave variant); S = 2: 2x4x16
   constexpr int PD = S * (TD - 1) + 3, PH = S * (TH - 1) + 3, PW = S * (TW - 1) + 3;  // LDS rows per W line (33 for S = 2: 17 even + 16 odd)
   constexpr int EW = TW + 1;                                                            // S = 2: rows of the even-column run
   constexpr int PLANE = ((PH * PW + 15) / 16) * 16;        // 112 rows: depth offsets keep (row mod 16)
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   constexpr int PATCH_BYTES = PROWS * DMA_ROWB;
   constexpr int WBUF_BYTES = WROWS * DMA_ROWB;
   constexpr int NGROUPS = 9;                               // 27 taps / G
-  constexpr int WPW = NW == 8 ? 2 : 3;  // DMA instructions per wave per weight panel: 8 waves x (1 full + 1 half piece) or 4 x 3 full
+  // DMA instructions per wave per weight panel (12 pieces): 8 waves x (1 full + 1 half piece), 4 waves x 3 full, or -- 16 waves --
+  // one full piece on waves 0..11 and none on waves 12..15 (the end-of-group wait count is then wave dependent)
+  constexpr int WPW = NW == 8 ? 2 : (NW == 4 ? 3 : 1);
   static_assert(WROWS == 192, "12 pieces per weight panel");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB]
@@ -109,6 +111,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const long long xrowb = p.x_ld * (long long)sizeof(T);
   // (Staging the patch through registers instead -- all loads of a lane in flight, then ds_write_b128 -- was measured 5-7 % slower.)
   auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
+#ifdef GM_CONV_ABLATE
+    if (p.debug_flags & 1024) return;  // bench-only: no patch traffic (results are garbage)
+#endif
     const char* cbase = xbase + (long long)chunk * (BK * (int)sizeof(T)) + pswz;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
@@ -124,12 +129,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   int wsrc[WPW];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
 #pragma unroll
   for (int h = 0; h < WPW; ++h) {
-    const int row = NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2)) : 16 * (wave + NW * h) + (lane >> 2);
+    const int row = NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2))
+                            : (NW == 4 ? 16 * (wave + NW * h) + (lane >> 2) : 16 * (wave < 12 ? wave : 0) + (lane >> 2));
     const int u = row >> 6, col = row & 63;
     const int co = cb * BN + col;
     wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
   }
   auto issue_w = [&](int t, int buf) __attribute__((always_inline)) {  // WPW instructions per wave, every wave
+#ifdef GM_CONV_ABLATE
+    if (p.debug_flags & 512) return;  // bench-only: no weight traffic (results are garbage)
+#endif
     const char* panel = wbase + (long long)t * G * cout_pad * DMA_ROWB;  // (chunk*27 + 3*grp) * cout_pad rows
     const unsigned dst = lds0 + PATCH_BYTES + (unsigned)buf * WBUF_BYTES;
 #pragma unroll
@@ -138,6 +147,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       if (NW == 8) {
         if (h == 0) dma16(src, dst + (unsigned)(16 * wave) * DMA_ROWB);
         else if (lane < 32) dma16(src, dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
+      } else if (NW == 16) {
+        if (wave < 12) dma16(src, dst + (unsigned)(16 * wave) * DMA_ROWB);
       } else {
         dma16(src, dst + (unsigned)(16 * (wave + NW * h)) * DMA_ROWB);
       }
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         }
       } else {
         // panel t+1 (issued a group ago) must have landed; panel t+2 (WPW instructions, just issued) may stay in flight
-        if (g < NGROUPS - 2 || !last_chunk) dma_wait<WPW>(); else dma_wait<0>();
+        if ((g < NGROUPS - 2 || !last_chunk) && (NW != 16 || wave < 12)) dma_wait<WPW>(); else dma_wait<0>();
         __builtin_amdgcn_s_barrier();
       }
       mma_tap();
@@ -343,8 +354,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   }
 }
 
-extern "C" long long gm_conv_dma_lds_bytes(int stride) {
-  const long long plane = stride == 1 ? 112 : 304, planes = stride == 1 ? 6 : 5;
+// variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile
+extern "C" long long gm_conv_dma_lds_bytes(int variant) {
+  const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
   return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB;
 }
 
@@ -355,7 +367,8 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   const int s = d->cfg == 15 ? 2 : 1;
   return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == s && d->sh == s && d->sw == s && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
          (d->in_mode == 0 || (d->in_mode == 1 && s == 1)) && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
-         (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->ltd == (s == 1 ? 2 : 1) && d->lth == 2 &&
+         (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 &&
+         d->ltd == (d->cfg == 16 ? 3 : (s == 1 ? 2 : 1)) && d->lth == 2 &&
          d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
          (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) &&
          (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31) && (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31) &&
@@ -375,12 +388,13 @@ static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(S), st>>>(d);
+  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(S == 2 ? 2 : (NW == 16 ? 3 : 1)), st>>>(d);
 }
 
 template <typename T>
 static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
-  if (d.cfg == 15) launch_dma<T, 8, 1, 2, 2>(d, nblocks, st);        // stride 2: 8 waves x 16 voxels, one work-group per CU
+  if (d.cfg == 16) launch_dma<T, 16, 2, 1, 4>(d, nblocks, st);       // 512 voxels (8x4x16), 16 waves, one work-group per CU
+  else if (d.cfg == 15) launch_dma<T, 8, 1, 2, 2>(d, nblocks, st);   // stride 2: 8 waves x 16 voxels, one work-group per CU
   else if (d.cfg == 14) launch_dma<T, 4, 4, 1, 2>(d, nblocks, st);   // 4 waves x 64 voxels
   else launch_dma<T, 8, 2, 1, 4>(d, nblocks, st);                    // cfg 11: 8 waves x 32 voxels, two work-groups per CU
 }

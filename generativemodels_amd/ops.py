@@ -539,6 +539,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         bm, _ = _cfg_tile(cfg)
         tb = _tile_bits_fast if cfg >= 5 else _tile_bits
         bits = tb(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
+        if cfg == 16:
+            bits = [3, 2, 4]  # the 16-wave LDS-DMA variant is built for 8x4x16 tiles
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy

@@ -252,7 +252,7 @@ def test_conv_every_tile_configuration(cfg, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [("plain", 32, 64, (8, 8, 16), False), ("ragged", 64, 40, (5, 7, 19), False),
                                   ("wide", 96, 136, (4, 6, 18), False), ("up", 32, 64, (3, 5, 9), True)], ids=lambda c: c[0])
-@pytest.mark.parametrize("cfg", [11, 14])
+@pytest.mark.parametrize("cfg", [11, 14, 16])
 def test_conv_lds_dma_kernel(case, dtype, cfg):
     """cfg 11 (conv_dma.hip): both operands through the LDS-DMA engine, source-side swizzle, zero page for the halo; ragged
     volumes, channel counts that are not tile multiples, folded 2x up-sampling, bias + timestep row + residual epilogue into a
