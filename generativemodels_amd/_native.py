@@ -93,6 +93,7 @@ PROTOTYPES = {
     "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       c_vp]),
     "gm_attention_max_head_dim": (C.c_int, []),
+    "gm_linear_rows": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_decode_scratch_bytes": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "gm_transformer_decode_step": (C.c_int, [C.POINTER(GmDecodeDesc), c_vp]),
     "gm_embed_tokens": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),

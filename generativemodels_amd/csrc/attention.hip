@@ -267,7 +267,8 @@ static int dispatch_attn(const GmAttnDesc& d, hipStream_t st) {
 }
 
 extern "C" int gm_attention_max_head_dim(void) { return 256; }
-extern "C" int gm_attention_dma_try(const GmAttnDesc* dp, void* stream);  // attention_dma.hip
+extern "C" int gm_attention_dma_try(const GmAttnDesc* dp, void* stream);     // attention_dma.hip
+extern "C" int gm_attention_decode_try(const GmAttnDesc* dp, void* stream);  // small_ops.hip
 
 extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream) {
   GM_REQUIRE(dp, "null descriptor");
@@ -279,6 +280,7 @@ extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream) {
   GM_REQUIRE((long long)d.B * d.H <= 65535, "too many (batch, head) pairs for one launch");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (gm_attention_decode_try(dp, stream)) GM_LAUNCH_CHECK();  // one query per (batch, head): the KV-cache decode kernel (small_ops.hip)
   if (gm_attention_dma_try(dp, stream)) GM_LAUNCH_CHECK();  // bf16, d in {64,128,256}, workspace given: LDS-DMA kernel
   int rc;
   if (d.dtype == GM_F32) rc = dispatch_attn<float>(d, st);

@@ -14,7 +14,6 @@ extern "C" int gm_layernorm(const void* x, long long x_ld, void* y, long long y_
                             int C, float eps, int dtype, void* stream);
 extern "C" int gm_copy_channels(const void* src, long long src_ld, int src_dtype, void* dst, long long dst_ld, int dst_dtype,
                                 long long rows, int C, void* stream);
-extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream);
 extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream);
 
 struct GmDecodeBlock {
@@ -47,19 +46,13 @@ extern "C" long long gm_decode_scratch_bytes(int B, int C, int M, int dtype) {
   return 4 * r((long long)B * C * elt(dtype)) + r(3LL * B * C * elt(dtype)) + r((long long)B * M * elt(dtype));
 }
 
-// y[rows][cout] = act(x[rows][cin] W^T + b) (+ res): the 1-tap form of the implicit-GEMM convolution over `rows` "voxels"
+extern "C" int gm_linear_rows(const void* x, long long x_ld, const void* w, const float* bias, const void* res, long long res_ld, void* y,
+                              long long y_ld, int rows, int cin, int cout, int pre_act, int post_act, int dtype, void* stream);
+
+// y[rows][cout] = act(x[rows][cin] W^T + b) (+ res) through the small-row GEMM kernel (small_ops.hip)
 static int linear_rows(const void* x, long long x_ld, const void* w, const float* b, const void* res, long long res_ld, void* y, long long y_ld,
                        int rows, int cin, int cout, int post_act, int dtype, void* stream) {
-  GmConvDesc d = {};
-  d.x = x; d.x_ld = x_ld; d.w = w; d.bias = b;
-  d.res = res; d.res_ld = res_ld; d.y = y; d.y_ld = y_ld;
-  d.N = 1; d.Cin = cin; d.Cout = cout;
-  d.Ds = d.Hs = 1; d.Ws = rows; d.Do = d.Ho = 1; d.Wo = rows;
-  d.kd = d.kh = d.kw = 1; d.sd = d.sh = d.sw = 1; d.dd = d.dh = d.dw = 1;
-  d.fd = d.fh = d.fw = 1;
-  d.post_act = post_act; d.dtype = dtype;
-  d.cfg = 4; d.ltd = 0; d.lth = 0; d.ltw = 6;  // 64 rows x 64 channels per work-group
-  return gm_conv_forward(&d, stream);
+  return gm_linear_rows(x, x_ld, w, b, res, res_ld, y, y_ld, rows, cin, cout, 0, post_act, dtype, stream);
 }
 
 extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) {

@@ -508,6 +508,7 @@ def _cfg_tile(cfg: int):
 
 _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
 
+SMALL_LINEAR_ROWS = 64       # 1x1 "convolutions" over at most this many rows take gm_linear_rows
 DMA_CONV = True              # route eligible 3x3x3 convolutions through conv_dma.hip (cfg 11)
 DMA_CONV_MIN_VOXELS = 1 << 12
 LDS_SOFT_LIMIT = 80 * 1024   # two workgroups per CU
@@ -598,6 +599,25 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
         wcin = weight.shape[0] if transposed else weight.shape[1]
         if wcin != cin:
             raise ValueError(f"input has {cin} channels but the weight expects {wcin}")
+    rows = n * math.prod(src)
+    vecw = 16 // x.element_size()
+    if (rows <= SMALL_LINEAR_ROWS and k == (1, 1, 1) and s == (1, 1, 1) and not transposed and not upsample and pre is None
+            and rowvec is None and not want_stats and skip is None and force_cfg is None and cin % vecw == 0
+            and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0 and plo == (0, 0, 0) and phi == (0, 0, 0)):
+        # a handful of rows (decode steps, the timestep MLP): the barrier-free small-row GEMM instead of the tiled kernel
+        out_shape = (*x.shape[:-1], cout)
+        if out is None:
+            out = torch.empty(out_shape, dtype=dtype, device=x.device)
+        elif tuple(out.shape) != out_shape or out.dtype != dtype:
+            raise ValueError(f"out has shape {tuple(out.shape)}, expected {out_shape}")
+        if res is not None and (tuple(res.shape) != out_shape or res.dtype != dtype):
+            raise ValueError(f"residual has shape {tuple(res.shape)} / {res.dtype}, expected {out_shape} / {dtype}")
+        b32 = as_f32(bias) if bias is not None else None
+        _timed(f"linear_rows<{str(dtype).split('.')[-1]}>", dict(flops=2.0 * rows * cin * cout, bytes=float(x.element_size() * cin * cout), shape=f"{rows}x{cin}->{cout}"),
+               lambda: check(lib().gm_linear_rows(x.data_ptr(), arena_ld(x), packed.data_ptr(), _ptr(b32), _ptr(res), 0 if res is None else arena_ld(res),
+                                                  out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act], POST_ACT[post_act], dt_code(dtype),
+                                                  _stream()), "gm_linear_rows"))
+        return out
     d = GmConvDesc()
     d.in_mode, d.fd, d.fh, d.fw = 0, 1, 1, 1
     act_axes = (0,) * (3 - nsp) + (1,) * nsp

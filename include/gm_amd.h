@@ -199,6 +199,12 @@ int gm_sample_probs(const void* logits, long long ld, float* probs, long long ro
 int gm_token_log_prob(const void* logits, long long ld, const long long* target, float* out, long long rows, int V, int dtype,
                       void* stream);
 
+/* y[rows][cout] = post_act(pre_act(x)[rows][cin] W^T + bias) (+ res) for a handful of rows (decode steps, the timestep MLP): one wave
+ * per 16 output channels, weights global -> registers -> MFMA, no LDS.  w: gm_pack_conv_weight image of the [cout][cin] matrix;
+ * pre_act / post_act as in GmConvDesc; cin and x_ld multiples of 16 bytes. */
+int gm_linear_rows(const void* x, long long x_ld, const void* w, const float* bias, const void* res, long long res_ld, void* y,
+                   long long y_ld, int rows, int cin, int cout, int pre_act, int post_act, int dtype, void* stream);
+
 /* One KV-cache decoding step of the decoder-only transformer issued natively (~110 launches back to back): embed the fed token at
  * `pos`, per block LayerNorm -> q|k|v -> append k, v to the caches -> 1 x (pos+1) attention -> out_proj + x -> LayerNorm -> MLP(GELU) + x,
  * then to_logits (networks/nets/transformer.py:98-106, blocks/transformerblock.py:86-91, blocks/selfattention.py:98-147; no cross
