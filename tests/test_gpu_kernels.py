@@ -481,6 +481,44 @@ def test_attention_lds_dma_kernel(case):
         _check(got2, want - res.double(), dtype, "attention (LDS-DMA, sliced qkv)")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cin,cout", [(1, 256, 768), (5, 64, 257), (17, 1024, 256), (64, 40, 24)])
+def test_small_row_linear_kernel(rows, cin, cout, dtype):
+    """gm_linear_rows (small_ops.hip): the barrier-free GEMM that ops.linear / ops.conv(kernel=1) route to for <= 64 rows -- SiLU
+    prologue, bias, GELU epilogue, residual, ragged channel counts."""
+    ops = _ops()
+    x = _rand((rows, cin), 191).to(dtype)
+    w = (_rand((cout, cin), 192) / math.sqrt(cin)).to(dtype)
+    b = _rand((cout,), 193) * 0.1
+    res = _rand((rows, cout), 194).to(dtype)
+    want = F.gelu(F.linear(F.silu(x.double()), w.double(), b.double())) + res.double()
+    ops.start_profile()
+    got = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), pre_act="silu", post_act="gelu", res=res.to(DEV))
+    names = [n for n, _, _ in ops.stop_profile()]
+    assert names and names[0].startswith("linear_rows"), names  # the small-row kernel, not the tiled convolution
+    _check(got, want, dtype, "small-row linear", extra=2.0)
+    plain = ops.linear(x.to(DEV).reshape(1, rows, cin), w.to(DEV), None)
+    _check(plain[0], F.linear(x.double(), w.double()), dtype, "small-row linear (plain, 3-D input)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(1, 8, 1, 32), (2, 8, 77, 32), (3, 2, 1000, 64), (1, 1, 4097, 256), (2, 4, 300, 16)],
+                         ids=lambda c: f"B{c[0]}H{c[1]}k{c[2]}d{c[3]}")
+def test_single_query_attention_over_a_kv_cache(case, dtype):
+    """One query per (batch, head) over the first Lk rows of a longer per-sample cache (batch stride != Lk * C): the decode kernel of
+    small_ops.hip behind gm_attention_forward."""
+    ops = _ops()
+    b, h, lk, dh = case
+    c = h * dh
+    q = _rand((b, 1, c), 201).to(dtype)
+    cache_k, cache_v = _rand((b, lk + 13, c), 202).to(dtype), _rand((b, lk + 13, c), 203).to(dtype)
+    scale = 1 / math.sqrt(dh)
+    want = R._mha(q.double(), cache_k[:, :lk].double(), cache_v[:, :lk].double(), h, scale)
+    kd, vd = cache_k.to(DEV), cache_v.to(DEV)
+    got = ops.attention(q.to(DEV), kd[:, :lk], vd[:, :lk], h, scale)
+    _check(got, want, dtype, "decode attention")
+
+
 def test_attention_softmax_is_stable_for_large_scores():
     ops = _ops()
     q = _rand((1, 70, 32), 61) * 30
