@@ -98,6 +98,7 @@ PROTOTYPES = {
     "gm_transformer_decode_step": (C.c_int, [C.POINTER(GmDecodeDesc), c_vp]),
     "gm_embed_tokens": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_sample_probs": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_sample_index": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, c_vp, c_vp]),
     "gm_token_log_prob": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, c_vp]),
     "gm_attention_workspace_bytes": (c_ll, [C.POINTER(GmAttnDesc)]),
     "gm_attention_forward": (C.c_int, [C.POINTER(GmAttnDesc), c_vp]),

@@ -1,7 +1,7 @@
 // One autoregressive decoding step of the decoder-only transformer, issued from native code.
 //
-// A token step is ~110 tiny launches (per block: LayerNorm, stacked q|k|v GEMM, two KV-cache row copies, 1 x t attention, out_proj +
-// residual, LayerNorm, MLP up + GELU, MLP down + residual).  Issued one by one through the Python binding it cost 2.7 ms per token
+// A token step is 62 tiny launches (per block: LayerNorm + stacked q|k|v GEMM writing k, v into the KV caches, 1 x t attention, out_proj +
+// residual, LayerNorm + MLP up + GELU, MLP down + residual).  Issued one by one through the Python binding it cost 2.7 ms per token
 // (20 us of interpreter + descriptor work per launch) -- no faster than the reference's recompute-the-prefix loop on this model
 // size.  This entry point walks the block table in C++ and enqueues the same kernels back to back
 // (reference semantics: networks/nets/transformer.py:98-106, blocks/transformerblock.py:86-91, blocks/selfattention.py:98-147).
@@ -49,6 +49,10 @@ extern "C" long long gm_decode_scratch_bytes(int B, int C, int M, int dtype) {
 extern "C" int gm_linear_rows(const void* x, long long x_ld, const void* w, const float* bias, const void* res, long long res_ld, void* y,
                               long long y_ld, int rows, int cin, int cout, int pre_act, int post_act, int dtype, void* stream);
 
+extern "C" int gm_linear_rows_ln(const void* x, long long x_ld, const float* ln_g, const float* ln_b, float ln_eps, const void* w,
+                                 const float* bias, void* y, long long y_ld, void* y1, void* y2, long long y12_ld, int split, int rows, int cin,
+                                 int cout, int post_act, int dtype, void* stream);
+
 // y[rows][cout] = act(x[rows][cin] W^T + b) (+ res) through the small-row GEMM kernel (small_ops.hip)
 static int linear_rows(const void* x, long long x_ld, const void* w, const float* b, const void* res, long long res_ld, void* y, long long y_ld,
                        int rows, int cin, int cout, int post_act, int dtype, void* stream) {
@@ -78,13 +82,10 @@ extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) 
   for (int i = 0; i < d.depth; ++i) {
     const GmDecodeBlock& b = d.blocks[i];
     GM_REQUIRE(b.w_qkv && b.w_o && b.w_1 && b.w_2 && b.k_cache && b.v_cache, "null block parameter");
-    if ((rc = gm_layernorm(x0, C, h, C, b.ln1_g, b.ln1_b, d.B, C, d.ln_eps, d.dtype, stream))) return rc;
-    if ((rc = linear_rows(h, C, b.w_qkv, b.b_qkv, nullptr, 0, qkv, 3 * C, d.B, C, 3 * C, 0, d.dtype, stream))) return rc;
-    // this token's key / value rows -> cache row `pos` of every sequence (row r of the copy = sequence r)
-    if ((rc = gm_copy_channels(qkv + (long long)C * es, 3 * C, d.dtype, reinterpret_cast<char*>(b.k_cache) + (long long)d.pos * C * es,
-                               (long long)d.max_len * C, d.dtype, d.B, C, stream))) return rc;
-    if ((rc = gm_copy_channels(qkv + 2LL * C * es, 3 * C, d.dtype, reinterpret_cast<char*>(b.v_cache) + (long long)d.pos * C * es,
-                               (long long)d.max_len * C, d.dtype, d.B, C, stream))) return rc;
+    // LayerNorm + stacked q | k | v projection in one launch; the key / value rows land directly in cache row `pos` of every sequence
+    if ((rc = gm_linear_rows_ln(x0, C, b.ln1_g, b.ln1_b, d.ln_eps, b.w_qkv, b.b_qkv, qkv, 3 * C,
+                                reinterpret_cast<char*>(b.k_cache) + (long long)d.pos * C * es, reinterpret_cast<char*>(b.v_cache) + (long long)d.pos * C * es,
+                                (long long)d.max_len * C, C, d.B, C, 3 * C, 0, d.dtype, stream))) return rc;
     GmAttnDesc at = {};
     at.q = qkv; at.q_ld = 3 * C;
     at.k = b.k_cache; at.k_ld = C; at.k_bs = (long long)d.max_len * C;
@@ -94,8 +95,8 @@ extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) 
     at.scale = scale; at.dtype = d.dtype;
     if ((rc = gm_attention_forward(&at, stream))) return rc;
     if ((rc = linear_rows(y, C, b.w_o, b.b_o, x0, C, x1, C, d.B, C, C, 0, d.dtype, stream))) return rc;
-    if ((rc = gm_layernorm(x1, C, h, C, b.ln3_g, b.ln3_b, d.B, C, d.ln_eps, d.dtype, stream))) return rc;
-    if ((rc = linear_rows(h, C, b.w_1, b.b_1, nullptr, 0, a, d.M, d.B, C, d.M, 6, d.dtype, stream))) return rc;
+    if ((rc = gm_linear_rows_ln(x1, C, b.ln3_g, b.ln3_b, d.ln_eps, b.w_1, b.b_1, a, d.M, nullptr, nullptr, 0, 0, d.B, C, d.M, 6, d.dtype,
+                                stream))) return rc;
     if ((rc = linear_rows(a, d.M, b.w_2, b.b_2, x1, C, x0, C, d.B, d.M, C, 0, d.dtype, stream))) return rc;
   }
   return linear_rows(x0, C, d.w_logits, d.b_logits, nullptr, 0, d.logits, d.num_tokens, d.B, C, d.num_tokens, 0, d.dtype, stream);

@@ -400,7 +400,8 @@ class VQVAETransformerInferer(Inferer):
     re-runs the whole prefix for every new token; here a token is one row through each GEMM + one 1 x t attention per block, and
     the sampling head (temperature, top-k, softmax, BOS mask) is one fused kernel.  When the prefix outgrows `max_seq_len` the
     reference's window slides and the absolute positions restart, so those (few) steps recompute the cropped window like the
-    reference does.  The categorical draw itself is torch.multinomial on the device, as in the reference."""
+    reference does.  The categorical draw is an inverse-CDF kernel fed by torch's device generator (same distribution as the reference's
+    torch.multinomial, without its per-call device -> host validation read)."""
 
     def __init__(self) -> None:
         pass
@@ -452,7 +453,7 @@ class VQVAETransformerInferer(Inferer):
                 idx_cond = latent_seq if n <= transformer_model.max_seq_len else latent_seq[:, -transformer_model.max_seq_len:]
                 logits = transformer_model(x=idx_cond.contiguous(), context=conditioning)[:, -1, :]
             probs = ops.sample_probs(logits, temperature, top_k, bos)
-            idx_next = torch.multinomial(probs, num_samples=1)
+            idx_next = ops.sample_index(probs)  # inverse-CDF draw on the device; torch.multinomial would drain the pipeline per token
             latent_seq = torch.cat((latent_seq, idx_next), dim=1)
         latent_seq = latent_seq[:, 1:]
         revert = torch.as_tensor(ordering.get_revert_sequence_ordering().copy(), device=latent_seq.device)

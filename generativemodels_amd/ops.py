@@ -837,6 +837,18 @@ def sample_probs(logits: torch.Tensor, temperature: float, top_k: Optional[int],
     return probs
 
 
+def sample_index(probs: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """One categorical draw per row of fp32 (rows, V) probabilities (need not be normalised) -> int64 (rows, 1).  The uniform numbers
+    come from torch's device generator; unlike torch.multinomial nothing is read back to the host."""
+    require_device(probs)
+    if probs.dim() != 2 or probs.dtype != torch.float32 or not probs.is_contiguous():
+        raise ValueError("sample_index expects contiguous fp32 (rows, V) probabilities")
+    u = torch.rand(probs.shape[0], device=probs.device, generator=generator)
+    out = torch.empty((probs.shape[0], 1), dtype=torch.long, device=probs.device)
+    check(lib().gm_sample_index(probs.data_ptr(), probs.shape[0], probs.shape[1], u.data_ptr(), out.data_ptr(), _stream()), "gm_sample_index")
+    return out
+
+
 def token_log_prob(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """log(softmax(logits)[target]) for (rows, V) logits and (rows,) int64 targets -> fp32 (rows,)."""
     require_device(logits, target)

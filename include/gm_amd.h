@@ -195,6 +195,9 @@ int gm_embed_tokens(const long long* indices, const void* token_weight, const vo
  * logits: [rows][ld >= V] in dtype, probs: fp32 [rows][V] */
 int gm_sample_probs(const void* logits, long long ld, float* probs, long long rows, int V, float temperature, int top_k, int bos_index,
                     int dtype, void* stream);
+/* one categorical draw per row by inverse CDF: out[row] = min{ j : sum_{i<=j} probs[row][i] >= u[row] * sum_i probs[row][i] } with u
+ * uniform in [0, 1) from the caller's generator (the draw of inferer.py:1235 without torch.multinomial's device -> host validation) */
+int gm_sample_index(const float* probs, long long rows, int V, const float* u, long long* out, void* stream);
 /* out[row] = log(softmax(logits[row])[target[row]])  (inferer.py:1290-1296, 1316) */
 int gm_token_log_prob(const void* logits, long long ld, const long long* target, float* out, long long rows, int V, int dtype,
                       void* stream);

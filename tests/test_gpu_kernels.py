@@ -519,6 +519,28 @@ def test_single_query_attention_over_a_kv_cache(case, dtype):
     _check(got, want, dtype, "decode attention")
 
 
+def test_categorical_sampling_kernel():
+    """gm_sample_index: inverse-CDF draws -- degenerate rows are exact, unnormalised rows with zeros (top-k crop, BOS mask) never return a
+    zero-probability index, and empirical frequencies over 2^18 draws match the distribution."""
+    ops = _ops()
+    onehot = torch.zeros((5, 37))
+    for r, j in enumerate([0, 36, 17, 5, 20]):
+        onehot[r, j] = 0.3 + r
+    assert ops.sample_index(onehot.to(DEV)).flatten().tolist() == [0, 36, 17, 5, 20]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    p = torch.tensor([0.0, 0.5, 0.0, 0.25, 0.125, 0.0, 0.125, 0.0]) * 3.0  # unnormalised, with holes
+    n = 1 << 18
+    idx = ops.sample_index(p.to(DEV).repeat(n, 1).contiguous(), generator=g).flatten().cpu()
+    freq = torch.bincount(idx, minlength=8).double() / n
+    want = (p / p.sum()).double()
+    assert torch.all(freq[want == 0] == 0)
+    assert (freq - want).abs().max().item() < 5e-3, freq
+    wide = torch.rand((64, 1000), generator=torch.Generator().manual_seed(4))
+    wide[:, ::3] = 0
+    got = ops.sample_index(wide.to(DEV), generator=g).flatten().cpu()
+    assert torch.all(wide[torch.arange(64), got] > 0)
+
+
 def test_attention_softmax_is_stable_for_large_scores():
     ops = _ops()
     q = _rand((1, 70, 32), 61) * 30
