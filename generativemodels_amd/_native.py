@@ -49,7 +49,7 @@ class GmDecodeDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("M", C.c_int), ("heads", C.c_int), ("depth", C.c_int), ("max_len", C.c_int),
                 ("num_tokens", C.c_int), ("dtype", C.c_int), ("ln_eps", C.c_float), ("pos", C.c_int), ("tokens", c_vp),
                 ("tok_emb", c_vp), ("pos_emb", c_vp), ("blocks", C.POINTER(GmDecodeBlock)), ("w_logits", c_vp), ("b_logits", c_vp),
-                ("logits", c_vp), ("scratch", c_vp), ("scratch_bytes", c_ll)]
+                ("logits", c_vp), ("scratch", c_vp), ("scratch_bytes", c_ll), ("pos_dev", c_vp)]
 
 
 class GmAttnDesc(C.Structure):
@@ -95,6 +95,7 @@ PROTOTYPES = {
     "gm_attention_max_head_dim": (C.c_int, []),
     "gm_linear_rows": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_decode_scratch_bytes": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gm_decode_advance": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, c_ll, c_vp]),
     "gm_transformer_decode_step": (C.c_int, [C.POINTER(GmDecodeDesc), c_vp]),
     "gm_embed_tokens": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_sample_probs": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_vp]),

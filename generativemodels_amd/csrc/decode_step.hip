@@ -8,8 +8,9 @@
 #include "attn_common.h"
 #include "conv_common.h"
 
-extern "C" int gm_embed_tokens(const long long* indices, const void* token_weight, const void* position_weight, void* out, long long batch,
-                               int seq_len, int C, int pos0, int num_tokens, int max_positions, int dtype, void* stream);
+extern "C" int gm_embed_tokens_dev(const long long* indices, const void* token_weight, const void* position_weight, void* out, long long batch,
+                                   int seq_len, int C, int pos0, int num_tokens, int max_positions, int dtype, const int* pos_dev, void* stream);
+extern "C" int gm_attention_decode_dev(const GmAttnDesc* dp, const int* lk_dev, void* stream);
 extern "C" int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta, long long rows,
                             int C, float eps, int dtype, void* stream);
 extern "C" int gm_copy_channels(const void* src, long long src_ld, int src_dtype, void* dst, long long dst_ld, int dst_dtype,
@@ -36,6 +37,7 @@ struct GmDecodeDesc {
   const void* w_logits; const float* b_logits;
   void* logits;                           // [B][num_tokens] in dtype
   void* scratch; long long scratch_bytes; // gm_decode_scratch_bytes(B, C, M, dtype)
+  const int* pos_dev;                     // optional: the position is read from device memory at run time (HIP-graph replay); `pos` is ignored
 };
 
 static long long elt(int dtype) { return dtype == GM_F32 ? 4 : 2; }
@@ -51,7 +53,7 @@ extern "C" int gm_linear_rows(const void* x, long long x_ld, const void* w, cons
 
 extern "C" int gm_linear_rows_ln(const void* x, long long x_ld, const float* ln_g, const float* ln_b, float ln_eps, const void* w,
                                  const float* bias, void* y, long long y_ld, void* y1, void* y2, long long y12_ld, int split, int rows, int cin,
-                                 int cout, int post_act, int dtype, void* stream);
+                                 int cout, int post_act, int dtype, const int* off_dev, long long off_mul, void* stream);
 
 // y[rows][cout] = act(x[rows][cin] W^T + b) (+ res) through the small-row GEMM kernel (small_ops.hip)
 static int linear_rows(const void* x, long long x_ld, const void* w, const float* b, const void* res, long long res_ld, void* y, long long y_ld,
@@ -64,7 +66,8 @@ extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) 
   const GmDecodeDesc& d = *dp;
   GM_REQUIRE(d.tokens && d.tok_emb && d.pos_emb && d.blocks && d.w_logits && d.logits && d.scratch, "null pointer");
   GM_REQUIRE(d.B > 0 && d.C > 0 && d.M > 0 && d.heads > 0 && d.C % d.heads == 0 && d.depth > 0, "bad geometry");
-  GM_REQUIRE(d.pos >= 0 && d.pos < d.max_len, "position outside the context window");
+  GM_REQUIRE(d.pos_dev || (d.pos >= 0 && d.pos < d.max_len), "position outside the context window");
+  const int hpos = d.pos_dev ? 0 : d.pos;  // host-side position (0 when the device supplies it)
   GM_REQUIRE(d.scratch_bytes >= gm_decode_scratch_bytes(d.B, d.C, d.M, d.dtype), "scratch too small");
   const long long es = elt(d.dtype);
   auto r = [](long long v) { return (v + 255) / 256 * 256; };
@@ -76,7 +79,7 @@ extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) 
   char* qkv = s; s += r(3LL * d.B * d.C * es);
   char* a = s;
   const int C = d.C;
-  int rc = gm_embed_tokens(d.tokens, d.tok_emb, d.pos_emb, x0, d.B, 1, C, d.pos, d.num_tokens, d.max_len, d.dtype, stream);
+  int rc = gm_embed_tokens_dev(d.tokens, d.tok_emb, d.pos_emb, x0, d.B, 1, C, hpos, d.num_tokens, d.max_len, d.dtype, d.pos_dev, stream);
   if (rc) return rc;
   const float scale = 1.0f / sqrtf((float)(C / d.heads));
   for (int i = 0; i < d.depth; ++i) {
@@ -84,19 +87,23 @@ extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) 
     GM_REQUIRE(b.w_qkv && b.w_o && b.w_1 && b.w_2 && b.k_cache && b.v_cache, "null block parameter");
     // LayerNorm + stacked q | k | v projection in one launch; the key / value rows land directly in cache row `pos` of every sequence
     if ((rc = gm_linear_rows_ln(x0, C, b.ln1_g, b.ln1_b, d.ln_eps, b.w_qkv, b.b_qkv, qkv, 3 * C,
-                                reinterpret_cast<char*>(b.k_cache) + (long long)d.pos * C * es, reinterpret_cast<char*>(b.v_cache) + (long long)d.pos * C * es,
-                                (long long)d.max_len * C, C, d.B, C, 3 * C, 0, d.dtype, stream))) return rc;
+                                reinterpret_cast<char*>(b.k_cache) + (long long)hpos * C * es, reinterpret_cast<char*>(b.v_cache) + (long long)hpos * C * es,
+                                (long long)d.max_len * C, C, d.B, C, 3 * C, 0, d.dtype, d.pos_dev, C, stream))) return rc;
     GmAttnDesc at = {};
     at.q = qkv; at.q_ld = 3 * C;
     at.k = b.k_cache; at.k_ld = C; at.k_bs = (long long)d.max_len * C;
     at.v = b.v_cache; at.v_ld = C; at.v_bs = (long long)d.max_len * C;
     at.o = y; at.o_ld = C;
-    at.B = d.B; at.H = d.heads; at.Lq = 1; at.Lk = d.pos + 1; at.dh = C / d.heads;
+    at.B = d.B; at.H = d.heads; at.Lq = 1; at.Lk = d.pos_dev ? d.max_len : d.pos + 1; at.dh = C / d.heads;
     at.scale = scale; at.dtype = d.dtype;
-    if ((rc = gm_attention_forward(&at, stream))) return rc;
+    if (d.pos_dev) {
+      GM_REQUIRE(gm_attention_decode_dev(&at, d.pos_dev, stream) == 1, "context window too long for the single-query attention kernel");
+    } else if ((rc = gm_attention_forward(&at, stream))) {
+      return rc;
+    }
     if ((rc = linear_rows(y, C, b.w_o, b.b_o, x0, C, x1, C, d.B, C, C, 0, d.dtype, stream))) return rc;
     if ((rc = gm_linear_rows_ln(x1, C, b.ln3_g, b.ln3_b, d.ln_eps, b.w_1, b.b_1, a, d.M, nullptr, nullptr, 0, 0, d.B, C, d.M, 6, d.dtype,
-                                stream))) return rc;
+                                nullptr, 0, stream))) return rc;
     if ((rc = linear_rows(a, d.M, b.w_2, b.b_2, x1, C, x0, C, d.B, d.M, C, 0, d.dtype, stream))) return rc;
   }
   return linear_rows(x0, C, d.w_logits, d.b_logits, nullptr, 0, d.logits, d.num_tokens, d.B, C, d.num_tokens, 0, d.dtype, stream);

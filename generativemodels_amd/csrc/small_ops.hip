@@ -14,6 +14,7 @@
 struct LinearRowsExtra {
   const float* ln_g; const float* ln_b; float ln_eps;  // ln_g != null: x <- LayerNorm(x) * g + b before the GEMM
   void* y1; void* y2; long long y12_ld; int split;     // split > 0: channels [split, 2*split) -> y1, [2*split, 3*split) -> y2 (row pitch y12_ld)
+  const int* off_dev; long long off_mul;               // y1 / y2 are advanced by (*off_dev) * off_mul elements at run time (KV-cache row = position)
 };
 
 template <typename T>
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
       v = conv_post_act(v, post_act);
       if (res) v += ElemIO<T>::ld(res + (long long)row * res_ld + co);
       if (ex.split > 0 && co >= ex.split) {
-        T* dst = reinterpret_cast<T*>(co < 2 * ex.split ? ex.y1 : ex.y2);
+        T* dst = reinterpret_cast<T*>(co < 2 * ex.split ? ex.y1 : ex.y2) + (ex.off_dev ? (long long)(*ex.off_dev) * ex.off_mul : 0);
         ElemIO<T>::st(dst + (long long)row * ex.y12_ld + (co - (co < 2 * ex.split ? ex.split : 2 * ex.split)), v);
       } else {
         ElemIO<T>::st(y + (long long)row * y_ld + co, v);
@@ -148,10 +149,11 @@ extern "C" int gm_linear_rows(const void* x, long long x_ld, const void* w, cons
 // the decode step's fused forms: LayerNorm prologue; q | k | v projection writing k, v rows into the caches (internal to the library)
 extern "C" int gm_linear_rows_ln(const void* x, long long x_ld, const float* ln_g, const float* ln_b, float ln_eps, const void* w,
                                  const float* bias, void* y, long long y_ld, void* y1, void* y2, long long y12_ld, int split, int rows, int cin,
-                                 int cout, int post_act, int dtype, void* stream) {
+                                 int cout, int post_act, int dtype, const int* off_dev, long long off_mul, void* stream) {
   LinearRowsExtra ex = {};
   ex.ln_g = ln_g; ex.ln_b = ln_b; ex.ln_eps = ln_eps;
   ex.y1 = y1; ex.y2 = y2; ex.y12_ld = y12_ld; ex.split = split;
+  ex.off_dev = off_dev; ex.off_mul = off_mul;
   return linear_rows_launch(x, x_ld, w, bias, nullptr, 0, y, y_ld, rows, cin, cout, 0, post_act, dtype, ex, stream);
 }
 
@@ -161,10 +163,12 @@ extern "C" int gm_linear_rows_ln(const void* x, long long x_ld, const float* ln_
 #define DEC_MAX_KEYS 15360  // scores live in LDS (fp32): 60 KiB + query + scratch stay under the default 64 KiB dynamic limit
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const GmAttnDesc p) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(GmAttnDesc p, const int* __restrict__ lk_dev) {
+  const int lds_keys = p.Lk;       // the launch sized the score buffer for this many keys
+  if (lk_dev) p.Lk = *lk_dev + 1;  // decode-graph replay: keys 0 .. position (LDS was sized for the descriptor's Lk = the cache length)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sc = reinterpret_cast<float*>(smem);            // [Lk] scores, then probabilities
-  float* qs = sc + (((p.Lk > 2048 ? p.Lk : 2048) + 3) & ~3);  // [dh] query (fp32); the score region doubles as the [KL][dh] partial table
+  float* qs = sc + ((((lk_dev ? lds_keys : p.Lk) > 2048 ? (lk_dev ? lds_keys : p.Lk) : 2048) + 3) & ~3);  // [dh] query (fp32); the score region doubles as the [KL][dh] partial table
   float* red = qs + p.dh;                                 // [256] reduction scratch / [slices][dh] partial outputs
   const int tid = threadIdx.x;
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
@@ -260,18 +264,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const GmAttnDesc p) {
   }
 }
 
-// returns 1 if launched, 0 if the geometry is not a single-query decode this kernel covers
-extern "C" int gm_attention_decode_try(const GmAttnDesc* dp, void* stream) {
+// returns 1 if launched, 0 if the geometry is not a single-query decode this kernel covers.  lk_dev != null: attend keys
+// 0 .. *lk_dev (read on the device at run time); d.Lk is then the upper bound the LDS buffer is sized for.
+extern "C" int gm_attention_decode_dev(const GmAttnDesc* dp, const int* lk_dev, void* stream) {
   const GmAttnDesc& d = *dp;
   if (d.Lq != 1 || d.Lk > DEC_MAX_KEYS || d.dh > 256 || d.Lk < 1) return 0;
   if (d.dtype != GM_F32 && d.dtype != GM_BF16) return 0;
   hipStream_t st = (hipStream_t)stream;
   const size_t smem = (size_t)((((d.Lk > 2048 ? d.Lk : 2048) + 3) & ~3) + d.dh + 256) * sizeof(float);
-  if (d.dtype == GM_F32) attn_decode_kernel<float><<<d.B * d.H, 256, smem, st>>>(d);
-  else attn_decode_kernel<bf16_raw><<<d.B * d.H, 256, smem, st>>>(d);
+  if (d.dtype == GM_F32) attn_decode_kernel<float><<<d.B * d.H, 256, smem, st>>>(d, lk_dev);
+  else attn_decode_kernel<bf16_raw><<<d.B * d.H, 256, smem, st>>>(d, lk_dev);
   return 1;
 }
 
+extern "C" int gm_attention_decode_try(const GmAttnDesc* dp, void* stream) { return gm_attention_decode_dev(dp, nullptr, stream); }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // One categorical draw per row by inverse CDF: idx = min{ j : sum_{i <= j} p_i >= u * sum_i p_i }, u uniform in [0, 1) supplied by

@@ -9,7 +9,8 @@
 template <typename T>
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __restrict__ idx, const T* __restrict__ tok,
                                                           const T* __restrict__ pos, T* __restrict__ out, long long rows, int T_len,
-                                                          int C, int pos0, int num_tokens, int max_pos) {
+                                                          int C, int pos0, int num_tokens, int max_pos, const int* __restrict__ pos_dev) {
+  if (pos_dev) pos0 = *pos_dev;  // decode-graph replay: the position lives on the device
   const long long total = rows * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / C;
@@ -22,8 +23,17 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __re
   }
 }
 
+extern "C" int gm_embed_tokens_dev(const long long* indices, const void* token_weight, const void* position_weight, void* out, long long batch,
+                                   int seq_len, int C, int pos0, int num_tokens, int max_positions, int dtype, const int* pos_dev, void* stream);
+
 extern "C" int gm_embed_tokens(const long long* indices, const void* token_weight, const void* position_weight, void* out,
                                long long batch, int seq_len, int C, int pos0, int num_tokens, int max_positions, int dtype, void* stream) {
+  return gm_embed_tokens_dev(indices, token_weight, position_weight, out, batch, seq_len, C, pos0, num_tokens, max_positions, dtype, nullptr, stream);
+}
+
+// pos_dev != null: the first position is read from device memory at run time (pos0 is only validated)
+extern "C" int gm_embed_tokens_dev(const long long* indices, const void* token_weight, const void* position_weight, void* out, long long batch,
+                                   int seq_len, int C, int pos0, int num_tokens, int max_positions, int dtype, const int* pos_dev, void* stream) {
   GM_REQUIRE(indices && token_weight && position_weight && out, "null pointer");
   GM_REQUIRE(seq_len > 0 && C > 0 && pos0 >= 0 && pos0 + seq_len <= max_positions, "positions exceed the embedding table");
   const long long rows = batch * seq_len;
@@ -33,10 +43,10 @@ extern "C" int gm_embed_tokens(const long long* indices, const void* token_weigh
   if (g > 4096) g = 4096;
   if (dtype == GM_F32)
     embed_tokens_kernel<float><<<(int)g, 256, 0, st>>>(indices, (const float*)token_weight, (const float*)position_weight, (float*)out, rows,
-                                                       seq_len, C, pos0, num_tokens, max_positions);
+                                                       seq_len, C, pos0, num_tokens, max_positions, pos_dev);
   else if (dtype == GM_BF16)
     embed_tokens_kernel<bf16_raw><<<(int)g, 256, 0, st>>>(indices, (const bf16_raw*)token_weight, (const bf16_raw*)position_weight,
-                                                          (bf16_raw*)out, rows, seq_len, C, pos0, num_tokens, max_positions);
+                                                          (bf16_raw*)out, rows, seq_len, C, pos0, num_tokens, max_positions, pos_dev);
   else
     GM_FAIL(-2, "unsupported dtype");
   GM_LAUNCH_CHECK();
@@ -146,5 +156,27 @@ extern "C" int gm_token_log_prob(const void* logits, long long ld, const long lo
     token_log_prob_kernel<bf16_raw><<<(unsigned)rows, 64, 0, st>>>((const bf16_raw*)logits, ld, target, out, V);
   else
     GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+// After a token has been drawn: append it to the sequence, make it the next step's input and advance the device-side position.
+//   seq[b][pos + 1] = idx[b]; tokens[b] = idx[b]; pos += 1      (the bookkeeping of inferer.py:1237-1239 kept on the device so that a
+// whole decode iteration -- step, sampling head, draw, this -- replays from one HIP graph)
+__global__ void decode_advance_kernel(int* __restrict__ pos, long long* __restrict__ tokens, const long long* __restrict__ idx,
+                                      long long* __restrict__ seq, int B, long long seq_ld) {
+  const int p = *pos;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const long long t = idx[b];
+    tokens[b] = t;
+    if (p + 1 < seq_ld) seq[(long long)b * seq_ld + p + 1] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *pos = p + 1;
+}
+
+extern "C" int gm_decode_advance(int* pos, long long* tokens, const long long* idx, long long* seq, int B, long long seq_ld, void* stream) {
+  GM_REQUIRE(pos && tokens && idx && seq, "null pointer");
+  if (B <= 0) return 0;
+  decode_advance_kernel<<<1, 64, 0, (hipStream_t)stream>>>(pos, tokens, idx, seq, B, seq_ld);
   GM_LAUNCH_CHECK();
 }

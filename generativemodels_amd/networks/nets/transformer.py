@@ -128,6 +128,22 @@ class DecoderOnlyTransformer(nn.Module):
         cache[0]["_native"] = tab
         return tab
 
+    def step_from_device_state(self, tokens: torch.Tensor, pos_dev: torch.Tensor, cache: list, logits: torch.Tensor) -> None:
+        """The native decode step with the position read from `pos_dev` (int32, 1 element, on the device) at run time and the logits
+        written into the caller's (B, num_tokens) buffer: every argument is a fixed device address, so the call can be captured into
+        a HIP graph and replayed once per token (VQVAETransformerInferer.sample).  No cross attention."""
+        if self.with_cross_attention:
+            raise ValueError("the graph-replayable step covers models without cross attention")
+        ops.require_device(tokens, pos_dev, logits)
+        if tokens.dtype != torch.long or pos_dev.dtype != torch.int32 or logits.dtype != self.to_logits.weight.dtype or not logits.is_contiguous():
+            raise TypeError("tokens int64, pos_dev int32, logits in the model dtype (contiguous)")
+        d = self._native_table(cache)["desc"]
+        d.tokens, d.logits, d.pos, d.pos_dev = tokens.data_ptr(), logits.data_ptr(), 0, pos_dev.data_ptr()
+        try:
+            check(lib().gm_transformer_decode_step(C.byref(d), ops._stream()), "gm_transformer_decode_step")
+        finally:
+            d.pos_dev = None
+
     def step(self, tokens: torch.Tensor, pos: int, cache: list, context: torch.Tensor | None = None) -> torch.Tensor:
         """Logits (B, num_tokens) for the token at position `pos` given `tokens` (B, 1) = that token and a cache holding positions
         0..pos-1; equal to forward(prefix)[:, -1] (pinned by tests)."""

@@ -849,6 +849,15 @@ def sample_index(probs: torch.Tensor, generator: Optional[torch.Generator] = Non
     return out
 
 
+def decode_advance(pos_dev: torch.Tensor, tokens: torch.Tensor, idx: torch.Tensor, seq: torch.Tensor) -> None:
+    """seq[:, pos + 1] = idx; tokens[:] = idx; pos += 1, all on the device (the sampling loop's bookkeeping, graph-replayable)."""
+    require_device(pos_dev, tokens, idx, seq)
+    if pos_dev.dtype != torch.int32 or any(t.dtype != torch.long for t in (tokens, idx, seq)) or not seq.is_contiguous():
+        raise TypeError("pos_dev int32; tokens, idx, seq int64 (seq contiguous)")
+    check(lib().gm_decode_advance(pos_dev.data_ptr(), tokens.data_ptr(), idx.data_ptr(), seq.data_ptr(), seq.shape[0], seq.shape[1], _stream()),
+          "gm_decode_advance")
+
+
 def token_log_prob(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """log(softmax(logits)[target]) for (rows, V) logits and (rows,) int64 targets -> fp32 (rows,)."""
     require_device(logits, target)

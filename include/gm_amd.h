@@ -231,9 +231,12 @@ typedef struct GmDecodeDesc {
   const void* w_logits; const float* b_logits;
   void* logits;                      /* [B][num_tokens], dtype */
   void* scratch; long long scratch_bytes;
+  const int* pos_dev;                /* optional: position read from device memory at run time (for HIP-graph replay); `pos` is then ignored */
 } GmDecodeDesc;
 long long gm_decode_scratch_bytes(int B, int C, int M, int dtype);
 int gm_transformer_decode_step(const GmDecodeDesc* d, void* stream);
+/* after a draw: seq[b][*pos + 1] = idx[b]; tokens[b] = idx[b]; *pos += 1 (inferer.py:1237-1239 kept on the device) */
+int gm_decode_advance(int* pos, long long* tokens, const long long* idx, long long* seq, int B, long long seq_ld, void* stream);
 
 /* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */
 int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long long* indices, long long tokens,

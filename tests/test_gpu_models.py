@@ -402,6 +402,8 @@ def test_transformer_and_vqvae_transformer_inferer_match_reference():
     _fp32_close(inf.get_likelihood(_dev(i["x"]), vq, tr, order), i["likelihood"], "transformer likelihood")
     img = inf.sample((4, 4), torch.full((2, 1), 16, device=DEV), vq, tr, order, top_k=1, verbose=False)
     _fp32_close(img, i["greedy_image"], "greedy sample (KV cache)")
+    img_g = VQVAETransformerInferer(use_hip_graph=True).sample((4, 4), torch.full((2, 1), 16, device=DEV), vq, tr, order, top_k=1, verbose=False)
+    _fp32_close(img_g, i["greedy_image"], "greedy sample (KV cache, one HIP-graph replay per token, device-side position)")
     # the sampling head against the oracle on the teacher-forced logits: temperature / top-k variants incl. ties and k >= V
     logits = i["logits"].reshape(-1, i["logits"].shape[-1])
     for temp, k in [(1.0, None), (0.7, 5), (1.3, 1), (1.0, 17), (2.0, 40)]:
