@@ -134,7 +134,16 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_DEBUG_SYNC = bool(os.environ.get("GM_DEBUG_SYNC"))  # synchronise after every native call and name the one that faulted
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().gm_last_error()
         raise RuntimeError(f"libgmamd {what} failed (code {rc}): {msg.decode() if msg else '?'}")
+    if _DEBUG_SYNC:
+        import torch
+
+        if not torch.cuda.is_current_stream_capturing():
+            print(f"[gm] {what}", flush=True)
+            torch.cuda.synchronize()
