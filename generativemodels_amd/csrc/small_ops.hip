@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
   const bool row_ok = row < rows;
   const int nchunks = (cin + BK - 1) / BK;
   const T* wrow = w + ((long long)(co0 + l15)) * BK + q * VECW;      // + chunk * cout_pad * BK
-  const T* xrow = x + (long long)(row_ok ? row : 0) * x_ld + q * VECW;  // + chunk * BK
+  const T* xrow = x + (long long)(row_ok ? row : 0) * x_ld + q * VECW;  // + chunk * BK; only dereferenced under its `ok` guard
   // ---- LayerNorm statistics of this lane's row: the 4 lanes sharing l15 cover the row between them (two passes: mean, then the
   //      centred second moment, like the reference's fp32 computation) ------------------------------------------------------------
   float mean = 0.f, rstd = 1.f;
@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
       const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;  // clamped: the duplicate is discarded below
       wf[u] = *reinterpret_cast<const uint4*>(wrow + (long long)c * cout_pad * BK);
       const bool ok = row_ok & (c * BK + q * VECW + VECW <= cin);  // host: cin % VECW == 0
-      const uint4 v = *reinterpret_cast<const uint4*>(xrow + (ok ? c * BK : 0));
+      // masked lanes read the first vector of the tensor: xrow + 0 is q * VECW elements into the row, which lies beyond a row (and, in
+      // the last row, beyond the allocation) whenever cin < 4 * VECW -- a faulting read even though its value is discarded
+      const uint4 v = *reinterpret_cast<const uint4*>(ok ? xrow + c * BK : x);
       xf[u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
     }
 #pragma unroll

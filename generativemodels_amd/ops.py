@@ -439,7 +439,15 @@ def fuse_gn_prologue(x: torch.Tensor) -> bool:
         return True
     if GN_APPLY_POLICY == "pass":
         return False
-    return not (x.dtype == torch.bfloat16 and x.numel() >= (1 << 22) and x.shape[-1] % 8 == 0)
+    if x.dtype != torch.bfloat16 or x.shape[-1] % 8 != 0:
+        return True
+    if x.numel() >= (1 << 22):
+        return False
+    # small 3-D tensors whose convolution the LDS-DMA kernel covers (C % 32 == 0): below ~16^3 voxels the prologue-fused kernels are
+    # serial chains of 200+ barriers per work-group (52-172 us, tools/bench_conv_small.py) while gn_apply (launch-bound, 16 us) + the
+    # LDS-DMA kernel take 43-64 us; in between (32^3 x 64) the fused kernel still wins (33 vs 41 us)
+    vox = x.numel() // max(x.shape[0] * x.shape[-1], 1)
+    return not (x.dim() == 5 and x.shape[-1] % 32 == 0 and vox <= 4096)
 
 
 def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
@@ -510,7 +518,7 @@ _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
 
 SMALL_LINEAR_ROWS = 64       # 1x1 "convolutions" over at most this many rows take gm_linear_rows
 DMA_CONV = True              # route eligible 3x3x3 convolutions through conv_dma.hip (cfg 11)
-DMA_CONV_MIN_VOXELS = 1 << 12
+DMA_CONV_MIN_VOXELS = 1 << 8
 LDS_SOFT_LIMIT = 80 * 1024   # two workgroups per CU
 LDS_HARD_LIMIT = 160 * 1024
 
@@ -533,15 +541,17 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             order = [12] + order  # taps-as-K kernel of the 1..4-channel input convolutions
     if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
         order = ([15] if desc.sd == 2 else [11]) + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
-    if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups
-        order = [c for c in order if _cfg_tile(c)[0] <= 64] + [c for c in order if _cfg_tile(c)[0] > 64]
+    if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups (the LDS-DMA kernels stay first)
+        dma_first = [c for c in order if c in (11, 15)]
+        rest = [c for c in order if c not in (11, 15)]
+        order = dma_first + [c for c in rest if _cfg_tile(c)[0] <= 64] + [c for c in rest if _cfg_tile(c)[0] > 64]
     best = None
     for cfg in order:
         bm, _ = _cfg_tile(cfg)
         tb = _tile_bits_fast if cfg >= 5 else _tile_bits
         bits = tb(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
-        if cfg == 16:
-            bits = [3, 2, 4]  # the 16-wave LDS-DMA variant is built for 8x4x16 tiles
+        if cfg in (11, 14, 15, 16):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
+            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy

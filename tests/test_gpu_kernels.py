@@ -502,6 +502,27 @@ def test_small_row_linear_kernel(rows, cin, cout, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_row_linear_reads_stay_inside_a_narrow_operand(dtype):
+    """A [rows, cin] operand narrower than one MFMA K step (cin = one 16-byte vector: the cross-attention context projections of a
+    small conditioned UNet) placed in the LAST bytes of its device allocation: masked lanes must not read past the row.  (Such a read
+    is discarded, so no value test sees it -- it surfaced as an intermittent `Memory access fault` one test later.)"""
+    ops = _ops()
+    cin = 16 // torch.empty(0, dtype=dtype).element_size()
+    rows, cout = 5, 24
+    arena = torch.empty(20 << 20, dtype=torch.uint8, device=DEV)  # a whole allocator segment of its own
+    x_host = _rand((rows, cin), 195).to(dtype)
+    x = arena.view(dtype)[-rows * cin:].view(rows, cin)
+    x.copy_(x_host)
+    w = (_rand((cout, cin), 196) / math.sqrt(cin)).to(dtype)
+    ops.start_profile()
+    got = ops.linear(x, w.to(DEV), None)
+    names = [n for n, _, _ in ops.stop_profile()]
+    assert names and names[0].startswith("linear_rows"), names
+    torch.cuda.synchronize()
+    _check(got, F.linear(x_host.double(), w.double()), dtype, "small-row linear at the end of an allocation")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(1, 8, 1, 32), (2, 8, 77, 32), (3, 2, 1000, 64), (1, 1, 4097, 256), (2, 4, 300, 16)],
                          ids=lambda c: f"B{c[0]}H{c[1]}k{c[2]}d{c[3]}")
 def test_single_query_attention_over_a_kv_cache(case, dtype):

@@ -1,0 +1,34 @@
+"""GPU: per-launch times of one forward of the C3 latent UNet (1x4x32^3, attention at levels 1 and 2) -- the launch-latency-bound part of the
+latent-diffusion sample.   usage: python tools/layer_times_c3.py"""
+import os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bench import rerandomize_zero_params
+from generativemodels_amd import ops
+from generativemodels_amd.networks.nets import DiffusionModelUNet
+dev, dt = "cuda", torch.bfloat16
+torch.manual_seed(0)
+unet = DiffusionModelUNet(spatial_dims=3, in_channels=4, out_channels=4, num_channels=(64, 128, 256), attention_levels=(False, True, True),
+                          num_res_blocks=2, num_head_channels=(0, 128, 256)).eval()
+unet.load_state_dict(rerandomize_zero_params({k: v.clone() for k, v in unet.state_dict().items()}))
+unet = unet.to(dev, dt)
+x = torch.randn((1, 4, 32, 32, 32), generator=torch.Generator().manual_seed(7)).to(dev, dt)
+t = torch.tensor([500.0], device=dev)
+for _ in range(3):
+    unet(x, t)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    unet(x, t)
+e1.record(); torch.cuda.synchronize()
+print("forward %.3f ms (eager, 10 runs)" % (e0.elapsed_time(e1) / 10))
+ops.start_profile(); unet(x, t); rec = ops.stop_profile()
+agg = collections.OrderedDict()
+for name, meta, ms in rec:
+    a = agg.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += ms
+tot = sum(v[1] for v in agg.values())
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"{v[1]:8.3f} ms  x{v[0]:3d}  avg {1e3 * v[1] / v[0]:7.1f} us  {k}")
+print("sum of profiled launches %.3f ms over %d launches" % (tot, sum(v[0] for v in agg.values())))
