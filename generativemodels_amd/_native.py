@@ -60,6 +60,13 @@ class GmAttnDesc(C.Structure):
                 ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll)]
 
 
+class GmWgradDesc(C.Structure):
+    _fields_ = [("x", c_vp), ("x_ld", c_ll), ("gy", c_vp), ("gy_ld", c_ll), ("dw", c_vp), ("workspace", c_vp), ("workspace_bytes", c_ll),
+                ("N", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Ds", C.c_int), ("Hs", C.c_int), ("Ws", C.c_int),
+                ("Do", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("kd", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("stride", C.c_int), ("pd", C.c_int), ("ph", C.c_int), ("pw", C.c_int), ("dtype", C.c_int), ("accumulate", C.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/gm_amd.h one to one (tests/test_abi.py checks the export list)
 PROTOTYPES = {
     "gm_abi_version": (C.c_int, []),
@@ -103,6 +110,13 @@ PROTOTYPES = {
     "gm_token_log_prob": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, c_vp]),
     "gm_attention_workspace_bytes": (c_ll, [C.POINTER(GmAttnDesc)]),
     "gm_attention_forward": (C.c_int, [C.POINTER(GmAttnDesc), c_vp]),
+    "gm_conv_wgrad_workspace_bytes": (c_ll, [C.POINTER(GmWgradDesc)]),
+    "gm_conv_wgrad": (C.c_int, [C.POINTER(GmWgradDesc), c_vp]),
+    "gm_gn_bwd_stats": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
+    "gm_gn_bwd_finalize": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_ll, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gm_gn_bwd_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, C.c_int, c_ll, C.c_int, C.c_int,
+                                  C.c_int, c_vp]),
+    "gm_stats_colsum": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
     "gm_vq_argmin": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_vq_gather_workspace_bytes": (c_ll, []),
     "gm_vq_gather": (C.c_int, [c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),

@@ -183,3 +183,24 @@ class ResnetBlock(nn.Module):
         if ops.fuse_gn_prologue(h):
             return self.conv2.run(h, pre=pre2, pre_act="silu", **fusion)
         return self.conv2.run(ops.gn_apply(h, pre2[0], pre2[1], "silu"), **fusion)
+
+    def run_train(self, x: torch.Tensor, temb: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same block with gradients: x an arena tensor, temb the [N, temb_channels] timestep embedding.
+        Native kernels in both directions (generativemodels_amd.autograd); the GroupNorm-apply passes are materialised because their
+        outputs are what the weight-gradient kernel contracts against.  The up / down resampling variants are not covered yet."""
+        from ... import autograd as A
+
+        if self.up or self.down:
+            raise NotImplementedError("run_train: resblock_updown blocks are not differentiable yet")
+        n1, n2 = self.norm1, self.norm2
+        h = A.group_norm_act(x, n1.weight, n1.bias, n1.num_groups, n1.eps, "silu")
+        row = None
+        if temb is not None:
+            # [N, temb] -> [N, Cout]: a handful of rows; the SiLU of this tiny vector is the one torch op of the block
+            row = A.linear(torch.nn.functional.silu(temb)[None], self.time_emb_proj.weight, self.time_emb_proj.bias)[0].float()
+        c1, c2 = self.conv1, self.conv2
+        h = A.conv(h, c1.conv.weight, c1.conv.bias, kernel=c1.kernel_size, stride=1, padding=c1.padding, rowvec=row)
+        h = A.group_norm_act(h, n2.weight, n2.bias, n2.num_groups, n2.eps, "silu")
+        shortcut = getattr(self, self.shortcut_name)
+        xs = A.conv(x, shortcut.conv.weight, shortcut.conv.bias, kernel=1) if isinstance(shortcut, ConvP) else x
+        return A.conv(h, c2.conv.weight, c2.conv.bias, kernel=c2.kernel_size, stride=1, padding=c2.padding, res=xs)

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _native as nat
-from ._native import GmAttnDesc, GmConvDesc, GmKlParams, GmStepParams, check, lib
+from ._native import GmAttnDesc, GmConvDesc, GmKlParams, GmStepParams, GmWgradDesc, check, lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 ACT = {"none": 0, "silu": 1, "relu": 2}
@@ -636,6 +636,9 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             raise ValueError("upsample and transposed are exclusive")
         d.in_mode = 2
         d.fd, d.fh, d.fw = s
+        if s == (1, 1, 1):
+            d.in_mode = 0  # no zero insertion: a plain convolution with the flipped, in/out-swapped panel (every fast kernel applies --
+            # this is the data gradient of the stride-1 convolutions)
         out_sp = tuple((src[i] - 1) * s[i] - plo[i] - phi[i] + dil[i] * (k[i] - 1) + opad[i] + 1 for i in range(3))
         conv_pad = tuple(dil[i] * (k[i] - 1) - plo[i] for i in range(3))
         conv_stride = (1, 1, 1)
@@ -757,6 +760,103 @@ def linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch
                 kw[key] = kw[key].unsqueeze(0)
         return conv(x.unsqueeze(0), weight, bias, kernel=1, **kw).squeeze(0)
     raise ValueError("linear expects (rows, C) or (N, L, C)")
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# backward kernels (wrapped as torch.autograd.Functions in generativemodels_amd/autograd.py)
+# ------------------------------------------------------------------------------------------------------------------------
+def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, kernel, stride=1, padding=0, out: Optional[torch.Tensor] = None,
+               accumulate: bool = False) -> torch.Tensor:
+    """Weight gradient of y = conv(x, W) (torch.nn.grad.conv*_weight): x, gy arena tensors (N, *spatial, C); returns fp32
+    [Cout, Cin, *kernel].  kernel 1 or 3 (the same on every spatial axis), stride 1 or 2, `padding` = low-side pad (the high side
+    is implied by gy's extents)."""
+    require_device(x, gy, out)
+    nsp = x.dim() - 2
+    if nsp < 1 or nsp > 3 or gy.dim() != x.dim() or gy.dtype != x.dtype or gy.shape[0] != x.shape[0]:
+        raise ValueError("conv_wgrad expects matching (N, *spatial, C) arena tensors")
+
+    def tup(v):
+        v = tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * nsp
+        if len(v) != nsp:
+            raise ValueError("per-axis argument has the wrong length")
+        return v
+
+    k, s_, p_ = tup(kernel), tup(stride), tup(padding)
+    if len(set(k)) != 1 or len(set(s_)) != 1:
+        raise ValueError("conv_wgrad: kernel and stride must be the same on every axis")
+    cin, cout = x.shape[-1], gy.shape[-1]
+    d = GmWgradDesc()
+    d.x, d.x_ld, d.gy, d.gy_ld = x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy)
+    d.N, d.Cin, d.Cout = x.shape[0], cin, cout
+    src = (1,) * (3 - nsp) + tuple(x.shape[1:-1])
+    dst = (1,) * (3 - nsp) + tuple(gy.shape[1:-1])
+    d.Ds, d.Hs, d.Ws = src
+    d.Do, d.Ho, d.Wo = dst
+    kk = (1,) * (3 - nsp) + k
+    if nsp == 1 and k[0] != 1:
+        raise ValueError("conv_wgrad: 1-D convolutions are covered for kernel 1 only")
+    d.kd, d.kh, d.kw = kk
+    d.stride = s_[0]
+    d.pd, d.ph, d.pw = (0,) * (3 - nsp) + p_
+    d.dtype, d.accumulate = dt_code(x.dtype), int(accumulate)
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing gradient tensor")
+        out = torch.empty((cout, cin, *k), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (cout, cin, *k) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("conv_wgrad: out must be a contiguous fp32 [Cout, Cin, *kernel] tensor")
+    d.dw = out.data_ptr()
+    ws_bytes = lib().gm_conv_wgrad_workspace_bytes(C.byref(d))
+    if ws_bytes < 0:
+        raise ValueError("conv_wgrad: geometry not covered (kernel 1 or 3, stride 1 or 2, channel counts multiples of a 16-byte vector)")
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
+    taps = math.prod(k)
+    nvo = gy.shape[0] * math.prod(gy.shape[1:-1])
+    _timed(f"conv_wgrad<{str(x.dtype).split('.')[-1]}>", dict(flops=2.0 * nvo * cin * cout * taps, bytes=float(x.element_size() * (x.numel() + gy.numel())),
+                                                          shape=f"{cin}->{cout} k{k} s{s_} out{tuple(gy.shape[1:-1])}"),
+           lambda: check(lib().gm_conv_wgrad(C.byref(d), _stream()), "gm_conv_wgrad"))
+    return out
+
+
+def bias_grad(gy: torch.Tensor, per_sample: bool = False) -> torch.Tensor:
+    """Column sums of an arena tensor over its voxels: fp32 [C] (a bias gradient) or, per sample, [N, C] (the gradient of the
+    per-sample row vector a convolution adds in its epilogue)."""
+    require_device(gy)
+    n, c = gy.shape[0], gy.shape[-1]
+    st = channel_stats(gy)
+    out = torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=gy.device)
+    check(lib().gm_stats_colsum(st.data_ptr(), n, c, out.data_ptr(), int(per_sample), _stream()), "gm_stats_colsum")
+    return out
+
+
+def gn_backward(x: torch.Tensor, gy: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, gamma: Optional[torch.Tensor],
+                groups: int, eps: float, act: str = "none", want_affine_grads: bool = True):
+    """Backward of y = act(GroupNorm(x)) given the forward (scale, shift) fp32 [N, C] tables: -> (dx, dgamma, dbeta) with the
+    parameter gradients fp32 [C] (None when not requested)."""
+    require_device(x, gy, scale, shift, gamma)
+    if gy.shape != x.shape or gy.dtype != x.dtype:
+        raise ValueError("gn_backward: gy must match x")
+    n, c = x.shape[0], x.shape[-1]
+    v = rows_of(x) // max(n, 1)
+    if tuple(scale.shape) != (n, c) or tuple(shift.shape) != (n, c) or scale.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+        raise ValueError("gn_backward: scale/shift must be matching fp32 [N, C] tables")
+    ss_ld = scale.stride(0) if n > 1 else max(scale.stride(0), c)
+    fwd = channel_stats(x)
+    bwd = _zero_stats(n, c, x.device)
+    a = ACT[act]
+    check(lib().gm_gn_bwd_stats(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), scale.data_ptr(), shift.data_ptr(), ss_ld, n, v, c, a,
+                                bwd.data_ptr(), dt_code(x.dtype), _stream()), "gm_gn_bwd_stats")
+    coef = torch.empty((3, n, c), dtype=torch.float32, device=x.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
+    check(lib().gm_gn_bwd_finalize(fwd.data_ptr(), bwd.data_ptr(), n, c, groups, v, float(eps), _ptr(as_f32(gamma)), coef[0].data_ptr(),
+                                   coef[1].data_ptr(), coef[2].data_ptr(), _ptr(dgamma), _ptr(dbeta), _stream()), "gm_gn_bwd_finalize")
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    check(lib().gm_gn_bwd_apply(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), scale.data_ptr(),
+                                shift.data_ptr(), ss_ld, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), n, v, c, a,
+                                dt_code(x.dtype), _stream()), "gm_gn_bwd_apply")
+    return dx, dgamma, dbeta
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -238,6 +238,44 @@ int gm_transformer_decode_step(const GmDecodeDesc* d, void* stream);
 /* after a draw: seq[b][*pos + 1] = idx[b]; tokens[b] = idx[b]; *pos += 1 (inferer.py:1237-1239 kept on the device) */
 int gm_decode_advance(int* pos, long long* tokens, const long long* idx, long long* seq, int B, long long seq_ld, void* stream);
 
+/* ---- backward kernels (the reference trains through torch autograd:
+ * tutorials/generative/distributed_training/ddpm_training_ddp.py:249-270, generative/engines/trainer.py:258-270) -------------------------
+ * The data gradient of a convolution is gm_conv_forward with in_mode = 2 (transposed convolution of gy with the same weight). */
+typedef struct GmWgradDesc {
+  const void* x; long long x_ld;      /* forward input  [N][Ds][Hs][Ws][Cin] */
+  const void* gy; long long gy_ld;    /* output gradient [N][Do][Ho][Wo][Cout] */
+  float* dw;                          /* fp32 [Cout][Cin][kd][kh][kw]: the nn.ConvNd / nn.Linear weight layout */
+  void* workspace; long long workspace_bytes;  /* gm_conv_wgrad_workspace_bytes(d) */
+  int N, Cin, Cout, Ds, Hs, Ws, Do, Ho, Wo;
+  int kd, kh, kw;                     /* 1 or 3 per axis, kh == kw */
+  int stride;                         /* 1 or 2 on every axis */
+  int pd, ph, pw;                     /* low-side padding */
+  int dtype;                          /* of x and gy */
+  int accumulate;                     /* 0: dw is overwritten, 1: added to */
+} GmWgradDesc;
+/* -1: geometry not covered */
+long long gm_conv_wgrad_workspace_bytes(const GmWgradDesc* d);
+/* dW[co][ci][tap] = sum_v gy[v][co] * x[v * stride - pad + tap][ci] (torch.nn.grad.conv*_weight); split-K partial sums reduced in
+ * a fixed order: deterministic */
+int gm_conv_wgrad(const GmWgradDesc* d, void* stream);
+/* GroupNorm (+ SiLU when act = 1) backward for y = act(x * scale[n][c] + shift[n][c]) (nn.GroupNorm + nn.SiLU,
+ * diffusion_model_unet.py:623-690).  With g = gy * act'(x * scale + shift):
+ *   gm_gn_bwd_stats     out[slot][n][c] += {sum_v g, sum_v g x}  (fp64, GM_STAT_SLOTS slots, zeroed by the caller)
+ *   gm_gn_bwd_finalize  per-(n, c) coefficients A, B, Cc of dx = A g + B x + Cc, and dgamma[c], dbeta[c] (nullable);
+ *                       fwd_stats = gm_gn_channel_stats table of x
+ *   gm_gn_bwd_apply     dx = g * A + x * B + Cc */
+int gm_gn_bwd_stats(const void* x, long long x_ld, const void* gy, long long gy_ld, const float* scale, const float* shift, long long ss_ld,
+                    int N, long long V, int C, int act, double* out, int dtype, void* stream);
+int gm_gn_bwd_finalize(const double* fwd_stats, const double* bwd_stats, int N, int C, int G, long long V, float eps, const float* gamma,
+                       float* A, float* B, float* Cc, float* dgamma, float* dbeta, void* stream);
+int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, const float* scale,
+                    const float* shift, long long ss_ld, const float* A, const float* B, const float* Cc, int N, long long V, int C, int act,
+                    int dtype, void* stream);
+/* per_sample = 0: out[c] = sum over slots and samples of stats[slot][n][c][0] (a bias gradient from the gm_gn_channel_stats table of
+ * gy); per_sample = 1: out[n][c] = sum over slots (gradient of the per-sample row vector a convolution epilogue adds: the timestep
+ * embedding projection, diffusion_model_unet.py:684-686) */
+int gm_stats_colsum(const double* stats, int N, int C, float* out, int per_sample, void* stream);
+
 /* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */
 int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long long* indices, long long tokens,
                  int num_embeddings, int dim, int dtype, void* stream);

@@ -1,0 +1,187 @@
+"""GPU (-m gpu): the backward kernels against torch autograd on the CPU in fp64 -- the reference trains
+through exactly that autograd (ddpm_training_ddp.py:249-270).  Operands are rounded to the tested dtype first, so the fp64
+result is the exact answer for the numbers the kernels see.  Tolerances: fp32 = exact-fp32 MFMA products, fp32 accumulation over
+up to 1e5 voxels: 1e-4 * scale; bf16 operands = exact products too (fp32 accumulate), the tolerance covers the bf16 rounding of the
+OUTPUT where the output is bf16 (dx), 1.5e-2 * scale; weight / affine gradients are returned in fp32: 2e-4 * scale."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from generativemodels_amd import ops
+    return ops
+
+
+def _rand(shape, seed, dtype=torch.float32, scale=1.0):
+    return (torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale).to(dtype)
+
+
+def _cl(x):
+    perm = [0] + list(range(2, x.dim())) + [1]
+    return x.permute(perm).contiguous().to(DEV)
+
+
+def _cf(a):
+    perm = [0, a.dim() - 1] + list(range(1, a.dim() - 1))
+    return a.detach().cpu().permute(perm).contiguous()
+
+
+def _close(got, want, tol, what):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert math.isfinite(err) and err <= tol * scale, f"{what}: max|err| {err:.3e} > {tol * scale:.3e} (scale {scale:.3g})"
+
+
+_CONVF = {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}
+
+WGRAD_CASES = {
+    # name: (spatial, N, Cin, Cout, kernel, stride, pad_lo, pad_hi)
+    "3d_k3": ((6, 9, 35), 2, 64, 64, 3, 1, 1, 1),
+    "3d_k3_wide": ((4, 5, 33), 1, 96, 160, 3, 1, 1, 1),          # partial channel blocks on both sides
+    "3d_k3_s2": ((9, 10, 37), 2, 32, 64, 3, 2, 1, 1),
+    "3d_k3_s2_asym": ((8, 8, 16), 1, 64, 64, 3, 2, 0, 1),        # AutoencoderKL Downsample: pad (0, 1)
+    "2d_k3": ((19, 45), 3, 64, 32, 3, 1, 1, 1),
+    "2d_k3_s2": ((20, 33), 2, 32, 32, 3, 2, 1, 1),
+    "3d_k1": ((3, 7, 21), 2, 128, 64, 1, 1, 0, 0),               # shortcut convolution
+    "tokens_k1": ((300,), 2, 64, 192, 1, 1, 0, 0),               # nn.Linear over (N, L, C)
+    "3d_k3_small_w": ((8, 8, 8), 2, 32, 32, 3, 1, 1, 1),         # W below one 32-voxel run
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", list(WGRAD_CASES), ids=list(WGRAD_CASES))
+def test_conv_weight_gradient(case, dtype):
+    """gm_conv_wgrad vs torch autograd (fp64) for every tile variant: 3-D / 2-D / stride 2 / 1x1-flat, ragged extents, partial
+    channel blocks, asymmetric padding."""
+    ops = _ops()
+    sp, n, cin, cout, k, s, plo, phi = WGRAD_CASES[case]
+    nsp = len(sp)
+    x = _rand((n, cin, *sp), 301).to(dtype)
+    w = _rand((cout, cin) + (k,) * nsp, 302).double().requires_grad_(True)
+    xp = F.pad(x.double(), [v for _ in range(nsp) for v in (plo, phi)])
+    y = _CONVF[nsp](xp, w, None, stride=s)
+    gy = _rand(tuple(y.shape), 303).to(dtype)
+    (y * gy.double()).sum().backward()
+    got = ops.conv_wgrad(_cl(x), _cl(gy), k, s, plo)
+    _close(got, w.grad, 2e-4, f"wgrad {case}")
+    # accumulate into an existing gradient
+    acc = got.clone()
+    ops.conv_wgrad(_cl(x), _cl(gy), k, s, plo, out=acc, accumulate=True)
+    _close(acc, 2 * w.grad, 4e-4, f"wgrad {case} accumulate")
+
+
+def test_conv_weight_gradient_is_deterministic():
+    ops = _ops()
+    x, gy = _cl(_rand((2, 64, 8, 16, 40), 311).bfloat16()), _cl(_rand((2, 64, 8, 16, 40), 312).bfloat16())
+    a = ops.conv_wgrad(x, gy, 3, 1, 1)
+    b = ops.conv_wgrad(x, gy, 3, 1, 1)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["3d_k3", "3d_k3_s2", "3d_k3_s2_asym", "2d_k3", "2d_k3_s2", "3d_k1", "tokens_k1"])
+def test_conv_autograd_function(case, dtype):
+    """autograd.conv: data gradient (transposed convolution), weight, bias, per-sample row vector and residual gradients."""
+    from generativemodels_amd import autograd as A
+    sp, n, cin, cout, k, s, plo, phi = WGRAD_CASES[case]
+    nsp = len(sp)
+    x = _rand((n, cin, *sp), 321).to(dtype)
+    w = (_rand((cout, cin) + (k,) * nsp, 322) / math.sqrt(cin * k ** nsp)).to(dtype)
+    b = _rand((cout,), 323).to(dtype)
+    row = _rand((n, cout), 324)
+    xr, wr, br, rr = (t.double().requires_grad_(True) for t in (x, w, b, row))
+    xp = F.pad(xr, [v for _ in range(nsp) for v in (plo, phi)])
+    y_ref = _CONVF[nsp](xp, wr, br, stride=s) + rr.reshape(n, cout, *([1] * nsp))
+    res = _rand(tuple(y_ref.shape), 325).to(dtype)
+    resr = res.double().requires_grad_(True)
+    y_ref = y_ref + resr
+    gy = _rand(tuple(y_ref.shape), 326).to(dtype)
+    (y_ref * gy.double()).sum().backward()
+
+    xd, resd = _cl(x).requires_grad_(True), _cl(res).requires_grad_(True)
+    wd, bd, rd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True), row.to(DEV).requires_grad_(True)
+    y = A.conv(xd, wd, bd, kernel=k, stride=s, padding=plo, pad_hi=phi, rowvec=rd, res=resd)
+    tol_out = 2e-5 if dtype == torch.float32 else 1.5e-2
+    _close(_cf(y), y_ref, tol_out, f"{case} forward")
+    y.backward(_cl(gy))
+    _close(_cf(xd.grad), xr.grad, tol_out * 5, f"{case} dx")
+    tol_p = 2e-4 if dtype == torch.float32 else 1.5e-2  # parameter gradients are cast to the parameter dtype
+    _close(wd.grad, wr.grad, tol_p, f"{case} dw")
+    _close(bd.grad, br.grad, tol_p, f"{case} db")
+    _close(rd.grad, rr.grad, 2e-4, f"{case} d rowvec")
+    assert torch.equal(_cf(resd.grad), gy)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["silu", "none"])
+@pytest.mark.parametrize("shape,groups", [((2, 64, 5, 6, 7), 32), ((1, 96, 9, 11), 8), ((3, 32, 4, 4, 4), 32)])
+def test_group_norm_backward(shape, groups, act, dtype):
+    from generativemodels_amd import autograd as A
+    x = (_rand(shape, 331) * 1.7 + 0.3).to(dtype)
+    gamma, beta = (1 + 0.2 * _rand((shape[1],), 332)), 0.1 * _rand((shape[1],), 333)
+    gy = _rand(shape, 334).to(dtype)
+    xr, gr, br = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y_ref = F.group_norm(xr, groups, gr, br, 1e-6)
+    if act == "silu":
+        y_ref = F.silu(y_ref)
+    (y_ref * gy.double()).sum().backward()
+    xd = _cl(x).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    y = A.group_norm_act(xd, gd, bd, groups, 1e-6, act)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    _close(_cf(y), y_ref, tol, "group norm forward")
+    y.backward(_cl(gy))
+    _close(_cf(xd.grad), xr.grad, tol, "group norm dx")
+    _close(gd.grad, gr.grad, 2e-4 if dtype == torch.float32 else 2e-2, "dgamma")   # bf16: silu'(bf16-path y_pre) differs at 1e-3
+    _close(bd.grad, br.grad, 2e-4 if dtype == torch.float32 else 2e-2, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64)])
+def test_resnet_block_trains_like_the_torch_reference(cin, cout, dtype):
+    """ResnetBlock.run_train (GN -> SiLU -> conv + timestep row -> GN -> SiLU -> conv + 1x1 / identity shortcut): the loss gradient
+    with respect to the input, the timestep embedding and every parameter against torch autograd over the same block in fp64
+    (reference diffusion_model_unet.py:589-696)."""
+    from generativemodels_amd import autograd as A
+    from generativemodels_amd.networks.nets._blocks import ResnetBlock
+    torch.manual_seed(7)
+    blk = ResnetBlock(3, cin, cout, 128, norm_num_groups=32, norm_eps=1e-6, zero_conv2=False)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(p.to(dtype).float())  # parameters representable in the tested dtype
+    n, sp = 2, (6, 7, 9)
+    x = _rand((n, cin, *sp), 341).to(dtype)
+    temb = _rand((n, 128), 342).to(dtype)
+    gy = _rand((n, cout, *sp), 343).to(dtype)
+
+    ref = {k: v.detach().double().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xr, tr = x.double().requires_grad_(True), temb.double().requires_grad_(True)
+    h = F.silu(F.group_norm(xr, 32, ref["norm1.weight"], ref["norm1.bias"], 1e-6))
+    h = F.conv3d(h, ref["conv1.conv.weight"], ref["conv1.conv.bias"], padding=1)
+    h = h + F.linear(F.silu(tr), ref["time_emb_proj.weight"], ref["time_emb_proj.bias"])[:, :, None, None, None]
+    h = F.silu(F.group_norm(h, 32, ref["norm2.weight"], ref["norm2.bias"], 1e-6))
+    h = F.conv3d(h, ref["conv2.conv.weight"], ref["conv2.conv.bias"], padding=1)
+    xs = F.conv3d(xr, ref["skip_connection.conv.weight"], ref["skip_connection.conv.bias"]) if cin != cout else xr
+    y_ref = h + xs
+    (y_ref * gy.double()).sum().backward()
+
+    blk = blk.to(DEV).to(dtype)
+    xd, td = x.to(DEV).requires_grad_(True), temb.to(DEV).requires_grad_(True)
+    y = A.from_arena(blk.run_train(A.to_arena(xd), td))
+    tol = 1e-4 if dtype == torch.float32 else 4e-2   # bf16: two bf16-rounded intermediate activations in the chain
+    _close(y, y_ref, tol, "block forward")
+    y.backward(gy.to(DEV))
+    _close(xd.grad, xr.grad, tol * 2, "block dx")
+    _close(td.grad, tr.grad, tol * 2, "block dtemb")
+    for name, p in blk.named_parameters():
+        assert p.grad is not None, name
+        _close(p.grad, ref[name].grad, tol * 2, f"block d {name}")
