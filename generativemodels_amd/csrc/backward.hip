@@ -77,11 +77,53 @@ template <int S, int KHW> struct WgShift<float, S, KHW> {
   }
 };
 
-template <typename T> __device__ __forceinline__ void wg_store_elem(char* p, uint32_t word, int half);
-template <> __device__ __forceinline__ void wg_store_elem<bf16_raw>(char* p, uint32_t word, int half) {
-  *reinterpret_cast<bf16_raw*>(p) = (bf16_raw)(half ? (word >> 16) : (word & 0xffffu));
+// GS x GS transpose across GS consecutive lanes (GS = elements per 16-byte vector): in, lane v holds elements (channels) 0 .. GS-1 of
+// voxel v; out, lane j holds voxels 0 .. GS-1 of channel j.  Butterfly: swap lane bit k with register-index bit k, one exchange each.
+// lane ^ 1 and lane ^ 2 are DPP quad permutes (VALU, no LDS traffic), lane ^ 4 a ds_swizzle; __shfl_xor compiled to ds_bpermute_b32.
+__device__ __forceinline__ uint32_t wg_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ uint32_t wg_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ uint32_t wg_xor4(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F); }           // and 0x1f, xor 4
+template <typename T> __device__ __forceinline__ uint4 wg_transpose(uint4 r, int lane);
+template <> __device__ __forceinline__ uint4 wg_transpose<float>(uint4 r, int lane) {
+  {  // lane bit 1 <-> dword bit 1
+    const bool hi = lane & 2;
+    const uint32_t a = wg_xor2(hi ? r.x : r.z), b = wg_xor2(hi ? r.y : r.w);
+    if (hi) { r.x = a; r.y = b; } else { r.z = a; r.w = b; }
+  }
+  {  // lane bit 0 <-> dword bit 0
+    const bool hi = lane & 1;
+    const uint32_t a = wg_xor1(hi ? r.x : r.y), b = wg_xor1(hi ? r.z : r.w);
+    if (hi) { r.x = a; r.z = b; } else { r.y = a; r.w = b; }
+  }
+  return r;
 }
-template <> __device__ __forceinline__ void wg_store_elem<float>(char* p, uint32_t word, int) { *reinterpret_cast<uint32_t*>(p) = word; }
+template <> __device__ __forceinline__ uint4 wg_transpose<bf16_raw>(uint4 r, int lane) {
+  {  // lane bit 2 <-> dword bit 1
+    const bool hi = lane & 4;
+    const uint32_t a = wg_xor4(hi ? r.x : r.z), b = wg_xor4(hi ? r.y : r.w);
+    if (hi) { r.x = a; r.y = b; } else { r.z = a; r.w = b; }
+  }
+  {  // lane bit 1 <-> dword bit 0
+    const bool hi = lane & 2;
+    const uint32_t a = wg_xor2(hi ? r.x : r.y), b = wg_xor2(hi ? r.z : r.w);
+    if (hi) { r.x = a; r.z = b; } else { r.y = a; r.w = b; }
+  }
+  {  // lane bit 0 <-> half-word: each lane sends the half its partner needs, packed two to a dword
+    const bool hi = lane & 1;
+    // even lane keeps the low halves and needs the partner's low halves; odd lane keeps the high halves and needs the partner's high ones
+    const uint32_t s0 = hi ? __builtin_amdgcn_perm(r.y, r.x, 0x05040100) : __builtin_amdgcn_perm(r.y, r.x, 0x07060302);  // what the PARTNER needs
+    const uint32_t s1 = hi ? __builtin_amdgcn_perm(r.w, r.z, 0x05040100) : __builtin_amdgcn_perm(r.w, r.z, 0x07060302);
+    const uint32_t p0 = wg_xor1(s0), p1 = wg_xor1(s1);  // even lane: partner's (x.lo, y.lo), (z.lo, w.lo); odd lane: partner's high halves
+    if (hi) {
+      r.x = (p0 & 0xffffu) | (r.x & 0xffff0000u); r.y = (p0 >> 16) | (r.y & 0xffff0000u);
+      r.z = (p1 & 0xffffu) | (r.z & 0xffff0000u); r.w = (p1 >> 16) | (r.w & 0xffff0000u);
+    } else {
+      r.x = (r.x & 0xffffu) | (p0 << 16); r.y = (r.y & 0xffffu) | (p0 & 0xffff0000u);
+      r.z = (r.z & 0xffffu) | (p1 << 16); r.w = (r.w & 0xffffu) | (p1 & 0xffff0000u);
+    }
+  }
+  return r;
+}
 
 // S: stride; KHW: kernel extent along H and W (1 or 3); TD x TH x 32: output-voxel tile.  KHW == 1 is "flat": the rows of the two
 // operands are walked as one long W axis (1x1 convolutions and nn.Linear layers: the spatial structure does not matter).
@@ -126,7 +168,49 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const GmWgradDesc p,
   const T* xin = reinterpret_cast<const T*>(p.x);
   const T* gin = reinterpret_cast<const T*>(p.gy);
 
-  for (long long tile = split; tile < tiles_total; tile += nsplit) {
+  // A tile's operands travel global -> registers -> (transposed) LDS.  GS = VECW consecutive lanes hold the 16-byte channel vectors of
+  // GS consecutive voxels (same channel vector): a GS x GS transpose across those lanes (a butterfly of DPP / swizzle exchanges) leaves
+  // lane j with GS consecutive voxels of channel j, written by ONE ds_write_b128.  The lane groups of a wave-load are the channel
+  // vectors of the same voxels, so global reads stay full 128-byte lines.  All loads of a tile are issued back to back, and those of
+  // tile t + 1 right after tile t's LDS image is complete: they fly during its multiply.
+  // What the first versions taught (rocprofv3 + the ISA): eight 2-byte LDS writes per vector with 4-way bank conflicts, then ~1000
+  // integer instructions per tile and wave re-deriving every item's patch coordinates and LDS address (div / mod chains) plus 96
+  // ds_bpermute per tile -- 2850 non-MFMA instructions against 144 MFMAs, 440-520 TFLOP/s.  Everything tile independent (patch
+  // coordinates, channel vector, validity, LDS destination) is therefore packed into ONE register per item before the tile loop.
+  constexpr int GS = VECW, XGR = PLW / GS, GGR = TW / GS;
+  constexpr int XITEMS = NR * S * PLW * CVX, GITEMS = GROWS * TW * CVG;
+  constexpr int XI = (XITEMS + 511) / 512, GI = (GITEMS + 511) / 512;
+  static_assert(XITEMS % 64 == 0 && GITEMS % 64 == 0, "whole waves of items");
+  static_assert(S * (TD - 1) < 4 && PH <= 16 && PCOLS <= 128 && CVX <= 8 && CVG <= 16, "field widths of the packed item descriptor");
+  static_assert(CIB * XPITCH < (1 << 18) && 64 * GPITCH < (1 << 18), "LDS offsets fit the packed item descriptor");
+  // x item: [1:0] S*dd  [5:2] hh  [12:6] pc  [15:13] channel vector  [16] valid  [31:17] LDS offset / 16
+  // gy item: [0] gd  [3:1] gh  [8:4] w  [12:9] channel vector  [16] valid  [31:17] LDS offset / 16 (from gT)
+  unsigned xpk[XI], gpk[GI];
+#pragma unroll
+  for (int j = 0; j < XI; ++j) {
+    const int it = tid + j * 512;
+    const int v = it % GS, cv = (it / GS) % CVX, grp = it / (GS * CVX);
+    const int g = grp % XGR, plane = (grp / XGR) % S, pr = grp / (XGR * S);
+    const int idx = g * GS + v, pc = S == 1 ? idx : 2 * idx + plane;
+    const int dd = pr / PH, hh = pr - dd * PH;
+    const bool valid = (it < XITEMS) & (pc < PCOLS) & (ci0 + cv * VECW < p.Cin);  // host: Cin % VECW == 0
+    const unsigned dst = (unsigned)((cv * VECW + v) * XPITCH + (pr * RW + plane * PLW + g * GS) * ES);
+    xpk[j] = (unsigned)(KHW == 1 ? 0 : S * dd) | ((unsigned)(KHW == 1 ? pr : hh) << 2) | ((unsigned)(pc & 127) << 6) | ((unsigned)cv << 13) |
+             ((unsigned)valid << 16) | ((dst >> 4) << 17);
+  }
+#pragma unroll
+  for (int j = 0; j < GI; ++j) {
+    const int it = tid + j * 512;
+    const int v = it % GS, cv = (it / GS) % CVG, grp = it / (GS * CVG);
+    const int g = grp % GGR, gr = grp / GGR;
+    const int w_ = g * GS + v;
+    const bool valid = (it < GITEMS) & (co0 + cv * VECW < p.Cout);  // host: Cout % VECW == 0
+    const unsigned dst = (unsigned)((cv * VECW + v) * GPITCH + (gr * TW + g * GS) * ES);
+    gpk[j] = (unsigned)(KHW == 1 ? 0 : gr / TH) | ((unsigned)(KHW == 1 ? gr : gr % TH) << 1) | ((unsigned)w_ << 4) | ((unsigned)cv << 9) |
+             ((unsigned)valid << 16) | ((dst >> 4) << 17);
+  }
+  uint4 xreg[XI], greg[GI];
+  auto load_tile = [&](long long tile) __attribute__((always_inline)) {
     int n = 0, od0 = 0, oh0 = 0, ow0 = 0;
     if (KHW != 1) {
       long long t = tile;
@@ -135,55 +219,61 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const GmWgradDesc p,
       od0 = (int)(t % ntd) * TD; t /= ntd;
       n = (int)t;
     }
-    // ---- stage xT: (patch voxel, 16-byte channel vector) items, the channel vector fastest over the lanes (coalesced rows) ----------
-    for (int it = tid; it < NR * PCOLS * CVX; it += 512) {
-      const int cv = it % CVX, pv = it / CVX;
-      const int pc = pv % PCOLS, pr = pv / PCOLS;
-      const int dd = pr / PH, hh = pr - dd * PH;
-      bool ok;
+    const int ud0 = S * od0 - p.pd + kdi, uh0 = S * oh0 - p.ph, uw0 = S * ow0 - p.pw;
+    const long long flat0 = tile * (GROWS * TW);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const unsigned pk = xpk[j];
+      const int a0 = pk & 3, a1 = (pk >> 2) & 15, a2 = (pk >> 6) & 127, cv = (pk >> 13) & 7;
+      bool ok = (pk >> 16) & 1;
       long long vox;
       if (KHW == 1) {
-        vox = (tile * GROWS + pr) * TW + pc;
-        ok = vox < rows_flat;
+        vox = flat0 + a1 * TW + a2;
+        ok = ok & (vox < rows_flat);
       } else {
-        const int ud = S * (od0 + dd) - p.pd + kdi, uh = S * oh0 - p.ph + hh, uw = S * ow0 - p.pw + pc;
-        ok = (ud >= 0) & (ud < p.Ds) & (uh >= 0) & (uh < p.Hs) & (uw >= 0) & (uw < p.Ws);
-        vox = (((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw;
+        const int ud = ud0 + a0, uh = uh0 + a1, uw = uw0 + a2;
+        ok = ok & ((unsigned)ud < (unsigned)p.Ds) & ((unsigned)uh < (unsigned)p.Hs) & ((unsigned)uw < (unsigned)p.Ws);
+        vox = ((n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw;  // 32-bit: host checks N * D * H * W < 2^31
       }
-      const int c = ci0 + cv * VECW;
-      ok = ok & (c < p.Cin);  // host: Cin % VECW == 0
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *reinterpret_cast<const uint4*>(xin + vox * p.x_ld + c);
-      const int col = S == 2 ? (pc & 1) * PLW + (pc >> 1) : pc;
-      char* dst = xT + (size_t)(cv * VECW) * XPITCH + (pr * RW + col) * ES;
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int i = 0; i < VECW; ++i) wg_store_elem<T>(dst + (size_t)i * XPITCH, w[ES == 2 ? i >> 1 : i], i & 1);
+      xreg[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) xreg[j] = *reinterpret_cast<const uint4*>(xin + vox * p.x_ld + ci0 + cv * VECW);
     }
-    // ---- stage gT -------------------------------------------------------------------------------------------------------------
-    for (int it = tid; it < GROWS * TW * CVG; it += 512) {
-      const int cv = it % CVG, pv = it / CVG;
-      const int w_ = pv % TW, gr = pv / TW;
-      bool ok;
+#pragma unroll
+    for (int j = 0; j < GI; ++j) {
+      const unsigned pk = gpk[j];
+      const int a0 = pk & 1, a1 = (pk >> 1) & 7, a2 = (pk >> 4) & 31, cv = (pk >> 9) & 15;
+      bool ok = (pk >> 16) & 1;
       long long vox;
       if (KHW == 1) {
-        vox = (tile * GROWS + gr) * TW + w_;
-        ok = vox < rows_flat;
+        vox = flat0 + a1 * TW + a2;
+        ok = ok & (vox < rows_flat);
       } else {
-        const int od = od0 + gr / TH, oh = oh0 + gr % TH, ow = ow0 + w_;
-        ok = (od < p.Do) & (oh < p.Ho) & (ow < p.Wo);
-        vox = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+        const int od = od0 + a0, oh = oh0 + a1, ow = ow0 + a2;
+        ok = ok & (od < p.Do) & (oh < p.Ho) & (ow < p.Wo);
+        vox = ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
       }
-      const int c = co0 + cv * VECW;
-      ok = ok & (c < p.Cout);  // host: Cout % VECW == 0
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *reinterpret_cast<const uint4*>(gin + vox * p.gy_ld + c);
-      char* dst = gT + (size_t)(cv * VECW) * GPITCH + (gr * TW + w_) * ES;
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int i = 0; i < VECW; ++i) wg_store_elem<T>(dst + (size_t)i * GPITCH, w[ES == 2 ? i >> 1 : i], i & 1);
+      greg[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) greg[j] = *reinterpret_cast<const uint4*>(gin + vox * p.gy_ld + co0 + cv * VECW);
     }
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const uint4 tr = wg_transpose<T>(xreg[j], lane);  // every lane of the wave takes part in the exchanges
+      if (tid + j * 512 < XITEMS) *reinterpret_cast<uint4*>(xT + ((xpk[j] >> 17) << 4)) = tr;
+    }
+#pragma unroll
+    for (int j = 0; j < GI; ++j) {
+      const uint4 tr = wg_transpose<T>(greg[j], lane);
+      if (tid + j * 512 < GITEMS) *reinterpret_cast<uint4*>(gT + ((gpk[j] >> 17) << 4)) = tr;
+    }
+  };
+
+  if (split < tiles_total) load_tile(split);
+  for (long long tile = split; tile < tiles_total; tile += nsplit) {
+    store_tile();
     __syncthreads();
+    if (tile + nsplit < tiles_total) load_tile(tile + nsplit);
     // ---- multiply: one k-step per (tile row, 32-voxel run) ----------------------------------------------------------------------
     const char* arow = gT + (size_t)(cog * COFW * 16 + l15) * GPITCH + q * VECW * ES;
     const char* brow = xT + (size_t)(cif * 16 + l15) * XPITCH + q * VECW * ES;
@@ -247,6 +337,7 @@ static bool wgrad_plan(const GmWgradDesc& d, WgPlan& pl) {
   if ((reinterpret_cast<uintptr_t>(d.x) & 15) || (reinterpret_cast<uintptr_t>(d.gy) & 15)) return false;
   if (d.kh != d.kw || (d.kh != 1 && d.kh != 3) || (d.kd != 1 && d.kd != 3) || (d.kd == 3 && d.kh != 3)) return false;
   if (d.stride != 1 && d.stride != 2) return false;
+  if ((long long)d.N * d.Ds * d.Hs * d.Ws >= (1LL << 31) || (long long)d.N * d.Do * d.Ho * d.Wo >= (1LL << 31)) return false;
   pl.cib = d.dtype == GM_F32 ? 32 : 64;
   pl.ncob = (d.Cout + 63) / 64;
   pl.ncib = (d.Cin + pl.cib - 1) / pl.cib;
@@ -263,7 +354,7 @@ static bool wgrad_plan(const GmWgradDesc& d, WgPlan& pl) {
     pl.tiles = (long long)d.N * ((d.Do + pl.td - 1) / pl.td) * ((d.Ho + pl.th - 1) / pl.th) * ((d.Wo + 31) / 32);
   }
   const long long base = (long long)d.kd * pl.ncob * pl.ncib;
-  long long ns = (768 + base - 1) / base;  // ~3 work-groups per CU in total (one is resident per CU: ~100 KiB of LDS)
+  long long ns = 256 / base;  // one work-group per CU (~100 KiB of LDS each), every one with the same number of tiles (+-1)
   if (ns > pl.tiles) ns = pl.tiles;
   if (ns < 1) ns = 1;
   pl.nsplit = (int)ns;
@@ -339,38 +430,78 @@ extern "C" int gm_conv_wgrad(const GmWgradDesc* dp, void* stream) {
 // (reference: torch.nn.functional.group_norm / SiLU autograd as used by diffusion_model_unet.py:623-690)
 // ---------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float silu_grad(float z) {
-  const float s = 1.0f / (1.0f + expf(-z));
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-z));  // v_exp_f32 + v_rcp_f32: ~1 ulp each
   return s * (1.0f + z * (1.0f - s));
 }
 
-// out[slot][n][c] += {sum_v g, sum_v g * x} (fp64 atomics, table zeroed by the caller); grid (nblk, N)
-template <typename T>
+// out[slot][n][c] += {sum_v g, sum_v g * x} (fp64 atomics, table zeroed by the caller); grid (nblk, N).
+// Lane <-> 16-byte channel vector, 256 / CV rows in flight per block, fp32 partial sums over <= rows_per_block / R rows, LDS reduction
+// over the rows in flight, one fp64 atomic pair per channel and block (HBM-bound: x and gy read once).
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ gy, long long gy_ld,
                                                           const float* __restrict__ scale, const float* __restrict__ shift, long long ss_ld,
                                                           long long V, int C, int act, int rows_per_block, double* __restrict__ out) {
-  const int n = blockIdx.y, blk = blockIdx.x;
-  const long long r0 = (long long)blk * rows_per_block;
-  long long r1 = r0 + rows_per_block;
-  if (r1 > V) r1 = V;
-  // thread <-> channel (strided), rows walked serially: consecutive threads read consecutive channels of a row
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float sc = scale[n * ss_ld + c], sh = shift[n * ss_ld + c];
-    float a = 0.f, b2 = 0.f;
-    double da = 0.0, db = 0.0;
-    int cnt = 0;
-    for (long long r = r0; r < r1; ++r) {
-      const long long row = (long long)n * V + r;
-      const float xv = ElemIO<T>::ld(x + row * x_ld + c);
-      float g = ElemIO<T>::ld(gy + row * gy_ld + c);
-      if (act == 1) g *= silu_grad(xv * sc + sh);
-      a += g; b2 += g * xv;
-      if (++cnt == 256) { da += (double)a; db += (double)b2; a = 0.f; b2 = 0.f; cnt = 0; }
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int CV = C / VEC, R = 256 / CV;                 // host: CV <= 256
+  float* part_a = reinterpret_cast<float*>(smem_raw);   // [R][C]
+  float* part_b = part_a + (size_t)R * C;
+  const int n = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  const int cv = t % CV, r0 = t / CV;
+  const long long row_begin = (long long)blk * rows_per_block;
+  long long row_end = row_begin + rows_per_block;
+  if (row_end > V) row_end = V;
+  if (r0 < R) {
+    float sc[VEC], sh[VEC], a[VEC], b2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      sc[i] = scale[n * ss_ld + cv * VEC + i];
+      sh[i] = shift[n * ss_ld + cv * VEC + i];
+      a[i] = 0.f; b2[i] = 0.f;
     }
-    da += (double)a; db += (double)b2;
+    const T* xb = x + ((long long)n * V) * x_ld + (long long)cv * VEC;
+    const T* gb = gy + ((long long)n * V) * gy_ld + (long long)cv * VEC;
+    for (long long r = row_begin + r0; r < row_end; r += R) {
+      float xv[VEC], gv[VEC];
+      if constexpr (VEC == 1) { xv[0] = ElemIO<T>::ld(xb + r * x_ld); gv[0] = ElemIO<T>::ld(gb + r * gy_ld); }
+      else {
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + r * x_ld), xv);
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gb + r * gy_ld), gv);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float g = gv[i];
+        if (act == 1) g *= silu_grad(xv[i] * sc[i] + sh[i]);
+        a[i] += g; b2[i] += g * xv[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      part_a[(size_t)r0 * C + cv * VEC + i] = a[i];
+      part_b[(size_t)r0 * C + cv * VEC + i] = b2[i];
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    double da = 0.0, db = 0.0;
+    for (int r = 0; r < R; ++r) { da += (double)part_a[(size_t)r * C + c]; db += (double)part_b[(size_t)r * C + c]; }
     double* dst = out + (((long long)(blk % GM_STAT_SLOTS) * gridDim.y + n) * C + c) * 2;
     atomicAdd(dst, da);
     atomicAdd(dst + 1, db);
   }
+}
+
+template <typename T, int VEC>
+static void launch_gn_bwd_stats(const void* x, long long x_ld, const void* gy, long long gy_ld, const float* scale, const float* shift,
+                                long long ss_ld, int N, long long V, int C, int act, double* out, hipStream_t st) {
+  const int CV = C / VEC, R = 256 / CV;
+  long long nblk = (V + 255) / 256;            // >= 256 rows per block, at most ~4 blocks per CU and sample
+  const long long cap = 1024 / (N < 1 ? 1 : (N > 8 ? 8 : N)) + 1;
+  if (nblk > cap) nblk = cap;
+  const int rpb = (int)((V + nblk - 1) / nblk);
+  nblk = (V + rpb - 1) / rpb;
+  dim3 grid((unsigned)nblk, N);
+  const size_t smem = (size_t)R * C * 2 * sizeof(float);
+  gn_bwd_stats_kernel<T, VEC><<<grid, 256, smem, st>>>((const T*)x, x_ld, (const T*)gy, gy_ld, scale, shift, ss_ld, V, C, act, rpb, out);
 }
 
 extern "C" int gm_gn_bwd_stats(const void* x, long long x_ld, const void* gy, long long gy_ld, const float* scale, const float* shift,
@@ -378,18 +509,19 @@ extern "C" int gm_gn_bwd_stats(const void* x, long long x_ld, const void* gy, lo
   GM_REQUIRE(x && gy && scale && shift && out, "null pointer");
   GM_REQUIRE(N <= 65535, "batch too large");
   if (N == 0 || V == 0) return 0;
-  long long nblk = (V + 511) / 512;
-  if (nblk > 2048) nblk = 2048;
-  const int rpb = (int)((V + nblk - 1) / nblk);
-  nblk = (V + rpb - 1) / rpb;
-  dim3 grid((unsigned)nblk, N);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GM_F32)
-    gn_bwd_stats_kernel<float><<<grid, 256, 0, st>>>((const float*)x, x_ld, (const float*)gy, gy_ld, scale, shift, ss_ld, V, C, act, rpb, out);
-  else if (dtype == GM_BF16)
-    gn_bwd_stats_kernel<bf16_raw><<<grid, 256, 0, st>>>((const bf16_raw*)x, x_ld, (const bf16_raw*)gy, gy_ld, scale, shift, ss_ld, V, C, act, rpb, out);
-  else
+  const int vec = dtype == GM_F32 ? 4 : 8;
+  const bool vec_ok = (C % vec == 0) && (x_ld % vec == 0) && (gy_ld % vec == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)gy & 15) == 0);
+  GM_REQUIRE((vec_ok ? C / vec : C) <= 256, "too many channels for gm_gn_bwd_stats");
+  if (dtype == GM_F32) {
+    if (vec_ok) launch_gn_bwd_stats<float, 4>(x, x_ld, gy, gy_ld, scale, shift, ss_ld, N, V, C, act, out, st);
+    else launch_gn_bwd_stats<float, 1>(x, x_ld, gy, gy_ld, scale, shift, ss_ld, N, V, C, act, out, st);
+  } else if (dtype == GM_BF16) {
+    if (vec_ok) launch_gn_bwd_stats<bf16_raw, 8>(x, x_ld, gy, gy_ld, scale, shift, ss_ld, N, V, C, act, out, st);
+    else launch_gn_bwd_stats<bf16_raw, 1>(x, x_ld, gy, gy_ld, scale, shift, ss_ld, N, V, C, act, out, st);
+  } else {
     GM_FAIL(-2, "unsupported dtype");
+  }
   GM_LAUNCH_CHECK();
 }
 
@@ -446,21 +578,47 @@ extern "C" int gm_gn_bwd_finalize(const double* fwd_stats, const double* bwd_sta
   GM_LAUNCH_CHECK();
 }
 
-// dx = gy * act'(x * scale + shift) * A + x * B + Cc
-template <typename T>
+// dx = gy * act'(x * scale + shift) * A + x * B + Cc.  Lane <-> one 16-byte channel vector, its five coefficient vectors in registers,
+// rows walked with 256 / CV rows in flight per block (a grid-stride loop over (voxel, vector) items re-read the five [N][C] tables per
+// element: 0.6-2.3 ms on 268-537 MB tensors against 0.2-0.4 ms of HBM time).  grid (nblk, N)
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ gy, long long gy_ld,
                                                           T* __restrict__ dx, long long dx_ld, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, long long ss_ld, const float* __restrict__ A,
                                                           const float* __restrict__ B, const float* __restrict__ Cc, long long V, int C,
-                                                          long long total, int act) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long row = i / C;
-    const int c = (int)(i - row * C);
-    const long long n = row / V;
-    const float xv = ElemIO<T>::ld(x + row * x_ld + c);
-    float g = ElemIO<T>::ld(gy + row * gy_ld + c);
-    if (act == 1) g *= silu_grad(xv * scale[n * ss_ld + c] + shift[n * ss_ld + c]);
-    ElemIO<T>::st(dx + row * dx_ld + c, g * A[n * C + c] + xv * B[n * C + c] + Cc[n * C + c]);
+                                                          int rows_per_block, int act) {
+  const int CV = C / VEC, R = 256 / CV;
+  const int n = blockIdx.y, t = threadIdx.x;
+  const int cv = t % CV, r0 = t / CV;
+  if (r0 >= R) return;
+  const long long row_begin = (long long)blockIdx.x * rows_per_block;
+  long long row_end = row_begin + rows_per_block;
+  if (row_end > V) row_end = V;
+  float sc[VEC], sh[VEC], ca[VEC], cb[VEC], cc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = cv * VEC + i;
+    sc[i] = scale[n * ss_ld + c]; sh[i] = shift[n * ss_ld + c];
+    ca[i] = A[(long long)n * C + c]; cb[i] = B[(long long)n * C + c]; cc[i] = Cc[(long long)n * C + c];
+  }
+  const T* xb = x + ((long long)n * V) * x_ld + (long long)cv * VEC;
+  const T* gb = gy + ((long long)n * V) * gy_ld + (long long)cv * VEC;
+  T* db = dx + ((long long)n * V) * dx_ld + (long long)cv * VEC;
+  for (long long r = row_begin + r0; r < row_end; r += R) {
+    float xv[VEC], gv[VEC], o[VEC];
+    if constexpr (VEC == 1) { xv[0] = ElemIO<T>::ld(xb + r * x_ld); gv[0] = ElemIO<T>::ld(gb + r * gy_ld); }
+    else {
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + r * x_ld), xv);
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gb + r * gy_ld), gv);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float g = gv[k];
+      if (act == 1) g *= silu_grad(xv[k] * sc[k] + sh[k]);
+      o[k] = g * ca[k] + xv[k] * cb[k] + cc[k];
+    }
+    if constexpr (VEC == 1) ElemIO<T>::st(db + r * dx_ld, o[0]);
+    else *reinterpret_cast<uint4*>(db + r * dx_ld) = Vec16<T>::pack(o);
   }
 }
 
@@ -468,19 +626,27 @@ extern "C" int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, lo
                                const float* shift, long long ss_ld, const float* A, const float* B, const float* Cc, int N, long long V, int C,
                                int act, int dtype, void* stream) {
   GM_REQUIRE(x && gy && dx && scale && shift && A && B && Cc, "null pointer");
-  const long long total = (long long)N * V * C;
-  if (total == 0) return 0;
-  long long g = (total + 255) / 256;
-  if (g > 8192) g = 8192;
+  GM_REQUIRE(N <= 65535, "batch too large");
+  if ((long long)N * V * C == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GM_F32)
-    gn_bwd_apply_kernel<float><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (const float*)gy, gy_ld, (float*)dx, dx_ld, scale, shift, ss_ld, A, B, Cc,
-                                                       V, C, total, act);
-  else if (dtype == GM_BF16)
-    gn_bwd_apply_kernel<bf16_raw><<<(int)g, 256, 0, st>>>((const bf16_raw*)x, x_ld, (const bf16_raw*)gy, gy_ld, (bf16_raw*)dx, dx_ld, scale, shift,
-                                                          ss_ld, A, B, Cc, V, C, total, act);
-  else
-    GM_FAIL(-2, "unsupported dtype");
+  const int vec = dtype == GM_F32 ? 4 : 8;
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec_ok = (C % vec == 0) && (x_ld % vec == 0) && (gy_ld % vec == 0) && (dx_ld % vec == 0) && al(x) && al(gy) && al(dx);
+  const int CV = vec_ok ? C / vec : C;
+  GM_REQUIRE(CV <= 256, "too many channels for gm_gn_bwd_apply");
+  const int R = 256 / CV;
+  long long nblk = (V + (long long)R * 8 - 1) / ((long long)R * 8);  // >= 8 rows per lane
+  const long long cap = 4096 / (N > 16 ? 16 : N) + 1;
+  if (nblk > cap) nblk = cap;
+  const int rpb = (int)((V + nblk - 1) / nblk);
+  nblk = (V + rpb - 1) / rpb;
+  dim3 grid((unsigned)nblk, N);
+#define GM_GNB_LAUNCH(T, VEC) \
+  gn_bwd_apply_kernel<T, VEC><<<grid, 256, 0, st>>>((const T*)x, x_ld, (const T*)gy, gy_ld, (T*)dx, dx_ld, scale, shift, ss_ld, A, B, Cc, V, C, rpb, act)
+  if (dtype == GM_F32) { if (vec_ok) GM_GNB_LAUNCH(float, 4); else GM_GNB_LAUNCH(float, 1); }
+  else if (dtype == GM_BF16) { if (vec_ok) GM_GNB_LAUNCH(bf16_raw, 8); else GM_GNB_LAUNCH(bf16_raw, 1); }
+  else GM_FAIL(-2, "unsupported dtype");
+#undef GM_GNB_LAUNCH
   GM_LAUNCH_CHECK();
 }
 
