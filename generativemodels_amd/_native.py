@@ -117,6 +117,7 @@ PROTOTYPES = {
     "gm_gn_bwd_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, C.c_int, c_ll, C.c_int, C.c_int,
                                   C.c_int, c_vp]),
     "gm_stats_colsum": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
+    "gm_softmax_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_float, c_vp]),
     "gm_vq_argmin": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_vq_gather_workspace_bytes": (c_ll, []),
     "gm_vq_gather": (C.c_int, [c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),

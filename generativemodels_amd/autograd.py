@@ -8,6 +8,11 @@ Every function here works on arena tensors (N, *spatial, C) and runs native kern
                   dW: gm_conv_wgrad (MFMA, split-K, deterministic); db / d(row vector): column sums of gy
   group_norm_act  forward: per-channel statistics -> (scale, shift) -> one apply pass (+ SiLU)
                   backward: gm_gn_bwd_stats / _finalize / _apply (dx, dgamma, dbeta)
+  upsample_conv   nearest 2x folded into the convolution; backward: dgrad on the fine grid, 2x sum-pool; dW against the upsampled input
+  attention       forward: the flash-attention kernel; backward: per (sample, head) in fp32 -- scores, softmax, dV = P^T dO, dP = dO V^T,
+                  dS (gm_softmax_bwd), dQ = dS K, dK = dS^T Q -- on the GEMM / weight-gradient kernels (L x L matrices are materialised:
+                  sequences up to 8192 tokens; a fused flash backward is the follow-up)
+  add / cat       residual add and channel concatenation
   to_arena / from_arena   the NC[D]HW <-> N[D]HWC permutations
 There is no eager fallback: a CPU tensor raises in the first native call."""
 from __future__ import annotations
@@ -18,7 +23,7 @@ import torch
 
 from . import ops
 
-__all__ = ["conv", "linear", "group_norm_act", "to_arena", "from_arena"]
+__all__ = ["conv", "linear", "group_norm_act", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
 
 
 def _tup(v, n):
@@ -139,3 +144,123 @@ def to_arena(x: torch.Tensor) -> torch.Tensor:
 def from_arena(x: torch.Tensor) -> torch.Tensor:
     """N[D]HWC -> NC[D]HW, differentiable."""
     return _FromArena.apply(x)
+
+
+class _UpsampleConv(torch.autograd.Function):
+    """Nearest 2x upsampling folded into a 3^d stride-1 convolution (reference Upsample, diffusion_model_unet.py:534-586)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = ops.conv(x, weight, bias, kernel=3, stride=1, padding=1, upsample=True)
+        ctx.save_for_backward(x, weight)
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = dw = db = None
+        nsp = x.dim() - 2
+        if ctx.needs_input_grad[0]:
+            du = ops.conv(gy, weight, None, kernel=3, stride=1, padding=1, transposed=True)  # gradient on the upsampled grid
+            dx = ops.scale(ops.resample2x(du, "down"), float(2 ** nsp))                        # sum over each 2^d cell
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(ops.resample2x(x, "up"), gy, 3, 1, 1).reshape(weight.shape).to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            db = ops.bias_grad(gy).to(ctx.bias_dtype)
+        return dx, dw, db
+
+
+def upsample_conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return _UpsampleConv.apply(x, weight, bias)
+
+
+ATTENTION_BWD_MAX_TOKENS = 8192
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        o = ops.attention(q, k, v, heads, scale)
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = (heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        b, lq, c = q.shape
+        lk = k.shape[1]
+        dh = c // heads
+        if max(lq, lk) > ATTENTION_BWD_MAX_TOKENS:
+            raise NotImplementedError(f"attention backward materialises the {lq} x {lk} score matrix per head: sequences above "
+                                      f"{ATTENTION_BWD_MAX_TOKENS} tokens need the fused flash backward (not built yet)")
+        if dh % 4 or lk % 4 or lq % 4:
+            raise NotImplementedError("attention backward: head dim and sequence lengths must be multiples of 4")
+        f32 = torch.float32
+        go = go.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+
+        def head(t, bi, hi, rows):  # fp32 contiguous [1, rows, dh] copy of one (sample, head) slice
+            out = torch.empty((1, rows, dh), dtype=f32, device=t.device)
+            ops.copy_channels(t[bi:bi + 1, :, hi * dh:(hi + 1) * dh], out)
+            return out
+
+        for bi in range(b):
+            for hi in range(heads):
+                qf, kf, vf, gf = head(q, bi, hi, lq), head(k, bi, hi, lk), head(v, bi, hi, lk), head(go, bi, hi, lq)
+                s_ = ops.conv(qf, kf[0], None, kernel=1)                                   # [1, lq, lk] = Q K^T
+                p_ = ops.sample_probs(s_[0], 1.0 / scale, None, -1)                        # softmax(scale * S), fp32
+                dvh = ops.conv_wgrad(gf, p_[None], 1, 1, 0)                                # [lk, dh, 1] = P^T dO
+                dp = ops.conv(gf, vf[0], None, kernel=1)                                   # [1, lq, lk] = dO V^T
+                ds = ops.softmax_bwd(p_, dp[0], scale)                                     # [lq, lk]
+                dqh = ops.conv(ds[None], kf[0], None, kernel=1, transposed=True)           # [1, lq, dh] = dS K
+                dkh = ops.conv_wgrad(qf, ds[None], 1, 1, 0)                                # [lk, dh, 1] = dS^T Q
+                sl = slice(hi * dh, (hi + 1) * dh)
+                ops.copy_channels(dqh, dq[bi:bi + 1, :, sl])
+                ops.copy_channels(dkh.reshape(1, lk, dh), dk[bi:bi + 1, :, sl])
+                ops.copy_channels(dvh.reshape(1, lk, dh), dv[bi:bi + 1, :, sl])
+        return dq, dk, dv, None, None
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """softmax(scale Q K^T) V per (sample, head) over (B, L, heads * dh) operands; differentiable in q, k, v."""
+    return _Attention.apply(q, k, v, heads, scale)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ones = torch.ones(a.shape[0], dtype=torch.float32, device=a.device)
+        return ops.axpby_rows(a, b, ones, ones).reshape(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _Add.apply(a, b)
+
+
+class _Cat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.split = a.shape[-1]
+        return ops.concat_channels([a, b])
+
+    @staticmethod
+    def backward(ctx, g):
+        ca = ctx.split
+        ga = torch.empty((*g.shape[:-1], ca), dtype=g.dtype, device=g.device)
+        gb = torch.empty((*g.shape[:-1], g.shape[-1] - ca), dtype=g.dtype, device=g.device)
+        ops.copy_channels(g[..., :ca], ga)
+        ops.copy_channels(g[..., ca:], gb)
+        return ga, gb
+
+
+def cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Channel concatenation of two arena tensors (the decoder's skip connections, diffusion_model_unet.py:1232,1340,1461)."""
+    return _Cat.apply(a, b)

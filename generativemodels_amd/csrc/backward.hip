@@ -210,14 +210,34 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const GmWgradDesc p,
              ((unsigned)valid << 16) | ((dst >> 4) << 17);
   }
   uint4 xreg[XI], greg[GI];
+  // tile coordinates of the next tile to load, advanced by nsplit tiles with mixed-radix carries (decoding tile -> (n, td, th, tw) with
+  // 64-bit divisions cost ~600 scalar instructions per tile)
+  int c_tw = 0, c_th = 0, c_td = 0, c_n = 0, s_tw = 0, s_th = 0, s_td = 0, s_n = 0;
+  if (KHW != 1) {
+    long long t = split;
+    c_tw = (int)(t % ntw); t /= ntw;
+    c_th = (int)(t % nth); t /= nth;
+    c_td = (int)(t % ntd); t /= ntd;
+    c_n = (int)t;
+    t = nsplit;
+    s_tw = (int)(t % ntw); t /= ntw;
+    s_th = (int)(t % nth); t /= nth;
+    s_td = (int)(t % ntd); t /= ntd;
+    s_n = (int)t;
+  }
   auto load_tile = [&](long long tile) __attribute__((always_inline)) {
-    int n = 0, od0 = 0, oh0 = 0, ow0 = 0;
+    const int n = c_n, od0 = c_td * TD, oh0 = c_th * TH, ow0 = c_tw * TW;
     if (KHW != 1) {
-      long long t = tile;
-      ow0 = (int)(t % ntw) * TW; t /= ntw;
-      oh0 = (int)(t % nth) * TH; t /= nth;
-      od0 = (int)(t % ntd) * TD; t /= ntd;
-      n = (int)t;
+      c_tw += s_tw;
+      int carry = c_tw >= ntw ? 1 : 0;
+      c_tw -= carry * ntw;
+      c_th += s_th + carry;
+      carry = c_th >= nth ? 1 : 0;
+      c_th -= carry * nth;
+      c_td += s_td + carry;
+      carry = c_td >= ntd ? 1 : 0;
+      c_td -= carry * ntd;
+      c_n += s_n + carry;
     }
     const int ud0 = S * od0 - p.pd + kdi, uh0 = S * oh0 - p.ph, uw0 = S * ow0 - p.pw;
     const long long flat0 = tile * (GROWS * TW);
@@ -669,5 +689,28 @@ extern "C" int gm_stats_colsum(const double* stats, int N, int C, float* out, in
   if (C == 0 || N == 0) return 0;
   const int total = per_sample ? N * C : C;
   stats_colsum_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(stats, N, C, out, per_sample);
+  GM_LAUNCH_CHECK();
+}
+
+// dS[row][j] = scale * P[row][j] * (dP[row][j] - sum_k dP[row][k] P[row][k]): the softmax backward of attention scores S = scale Q K^T
+// (torch softmax autograd as used by diffusion_model_unet.py:143-153, 407-415).  One wave per row, fp32.
+__global__ __launch_bounds__(64) void softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dP, float* __restrict__ dS, int V,
+                                                        float scale) {
+  const long long row = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* pr = P + row * (long long)V;
+  const float* dp = dP + row * (long long)V;
+  float dot = 0.f;
+  for (int j = lane; j < V; j += 64) dot += pr[j] * dp[j];
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  float* out = dS + row * (long long)V;
+  for (int j = lane; j < V; j += 64) out[j] = scale * pr[j] * (dp[j] - dot);
+}
+
+extern "C" int gm_softmax_bwd(const float* probs, const float* dprobs, float* dscores, long long rows, int V, float scale, void* stream) {
+  GM_REQUIRE(probs && dprobs && dscores, "null pointer");
+  GM_REQUIRE(V > 0 && rows < (1LL << 31), "bad geometry");
+  if (rows == 0) return 0;
+  softmax_bwd_kernel<<<(unsigned)rows, 64, 0, (hipStream_t)stream>>>(probs, dprobs, dscores, V, scale);
   GM_LAUNCH_CHECK();
 }

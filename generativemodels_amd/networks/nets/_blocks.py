@@ -115,6 +115,18 @@ class AttentionBlock(nn.Module):
         o = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], self.num_heads, self.scale, res=xt)
         return o.reshape(x.shape)
 
+    def run_train(self, x: torch.Tensor) -> torch.Tensor:
+        """The same block with gradients (generativemodels_amd.autograd): GroupNorm, three projections, attention, residual."""
+        from ... import autograd as A
+
+        n = self.norm
+        t = tokens(A.group_norm_act(x, n.weight, n.bias, n.num_groups, n.eps, "none"))
+        q = A.linear(t, self.to_q.weight, self.to_q.bias)
+        k = A.linear(t, self.to_k.weight, self.to_k.bias)
+        v = A.linear(t, self.to_v.weight, self.to_v.bias)
+        o = A.attention(q, k, v, self.num_heads, self.scale)
+        return A.add(o, tokens(x)).reshape(x.shape)
+
 
 class ResnetBlock(nn.Module):
     """GN -> SiLU -> conv3 (+ timestep row) -> GN -> SiLU -> conv3 -> + skip(x).

@@ -362,6 +362,63 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
             return ops.to_channels_first(y)
 
 
+def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+    """DiffusionModelUNet.forward with gradients (the reference's training step differentiates the same
+    forward through torch autograd: ddpm_training_ddp.py:249-270).  Every layer runs native kernels in both directions
+    (generativemodels_amd.autograd).  Covered: the unconditioned network (AttentionBlock levels, strided-convolution / nearest +
+    convolution resampling); cross-attention conditioning, class embeddings and resblock_updown are inference-only for now."""
+    from ... import autograd as A
+
+    if self.with_conditioning or self.num_class_embeds is not None:
+        raise NotImplementedError("forward_train covers the unconditioned DiffusionModelUNet")
+    if timesteps.ndim != 1 or timesteps.shape[0] not in (1, x.shape[0]):
+        raise ValueError("timesteps must be 1-D with one entry, or one per batch element")
+    ops.require_device(x)
+    dtype = self.conv_in.conv.weight.dtype
+    if x.dtype != dtype:
+        raise TypeError(f"input dtype {x.dtype} does not match the model dtype {dtype}")
+    t_emb = ops.timestep_embedding(timesteps.to(x.device), self.block_out_channels[0], dtype=dtype)
+    l0, l2 = self.time_embed[0], self.time_embed[2]
+    emb = A.linear(torch.nn.functional.silu(A.linear(t_emb[None], l0.weight, l0.bias)), l2.weight, l2.bias)[0]  # [B_t, 4 C0]
+
+    def resample(blk, h):
+        if isinstance(blk, ResnetBlock):
+            raise NotImplementedError("forward_train: resblock_updown is inference-only for now")
+        if isinstance(blk, _Downsample):
+            c = blk.op
+            return A.conv(h, c.conv.weight, c.conv.bias, kernel=3, stride=2, padding=c.padding)
+        return A.upsample_conv(h, blk.conv.conv.weight, blk.conv.conv.bias)
+
+    ci = self.conv_in
+    h = A.conv(A.to_arena(x), ci.conv.weight, ci.conv.bias, kernel=3, stride=1, padding=1)
+    skips = [h]
+    for st in self.down_blocks:
+        for j, rb in enumerate(st.resnets):
+            h = rb.run_train(h, emb)
+            if st.attentions is not None:
+                h = st.attentions[j].run_train(h)
+            skips.append(h)
+        if st.resampler_name == "downsampler":
+            h = resample(st.downsampler, h)
+            skips.append(h)
+    mb = self.middle_block
+    h = mb.resnet_2.run_train(mb.attention.run_train(mb.resnet_1.run_train(h, emb)), emb)
+    for st in self.up_blocks:
+        for j, rb in enumerate(st.resnets):
+            h = rb.run_train(A.cat(h, skips.pop()), emb)
+            if st.attentions is not None:
+                h = st.attentions[j].run_train(h)
+        if st.resampler_name == "upsampler":
+            h = resample(st.upsampler, h)
+    n = self.out[0]
+    h = A.group_norm_act(h, n.weight, n.bias, n.num_groups, n.eps, "silu")
+    co = self.out[2]
+    return A.from_arena(A.conv(h, co.conv.weight, co.conv.bias, kernel=3, stride=1, padding=1))
+
+
+DiffusionModelUNet.forward_train = _forward_train
+
+
 def _add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a + b for two dense arena tensors of the same shape (ControlNet residual hook, diffusion_model_unet.py:1917-1932)."""
     ones = torch.ones(a.shape[0], dtype=torch.float32, device=a.device)

@@ -784,6 +784,18 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, kernel, stride=1, padding=0, o
     k, s_, p_ = tup(kernel), tup(stride), tup(padding)
     if len(set(k)) != 1 or len(set(s_)) != 1:
         raise ValueError("conv_wgrad: kernel and stride must be the same on every axis")
+    vec = 16 // x.element_size()
+    if x.shape[-1] % vec or gy.shape[-1] % vec or arena_ld(x) % vec or arena_ld(gy) % vec or x.data_ptr() % 16 or gy.data_ptr() % 16:
+        # ragged channel counts (the 1-channel input / output convolutions): zero-pad the channels to one 16-byte vector
+        def padded(t):
+            cp = (t.shape[-1] + vec - 1) // vec * vec
+            z = torch.zeros((*t.shape[:-1], cp), dtype=t.dtype, device=t.device)
+            copy_channels(t, z[..., :t.shape[-1]])
+            return z
+        if out is not None or accumulate:
+            raise ValueError("conv_wgrad: out / accumulate need channel counts that are multiples of a 16-byte vector")
+        full = conv_wgrad(padded(x), padded(gy), kernel, stride, padding)
+        return full[:gy.shape[-1], :x.shape[-1]].contiguous()
     cin, cout = x.shape[-1], gy.shape[-1]
     d = GmWgradDesc()
     d.x, d.x_ld, d.gy, d.gy_ld = x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy)
@@ -857,6 +869,18 @@ def gn_backward(x: torch.Tensor, gy: torch.Tensor, scale: torch.Tensor, shift: t
                                 shift.data_ptr(), ss_ld, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), n, v, c, a,
                                 dt_code(x.dtype), _stream()), "gm_gn_bwd_apply")
     return dx, dgamma, dbeta
+
+
+def softmax_bwd(probs: torch.Tensor, dprobs: torch.Tensor, scale: float) -> torch.Tensor:
+    """scale * P * (dP - rowsum(dP * P)) on fp32 (rows, V) matrices: the gradient of the scores scale * Q K^T through the softmax."""
+    require_device(probs, dprobs)
+    if probs.shape != dprobs.shape or probs.dim() != 2 or probs.dtype != torch.float32 or dprobs.dtype != torch.float32:
+        raise ValueError("softmax_bwd expects matching fp32 (rows, V) matrices")
+    probs, dprobs = probs.contiguous(), dprobs.contiguous()
+    out = torch.empty_like(probs)
+    check(lib().gm_softmax_bwd(probs.data_ptr(), dprobs.data_ptr(), out.data_ptr(), probs.shape[0], probs.shape[1], float(scale), _stream()),
+          "gm_softmax_bwd")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -276,6 +276,10 @@ int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, long long gy_
  * embedding projection, diffusion_model_unet.py:684-686) */
 int gm_stats_colsum(const double* stats, int N, int C, float* out, int per_sample, void* stream);
 
+/* dscores = scale * probs * (dprobs - rowsum(dprobs * probs)): softmax backward of the attention scores scale * Q K^T, fp32 [rows][V]
+ * (the softmax of diffusion_model_unet.py:143-153 / 407-415 under torch autograd) */
+int gm_softmax_bwd(const float* probs, const float* dprobs, float* dscores, long long rows, int V, float scale, void* stream);
+
 /* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */
 int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long long* indices, long long tokens,
                  int num_embeddings, int dim, int dtype, void* stream);

@@ -185,3 +185,91 @@ def test_resnet_block_trains_like_the_torch_reference(cin, cout, dtype):
     for name, p in blk.named_parameters():
         assert p.grad is not None, name
         _close(p.grad, ref[name].grad, tol * 2, f"block d {name}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("b,l,heads,dh", [(2, 64, 2, 16), (1, 200, 1, 64), (1, 512, 4, 8)])
+def test_attention_backward(b, l, heads, dh, dtype):
+    """autograd.attention: flash-attention forward, composed fp32 backward (scores, softmax, gm_softmax_bwd, GEMM / weight-gradient
+    kernels) vs torch autograd in fp64."""
+    from generativemodels_amd import autograd as A
+    c = heads * dh
+    q, k, v, go = (_rand((b, l, c), 351 + i).to(dtype) for i in range(4))
+    scale = 1 / math.sqrt(dh)
+    ref = [t.double().requires_grad_(True) for t in (q, k, v)]
+    qh, kh, vh = (t.reshape(b, l, heads, dh).transpose(1, 2) for t in ref)
+    o_ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(b, l, c)
+    (o_ref * go.double()).sum().backward()
+    dev = [t.to(DEV).requires_grad_(True) for t in (q, k, v)]
+    o = A.attention(*dev, heads, scale)
+    tol = 1e-4 if dtype == torch.float32 else 1.5e-2
+    _close(o, o_ref, tol, "attention forward")
+    o.backward(go.to(DEV))
+    for name, d, r in zip("qkv", dev, ref):
+        _close(d.grad, r.grad, tol, f"attention d{name}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("sp", [(4, 5, 6), (7, 9)])
+def test_upsample_conv_backward(sp, dtype):
+    from generativemodels_amd import autograd as A
+    nsp = len(sp)
+    n, c = 2, 32
+    x = _rand((n, c, *sp), 361).to(dtype)
+    w = (_rand((c, c) + (3,) * nsp, 362) / math.sqrt(c * 3 ** nsp)).to(dtype)
+    bias = _rand((c,), 363).to(dtype)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, bias))
+    y_ref = _CONVF[nsp](F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, br, padding=1)
+    gy = _rand(tuple(y_ref.shape), 364).to(dtype)
+    (y_ref * gy.double()).sum().backward()
+    xd = _cl(x).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    y = A.upsample_conv(xd, wd, bd)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    _close(_cf(y), y_ref, tol, "upsample conv forward")
+    y.backward(_cl(gy))
+    _close(_cf(xd.grad), xr.grad, tol * 5, "upsample conv dx")
+    _close(wd.grad, wr.grad, 2e-4 if dtype == torch.float32 else 1.5e-2, "upsample conv dw")
+    _close(bd.grad, br.grad, 2e-4 if dtype == torch.float32 else 1.5e-2, "upsample conv db")
+
+
+@pytest.mark.parametrize("dtype,spatial_dims", [(torch.float32, 3), (torch.float32, 2), (torch.bfloat16, 3)])
+def test_unet_training_gradients_match_the_oracle_autograd(dtype, spatial_dims):
+    """DiffusionModelUNet.forward_train: d(loss)/d(every parameter) of a small unconditioned UNet (attention at the deep level, strided
+    and nearest+conv resampling, 1-channel input / output convolutions) against torch autograd through the CPU oracle
+    (oracle/restatement.py: the reference forward, pinned to reference outputs) in fp64."""
+    import restatement as R
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    cfg = dict(spatial_dims=spatial_dims, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 64),
+               attention_levels=(False, True), num_head_channels=32, norm_num_groups=32)
+    torch.manual_seed(11)
+    model = DiffusionModelUNet(**cfg)
+    R.derandomize_zeros(model, seed=5)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(dtype).float())
+    sp = (8,) * spatial_dims
+    x = _rand((2, 1, *sp), 371).to(dtype)
+    t = torch.tensor([17, 803])
+    target = _rand((2, 1, *sp), 372).to(dtype)
+    sd = {k_: v_.detach().double().requires_grad_(True) for k_, v_ in model.state_dict().items()}
+    y_ref = R.unet_forward(sd, cfg, x.double(), t)
+    F.mse_loss(y_ref, target.double()).backward()
+
+    model = model.to(DEV).to(dtype)
+    y = model.forward_train(x.to(DEV), t.to(DEV))
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    _close(y, y_ref, tol, "unet train forward")
+    # the native inference forward computes the same function
+    with torch.no_grad():
+        _close(model(x.to(DEV), t.to(DEV)), y_ref, tol, "unet inference forward")
+    F.mse_loss(y.float(), target.to(DEV).float()).backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if "proj_attn" in name:  # constructed but never applied by the reference forward (SURVEY.md fact 4): no gradient
+            assert p.grad is None
+            continue
+        assert p.grad is not None, name
+        _close(p.grad, sd[name].grad, tol * 3, f"d {name}")
+        checked += 1
+    assert checked > 40
