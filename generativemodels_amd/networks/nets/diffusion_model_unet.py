@@ -416,7 +416,14 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tens
     return A.from_arena(A.conv(h, co.conv.weight, co.conv.bias, kernel=3, stride=1, padding=1))
 
 
+def _supports_training(self) -> bool:
+    """True when forward_train covers this configuration (DiffusionInferer.__call__ then returns a differentiable prediction)."""
+    return (not self.with_conditioning and self.num_class_embeds is None
+            and not any(isinstance(m, ResnetBlock) and (m.up or m.down) for m in self.modules()))
+
+
 DiffusionModelUNet.forward_train = _forward_train
+DiffusionModelUNet.supports_training = _supports_training
 
 
 def _add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

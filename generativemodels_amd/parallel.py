@@ -65,3 +65,108 @@ def gather_units(ids: List[int], outs: List[torch.Tensor], n_units: int, group=N
     if sorted(table) != list(range(n_units)):
         raise RuntimeError("some units are missing after the gather")
     return [table[i] for i in range(n_units)]
+
+
+class GradientReducer:
+    """Batch-sharded data-parallel training (BASELINE config C4): every rank holds a replica, runs forward / backward on
+    its own shard of the batch, and the gradients are averaged with ONE exchange per step -- a bucketed all-reduce over
+    torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; gloo on CPU for the tests).  It replaces what the reference gets
+    from torch DistributedDataParallel(find_unused_parameters=True) (tutorials/generative/distributed_training/ddpm_training_ddp.py:199).
+
+    * Buckets of ~`bucket_mb` MB are formed in reverse parameter order (the order gradients become ready in backward).
+    * A bucket is launched as soon as its last gradient has been accumulated (post-accumulate-grad hooks): packed into a flat buffer and
+      all-reduced on a SIDE stream that waits for the producing stream's event, so the exchange overlaps the rest of backward.
+      xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce of the 167 MB of fp32 gradients of the 41.7 M-parameter UNet is
+      ~1.9 ms per-link bound, far below one backward pass -- few, large buckets are the right shape.
+    * Parameters that receive no gradient (the reference's never-applied `proj_attn`) contribute zeros to their bucket
+      and keep `grad = None`, like DDP's unused-parameter handling.
+    * `finish()` (before optimizer.step) waits for the exchanges, divides by the world size and writes the averaged gradients back.
+    With world_size 1 (or torch.distributed uninitialised) every call is a no-op."""
+
+    def __init__(self, params, bucket_mb: float = 25.0, group=None) -> None:
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets: List[List[torch.nn.Parameter]] = []
+        cap = int(bucket_mb * (1 << 20))
+        cur, cur_bytes, cur_key = [], 0, None
+        for p in reversed(self.params):
+            key = (p.dtype, p.device)
+            nbytes = p.numel() * p.element_size()
+            if cur and (key != cur_key or cur_bytes + nbytes > cap):
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+            cur_key = key
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._pending = [0] * len(self.buckets)
+        self._launched: List[Optional[tuple]] = [None] * len(self.buckets)
+        self._side = None
+        self._handles = []
+        if self.active:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        self.reset()
+
+    def reset(self) -> None:
+        """Call before every backward pass (done by `finish`)."""
+        self._pending = [len(b) for b in self.buckets]
+        self._launched = [None] * len(self.buckets)
+
+    def _on_grad(self, p) -> None:
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            self._launch(i)
+
+    def _launch(self, i: int) -> None:
+        bucket = self.buckets[i]
+        dev = bucket[0].device
+        flat = torch.zeros(sum(p.numel() for p in bucket), dtype=bucket[0].dtype, device=dev)
+        if dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            ready = torch.cuda.current_stream(dev).record_event()
+            self._side.wait_event(ready)
+            ctx = torch.cuda.stream(self._side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            off = 0
+            for p in bucket:
+                if p.grad is not None:
+                    flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                    if dev.type == "cuda":
+                        p.grad.record_stream(self._side)
+                off += p.numel()
+            work = self._dist.all_reduce(flat, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._launched[i] = (flat, work)
+
+    def finish(self) -> None:
+        """Wait for every exchange, average, write the gradients back; launches the buckets whose parameters never all became ready."""
+        if not self.active:
+            return
+        for i in range(len(self.buckets)):
+            if self._launched[i] is None:
+                self._launch(i)
+        for i, bucket in enumerate(self.buckets):
+            flat, work = self._launched[i]
+            work.wait()  # on CUDA: makes the current stream wait for the collective
+            dev = bucket[0].device
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).wait_stream(self._side)
+            flat.div_(self.world)
+            off = 0
+            for p in bucket:
+                if p.grad is not None:
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
+        self.reset()

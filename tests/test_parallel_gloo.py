@@ -68,3 +68,57 @@ def test_two_rank_sampling_matches_single_process():
     assert ids1 == list(range(n_units))
     for a, b in zip(gathered, ref):
         assert torch.equal(a, b)  # same volumes as a single-process run, in global order
+
+
+def _reducer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import torch.nn as nn
+    from generativemodels_amd.parallel import GradientReducer, shard_range
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        model = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 3))
+        unused = nn.Linear(4, 4)  # never applied: like the reference's proj_attn it gets no gradient
+        params = list(model.parameters()) + list(unused.parameters())
+        red = GradientReducer(params, bucket_mb=0.0005)  # ~500-byte buckets: several exchanges per step
+        assert red.active and len(red.buckets) >= 3
+        data = torch.randn(8, 6, generator=torch.Generator().manual_seed(5))
+        target = torch.randn(8, 3, generator=torch.Generator().manual_seed(6))
+        lo, hi = shard_range(8, rank, world)
+        for _ in range(2):  # two steps: the reducer re-arms itself
+            for p in params:
+                p.grad = None
+            loss = torch.nn.functional.mse_loss(model(data[lo:hi]), target[lo:hi])
+            loss.backward()
+            red.finish()
+        q.put((rank, [None if p.grad is None else p.grad.clone() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_matches_the_full_batch():
+    """GradientReducer (bucketed, hook-driven all-reduce + averaging) over gloo, world_size 2: the averaged shard gradients equal the
+    single-process gradients of the full batch; a parameter without a gradient stays None."""
+    import torch.multiprocessing as mp
+    import torch.nn as nn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(3)
+    model = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 3))
+    data = torch.randn(8, 6, generator=torch.Generator().manual_seed(5))
+    target = torch.randn(8, 3, generator=torch.Generator().manual_seed(6))
+    torch.nn.functional.mse_loss(model(data), target).backward()
+    want = [p.grad for p in model.parameters()]
+    for rank in (0, 1):
+        grads = got[rank]
+        assert grads[-1] is None and grads[-2] is None
+        for g, w in zip(grads[:len(want)], want):
+            assert torch.allclose(g, w, atol=1e-6), (g - w).abs().max()

@@ -1,0 +1,114 @@
+"""GPU: one training step of BASELINE config C4 on ONE MI355X (the per-rank work of the batch-sharded DDP job): a frozen AutoencoderKL
+encodes B x 1 x S^3 volumes to B x 4 x (S/8)^3 latents, DiffusionInferer.__call__ noises them and runs the 41.7 M-parameter latent UNet
+forward WITH gradients (native kernels in both directions), MSE loss, backward, GradientReducer.finish(), Adam.
+usage: python tools/bench_train.py [size=256] [batch=1] [dtype=bf16|fp32] [steps=3]     (under torchrun: one process per GPU, RCCL)"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+
+from bench import rerandomize_zero_params
+from generativemodels_amd import ops
+from generativemodels_amd.inferers import LatentDiffusionInferer
+from generativemodels_amd.networks.nets import AutoencoderKL, DiffusionModelUNet
+from generativemodels_amd.networks.schedulers import DDPMScheduler
+from generativemodels_amd.parallel import GradientReducer
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "fp32") else torch.bfloat16
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+local = int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("nccl")
+dev = f"cuda:{local}"
+torch.manual_seed(0)
+ae = AutoencoderKL(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4, num_channels=(64, 128, 128, 128), num_res_blocks=2,
+                   attention_levels=(False, False, False, False), with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False).eval().to(dev, dt)
+for p in ae.parameters():
+    p.requires_grad_(False)
+unet = DiffusionModelUNet(spatial_dims=3, in_channels=4, out_channels=4, num_channels=(64, 128, 256), attention_levels=(False, True, True),
+                          num_res_blocks=2, num_head_channels=(0, 128, 256))
+unet.load_state_dict(rerandomize_zero_params({k: v.clone() for k, v in unet.state_dict().items()}))
+unet = unet.to(dev, dt)
+sched = DDPMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205)
+inf = LatentDiffusionInferer(sched, scale_factor=1.0)
+opt = torch.optim.Adam(unet.parameters(), lr=1e-5)
+red = GradientReducer(unet.parameters())
+g = torch.Generator().manual_seed(100 + rank)
+imgs = torch.randn((batch, 1, size, size, size), generator=g).to(dev, dt)
+lat = size // 8
+
+
+def step():
+    noise = torch.randn((batch, 4, lat, lat, lat), generator=g).to(dev, dt)
+    t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
+    opt.zero_grad(set_to_none=True)
+    pred = inf(inputs=imgs, autoencoder_model=ae, diffusion_model=unet, noise=noise, timesteps=t)
+    loss = F.mse_loss(pred.float(), noise.float())
+    loss.backward()
+    red.finish()
+    opt.step()
+    return loss
+
+
+def phase_times():
+    """One instrumented step: encode / forward / backward / optimizer, each bracketed by synchronize."""
+    out = {}
+    noise = torch.randn((batch, 4, lat, lat, lat), generator=g).to(dev, dt)
+    t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
+    opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    with torch.no_grad():
+        z = ae.encode_stage_2_inputs(imgs)
+    torch.cuda.synchronize(); out["encode_ms"] = (time.perf_counter() - t0) * 1e3; t0 = time.perf_counter()
+    noisy = sched.add_noise(z, noise, t)
+    pred = unet.forward_train(noisy, t)
+    loss = F.mse_loss(pred.float(), noise.float())
+    torch.cuda.synchronize(); out["forward_ms"] = (time.perf_counter() - t0) * 1e3; t0 = time.perf_counter()
+    loss.backward()
+    torch.cuda.synchronize(); out["backward_ms"] = (time.perf_counter() - t0) * 1e3; t0 = time.perf_counter()
+    red.finish()
+    opt.step()
+    torch.cuda.synchronize(); out["reduce_optimizer_ms"] = (time.perf_counter() - t0) * 1e3
+    return {k: round(v, 2) for k, v in out.items()}
+
+
+losses = [float(step()) for _ in range(2)]  # warm-up (weight packing, allocator)
+torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
+t0 = time.perf_counter()
+for _ in range(steps):
+    losses.append(float(step()))
+torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
+dt_step = (time.perf_counter() - t0) / steps
+phases = phase_times()
+ops.start_profile()
+noise = torch.randn((batch, 4, lat, lat, lat), generator=g).to(dev, dt)
+tt = torch.randint(0, 1000, (batch,), generator=g).to(dev)
+pred = unet.forward_train(sched.add_noise(torch.randn_like(noise), noise, tt), tt)
+F.mse_loss(pred.float(), noise.float()).backward()
+agg = {}
+for name, meta, ms in ops.stop_profile():
+    a = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+    a["launches"] += 1; a["ms"] += ms; a["flops"] += meta["flops"]
+if rank == 0:
+    print(json.dumps(dict(config=f"C4 per-rank training step: {batch} x 1 x {size}^3 volumes -> {batch} x 4 x {lat}^3 latents, 41.7 M-parameter UNet",
+                          dtype=str(dt).split(".")[-1], n_gpus=world, step_ms=round(dt_step * 1e3, 2),
+                          volumes_per_s=round(world * batch / dt_step, 3), losses=[round(v, 4) for v in losses], phases=phases,
+                          unet_fwd_bwd_breakdown={k: dict(launches=v["launches"], ms=round(v["ms"], 3), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1))
+                                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]})))
+if world > 1:
+    dist.destroy_process_group()
