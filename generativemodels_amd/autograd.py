@@ -33,7 +33,9 @@ def _tup(v, n):
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, rowvec, res, kernel, stride, padding, pad_hi):
-        y = ops.conv(x, weight, bias, kernel=kernel, stride=stride, padding=padding, pad_hi=pad_hi, rowvec=rowvec, res=res)
+        # want_stats: the fast kernels leave the per-channel statistics of y on the tensor, so the GroupNorm that follows needs no pass
+        y = ops.conv(x, weight, bias, kernel=kernel, stride=stride, padding=padding, pad_hi=pad_hi, rowvec=rowvec, res=res,
+                     want_stats=x.dim() >= 4)
         ctx.save_for_backward(x, weight)
         ctx.geom = (kernel, stride, padding, pad_hi)
         ctx.bias_dtype = None if bias is None else bias.dtype
