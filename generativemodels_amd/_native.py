@@ -60,6 +60,13 @@ class GmAttnDesc(C.Structure):
                 ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll)]
 
 
+class GmAttnBwdDesc(C.Structure):
+    _fields_ = [("q", c_vp), ("q_ld", c_ll), ("k", c_vp), ("k_ld", c_ll), ("v", c_vp), ("v_ld", c_ll), ("o", c_vp), ("o_ld", c_ll),
+                ("go", c_vp), ("go_ld", c_ll), ("dq", c_vp), ("dq_ld", c_ll), ("dk", c_vp), ("dk_ld", c_ll), ("dv", c_vp), ("dv_ld", c_ll),
+                ("B", C.c_int), ("H", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int), ("dh", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
+                ("workspace", c_vp), ("workspace_bytes", c_ll)]
+
+
 class GmWgradDesc(C.Structure):
     _fields_ = [("x", c_vp), ("x_ld", c_ll), ("gy", c_vp), ("gy_ld", c_ll), ("dw", c_vp), ("workspace", c_vp), ("workspace_bytes", c_ll),
                 ("N", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Ds", C.c_int), ("Hs", C.c_int), ("Ws", C.c_int),
@@ -117,6 +124,8 @@ PROTOTYPES = {
     "gm_gn_bwd_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, C.c_int, c_ll, C.c_int, C.c_int,
                                   C.c_int, c_vp]),
     "gm_stats_colsum": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
+    "gm_attention_backward_workspace_bytes": (c_ll, [C.POINTER(GmAttnBwdDesc)]),
+    "gm_attention_backward": (C.c_int, [C.POINTER(GmAttnBwdDesc), c_vp]),
     "gm_softmax_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_float, c_vp]),
     "gm_vq_argmin": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_vq_gather_workspace_bytes": (c_ll, []),

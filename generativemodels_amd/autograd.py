@@ -9,9 +9,9 @@ Every function here works on arena tensors (N, *spatial, C) and runs native kern
   group_norm_act  forward: per-channel statistics -> (scale, shift) -> one apply pass (+ SiLU)
                   backward: gm_gn_bwd_stats / _finalize / _apply (dx, dgamma, dbeta)
   upsample_conv   nearest 2x folded into the convolution; backward: dgrad on the fine grid, 2x sum-pool; dW against the upsampled input
-  attention       forward: the flash-attention kernel; backward: per (sample, head) in fp32 -- scores, softmax, dV = P^T dO, dP = dO V^T,
-                  dS (gm_softmax_bwd), dQ = dS K, dK = dS^T Q -- on the GEMM / weight-gradient kernels (L x L matrices are materialised:
-                  sequences up to 8192 tokens; a fused flash backward is the follow-up)
+  attention       forward: the flash-attention kernel; backward: the fused flash backward gm_attention_backward (head dims 16 .. 256: scores
+                  recomputed per tile, nothing L x L stored); other head dims per (sample, head) in fp32 -- scores, softmax, dV = P^T dO,
+                  dP = dO V^T, dS (gm_softmax_bwd), dQ = dS K, dK = dS^T Q -- on the GEMM / weight-gradient kernels (up to 8192 tokens)
   add / cat       residual add and channel concatenation
   to_arena / from_arena   the NC[D]HW <-> N[D]HWC permutations
 There is no eager fallback: a CPU tensor raises in the first native call."""
@@ -185,17 +185,22 @@ class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, heads, scale):
         o = ops.attention(q, k, v, heads, scale)
-        ctx.save_for_backward(q, k, v)
+        ctx.save_for_backward(q, k, v, o)
         ctx.cfg = (heads, scale)
         return o
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v = ctx.saved_tensors
+        q, k, v, o = ctx.saved_tensors
         heads, scale = ctx.cfg
         b, lq, c = q.shape
         lk = k.shape[1]
         dh = c // heads
+        if dh in ops.ATTENTION_BWD_HEAD_DIMS:
+            # fused flash backward: scores recomputed tile by tile, any sequence length
+            dq, dk, dv = ops.attention_backward(q, k, v, o, go.contiguous(), heads, scale)
+            return dq, dk, dv, None, None
+        # other head dims: per (sample, head) in fp32 on the GEMM / weight-gradient kernels (materialises the L x L scores)
         if max(lq, lk) > ATTENTION_BWD_MAX_TOKENS:
             raise NotImplementedError(f"attention backward materialises the {lq} x {lk} score matrix per head: sequences above "
                                       f"{ATTENTION_BWD_MAX_TOKENS} tokens need the fused flash backward (not built yet)")

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _native as nat
-from ._native import GmAttnDesc, GmConvDesc, GmKlParams, GmStepParams, GmWgradDesc, check, lib
+from ._native import GmAttnBwdDesc, GmAttnDesc, GmConvDesc, GmKlParams, GmStepParams, GmWgradDesc, check, lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 ACT = {"none": 0, "silu": 1, "relu": 2}
@@ -869,6 +869,39 @@ def gn_backward(x: torch.Tensor, gy: torch.Tensor, scale: torch.Tensor, shift: t
                                 shift.data_ptr(), ss_ld, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), n, v, c, a,
                                 dt_code(x.dtype), _stream()), "gm_gn_bwd_apply")
     return dx, dgamma, dbeta
+
+
+ATTENTION_BWD_HEAD_DIMS = (16, 32, 64, 128, 256)
+
+
+def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, go: torch.Tensor, heads: int, scale: float):
+    """(dq, dk, dv) of o = softmax(scale q k^T) v per (batch, head) by the fused flash backward (gm_attention_backward): the scores are
+    recomputed tile by tile, nothing L x L is stored.  (B, L, heads * dh) operands (channel slices allowed), dh in ATTENTION_BWD_HEAD_DIMS."""
+    require_device(q, k, v, o, go)
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    dh = c // heads
+    if dh not in ATTENTION_BWD_HEAD_DIMS:
+        raise ValueError(f"attention_backward: head dim {dh} not in {ATTENTION_BWD_HEAD_DIMS}")
+    if o.shape != q.shape or go.shape != q.shape or k.shape != v.shape or k.shape[2] != c:
+        raise ValueError("attention_backward operand shapes are inconsistent")
+    dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
+    d = GmAttnBwdDesc()
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o), ("go", go), ("dq", dq), ("dk", dk), ("dv", dv)):
+        setattr(d, name, t.data_ptr())
+        setattr(d, name + "_ld", _kv_ld(t))
+    for t, l in ((q, lq), (o, lq), (go, lq), (k, lk), (v, lk)):
+        if t.shape[0] > 1 and t.stride(0) != l * _kv_ld(t):
+            raise ValueError("attention_backward operands must be batch-dense")
+    d.B, d.H, d.Lq, d.Lk, d.dh = b, heads, lq, lk, dh
+    d.scale, d.dtype = float(scale), dt_code(q.dtype)
+    nbytes = lib().gm_attention_backward_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    _timed(f"attention_bwd<{str(q.dtype).split('.')[-1]}>", dict(flops=14.0 * b * heads * lq * lk * dh, bytes=float(5 * q.element_size() * q.numel()),
+                                                              shape=f"B{b} H{heads} L{lq}x{lk} d{dh}"),
+           lambda: check(lib().gm_attention_backward(C.byref(d), _stream()), "gm_attention_backward"))
+    return dq, dk, dv
 
 
 def softmax_bwd(probs: torch.Tensor, dprobs: torch.Tensor, scale: float) -> torch.Tensor:

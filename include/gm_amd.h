@@ -276,6 +276,26 @@ int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, long long gy_
  * embedding projection, diffusion_model_unet.py:684-686) */
 int gm_stats_colsum(const double* stats, int N, int C, float* out, int per_sample, void* stream);
 
+/* Flash-attention backward: dq, dk, dv of o = softmax(scale q k^T) v per (batch, head) (torch autograd through
+ * diffusion_model_unet.py:143-153 / 407-415); the L x L scores are recomputed tile by tile, never stored.  o = the forward output
+ * WITHOUT the residual, go = its gradient.  head dim in {16, 32, 64, 128, 256}; fp32 accumulation and fp32 MFMA products for every
+ * storage dtype; deterministic (no atomics). */
+typedef struct GmAttnBwdDesc {
+  const void* q; long long q_ld;
+  const void* k; long long k_ld;
+  const void* v; long long v_ld;
+  const void* o; long long o_ld;
+  const void* go; long long go_ld;
+  void* dq; long long dq_ld;
+  void* dk; long long dk_ld;
+  void* dv; long long dv_ld;
+  int B, H, Lq, Lk, dh;
+  float scale;
+  int dtype;
+  void* workspace; long long workspace_bytes;  /* gm_attention_backward_workspace_bytes(d): LSE and dO.O per query */
+} GmAttnBwdDesc;
+long long gm_attention_backward_workspace_bytes(const GmAttnBwdDesc* d);
+int gm_attention_backward(const GmAttnBwdDesc* d, void* stream);
 /* dscores = scale * probs * (dprobs - rowsum(dprobs * probs)): softmax backward of the attention scores scale * Q K^T, fp32 [rows][V]
  * (the softmax of diffusion_model_unet.py:143-153 / 407-415 under torch autograd) */
 int gm_softmax_bwd(const float* probs, const float* dprobs, float* dscores, long long rows, int V, float scale, void* stream);

@@ -188,10 +188,10 @@ def test_resnet_block_trains_like_the_torch_reference(cin, cout, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("b,l,heads,dh", [(2, 64, 2, 16), (1, 200, 1, 64), (1, 512, 4, 8)])
+@pytest.mark.parametrize("b,l,heads,dh", [(2, 64, 2, 16), (1, 200, 1, 64), (1, 512, 4, 8), (1, 301, 2, 128), (2, 96, 1, 256), (1, 77, 3, 32)])
 def test_attention_backward(b, l, heads, dh, dtype):
-    """autograd.attention: flash-attention forward, composed fp32 backward (scores, softmax, gm_softmax_bwd, GEMM / weight-gradient
-    kernels) vs torch autograd in fp64."""
+    """autograd.attention: flash-attention forward; backward by the fused flash kernels (head dims 16 .. 256, ragged sequence lengths)
+    or, for other head dims, composed in fp32 from the GEMM / weight-gradient / gm_softmax_bwd kernels -- vs torch autograd in fp64."""
     from generativemodels_amd import autograd as A
     c = heads * dh
     q, k, v, go = (_rand((b, l, c), 351 + i).to(dtype) for i in range(4))
@@ -273,3 +273,28 @@ def test_unet_training_gradients_match_the_oracle_autograd(dtype, spatial_dims):
         _close(p.grad, sd[name].grad, tol * 3, f"d {name}")
         checked += 1
     assert checked > 40
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flash_attention_backward_cross_lengths(dtype):
+    """gm_attention_backward with Lq != Lk (cross-attention shapes) and operands that are channel slices of a stacked q|k|v buffer."""
+    ops = _ops()
+    b, lq, lk, heads, dh = 2, 100, 72, 2, 32
+    c = heads * dh
+    scale = 1 / math.sqrt(dh)
+    qkv = _rand((b, lq, 3 * c), 381).to(dtype)
+    kv = _rand((b, lk, 2 * c), 382).to(dtype)
+    go = _rand((b, lq, c), 383).to(dtype)
+    q, k, v = qkv[..., c:2 * c], kv[..., :c], kv[..., c:]
+    ref = [t.double().requires_grad_(True) for t in (q, k, v)]
+    qh = ref[0].reshape(b, lq, heads, dh).transpose(1, 2)
+    kh, vh = (t.reshape(b, lk, heads, dh).transpose(1, 2) for t in ref[1:])
+    o_ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(b, lq, c)
+    (o_ref * go.double()).sum().backward()
+    qkv_d, kv_d = qkv.to(DEV), kv.to(DEV)
+    qd, kd, vd = qkv_d[..., c:2 * c], kv_d[..., :c], kv_d[..., c:]
+    o = ops.attention(qd, kd, vd, heads, scale)
+    dq, dk, dv = ops.attention_backward(qd, kd, vd, o, go.to(DEV), heads, scale)
+    tol = 1e-4 if dtype == torch.float32 else 1.5e-2
+    for name, got, r in zip("qkv", (dq, dk, dv), ref):
+        _close(got, r.grad, tol, f"flash backward d{name}")
