@@ -196,7 +196,12 @@ class _Attention(torch.autograd.Function):
         b, lq, c = q.shape
         lk = k.shape[1]
         dh = c // heads
-        if dh in ops.ATTENTION_BWD_HEAD_DIMS:
+        # Measured on MI355X (tools/cmp_attention_backward.py): the fused kernels own 64 rows per work-group, so ONE head of a few
+        # thousand tokens leaves most CUs idle (L = 4096, d = 128: 1.9 ms fused vs 0.86 ms composed), while many (sample, head) pairs
+        # favour them (2 x 4 heads of 1024 tokens: 0.21 vs 2.5 ms) and long sequences leave no choice (the composed path stores L x L).
+        composed_ok = dh % 4 == 0 and lq % 4 == 0 and lk % 4 == 0 and max(lq, lk) <= ATTENTION_BWD_MAX_TOKENS
+        prefer_composed = composed_ok and b * heads <= 2 and max(lq, lk) >= 2048
+        if dh in ops.ATTENTION_BWD_HEAD_DIMS and not prefer_composed:
             # fused flash backward: scores recomputed tile by tile, any sequence length
             dq, dk, dv = ops.attention_backward(q, k, v, o, go.contiguous(), heads, scale)
             return dq, dk, dv, None, None

@@ -46,7 +46,7 @@ template <> __device__ __forceinline__ void ab_store4<bf16_raw>(bf16_raw* p, flo
 template <typename T, int DH>
 __device__ __forceinline__ void ab_stage(const T* base, long long ld, int row0, int L, float* lds, int tid) {
   constexpr int PITCH = DH + 4;
-  for (int it = tid; it < AB_ROWS * (DH / 4); it += 256) {
+  for (int it = tid; it < AB_ROWS * (DH / 4); it += (int)blockDim.x) {
     const int row = it / (DH / 4), c4 = it % (DH / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + row < L) v = ab_load4<T>(base + (long long)(row0 + row) * ld + c4 * 4);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_bwd_pre_kernel(const GmAttnBwdDesc p
   float* ldsK = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, qg = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-  const int my_q = blockIdx.x * 64 + wave * 16 + l15;
+  const int my_q = blockIdx.x * ((int)blockDim.x >> 2) + wave * 16 + l15;
   const bool q_ok = my_q < p.Lq;
   const T* Qb = reinterpret_cast<const T*>(p.q) + (long long)b * p.Lq * p.q_ld + h * p.dh;
   const T* Kb = reinterpret_cast<const T*>(p.k) + (long long)b * p.Lk * p.k_ld + h * p.dh;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const GmAttnBwdDesc p,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, qg = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
   const int c0 = blockIdx.z * (DH / CS);
-  const int my_q = blockIdx.x * 64 + wave * 16 + l15;
+  const int my_q = blockIdx.x * ((int)blockDim.x >> 2) + wave * 16 + l15;
   const bool q_ok = my_q < p.Lq;
   const long long qrow = (long long)b * p.Lq + (q_ok ? my_q : 0);
   const T* Kb = reinterpret_cast<const T*>(p.k) + (long long)b * p.Lk * p.k_ld + h * p.dh;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const GmAttnBwdDesc p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, qg = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
   const int c0 = blockIdx.z * (DH / CS);
-  const int my_k = blockIdx.x * 64 + wave * 16 + l15;
+  const int my_k = blockIdx.x * ((int)blockDim.x >> 2) + wave * 16 + l15;
   const bool k_ok = my_k < p.Lk;
   const long long krow = (long long)b * p.Lk + (k_ok ? my_k : 0);
   const T* Qb = reinterpret_cast<const T*>(p.q) + (long long)b * p.Lq * p.q_ld + h * p.dh;
@@ -283,9 +283,15 @@ static void launch_attn_bwd(const GmAttnBwdDesc& d, hipStream_t st) {
     ab_set_lds(attn_bwd_dkv_kernel<T, DH, CS>);
     attr_set = true;
   }
-  attn_bwd_pre_kernel<T, DH><<<dim3((d.Lq + 63) / 64, d.B * d.H), 256, tile, st>>>(d, lse, dsum);
-  attn_bwd_dq_kernel<T, DH, CS><<<dim3((d.Lq + 63) / 64, d.B * d.H, CS), 256, 2 * tile, st>>>(d, lse, dsum);
-  attn_bwd_dkv_kernel<T, DH, CS><<<dim3((d.Lk + 63) / 64, d.B * d.H, CS), 256, 2 * tile + 2 * AB_ROWS * sizeof(float), st>>>(d, lse, dsum);
+  // own rows per work-group: 64 (4 waves share every streamed tile).  Measured at L = 4096, d = 128, one head (64 work-groups on 256
+  // CUs): one-wave work-groups (256 of them) were 2x SLOWER -- a lone wave staging whole tiles costs more than the idle CUs; short
+  // single-head problems are better served by the composed backward (autograd.py), long or multi-head ones fill the chip anyway.
+  auto waves = [&](int, int) { return 4; };
+  const int wq0 = waves(d.Lq, 1), wq = waves(d.Lq, CS), wk = waves(d.Lk, CS);
+  attn_bwd_pre_kernel<T, DH><<<dim3((d.Lq + 16 * wq0 - 1) / (16 * wq0), d.B * d.H), 64 * wq0, tile, st>>>(d, lse, dsum);
+  attn_bwd_dq_kernel<T, DH, CS><<<dim3((d.Lq + 16 * wq - 1) / (16 * wq), d.B * d.H, CS), 64 * wq, 2 * tile, st>>>(d, lse, dsum);
+  attn_bwd_dkv_kernel<T, DH, CS><<<dim3((d.Lk + 16 * wk - 1) / (16 * wk), d.B * d.H, CS), 64 * wk, 2 * tile + 2 * AB_ROWS * sizeof(float), st>>>(
+      d, lse, dsum);
 }
 
 template <typename T>

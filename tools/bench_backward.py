@@ -59,3 +59,23 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def attention_rows():
+    """Fused flash backward vs the forward kernel at the training (C4) and sampling (C2) attention shapes."""
+    dtype = torch.bfloat16
+    import math
+    for b, l, heads, dh in [(1, 4096, 1, 128), (1, 512, 1, 256), (1, 32768, 1, 256)]:
+        c = heads * dh
+        q, k, v, go = (torch.randn((b, l, c), device=DEV).to(dtype) for _ in range(4))
+        scale = 1 / math.sqrt(dh)
+        o = ops.attention(q, k, v, heads, scale)
+        t_f = timeit(lambda: ops.attention(q, k, v, heads, scale), reps=3, warm=1)
+        t_b = timeit(lambda: ops.attention_backward(q, k, v, o, go, heads, scale), reps=3, warm=1)
+        f_fwd, f_bwd = 4.0 * b * heads * l * l * dh, 14.0 * b * heads * l * l * dh  # 2 / 7 GEMM units (S is recomputed twice)
+        print(json.dumps(dict(op="attention", B=b, L=l, heads=heads, dh=dh, fwd_ms=round(t_f, 3), fwd_tflops=round(f_fwd / t_f / 1e9, 1),
+                              bwd_ms=round(t_b, 3), bwd_tflops=round(f_bwd / t_b / 1e9, 1))), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "attn":
+    attention_rows()
