@@ -97,6 +97,7 @@ PROTOTYPES = {
     "gm_gn_scale_shift": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_vp, c_vp, C.c_int, c_vp]),
     "gm_gn_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_spade_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_gn_channel_stats": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp, C.c_int, c_vp]),
     "gm_gn_finalize_channels": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_ll, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gm_layernorm": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_float, C.c_int, c_vp]),

@@ -335,6 +335,58 @@ extern "C" int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_l
   GM_LAUNCH_CHECK();
 }
 
+// SPADE modulation (reference: generative/networks/blocks/spade_norm.py:79-96): y = act((x * scale[n, c] + shift[n, c]) * G[n, v, c] + Bm[n, v, c])
+// with (scale, shift) the parameter-free GroupNorm / InstanceNorm of x and G = 1 + gamma(seg), Bm = beta(seg) per-voxel maps (constant
+// over the timesteps of a sampling chain: computed once per layer and segmentation, read here every step).  One 16-byte vector per lane.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void spade_apply_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y, long long y_ld,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, long long ss_ld,
+                                                         const T* __restrict__ g, const T* __restrict__ bm, long long gb_ld, long long V, int C,
+                                                         long long total_vec, int act) {
+  const int CV = C / VEC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / CV;
+    const int c = (int)(i - row * CV) * VEC;
+    const long long n = row / V;
+    float v[VEC], gv[VEC], bv[VEC];
+    VecLd<T, VEC>::ld(x + row * x_ld + c, v);
+    VecLd<T, VEC>::ld(g + row * gb_ld + c, gv);
+    VecLd<T, VEC>::ld(bm + row * gb_ld + c, bv);
+    const float* sc = scale + n * ss_ld + c;
+    const float* sh = shift + n * ss_ld + c;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float t = (v[k] * sc[k] + sh[k]) * gv[k] + bv[k];
+      if (act == 1) t = sizeof(T) == 4 ? gm_silu_precise(t) : gm_silu(t);
+      v[k] = t;
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) ElemIO<T>::st(y + row * y_ld + c + k, v[k]);
+  }
+}
+
+extern "C" int gm_spade_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift, long long ss_ld,
+                              const void* g, const void* bm, long long gb_ld, int N, long long V, int C, int act, int dtype, void* stream) {
+  GM_REQUIRE(x && y && scale && shift && g && bm, "null pointer");
+  const long long total = (long long)N * V * C;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == GM_F32 ? 4 : 8;
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec_ok = (C % vec == 0) && (x_ld % vec == 0) && (gb_ld % vec == 0) && al(x) && al(g) && al(bm);
+  const long long items = vec_ok ? total / vec : total;
+  long long grid = (items + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+#define GM_SPADE_LAUNCH(T, VEC)                                                                                                        \
+  spade_apply_kernel<T, VEC><<<(int)grid, 256, 0, st>>>((const T*)x, x_ld, (T*)y, y_ld, scale, shift, ss_ld, (const T*)g, (const T*)bm, gb_ld, V, C, \
+                                                     items, act)
+  if (dtype == GM_F32) { if (vec_ok) GM_SPADE_LAUNCH(float, 4); else GM_SPADE_LAUNCH(float, 1); }
+  else if (dtype == GM_BF16) { if (vec_ok) GM_SPADE_LAUNCH(bf16_raw, 8); else GM_SPADE_LAUNCH(bf16_raw, 1); }
+  else GM_FAIL(-2, "unsupported dtype");
+#undef GM_SPADE_LAUNCH
+  GM_LAUNCH_CHECK();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim of [rows][ld] (transformer blocks: diffusion_model_unet.py:219-223): one wave per row.
 // ---------------------------------------------------------------------------------------------------------------------

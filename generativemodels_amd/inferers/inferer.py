@@ -9,6 +9,7 @@ MI355X-specific execution of `sample`:
     captured once on the first step and replayed for the remaining steps."""
 from __future__ import annotations
 
+import functools
 import math
 from typing import Callable, Optional
 
@@ -17,7 +18,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._native import GmKlParams
-from ..networks.nets import VQVAE, DecoderOnlyTransformer, DiffusionModelUNet
+from ..networks.nets import VQVAE, DecoderOnlyTransformer, DiffusionModelUNet, SPADEAutoencoderKL, SPADEDiffusionModelUNet
 
 try:  # progress bar is optional, like in the reference (inferer.py:28)
     from tqdm import tqdm
@@ -32,6 +33,13 @@ class Inferer:
 
     def __call__(self, *args, **kwargs):  # pragma: no cover
         raise NotImplementedError
+
+
+def _bind_seg(diffusion_model, seg):
+    """SPADE networks take the segmentation as a forward argument (reference inferer.py:68-70, 121-123, 193-195: functools.partial)."""
+    if isinstance(diffusion_model, SPADEDiffusionModelUNet):
+        return functools.partial(diffusion_model, seg=seg)
+    return diffusion_model
 
 
 def _check_mode(mode: str) -> None:
@@ -83,6 +91,7 @@ class DiffusionInferer(Inferer):
         if mode == "concat":
             noisy = ops.concat_dim1([noisy, condition])
             condition = None
+        diffusion_model = _bind_seg(diffusion_model, seg)
         if condition is None and torch.is_grad_enabled() and getattr(diffusion_model, "supports_training", lambda: False)() \
                 and any(p.requires_grad for p in diffusion_model.parameters()):
             # a training step (ddpm_training_ddp.py:249-270): the differentiable forward, native kernels in both directions
@@ -106,6 +115,8 @@ class DiffusionInferer(Inferer):
         it = tqdm(range(len(steps))) if (verbose and has_tqdm) else range(len(steps))
         graphed = None
         intermediates = []
+        graphable = isinstance(diffusion_model, DiffusionModelUNet) and not isinstance(diffusion_model, SPADEDiffusionModelUNet)
+        diffusion_model = _bind_seg(diffusion_model, seg)
         for i in it:
             t, tt = steps[i], t_dev[i:i + 1]
             if mode == "concat":
@@ -113,7 +124,7 @@ class DiffusionInferer(Inferer):
             else:
                 model_input, ctx = image, conditioning
             use_graph = self.use_hip_graph if self.use_hip_graph is not None else model_input.numel() <= self.GRAPH_AUTO_MAX_ELEMENTS
-            if use_graph and isinstance(diffusion_model, DiffusionModelUNet):
+            if use_graph and graphable:
                 if graphed is None:
                     graphed = _GraphedUNet(diffusion_model, model_input, tt, ctx)
                 model_output = graphed(model_input, tt)
@@ -143,6 +154,7 @@ class DiffusionInferer(Inferer):
             raise NotImplementedError(f"Likelihood computation is only compatible with DDPMScheduler, you are using {scheduler._get_name()}")
         _check_mode(mode)
         ops.require_device(inputs)
+        diffusion_model = _bind_seg(diffusion_model, seg)
         steps = [int(t) for t in torch.as_tensor(scheduler.timesteps).cpu().tolist()]
         it = tqdm(steps) if (verbose and has_tqdm) else steps
         noise = torch.randn_like(inputs) if _noise is None else _noise
@@ -244,7 +256,7 @@ class LatentDiffusionInferer(DiffusionInferer):
         if self.ldm_latent_shape is not None:
             latent = _spatial_pad(latent, self.ldm_latent_shape)
         return super().__call__(inputs=latent, diffusion_model=diffusion_model, noise=noise, timesteps=timesteps,
-                                condition=condition, mode=mode)
+                                condition=condition, mode=mode, seg=seg)
 
     @torch.no_grad()
     def sample(self, input_noise: torch.Tensor, autoencoder_model: Callable[..., torch.Tensor],
@@ -254,12 +266,14 @@ class LatentDiffusionInferer(DiffusionInferer):
                seg: torch.Tensor | None = None):
         outputs = super().sample(input_noise=input_noise, diffusion_model=diffusion_model, scheduler=scheduler,
                                  save_intermediates=save_intermediates, intermediate_steps=intermediate_steps,
-                                 conditioning=conditioning, mode=mode, verbose=verbose)
+                                 conditioning=conditioning, mode=mode, verbose=verbose, seg=seg)
         latent, latent_intermediates = outputs if save_intermediates else (outputs, [])
         if self.autoencoder_latent_shape is not None:
             latent = _center_crop(latent, self.autoencoder_latent_shape)
             latent_intermediates = [_center_crop(l, self.autoencoder_latent_shape) for l in latent_intermediates]
         decode = autoencoder_model.decode_stage_2_outputs
+        if isinstance(autoencoder_model, SPADEAutoencoderKL):  # reference inferer.py:461-462
+            decode = functools.partial(autoencoder_model.decode_stage_2_outputs, seg=seg)
         image = decode(self._scaled(latent, divide=True))
         if save_intermediates:
             return image, [decode(self._scaled(l, divide=True)) for l in latent_intermediates]
@@ -288,7 +302,7 @@ class LatentDiffusionInferer(DiffusionInferer):
             latents = _spatial_pad(latents, self.ldm_latent_shape)
         outputs = super().get_likelihood(inputs=latents, diffusion_model=diffusion_model, scheduler=scheduler,
                                          save_intermediates=save_intermediates, conditioning=conditioning, mode=mode,
-                                         verbose=verbose, _noise=_noise)
+                                         verbose=verbose, seg=seg, _noise=_noise)
         if save_intermediates and resample_latent_likelihoods:
             resizer = nn.Upsample(size=inputs.shape[2:], mode=resample_interpolation_mode)
             outputs = (outputs[0], [resizer(x) for x in outputs[1]])

@@ -1,4 +1,5 @@
 from .selfattention import SABlock
+from .spade_norm import SPADE
 from .transformerblock import MLPBlock, TransformerBlock
 
-__all__ = ["SABlock", "TransformerBlock", "MLPBlock"]
+__all__ = ["SABlock", "TransformerBlock", "MLPBlock", "SPADE"]

@@ -216,3 +216,37 @@ class ResnetBlock(nn.Module):
         shortcut = getattr(self, self.shortcut_name)
         xs = A.conv(x, shortcut.conv.weight, shortcut.conv.bias, kernel=1) if isinstance(shortcut, ConvP) else x
         return A.conv(h, c2.conv.weight, c2.conv.bias, kernel=c2.kernel_size, stride=1, padding=c2.padding, res=xs)
+
+
+class SPADEResnetBlock(ResnetBlock):
+    """ResnetBlock whose two GroupNorms are SPADE-modulated by a segmentation map: the decoder blocks of SPADEDiffusionModelUNet
+    (reference spade_diffusion_model_unet.py:72-200; GroupNorm with affine parameters and `norm_eps` as the parameter-free norm) and,
+    with `temb_channels=None`, the SPADEResBlock of SPADEAutoencoderKL (spade_autoencoderkl.py:42-134; affine-free GroupNorm with the
+    default eps 1e-5, shortcut named `nin_shortcut`).  One fused SPADE pass (norm x modulation x SiLU) replaces each GroupNorm-apply."""
+
+    def __init__(self, spatial_dims: int, in_channels: int, out_channels: Optional[int], temb_channels: Optional[int], label_nc: int,
+                 norm_num_groups: int = 32, norm_eps: float = 1e-6, spade_intermediate_channels: int = 128,
+                 shortcut_name: str = "skip_connection", zero_conv2: bool = True, affine: bool = True) -> None:
+        super().__init__(spatial_dims, in_channels, out_channels, temb_channels, norm_num_groups, norm_eps, shortcut_name=shortcut_name,
+                         zero_conv2=zero_conv2)
+        from ..blocks.spade_norm import SPADE
+
+        params = {"num_groups": norm_num_groups, "eps": norm_eps, "affine": True} if affine else {"num_groups": norm_num_groups, "affine": False}
+        self.norm1 = SPADE(label_nc, in_channels, 3, spatial_dims, spade_intermediate_channels, "GROUP", params)
+        self.norm2 = SPADE(label_nc, self.out_channels, 3, spatial_dims, spade_intermediate_channels, "GROUP", params)
+
+    def run(self, x, temb_row: Optional[torch.Tensor] = None, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if seg is None:
+            raise ValueError("SPADEResnetBlock needs the segmentation map")
+        cat = isinstance(x, ops.VirtualCat)
+        h = self.conv1.run(self.norm1.run(x, seg, "silu"), rowvec=temb_row, want_stats=True)
+        shortcut = getattr(self, self.shortcut_name)
+        fusion = {}
+        if not isinstance(shortcut, ConvP):
+            fusion["res"] = x
+        else:
+            fusion["skip"] = (list(x.parts) if cat else [x], shortcut.conv.weight, shortcut.conv.bias)
+        return self.conv2.run(self.norm2.run(h, seg, "silu"), want_stats=True, **fusion)
+
+    def run_train(self, x, temb=None):  # pragma: no cover
+        raise NotImplementedError("SPADE blocks are inference-only")

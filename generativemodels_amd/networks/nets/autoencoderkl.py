@@ -4,13 +4,13 @@ executed with the same fused HIP kernels as the diffusion UNet (N[D]HWC arena; G
 nearest-2x folded into the up-sampling convolution, asymmetric-pad strided convolution for down-sampling)."""
 from __future__ import annotations
 
-from typing import Sequence
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn
 
 from ... import ops
-from ._blocks import AttentionBlock, ConvP, ResnetBlock, ensure_tuple_rep, gn_prologue
+from ._blocks import AttentionBlock, ConvP, ResnetBlock, SPADEResnetBlock, ensure_tuple_rep, gn_prologue
 
 __all__ = ["AutoencoderKL"]
 
@@ -46,7 +46,8 @@ def _res(spatial_dims, cin, cout, groups, eps):
     return ResnetBlock(spatial_dims, cin, cout, None, groups, eps, shortcut_name="nin_shortcut", zero_conv2=False)
 
 
-def _run_blocks(blocks: nn.ModuleList, h: torch.Tensor) -> torch.Tensor:
+def _run_blocks(blocks: nn.ModuleList, h: torch.Tensor, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """seg: arena segmentation handed to the SPADE blocks of a SPADEDecoder (spade_autoencoderkl.py:283-289)."""
     pre = None
     for blk in blocks:
         if isinstance(blk, nn.GroupNorm):
@@ -54,6 +55,8 @@ def _run_blocks(blocks: nn.ModuleList, h: torch.Tensor) -> torch.Tensor:
         elif isinstance(blk, ConvP):
             h = blk.run(h, pre=pre, want_stats=True)
             pre = None
+        elif isinstance(blk, SPADEResnetBlock):
+            h = blk.run(h, None, seg)
         else:
             h = blk.run(h)
     return h
@@ -93,21 +96,28 @@ class Decoder(nn.Module):
     """Mirror of the encoder (reference autoencoderkl.py:455-597)."""
 
     def __init__(self, spatial_dims, num_channels, in_channels, out_channels, num_res_blocks, norm_num_groups, norm_eps,
-                 attention_levels, with_nonlocal_attn=True, use_convtranspose=False) -> None:
+                 attention_levels, with_nonlocal_attn=True, use_convtranspose=False, spade: Optional[tuple] = None) -> None:
+        """spade = (label_nc, spade_intermediate_channels): the residual blocks are SPADE-modulated (reference SPADEDecoder,
+        spade_autoencoderkl.py:137-289: affine-free GroupNorm with nn.GroupNorm's default eps as the parameter-free norm)."""
         super().__init__()
         g, eps = norm_num_groups, norm_eps
+        if spade is not None:
+            make_res = lambda sd, cin, cout, g_, eps_: SPADEResnetBlock(sd, cin, cout, None, spade[0], g_, eps_, spade[1],  # noqa: E731
+                                                                        shortcut_name="nin_shortcut", zero_conv2=False, affine=False)
+        else:
+            make_res = _res
         rc = list(reversed(num_channels))
         rr = list(reversed(num_res_blocks))
         ra = list(reversed(attention_levels))
         blocks: list[nn.Module] = [ConvP(spatial_dims, in_channels, rc[0], 3, 1, 1)]
         if with_nonlocal_attn:
-            blocks += [_res(spatial_dims, rc[0], rc[0], g, eps), AttentionBlock(spatial_dims, rc[0], None, g, eps),
-                       _res(spatial_dims, rc[0], rc[0], g, eps)]
+            blocks += [make_res(spatial_dims, rc[0], rc[0], g, eps), AttentionBlock(spatial_dims, rc[0], None, g, eps),
+                       make_res(spatial_dims, rc[0], rc[0], g, eps)]
         out_c = rc[0]
         for i in range(len(rc)):
             in_c, out_c = out_c, rc[i]
             for _ in range(rr[i]):
-                blocks.append(_res(spatial_dims, in_c, out_c, g, eps))
+                blocks.append(make_res(spatial_dims, in_c, out_c, g, eps))
                 in_c = out_c
                 if ra[i]:
                     blocks.append(AttentionBlock(spatial_dims, in_c, None, g, eps))
@@ -117,8 +127,8 @@ class Decoder(nn.Module):
         blocks.append(ConvP(spatial_dims, in_c, out_channels, 3, 1, 1))
         self.blocks = nn.ModuleList(blocks)
 
-    def run(self, x):
-        return _run_blocks(self.blocks, x)
+    def run(self, x, seg: Optional[torch.Tensor] = None):
+        return _run_blocks(self.blocks, x, seg)
 
 
 class AutoencoderKL(nn.Module):

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ._blocks import AttentionBlock, ConvP, ResnetBlock, ensure_tuple_rep, gn_prologue, lin, tokens, zero_module
+from ._blocks import SPADEResnetBlock, AttentionBlock, ConvP, ResnetBlock, ensure_tuple_rep, gn_prologue, lin, tokens, zero_module
 
 __all__ = ["DiffusionModelUNet"]
 
@@ -145,7 +145,10 @@ class _Stage(nn.Module):
     (diffusion_model_unet.py:699-1469); sub-module names are the reference's."""
 
     def __init__(self, spatial_dims, resnet_io: Sequence[tuple], temb_channels, groups, eps, attn: bool, cond: bool, heads_ch: int,
-                 nlayers: int, cross_dim, upcast, dropout, resampler: Optional[str], resblock_updown: bool, out_channels: int) -> None:
+                 nlayers: int, cross_dim, upcast, dropout, resampler: Optional[str], resblock_updown: bool, out_channels: int,
+                 spade: Optional[tuple] = None) -> None:
+        """spade = (label_nc, spade_intermediate_channels): the resnets are SPADEResnetBlocks (the SPADE up-block family,
+        reference spade_diffusion_model_unet.py:203-535); the resampler stays a plain ResnetBlock / Upsample as in the reference."""
         super().__init__()
         if attn:  # registered before `resnets`, like the reference's attention block families
             mk = (lambda: SpatialTransformer(spatial_dims, out_channels, out_channels // heads_ch, heads_ch, nlayers, dropout,
@@ -154,7 +157,11 @@ class _Stage(nn.Module):
             self.attentions = nn.ModuleList([mk() for _ in resnet_io])
         else:
             self.attentions = None
-        self.resnets = nn.ModuleList([ResnetBlock(spatial_dims, ci, co, temb_channels, groups, eps) for ci, co in resnet_io])
+        if spade is None:
+            self.resnets = nn.ModuleList([ResnetBlock(spatial_dims, ci, co, temb_channels, groups, eps) for ci, co in resnet_io])
+        else:
+            self.resnets = nn.ModuleList([SPADEResnetBlock(spatial_dims, ci, co, temb_channels, spade[0], groups, eps, spade[1])
+                                          for ci, co in resnet_io])
         self.cond = cond
         self.resampler_name = resampler
         if resampler == "downsampler":
@@ -269,6 +276,8 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
         common = dict(cond=with_conditioning, nlayers=transformer_num_layers, cross_dim=cross_attention_dim,
                       upcast=upcast_attention, dropout=dropout_cattn)
 
+        self._spade = getattr(self, "_spade", None)  # SPADEDiffusionModelUNet sets (label_nc, spade_intermediate_channels) first
+
         self.conv_in = ConvP(spatial_dims, in_channels, num_channels[0], 3, 1, 1)
         self.time_embed = nn.Sequential(nn.Linear(num_channels[0], ted), nn.SiLU(), nn.Linear(ted, ted))
         if num_class_embeds is not None:
@@ -300,7 +309,7 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
             io = [((prev_c if j == 0 else out_c) + (skip_c if j == n - 1 else out_c), out_c) for j in range(n)]
             self.up_blocks.append(_Stage(spatial_dims, io, ted, g, eps, rev_a[i], heads_ch=rev_h[i],
                                          resampler=None if i == nlev - 1 else "upsampler",
-                                         resblock_updown=resblock_updown, out_channels=out_c, **common))
+                                         resblock_updown=resblock_updown, out_channels=out_c, spade=self._spade, **common))
 
         self.out = nn.Sequential(nn.GroupNorm(num_groups=g, num_channels=num_channels[0], eps=eps, affine=True), nn.SiLU(),
                                  zero_module(ConvP(spatial_dims, num_channels[0], out_channels, 3, 1, 1)))
@@ -310,6 +319,11 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
                 class_labels: torch.Tensor | None = None, down_block_additional_residuals: tuple[torch.Tensor] | None = None,
                 mid_block_additional_residual: torch.Tensor | None = None) -> torch.Tensor:
         """x: (N, C, *spatial); timesteps: (N,) or (1,); context: (N, L_ctx, cross_attention_dim). Returns (N, C_out, *spatial)."""
+        return self._forward_impl(x, timesteps, context, class_labels, down_block_additional_residuals, mid_block_additional_residual)
+
+    def _forward_impl(self, x, timesteps, context, class_labels, down_block_additional_residuals, mid_block_additional_residual,
+                      seg: torch.Tensor | None = None) -> torch.Tensor:
+        """seg: (N, label_nc, *spatial) segmentation for the SPADE decoder blocks (SPADEDiffusionModelUNet), else None."""
         if timesteps.ndim != 1:
             raise ValueError("Timesteps should be a 1d-array")
         if context is not None and self.with_conditioning is False:
@@ -329,6 +343,19 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
                 context = ops.cast(context.contiguous(), dtype)
             temb = lambda blk: rows[id(blk)]
 
+            seg_a = None
+            if seg is not None:
+                ops.require_device(seg)
+                if seg.shape[0] != x.shape[0] or seg.dim() != x.dim():
+                    raise ValueError("seg must be (N, label_nc, *spatial) with the batch size of x")
+                # the arena copy is kept per segmentation tensor: the SPADE layers key their cached (1 + gamma, beta) maps on it, so a
+                # sampling chain converts the segmentation and evaluates the map convolutions once, not once per timestep
+                key = (seg.data_ptr(), seg._version, tuple(seg.shape), seg.dtype, dtype)
+                cached = getattr(self, "_seg_arena", None)
+                if cached is None or cached[0] != key:
+                    cached = (key, ops.to_channels_last(ops.cast(seg.contiguous(), dtype)), seg)
+                    self._seg_arena = cached
+                seg_a = cached[1]
             h = self.conv_in.run(ops.to_channels_last(x), want_stats=True)
             skips = [h]
             for st in self.down_blocks:
@@ -352,7 +379,8 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
 
             for st in self.up_blocks:
                 for j, rb in enumerate(st.resnets):
-                    h = rb.run(ops.VirtualCat([h, skips.pop()]), temb(rb))
+                    cat = ops.VirtualCat([h, skips.pop()])
+                    h = rb.run(cat, temb(rb)) if seg_a is None else rb.run(cat, temb(rb), seg_a)
                     h = st.attend(j, h, context)
                 if st.resampler_name == "upsampler":
                     us = st.upsampler
@@ -369,7 +397,7 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tens
     convolution resampling); cross-attention conditioning, class embeddings and resblock_updown are inference-only for now."""
     from ... import autograd as A
 
-    if self.with_conditioning or self.num_class_embeds is not None:
+    if self.with_conditioning or self.num_class_embeds is not None or self._spade is not None:
         raise NotImplementedError("forward_train covers the unconditioned DiffusionModelUNet")
     if timesteps.ndim != 1 or timesteps.shape[0] not in (1, x.shape[0]):
         raise ValueError("timesteps must be 1-D with one entry, or one per batch element")
@@ -418,7 +446,7 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tens
 
 def _supports_training(self) -> bool:
     """True when forward_train covers this configuration (DiffusionInferer.__call__ then returns a differentiable prediction)."""
-    return (not self.with_conditioning and self.num_class_embeds is None
+    return (not self.with_conditioning and self.num_class_embeds is None and self._spade is None
             and not any(isinstance(m, ResnetBlock) and (m.up or m.down) for m in self.modules()))
 
 

@@ -169,9 +169,10 @@ def packed_cat_weight(weights: Sequence[torch.Tensor], dtype: torch.dtype) -> to
     def make():
         w = torch.cat([x.detach() for x in weights], dim=0).contiguous()
         cout, cin = w.shape[0], w.shape[1]
-        n = lib().gm_packed_conv_weight_elems(cout, cin, 1, 1, 1, dt_code(dtype))
+        k = [1] * (5 - w.dim()) + list(w.shape[2:])  # nn.Linear [Cout, Cin] or nn.ConvNd [Cout, Cin, *kernel] weights
+        n = lib().gm_packed_conv_weight_elems(cout, cin, k[0], k[1], k[2], dt_code(dtype))
         out = torch.empty(n, dtype=dtype, device=w.device)
-        check(lib().gm_pack_conv_weight(w.data_ptr(), dt_code(w.dtype), out.data_ptr(), dt_code(dtype), cout, cin, 1, 1, 1, 0,
+        check(lib().gm_pack_conv_weight(w.data_ptr(), dt_code(w.dtype), out.data_ptr(), dt_code(dtype), cout, cin, k[0], k[1], k[2], 0,
                                         _stream()), "gm_pack_conv_weight")
         return out
 
@@ -340,6 +341,26 @@ def gn_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act: str
     _timed(f"gn_apply<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(2 * x.element_size() * x.numel()), shape=str(tuple(x.shape))),
            lambda: check(lib().gm_gn_apply(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), scale.data_ptr(), shift.data_ptr(),
                                            ss_ld, n, v, c, ACT[act], dt_code(x.dtype), _stream()), "gm_gn_apply"))
+    return out
+
+
+def spade_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, g: torch.Tensor, bm: torch.Tensor, act: str = "none",
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act((x * scale[n, c] + shift[n, c]) * g + bm): the SPADE modulation of a parameter-free-normalised tensor; g = 1 + gamma(seg) and
+    bm = beta(seg) are arena tensors like x (channel slices of wider buffers allowed, as are x / out)."""
+    require_device(x, scale, shift, g, bm, out)
+    n, c = x.shape[0], x.shape[-1]
+    v = rows_of(x) // max(n, 1)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if g.shape != x.shape or bm.shape != x.shape or g.dtype != x.dtype or bm.dtype != x.dtype or arena_ld(g) != arena_ld(bm):
+        raise ValueError("spade_apply: g / bm must match x (shape, dtype) and share a row pitch")
+    if scale.shape != (n, c) or shift.shape != (n, c) or scale.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+        raise ValueError("spade_apply: scale/shift must be matching [N, C] (slices of) fp32 tables")
+    ss_ld = scale.stride(0) if n > 1 else max(scale.stride(0), c)
+    _timed(f"spade_apply<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(4 * x.element_size() * x.numel()), shape=str(tuple(x.shape))),
+           lambda: check(lib().gm_spade_apply(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), scale.data_ptr(), shift.data_ptr(), ss_ld,
+                                              g.data_ptr(), bm.data_ptr(), arena_ld(g), n, v, c, ACT[act], dt_code(x.dtype), _stream()), "gm_spade_apply"))
     return out
 
 

@@ -110,6 +110,10 @@ int gm_gn_scale_shift(const void* x, long long ld, int N, long long V, int C, in
 /* scale/shift rows are ss_ld floats apart (a channel slice of a wider [N][C_total] table is a valid operand) */
 int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift, long long ss_ld,
                 int N, long long V, int C, int act, int dtype, void* stream);
+/* SPADE modulation (generative/networks/blocks/spade_norm.py:79-96): y = act((x * scale[n][c] + shift[n][c]) * g[n][v][c] + bm[n][v][c]);
+ * (scale, shift) = the parameter-free GroupNorm / InstanceNorm of x, g = 1 + gamma(seg), bm = beta(seg) in the dtype of x (row pitch gb_ld) */
+int gm_spade_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift, long long ss_ld,
+                   const void* g, const void* bm, long long gb_ld, int N, long long V, int C, int act, int dtype, void* stream);
 /* Composable form: per-channel {sum, sum of squares} in fp64 ([GM_STAT_SLOTS][N][C][2], zero-initialised by the caller; also produced by the
  * fast convolution kernels' epilogue through GmConvDesc.stats), and the GroupNorm finalisation over up to two
  * channel-concatenated sources -- torch.cat([h, skip]) followed by GroupNorm (diffusion_model_unet.py:1232 + 671) without ever

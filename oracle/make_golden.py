@@ -374,6 +374,88 @@ def grid_fixture():
     print("grid", len(out["unet"]), len(out["aekl"]), len(out["vqvae"]))
 
 
+def spade_fixtures():
+    """tests/golden/spade.pt: SPADE block, SPADEDiffusionModelUNet forwards (2-D with attention + a coarser segmentation, 3-D with
+    cross-attention), SPADEAutoencoderKL forward / decode, and a SPADE latent-diffusion chain through LatentDiffusionInferer.sample
+    (seg handed to both networks).  Outputs of the unmodified reference."""
+    from generative.inferers import LatentDiffusionInferer
+    from generative.networks.blocks.spade_norm import SPADE
+    from generative.networks.nets import SPADEAutoencoderKL, SPADEDiffusionModelUNet
+    from generative.networks.schedulers import DDIMScheduler
+
+    out = dict(kind="spade", blocks={}, unets={}, aekls={})
+    for name, kw, xs, ss in [("inst2d", dict(label_nc=3, norm_nc=8, spatial_dims=2, hidden_channels=16), (2, 8, 6, 10), (2, 3, 12, 20)),
+                             ("group3d", dict(label_nc=2, norm_nc=16, spatial_dims=3, hidden_channels=8, norm="GROUP",
+                                              norm_params={"num_groups": 4, "eps": 1e-6, "affine": True}), (1, 16, 4, 6, 8), (1, 2, 4, 6, 8))]:
+        torch.manual_seed(0)
+        m = SPADE(**kw).eval()
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.add_(torch.randn(p_.shape, generator=torch.Generator().manual_seed(p_.numel())) * 0.05)
+        x, seg = _randn(xs, 41), _randn(ss, 42)
+        with torch.no_grad():
+            y = m(x, seg)
+        out["blocks"][name] = dict(kwargs=kw, state_dict=m.state_dict(), x=x, seg=seg, y=y)
+        print("spade block", name, float(y.abs().max()))
+    ucases = {
+        "spade_unet2d": dict(cfg=dict(spatial_dims=2, in_channels=1, out_channels=1, label_nc=3, num_channels=(8, 16), attention_levels=(False, True),
+                                      num_res_blocks=1, norm_num_groups=8, num_head_channels=8, spade_intermediate_channels=16),
+                             x=(2, 1, 16, 16), seg=(2, 3, 8, 8)),
+        "spade_unet3d_cross": dict(cfg=dict(spatial_dims=3, in_channels=1, out_channels=2, label_nc=2, num_channels=(8, 8), attention_levels=(True, True),
+                                            num_res_blocks=(1, 2), norm_num_groups=8, num_head_channels=4, with_conditioning=True,
+                                            cross_attention_dim=3, resblock_updown=True, spade_intermediate_channels=8),
+                                   x=(2, 1, 8, 8, 8), seg=(2, 2, 8, 8, 8), context=(2, 2, 3)),
+    }
+    for name, case in ucases.items():
+        torch.manual_seed(0)
+        m = SPADEDiffusionModelUNet(**case["cfg"]).eval()
+        derandomize_zeros(m)
+        x, seg = _randn(case["x"], 7), _randn(case["seg"], 9)
+        t = torch.tensor([980, 20])
+        ctx = _randn(case["context"], 8) if "context" in case else None
+        with torch.no_grad():
+            y = m(x, t, seg, context=ctx)
+        out["unets"][name] = dict(cfg=case["cfg"], state_dict=m.state_dict(), x=x, timesteps=t, seg=seg, context=ctx, y=y)
+        print(name, tuple(y.shape), float(y.abs().max()))
+    acases = {
+        "spade_aekl2d": dict(cfg=dict(spatial_dims=2, label_nc=3, in_channels=1, out_channels=1, num_channels=(8, 8, 16), latent_channels=4,
+                                      attention_levels=(False, False, True), num_res_blocks=(1, 1, 2), norm_num_groups=4,
+                                      spade_intermediate_channels=16), x=(2, 1, 16, 16), seg=(2, 3, 16, 16)),
+        "spade_aekl3d": dict(cfg=dict(spatial_dims=3, label_nc=2, in_channels=1, out_channels=1, num_channels=(8, 16), latent_channels=4,
+                                      attention_levels=(False, False), num_res_blocks=1, norm_num_groups=8, with_encoder_nonlocal_attn=False,
+                                      with_decoder_nonlocal_attn=False, spade_intermediate_channels=8), x=(1, 1, 8, 8, 8), seg=(1, 2, 4, 4, 4)),
+    }
+    for name, case in acases.items():
+        torch.manual_seed(0)
+        m = SPADEAutoencoderKL(**case["cfg"]).eval()
+        x, seg = _randn(case["x"], 11), _randn(case["seg"], 12)
+        with torch.no_grad():
+            z_mu, z_sigma = m.encode(x)
+            dec = m.decode(z_mu, seg)
+        out["aekls"][name] = dict(cfg=case["cfg"], state_dict=m.state_dict(), x=x, seg=seg, z_mu=z_mu, z_sigma=z_sigma, decoded=dec)
+        print(name, tuple(dec.shape), float(dec.abs().max()))
+    # SPADE latent diffusion: 2-D SPADE AE (16x16 -> 4x4x4) + SPADE UNet on the latent, DDIM-4, seg at image resolution
+    acfg = acases["spade_aekl2d"]["cfg"]
+    ucfg = dict(spatial_dims=2, in_channels=4, out_channels=4, label_nc=3, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1,
+                norm_num_groups=8, num_head_channels=8, spade_intermediate_channels=16)
+    torch.manual_seed(2)
+    ae = SPADEAutoencoderKL(**acfg).eval()
+    torch.manual_seed(3)
+    unet = SPADEDiffusionModelUNet(**ucfg).eval()
+    derandomize_zeros(unet)
+    noise, seg = _randn((2, 4, 4, 4), 51), _randn((2, 3, 16, 16), 52)
+    sch = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    sch.set_timesteps(4)
+    inf = LatentDiffusionInferer(sch, scale_factor=0.8)
+    img = inf.sample(noise, ae, unet, sch, verbose=False, seg=seg)
+    xin, ts = _randn((2, 1, 16, 16), 53), torch.tensor([700, 30])
+    torch.manual_seed(9)  # the AE's reparametrisation draw inside __call__ is not compared: only the chain is
+    out["latent"] = dict(ae_cfg=acfg, ae_sd=ae.state_dict(), unet_cfg=ucfg, unet_sd=unet.state_dict(), noise=noise, seg=seg, steps=4,
+                         scale_factor=0.8, image=img)
+    torch.save(out, os.path.join(OUT, "spade.pt"))
+    print("spade latent chain", tuple(img.shape), float(img.abs().max()))
+
+
 def main():
     g = load_reference()
     if g is None:
@@ -386,6 +468,9 @@ def main():
         return
     if "--controlnet-only" in sys.argv:
         controlnet_fixtures()
+        return
+    if "--spade-only" in sys.argv:
+        spade_fixtures()
         return
     if "--extras-only" in sys.argv:  # PNDM + get_likelihood fixtures only
         extras()

@@ -163,10 +163,14 @@ if "monai" not in sys.modules:
             op = {"A": None, "D": None, "N": None}
             if norm is not None:
                 nm = norm if isinstance(norm, str) else norm[0]
+                nargs = {} if isinstance(norm, str) else dict(norm[1])
+                # monai.networks.layers.utils.get_norm_layer: the layer gets the channel count plus the user's keyword arguments
                 if nm.lower() == "instance":
-                    op["N"] = [nn.InstanceNorm1d, nn.InstanceNorm2d, nn.InstanceNorm3d][norm_dim - 1](in_channels)
+                    op["N"] = [nn.InstanceNorm1d, nn.InstanceNorm2d, nn.InstanceNorm3d][norm_dim - 1](in_channels, **nargs)
                 elif nm.lower() == "batch":
-                    op["N"] = [nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d][norm_dim - 1](in_channels)
+                    op["N"] = [nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d][norm_dim - 1](in_channels, **nargs)
+                elif nm.lower() == "group":
+                    op["N"] = nn.GroupNorm(num_channels=in_channels, **nargs)
                 else:
                     raise NotImplementedError(nm)
             if act is not None:

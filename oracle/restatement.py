@@ -143,6 +143,39 @@ def unet_resnet(sd, p, x, emb, groups, eps, up=False, down=False):
     return x + h
 
 
+def spade(sd, p, x, seg, groups, eps):
+    """SPADE.forward, networks/blocks/spade_norm.py:79-96.  The parameter-free norm is GroupNorm (affine iff `param_free_norm.N.weight`
+    is in the state dict: spade_diffusion_model_unet.py:110-118 vs spade_autoencoderkl.py:72-80); mlp_shared is conv + LeakyReLU(0.01);
+    mlp_gamma / mlp_beta are MONAI Convolution(act=None) and therefore conv + the default InstanceNorm (affine-free, eps 1e-5)."""
+    normalized = F.group_norm(x, groups, sd.get(p + ".param_free_norm.N.weight"), sd.get(p + ".param_free_norm.N.bias"), eps)
+    segmap = F.interpolate(seg, size=x.shape[2:], mode="nearest")
+    k = sd[p + ".mlp_shared.conv.weight"].shape[-1]
+    actv = F.leaky_relu(_conv(sd, p + ".mlp_shared", segmap, padding=k // 2), 0.01)
+    gamma = F.instance_norm(_conv(sd, p + ".mlp_gamma", actv, padding=k // 2), eps=1e-5)
+    beta = F.instance_norm(_conv(sd, p + ".mlp_beta", actv, padding=k // 2), eps=1e-5)
+    return normalized * (1 + gamma) + beta
+
+
+def spade_unet_resnet(sd, p, x, emb, seg, groups, eps):
+    """SPADEResnetBlock.forward, nets/spade_diffusion_model_unet.py:173-200 (the decoder blocks are never up / down sampling)."""
+    h = _conv(sd, p + ".conv1", F.silu(spade(sd, p + ".norm1", x, seg, groups, eps)))
+    t = _lin(sd, p + ".time_emb_proj", F.silu(emb))
+    h = h + t.reshape(*t.shape, *([1] * (x.ndim - 2)))
+    h = _conv(sd, p + ".conv2", F.silu(spade(sd, p + ".norm2", h, seg, groups, eps)))
+    if (p + ".skip_connection.conv.weight") in sd:
+        x = _conv(sd, p + ".skip_connection", x, padding=0)
+    return x + h
+
+
+def spade_aekl_resblock(sd, p, x, seg, groups):
+    """SPADEResBlock.forward, nets/spade_autoencoderkl.py:122-134; its GroupNorm is built without `eps`: nn.GroupNorm's default 1e-5."""
+    h = _conv(sd, p + ".conv1", F.silu(spade(sd, p + ".norm1", x, seg, groups, 1e-5)))
+    h = _conv(sd, p + ".conv2", F.silu(spade(sd, p + ".norm2", h, seg, groups, 1e-5)))
+    if (p + ".nin_shortcut.conv.weight") in sd:
+        x = _conv(sd, p + ".nin_shortcut", x, padding=0)
+    return x + h
+
+
 def attention_block(sd, p, x, groups, eps, num_head_channels):
     """AttentionBlock.forward, nets/diffusion_model_unet.py:418-458 (twin nets/autoencoderkl.py:272-312).
 
@@ -188,11 +221,12 @@ def spatial_transformer(sd, p, x, context, groups, eps, num_head_channels, num_l
 
 
 def unet_forward(sd, cfg, x, timesteps, context=None, class_labels=None, down_block_additional_residuals=None,
-                 mid_block_additional_residual=None):
+                 mid_block_additional_residual=None, seg=None):
     """DiffusionModelUNet.forward, nets/diffusion_model_unet.py:1869-1943, over the block layout built at :1770-1867.
 
     cfg: the constructor kwargs (spatial_dims, in_channels, out_channels + any of UNET_DEFAULTS)."""
-    c = dict(UNET_DEFAULTS, **cfg)
+    c = dict(UNET_DEFAULTS, **{k: v for k, v in cfg.items() if k not in ("label_nc", "spade_intermediate_channels")})
+    # seg given: SPADEDiffusionModelUNet.forward (nets/spade_diffusion_model_unet.py:836-912) -- same network, SPADE decoder resnets
     chans = tuple(c["num_channels"])
     nlev = len(chans)
     att = tuple(c["attention_levels"])
@@ -249,7 +283,10 @@ def unet_forward(sd, cfg, x, timesteps, context=None, class_labels=None, down_bl
         p = f"up_blocks.{i}"
         for j in range(rres[i] + 1):
             h = torch.cat([h, skips.pop()], dim=1)
-            h = unet_resnet(sd, f"{p}.resnets.{j}", h, emb, groups, eps)
+            if seg is None:
+                h = unet_resnet(sd, f"{p}.resnets.{j}", h, emb, groups, eps)
+            else:
+                h = spade_unet_resnet(sd, f"{p}.resnets.{j}", h, emb, seg, groups, eps)
             if ratt[i]:
                 h = attend(f"{p}.attentions.{j}", h, rnhc[i])
         if i != nlev - 1:
@@ -396,9 +433,11 @@ def aekl_encode(sd, cfg, x):
     return z_mu, torch.exp(z_log_var / 2)
 
 
-def aekl_decode(sd, cfg, z):
-    """AutoencoderKL.decode, nets/autoencoderkl.py:769-784 -> Decoder :500-597."""
-    c = _aekl_cfg(cfg)
+def aekl_decode(sd, cfg, z, seg=None):
+    """AutoencoderKL.decode, nets/autoencoderkl.py:769-784 -> Decoder :500-597.  seg given: SPADEAutoencoderKL.decode,
+    nets/spade_autoencoderkl.py:457-469 -> SPADEDecoder :137-289 (same layout, SPADE residual blocks)."""
+    c = _aekl_cfg({k: v for k, v in cfg.items() if k not in ("label_nc", "spade_intermediate_channels")})
+    res = aekl_resblock if seg is None else (lambda sd_, p_, h_, g_, e_: spade_aekl_resblock(sd_, p_, h_, seg, g_))
     chans, att, nres = c["num_channels"][::-1], c["attention_levels"][::-1], c["num_res_blocks"][::-1]
     groups, eps = c["norm_num_groups"], c["norm_eps"]
     h = _conv(sd, "post_quant_conv", z, padding=0)
@@ -407,13 +446,13 @@ def aekl_decode(sd, cfg, z):
     h = _conv(sd, f"{p}{k}", h)
     k += 1
     if c["with_decoder_nonlocal_attn"]:
-        h = aekl_resblock(sd, f"{p}{k}", h, groups, eps)
+        h = res(sd, f"{p}{k}", h, groups, eps)
         h = attention_block(sd, f"{p}{k + 1}", h, groups, eps, None)
-        h = aekl_resblock(sd, f"{p}{k + 2}", h, groups, eps)
+        h = res(sd, f"{p}{k + 2}", h, groups, eps)
         k += 3
     for i in range(len(chans)):
         for _ in range(nres[i]):
-            h = aekl_resblock(sd, f"{p}{k}", h, groups, eps)
+            h = res(sd, f"{p}{k}", h, groups, eps)
             k += 1
             if att[i]:
                 h = attention_block(sd, f"{p}{k}", h, groups, eps, None)

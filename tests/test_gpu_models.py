@@ -475,3 +475,51 @@ def test_unet3d_ragged_volume_matches_oracle(shape):
     _fp32_close(got, want, f"ragged unet {shape}")
     yb = m.to(DEV, torch.bfloat16)(_dev(x.bfloat16()), _dev(t))
     _bf16_close(yb, want, f"ragged unet bf16 {shape}")
+
+
+def test_spade_networks_match_reference():
+    """SPADE block, SPADEDiffusionModelUNet (2-D with attention and a coarser segmentation; 3-D with cross-attention + resblock_updown),
+    SPADEAutoencoderKL encode / decode and the seg-conditioned latent DDIM chain against the reference's outputs (fp32), plus bf16
+    closeness; the per-layer (1 + gamma, beta) maps are cached across the chain's steps."""
+    from generativemodels_amd.inferers import LatentDiffusionInferer
+    from generativemodels_amd.networks.blocks import SPADE
+    from generativemodels_amd.networks.nets import SPADEAutoencoderKL, SPADEDiffusionModelUNet
+    from generativemodels_amd.networks.schedulers import DDIMScheduler
+    fx = load_fixture("spade")
+    for name, e in fx["blocks"].items():
+        m = SPADE(**e["kwargs"]).eval()
+        m.load_state_dict(e["state_dict"])
+        m = m.to(DEV)
+        _fp32_close(m(_dev(e["x"]), _dev(e["seg"])), e["y"], f"spade block {name}", factor=2.0)
+    for name, e in fx["unets"].items():
+        m = SPADEDiffusionModelUNet(**e["cfg"]).eval()
+        m.load_state_dict(e["state_dict"])
+        m = m.to(DEV)
+        seg = _dev(e["seg"])
+        y = m(_dev(e["x"]), _dev(e["timesteps"]), seg, context=_dev(e["context"]))
+        _fp32_close(y, e["y"], name)
+        _fp32_close(m(_dev(e["x"]), _dev(e["timesteps"]), seg, context=_dev(e["context"])), e["y"], f"{name} (cached maps)")
+        mb = SPADEDiffusionModelUNet(**e["cfg"]).eval()
+        mb.load_state_dict(e["state_dict"])
+        mb = mb.to(DEV, torch.bfloat16)
+        ctx = None if e["context"] is None else e["context"].bfloat16()
+        yb = mb(_dev(e["x"].bfloat16()), _dev(e["timesteps"]), _dev(e["seg"].bfloat16()), context=_dev(ctx))
+        _bf16_close(yb, e["y"], f"{name} bf16")
+    for name, e in fx["aekls"].items():
+        m = SPADEAutoencoderKL(**e["cfg"]).eval()
+        m.load_state_dict(e["state_dict"])
+        m = m.to(DEV)
+        z_mu, z_sigma = m.encode(_dev(e["x"]))
+        _fp32_close(z_mu, e["z_mu"], f"{name} z_mu")
+        _fp32_close(m.decode(_dev(e["z_mu"]), _dev(e["seg"])), e["decoded"], f"{name} decode", factor=2.0)
+    l = fx["latent"]
+    ae = SPADEAutoencoderKL(**l["ae_cfg"]).eval()
+    ae.load_state_dict(l["ae_sd"])
+    unet = SPADEDiffusionModelUNet(**l["unet_cfg"]).eval()
+    unet.load_state_dict(l["unet_sd"])
+    ae, unet = ae.to(DEV), unet.to(DEV)
+    sch = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    sch.set_timesteps(l["steps"])
+    inf = LatentDiffusionInferer(sch, scale_factor=l["scale_factor"])
+    img = inf.sample(_dev(l["noise"]), ae, unet, sch, verbose=False, seg=_dev(l["seg"]))
+    _fp32_close(img, l["image"], "spade latent chain", factor=4.0)

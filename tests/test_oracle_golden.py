@@ -163,6 +163,38 @@ def test_controlnet_forward_and_conditioned_chain_match_reference():
     assert_close(pred, i["call_prediction"], atol=2e-5, what="controlnet inferer __call__")
 
 
+def test_spade_networks_match_reference():
+    """SPADE (spade_norm.py:79-96), SPADEDiffusionModelUNet (spade_diffusion_model_unet.py:836-912), SPADEAutoencoderKL
+    (spade_autoencoderkl.py:410-484) and the seg-conditioned latent DDIM chain (inferer.py:364-487) restated vs the reference."""
+    fx = load_fixture("spade")
+    for name, e in fx["blocks"].items():
+        kw = e["kwargs"]
+        groups = kw.get("norm_params", {}).get("num_groups", kw["norm_nc"])  # instance norm = one group per channel
+        eps = kw.get("norm_params", {}).get("eps", 1e-5)
+        with torch.no_grad():
+            y = R.spade({"." + k: v for k, v in e["state_dict"].items()}, "", e["x"], e["seg"], groups, eps)
+        assert_close(y, e["y"], atol=2e-5 * max(1.0, e["y"].abs().max().item()), what=f"spade block {name}")
+    for name, e in fx["unets"].items():
+        with torch.no_grad():
+            y = R.unet_forward(e["state_dict"], e["cfg"], e["x"], e["timesteps"], e["context"], seg=e["seg"])
+        assert_close(y, e["y"], atol=2e-5, what=name)
+    for name, e in fx["aekls"].items():
+        with torch.no_grad():
+            z_mu, z_sigma = R.aekl_encode(e["state_dict"], e["cfg"], e["x"])
+            dec = R.aekl_decode(e["state_dict"], e["cfg"], e["z_mu"], e["seg"])
+        assert_close(z_mu, e["z_mu"], atol=2e-5, what=f"{name} z_mu")
+        assert_close(dec, e["decoded"], atol=2e-5 * max(1.0, e["decoded"].abs().max().item()), what=f"{name} decode")
+    l = fx["latent"]
+    _, _, ac = R.noise_schedule("scaled_linear_beta", 1000, beta_start=0.0005, beta_end=0.0195)
+    img = l["noise"]
+    with torch.no_grad():
+        for t in R.inference_timesteps(1000, l["steps"]):
+            eps_ = R.unet_forward(l["unet_sd"], l["unet_cfg"], img, torch.Tensor((int(t),)), seg=l["seg"])
+            img, _ = R.ddim_step(ac, 1000, l["steps"], eps_, int(t), img, clip_sample=False)
+        out = R.aekl_decode(l["ae_sd"], l["ae_cfg"], img / l["scale_factor"], l["seg"])
+    assert_close(out, l["image"], atol=2e-5 * max(1.0, l["image"].abs().max().item()), what="spade latent chain")
+
+
 def test_transformer_ordering_and_vqvae_transformer_inferer_match_reference():
     """DecoderOnlyTransformer (transformer.py:98-106), Ordering (ordering.py), VQVAETransformerInferer __call__ / get_likelihood /
     greedy sample (inferer.py:1126-1330) restated vs the reference's outputs."""
