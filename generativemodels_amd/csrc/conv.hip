@@ -289,7 +289,7 @@ static inline int conv_fast_bn(int cfg) { int v = 0, c = 0, t = 0; gm_conv_fast_
 extern "C" long long gm_conv_dma_lds_bytes(int stride);
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
-static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 16); }  // 14: 4 waves x 64 voxels; 15: stride 2; 16: 512 voxels
+static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 17); }  // 14: 4 waves x 64 voxels; 15: stride 2; 16: 512 voxels; 17: sub-pixel up-sampling
 // HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
 #define CONV_CFG_CIN 12
 #define CONV_CFG_COUT1 13
@@ -351,7 +351,7 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   if (d && d->skip_x[0] && !conv_is_dma(d->cfg)) return -1;  // the fused 1x1 shortcut exists in the LDS-DMA kernel only
-  if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes(d->cfg == 15 ? 2 : (d->cfg == 16 ? 3 : 1)) : -1;
+  if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes(d->cfg == 17 ? 4 : (d->cfg == 15 ? 2 : (d->cfg == 16 ? 3 : 1))) : -1;
   if (d && d->cfg == CONV_CFG_CIN) return gm_conv_cin_eligible(d) ? gm_conv_cin_lds_bytes(d) : -1;
   if (d && d->cfg == CONV_CFG_COUT1) return gm_conv_cout1_eligible(d) ? gm_conv_cout1_lds_bytes() : -1;
   if (d && conv_is_fast(d->cfg)) {
@@ -378,7 +378,8 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE((d.pre_scale == nullptr) == (d.pre_shift == nullptr), "pre_scale and pre_shift go together");
   GM_REQUIRE(d.N >= 0 && d.Cin > 0 && d.Cout > 0, "bad channel / batch count");
   GM_REQUIRE(d.kd > 0 && d.kh > 0 && d.kw > 0 && d.sd > 0 && d.sh > 0 && d.sw > 0 && d.dd > 0 && d.dh > 0 && d.dw > 0, "bad kernel geometry");
-  GM_REQUIRE(d.in_mode == 0 || (d.fd > 0 && d.fh > 0 && d.fw > 0), "bad input-mode factors");
+  GM_REQUIRE(d.in_mode == 0 || d.in_mode == 3 || (d.fd > 0 && d.fh > 0 && d.fw > 0), "bad input-mode factors");
+  GM_REQUIRE(d.in_mode != 3 || d.cfg == 17, "in_mode 3 (sub-pixel up-sampling) is implemented by configuration 17 only");
   if (d.N == 0 || d.Do == 0 || d.Ho == 0 || d.Wo == 0) return 0;
   int bm = 0, bn = 0;
   gm_conv_cfg_tile(d.cfg, &bm, &bn);
@@ -390,10 +391,12 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
              "geometry is not eligible for the C_in<=4 / C_out==1 kernels");
   const long long smem = gm_conv_lds_bytes(dp);
   GM_REQUIRE(smem > 0 && smem <= 160 * 1024, "tile needs more than 160 KiB of LDS");
-  const long long ntd = (d.Do + (1 << d.ltd) - 1) >> d.ltd, nth = (d.Ho + (1 << d.lth) - 1) >> d.lth,
-                  ntw = (d.Wo + (1 << d.ltw) - 1) >> d.ltw;
+  // cfg 17 (sub-pixel up-sampling): the tiles walk the low-resolution grid, once per output parity
+  const bool subpixel = d.cfg == 17;
+  const long long De = subpixel ? d.Ds : d.Do, He = subpixel ? d.Hs : d.Ho, We = subpixel ? d.Ws : d.Wo;
+  const long long ntd = (De + (1 << d.ltd) - 1) >> d.ltd, nth = (He + (1 << d.lth) - 1) >> d.lth, ntw = (We + (1 << d.ltw) - 1) >> d.ltw;
   const long long ncb = (d.Cout + bn - 1) / bn;
-  const long long nblocks = (long long)d.N * ntd * nth * ntw * ncb;
+  const long long nblocks = (long long)d.N * ntd * nth * ntw * ncb * (subpixel ? 8 : 1);
   GM_REQUIRE(nblocks < (1LL << 31), "grid too large");
   hipStream_t st = (hipStream_t)stream;
   int rc;

@@ -43,15 +43,21 @@ __device__ __forceinline__ void dma_wait() {
 // S = 1: stride 1 (optionally over a 2x nearest-upsampled input), 4x4x16 output tile.  S = 2: stride 2 (the Downsample convolutions),
 // 2x4x16 output tile whose 5 x 9 x 33 input patch is stored with even and odd W columns in separate row runs, so that the 16 voxels of
 // a fragment still read 16 consecutive LDS rows for every tap (the DMA source address is free per lane: any layout costs nothing).
-template <typename T, int NW, int MF, int S, int MINW>
+// KS = 3: the 3x3x3 kernel.  KS = 2 (in_mode 3): a nearest-2x up-sampling followed by a 3x3x3 convolution, evaluated as 8 sub-pixel
+// 2x2x2 convolutions on the LOW-resolution input -- of the 27 taps of an output voxel only 8 distinct input voxels exist, so the weights
+// are pre-summed per output parity (ops.py) and the launch does 8/27 of the multiply-adds (reference: Upsample = interpolate + conv,
+// diffusion_model_unet.py:572-585, autoencoderkl.py:76-93).  The parity is a grid dimension: it selects the weight image, the low-side
+// padding (1 - parity per axis) and the output sub-lattice the tile is written to.
+template <typename T, int NW, int MF, int S, int MINW, int KS = 3>
 __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * NW;
-  constexpr int NFR = 4, G = 3;
+  constexpr int NFR = 4, G = KS == 3 ? 3 : 2, RING = KS == 3 ? 3 : 4;  // taps per weight panel; panels in the LDS ring
+  static_assert(KS == 3 || (KS == 2 && S == 1 && NW == 8), "the sub-pixel variant is stride 1, 8 waves");
   static_assert(NW * MF * 16 == 512 || NW * MF * 16 == (S == 1 ? 256 : 128), "waves x fragments cover the tile");
   constexpr int TH = 4, TW = 16, BM = NW * MF * 16, TD = BM / (TH * TW);  // 4x4x16 (8x4x16 for the 16-wave variant); S = 2: 2x4x16
-  constexpr int PD = S * (TD - 1) + 3, PH = S * (TH - 1) + 3, PW = S * (TW - 1) + 3;  // LDS rows per W line (33 for S = 2: 17 even + 16 odd)
+  constexpr int PD = S * (TD - 1) + KS, PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS;  // LDS rows per W line (33 for S = 2: 17 even + 16 odd)
   constexpr int EW = TW + 1;                                                            // S = 2: rows of the even-column run
   constexpr int PLANE = ((PH * PW + 15) / 16) * 16;        // 112 rows: depth offsets keep (row mod 16)
   constexpr int PROWS = PD * PLANE;                        // 672 rows = 42 DMA pieces
@@ -61,11 +67,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   constexpr int WROWS = G * BN;                            // 192 rows per weight panel = 12 KiB = 1.5 pieces per wave
   constexpr int PATCH_BYTES = PROWS * DMA_ROWB;
   constexpr int WBUF_BYTES = WROWS * DMA_ROWB;
-  constexpr int NGROUPS = 9;                               // 27 taps / G
+  constexpr int NGROUPS = KS * KS * KS / G;                // 27 taps / 3, or 8 taps / 2
   // DMA instructions per wave per weight panel (12 pieces): 8 waves x (1 full + 1 half piece), 4 waves x 3 full, or -- 16 waves --
   // one full piece on waves 0..11 and none on waves 12..15 (the end-of-group wait count is then wave dependent)
-  constexpr int WPW = NW == 8 ? 2 : (NW == 4 ? 3 : 1);
-  static_assert(WROWS == 192, "12 pieces per weight panel");
+  constexpr int WPW = KS == 2 ? 1 : (NW == 8 ? 2 : (NW == 4 ? 3 : 1));  // KS = 2: 128 rows = 8 pieces, one per wave
+  static_assert(WROWS == (KS == 3 ? 192 : 128), "12 (or 8) pieces per weight panel");
+  static_assert(NGROUPS % RING == 0, "the ring slot of a group is a compile-time constant");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB]
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -75,10 +82,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
 
-  const int ntd = (p.Do + TD - 1) / TD, nth = (p.Ho + TH - 1) / TH, ntw = (p.Wo + TW - 1) / TW;
+  // KS = 2: the tiles walk the low-resolution grid (= the input grid); p.Do/Ho/Wo are the full-resolution output extents
+  const int Dt = KS == 2 ? p.Ds : p.Do, Ht = KS == 2 ? p.Hs : p.Ho, Wt = KS == 2 ? p.Ws : p.Wo;
+  const int ntd = (Dt + TD - 1) / TD, nth = (Ht + TH - 1) / TH, ntw = (Wt + TW - 1) / TW;
   const int ncb = (p.Cout + BN - 1) / BN;
   unsigned b = xcd_remap(blockIdx.x, gridDim.x);
   const int cb = b % ncb; b /= ncb;
+  int par = 0;
+  if (KS == 2) { par = b & 7; b >>= 3; }
   const int tw_i = b % ntw; b /= ntw;
   const int th_i = b % nth; b /= nth;
   const int td_i = b % ntd; b /= ntd;
@@ -86,7 +97,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
   int Dv = p.Ds, Hv = p.Hs, Wv = p.Ws;
   if (p.in_mode == 1) { Dv *= p.fd; Hv *= p.fh; Wv *= p.fw; }
-  const int ud0 = od0 * S - p.pd, uh0 = oh0 * S - p.ph, uw0 = ow0 * S - p.pw;
+  // KS = 2: output parity 0 reads inputs (i - 1, i), parity 1 reads (i, i + 1): low-side padding 1 - parity
+  const int ud0 = od0 * S - (KS == 2 ? 1 - ((par >> 2) & 1) : p.pd), uh0 = oh0 * S - (KS == 2 ? 1 - ((par >> 1) & 1) : p.ph),
+            uw0 = ow0 * S - (KS == 2 ? 1 - (par & 1) : p.pw);
   const int nchunks = p.Cin / BK;                          // host-checked: Cin % BK == 0
   const int cout_pad = (p.Cout + 15) & ~15;
   const int total = nchunks * NGROUPS;
@@ -125,12 +138,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   };
   // weight panel of global tap group t (chunk = t / 9, taps 3*(t%9) ..): rows r = u*64 + co_local.  Wave w moves rows
   // 16w .. 16w+15 (full piece) and rows 128 + 8w .. +7 (half piece, lanes 0..31).
-  const char* wbase = reinterpret_cast<const char*>(p.w);
+  const char* wbase = reinterpret_cast<const char*>(p.w) + (long long)par * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;  // parity image
   int wsrc[WPW];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
 #pragma unroll
   for (int h = 0; h < WPW; ++h) {
-    const int row = NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2))
-                            : (NW == 4 ? 16 * (wave + NW * h) + (lane >> 2) : 16 * (wave < 12 ? wave : 0) + (lane >> 2));
+    const int row = KS == 2 ? 16 * wave + (lane >> 2)
+                            : NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2))
+                                      : (NW == 4 ? 16 * (wave + NW * h) + (lane >> 2) : 16 * (wave < 12 ? wave : 0) + (lane >> 2));
     const int u = row >> 6, col = row & 63;
     const int co = cb * BN + col;
     wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
@@ -144,7 +158,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
     for (int h = 0; h < WPW; ++h) {
       const char* src = wsrc[h] >= 0 ? panel + wsrc[h] : zero + ((lane & 3) << 4);
-      if (NW == 8) {
+      if (KS == 2) {
+        dma16(src, dst + (unsigned)(16 * wave) * DMA_ROWB);
+      } else if (NW == 8) {
         if (h == 0) dma16(src, dst + (unsigned)(16 * wave) * DMA_ROWB);
         else if (lane < 32) dma16(src, dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
       } else if (NW == 16) {
@@ -156,15 +172,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   };
 
   // ---- per-lane operand read addresses (bytes from smem) ------------------------------------------------------------------
-  int xaddr[MF][3][3];  // voxel fragment mf at tap (0, kh, kw); depth taps add kd * PLANE * 64 as an immediate
+  int xaddr[MF][KS][KS];  // voxel fragment mf at tap (0, kh, kw); depth taps add kd * PLANE * 64 as an immediate
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int m = (wave * MF + mf) * 16 + l15;
     const int a = m >> 6, bb = (m >> 4) & 3, c = m & 15;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
+      for (int kw = 0; kw < KS; ++kw) {
         const int col = S == 1 ? c + kw : (kw == 1 ? EW + c : c + (kw >> 1));  // patch column S*c + kw in the split layout
         const int row = S * a * PLANE + (S * bb + kh) * PW + col;
         xaddr[mf][kh][kw] = row * DMA_ROWB + ((q ^ dma_swz(row)) << 4);
@@ -196,17 +212,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     for (int g = 0; g < NGROUPS; ++g) {
       const int t = chunk * NGROUPS + g;
       // panel t+2 goes into the ring slot group t-1 read from (every wave is past the barrier that ended it)
-      if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % 3);
+      if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % RING);
       // The last tap's operand reads are issued before the end-of-group wait and its MFMAs after the barrier.  The wait retires
       // every LDS read of the group (lgkmcnt(0)): the barrier releases other waves to DMA into the ring slot this group read.
       // (Measured against an ordering that keeps the two patch reads of the last tap in flight across the barrier: 2-3 % slower.)
       uint4 xf[MF], wf[NFR];
       auto read_tap = [&](int u) __attribute__((always_inline)) {
         const int tap = g * G + u;
-        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf)
-          wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + (g % 3) * WBUF_BYTES + u * (BN * DMA_ROWB));
+          wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
           xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[mf][kh][kw] + kd * (PLANE * DMA_ROWB));
@@ -317,7 +333,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
     for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
-  conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wave * MF * 16, cb * BN, od0, oh0, ow0, lane, st_s, st_q);
+  const ConvOutMap om = {p.Ds, p.Hs, p.Ws, (par >> 2) & 1, (par >> 1) & 1, par & 1};
+  conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wave * MF * 16, cb * BN, od0, oh0, ow0, lane, st_s, st_q,
+                                KS == 2 ? &om : nullptr);
   if (p.stats) {
     float* sst = reinterpret_cast<float*>(smem);  // [NW][64 channels][2]
     __syncthreads();
@@ -354,8 +372,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   }
 }
 
-// variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile
+// variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile; 4 = sub-pixel 2x2x2 (5 planes of 5 x 17 -> 96 rows,
+// four 128-row weight panels)
 extern "C" long long gm_conv_dma_lds_bytes(int variant) {
+  if (variant == 4) return 5LL * 96 * DMA_ROWB + 4LL * 128 * DMA_ROWB;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
   return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB;
 }
@@ -365,6 +385,15 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const int s = d->cfg == 15 ? 2 : 1;
+  if (d->cfg == 17) {  // sub-pixel up-sampling convolution: 8 parity images of a 2x2x2 kernel, output = 2x the input grid
+    return d->in_mode == 3 && d->kd == 2 && d->kh == 2 && d->kw == 2 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->dd == 1 && d->dh == 1 &&
+           d->dw == 1 && d->Do == 2 * d->Ds && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
+           (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->ltd == 2 && d->lth == 2 &&
+           d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
+           (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) && !d->skip_x[0] &&
+           (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31);
+  }
+  if (d->in_mode == 3) return 0;
   return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == s && d->sh == s && d->sw == s && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
          (d->in_mode == 0 || (d->in_mode == 1 && s == 1)) && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
          (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 &&
@@ -379,21 +408,22 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
                               (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
 }
 
-template <typename T, int NW, int MF, int S, int MINW>
+template <typename T, int NW, int MF, int S, int MINW, int KS = 3>
 static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_dma_kernel<T, NW, MF, S, MINW>;
+  auto kern = conv_dma_kernel<T, NW, MF, S, MINW, KS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(S == 2 ? 2 : (NW == 16 ? 3 : 1)), st>>>(d);
+  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(KS == 2 ? 4 : (S == 2 ? 2 : (NW == 16 ? 3 : 1))), st>>>(d);
 }
 
 template <typename T>
 static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
-  if (d.cfg == 16) launch_dma<T, 16, 2, 1, 4>(d, nblocks, st);       // 512 voxels (8x4x16), 16 waves, one work-group per CU
+  if (d.cfg == 17) launch_dma<T, 8, 2, 1, 4, 2>(d, nblocks, st);     // sub-pixel 2x2x2 kernels of an up-sampling convolution
+  else if (d.cfg == 16) launch_dma<T, 16, 2, 1, 4>(d, nblocks, st);  // 512 voxels (8x4x16), 16 waves, one work-group per CU
   else if (d.cfg == 15) launch_dma<T, 8, 1, 2, 2>(d, nblocks, st);   // stride 2: 8 waves x 16 voxels, one work-group per CU
   else if (d.cfg == 14) launch_dma<T, 4, 4, 1, 2>(d, nblocks, st);   // 4 waves x 64 voxels
   else launch_dma<T, 8, 2, 1, 4>(d, nblocks, st);                    // cfg 11: 8 waves x 32 voxels, two work-groups per CU

@@ -83,11 +83,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
 // Requirements (checked by the caller): Cout, y_ld (and res_ld) multiples of 16/sizeof(T), 16-byte aligned bases.
 // Optionally accumulates, per lane, sum / sum of squares of the values it stores (st_s/st_q[pass][i] = channel
 // co_base + pass*NF_PER_PASS*16 + (lane&7)*VECW + i over this lane's rows) for the fused GroupNorm statistics.
+// Sub-pixel output placement (in_mode 3, conv_dma.hip): the tile walks the LOW-resolution grid (Dl x Hl x Wl) and every voxel lands at
+// (2 od + pd, 2 oh + ph, 2 ow + pw) of the full-resolution output p.Do x p.Ho x p.Wo.
+struct ConvOutMap { int Dl, Hl, Wl, pd, ph, pw; };
+
 template <typename T, int MF, int NFR>
 __device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, int n, int m_base,
                                                   int co_base, int od0, int oh0, int ow0, int lane,
                                                   float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
-                                                  float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)]) {
+                                                  float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
+                                                  const ConvOutMap* om = nullptr) {
   constexpr int VECW = 16 / (int)sizeof(T);
   constexpr int ROWB_E = 144;                                   // 128 B of channels + 16 B pad
   constexpr int NF_PER_PASS = 128 / (16 * (int)sizeof(T));      // 4 (bf16) or 2 (fp32) channel fragments per pass
@@ -133,8 +138,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (
       const int m = m_base + v;
       const int a = m >> (p.lth + p.ltw), bb = (m >> p.ltw) & (th - 1), c = m & (tw - 1);
       const int od = od0 + a, oh = oh0 + bb, ow = ow0 + c;
-      if (od < p.Do && oh < p.Ho && ow < p.Wo && co < p.Cout) {
-        const long long vox = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+      const bool inside = om ? (od < om->Dl && oh < om->Hl && ow < om->Wl) : (od < p.Do && oh < p.Ho && ow < p.Wo);
+      if (inside && co < p.Cout) {
+        const long long vox = om ? (((long long)n * p.Do + 2 * od + om->pd) * p.Ho + 2 * oh + om->ph) * p.Wo + 2 * ow + om->pw
+                                 : (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
         uint4 raw = *reinterpret_cast<const uint4*>(lds + v * ROWB_E + seg * 16);
         if (res || p.post_act) {
           float o[VECW];

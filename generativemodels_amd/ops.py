@@ -163,6 +163,30 @@ def packed_conv_weight(weight: torch.Tensor, dtype: torch.dtype, transposed: boo
     return _cached(weight, ("pack", dtype, transposed, cin_range), make)
 
 
+SUBPIXEL_UPSAMPLE = True  # nearest-2x + 3x3x3 convolutions run as 8 sub-pixel 2x2x2 convolutions (8/27 of the multiply-adds)
+
+
+def packed_subpixel_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[Cout, Cin, 3, 3, 3] -> the 8 parity images of 2x2x2 kernels (packed back to back) of `Upsample(nearest 2x) -> conv3x3x3`.  Output
+    voxel 2i + p sees the up-sampled taps (2i + p - 1, 2i + p, 2i + p + 1) = input voxels (i - 1, i, i) for p = 0 and (i, i, i + 1)
+    for p = 1: per axis the three weights collapse to (w0, w1 + w2) resp. (w0 + w1, w2).  Summed in fp32, then rounded to `dtype`."""
+    require_device(weight)
+
+    def make():
+        w = weight.detach().float()
+        a = [torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 1.0]], device=w.device), torch.tensor([[1.0, 1.0, 0.0], [0.0, 0.0, 1.0]], device=w.device)]
+        cout, cin = w.shape[0], w.shape[1]
+        n = lib().gm_packed_conv_weight_elems(cout, cin, 2, 2, 2, dt_code(dtype))
+        out = torch.empty(8 * n, dtype=dtype, device=w.device)
+        for par in range(8):
+            w2 = torch.einsum("oiabc,xa,yb,zc->oixyz", w, a[(par >> 2) & 1], a[(par >> 1) & 1], a[par & 1]).contiguous()
+            check(lib().gm_pack_conv_weight(w2.data_ptr(), dt_code(w2.dtype), out[par * n:].data_ptr(), dt_code(dtype), cout, cin, 2, 2, 2, 0,
+                                            _stream()), "gm_pack_conv_weight")
+        return out
+
+    return _cached(weight, ("subpixel", dtype), make)
+
+
 def packed_cat_weight(weights: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
     """Linear weights [Cout_i, Cin] stacked along Cout and packed as one panel (fused q/k/v projections etc.)."""
 
@@ -585,6 +609,64 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
     desc.cfg, (desc.ltd, desc.lth, desc.ltw) = best[0], best[1]
 
 
+def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, cin, cout, src):
+    """Nearest-2x up-sampling + 3x3x3 convolution as 8 sub-pixel 2x2x2 convolutions (GmConvDesc.in_mode 3, configuration 17).
+    Returns None when the geometry is not covered (the caller falls back to the folded up-sampling path)."""
+    dtype = x.dtype
+    out_sp = tuple(2 * v for v in src)
+    out_shape = (n, *out_sp, cout)
+    if out is None:
+        out = torch.empty(out_shape, dtype=dtype, device=x.device)
+    elif tuple(out.shape) != out_shape or out.dtype != dtype:
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {out_shape}")
+    d = GmConvDesc()
+    packed = packed_subpixel_weight(weight, dtype)
+    d.in_mode, d.fd, d.fh, d.fw = 3, 2, 2, 2
+    d.x, d.x_ld, d.w = x.data_ptr(), arena_ld(x), packed.data_ptr()
+    b32 = as_f32(bias) if bias is not None else None
+    d.bias = _ptr(b32)
+    d.pre_scale = d.pre_shift = None
+    if rowvec is not None:
+        if rowvec.dtype != torch.float32 or rowvec.dim() != 2 or rowvec.shape[1] != cout or rowvec.shape[0] not in (1, n) or rowvec.stride(1) != 1:
+            raise ValueError(f"rowvec must be fp32 [1 or N, Cout], got {tuple(rowvec.shape)} {rowvec.dtype}")
+        d.rowvec, d.rowvec_bstride = rowvec.data_ptr(), (0 if rowvec.shape[0] == 1 else rowvec.stride(0))
+    else:
+        d.rowvec, d.rowvec_bstride = None, 0
+    if res is not None:
+        if tuple(res.shape) != out_shape or res.dtype != dtype:
+            raise ValueError(f"residual has shape {tuple(res.shape)} / {res.dtype}, expected {out_shape} / {dtype}")
+        d.res, d.res_ld = res.data_ptr(), arena_ld(res)
+    else:
+        d.res, d.res_ld = None, 0
+    d.y, d.y_ld = out.data_ptr(), arena_ld(out)
+    d.skip_w = d.skip_bias = None
+    d.skip_x[0] = d.skip_x[1] = None
+    d.N, d.Cin, d.Cout = n, cin, cout
+    d.Ds, d.Hs, d.Ws = src
+    d.Do, d.Ho, d.Wo = out_sp
+    d.kd = d.kh = d.kw = 2
+    d.sd = d.sh = d.sw = 1
+    d.pd = d.ph = d.pw = 0
+    d.dd = d.dh = d.dw = 1
+    d.pre_act, d.post_act, d.dtype = 0, POST_ACT[post_act], dt_code(dtype)
+    d.debug_flags = _CONV_DEBUG_FLAGS
+    d.cfg, d.ltd, d.lth, d.ltw = 17, 2, 2, 4
+    if lib().gm_conv_lds_bytes(C.byref(d)) <= 0:
+        return None
+    d.stats = None
+    if want_stats:
+        cst = _zero_stats(n, cout, x.device)
+        d.stats = cst.data_ptr()
+        out._gm_cstats = cst
+    nvo = n * math.prod(out_sp)
+    es = x.element_size()
+    _timed(f"conv_igemm<{str(dtype).split('.')[-1]},cfg17>",
+           dict(flops=2.0 * nvo * cout * cin * 27, bytes=float(es * (n * math.prod(src) * cin + nvo * cout * (2 if res is not None else 1) + 8 * cout * cin * 8)),
+                shape=f"{cin}->{cout} k(3, 3, 3) s(1, 1, 1) out{out_sp} mode3 (8/27 of the listed flops are executed)"),
+           lambda: check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward"))
+    return out
+
+
 def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *, kernel, stride=1, padding=0, dilation=1,
          pad_hi=None, upsample: bool = False, transposed: bool = False, output_padding=0,
          pre: Optional[tuple] = None, pre_act: str = "none", rowvec: Optional[torch.Tensor] = None,
@@ -649,6 +731,13 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                                                   out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act], POST_ACT[post_act], dt_code(dtype),
                                                   _stream()), "gm_linear_rows"))
         return out
+    if (upsample and SUBPIXEL_UPSAMPLE and nsp == 3 and k == (3, 3, 3) and s == (1, 1, 1) and plo == (1, 1, 1) and phi == (1, 1, 1)
+            and dil == (1, 1, 1) and pre is None and pre_act == "none" and skip is None and force_cfg is None and weight is not None
+            and cin % (64 // x.element_size()) == 0 and cout % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0
+            and math.prod(src) * n >= DMA_CONV_MIN_VOXELS):
+        got = _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, cin, cout, src)
+        if got is not None:
+            return got
     d = GmConvDesc()
     d.in_mode, d.fd, d.fh, d.fw = 0, 1, 1, 1
     act_axes = (0,) * (3 - nsp) + (1,) * nsp

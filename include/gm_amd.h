@@ -145,7 +145,9 @@ typedef struct GmConvDesc {
   int sd, sh, sw;
   int pd, ph, pw;            /* low-side padding */
   int dd, dh, dw;            /* dilation */
-  int in_mode;               /* 0 direct, 1 nearest up-sample, 2 zero insertion (transposed conv) */
+  int in_mode;               /* 0 direct, 1 nearest up-sample, 2 zero insertion (transposed conv), 3 nearest 2x up-sample + 3x3x3 kernel
+                              * evaluated as 8 sub-pixel 2x2x2 kernels on the low-resolution input: kd = kh = kw = 2, w = the 8 parity
+                              * images (d, h, w parity = bits 2, 1, 0) of pre-summed weights, Do/Ho/Wo = 2 x Ds/Hs/Ws, cfg = 17 */
   int fd, fh, fw;
   int pre_act;               /* 0 none, 1 SiLU, 2 ReLU */
   int post_act;              /* 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01), 6 GELU (erf) */

@@ -662,3 +662,36 @@ def test_fused_output_statistics_and_virtual_concat_groupnorm(dtype):
     y = ops.conv(h, wd, b1.to(DEV), kernel=1, packed=ops.packed_conv_weight(wd, dtype, cin_range=(0, ch)), cout=24)
     y = ops.conv(sk, wd, None, kernel=1, packed=ops.packed_conv_weight(wd, dtype, cin_range=(ch, ch + cs)), cout=24, res=y)
     _check(_cf(y), F.conv3d(full, w1.double()[:, :, None, None, None], b1.double()), dtype, "split 1x1 conv over a virtual concat", extra=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,cin,cout", [((5, 6, 19), 32, 64), ((8, 8, 8), 64, 32), ((4, 9, 33), 128, 96)])
+def test_upsample_conv_as_subpixel_convolutions(shape, cin, cout, dtype):
+    """Nearest-2x + 3x3x3 convolution evaluated as 8 sub-pixel 2x2x2 convolutions with pre-summed weights (in_mode 3, cfg 17: 8/27 of the
+    multiply-adds) vs torch (interpolate + conv3d, fp64) and vs the folded up-sampling path; ragged extents, residual, bias, timestep
+    row, fused output statistics."""
+    ops = _ops()
+    n = 2
+    x = _rand((n, cin, *shape), 401).to(dtype)
+    w = (_rand((cout, cin, 3, 3, 3), 402) / math.sqrt(cin * 27)).to(dtype)
+    b = _rand((cout,), 403) * 0.1
+    row = _rand((n, cout), 404) * 0.1
+    up = tuple(2 * v for v in shape)
+    res = _rand((n, cout, *up), 405).to(dtype)
+    want = F.conv3d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1) \
+        + row.double()[:, :, None, None, None] + res.double()
+    ops.start_profile()
+    got = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=3, padding=1, upsample=True, rowvec=row.to(DEV), res=_cl(res), want_stats=True)
+    names = [nm for nm, _, _ in ops.stop_profile()]
+    assert any("cfg17" in nm for nm in names), names
+    _check(_cf(got), want, dtype, "sub-pixel upsample conv", extra=2.0)
+    st = ops.channel_stats(got).sum(dim=0).cpu()  # [N, C, 2]: statistics of the values as stored
+    gd = _cf(got).double()
+    assert torch.allclose(st[..., 0], gd.sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[..., 1], (gd * gd).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
+    ops.SUBPIXEL_UPSAMPLE = False
+    try:
+        folded = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=3, padding=1, upsample=True, rowvec=row.to(DEV), res=_cl(res))
+    finally:
+        ops.SUBPIXEL_UPSAMPLE = True
+    _check(_cf(got), _cf(folded).double(), dtype, "sub-pixel vs folded up-sampling", extra=2.0)
