@@ -62,11 +62,13 @@ def measured_hbm_traffic(label: str, dtype) -> dict:
     except Exception:
         return dict(traffic=None)
     elem = "unsigned short" if dtype == torch.bfloat16 else "float"
+    # template arguments <T, waves, fragments, stride, min waves / EU[, kernel extent]>: the trailing kernel-extent argument (3, or 2 for the
+    # sub-pixel up-sampling variant) was added after the first PMC files were recorded, so cfg 11 matches "...4>" and "...4, 3>"
     sym = (f"conv_fast_kernel<{elem}, {FAST_CFG_TEMPLATE[cfg]}>" if cfg in FAST_CFG_TEMPLATE else
-           f"conv_dma_kernel<{elem}, 8, 2, 1, 4>" if cfg == 11 else f"conv_dma_kernel<{elem}, 4, 4, 1, 2>" if cfg == 14 else
-           f"conv_dma_kernel<{elem}, 8, 1, 2, 2>" if cfg == 15 else None)
+           f"conv_dma_kernel<{elem}, 8, 2, 1, 4" if cfg == 11 else f"conv_dma_kernel<{elem}, 4, 4, 1, 2" if cfg == 14 else
+           f"conv_dma_kernel<{elem}, 8, 1, 2, 2" if cfg == 15 else None)
     for r in rows:
-        if sym is not None and sym in r["kernel"]:
+        if sym is not None and sym in r["kernel"] and (cfg in FAST_CFG_TEMPLATE or r["kernel"].split(sym)[1][:4] in (">(Gm", ", 3>")):
             return dict(traffic=round(r["hbm_mb_per_launch_corrected"] * 1e6), traffic_unit="bytes/launch (avg over the same launches)",
                         traffic_source=os.path.relpath(TRAFFIC_FILE, ROOT), traffic_launches_sampled=r["launches"])
     return dict(traffic=None)
