@@ -23,7 +23,7 @@ import torch
 
 from . import ops
 
-__all__ = ["conv", "linear", "group_norm_act", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
+__all__ = ["conv", "linear", "group_norm_act", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
 
 
 def _tup(v, n):
@@ -276,3 +276,37 @@ class _Cat(torch.autograd.Function):
 def cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """Channel concatenation of two arena tensors (the decoder's skip connections, diffusion_model_unet.py:1232,1340,1461)."""
     return _Cat.apply(a, b)
+
+
+class _SiLU(torch.autograd.Function):
+    """SiLU of a small (N, L, C) tensor (the timestep-embedding MLP) on the GroupNorm apply / backward kernels with an identity affine."""
+
+    @staticmethod
+    def _tables(x):
+        c = x.shape[-1]
+        one = torch.ones((x.shape[0], c), dtype=torch.float32, device=x.device)
+        return one, torch.zeros_like(one)
+
+    @staticmethod
+    def forward(ctx, x):
+        one, zero = _SiLU._tables(x)
+        ctx.save_for_backward(x)
+        return ops.gn_apply(x.contiguous(), one, zero, "silu")
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        x, gy = x.contiguous(), gy.contiguous()
+        one, zero = _SiLU._tables(x)
+        n, c = x.shape[0], x.shape[-1]
+        v = ops.rows_of(x) // max(n, 1)
+        dx = torch.empty_like(x)
+        ops.check(ops.lib().gm_gn_bwd_apply(x.data_ptr(), ops.arena_ld(x), gy.data_ptr(), ops.arena_ld(gy), dx.data_ptr(), ops.arena_ld(dx),
+                                            one.data_ptr(), zero.data_ptr(), c, one.data_ptr(), zero.data_ptr(), zero.data_ptr(), n, v, c, 1,
+                                            ops.dt_code(x.dtype), ops._stream()), "gm_gn_bwd_apply")
+        return dx
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    """x * sigmoid(x) over an (N, L, C) tensor; differentiable."""
+    return _SiLU.apply(x)

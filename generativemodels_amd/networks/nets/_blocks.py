@@ -208,8 +208,8 @@ class ResnetBlock(nn.Module):
         h = A.group_norm_act(x, n1.weight, n1.bias, n1.num_groups, n1.eps, "silu")
         row = None
         if temb is not None:
-            # [N, temb] -> [N, Cout]: a handful of rows; the SiLU of this tiny vector is the one torch op of the block
-            row = A.linear(torch.nn.functional.silu(temb)[None], self.time_emb_proj.weight, self.time_emb_proj.bias)[0].float()
+            # [N, temb] -> [N, Cout]: a handful of rows through the small-row GEMM
+            row = A.linear(A.silu(temb[None]), self.time_emb_proj.weight, self.time_emb_proj.bias)[0].float()
         c1, c2 = self.conv1, self.conv2
         h = A.conv(h, c1.conv.weight, c1.conv.bias, kernel=c1.kernel_size, stride=1, padding=c1.padding, rowvec=row)
         h = A.group_norm_act(h, n2.weight, n2.bias, n2.num_groups, n2.eps, "silu")

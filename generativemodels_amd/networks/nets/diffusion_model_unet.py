@@ -407,7 +407,7 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tens
         raise TypeError(f"input dtype {x.dtype} does not match the model dtype {dtype}")
     t_emb = ops.timestep_embedding(timesteps.to(x.device), self.block_out_channels[0], dtype=dtype)
     l0, l2 = self.time_embed[0], self.time_embed[2]
-    emb = A.linear(torch.nn.functional.silu(A.linear(t_emb[None], l0.weight, l0.bias)), l2.weight, l2.bias)[0]  # [B_t, 4 C0]
+    emb = A.linear(A.silu(A.linear(t_emb[None], l0.weight, l0.bias)), l2.weight, l2.bias)[0]  # [B_t, 4 C0]
 
     def resample(blk, h):
         if isinstance(blk, ResnetBlock):
