@@ -298,3 +298,46 @@ def test_flash_attention_backward_cross_lengths(dtype):
     tol = 1e-4 if dtype == torch.float32 else 1.5e-2
     for name, got, r in zip("qkv", (dq, dk, dv), ref):
         _close(got, r.grad, tol, f"flash backward d{name}")
+
+
+def test_three_optimizer_steps_follow_the_reference_training_trajectory():
+    """The reference training step (ddpm_training_ddp.py:249-270: inferer(inputs, model, noise, timesteps) -> F.mse_loss(prediction, noise)
+    -> backward -> optimizer step) for three iterations on a small 2-D UNet, fp32: losses and every parameter after the third update
+    against the same loop run with torch autograd through the CPU oracle in fp64.  SGD with momentum stands in for the tutorial's Adam:
+    Adam divides by sqrt(v), which turns the rounding noise of analytically-zero gradients (a conv bias in front of a GroupNorm) into
+    +-lr steps and would make the comparison a coin toss.  DiffusionInferer.__call__ returns the differentiable prediction."""
+    import restatement as R
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    from generativemodels_amd.networks.schedulers import DDPMScheduler
+    cfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 64), attention_levels=(False, True),
+               num_head_channels=32, norm_num_groups=32)
+    torch.manual_seed(21)
+    model = DiffusionModelUNet(**cfg)
+    R.derandomize_zeros(model, seed=6)
+    ref = {k: v.detach().double().clone().requires_grad_("proj_attn" not in k) for k, v in model.state_dict().items()}
+    ref_opt = torch.optim.SGD([v for v in ref.values() if v.requires_grad], lr=0.05, momentum=0.9)
+    _, _, acp = R.noise_schedule("linear_beta", 1000)
+    model = model.to(DEV)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    inf = DiffusionInferer(DDPMScheduler(1000))
+    images = _rand((4, 1, 16, 16), 391)
+    for it in range(3):
+        noise = _rand((4, 1, 16, 16), 392 + it)
+        t = torch.tensor([11 + 200 * it, 950 - 300 * it, 500, 3 + it])
+        ref_opt.zero_grad()
+        ref_loss = F.mse_loss(R.unet_forward(ref, cfg, R.add_noise(acp, images, noise, t).double(), t), noise.double())
+        ref_loss.backward()
+        ref_opt.step()
+        opt.zero_grad(set_to_none=True)
+        pred = inf(inputs=images.to(DEV), diffusion_model=model, noise=noise.to(DEV), timesteps=t.to(DEV))
+        assert pred.requires_grad
+        loss = F.mse_loss(pred, noise.to(DEV))
+        loss.backward()
+        opt.step()
+        lv, rv = float(loss.detach()), float(ref_loss.detach())
+        assert abs(lv - rv) <= 2e-4 * max(1.0, rv), (it, lv, rv)
+    for name, p in model.named_parameters():
+        if "proj_attn" in name:
+            continue
+        _close(p, ref[name], 5e-4, f"after 3 steps: {name}")
