@@ -23,7 +23,7 @@ import torch
 
 from . import ops
 
-__all__ = ["conv", "linear", "group_norm_act", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
+__all__ = ["conv", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
 
 
 def _tup(v, n):
@@ -199,7 +199,7 @@ class _Attention(torch.autograd.Function):
         # Measured on MI355X (tools/cmp_attention_backward.py): the fused kernels own 64 rows per work-group, so ONE head of a few
         # thousand tokens leaves most CUs idle (L = 4096, d = 128: 1.9 ms fused vs 0.86 ms composed), while many (sample, head) pairs
         # favour them (2 x 4 heads of 1024 tokens: 0.21 vs 2.5 ms) and long sequences leave no choice (the composed path stores L x L).
-        composed_ok = dh % 4 == 0 and lq % 4 == 0 and lk % 4 == 0 and max(lq, lk) <= ATTENTION_BWD_MAX_TOKENS
+        composed_ok = max(lq, lk) <= ATTENTION_BWD_MAX_TOKENS
         prefer_composed = composed_ok and b * heads <= 2 and max(lq, lk) >= 2048
         if dh in ops.ATTENTION_BWD_HEAD_DIMS and not prefer_composed:
             # fused flash backward: scores recomputed tile by tile, any sequence length
@@ -209,8 +209,6 @@ class _Attention(torch.autograd.Function):
         if max(lq, lk) > ATTENTION_BWD_MAX_TOKENS:
             raise NotImplementedError(f"attention backward materialises the {lq} x {lk} score matrix per head: sequences above "
                                       f"{ATTENTION_BWD_MAX_TOKENS} tokens need the fused flash backward (not built yet)")
-        if dh % 4 or lk % 4 or lq % 4:
-            raise NotImplementedError("attention backward: head dim and sequence lengths must be multiples of 4")
         f32 = torch.float32
         go = go.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -310,3 +308,85 @@ class _SiLU(torch.autograd.Function):
 def silu(x: torch.Tensor) -> torch.Tensor:
     """x * sigmoid(x) over an (N, L, C) tensor; differentiable."""
     return _SiLU.apply(x)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        ctx.dtypes = (None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
+        return ops.layernorm(x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma = ctx.saved_tensors
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dg, db = ops.layernorm_backward(x, gy.contiguous(), gamma, ctx.eps, want_param_grads=want)
+        dg = dg.to(ctx.dtypes[0]) if (dg is not None and ctx.needs_input_grad[1]) else None
+        db = db.to(ctx.dtypes[1]) if (db is not None and ctx.needs_input_grad[2]) else None
+        return dx, dg, db, None
+
+
+def layer_norm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    """nn.LayerNorm over the last dim of (N, L, C); differentiable in x, gamma, beta."""
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _GEGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.geglu(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return ops.geglu_backward(x, gy.contiguous())
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    """x[..., :M] * gelu(x[..., M:]) (MONAI MLPBlock act="GEGLU"); differentiable."""
+    return _GEGLU.apply(x)
+
+
+class _Resample2x(torch.autograd.Function):
+    """Nearest 2x up-sampling / 2x average pooling of an arena tensor (the resblock_updown ResnetBlocks, diffusion_model_unet.py:674-682)."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        ctx.mode = mode
+        ctx.cells = float(2 ** (x.dim() - 2))
+        return ops.resample2x(x, mode)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        if ctx.mode == "up":   # every input voxel fed 2^d outputs: sum = 2^d x their average
+            return ops.scale(ops.resample2x(gy, "down"), ctx.cells), None
+        return ops.scale(ops.resample2x(gy, "up"), ctx.cells, True), None  # average pooling: each input gets gy / 2^d
+
+
+def resample2x(x: torch.Tensor, mode: str) -> torch.Tensor:
+    return _Resample2x.apply(x, mode)
+
+
+class _Embedding(torch.autograd.Function):
+    """nn.Embedding lookup of a handful of class labels (diffusion_model_unet.py:1897-1902); the weight gradient is a scatter-add of the
+    N gradient rows into a [num_classes, C] table -- left to torch (N rows)."""
+
+    @staticmethod
+    def forward(ctx, labels, weight):
+        ctx.save_for_backward(labels)
+        ctx.shape, ctx.dtype = weight.shape, weight.dtype
+        return ops.vq_gather(labels, weight, weight.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (labels,) = ctx.saved_tensors
+        dw = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device).index_add_(0, labels, g.float())
+        return None, dw.to(ctx.dtype)
+
+
+def embedding(labels: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    return _Embedding.apply(labels, weight)

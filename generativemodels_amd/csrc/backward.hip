@@ -714,3 +714,104 @@ extern "C" int gm_softmax_bwd(const float* probs, const float* dprobs, float* ds
   softmax_bwd_kernel<<<(unsigned)rows, 64, 0, (hipStream_t)stream>>>(probs, dprobs, dscores, V, scale);
   GM_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward (nn.LayerNorm of the transformer blocks, diffusion_model_unet.py:219-223): one wave per row.
+//   xhat = (x - mean) rstd,  g = gy gamma,  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat));
+//   param_stats[slot][c] += {sum_rows gy xhat, sum_rows gy}  (fp64, GM_STAT_SLOTS slots, zeroed by the caller; nullable)
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ gy, long long gy_ld,
+                                                           T* __restrict__ dx, long long dx_ld, const float* __restrict__ gamma, long long rows,
+                                                           int C, float eps, double* __restrict__ param_stats) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* acc = reinterpret_cast<float*>(smem_raw);  // [4 waves][C][2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  for (int c = lane; c < C; c += 64) { acc[(wave * C + c) * 2] = 0.f; acc[(wave * C + c) * 2 + 1] = 0.f; }
+  if (row < rows) {
+    const T* xr = x + row * x_ld;
+    const T* gr = gy + row * gy_ld;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ElemIO<T>::ld(xr + c);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = ElemIO<T>::ld(xr + c) - mean; q += d * d; }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (ElemIO<T>::ld(xr + c) - mean) * rstd, g = ElemIO<T>::ld(gr + c) * (gamma ? gamma[c] : 1.f);
+      m1 += g; m2 += g * xh;
+    }
+    for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+    m1 /= (float)C; m2 /= (float)C;
+    T* dr = dx + row * dx_ld;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (ElemIO<T>::ld(xr + c) - mean) * rstd, gv = ElemIO<T>::ld(gr + c);
+      ElemIO<T>::st(dr + c, rstd * (gv * (gamma ? gamma[c] : 1.f) - m1 - xh * m2));
+      acc[(wave * C + c) * 2] = gv * xh;
+      acc[(wave * C + c) * 2 + 1] = gv;
+    }
+  }
+  if (!param_stats) return;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 4; ++w) { a += (double)acc[(w * C + c) * 2]; b += (double)acc[(w * C + c) * 2 + 1]; }
+    double* dst = param_stats + (((long long)(blockIdx.x % GM_STAT_SLOTS)) * C + c) * 2;
+    atomicAdd(dst, a);
+    atomicAdd(dst + 1, b);
+  }
+}
+
+extern "C" int gm_layernorm_bwd(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, const float* gamma,
+                                long long rows, int C, float eps, double* param_stats, int dtype, void* stream) {
+  GM_REQUIRE(x && gy && dx, "null pointer");
+  GM_REQUIRE(C > 0 && C <= 4096, "LayerNorm width out of range");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const size_t smem = (size_t)4 * C * 2 * sizeof(float);
+  if (dtype == GM_F32)
+    layernorm_bwd_kernel<float><<<grid, 256, smem, st>>>((const float*)x, x_ld, (const float*)gy, gy_ld, (float*)dx, dx_ld, gamma, rows, C, eps, param_stats);
+  else if (dtype == GM_BF16)
+    layernorm_bwd_kernel<bf16_raw><<<grid, 256, smem, st>>>((const bf16_raw*)x, x_ld, (const bf16_raw*)gy, gy_ld, (bf16_raw*)dx, dx_ld, gamma, rows, C,
+                                                            eps, param_stats);
+  else
+    GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+// GEGLU backward (MONAI MLPBlock act = "GEGLU", diffusion_model_unet.py:211): y = a * gelu(gate), x = [a | gate]:
+//   dx[:, :inner] = gy * gelu(gate),  dx[:, inner:] = gy * a * gelu'(gate),  gelu'(g) = Phi(g) + g phi(g)
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ gy, long long gy_ld,
+                                                       T* __restrict__ dx, long long dx_ld, long long rows, int inner) {
+  const long long total = rows * inner;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / inner;
+    const int j = (int)(i - r * inner);
+    const float a = ElemIO<T>::ld(x + r * x_ld + j), g = ElemIO<T>::ld(x + r * x_ld + inner + j), go = ElemIO<T>::ld(gy + r * gy_ld + j);
+    const float cdf = 0.5f * (1.0f + erff(g * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * g * g);
+    ElemIO<T>::st(dx + r * dx_ld + j, go * g * cdf);
+    ElemIO<T>::st(dx + r * dx_ld + inner + j, go * a * (cdf + g * pdf));
+  }
+}
+
+extern "C" int gm_geglu_bwd(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, long long rows, int inner,
+                            int dtype, void* stream) {
+  GM_REQUIRE(x && gy && dx, "null pointer");
+  const long long total = rows * inner;
+  if (total == 0) return 0;
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32) geglu_bwd_kernel<float><<<(int)g, 256, 0, st>>>((const float*)x, x_ld, (const float*)gy, gy_ld, (float*)dx, dx_ld, rows, inner);
+  else if (dtype == GM_BF16)
+    geglu_bwd_kernel<bf16_raw><<<(int)g, 256, 0, st>>>((const bf16_raw*)x, x_ld, (const bf16_raw*)gy, gy_ld, (bf16_raw*)dx, dx_ld, rows, inner);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}

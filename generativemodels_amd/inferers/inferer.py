@@ -92,10 +92,10 @@ class DiffusionInferer(Inferer):
             noisy = ops.concat_dim1([noisy, condition])
             condition = None
         diffusion_model = _bind_seg(diffusion_model, seg)
-        if condition is None and torch.is_grad_enabled() and getattr(diffusion_model, "supports_training", lambda: False)() \
+        if torch.is_grad_enabled() and getattr(diffusion_model, "supports_training", lambda: False)() \
                 and any(p.requires_grad for p in diffusion_model.parameters()):
             # a training step (ddpm_training_ddp.py:249-270): the differentiable forward, native kernels in both directions
-            return diffusion_model.forward_train(noisy, timesteps)
+            return diffusion_model.forward_train(noisy, timesteps, context=condition)
         return diffusion_model(x=noisy, timesteps=timesteps, context=condition)
 
     @torch.no_grad()

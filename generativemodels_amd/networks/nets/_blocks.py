@@ -199,13 +199,14 @@ class ResnetBlock(nn.Module):
     def run_train(self, x: torch.Tensor, temb: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The same block with gradients: x an arena tensor, temb the [N, temb_channels] timestep embedding.
         Native kernels in both directions (generativemodels_amd.autograd); the GroupNorm-apply passes are materialised because their
-        outputs are what the weight-gradient kernel contracts against.  The up / down resampling variants are not covered yet."""
+        outputs are what the weight-gradient kernel contracts against."""
         from ... import autograd as A
 
-        if self.up or self.down:
-            raise NotImplementedError("run_train: resblock_updown blocks are not differentiable yet")
         n1, n2 = self.norm1, self.norm2
         h = A.group_norm_act(x, n1.weight, n1.bias, n1.num_groups, n1.eps, "silu")
+        if self.up or self.down:  # resblock_updown: BOTH branches are resampled after norm1 + SiLU (diffusion_model_unet.py:674-682)
+            mode = "up" if self.up else "down"
+            x, h = A.resample2x(x, mode), A.resample2x(h, mode)
         row = None
         if temb is not None:
             # [N, temb] -> [N, Cout]: a handful of rows through the small-row GEMM

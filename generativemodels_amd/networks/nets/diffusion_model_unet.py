@@ -56,6 +56,16 @@ class CrossAttention(nn.Module):
         a = ops.attention(q, k, v, self.num_heads, self.scale)
         return lin(a, self.to_out[0], res=residual)
 
+    def run_train(self, x_norm: torch.Tensor, context: Optional[torch.Tensor], residual: torch.Tensor) -> torch.Tensor:
+        from ... import autograd as A
+
+        kv_src = x_norm if context is None else context
+        q = A.linear(x_norm, self.to_q.weight)
+        k = A.linear(kv_src, self.to_k.weight)
+        v = A.linear(kv_src, self.to_v.weight)
+        a = A.attention(q, k, v, self.num_heads, self.scale)
+        return A.linear(a, self.to_out[0].weight, self.to_out[0].bias, res=residual)
+
 
 class _GEGLUMLP(nn.Module):
     """MONAI MLPBlock(hidden, mlp_dim, act="GEGLU") container: linear1 -> x*gelu(gate) -> linear2."""
@@ -69,6 +79,12 @@ class _GEGLUMLP(nn.Module):
 
     def run(self, x_norm: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         return lin(ops.geglu(lin(x_norm, self.linear1)), self.linear2, res=residual)
+
+    def run_train(self, x_norm: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        from ... import autograd as A
+
+        h = A.geglu(A.linear(x_norm, self.linear1.weight, self.linear1.bias))
+        return A.linear(h, self.linear2.weight, self.linear2.bias, res=residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -90,6 +106,14 @@ class BasicTransformerBlock(nn.Module):
         x = self.attn1.run(ln(self.norm1, x), None, x)
         x = self.attn2.run(ln(self.norm2, x), context, x)
         return self.ff.run(ln(self.norm3, x), x)
+
+    def run_train(self, x: torch.Tensor, context: Optional[torch.Tensor]) -> torch.Tensor:
+        from ... import autograd as A
+
+        ln = lambda m, t: A.layer_norm(t, m.weight, m.bias, m.eps)
+        x = self.attn1.run_train(ln(self.norm1, x), None, x)
+        x = self.attn2.run_train(ln(self.norm2, x), context, x)
+        return self.ff.run_train(ln(self.norm3, x), x)
 
 
 class SpatialTransformer(nn.Module):
@@ -114,6 +138,17 @@ class SpatialTransformer(nn.Module):
         for blk in self.transformer_blocks:
             t = blk.run(t, context)
         return self.proj_out.run(t.reshape(h.shape), res=x)
+
+    def run_train(self, x: torch.Tensor, context: Optional[torch.Tensor]) -> torch.Tensor:
+        from ... import autograd as A
+
+        n = self.norm
+        h = A.group_norm_act(x, n.weight, n.bias, n.num_groups, n.eps, "none")
+        h = A.conv(h, self.proj_in.conv.weight, self.proj_in.conv.bias, kernel=1)
+        t = tokens(h)
+        for blk in self.transformer_blocks:
+            t = blk.run_train(t, context)
+        return A.conv(t.reshape(h.shape), self.proj_out.conv.weight, self.proj_out.conv.bias, kernel=1, res=x)
 
 
 class _Downsample(nn.Module):
@@ -390,15 +425,19 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
             return ops.to_channels_first(y)
 
 
-def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor | None = None,
+                   class_labels: torch.Tensor | None = None) -> torch.Tensor:
     """DiffusionModelUNet.forward with gradients (the reference's training step differentiates the same
     forward through torch autograd: ddpm_training_ddp.py:249-270).  Every layer runs native kernels in both directions
-    (generativemodels_amd.autograd).  Covered: the unconditioned network (AttentionBlock levels, strided-convolution / nearest +
-    convolution resampling); cross-attention conditioning, class embeddings and resblock_updown are inference-only for now."""
+    (generativemodels_amd.autograd).  Covered: every DiffusionModelUNet configuration -- AttentionBlock or SpatialTransformer levels
+    (cross-attention on `context`, LayerNorm / GEGLU backward kernels), class embeddings, strided-convolution / nearest + convolution or
+    resblock_updown resampling.  ControlNet residuals and the SPADE variant are inference-only."""
     from ... import autograd as A
 
-    if self.with_conditioning or self.num_class_embeds is not None or self._spade is not None:
-        raise NotImplementedError("forward_train covers the unconditioned DiffusionModelUNet")
+    if self._spade is not None:
+        raise NotImplementedError("forward_train: the SPADE variant is inference-only")
+    if context is not None and self.with_conditioning is False:
+        raise ValueError("model should have with_conditioning = True if context is provided")
     if timesteps.ndim != 1 or timesteps.shape[0] not in (1, x.shape[0]):
         raise ValueError("timesteps must be 1-D with one entry, or one per batch element")
     ops.require_device(x)
@@ -408,10 +447,23 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tens
     t_emb = ops.timestep_embedding(timesteps.to(x.device), self.block_out_channels[0], dtype=dtype)
     l0, l2 = self.time_embed[0], self.time_embed[2]
     emb = A.linear(A.silu(A.linear(t_emb[None], l0.weight, l0.bias)), l2.weight, l2.bias)[0]  # [B_t, 4 C0]
+    if self.num_class_embeds is not None:
+        if class_labels is None:
+            raise ValueError("class_labels should be provided when num_class_embeds > 0")
+        ce = A.embedding(class_labels.to(x.device), self.class_embedding.weight)
+        if ce.shape[0] != emb.shape[0]:
+            raise ValueError("class_labels and timesteps must have the same batch size")
+        emb = A.add(emb[None], ce[None])[0]
+    if context is not None:
+        ops.require_device(context)
+        context = ops.cast(context.contiguous(), dtype)
+
+    def attend(blk, h):
+        return blk.run_train(h, context) if isinstance(blk, SpatialTransformer) else blk.run_train(h)
 
     def resample(blk, h):
         if isinstance(blk, ResnetBlock):
-            raise NotImplementedError("forward_train: resblock_updown is inference-only for now")
+            return blk.run_train(h, emb)
         if isinstance(blk, _Downsample):
             c = blk.op
             return A.conv(h, c.conv.weight, c.conv.bias, kernel=3, stride=2, padding=c.padding)
@@ -424,18 +476,18 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tens
         for j, rb in enumerate(st.resnets):
             h = rb.run_train(h, emb)
             if st.attentions is not None:
-                h = st.attentions[j].run_train(h)
+                h = attend(st.attentions[j], h)
             skips.append(h)
         if st.resampler_name == "downsampler":
             h = resample(st.downsampler, h)
             skips.append(h)
     mb = self.middle_block
-    h = mb.resnet_2.run_train(mb.attention.run_train(mb.resnet_1.run_train(h, emb)), emb)
+    h = mb.resnet_2.run_train(attend(mb.attention, mb.resnet_1.run_train(h, emb)), emb)
     for st in self.up_blocks:
         for j, rb in enumerate(st.resnets):
             h = rb.run_train(A.cat(h, skips.pop()), emb)
             if st.attentions is not None:
-                h = st.attentions[j].run_train(h)
+                h = attend(st.attentions[j], h)
         if st.resampler_name == "upsampler":
             h = resample(st.upsampler, h)
     n = self.out[0]
@@ -446,8 +498,7 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tens
 
 def _supports_training(self) -> bool:
     """True when forward_train covers this configuration (DiffusionInferer.__call__ then returns a differentiable prediction)."""
-    return (not self.with_conditioning and self.num_class_embeds is None and self._spade is None
-            and not any(isinstance(m, ResnetBlock) and (m.up or m.down) for m in self.modules()))
+    return self._spade is None
 
 
 DiffusionModelUNet.forward_train = _forward_train

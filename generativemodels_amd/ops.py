@@ -946,7 +946,12 @@ def bias_grad(gy: torch.Tensor, per_sample: bool = False) -> torch.Tensor:
     per-sample row vector a convolution adds in its epilogue)."""
     require_device(gy)
     n, c = gy.shape[0], gy.shape[-1]
-    st = channel_stats(gy)
+    # Fresh statistics, never the tensor's cached table: a gradient tensor can be accumulated IN PLACE by the autograd engine after a first
+    # consumer attached its column sums to the Python object (dres = gy hands the same object to two branches) -- measured as 12-24 %
+    # errors in exactly the bias gradients behind an identity residual.
+    v = rows_of(gy) // max(n, 1)
+    st = _zero_stats(n, c, gy.device)
+    check(lib().gm_gn_channel_stats(gy.data_ptr(), arena_ld(gy), n, v, c, st.data_ptr(), dt_code(gy.dtype), _stream()), "gm_gn_channel_stats")
     out = torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=gy.device)
     check(lib().gm_stats_colsum(st.data_ptr(), n, c, out.data_ptr(), int(per_sample), _stream()), "gm_stats_colsum")
     return out
@@ -1012,6 +1017,38 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: tor
                                                               shape=f"B{b} H{heads} L{lq}x{lk} d{dh}"),
            lambda: check(lib().gm_attention_backward(C.byref(d), _stream()), "gm_attention_backward"))
     return dq, dk, dv
+
+
+def layernorm_backward(x: torch.Tensor, gy: torch.Tensor, gamma: Optional[torch.Tensor], eps: float, want_param_grads: bool = True):
+    """nn.LayerNorm backward over the last dim: -> (dx, dgamma, dbeta) with fp32 [C] parameter gradients (None when not requested)."""
+    require_device(x, gy, gamma)
+    if gy.shape != x.shape or gy.dtype != x.dtype:
+        raise ValueError("layernorm_backward: gy must match x")
+    c = x.shape[-1]
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    st = torch.zeros((STAT_SLOTS, c, 2), dtype=torch.float64, device=x.device) if want_param_grads else None
+    check(lib().gm_layernorm_bwd(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), _ptr(as_f32(gamma)),
+                                 rows_of(x), c, float(eps), _ptr(st), dt_code(x.dtype), _stream()), "gm_layernorm_bwd")
+    if not want_param_grads:
+        return dx, None, None
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    flat = st.view(-1)
+    check(lib().gm_stats_colsum(flat.data_ptr(), 1, c, dgamma.data_ptr(), 0, _stream()), "gm_stats_colsum")
+    check(lib().gm_stats_colsum(flat[1:].data_ptr(), 1, c, dbeta.data_ptr(), 0, _stream()), "gm_stats_colsum")
+    return dx, dgamma, dbeta
+
+
+def geglu_backward(x: torch.Tensor, gy: torch.Tensor) -> torch.Tensor:
+    """Backward of geglu(x) = x[..., :M] * gelu(x[..., M:]): -> dx with the shape of x."""
+    require_device(x, gy)
+    inner = x.shape[-1] // 2
+    if gy.shape != (*x.shape[:-1], inner) or gy.dtype != x.dtype:
+        raise ValueError("geglu_backward: gy must be the forward output's shape")
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    check(lib().gm_geglu_bwd(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), rows_of(x), inner,
+                             dt_code(x.dtype), _stream()), "gm_geglu_bwd")
+    return dx
 
 
 def softmax_bwd(probs: torch.Tensor, dprobs: torch.Tensor, scale: float) -> torch.Tensor:

@@ -306,6 +306,14 @@ int gm_attention_backward(const GmAttnBwdDesc* d, void* stream);
  * (the softmax of diffusion_model_unet.py:143-153 / 407-415 under torch autograd) */
 int gm_softmax_bwd(const float* probs, const float* dprobs, float* dscores, long long rows, int V, float scale, void* stream);
 
+/* nn.LayerNorm backward (diffusion_model_unet.py:219-223 under autograd): dx per row; param_stats[slot][c] += {sum_rows gy xhat, sum_rows gy}
+ * (fp64 [GM_STAT_SLOTS][C][2], zeroed by the caller, nullable): dgamma / dbeta = gm_stats_colsum over the two components */
+int gm_layernorm_bwd(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, const float* gamma,
+                     long long rows, int C, float eps, double* param_stats, int dtype, void* stream);
+/* GEGLU backward: x = [a | gate] (2 * inner channels), y = a * gelu(gate) -> dx = [gy gelu(gate) | gy a gelu'(gate)] */
+int gm_geglu_bwd(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, long long rows, int inner, int dtype,
+                 void* stream);
+
 /* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */
 int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long long* indices, long long tokens,
                  int num_embeddings, int dim, int dtype, void* stream);

@@ -188,7 +188,8 @@ def test_resnet_block_trains_like_the_torch_reference(cin, cout, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("b,l,heads,dh", [(2, 64, 2, 16), (1, 200, 1, 64), (1, 512, 4, 8), (1, 301, 2, 128), (2, 96, 1, 256), (1, 77, 3, 32)])
+@pytest.mark.parametrize("b,l,heads,dh", [(2, 64, 2, 16), (1, 200, 1, 64), (1, 512, 4, 8), (1, 301, 2, 128), (2, 96, 1, 256), (1, 77, 3, 32),
+                                          (2, 64, 4, 4), (2, 30, 2, 6)])
 def test_attention_backward(b, l, heads, dh, dtype):
     """autograd.attention: flash-attention forward; backward by the fused flash kernels (head dims 16 .. 256, ragged sequence lengths)
     or, for other head dims, composed in fp32 from the GEMM / weight-gradient / gm_softmax_bwd kernels -- vs torch autograd in fp64."""
@@ -341,3 +342,96 @@ def test_three_optimizer_steps_follow_the_reference_training_trajectory():
         if "proj_attn" in name:
             continue
         _close(p, ref[name], 5e-4, f"after 3 steps: {name}")
+
+
+COND_TRAIN_CASES = {
+    # cross-attention (2 transformer layers, context of 3 tokens), class embedding, resblock_updown, 2 -> 3 channels
+    "cond2d": dict(cfg=dict(spatial_dims=2, in_channels=2, out_channels=3, num_channels=(8, 16, 16), attention_levels=(False, True, True),
+                            num_res_blocks=1, norm_num_groups=8, num_head_channels=4, with_conditioning=True, cross_attention_dim=5,
+                            transformer_num_layers=2, resblock_updown=True, num_class_embeds=4),
+                   shape=(2, 2, 8, 8), context=(2, 3, 5), class_labels=[1, 3]),
+    "cond3d": dict(cfg=dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(8, 16), attention_levels=(True, True),
+                            num_res_blocks=(1, 2), norm_num_groups=8, num_head_channels=(8, 4), with_conditioning=True, cross_attention_dim=3,
+                            upcast_attention=True), shape=(2, 1, 8, 8, 8), context=(2, 1, 3), class_labels=None),
+}
+
+
+@pytest.mark.parametrize("case,dtype", [("cond2d", torch.float32), ("cond3d", torch.float32), ("cond2d", torch.bfloat16)])
+def test_conditioned_unet_training_gradients_match_the_oracle_autograd(case, dtype):
+    """forward_train of the conditioned networks: SpatialTransformer levels (LayerNorm / GEGLU / cross-attention backward, context of 1-3
+    tokens), class embedding, resblock_updown resampling -- every parameter gradient against torch autograd through the CPU oracle (fp64)."""
+    import restatement as R
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    c = COND_TRAIN_CASES[case]
+    cfg = c["cfg"]
+    torch.manual_seed(13)
+    model = DiffusionModelUNet(**cfg)
+    R.derandomize_zeros(model, seed=8)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(dtype).float())
+    x, ctx = _rand(c["shape"], 411).to(dtype), _rand(c["context"], 412).to(dtype)
+    t = torch.tensor([40, 731])
+    labels = None if c["class_labels"] is None else torch.tensor(c["class_labels"])
+    target = _rand((c["shape"][0], cfg["out_channels"], *c["shape"][2:]), 413).to(dtype)
+    sd = {k_: v_.detach().double().requires_grad_(True) for k_, v_ in model.state_dict().items()}
+    y_ref = R.unet_forward(sd, cfg, x.double(), t, ctx.double(), labels)
+    F.mse_loss(y_ref, target.double()).backward()
+    model = model.to(DEV).to(dtype)
+    y = model.forward_train(x.to(DEV), t.to(DEV), context=ctx.to(DEV), class_labels=None if labels is None else labels.to(DEV))
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    _close(y, y_ref, tol, f"{case} train forward")
+    F.mse_loss(y.float(), target.to(DEV).float()).backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if "proj_attn" in name:
+            assert p.grad is None
+            continue
+        assert p.grad is not None, name
+        _close(p.grad, sd[name].grad, tol * 3, f"{case} d {name}")
+        checked += 1
+    assert checked > 60
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,c", [(37, 16), (130, 96), (5, 320)])
+def test_layer_norm_and_geglu_backward(rows, c, dtype):
+    from generativemodels_amd import autograd as A
+    x = (_rand((2, rows, c), 421) * 1.3 + 0.2).to(dtype)
+    gamma, beta = 1 + 0.2 * _rand((c,), 422), 0.1 * _rand((c,), 423)
+    gy = _rand((2, rows, c), 424).to(dtype)
+    xr, gr, br = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    (F.layer_norm(xr, (c,), gr, br, 1e-5) * gy.double()).sum().backward()
+    xd, gd, bd = x.to(DEV).requires_grad_(True), gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    y = A.layer_norm(xd, gd, bd, 1e-5)
+    y.backward(gy.to(DEV))
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    _close(xd.grad, xr.grad, tol, "layer norm dx")
+    _close(gd.grad, gr.grad, 2e-4 if dtype == torch.float32 else 2e-2, "layer norm dgamma")
+    _close(bd.grad, br.grad, 2e-4 if dtype == torch.float32 else 2e-2, "layer norm dbeta")
+    if c % 2 == 0:
+        go = _rand((2, rows, c // 2), 425).to(dtype)
+        xr2 = x.double().requires_grad_(True)
+        a, g = xr2.chunk(2, dim=-1)
+        ((a * F.gelu(g)) * go.double()).sum().backward()
+        xd2 = x.to(DEV).requires_grad_(True)
+        A.geglu(xd2).backward(go.to(DEV))
+        _close(xd2.grad, xr2.grad, tol, "geglu dx")
+
+
+@pytest.mark.parametrize("lk", [1, 3])
+def test_cross_attention_backward_with_a_tiny_context(lk):
+    from generativemodels_amd import autograd as A
+    b, lq, heads, dh = 2, 64, 4, 4
+    c = heads * dh
+    scale = 1 / math.sqrt(dh)
+    q, k, v, go = _rand((b, lq, c), 431), _rand((b, lk, c), 432), _rand((b, lk, c), 433), _rand((b, lq, c), 434)
+    ref = [t.double().requires_grad_(True) for t in (q, k, v)]
+    qh = ref[0].reshape(b, lq, heads, dh).transpose(1, 2)
+    kh, vh = (t.reshape(b, lk, heads, dh).transpose(1, 2) for t in ref[1:])
+    o_ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(b, lq, c)
+    (o_ref * go.double()).sum().backward()
+    dev = [t.to(DEV).requires_grad_(True) for t in (q, k, v)]
+    A.attention(*dev, heads, scale).backward(go.to(DEV))
+    for name, d, r in zip("qkv", dev, ref):
+        _close(d.grad, r.grad, 1e-4, f"cross attention (lk = {lk}) d{name}")
