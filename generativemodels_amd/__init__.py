@@ -12,7 +12,8 @@ import sys
 
 __version__ = "0.1.0"
 
-_MIRRORED = ["", ".networks", ".networks.nets", ".networks.schedulers", ".networks.layers", ".inferers", ".utils"]
+_MIRRORED = ["", ".networks", ".networks.nets", ".networks.blocks", ".networks.blocks.spade_norm", ".networks.schedulers", ".networks.layers",
+             ".inferers", ".utils"]
 
 
 def install_as_generative(force: bool = False) -> None:

@@ -186,7 +186,8 @@ def test_install_as_generative_aliases_the_reference_import_paths():
             "from generative.networks.nets import DiffusionModelUNet, AutoencoderKL, VQVAE; "
             "from generative.networks.schedulers import DDIMScheduler, DDPMScheduler; "
             "from generative.inferers import DiffusionInferer, LatentDiffusionInferer; "
-            "from generative.networks.layers import VectorQuantizer; print('ok')")
+            "from generative.networks.layers import VectorQuantizer; "
+            "from generative.networks.blocks.spade_norm import SPADE; from generative.networks.nets import SPADEDiffusionModelUNet; print('ok')")
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
@@ -226,6 +227,49 @@ def test_controlnet_state_dict_and_constructor_errors():
     x = torch.zeros(1, 1, 8, 8)
     with pytest.raises(RuntimeError, match="MI355X"):
         m(x, torch.tensor([1]), x)
+
+
+def test_spade_state_dicts_constructor_errors_and_no_cpu_fallback():
+    """SPADE host logic (reference spade_norm.py:33-77, spade_diffusion_model_unet.py:641-834, spade_autoencoderkl.py:315-408): strict
+    state_dict compatibility with the reference's keys (incl. `param_free_norm.N.*` only where the GroupNorm is affine), constructor
+    errors under the reference's class names, forward argument checks, no CPU fallback."""
+    from generativemodels_amd.networks.blocks import SPADE
+    from generativemodels_amd.networks.nets import SPADEAutoencoderKL, SPADEDiffusionModelUNet
+
+    fx = load_fixture("spade")
+    for name, e in fx["blocks"].items():
+        m = SPADE(**e["kwargs"])
+        assert set(m.state_dict()) == set(e["state_dict"]), name
+        m.load_state_dict(e["state_dict"], strict=True)
+    for group, cls in (("unets", SPADEDiffusionModelUNet), ("aekls", SPADEAutoencoderKL)):
+        for name, e in fx[group].items():
+            m = cls(**e["cfg"])
+            assert set(m.state_dict()) == set(e["state_dict"]), name
+            for k, v in m.state_dict().items():
+                assert tuple(v.shape) == tuple(e["state_dict"][k].shape), (name, k)
+            m.load_state_dict(e["state_dict"], strict=True)
+    u = SPADEDiffusionModelUNet(2, 1, 1, label_nc=3, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1, norm_num_groups=8,
+                                num_head_channels=8, spade_intermediate_channels=16)
+    assert any(k.endswith("norm1.param_free_norm.N.weight") for k in u.state_dict())          # affine GroupNorm inside the UNet's SPADE
+    assert not any("down_blocks" in k and "mlp_shared" in k for k in u.state_dict())           # encoder blocks are the plain ones
+    a = SPADEAutoencoderKL(2, label_nc=3, num_channels=(8, 16), attention_levels=(False, False), num_res_blocks=1, norm_num_groups=8,
+                           latent_channels=4, with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False, spade_intermediate_channels=16)
+    assert not any("param_free_norm" in k for k in a.state_dict())                             # affine-free GroupNorm: no parameters
+    assert a.decoder.blocks[1].norm1.eps == 1e-5                                               # nn.GroupNorm default, not norm_eps
+    with pytest.raises(ValueError, match="SPADEDiffusionModelUNet"):
+        SPADEDiffusionModelUNet(2, 1, 1, label_nc=3, with_conditioning=True)
+    with pytest.raises(ValueError, match="SPADEAutoencoderKL"):
+        SPADEAutoencoderKL(2, label_nc=3, num_channels=(8, 12), norm_num_groups=8, attention_levels=(False, False))
+    with pytest.raises(NotImplementedError):
+        SPADE(3, 8, norm="BATCH")
+    x = torch.zeros(1, 1, 8, 8)
+    with pytest.raises(ValueError):
+        u(x, torch.tensor([1]), None)
+    with pytest.raises(ValueError):
+        u(x, torch.tensor([1]), torch.zeros(1, 2, 8, 8))   # label_nc mismatch
+    with pytest.raises(RuntimeError, match="MI355X"):
+        u(x, torch.tensor([1]), torch.zeros(1, 3, 8, 8))
+    assert not u.supports_training()
 
 
 def test_transformer_state_dict_ordering_and_errors():
