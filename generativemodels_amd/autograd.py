@@ -153,7 +153,8 @@ class _UpsampleConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        y = ops.conv(x, weight, bias, kernel=3, stride=1, padding=1, upsample=True)
+        # the folded up-sampling path: the sub-pixel variant pre-sums its weights per parameter version, i.e. on every training step
+        y = ops.conv(x, weight, bias, kernel=3, stride=1, padding=1, upsample=True, allow_subpixel=False, want_stats=True)
         ctx.save_for_backward(x, weight)
         ctx.bias_dtype = None if bias is None else bias.dtype
         return y

@@ -174,12 +174,16 @@ def packed_subpixel_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Te
 
     def make():
         w = weight.detach().float()
-        a = [torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 1.0]], device=w.device), torch.tensor([[1.0, 1.0, 0.0], [0.0, 0.0, 1.0]], device=w.device)]
+
+        def collapse(t, axis, parity):  # three taps -> two along `axis`: (w0, w1 + w2) for parity 0, (w0 + w1, w2) for parity 1
+            t0, t1, t2 = t.select(axis, 0), t.select(axis, 1), t.select(axis, 2)
+            return torch.stack((t0, t1 + t2) if parity == 0 else (t0 + t1, t2), dim=axis)
+
         cout, cin = w.shape[0], w.shape[1]
         n = lib().gm_packed_conv_weight_elems(cout, cin, 2, 2, 2, dt_code(dtype))
         out = torch.empty(8 * n, dtype=dtype, device=w.device)
         for par in range(8):
-            w2 = torch.einsum("oiabc,xa,yb,zc->oixyz", w, a[(par >> 2) & 1], a[(par >> 1) & 1], a[par & 1]).contiguous()
+            w2 = collapse(collapse(collapse(w, 2, (par >> 2) & 1), 3, (par >> 1) & 1), 4, par & 1).contiguous()
             check(lib().gm_pack_conv_weight(w2.data_ptr(), dt_code(w2.dtype), out[par * n:].data_ptr(), dt_code(dtype), cout, cin, 2, 2, 2, 0,
                                             _stream()), "gm_pack_conv_weight")
         return out
@@ -672,7 +676,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
          pre: Optional[tuple] = None, pre_act: str = "none", rowvec: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, post_act: str = "none", out: Optional[torch.Tensor] = None,
          packed: Optional[torch.Tensor] = None, cout: Optional[int] = None, force_cfg: Optional[int] = None,
-         want_stats: bool = False, skip: Optional[tuple] = None) -> torch.Tensor:
+         want_stats: bool = False, skip: Optional[tuple] = None, allow_subpixel: bool = True) -> torch.Tensor:
     """Fused convolution over an arena tensor x = (N, *spatial, Cin).
 
     kernel/stride/padding/dilation: int or per-axis tuples (len = number of spatial axes). `padding` is the low-side pad,
@@ -682,7 +686,9 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     `packed`/`cout` override the weight panel (fused multi-head projections).
     skip = (parts, weight, bias): a ResnetBlock's 1x1 shortcut convolution over cat(parts) (1 or 2 arena tensors in the output
     geometry), added to the result.  Fused into the LDS-DMA kernel as extra K chunks when it covers the geometry; otherwise
-    computed by 1x1 launches first and added as the residual (`res` must then be None)."""
+    computed by 1x1 launches first and added as the residual (`res` must then be None).
+    allow_subpixel: an eligible up-sampling convolution runs as 8 sub-pixel 2x2x2 convolutions on pre-summed weights (cached per weight
+    version: right for inference; a training step, whose weights change every iteration, passes False)."""
     require_device(x, weight, bias, rowvec, res, out)
     nsp = x.dim() - 2
     if nsp < 1 or nsp > 3:
@@ -731,7 +737,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                                                   out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act], POST_ACT[post_act], dt_code(dtype),
                                                   _stream()), "gm_linear_rows"))
         return out
-    if (upsample and SUBPIXEL_UPSAMPLE and nsp == 3 and k == (3, 3, 3) and s == (1, 1, 1) and plo == (1, 1, 1) and phi == (1, 1, 1)
+    if (upsample and SUBPIXEL_UPSAMPLE and allow_subpixel and nsp == 3 and k == (3, 3, 3) and s == (1, 1, 1) and plo == (1, 1, 1) and phi == (1, 1, 1)
             and dil == (1, 1, 1) and pre is None and pre_act == "none" and skip is None and force_cfg is None and weight is not None
             and cin % (64 // x.element_size()) == 0 and cout % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0
             and math.prod(src) * n >= DMA_CONV_MIN_VOXELS):
