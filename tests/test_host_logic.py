@@ -317,3 +317,56 @@ def test_transformer_state_dict_ordering_and_errors():
     m = DecoderOnlyTransformer(num_tokens=10, max_seq_len=8, attn_layers_dim=16, attn_layers_depth=1, attn_layers_heads=2)
     with pytest.raises(RuntimeError, match="MI355X"):
         m(torch.zeros((1, 4), dtype=torch.long))
+
+
+def test_native_planners_accept_and_reject_geometries_without_a_gpu():
+    """Host-side planning of the C-ABI library runs without a GPU: tile-configuration eligibility (gm_conv_lds_bytes: > 0 = bytes of LDS,
+    -1 = configuration does not cover the geometry) for the LDS-DMA kernels incl. the sub-pixel up-sampling variant, and the weight-gradient
+    planner (gm_conv_wgrad_workspace_bytes: -1 = not covered)."""
+    import ctypes as C
+
+    from generativemodels_amd import _native as nat
+
+    lib = nat.lib()
+
+    def conv_desc(**kw):
+        d = nat.GmConvDesc()
+        base = dict(N=1, Cin=64, Cout=64, Ds=16, Hs=16, Ws=16, Do=16, Ho=16, Wo=16, kd=3, kh=3, kw=3, sd=1, sh=1, sw=1, pd=1, ph=1, pw=1,
+                    dd=1, dh=1, dw=1, in_mode=0, fd=1, fh=1, fw=1, dtype=1, ltd=2, lth=2, ltw=4, cfg=11, x_ld=64, y_ld=64)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d, k, v)
+        d.x, d.y, d.w = 0x1000, 0x2000, 0x3000  # aligned dummies: the planner only inspects them
+        return d
+
+    def lds(**kw):
+        return lib.gm_conv_lds_bytes(C.byref(conv_desc(**kw)))
+
+    assert lds() == 6 * 112 * 64 + 3 * 192 * 64                       # cfg 11: 3x3x3 stride 1
+    assert lds(Cin=48) == -1                                          # C_in must be a multiple of the 32-channel K step (bf16)
+    assert lds(kd=1, Ds=1, Do=1) == -1                                # 2-D convolutions stay on the other kernels
+    assert lds(cfg=15, sd=2, sh=2, sw=2, Do=8, Ho=8, Wo=8, ltd=1) > 0 # stride-2 variant
+    assert lds(cfg=15) == -1                                          # ... which does not take stride 1
+    sub = dict(cfg=17, in_mode=3, kd=2, kh=2, kw=2, Do=32, Ho=32, Wo=32, pd=0, ph=0, pw=0)
+    assert lds(**sub) == 5 * 96 * 64 + 4 * 128 * 64                   # sub-pixel up-sampling: 2x2x2 kernels, output = 2x the input grid
+    assert lds(**dict(sub, Do=31)) == -1
+    assert lds(**dict(sub, in_mode=1)) == -1
+    assert lds(in_mode=3, kd=2, kh=2, kw=2, Do=32, Ho=32, Wo=32) == -1  # in_mode 3 exists for configuration 17 only
+
+    def wgrad_bytes(**kw):
+        d = nat.GmWgradDesc()
+        base = dict(N=1, Cin=64, Cout=64, Ds=16, Hs=16, Ws=16, Do=16, Ho=16, Wo=16, kd=3, kh=3, kw=3, stride=1, pd=1, ph=1, pw=1, dtype=1,
+                    accumulate=0, x_ld=64, gy_ld=64)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d, k, v)
+        d.x, d.gy = 0x1000, 0x2000
+        return lib.gm_conv_wgrad_workspace_bytes(C.byref(d))
+
+    tiles = (16 // 2) * (16 // 4) * 1                                  # 2 x 4 x 32 voxel tiles
+    assert wgrad_bytes() == min(256 // 3, tiles) * 3 * 9 * 64 * 64 * 4 # one work-group per CU, capped by the tile count
+    assert wgrad_bytes(kd=1, kh=1, kw=1, pd=0, ph=0, pw=0) > 0         # 1x1 convolutions / nn.Linear: flat mode
+    assert wgrad_bytes(stride=2, Do=8, Ho=8, Wo=8) > 0
+    assert wgrad_bytes(Cin=60) == -1                                   # ragged channel counts are padded by ops.conv_wgrad, not here
+    assert wgrad_bytes(kd=3, kh=5, kw=5) == -1
+    assert wgrad_bytes(stride=3) == -1
