@@ -673,22 +673,26 @@ extern "C" int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, lo
 // out[c] = sum over slots and samples of stats[slot][n][c][0] (a bias gradient from the gm_gn_channel_stats table of gy), or, per sample,
 // out[n][c] = sum over slots (the gradient of a per-sample row vector added by the convolution epilogue: the timestep embedding)
 __global__ __launch_bounds__(256) void stats_colsum_kernel(const double* __restrict__ stats, int N, int C, float* __restrict__ out, int per_sample) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (per_sample ? N * C : C)) return;
+  // one wave per output element, lanes over the slot (x sample) copies, xor-shuffle reduction in a fixed order: a thread walking the 64
+  // copies serially cost 22 us per call = 2.6 ms per C4 training step (profiles/r01_c4_train_kernel_stats.csv)
+  const int lane = threadIdx.x & 63;
+  const int w = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (w >= (per_sample ? N * C : C)) return;  // wave-uniform
   double s = 0.0;
   if (per_sample) {
-    for (int sl = 0; sl < GM_STAT_SLOTS; ++sl) s += stats[((long long)sl * N * C + i) * 2];
+    for (int sl = lane; sl < GM_STAT_SLOTS; sl += 64) s += stats[((long long)sl * N * C + w) * 2];
   } else {
-    for (long long j = 0; j < (long long)GM_STAT_SLOTS * N; ++j) s += stats[(j * C + i) * 2];
+    for (long long j = lane; j < (long long)GM_STAT_SLOTS * N; j += 64) s += stats[(j * C + w) * 2];
   }
-  out[i] = (float)s;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[w] = (float)s;
 }
 
 extern "C" int gm_stats_colsum(const double* stats, int N, int C, float* out, int per_sample, void* stream) {
   GM_REQUIRE(stats && out, "null pointer");
   if (C == 0 || N == 0) return 0;
-  const int total = per_sample ? N * C : C;
-  stats_colsum_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(stats, N, C, out, per_sample);
+  const long long total = per_sample ? (long long)N * C : C;
+  stats_colsum_kernel<<<(unsigned)((total * 64 + 255) / 256), 256, 0, (hipStream_t)stream>>>(stats, N, C, out, per_sample);
   GM_LAUNCH_CHECK();
 }
 
