@@ -665,8 +665,8 @@ def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, c
     nvo = n * math.prod(out_sp)
     es = x.element_size()
     _timed(f"conv_igemm<{str(dtype).split('.')[-1]},cfg17>",
-           dict(flops=2.0 * nvo * cout * cin * 27, bytes=float(es * (n * math.prod(src) * cin + nvo * cout * (2 if res is not None else 1) + 8 * cout * cin * 8)),
-                shape=f"{cin}->{cout} k(3, 3, 3) s(1, 1, 1) out{out_sp} mode3 (8/27 of the listed flops are executed)"),
+           dict(flops=2.0 * nvo * cout * cin * 8, bytes=float(es * (n * math.prod(src) * cin + nvo * cout * (2 if res is not None else 1) + 8 * cout * cin * 8)),
+                shape=f"{cin}->{cout} k(3, 3, 3) s(1, 1, 1) out{out_sp} mode3 (executed flops: 8 of the 27 taps)"),
            lambda: check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward"))
     return out
 
