@@ -370,3 +370,30 @@ def test_native_planners_accept_and_reject_geometries_without_a_gpu():
     assert wgrad_bytes(Cin=60) == -1                                   # ragged channel counts are padded by ops.conv_wgrad, not here
     assert wgrad_bytes(kd=3, kh=5, kw=5) == -1
     assert wgrad_bytes(stride=3) == -1
+
+
+def test_training_api_has_no_cpu_fallback_and_checks_its_arguments():
+    """generativemodels_amd.autograd / forward_train on CPU tensors raise (no eager fallback); argument checks run before any kernel."""
+    from generativemodels_amd import autograd as A
+    from generativemodels_amd import ops
+
+    x = torch.zeros(1, 4, 4, 4, 8, requires_grad=True)
+    w = torch.zeros(8, 8, 3, 3, 3, requires_grad=True)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        A.conv(x, w, None, kernel=3, padding=1)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        A.group_norm_act(x, None, None, 4, 1e-6, "silu")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        A.attention(torch.zeros(1, 8, 16), torch.zeros(1, 8, 16), torch.zeros(1, 8, 16), 2, 0.35)
+    with pytest.raises(ValueError):
+        A.linear(torch.zeros(4, 8), torch.zeros(8, 8))             # (N, L, C) expected
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.conv_wgrad(torch.zeros(1, 4, 4, 8), torch.zeros(1, 4, 4, 4, 8), 3, 1, 1)  # rank mismatch / CPU tensors
+    unet = DiffusionModelUNet(2, 1, 1, num_channels=(8, 16), attention_levels=(False, True), num_res_blocks=1, norm_num_groups=8, num_head_channels=8)
+    assert unet.supports_training()
+    with pytest.raises(RuntimeError, match="MI355X"):
+        unet.forward_train(torch.zeros(1, 1, 8, 8), torch.tensor([3]))
+    with pytest.raises(ValueError):
+        unet.forward_train(torch.zeros(1, 1, 8, 8), torch.tensor([[3]]))
+    with pytest.raises(ValueError):
+        unet.forward_train(torch.zeros(1, 1, 8, 8), torch.tensor([3]), context=torch.zeros(1, 2, 4))   # no conditioning in this network
