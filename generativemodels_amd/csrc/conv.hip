@@ -289,7 +289,9 @@ static inline int conv_fast_bn(int cfg) { int v = 0, c = 0, t = 0; gm_conv_fast_
 extern "C" long long gm_conv_dma_lds_bytes(int stride);
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
-static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 17); }  // 14: 4 waves x 64 voxels; 15: stride 2; 16: 512 voxels; 17: sub-pixel up-sampling
+extern "C" int gm_conv_dma_variant(int cfg);
+// 14: 4 waves x 64 voxels; 15: stride 2; 16: 512 voxels, 16 waves; 17: sub-pixel up-sampling; 18: 512 voxels, 8 waves x 64 voxels; 19: 512 voxels x 128 channels
+static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19); }
 // HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
 #define CONV_CFG_CIN 12
 #define CONV_CFG_COUT1 13
@@ -313,7 +315,8 @@ static bool conv_fast_eligible(const GmConvDesc& d) {
 
 extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
   if (cfg == 15) { *bm = 128; *bn = 64; return 0; }
-  if (cfg == 16) { *bm = 512; *bn = 64; return 0; }
+  if (cfg == 16 || cfg == 18) { *bm = 512; *bn = 64; return 0; }
+  if (cfg == 19) { *bm = 512; *bn = 128; return 0; }
   if (conv_is_dma(cfg) || cfg == CONV_CFG_CIN) { *bm = 256; *bn = 64; return 0; }
   if (cfg == CONV_CFG_COUT1) { *bm = 256; *bn = 16; return 0; }
   if (conv_is_fast(cfg)) { int t = 0; return gm_conv_fast_variant_geometry(conv_fast_variant(cfg), bm, bn, &t); }
@@ -351,7 +354,7 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   if (d && d->skip_x[0] && !conv_is_dma(d->cfg)) return -1;  // the fused 1x1 shortcut exists in the LDS-DMA kernel only
-  if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes(d->cfg == 17 ? 4 : (d->cfg == 15 ? 2 : (d->cfg == 16 ? 3 : 1))) : -1;
+  if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes(gm_conv_dma_variant(d->cfg)) : -1;
   if (d && d->cfg == CONV_CFG_CIN) return gm_conv_cin_eligible(d) ? gm_conv_cin_lds_bytes(d) : -1;
   if (d && d->cfg == CONV_CFG_COUT1) return gm_conv_cout1_eligible(d) ? gm_conv_cout1_lds_bytes() : -1;
   if (d && conv_is_fast(d->cfg)) {

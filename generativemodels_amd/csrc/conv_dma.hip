@@ -48,12 +48,14 @@ __device__ __forceinline__ void dma_wait() {
 // are pre-summed per output parity (ops.py) and the launch does 8/27 of the multiply-adds (reference: Upsample = interpolate + conv,
 // diffusion_model_unet.py:572-585, autoencoderkl.py:76-93).  The parity is a grid dimension: it selects the weight image, the low-side
 // padding (1 - parity per axis) and the output sub-lattice the tile is written to.
-template <typename T, int NW, int MF, int S, int MINW, int KS = 3>
+// NFR_ = 16-channel output fragments per wave: 4 (BN = 64 output channels per work-group) or 8 (BN = 128: one staged patch feeds
+// twice the output channels -- half the patch traffic per multiply-add, 0.375 instead of 0.5 LDS operand reads per MFMA at MF = 4).
+template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR_ = 4>
 __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * NW;
-  constexpr int NFR = 4, G = KS == 3 ? 3 : 2, RING = KS == 3 ? 3 : 4;  // taps per weight panel; panels in the LDS ring
+  constexpr int NFR = NFR_, G = KS == 3 ? 3 : 2, RING = KS == 3 ? 3 : 4;  // taps per weight panel; panels in the LDS ring
   static_assert(KS == 3 || (KS == 2 && S == 1 && NW == 8), "the sub-pixel variant is stride 1, 8 waves");
   static_assert(NW * MF * 16 == 512 || NW * MF * 16 == (S == 1 ? 256 : 128), "waves x fragments cover the tile");
   constexpr int TH = 4, TW = 16, BM = NW * MF * 16, TD = BM / (TH * TW);  // 4x4x16 (8x4x16 for the 16-wave variant); S = 2: 2x4x16
@@ -63,15 +65,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   constexpr int PROWS = PD * PLANE;                        // 672 rows = 42 DMA pieces
   constexpr int PPIECES = PROWS / 16;
   constexpr int PPW = (PPIECES + NW - 1) / NW;             // patch pieces per wave (6; the last round is partial)
-  constexpr int BN = 64;
-  constexpr int WROWS = G * BN;                            // 192 rows per weight panel = 12 KiB = 1.5 pieces per wave
+  constexpr int BN = 16 * NFR;
+  constexpr int WROWS = G * BN;                            // 192 rows per weight panel = 12 KiB = 1.5 pieces per wave (BN = 64)
+  constexpr bool WGEN = NFR != 4;                          // general panel distribution: piece wave + NW * h, whole pieces only
   constexpr int PATCH_BYTES = PROWS * DMA_ROWB;
   constexpr int WBUF_BYTES = WROWS * DMA_ROWB;
   constexpr int NGROUPS = KS * KS * KS / G;                // 27 taps / 3, or 8 taps / 2
   // DMA instructions per wave per weight panel (12 pieces): 8 waves x (1 full + 1 half piece), 4 waves x 3 full, or -- 16 waves --
   // one full piece on waves 0..11 and none on waves 12..15 (the end-of-group wait count is then wave dependent)
-  constexpr int WPW = KS == 2 ? 1 : (NW == 8 ? 2 : (NW == 4 ? 3 : 1));  // KS = 2: 128 rows = 8 pieces, one per wave
-  static_assert(WROWS == (KS == 3 ? 192 : 128), "12 (or 8) pieces per weight panel");
+  constexpr int WPW = WGEN ? WROWS / 16 / NW : (KS == 2 ? 1 : (NW == 8 ? 2 : (NW == 4 ? 3 : 1)));  // KS = 2: 128 rows = 8 pieces, one per wave
+  static_assert(NFR == 4 || (NFR == 8 && KS == 3 && S == 1 && (WROWS / 16) % NW == 0), "BN = 128: whole pieces per wave");
+  static_assert(WROWS == (KS == 3 ? 3 : 2) * BN, "G taps per weight panel");
   static_assert(NGROUPS % RING == 0, "the ring slot of a group is a compile-time constant");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB]
@@ -142,10 +146,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   int wsrc[WPW];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
 #pragma unroll
   for (int h = 0; h < WPW; ++h) {
-    const int row = KS == 2 ? 16 * wave + (lane >> 2)
+    const int row = WGEN ? 16 * (wave + NW * h) + (lane >> 2)
+                  : KS == 2 ? 16 * wave + (lane >> 2)
                             : NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2))
                                       : (NW == 4 ? 16 * (wave + NW * h) + (lane >> 2) : 16 * (wave < 12 ? wave : 0) + (lane >> 2));
-    const int u = row >> 6, col = row & 63;
+    const int u = row / BN, col = row % BN;
     const int co = cb * BN + col;
     wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
   }
@@ -158,7 +163,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
     for (int h = 0; h < WPW; ++h) {
       const char* src = wsrc[h] >= 0 ? panel + wsrc[h] : zero + ((lane & 3) << 4);
-      if (KS == 2) {
+      if (WGEN) {
+        dma16(src, dst + (unsigned)(16 * (wave + NW * h)) * DMA_ROWB);
+      } else if (KS == 2) {
         dma16(src, dst + (unsigned)(16 * wave) * DMA_ROWB);
       } else if (NW == 8) {
         if (h == 0) dma16(src, dst + (unsigned)(16 * wave) * DMA_ROWB);
@@ -172,23 +179,27 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   };
 
   // ---- per-lane operand read addresses (bytes from smem) ------------------------------------------------------------------
-  int xaddr[MF][KS][KS];  // voxel fragment mf at tap (0, kh, kw); depth taps add kd * PLANE * 64 as an immediate
+  // A wave's MF fragments are MF consecutive H rows of one tile plane ((wave * MF + mf) * 16 + l15 with TH = 4, TW = 16), so fragment mf
+  // at tap row kh reads patch row S * (bb0 + mf) + kh: the addresses depend on hk = S * mf + kh only -- HK x KS registers, not MF x KS x KS.
+  constexpr int HK = S * (MF - 1) + KS;
+  static_assert(MF <= 4 && (4 % MF) == 0, "a wave's fragments stay inside one 4-row tile plane");
+  int xaddr[HK][KS];  // patch row (hk, kw) of this lane's voxel column; depth taps add kd * PLANE * 64 as an immediate
+  {
+    const int m0 = wave * MF * 16 + l15;
+    const int a = m0 >> 6, bb0 = (m0 >> 4) & 3, c = m0 & 15;
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf) {
-    const int m = (wave * MF + mf) * 16 + l15;
-    const int a = m >> 6, bb = (m >> 4) & 3, c = m & 15;
-#pragma unroll
-    for (int kh = 0; kh < KS; ++kh)
+    for (int hk = 0; hk < HK; ++hk)
 #pragma unroll
       for (int kw = 0; kw < KS; ++kw) {
         const int col = S == 1 ? c + kw : (kw == 1 ? EW + c : c + (kw >> 1));  // patch column S*c + kw in the split layout
-        const int row = S * a * PLANE + (S * bb + kh) * PW + col;
-        xaddr[mf][kh][kw] = row * DMA_ROWB + ((q ^ dma_swz(row)) << 4);
+        const int row = S * a * PLANE + (S * bb0 + hk) * PW + col;
+        xaddr[hk][kw] = row * DMA_ROWB + ((q ^ dma_swz(row)) << 4);
       }
   }
-  int waddr[NFR];
+  // weight rows nf * 16 + l15: the swizzle has period 8 rows, so fragments 4..7 (BN = 128) are fragments 0..3 plus 64 rows -- an immediate
+  int waddr[4];
 #pragma unroll
-  for (int nf = 0; nf < NFR; ++nf) {
+  for (int nf = 0; nf < 4; ++nf) {
     const int r = nf * 16 + l15;
     waddr[nf] = PATCH_BYTES + r * DMA_ROWB + ((q ^ dma_swz(r)) << 4);
   }
@@ -216,32 +227,39 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       // The last tap's operand reads are issued before the end-of-group wait and its MFMAs after the barrier.  The wait retires
       // every LDS read of the group (lgkmcnt(0)): the barrier releases other waves to DMA into the ring slot this group read.
       // (Measured against an ordering that keeps the two patch reads of the last tap in flight across the barrier: 2-3 % slower.)
-      uint4 xf[MF], wf[NFR];
-      auto read_tap = [&](int u) __attribute__((always_inline)) {
+      // BN = 128 splits a tap into NH = 2 half-steps of four channel fragments each (16 + 16 operand registers instead of 48).
+      constexpr int NH = NFR / 4, NSTEPS = G * NH;
+      uint4 xf[MF], wf[4];
+      auto read_step = [&](int st) __attribute__((always_inline)) {
+        const int u = st / NH, hf = st % NH;
         const int tap = g * G + u;
         const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
 #pragma unroll
-        for (int nf = 0; nf < NFR; ++nf)
-          wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
+        for (int nf = 0; nf < 4; ++nf)
+          wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + hf * (64 * DMA_ROWB) + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
+        if (hf == 0) {
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-          xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[mf][kh][kw] + kd * (PLANE * DMA_ROWB));
+          for (int mf = 0; mf < MF; ++mf)
+            xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[S * mf + kh][kw] + kd * (PLANE * DMA_ROWB));
+        }
       };
-      auto mma_tap = [&]() __attribute__((always_inline)) {
+      auto mma_step = [&](int st) __attribute__((always_inline)) {
+        const int hf = st % NH;
 #pragma unroll
-        for (int nf = 0; nf < NFR; ++nf)
+        for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[nf][mf]);
+          for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[hf * 4 + nf][mf]);
       };
-      constexpr int NMMA = MF * NFR * (sizeof(T) == 2 ? 1 : 4);
+      constexpr int NMMA = MF * 4 * (sizeof(T) == 2 ? 1 : 4);
 #pragma unroll
-      for (int u = 0; u < G - 1; ++u) {
-        read_tap(u);
-        mma_tap();
-        __builtin_amdgcn_sched_group_barrier(0x100, MF + NFR, 0);  // all operand reads of a tap before its MFMAs
+      for (int st = 0; st < NSTEPS - 1; ++st) {
+        read_step(st);
+        mma_step(st);
+        if (st % NH == 0) __builtin_amdgcn_sched_group_barrier(0x100, MF + 4, 0);  // all operand reads of a step before its MFMAs
+        else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
       }
-      read_tap(G - 1);
+      read_step(NSTEPS - 1);
       if (g == NGROUPS - 1) {
         if (!last_chunk) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         if ((g < NGROUPS - 2 || !last_chunk) && (NW != 16 || wave < 12)) dma_wait<WPW>(); else dma_wait<0>();
         __builtin_amdgcn_s_barrier();
       }
-      mma_tap();
+      mma_step(NSTEPS - 1);
     }
   }
 
@@ -271,7 +289,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
       svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
     }
-    const int wcol = (wave & 3) * 16 + (lane >> 2);     // weight row of this lane's panel piece (piece wave&3 of a 4-piece panel)
+    const int wpiece = WGEN ? wave : (wave & 3);        // BN = 64: piece wave&3 of a 4-piece panel; BN = 128 (8 waves): piece wave of 8
+    const int wcol = wpiece * 16 + (lane >> 2);         // weight row of this lane's panel piece
     const int wco = cb * BN + wcol;
     const int wswz = ((lane & 3) ^ dma_swz(wcol)) << 4;
     int caddr[MF];
@@ -296,9 +315,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
             const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
             dma16(src, lds0 + (unsigned)(j * BM + wave * (MF * 16) + h * 16) * DMA_ROWB);
           }
-          if (NW == 4 || (wave >> 2) == j) {  // 8 waves: waves 0-3 move panel 0, waves 4-7 panel 1; 4 waves: every wave moves both
+          if (WGEN || NW == 4 || (wave >> 2) == j) {  // 8 waves: waves 0-3 move panel 0, waves 4-7 panel 1; 4 waves / BN = 128: every wave moves both
             const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane & 3) << 4);
-            dma16(src, lds0 + PATCH_BYTES + (unsigned)(j * BN + (wave & 3) * 16) * DMA_ROWB);
+            dma16(src, lds0 + PATCH_BYTES + (unsigned)(j * BN + wpiece * 16) * DMA_ROWB);
           }
         }
       }
@@ -307,15 +326,19 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (sc0 + j < nsc) {
-          uint4 xf[MF], wf[NFR];
-#pragma unroll
-          for (int nf = 0; nf < NFR; ++nf) wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + j * (BN * DMA_ROWB));
+          uint4 xf[MF], wf[4];
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(smem + caddr[mf] + j * (BM * DMA_ROWB));
 #pragma unroll
-          for (int nf = 0; nf < NFR; ++nf)
+          for (int hf = 0; hf < NFR / 4; ++hf) {
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[nf][mf]);
+            for (int nf = 0; nf < 4; ++nf)
+              wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + hf * (64 * DMA_ROWB) + j * (BN * DMA_ROWB));
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[hf * 4 + nf][mf]);
+          }
         }
       }
     }
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wave * MF * 16, cb * BN, od0, oh0, ow0, lane, st_s, st_q,
                                 KS == 2 ? &om : nullptr);
   if (p.stats) {
-    float* sst = reinterpret_cast<float*>(smem);  // [NW][64 channels][2]
+    float* sst = reinterpret_cast<float*>(smem);  // [NW][BN channels][2]
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < EPASSES; ++e)
@@ -349,8 +372,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64);
         if (lane < 8) {
           const int ch = e * CH_PER_PASS + lane * VECW + i;
-          sst[(wave * 64 + ch) * 2] = a;
-          sst[(wave * 64 + ch) * 2 + 1] = b2;
+          sst[(wave * BN + ch) * 2] = a;
+          sst[(wave * BN + ch) * 2 + 1] = b2;
         }
       }
     __syncthreads();
@@ -358,8 +381,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       double a = 0.0, b2 = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        a += (double)sst[(w * 64 + tid) * 2];
-        b2 += (double)sst[(w * 64 + tid) * 2 + 1];
+        a += (double)sst[(w * BN + tid) * 2];
+        b2 += (double)sst[(w * BN + tid) * 2 + 1];
       }
       const int co = cb * BN + tid;
       if (co < p.Cout) {
@@ -373,14 +396,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 }
 
 // variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile; 4 = sub-pixel 2x2x2 (5 planes of 5 x 17 -> 96 rows,
-// four 128-row weight panels)
+// four 128-row weight panels); 5 = 8x4x16 tile x 128 output channels (three 384-row weight panels)
 extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   if (variant == 4) return 5LL * 96 * DMA_ROWB + 4LL * 128 * DMA_ROWB;
+  if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
   return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB;
 }
 
 // geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)
+extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
+
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
@@ -397,7 +423,7 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == s && d->sh == s && d->sw == s && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
          (d->in_mode == 0 || (d->in_mode == 1 && s == 1)) && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
          (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 &&
-         d->ltd == (d->cfg == 16 ? 3 : (s == 1 ? 2 : 1)) && d->lth == 2 &&
+         d->ltd == (d->cfg == 16 || d->cfg == 18 || d->cfg == 19 ? 3 : (s == 1 ? 2 : 1)) && d->lth == 2 &&
          d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
          (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) &&
          (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31) && (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31) &&
@@ -408,21 +434,23 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
                               (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
 }
 
-template <typename T, int NW, int MF, int S, int MINW, int KS = 3>
+template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR = 4>
 static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_dma_kernel<T, NW, MF, S, MINW, KS>;
+  auto kern = conv_dma_kernel<T, NW, MF, S, MINW, KS, NFR>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(KS == 2 ? 4 : (S == 2 ? 2 : (NW == 16 ? 3 : 1))), st>>>(d);
+  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(gm_conv_dma_variant(d.cfg)), st>>>(d);
 }
 
 template <typename T>
 static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
-  if (d.cfg == 17) launch_dma<T, 8, 2, 1, 4, 2>(d, nblocks, st);     // sub-pixel 2x2x2 kernels of an up-sampling convolution
+  if (d.cfg == 19) launch_dma<T, 8, 4, 1, 2, 3, 8>(d, nblocks, st);  // 512 voxels x 128 channels: 8 waves x (64 voxels x 128 channels), one work-group per CU
+  else if (d.cfg == 18) launch_dma<T, 8, 4, 1, 2>(d, nblocks, st);   // 512 voxels x 64 channels: 8 waves x (64 voxels x 64 channels), one work-group per CU
+  else if (d.cfg == 17) launch_dma<T, 8, 2, 1, 4, 2>(d, nblocks, st);  // sub-pixel 2x2x2 kernels of an up-sampling convolution
   else if (d.cfg == 16) launch_dma<T, 16, 2, 1, 4>(d, nblocks, st);  // 512 voxels (8x4x16), 16 waves, one work-group per CU
   else if (d.cfg == 15) launch_dma<T, 8, 1, 2, 2>(d, nblocks, st);   // stride 2: 8 waves x 16 voxels, one work-group per CU
   else if (d.cfg == 14) launch_dma<T, 4, 4, 1, 2>(d, nblocks, st);   // 4 waves x 64 voxels

@@ -87,27 +87,28 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
 // (2 od + pd, 2 oh + ph, 2 ow + pw) of the full-resolution output p.Do x p.Ho x p.Wo.
 struct ConvOutMap { int Dl, Hl, Wl, pd, ph, pw; };
 
-template <typename T, int MF, int NFR>
-__device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, int n, int m_base,
-                                                  int co_base, int od0, int oh0, int ow0, int lane,
-                                                  float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
-                                                  float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
-                                                  const ConvOutMap* om = nullptr) {
+// One pass (128 bytes of channels per voxel row) of the LDS-transposed epilogue; PASS is a template constant so that the accumulator
+// fragments it touches are compile-time register indices (a run-time pass loop that the unroller gives up on would force the whole
+// accumulator array into scratch memory -- seen on the 128-channel tile: one scratch store behind every MFMA).
+template <typename T, int MF, int NFR, int PASS>
+__device__ __forceinline__ void conv_epilogue_lds_pass(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, int n, int m_base,
+                                                       int co_base, int od0, int oh0, int ow0, int lane,
+                                                       float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
+                                                       float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
+                                                       const ConvOutMap* om) {
   constexpr int VECW = 16 / (int)sizeof(T);
   constexpr int ROWB_E = 144;                                   // 128 B of channels + 16 B pad
   constexpr int NF_PER_PASS = 128 / (16 * (int)sizeof(T));      // 4 (bf16) or 2 (fp32) channel fragments per pass
-  constexpr int PASSES = (NFR + NF_PER_PASS - 1) / NF_PER_PASS;
   const int l15 = lane & 15, q = lane >> 4;
   const int th = 1 << p.lth, tw = 1 << p.ltw;
   T* yout = reinterpret_cast<T*>(p.y);
   const T* res = reinterpret_cast<const T*>(p.res);
+  // ---- accumulators (+ bias, + timestep row) -> LDS, row = voxel, 4 channels per lane ---------------------------------
 #pragma unroll
-  for (int pass = 0; pass < PASSES; ++pass) {
-    // ---- accumulators (+ bias, + timestep row) -> LDS, row = voxel, 4 channels per lane ---------------------------------
-#pragma unroll
-    for (int nl = 0; nl < NF_PER_PASS; ++nl) {
-      const int nf = pass * NF_PER_PASS + nl;
-      if (nf >= NFR) break;
+  for (int nl = 0; nl < NF_PER_PASS; ++nl) {
+    constexpr int NF0 = PASS * NF_PER_PASS;
+    if (NF0 + nl < NFR) {
+      const int nf = NF0 + nl < NFR ? NF0 + nl : NFR - 1;
       const int co = co_base + nf * 16 + q * 4;
       float add[4];
 #pragma unroll
@@ -128,47 +129,61 @@ __device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (
         else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
       }
     }
-    __syncthreads();
-    // ---- LDS -> global: lane = (voxel it*8 + lane/8, 16-byte segment lane%8) ---------------------------------------------
-    const int seg = lane & 7;
-    const int co = co_base + pass * NF_PER_PASS * 16 + seg * VECW;
+  }
+  __syncthreads();
+  // ---- LDS -> global: lane = (voxel it*8 + lane/8, 16-byte segment lane%8) ---------------------------------------------
+  const int seg = lane & 7;
+  const int co = co_base + PASS * NF_PER_PASS * 16 + seg * VECW;
 #pragma unroll
-    for (int it = 0; it < MF * 2; ++it) {
-      const int v = it * 8 + (lane >> 3);
-      const int m = m_base + v;
-      const int a = m >> (p.lth + p.ltw), bb = (m >> p.ltw) & (th - 1), c = m & (tw - 1);
-      const int od = od0 + a, oh = oh0 + bb, ow = ow0 + c;
-      const bool inside = om ? (od < om->Dl && oh < om->Hl && ow < om->Wl) : (od < p.Do && oh < p.Ho && ow < p.Wo);
-      if (inside && co < p.Cout) {
-        const long long vox = om ? (((long long)n * p.Do + 2 * od + om->pd) * p.Ho + 2 * oh + om->ph) * p.Wo + 2 * ow + om->pw
-                                 : (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
-        uint4 raw = *reinterpret_cast<const uint4*>(lds + v * ROWB_E + seg * 16);
-        if (res || p.post_act) {
-          float o[VECW];
-          Vec16<T>::unpack(raw, o);
-          if (res) {
-            float rv[VECW];
-            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(res + vox * p.res_ld + co), rv);
+  for (int it = 0; it < MF * 2; ++it) {
+    const int v = it * 8 + (lane >> 3);
+    const int m = m_base + v;
+    const int a = m >> (p.lth + p.ltw), bb = (m >> p.ltw) & (th - 1), c = m & (tw - 1);
+    const int od = od0 + a, oh = oh0 + bb, ow = ow0 + c;
+    const bool inside = om ? (od < om->Dl && oh < om->Hl && ow < om->Wl) : (od < p.Do && oh < p.Ho && ow < p.Wo);
+    if (inside && co < p.Cout) {
+      const long long vox = om ? (((long long)n * p.Do + 2 * od + om->pd) * p.Ho + 2 * oh + om->ph) * p.Wo + 2 * ow + om->pw
+                               : (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+      uint4 raw = *reinterpret_cast<const uint4*>(lds + v * ROWB_E + seg * 16);
+      if (res || p.post_act) {
+        float o[VECW];
+        Vec16<T>::unpack(raw, o);
+        if (res) {
+          float rv[VECW];
+          Vec16<T>::unpack(*reinterpret_cast<const uint4*>(res + vox * p.res_ld + co), rv);
 #pragma unroll
-            for (int i = 0; i < VECW; ++i) o[i] += rv[i];
-          }
-          if (p.post_act) {
-#pragma unroll
-            for (int i = 0; i < VECW; ++i) o[i] = conv_post_act(o[i], p.post_act);
-          }
-          raw = Vec16<T>::pack(o);
+          for (int i = 0; i < VECW; ++i) o[i] += rv[i];
         }
-        *reinterpret_cast<uint4*>(yout + vox * p.y_ld + co) = raw;
-        if (p.stats) {  // statistics of the values as stored (rounded to T), like a separate pass over the tensor would see them
-          float o[VECW];
-          Vec16<T>::unpack(raw, o);
+        if (p.post_act) {
 #pragma unroll
-          for (int i = 0; i < VECW; ++i) { st_s[pass][i] += o[i]; st_q[pass][i] += o[i] * o[i]; }
+          for (int i = 0; i < VECW; ++i) o[i] = conv_post_act(o[i], p.post_act);
         }
+        raw = Vec16<T>::pack(o);
+      }
+      *reinterpret_cast<uint4*>(yout + vox * p.y_ld + co) = raw;
+      if (p.stats) {  // statistics of the values as stored (rounded to T), like a separate pass over the tensor would see them
+        float o[VECW];
+        Vec16<T>::unpack(raw, o);
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) { st_s[PASS][i] += o[i]; st_q[PASS][i] += o[i] * o[i]; }
       }
     }
-    if (pass + 1 < PASSES) __syncthreads();
   }
+}
+
+template <typename T, int MF, int NFR>
+__device__ __forceinline__ void conv_epilogue_lds(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, int n, int m_base,
+                                                  int co_base, int od0, int oh0, int ow0, int lane,
+                                                  float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
+                                                  float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
+                                                  const ConvOutMap* om = nullptr) {
+  constexpr int NF_PER_PASS = 128 / (16 * (int)sizeof(T));
+  constexpr int PASSES = (NFR + NF_PER_PASS - 1) / NF_PER_PASS;
+  static_assert(PASSES <= 4, "at most 4 epilogue passes (128 output channels in fp32)");
+  conv_epilogue_lds_pass<T, MF, NFR, 0>(p, acc, lds, n, m_base, co_base, od0, oh0, ow0, lane, st_s, st_q, om);
+  if constexpr (PASSES > 1) { __syncthreads(); conv_epilogue_lds_pass<T, MF, NFR, 1>(p, acc, lds, n, m_base, co_base, od0, oh0, ow0, lane, st_s, st_q, om); }
+  if constexpr (PASSES > 2) { __syncthreads(); conv_epilogue_lds_pass<T, MF, NFR, 2>(p, acc, lds, n, m_base, co_base, od0, oh0, ow0, lane, st_s, st_q, om); }
+  if constexpr (PASSES > 3) { __syncthreads(); conv_epilogue_lds_pass<T, MF, NFR, 3>(p, acc, lds, n, m_base, co_base, od0, oh0, ow0, lane, st_s, st_q, om); }
 }
 
 template <typename T>

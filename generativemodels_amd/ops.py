@@ -591,16 +591,16 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
     if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
         order = ([15] if desc.sd == 2 else [11]) + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups (the LDS-DMA kernels stay first)
-        dma_first = [c for c in order if c in (11, 15)]
-        rest = [c for c in order if c not in (11, 15)]
+        dma_first = [c for c in order if c in (11, 15, 18, 19)]
+        rest = [c for c in order if c not in (11, 15, 18, 19)]
         order = dma_first + [c for c in rest if _cfg_tile(c)[0] <= 64] + [c for c in rest if _cfg_tile(c)[0] > 64]
     best = None
     for cfg in order:
         bm, _ = _cfg_tile(cfg)
         tb = _tile_bits_fast if cfg >= 5 else _tile_bits
         bits = tb(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
-        if cfg in (11, 14, 15, 16):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
-            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
+        if cfg in (11, 14, 15, 16, 18, 19):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
+            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
@@ -829,7 +829,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     d.debug_flags = _CONV_DEBUG_FLAGS
     if skip is not None:
         try:
-            _choose_conv_cfg(d, math.prod(out_sp), 11)  # only the LDS-DMA kernel fuses the shortcut
+            _choose_conv_cfg(d, math.prod(out_sp), force_cfg if force_cfg is not None else 11)  # only the LDS-DMA kernels fuse the shortcut
         except ValueError:
             # not covered (fused prologue, 2-D, small / ragged channel counts ...): 1x1 launches over the parts, then a residual
             parts, sw, sb = skip
