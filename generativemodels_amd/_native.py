@@ -99,10 +99,12 @@ PROTOTYPES = {
     "gm_gn_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_spade_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_gn_channel_stats": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp, C.c_int, c_vp]),
-    "gm_gn_finalize_channels": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_ll, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gm_gn_channel_stats_slots": (c_ll, [c_vp, c_ll, c_ll, C.c_int, C.c_int]),
+    "gm_gn_finalize_channels": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gm_layernorm": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_float, C.c_int, c_vp]),
     "gm_conv_cfg_tile": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gm_conv_lds_bytes": (c_ll, [C.POINTER(GmConvDesc)]),
+    "gm_conv_stats_slots": (c_ll, [C.POINTER(GmConvDesc)]),
     "gm_conv_forward": (C.c_int, [C.POINTER(GmConvDesc), c_vp]),
     "gm_packed_conv_weight_elems": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -121,10 +123,10 @@ PROTOTYPES = {
     "gm_conv_wgrad_workspace_bytes": (c_ll, [C.POINTER(GmWgradDesc)]),
     "gm_conv_wgrad": (C.c_int, [C.POINTER(GmWgradDesc), c_vp]),
     "gm_gn_bwd_stats": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
-    "gm_gn_bwd_finalize": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_ll, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gm_gn_bwd_finalize": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gm_gn_bwd_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, C.c_int, c_ll, C.c_int, C.c_int,
                                   C.c_int, c_vp]),
-    "gm_stats_colsum": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
+    "gm_stats_colsum": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
     "gm_attention_backward_workspace_bytes": (c_ll, [C.POINTER(GmAttnBwdDesc)]),
     "gm_attention_backward": (C.c_int, [C.POINTER(GmAttnBwdDesc), c_vp]),
     "gm_layernorm_bwd": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_float, c_vp, C.c_int, c_vp]),

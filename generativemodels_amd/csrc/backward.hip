@@ -545,22 +545,23 @@ extern "C" int gm_gn_bwd_stats(const void* x, long long x_ld, const void* gy, lo
   GM_LAUNCH_CHECK();
 }
 
-// one wave per group; fwd = forward per-channel statistics {sum x, sum x^2}, bwd = {sum g, sum g x}, both [slots][N][C][2] fp64
-__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const double* __restrict__ fwd, const double* __restrict__ bwd, int N, int C, int G,
+// one wave per group; fwd = forward per-channel statistics {sum x, sum x^2} [S_fwd][N][C][2] (gm_gn_channel_stats / a convolution epilogue),
+// bwd = {sum g, sum g x} [GM_STAT_SLOTS][N][C][2] (gm_gn_bwd_stats), both fp64
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const double* __restrict__ fwd, int S_fwd, const double* __restrict__ bwd, int N, int C, int G,
                                                             long long V, float eps, const float* __restrict__ gamma, float* __restrict__ A,
                                                             float* __restrict__ B, float* __restrict__ Cc, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const int cpg = C / G;
   const double m = (double)cpg * (double)V;
-  auto slot_sum = [&](const double* t, int n, int c, int which) {
+  auto slot_sum = [&](const double* t, int n, int c, int which, int slots = GM_STAT_SLOTS) {
     double s = 0.0;
-    for (int sl = 0; sl < GM_STAT_SLOTS; ++sl) s += t[(((long long)sl * N + n) * C + c) * 2 + which];
+    for (int sl = 0; sl < slots; ++sl) s += t[(((long long)sl * N + n) * C + c) * 2 + which];
     return s;
   };
   for (int n = 0; n < N; ++n) {
     double sx = 0.0, sxx = 0.0;
-    for (int j = lane; j < cpg; j += 64) { sx += slot_sum(fwd, n, g * cpg + j, 0); sxx += slot_sum(fwd, n, g * cpg + j, 1); }
+    for (int j = lane; j < cpg; j += 64) { sx += slot_sum(fwd, n, g * cpg + j, 0, S_fwd); sxx += slot_sum(fwd, n, g * cpg + j, 1, S_fwd); }
     for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sxx += __shfl_xor(sxx, o, 64); }
     const double mean = sx / m;
     double var = sxx / m - mean * mean;
@@ -589,12 +590,12 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const double* __res
   }
 }
 
-extern "C" int gm_gn_bwd_finalize(const double* fwd_stats, const double* bwd_stats, int N, int C, int G, long long V, float eps,
+extern "C" int gm_gn_bwd_finalize(const double* fwd_stats, int fwd_slots, const double* bwd_stats, int N, int C, int G, long long V, float eps,
                                   const float* gamma, float* A, float* B, float* Cc, float* dgamma, float* dbeta, void* stream) {
-  GM_REQUIRE(fwd_stats && bwd_stats && A && B && Cc, "null pointer");
+  GM_REQUIRE(fwd_stats && bwd_stats && A && B && Cc && fwd_slots > 0, "null pointer");
   GM_REQUIRE(G > 0 && C % G == 0, "channels must be divisible by groups");
   if (N == 0) return 0;
-  gn_bwd_finalize_kernel<<<G, 64, 0, (hipStream_t)stream>>>(fwd_stats, bwd_stats, N, C, G, V, eps, gamma, A, B, Cc, dgamma, dbeta);
+  gn_bwd_finalize_kernel<<<G, 64, 0, (hipStream_t)stream>>>(fwd_stats, fwd_slots, bwd_stats, N, C, G, V, eps, gamma, A, B, Cc, dgamma, dbeta);
   GM_LAUNCH_CHECK();
 }
 
@@ -672,7 +673,7 @@ extern "C" int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, lo
 
 // out[c] = sum over slots and samples of stats[slot][n][c][0] (a bias gradient from the gm_gn_channel_stats table of gy), or, per sample,
 // out[n][c] = sum over slots (the gradient of a per-sample row vector added by the convolution epilogue: the timestep embedding)
-__global__ __launch_bounds__(256) void stats_colsum_kernel(const double* __restrict__ stats, int N, int C, float* __restrict__ out, int per_sample) {
+__global__ __launch_bounds__(256) void stats_colsum_kernel(const double* __restrict__ stats, int slots, int N, int C, float* __restrict__ out, int per_sample) {
   // one wave per output element, lanes over the slot (x sample) copies, xor-shuffle reduction in a fixed order: a thread walking the 64
   // copies serially cost 22 us per call = 2.6 ms per C4 training step (profiles/r01_c4_train_kernel_stats.csv)
   const int lane = threadIdx.x & 63;
@@ -680,19 +681,19 @@ __global__ __launch_bounds__(256) void stats_colsum_kernel(const double* __restr
   if (w >= (per_sample ? N * C : C)) return;  // wave-uniform
   double s = 0.0;
   if (per_sample) {
-    for (int sl = lane; sl < GM_STAT_SLOTS; sl += 64) s += stats[((long long)sl * N * C + w) * 2];
+    for (int sl = lane; sl < slots; sl += 64) s += stats[((long long)sl * N * C + w) * 2];
   } else {
-    for (long long j = lane; j < (long long)GM_STAT_SLOTS * N; j += 64) s += stats[(j * C + w) * 2];
+    for (long long j = lane; j < (long long)slots * N; j += 64) s += stats[(j * C + w) * 2];
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) out[w] = (float)s;
 }
 
-extern "C" int gm_stats_colsum(const double* stats, int N, int C, float* out, int per_sample, void* stream) {
-  GM_REQUIRE(stats && out, "null pointer");
+extern "C" int gm_stats_colsum(const double* stats, int slots, int N, int C, float* out, int per_sample, void* stream) {
+  GM_REQUIRE(stats && out && slots > 0, "null pointer");
   if (C == 0 || N == 0) return 0;
   const long long total = per_sample ? (long long)N * C : C;
-  stats_colsum_kernel<<<(unsigned)((total * 64 + 255) / 256), 256, 0, (hipStream_t)stream>>>(stats, N, C, out, per_sample);
+  stats_colsum_kernel<<<(unsigned)((total * 64 + 255) / 256), 256, 0, (hipStream_t)stream>>>(stats, slots, N, C, out, per_sample);
   GM_LAUNCH_CHECK();
 }
 

@@ -370,6 +370,23 @@ extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   return pD * pH * pW * CONV_ROWB + 2LL * bn * CONV_ROWB;
 }
 
+// Number S of per-tile partials a launch with this descriptor (tile configuration chosen) writes into GmConvDesc.stats, laid out
+// [S][N][Cout][2] fp64 -- or 0 when this configuration does not fuse the output statistics (generic kernels, the C_out = 1 head, a
+// ragged channel count that takes the scalar epilogue): the caller then runs gm_gn_channel_stats over the stored tensor instead.
+extern "C" long long gm_conv_stats_slots(const GmConvDesc* d) {
+  if (!d) return 0;
+  const bool fused = conv_is_fast(d->cfg) || conv_is_dma(d->cfg) || d->cfg == CONV_CFG_CIN;
+  if (!fused) return 0;
+  const int vecw = d->dtype == GM_F32 ? 4 : 8;
+  const bool lds_epilogue = (d->Cout % vecw == 0) && (d->y_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0) &&
+                            (!d->res || ((d->res_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->res) & 15) == 0)));
+  if (!lds_epilogue) return 0;
+  const bool subpixel = d->cfg == 17;
+  const long long De = subpixel ? d->Ds : d->Do, He = subpixel ? d->Hs : d->Ho, We = subpixel ? d->Ws : d->Wo;
+  const long long ntd = (De + (1 << d->ltd) - 1) >> d->ltd, nth = (He + (1 << d->lth) - 1) >> d->lth, ntw = (We + (1 << d->ltw) - 1) >> d->ltw;
+  return ntd * nth * ntw * (subpixel ? 8 : 1);
+}
+
 extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(dp, "null descriptor");
   const GmConvDesc& d = *dp;
@@ -394,6 +411,7 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
              "geometry is not eligible for the C_in<=4 / C_out==1 kernels");
   const long long smem = gm_conv_lds_bytes(dp);
   GM_REQUIRE(smem > 0 && smem <= 160 * 1024, "tile needs more than 160 KiB of LDS");
+  GM_REQUIRE(d.stats == nullptr || gm_conv_stats_slots(dp) > 0, "this tile configuration does not fuse the output statistics");
   // cfg 17 (sub-pixel up-sampling): the tiles walk the low-resolution grid, once per output parity
   const bool subpixel = d.cfg == 17;
   const long long De = subpixel ? d.Ds : d.Do, He = subpixel ? d.Hs : d.Ho, We = subpixel ? d.Ws : d.Wo;

@@ -27,7 +27,9 @@ struct GmConvDesc {
   int ltd, lth, ltw;              // log2 of the output tile dims
   int cfg;                        // tile configuration id (see dispatch)
   int debug_flags;                // 0 in production; bench-only ablation switches of conv_fast.hip
-  double* stats;                  // optional [GM_STAT_SLOTS][N][Cout][2] (sum, sum of squares) of the OUTPUT, fp64 atomics
+  double* stats;                  // optional [S][N][Cout][2] (sum, sum of squares) of the OUTPUT, S = gm_conv_stats_slots(desc) = tiles per
+                                  // sample: every work-group STORES its partial exactly once (no atomics, no zero fill); consumers add the S
+                                  // partials in a fixed order, so the statistics -- and everything downstream -- are bit-reproducible run to run
   // optional fused 1x1 "skip" convolution (ResnetBlock shortcut): y += W_skip * cat(skip_x[0], skip_x[1]) + skip_bias, sources in
   // the OUTPUT geometry; only the LDS-DMA kernel (cfg 11) implements it
   const void* skip_x[2]; long long skip_ld[2]; int skip_cin[2];
@@ -35,8 +37,8 @@ struct GmConvDesc {
   const float* skip_bias;         // [Cout] or null
 };
 
-// per-channel statistics are accumulated with fp64 atomics into GM_STAT_SLOTS copies (slot = tile index mod slots): with a
-// single copy every work-group of a launch hammers the same 2*C addresses and the L2 serialises them (~0.15 ms per launch)
+// slot count of the zero-initialised, atomically accumulated statistic tables the BACKWARD kernels still use ([GM_STAT_SLOTS][N][C][2];
+// gm_gn_bwd_stats, gm_layernorm_bwd).  The forward tables (convolution epilogues, gm_gn_channel_stats) hold one partial per tile instead.
 #define GM_STAT_SLOTS 64
 
 #define CONV_ROWB 80  // LDS row pitch in bytes: 64 B of operands + 16 B pad

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const int ncb = (p.Cout + BN - 1) / BN;
   unsigned b = xcd_remap(blockIdx.x, gridDim.x);
   const int cb = b % ncb; b /= ncb;
+  const unsigned tile_id = b;  // ((n, td, th, tw)[, parity]): the statistics slot of this work-group is tile_id modulo the tiles per sample
   int par = 0;
   if (KS == 2) { par = b & 7; b >>= 3; }
   const int tw_i = b % ntw; b /= ntw;
@@ -386,10 +387,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       }
       const int co = cb * BN + tid;
       if (co < p.Cout) {
-        const long long slot = (blockIdx.x / ncb) % GM_STAT_SLOTS;
-        double* dst = p.stats + ((slot * p.N + n) * p.Cout + co) * 2;
-        atomicAdd(dst, a);
-        atomicAdd(dst + 1, b2);
+        const long long slot = tile_id % (unsigned)(ntd * nth * ntw * (KS == 2 ? 8 : 1));  // one plain store per (tile, channel): fixed-order
+        double* dst = p.stats + ((slot * p.N + n) * p.Cout + co) * 2;                       // reduction by the consumers, no atomics
+        *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
       }
     }
   }

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
   const int ncb = (p.Cout + BN - 1) / BN;
   unsigned b = xcd_remap(blockIdx.x, gridDim.x);
   const int cb = b % ncb; b /= ncb;
+  const unsigned tile_id = b;  // (n, td, th, tw): statistics slot = tile_id modulo the tiles per sample
   const int tw_i = b % ntw; b /= ntw;
   const int th_i = b % nth; b /= nth;
   const int td_i = b % ntd; b /= ntd;
@@ -142,10 +143,9 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
       }
       const int co = cb * BN + tid;
       if (co < p.Cout) {
-        const long long slot = (blockIdx.x / ncb) % GM_STAT_SLOTS;
+        const long long slot = tile_id % (unsigned)(ntd * nth * ntw);  // one plain store per (tile, channel): no atomics, fixed-order reduction later
         double* dst = p.stats + ((slot * p.N + n) * p.Cout + co) * 2;
-        atomicAdd(dst, a);
-        atomicAdd(dst + 1, b2);
+        *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
       }
     }
   }

@@ -81,10 +81,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
     double a = 0.0, b = 0.0;
     for (int r = 0; r < R; ++r) { a += (double)part_s[(size_t)r * C + c]; b += (double)part_q[(size_t)r * C + c]; }
     ch_s[c] = a; ch_q[c] = b;
-    if (chan_out) {  // per-channel mode (fp64 atomics into [slots][N][C][2]): composable over channel concatenations
-      double* dst = chan_out + (((long long)(blk % GM_STAT_SLOTS) * gridDim.y + n) * C + c) * 2;
-      atomicAdd(dst, a);
-      atomicAdd(dst + 1, b);
+    if (chan_out) {  // per-channel mode: one partial per block, [gridDim.x][N][C][2], plain stores (composable over channel concatenations;
+      double* dst = chan_out + (((long long)blk * gridDim.y + n) * C + c) * 2;  // the consumers add the partials in a fixed order)
+      *reinterpret_cast<double2*>(dst) = make_double2(a, b);
     }
   }
   if (!partial) return;
@@ -197,7 +196,17 @@ extern "C" int gm_gn_scale_shift(const void* x, long long ld, int N, long long V
   GM_LAUNCH_CHECK();
 }
 
-// Per-channel statistics: chan_out[n][c] += {sum, sum of squares} over the V voxels (zero-initialised by the caller).
+// Slots S of the [S][N][C][2] table gm_gn_channel_stats writes for this tensor (one partial per block of rows; depends on the load width
+// the dispatcher picks, hence the pointer / pitch arguments).  -1: channel count not covered.
+extern "C" long long gm_gn_channel_stats_slots(const void* x, long long ld, long long V, int C, int dtype) {
+  const int vecmax = dtype == GM_F32 ? 4 : 8;
+  const bool vec_ok = (C % vecmax == 0) && (ld % vecmax == 0) && (((uintptr_t)x & 15) == 0);
+  if ((vec_ok ? C / vecmax : C) > GN_THREADS) return -1;
+  return V == 0 ? 1 : gn_nblk(V, C, vec_ok ? vecmax : 1);
+}
+
+// Per-channel statistics: chan_out[slot][n][c] = {sum, sum of squares} over the rows of block `slot` (every entry of the
+// [gm_gn_channel_stats_slots][N][C][2] table is written exactly once: no zero fill, no atomics).
 extern "C" int gm_gn_channel_stats(const void* x, long long ld, int N, long long V, int C, double* chan_out, int dtype, void* stream) {
   GM_REQUIRE(x && chan_out, "null pointer");
   GM_REQUIRE(N <= 65535, "batch too large");
@@ -219,27 +228,40 @@ extern "C" int gm_gn_channel_stats(const void* x, long long ld, int N, long long
   GM_LAUNCH_CHECK();
 }
 
-// GroupNorm scale/shift from per-channel statistics of up to two channel-concatenated sources (C = C0 + C1).
-__global__ __launch_bounds__(64) void gn_finalize_channels_kernel(const double* __restrict__ s0, int C0, const double* __restrict__ s1,
-                                                                 int C1, int N, int G, long long V, float eps,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 float* __restrict__ scale, float* __restrict__ shift) {
+// GroupNorm scale/shift from per-channel statistic partials of up to two channel-concatenated sources (C = C0 + C1): source i holds
+// S_i partials [S_i][N][C_i][2].  One 256-thread block per (n, group); every thread adds its strided share of the partials in index order,
+// then lanes and waves are combined by a fixed butterfly / a fixed 4-term sum: the result depends on the table contents only.
+__global__ __launch_bounds__(256) void gn_finalize_channels_kernel(const double* __restrict__ s0, int S0, int C0, const double* __restrict__ s1,
+                                                                  int S1, int C1, int N, int G, long long V, float eps,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[4][2];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
-  const int lane = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int C = C0 + C1, cpg = C / G;
   double a = 0.0, b = 0.0;
-  for (int j = lane; j < cpg * GM_STAT_SLOTS; j += 64) {  // fixed summation order: deterministic given the slot contents
-    const int c = g * cpg + j % cpg, slot = j / cpg;
-    const double* src = c < C0 ? s0 + (((long long)slot * N + n) * C0 + c) * 2 : s1 + (((long long)slot * N + n) * C1 + (c - C0)) * 2;
-    a += src[0]; b += src[1];
+  for (int j = 0; j < cpg; ++j) {  // a group may straddle the two sources: per channel, then per partial
+    const int c = g * cpg + j;
+    const bool first = c < C0;
+    const double* src = first ? s0 + ((long long)n * C0 + c) * 2 : s1 + ((long long)n * C1 + (c - C0)) * 2;
+    const long long pitch = (long long)N * (first ? C0 : C1) * 2;
+    const int S = first ? S0 : S1;
+    for (int sl = t; sl < S; sl += 256) {
+      const double2 v = *reinterpret_cast<const double2*>(src + sl * pitch);
+      a += v.x; b += v.y;
+    }
   }
   a = wave_sum(a); b = wave_sum(b);
+  if (lane == 0) { red[wave][0] = a; red[wave][1] = b; }
+  __syncthreads();
+  a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+  b = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
   const double cnt = (double)cpg * (double)V;
   const double mean = a / cnt;
   double var = b / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
-  for (int j = lane; j < cpg; j += 64) {
+  for (int j = t; j < cpg; j += 256) {
     const int c = g * cpg + j;
     const double ga = gamma ? (double)gamma[c] : 1.0;
     const double be = beta ? (double)beta[c] : 0.0;
@@ -248,13 +270,14 @@ __global__ __launch_bounds__(64) void gn_finalize_channels_kernel(const double* 
   }
 }
 
-extern "C" int gm_gn_finalize_channels(const double* stats0, int C0, const double* stats1, int C1, int N, long long V, int G,
+extern "C" int gm_gn_finalize_channels(const double* stats0, int S0, int C0, const double* stats1, int S1, int C1, int N, long long V, int G,
                                        float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
   GM_REQUIRE(stats0 && scale && shift, "null pointer");
   GM_REQUIRE(C1 == 0 || stats1, "second source without statistics");
+  GM_REQUIRE(S0 > 0 && (C1 == 0 || S1 > 0), "statistic tables need at least one partial");
   GM_REQUIRE(G > 0 && (C0 + C1) % G == 0, "channels must be divisible by groups");
   if (N == 0) return 0;
-  gn_finalize_channels_kernel<<<N * G, 64, 0, (hipStream_t)stream>>>(stats0, C0, stats1, C1, N, G, V, eps, gamma, beta, scale, shift);
+  gn_finalize_channels_kernel<<<N * G, 256, 0, (hipStream_t)stream>>>(stats0, S0, C0, stats1, S1, C1, N, G, V, eps, gamma, beta, scale, shift);
   GM_LAUNCH_CHECK();
 }
 

@@ -392,15 +392,15 @@ def spade_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, g: to
     return out
 
 
-STAT_SLOTS = 64  # GM_STAT_SLOTS of include/gm_amd.h
+STAT_SLOTS = 64  # GM_STAT_SLOTS of include/gm_amd.h: the zero-filled, atomically accumulated tables of the BACKWARD kernels only
 
 _STATS_CHUNK = 1 << 20  # doubles per zero-filled chunk (8 MB): one memset serves ~40 statistic tables of a C2 forward
 _stats_pool: dict = {}
 
 
 def _zero_stats(n: int, c: int, device) -> torch.Tensor:
-    """A zeroed fp64 [STAT_SLOTS, N, C, 2] table carved out of a pooled zero-filled chunk (each table is used once; a separate
-    torch.zeros per table cost 40 fill launches = 0.19 ms per C2 forward)."""
+    """A zeroed fp64 [STAT_SLOTS, N, C, 2] table carved out of a pooled zero-filled chunk (each table is used once): the accumulator of
+    gm_gn_bwd_stats.  (The forward statistics need no zero fill: one stored partial per tile, see channel_stats.)"""
     need = STAT_SLOTS * n * c * 2
     if need > _STATS_CHUNK // 4 or torch.cuda.is_current_stream_capturing():
         # under HIP-graph capture every table needs its own captured fill: a pooled chunk zeroed before the capture would be
@@ -438,22 +438,31 @@ class VirtualCat:
 
 
 def channel_stats(x: torch.Tensor) -> torch.Tensor:
-    """fp64 [STAT_SLOTS, N, C, 2] per-channel (sum, sum of squares) partials of an arena tensor (sum over dim 0 = the statistics); cached on the tensor object (the fast convolution
-    kernels attach it to their outputs for free)."""
+    """fp64 [S, N, C, 2] per-channel (sum, sum of squares) partials of an arena tensor (sum over dim 0 = the statistics; S = one partial per
+    block of rows, each stored exactly once -- no atomics -- so every consumer's fixed-order sum is bit-reproducible); cached on the tensor
+    object (the fast convolution kernels attach their per-tile partials to their outputs for free)."""
     cached = getattr(x, "_gm_cstats", None)
     if cached is not None:
         return cached
-    require_device(x)
-    n, c = x.shape[0], x.shape[-1]
-    v = rows_of(x) // max(n, 1)
-    st = _zero_stats(n, c, x.device)
-    _timed(f"gn_stats<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(x.element_size() * x.numel()), shape=f"N{n} V{v} C{c}"),
-           lambda: check(lib().gm_gn_channel_stats(x.data_ptr(), arena_ld(x), n, v, c, st.data_ptr(), dt_code(x.dtype), _stream()),
-                         "gm_gn_channel_stats"))
+    st = _fresh_channel_stats(x)
     try:
         x._gm_cstats = st
     except Exception:  # pragma: no cover
         pass
+    return st
+
+
+def _fresh_channel_stats(x: torch.Tensor) -> torch.Tensor:
+    require_device(x)
+    n, c = x.shape[0], x.shape[-1]
+    v = rows_of(x) // max(n, 1)
+    slots = lib().gm_gn_channel_stats_slots(x.data_ptr(), arena_ld(x), v, c, dt_code(x.dtype))
+    if slots <= 0:
+        raise ValueError(f"per-channel statistics over {c} channels are not supported by the gfx950 kernel")
+    st = torch.empty((slots, n, c, 2), dtype=torch.float64, device=x.device)
+    _timed(f"gn_stats<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(x.element_size() * x.numel()), shape=f"N{n} V{v} C{c}"),
+           lambda: check(lib().gm_gn_channel_stats(x.data_ptr(), arena_ld(x), n, v, c, st.data_ptr(), dt_code(x.dtype), _stream()),
+                         "gm_gn_channel_stats"))
     return st
 
 
@@ -470,9 +479,10 @@ def gn_scale_shift_composed(x, groups: int, eps: float, gamma: Optional[torch.Te
     stats = [channel_stats(p) for p in parts]
     scale = torch.empty((n, c), dtype=torch.float32, device=parts[0].device)
     shift = torch.empty((n, c), dtype=torch.float32, device=parts[0].device)
-    check(lib().gm_gn_finalize_channels(stats[0].data_ptr(), cs[0], stats[1].data_ptr() if len(parts) > 1 else None,
-                                        cs[1] if len(parts) > 1 else 0, n, v, groups, float(eps), _ptr(as_f32(gamma)), _ptr(as_f32(beta)),
-                                        scale.data_ptr(), shift.data_ptr(), _stream()), "gm_gn_finalize_channels")
+    check(lib().gm_gn_finalize_channels(stats[0].data_ptr(), stats[0].shape[0], cs[0], stats[1].data_ptr() if len(parts) > 1 else None,
+                                        stats[1].shape[0] if len(parts) > 1 else 0, cs[1] if len(parts) > 1 else 0, n, v, groups, float(eps),
+                                        _ptr(as_f32(gamma)), _ptr(as_f32(beta)), scale.data_ptr(), shift.data_ptr(), _stream()),
+          "gm_gn_finalize_channels")
     return scale, shift
 
 
@@ -613,6 +623,16 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
     desc.cfg, (desc.ltd, desc.lth, desc.ltw) = best[0], best[1]
 
 
+def _attach_conv_stats(d: GmConvDesc, out: torch.Tensor, n: int, cout: int) -> None:
+    """Point the descriptor (tile configuration already chosen) at a fresh [S, N, Cout, 2] table of per-tile partials and attach it to the
+    output tensor; nothing happens when this configuration does not fuse the statistics (gm_conv_stats_slots = 0)."""
+    slots = lib().gm_conv_stats_slots(C.byref(d))
+    if slots > 0:
+        cst = torch.empty((slots, n, cout, 2), dtype=torch.float64, device=out.device)
+        d.stats = cst.data_ptr()
+        out._gm_cstats = cst
+
+
 def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, cin, cout, src):
     """Nearest-2x up-sampling + 3x3x3 convolution as 8 sub-pixel 2x2x2 convolutions (GmConvDesc.in_mode 3, configuration 17).
     Returns None when the geometry is not covered (the caller falls back to the folded up-sampling path)."""
@@ -659,9 +679,7 @@ def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, c
         return None
     d.stats = None
     if want_stats:
-        cst = _zero_stats(n, cout, x.device)
-        d.stats = cst.data_ptr()
-        out._gm_cstats = cst
+        _attach_conv_stats(d, out, n, cout)
     nvo = n * math.prod(out_sp)
     es = x.element_size()
     _timed(f"conv_igemm<{str(dtype).split('.')[-1]},cfg17>",
@@ -847,10 +865,8 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     else:
         _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
     d.stats = None
-    if want_stats and d.cfg >= 5 and d.cfg != 13:  # the fast stride-1 kernels fuse the output statistics into their epilogue
-        cst = _zero_stats(n, cout, x.device)
-        d.stats = cst.data_ptr()
-        out._gm_cstats = cst
+    if want_stats:  # the fast kernels fuse the output statistics into their epilogue (else: one stand-alone pass when a consumer asks)
+        _attach_conv_stats(d, out, n, cout)
     if _PROFILE is None:
         check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward")
     else:
@@ -955,11 +971,9 @@ def bias_grad(gy: torch.Tensor, per_sample: bool = False) -> torch.Tensor:
     # Fresh statistics, never the tensor's cached table: a gradient tensor can be accumulated IN PLACE by the autograd engine after a first
     # consumer attached its column sums to the Python object (dres = gy hands the same object to two branches) -- measured as 12-24 %
     # errors in exactly the bias gradients behind an identity residual.
-    v = rows_of(gy) // max(n, 1)
-    st = _zero_stats(n, c, gy.device)
-    check(lib().gm_gn_channel_stats(gy.data_ptr(), arena_ld(gy), n, v, c, st.data_ptr(), dt_code(gy.dtype), _stream()), "gm_gn_channel_stats")
+    st = _fresh_channel_stats(gy)
     out = torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=gy.device)
-    check(lib().gm_stats_colsum(st.data_ptr(), n, c, out.data_ptr(), int(per_sample), _stream()), "gm_stats_colsum")
+    check(lib().gm_stats_colsum(st.data_ptr(), st.shape[0], n, c, out.data_ptr(), int(per_sample), _stream()), "gm_stats_colsum")
     return out
 
 
@@ -983,7 +997,7 @@ def gn_backward(x: torch.Tensor, gy: torch.Tensor, scale: torch.Tensor, shift: t
     coef = torch.empty((3, n, c), dtype=torch.float32, device=x.device)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
-    check(lib().gm_gn_bwd_finalize(fwd.data_ptr(), bwd.data_ptr(), n, c, groups, v, float(eps), _ptr(as_f32(gamma)), coef[0].data_ptr(),
+    check(lib().gm_gn_bwd_finalize(fwd.data_ptr(), fwd.shape[0], bwd.data_ptr(), n, c, groups, v, float(eps), _ptr(as_f32(gamma)), coef[0].data_ptr(),
                                    coef[1].data_ptr(), coef[2].data_ptr(), _ptr(dgamma), _ptr(dbeta), _stream()), "gm_gn_bwd_finalize")
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     check(lib().gm_gn_bwd_apply(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), scale.data_ptr(),
@@ -1040,8 +1054,8 @@ def layernorm_backward(x: torch.Tensor, gy: torch.Tensor, gamma: Optional[torch.
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     flat = st.view(-1)
-    check(lib().gm_stats_colsum(flat.data_ptr(), 1, c, dgamma.data_ptr(), 0, _stream()), "gm_stats_colsum")
-    check(lib().gm_stats_colsum(flat[1:].data_ptr(), 1, c, dbeta.data_ptr(), 0, _stream()), "gm_stats_colsum")
+    check(lib().gm_stats_colsum(flat.data_ptr(), STAT_SLOTS, 1, c, dgamma.data_ptr(), 0, _stream()), "gm_stats_colsum")
+    check(lib().gm_stats_colsum(flat[1:].data_ptr(), STAT_SLOTS, 1, c, dbeta.data_ptr(), 0, _stream()), "gm_stats_colsum")
     return dx, dgamma, dbeta
 
 

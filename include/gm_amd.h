@@ -114,12 +114,15 @@ int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const fl
  * (scale, shift) = the parameter-free GroupNorm / InstanceNorm of x, g = 1 + gamma(seg), bm = beta(seg) in the dtype of x (row pitch gb_ld) */
 int gm_spade_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift, long long ss_ld,
                    const void* g, const void* bm, long long gb_ld, int N, long long V, int C, int act, int dtype, void* stream);
-/* Composable form: per-channel {sum, sum of squares} in fp64 ([GM_STAT_SLOTS][N][C][2], zero-initialised by the caller; also produced by the
- * fast convolution kernels' epilogue through GmConvDesc.stats), and the GroupNorm finalisation over up to two
- * channel-concatenated sources -- torch.cat([h, skip]) followed by GroupNorm (diffusion_model_unet.py:1232 + 671) without ever
- * materialising the concatenation. */
+/* Composable form: per-channel {sum, sum of squares} partials in fp64, [S][N][C][2] with one partial per block of rows / per output tile
+ * (S = gm_gn_channel_stats_slots for this entry point, gm_conv_stats_slots for a convolution epilogue writing GmConvDesc.stats).  Every
+ * entry is STORED exactly once (no atomics, no zero fill) and the consumers add the S partials in a fixed order, so GroupNorm -- and with
+ * it a whole sampling chain -- is bit-reproducible run to run.  gm_gn_finalize_channels is the GroupNorm finalisation over up to two
+ * channel-concatenated sources (S0 / S1 partials each) -- torch.cat([h, skip]) followed by GroupNorm (diffusion_model_unet.py:1232 + 671)
+ * without ever materialising the concatenation. */
+long long gm_gn_channel_stats_slots(const void* x, long long ld, long long V, int C, int dtype);
 int gm_gn_channel_stats(const void* x, long long ld, int N, long long V, int C, double* chan_out, int dtype, void* stream);
-int gm_gn_finalize_channels(const double* stats0, int C0, const double* stats1, int C1, int N, long long V, int G, float eps,
+int gm_gn_finalize_channels(const double* stats0, int S0, int C0, const double* stats1, int S1, int C1, int N, long long V, int G, float eps,
                             const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
                  long long rows, int C, float eps, int dtype, void* stream);
@@ -155,17 +158,20 @@ typedef struct GmConvDesc {
   int ltd, lth, ltw;         /* log2 output tile dims; product must equal the configuration's voxel count */
   int cfg;                   /* tile configuration, see gm_conv_cfg_tile */
   int debug_flags;           /* must be 0 (bench-only ablation switches: results are wrong when set) */
-  double* stats;             /* optional, zero-initialised [GM_STAT_SLOTS][N][Cout][2]: per-channel sum / sum of squares of the
-                                stored output, accumulated by the fast stride-1 kernels (cfg >= 5) for the next GroupNorm */
+  double* stats;             /* optional [gm_conv_stats_slots(desc)][N][Cout][2]: per-tile partials of the per-channel sum / sum of squares
+                                of the stored output for the next GroupNorm (plain stores, one per tile and channel: no zero fill needed);
+                                must be NULL when gm_conv_stats_slots() returns 0 for the chosen configuration */
   /* optional fused 1x1 shortcut convolution of a ResnetBlock (diffusion_model_unet.py:684-696, autoencoderkl.py:188-193):
    * y += W_skip * cat(skip_x[0], skip_x[1]) + skip_bias with the sources in the output geometry (skip_x[1] may be NULL).
-   * Implemented by cfg 11 only: gm_conv_lds_bytes() returns -1 for any other configuration when skip_x[0] is set. */
+   * Implemented by the LDS-DMA configurations (cfg 11, 14, 16, 18, 19): gm_conv_lds_bytes() returns -1 for any other when skip_x[0] is set. */
   const void* skip_x[2]; long long skip_ld[2]; int skip_cin[2];
   const void* skip_w;        /* gm_pack_conv_weight image of the [Cout][skip_cin[0]+skip_cin[1]] 1x1 kernel */
   const float* skip_bias;    /* [Cout] or NULL */
 } GmConvDesc;
 int gm_conv_cfg_tile(int cfg, int* voxels, int* channels);
 long long gm_conv_lds_bytes(const GmConvDesc* d);
+/* partials S a launch writes into GmConvDesc.stats ([S][N][Cout][2]); 0 = this configuration does not fuse the output statistics */
+long long gm_conv_stats_slots(const GmConvDesc* d);
 int gm_conv_forward(const GmConvDesc* d, void* stream);
 long long gm_packed_conv_weight_elems(int Cout, int Cin, int kd, int kh, int kw, int dtype);
 /* src: [Cout][Cin][kd][kh][kw] (transposed = 0) or [Cin][Cout][kd][kh][kw] (transposed = 1, nn.ConvTransposeNd) */
@@ -268,11 +274,11 @@ int gm_conv_wgrad(const GmWgradDesc* d, void* stream);
  * diffusion_model_unet.py:623-690).  With g = gy * act'(x * scale + shift):
  *   gm_gn_bwd_stats     out[slot][n][c] += {sum_v g, sum_v g x}  (fp64, GM_STAT_SLOTS slots, zeroed by the caller)
  *   gm_gn_bwd_finalize  per-(n, c) coefficients A, B, Cc of dx = A g + B x + Cc, and dgamma[c], dbeta[c] (nullable);
- *                       fwd_stats = gm_gn_channel_stats table of x
+ *                       fwd_stats = the [fwd_slots][N][C][2] forward table of x (gm_gn_channel_stats or a convolution epilogue)
  *   gm_gn_bwd_apply     dx = g * A + x * B + Cc */
 int gm_gn_bwd_stats(const void* x, long long x_ld, const void* gy, long long gy_ld, const float* scale, const float* shift, long long ss_ld,
                     int N, long long V, int C, int act, double* out, int dtype, void* stream);
-int gm_gn_bwd_finalize(const double* fwd_stats, const double* bwd_stats, int N, int C, int G, long long V, float eps, const float* gamma,
+int gm_gn_bwd_finalize(const double* fwd_stats, int fwd_slots, const double* bwd_stats, int N, int C, int G, long long V, float eps, const float* gamma,
                        float* A, float* B, float* Cc, float* dgamma, float* dbeta, void* stream);
 int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, const float* scale,
                     const float* shift, long long ss_ld, const float* A, const float* B, const float* Cc, int N, long long V, int C, int act,
@@ -280,7 +286,7 @@ int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, long long gy_
 /* per_sample = 0: out[c] = sum over slots and samples of stats[slot][n][c][0] (a bias gradient from the gm_gn_channel_stats table of
  * gy); per_sample = 1: out[n][c] = sum over slots (gradient of the per-sample row vector a convolution epilogue adds: the timestep
  * embedding projection, diffusion_model_unet.py:684-686) */
-int gm_stats_colsum(const double* stats, int N, int C, float* out, int per_sample, void* stream);
+int gm_stats_colsum(const double* stats, int slots, int N, int C, float* out, int per_sample, void* stream);
 
 /* Flash-attention backward: dq, dk, dv of o = softmax(scale q k^T) v per (batch, head) (torch autograd through
  * diffusion_model_unet.py:143-153 / 407-415); the L x L scores are recomputed tile by tile, never stored.  o = the forward output

@@ -27,7 +27,10 @@ def _randn(shape, seed, dtype=torch.bfloat16, scale=1.0):
     return (torch.randn(shape, generator=g, device=DEV) * scale).to(dtype)
 
 
-@pytest.mark.parametrize("cin,cout,size,up", [(64, 64, 128, False), (192, 64, 128, False), (128, 128, 64, True), (256, 256, 32, False)])
+# the last two cases are configuration C3's level-0 tensors (AutoencoderKL at 256^3: 2.1 GB per 64-channel tensor, a 4.3 GB output of the
+# up-sampling convolution -- byte offsets beyond 2^31 and 2^32)
+@pytest.mark.parametrize("cin,cout,size,up", [(64, 64, 128, False), (192, 64, 128, False), (128, 128, 64, True), (256, 256, 32, False),
+                                              (64, 64, 256, False), (128, 128, 128, True)])
 def test_conv_full_size_spot_checks_and_linearity(cin, cout, size, up):
     ops = _ops()
     x = _randn((1, size, size, size, cin), 1)
@@ -40,6 +43,7 @@ def test_conv_full_size_spot_checks_and_linearity(cin, cout, size, up):
     # ---- spot checks: 48 random output voxels + the 8 corners, all channels, fp64 reference from the same inputs ---------------
     g = torch.Generator().manual_seed(5)
     pts = torch.randint(0, osz, (48, 3), generator=g).tolist() + [[a, b_, c] for a in (0, osz - 1) for b_ in (0, osz - 1) for c in (0, osz - 1)]
+    pts += [[osz - 1 - a, osz - 2, osz - 3] for a in range(8)]  # the far end of the volume: the largest byte offsets
     w64 = w.double().cpu()
     worst = 0.0
     for d, h, ww in pts:
@@ -58,8 +62,15 @@ def test_conv_full_size_spot_checks_and_linearity(cin, cout, size, up):
     assert worst <= 1.5e-2, f"spot-check error {worst:.3e}"  # bf16 storage of the result: 2^-8 relative
     # ---- fused statistics vs an independent reduction of the stored tensor -------------------------------------------------------
     st = y._gm_cstats.sum(0)[0]  # [C][2]
-    v = y.double().reshape(-1, cout)
-    assert torch.allclose(st[:, 0], v.sum(0), rtol=1e-6, atol=1e-3) and torch.allclose(st[:, 1], (v * v).sum(0), rtol=1e-6, atol=1e-3)
+    s1 = torch.zeros(cout, dtype=torch.float64, device=DEV)
+    s2 = torch.zeros(cout, dtype=torch.float64, device=DEV)
+    for part in y.reshape(-1, cout).split(1 << 24):  # in slabs: a 4.3 GB tensor is 34 GB as fp64
+        v = part.double()
+        s1 += v.sum(0)
+        s2 += (v * v).sum(0)
+    assert torch.allclose(st[:, 0], s1, rtol=1e-6, atol=1e-3) and torch.allclose(st[:, 1], s2, rtol=1e-6, atol=1e-3)
+    if osz > 128:
+        return  # the 256^3 cases stop here (linearity below allocates five more full-size fp32 tensors)
     # ---- linearity over the whole volume -----------------------------------------------------------------------------------------
     x2 = _randn((1, size, size, size, cin), 6)
     ya = ops.conv(x, w, b, kernel=3, padding=1, upsample=up).float()
@@ -88,9 +99,8 @@ def test_attention_full_size_rows_match_a_host_softmax():
 
 
 def test_c2_sampling_chain_full_size_is_finite_and_reproducible():
-    """Three DDIM steps of the headline configuration at full size: finite, the same volume for the same noise (the only
-    run-to-run freedom is the summation order of the fp64 statistic atomics, far below bf16 resolution), different for different
-    noise, and an eps-prediction of unit scale for unit-variance input (random-init network)."""
+    """Three DDIM steps of the headline configuration at full size: finite, BITWISE the same volume for the same noise, different for
+    different noise, and an eps-prediction of unit scale for unit-variance input (random-init network)."""
     from bench import C2, rerandomize_zero_params
     from generativemodels_amd.inferers import DiffusionInferer
     from generativemodels_amd.networks.nets import DiffusionModelUNet
@@ -108,10 +118,45 @@ def test_c2_sampling_chain_full_size_is_finite_and_reproducible():
     b = inf.sample(noise, model, sched, verbose=False)
     c = inf.sample(_randn((1, 1, 128, 128, 128), 22), model, sched, verbose=False)
     assert a.shape == (1, 1, 128, 128, 128) and torch.isfinite(a.float()).all()
-    assert (a.float() - b.float()).abs().max().item() <= 2e-2 * a.float().abs().max().item()
+    assert torch.equal(a, b)  # bit-reproducible: the GroupNorm statistics are per-tile partials added in a fixed order, nothing is atomic
     assert (a.float() - c.float()).abs().mean().item() > 1e-2
     eps = model(noise, torch.tensor([500.0], device=DEV))
     assert torch.isfinite(eps.float()).all() and 1e-3 < eps.float().std().item() < 1e3
+
+
+def test_groupnorm_statistics_and_apply_at_256_cubed():
+    """GroupNorm over a 1x256^3x64 bf16 tensor (2.1 GB, configuration C3's level 0): per-channel statistics, the folded (scale, shift) and
+    the apply + SiLU pass against torch arithmetic on the same data (fp64 reductions in slabs; element-wise fp32)."""
+    ops = _ops()
+    c, groups, eps = 64, 32, 1e-6
+    x = _randn((1, 256, 256, 256, c), 31)
+    gamma = _randn((c,), 32, torch.float32) * 0.1 + 1.0
+    beta = _randn((c,), 33, torch.float32) * 0.1
+    flat = x.reshape(-1, c)
+    s1 = torch.zeros(c, dtype=torch.float64, device=DEV)
+    s2 = torch.zeros(c, dtype=torch.float64, device=DEV)
+    for part in flat.split(1 << 24):
+        v = part.double()
+        s1 += v.sum(0)
+        s2 += (v * v).sum(0)
+    st = ops.channel_stats(x).sum(0)[0]
+    assert torch.allclose(st[:, 0], s1, rtol=1e-9, atol=1e-4) and torch.allclose(st[:, 1], s2, rtol=1e-9, atol=1e-4)
+    scale, shift = ops.gn_scale_shift_composed(x, groups, eps, gamma, beta)
+    cnt = flat.shape[0] * (c // groups)
+    mean = s1.reshape(groups, -1).sum(1) / cnt
+    var = s2.reshape(groups, -1).sum(1) / cnt - mean * mean
+    rstd = 1.0 / torch.sqrt(var + eps)
+    want_scale = (rstd.repeat_interleave(c // groups) * gamma.double()).float()
+    want_shift = (beta.double() - mean.repeat_interleave(c // groups) * rstd.repeat_interleave(c // groups) * gamma.double()).float()
+    assert torch.allclose(scale[0], want_scale, rtol=1e-6, atol=1e-7) and torch.allclose(shift[0], want_shift, rtol=1e-6, atol=1e-7)
+    y = ops.gn_apply(x, scale, shift, "silu")
+    worst = 0.0
+    for xp, yp in zip(flat.split(1 << 24), y.reshape(-1, c).split(1 << 24)):
+        want = torch.nn.functional.silu(xp.float() * scale[0] + shift[0])
+        worst = max(worst, ((yp.float() - want).abs() / want.abs().clamp_min(1e-2)).max().item())
+    assert worst <= 2 ** -7, worst  # one bf16 rounding of the fp32 result (the kernel's SiLU uses v_exp / v_rcp: ~1 ulp fp32)
+    a = ops.gn_apply(x, scale, shift, "silu")
+    assert torch.equal(a, y)
 
 
 def test_c2_forward_bf16_tracks_the_fp32_path_at_full_size():
