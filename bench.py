@@ -111,8 +111,8 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
-        import torch.distributed as dist  # RCCL over xGMI; used only to bracket the timing
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):  # launched by torch.distributed.run (also at N = 1: the
+        import torch.distributed as dist  # RCCL over xGMI; used only to bracket the timing       # RCCL path then runs with one rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -147,7 +147,7 @@ def main() -> None:
         out = inferer.sample(noise, model, sched, verbose=False)
     sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
+    if dist is not None:  # max over ranks
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -251,7 +251,8 @@ def main() -> None:
             "config": {"workload": f"C2: 3D DiffusionModelUNet(64,128,256; 2 res blocks; mid-block attention 1 head x 256) DDIM-{args.inference_steps} "
                                    f"sampling of 1x1x{args.size}^3 volumes, 1 volume per GPU per step",
                        "volumes_per_gpu_per_step": 1, "inference_steps": args.inference_steps,
-                       "parallelism": f"{world} independent replicas (batch-sharded, no data-path collective)", "hip_graph": bool(args.graph)},
+                       "parallelism": f"{world} independent replicas (batch-sharded, no data-path collective)", "hip_graph": bool(args.graph),
+                       "process_group": None if dist is None else f"nccl (RCCL), world_size {world}"},
             "unet_forward_ms": None if fwd_ms is None else round(fwd_ms, 3),
             "ms_per_ddim_iteration": round(1e3 * elapsed / args.steps / args.inference_steps, 3),
             "output_finite": finite,

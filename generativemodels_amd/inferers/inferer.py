@@ -313,8 +313,15 @@ class _Controlled:
     """`diffusion_model(x, timesteps, context)` with the ControlNet evaluated first and its residuals injected -- the body the
     reference repeats in every ControlNet inferer method (inferer.py:610-626, 676-694, 778-793)."""
 
-    def __init__(self, diffusion_model, controlnet, cn_cond) -> None:
-        self.diffusion_model, self.controlnet, self.cn_cond = diffusion_model, controlnet, cn_cond
+    def __init__(self, diffusion_model, controlnet, cn_cond, seg=None) -> None:
+        # a SPADE network takes the segmentation as a forward argument: bound here like the reference's functools.partial (inferer.py:606-608)
+        self.diffusion_model, self.controlnet, self.cn_cond = _bind_seg(diffusion_model, seg), controlnet, cn_cond
+
+    def supports_training(self) -> bool:
+        return False  # the ControlNet path is inference-only here: DiffusionInferer.__call__ then takes the no-grad forward
+
+    def parameters(self):
+        return iter(())
 
     def __call__(self, x, timesteps, context=None):
         down, mid = self.controlnet(x=x, timesteps=timesteps, controlnet_cond=self.cn_cond, context=context)
@@ -332,7 +339,7 @@ class ControlNetDiffusionInferer(DiffusionInferer):
     def __call__(self, inputs: torch.Tensor, diffusion_model: Callable[..., torch.Tensor], controlnet: Callable[..., torch.Tensor],
                  noise: torch.Tensor, timesteps: torch.Tensor, cn_cond: torch.Tensor, condition: torch.Tensor | None = None,
                  mode: str = "crossattn", seg: torch.Tensor | None = None) -> torch.Tensor:
-        return super().__call__(inputs=inputs, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond), noise=noise,
+        return super().__call__(inputs=inputs, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond, seg), noise=noise,
                                 timesteps=timesteps, condition=condition, mode=mode)
 
     @torch.no_grad()
@@ -340,7 +347,7 @@ class ControlNetDiffusionInferer(DiffusionInferer):
                cn_cond: torch.Tensor, scheduler: Callable[..., torch.Tensor] | None = None, save_intermediates: bool | None = False,
                intermediate_steps: int | None = 100, conditioning: torch.Tensor | None = None, mode: str = "crossattn",
                verbose: bool = True, seg: torch.Tensor | None = None):
-        return super().sample(input_noise=input_noise, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond),
+        return super().sample(input_noise=input_noise, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond, seg),
                               scheduler=scheduler, save_intermediates=save_intermediates, intermediate_steps=intermediate_steps,
                               conditioning=conditioning, mode=mode, verbose=verbose)
 
@@ -350,7 +357,7 @@ class ControlNetDiffusionInferer(DiffusionInferer):
                        save_intermediates: bool | None = False, conditioning: torch.Tensor | None = None, mode: str = "crossattn",
                        original_input_range: tuple | None = (0, 255), scaled_input_range: tuple | None = (0, 1), verbose: bool = True,
                        seg: torch.Tensor | None = None, _noise: torch.Tensor | None = None):
-        return super().get_likelihood(inputs=inputs, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond), scheduler=scheduler,
+        return super().get_likelihood(inputs=inputs, diffusion_model=_Controlled(diffusion_model, controlnet, cn_cond, seg), scheduler=scheduler,
                                       save_intermediates=save_intermediates, conditioning=conditioning, mode=mode,
                                       original_input_range=original_input_range, scaled_input_range=scaled_input_range,
                                       verbose=verbose, _noise=_noise)
@@ -371,7 +378,7 @@ class ControlNetLatentDiffusionInferer(LatentDiffusionInferer):
                  controlnet: Callable[..., torch.Tensor], noise: torch.Tensor, timesteps: torch.Tensor, cn_cond: torch.Tensor,
                  condition: torch.Tensor | None = None, mode: str = "crossattn", seg: torch.Tensor | None = None,
                  quantized: bool = True) -> torch.Tensor:
-        model = _Controlled(diffusion_model, controlnet, _resize_like(cn_cond, noise.shape[2:]))  # noise has the latent's shape
+        model = _Controlled(diffusion_model, controlnet, _resize_like(cn_cond, noise.shape[2:]), seg)  # noise has the latent's shape
         return super().__call__(inputs=inputs, autoencoder_model=autoencoder_model, diffusion_model=model, noise=noise,
                                 timesteps=timesteps, condition=condition, mode=mode, quantized=quantized)
 
@@ -381,7 +388,7 @@ class ControlNetLatentDiffusionInferer(LatentDiffusionInferer):
                scheduler: Callable[..., torch.Tensor] | None = None, save_intermediates: bool | None = False,
                intermediate_steps: int | None = 100, conditioning: torch.Tensor | None = None, mode: str = "crossattn",
                verbose: bool = True, seg: torch.Tensor | None = None):
-        model = _Controlled(diffusion_model, controlnet, _resize_like(cn_cond, input_noise.shape[2:]))
+        model = _Controlled(diffusion_model, controlnet, _resize_like(cn_cond, input_noise.shape[2:]), seg)
         return super().sample(input_noise=input_noise, autoencoder_model=autoencoder_model, diffusion_model=model, scheduler=scheduler,
                               save_intermediates=save_intermediates, intermediate_steps=intermediate_steps, conditioning=conditioning,
                               mode=mode, verbose=verbose)
@@ -403,7 +410,7 @@ class ControlNetLatentDiffusionInferer(LatentDiffusionInferer):
                 return super().__call__(x, timesteps, context)
 
         return LatentDiffusionInferer.get_likelihood(inferer, inputs=inputs, autoencoder_model=autoencoder_model,
-                                                     diffusion_model=_Lazy(diffusion_model, controlnet, cn_cond), scheduler=scheduler,
+                                                     diffusion_model=_Lazy(diffusion_model, controlnet, cn_cond, seg), scheduler=scheduler,
                                                      save_intermediates=save_intermediates, conditioning=conditioning, mode=mode,
                                                      original_input_range=original_input_range, scaled_input_range=scaled_input_range,
                                                      verbose=verbose, resample_latent_likelihoods=resample_latent_likelihoods,

@@ -8,7 +8,10 @@ What runs per forward (vs. the reference's ~51 conv + 36 GroupNorm + SiLU/add/ca
     residual epilogue) (+ a 1x1 skip conv when the width changes);
   * Upsample = nearest-2x folded into the following convolution's input indexing; Downsample = strided convolution;
   * attention = GN stats + one stacked q|k|v GEMM + flash attention with the residual in its epilogue.
-The module is inference-only (no autograd through the kernels); dropout is the identity."""
+`forward` in eval mode (or under torch.no_grad) is this inference path; in train() mode with gradients enabled it dispatches to
+`forward_train` (native backward kernels behind torch.autograd.Functions, generativemodels_amd/autograd.py), as the reference's training
+loops call `model(x, timesteps)` directly (tutorials/generative/distributed_training/ddpm_training_ddp.py:249-270).  Dropout
+(`dropout_cattn` > 0) is the identity at inference, like nn.Dropout in eval mode; training with it raises (not implemented)."""
 from __future__ import annotations
 
 import math
@@ -305,6 +308,7 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
         self.num_head_channels = tuple(num_head_channels)
         self.with_conditioning = with_conditioning
         self.num_class_embeds = num_class_embeds
+        self.dropout_cattn = float(dropout_cattn)
         nlev = len(num_channels)
         ted = num_channels[0] * 4
         g, eps = norm_num_groups, norm_eps
@@ -353,8 +357,23 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
     def forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor | None = None,
                 class_labels: torch.Tensor | None = None, down_block_additional_residuals: tuple[torch.Tensor] | None = None,
                 mid_block_additional_residual: torch.Tensor | None = None) -> torch.Tensor:
-        """x: (N, C, *spatial); timesteps: (N,) or (1,); context: (N, L_ctx, cross_attention_dim). Returns (N, C_out, *spatial)."""
+        """x: (N, C, *spatial); timesteps: (N,) or (1,); context: (N, L_ctx, cross_attention_dim). Returns (N, C_out, *spatial).
+        A module in train() mode called with gradients enabled returns a differentiable prediction (forward_train); everything else --
+        eval(), torch.no_grad(), frozen parameters -- runs the fused inference path and returns a tensor without grad_fn."""
+        if self._wants_grad(x):
+            if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+                raise NotImplementedError("DiffusionModelUNet: the training forward does not take ControlNet residuals (inference-only); "
+                                          "call under torch.no_grad() or in eval() mode")
+            return self.forward_train(x, timesteps, context=context, class_labels=class_labels)
         return self._forward_impl(x, timesteps, context, class_labels, down_block_additional_residuals, mid_block_additional_residual)
+
+    def _wants_grad(self, x: torch.Tensor) -> bool:
+        """The reference's forward is differentiable whenever autograd records; here that costs a different (activation-saving) kernel
+        sequence, so it is taken when the caller is evidently training: train() mode (or an input that requires grad), gradients enabled and
+        at least one trainable parameter."""
+        if not torch.is_grad_enabled() or not (self.training or x.requires_grad):
+            return False
+        return self.supports_training() and any(p.requires_grad for p in self.parameters())
 
     def _forward_impl(self, x, timesteps, context, class_labels, down_block_additional_residuals, mid_block_additional_residual,
                       seg: torch.Tensor | None = None) -> torch.Tensor:
@@ -436,6 +455,9 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, context: torc
 
     if self._spade is not None:
         raise NotImplementedError("forward_train: the SPADE variant is inference-only")
+    if self.training and getattr(self, "dropout_cattn", 0.0) > 0.0:
+        raise NotImplementedError("forward_train: dropout_cattn > 0 in train() mode is not implemented (the fused attention / MLP kernels have no "
+                                  "dropout mask); call .eval() to train without dropout, or construct the model with dropout_cattn=0")
     if context is not None and self.with_conditioning is False:
         raise ValueError("model should have with_conditioning = True if context is provided")
     if timesteps.ndim != 1 or timesteps.shape[0] not in (1, x.shape[0]):

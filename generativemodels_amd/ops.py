@@ -32,11 +32,23 @@ def _stream() -> int:
 
 
 def require_device(*ts: Optional[torch.Tensor]) -> None:
+    """Every operand is a HIP tensor on the CURRENT device.  The kernels are enqueued on torch's current stream of the current device
+    (`_stream`); an operand living on another GPU would be read through a stream that is unordered against that GPU's own work -- silent
+    garbage -- so it is refused here instead (`with torch.cuda.device(t.device):` / `torch.cuda.set_device` select the device to run on)."""
+    cur = -1
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 "generativemodels_amd runs on MI355X (HIP) tensors only: got a tensor on "
                 f"'{t.device}'. There is no CPU / eager fallback (move the module and its inputs to 'cuda').")
+        if cur < 0:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(
+                f"generativemodels_amd: operand on '{t.device}' but the current HIP device is cuda:{cur}; kernels run on the current device's "
+                "stream -- wrap the call in `with torch.cuda.device(tensor.device):` (or torch.cuda.set_device) so data and stream agree")
 
 
 # ---- optional per-launch timing (bench.py / profiling only): HIP events on the launch stream around selected kernels --------

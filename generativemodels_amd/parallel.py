@@ -32,14 +32,20 @@ def unit_noise(shape: Sequence[int], base_seed: int, unit: int, dtype=torch.floa
 def sample_units(sample_one: Callable[[torch.Tensor], torch.Tensor], n_units: int, noise_shape: Sequence[int], base_seed: int,
                  rank: int, world_size: int, device=None, dtype=torch.float32) -> Tuple[List[int], List[torch.Tensor]]:
     """Run `sample_one(noise)` (e.g. `lambda z: inferer.sample(z, model, scheduler, verbose=False)`) on this rank's units."""
+    import contextlib
+
     begin, end = shard_range(n_units, rank, world_size)
     ids, outs = [], []
-    for u in range(begin, end):
-        z = unit_noise(noise_shape, base_seed, u, dtype)
-        if device is not None:
-            z = z.to(device)
-        ids.append(u)
-        outs.append(sample_one(z))
+    dev = None if device is None else torch.device(device)
+    # the kernels run on the CURRENT device's stream (ops.require_device): make the rank's device current while it samples
+    ctx = torch.cuda.device(dev) if (dev is not None and dev.type == "cuda") else contextlib.nullcontext()
+    with ctx:
+        for u in range(begin, end):
+            z = unit_noise(noise_shape, base_seed, u, dtype)
+            if dev is not None:
+                z = z.to(dev)
+            ids.append(u)
+            outs.append(sample_one(z))
     return ids, outs
 
 
@@ -73,24 +79,35 @@ class GradientReducer:
     torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; gloo on CPU for the tests).  It replaces what the reference gets
     from torch DistributedDataParallel(find_unused_parameters=True) (tutorials/generative/distributed_training/ddpm_training_ddp.py:199).
 
-    * Buckets of ~`bucket_mb` MB are formed in reverse parameter order (the order gradients become ready in backward).
-    * A bucket is launched as soon as its last gradient has been accumulated (post-accumulate-grad hooks): packed into a flat buffer and
-      all-reduced on a SIDE stream that waits for the producing stream's event, so the exchange overlaps the rest of backward.
-      xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce of the 167 MB of fp32 gradients of the 41.7 M-parameter UNet is
-      ~1.9 ms per-link bound, far below one backward pass -- few, large buckets are the right shape.
-    * Parameters that receive no gradient (the reference's never-applied `proj_attn`) contribute zeros to their bucket
-      and keep `grad = None`, like DDP's unused-parameter handling.
-    * `finish()` (before optimizer.step) waits for the exchanges, divides by the world size and writes the averaged gradients back.
-    With world_size 1 (or torch.distributed uninitialised) every call is a no-op."""
+    * Buckets of ~`bucket_mb` MB in reverse parameter order (the order gradients become ready in backward).  Each bucket owns ONE
+      persistent flat buffer and every parameter's `.grad` is a VIEW into it: autograd accumulates straight into the buffer, nothing is
+      packed or unpacked and nothing is allocated per step (`reducer.zero_grad()` = one memset per bucket).  A `.grad` that was replaced
+      (optimizer.zero_grad(set_to_none=True)) is copied back into its view on arrival and re-pointed.
+    * A bucket is all-reduced as soon as its last EXPECTED gradient has arrived (post-accumulate-grad hooks), in bucket order (the same
+      collective sequence on every rank), on a SIDE stream that waits for the producing stream's event: the exchange overlaps the rest of
+      backward.  xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce of the 167 MB of fp32 gradients of the 41.7 M-parameter
+      UNet is ~1.9 ms per-link bound, far below one backward pass -- few, large buckets are the right shape.
+    * Unused parameters (the reference's never-applied `proj_attn`, SURVEY.md fact 4 -- the reason the tutorial needs
+      find_unused_parameters): the set of parameters that received a gradient on ANY rank is learned on the first step (one small MAX
+      all-reduce of a usage mask per step, inside `finish`) and only those are waited for afterwards, so from the second step on every
+      bucket launches during backward.  A parameter that produces its first gradient later joins the set through a one-off exchange of
+      its own gradient.  Never-used parameters keep `grad = None`, like DDP.
+    * `finish()` (before optimizer.step) launches what is left, waits, averages and makes every globally-used parameter's `.grad` the
+      averaged view on EVERY rank (also where the local gradient was None), so replicas never diverge.
+    * Gradient accumulation: run the extra backward passes under `with reducer.no_sync():`; a second backward outside it raises.
+    With world_size 1 (or torch.distributed uninitialised) every call is a no-op unless `force=True` (single-rank exercise of the whole
+    path: the `-m gpu` test runs it on backend nccl = RCCL with one rank)."""
 
-    def __init__(self, params, bucket_mb: float = 25.0, group=None) -> None:
+    def __init__(self, params, bucket_mb: float = 25.0, group=None, force: bool = False) -> None:
         import torch.distributed as dist
 
         self._dist = dist
         self.group = group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        self.world = dist.get_world_size(group) if self.active else 1
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        self.active = ready and (self.world > 1 or force)
         self.params = [p for p in params if p.requires_grad]
+        self._index = {id(p): i for i, p in enumerate(self.params)}
         self.buckets: List[List[torch.nn.Parameter]] = []
         cap = int(bucket_mb * (1 << 20))
         cur, cur_bytes, cur_key = [], 0, None
@@ -106,67 +123,162 @@ class GradientReducer:
         if cur:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
-        self._pending = [0] * len(self.buckets)
-        self._launched: List[Optional[tuple]] = [None] * len(self.buckets)
+        self._flat: List[torch.Tensor] = []
+        self._view = {}
         self._side = None
-        self._handles = []
+        self._sync = True
+        self.launched_in_backward = 0  # diagnostics: buckets whose exchange started from a hook (overlapped) in the last step
         if self.active:
+            for b in self.buckets:
+                flat = torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype, device=b[0].device)
+                self._flat.append(flat)
+                off = 0
+                for p in b:
+                    self._view[id(p)] = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+        # parameters waited for before a bucket launches: all of them until the first step has shown which ones ever get a gradient
+        self._expected = [True] * len(self.params)
+        self._learned = False
         self.reset()
 
+    # ---- per-step state -----------------------------------------------------------------------------------------------------
     def reset(self) -> None:
-        """Call before every backward pass (done by `finish`)."""
-        self._pending = [len(b) for b in self.buckets]
-        self._launched = [None] * len(self.buckets)
+        """Re-arm for the next backward pass (done by `finish`)."""
+        self._pending = [sum(1 for p in b if self._expected[self._index[id(p)]]) for b in self.buckets]
+        self._seen = [False] * len(self.params)
+        self._work: List[Optional[object]] = [None] * len(self.buckets)
+        self._next = 0
+        self._late = {}
+        self._in_backward_launches = 0
+
+    def zero_grad(self) -> None:
+        """Zero every gradient with one fill per bucket and keep `.grad` pointing into the buckets (the cheap path; an optimizer's
+        zero_grad(set_to_none=True) also works -- the next gradient is then copied back into its view)."""
+        if not self.active:
+            for p in self.params:
+                p.grad = None
+            return
+        for flat in self._flat:
+            flat.zero_()
+
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it only accumulate locally (like DDP.no_sync)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            keep, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = keep
+        return ctx()
+
+    # ---- hooks --------------------------------------------------------------------------------------------------------------
+    def _side_ctx(self, dev):
+        import contextlib
+
+        if dev.type != "cuda":
+            return contextlib.nullcontext()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        self._side.wait_event(torch.cuda.current_stream(dev).record_event())
+        return torch.cuda.stream(self._side)
+
+    def _adopt(self, p) -> None:
+        """Make p.grad the bucket view (copying a gradient tensor autograd allocated itself into it first)."""
+        view = self._view[id(p)]
+        g = p.grad
+        if g is None or g.data_ptr() == view.data_ptr():
+            return
+        with torch.no_grad():
+            view.copy_(g)
+        p.grad = view
 
     def _on_grad(self, p) -> None:
+        j = self._index[id(p)]
+        if not self._expected[j]:
+            # first gradient of a parameter that had none so far: it is not part of its bucket's exchange this step (the bucket may be
+            # in flight already); finish() exchanges it on its own once every rank knows, and it is expected from then on
+            self._late[j] = p.grad
+            p.grad = None
+            self._seen[j] = True
+            return
+        self._adopt(p)
+        if not self._sync:
+            return
         i = self._bucket_of[id(p)]
+        if self._seen[j] or self._work[i] is not None:
+            raise RuntimeError("GradientReducer: a second backward pass reached a parameter before finish(); accumulate gradients under "
+                               "`with reducer.no_sync():` and run only the last backward outside it")
+        self._seen[j] = True
         self._pending[i] -= 1
-        if self._pending[i] == 0:
-            self._launch(i)
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:  # in bucket order: the same sequence on every rank
+            self._launch(self._next)
+            self._in_backward_launches += 1
+            self._next += 1
 
     def _launch(self, i: int) -> None:
-        bucket = self.buckets[i]
-        dev = bucket[0].device
-        flat = torch.zeros(sum(p.numel() for p in bucket), dtype=bucket[0].dtype, device=dev)
-        if dev.type == "cuda":
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-            ready = torch.cuda.current_stream(dev).record_event()
-            self._side.wait_event(ready)
-            ctx = torch.cuda.stream(self._side)
-        else:
-            import contextlib
-            ctx = contextlib.nullcontext()
-        with ctx:
-            off = 0
-            for p in bucket:
-                if p.grad is not None:
-                    flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
-                    if dev.type == "cuda":
-                        p.grad.record_stream(self._side)
-                off += p.numel()
-            work = self._dist.all_reduce(flat, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._launched[i] = (flat, work)
+        flat = self._flat[i]
+        with self._side_ctx(flat.device):
+            self._work[i] = self._dist.all_reduce(flat, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    # ---- join ---------------------------------------------------------------------------------------------------------------
     def finish(self) -> None:
-        """Wait for every exchange, average, write the gradients back; launches the buckets whose parameters never all became ready."""
+        """Launch the buckets that did not complete during backward, wait for every exchange, average, and leave the averaged gradient in
+        `.grad` of every parameter that is used on any rank."""
         if not self.active:
             return
-        for i in range(len(self.buckets)):
-            if self._launched[i] is None:
-                self._launch(i)
-        for i, bucket in enumerate(self.buckets):
-            flat, work = self._launched[i]
-            work.wait()  # on CUDA: makes the current stream wait for the collective
-            dev = bucket[0].device
-            if dev.type == "cuda":
-                torch.cuda.current_stream(dev).wait_stream(self._side)
+        if not self._sync:
+            raise RuntimeError("GradientReducer.finish() inside no_sync()")
+        dist = self._dist
+        # gradients that arrived under no_sync (or replaced views) are adopted now; stale regions of expected parameters that produced
+        # nothing this step (and whose .grad the optimizer set to None) are cleared so they contribute zeros
+        for j, p in enumerate(self.params):
+            if not self._expected[j]:
+                continue
+            if p.grad is None:
+                if not self._seen[j]:
+                    self._view[id(p)].zero_()
+            else:
+                self._adopt(p)
+                self._seen[j] = True
+        while self._next < len(self.buckets):
+            self._launch(self._next)
+            self._next += 1
+        # usage mask: which parameters got a gradient on ANY rank this step (DDP's unused-parameter bitmap)
+        dev = self._flat[0].device if self._flat else torch.device("cpu")
+        mask = torch.tensor([1 if s else 0 for s in self._seen], dtype=torch.int32, device=dev)
+        with self._side_ctx(dev):
+            mwork = dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        for i, flat in enumerate(self._flat):
+            self._work[i].wait()  # on CUDA: the current stream waits for the collective
+        mwork.wait()
+        if self._side is not None:
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+        used = [bool(v) for v in mask.cpu().tolist()]
+        if not self._learned:  # first step: from now on only parameters that ever produced a gradient (on any rank) are waited for
+            self._expected = list(used)
+        for flat in self._flat:
             flat.div_(self.world)
-            off = 0
-            for p in bucket:
-                if p.grad is not None:
-                    p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
-                off += p.numel()
+        # parameters whose FIRST gradient arrived this step (on some rank): one exchange each, in index order on every rank
+        for j, p in enumerate(self.params):
+            if used[j] and not self._expected[j]:
+                view = self._view[id(p)]
+                g = self._late.get(j)
+                with torch.no_grad():
+                    if g is None:
+                        view.zero_()
+                    else:
+                        view.copy_(g)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                view.div_(self.world)
+                self._expected[j] = True
+        for j, p in enumerate(self.params):
+            if self._expected[j] and (used[j] or p.grad is not None):
+                p.grad = self._view[id(p)]  # also where this rank had no gradient: replicas apply the same update
+        self._learned = True
+        self.launched_in_backward = self._in_backward_launches
         self.reset()

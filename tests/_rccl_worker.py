@@ -1,0 +1,76 @@
+"""Worker of tests/test_gpu_distributed.py, launched by `python -m torch.distributed.run --nproc-per-node 1`: GradientReducer on backend
+"nccl" (= RCCL on ROCm) with ONE rank and force=True -- every line of the multi-GPU training path (persistent flat buckets, hook-driven
+bucket launches on the side HIP stream, the usage-mask exchange, finish) executes on the GPU; with one rank the averaged gradients must
+equal the plain single-process gradients bit for bit (reference: ddpm_training_ddp.py:125,199,249-270)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+
+
+def main():
+    import restatement as R
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    from generativemodels_amd.networks.schedulers import DDPMScheduler
+    from generativemodels_amd.parallel import GradientReducer
+
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+    cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 64), attention_levels=(False, True),
+               num_head_channels=32, norm_num_groups=32)
+
+    def build():
+        torch.manual_seed(11)
+        m = DiffusionModelUNet(**cfg)
+        R.derandomize_zeros(m, seed=5)
+        return m.to(dev).train()
+
+    plain, sharded = build(), build()
+    red = GradientReducer(sharded.parameters(), bucket_mb=0.25, force=True)  # ~0.25 MB buckets: several exchanges per backward
+    assert red.active and red.world == 1 and len(red.buckets) >= 3
+    inferer = DiffusionInferer(DDPMScheduler(1000))
+    g = torch.Generator().manual_seed(3)
+    overlapped = []
+    for step in range(3):
+        x = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+        noise = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+        t = torch.randint(0, 1000, (2,), generator=g).to(dev)
+        for m in (plain, sharded):
+            for p in m.parameters():
+                p.grad = None
+        if step == 2:
+            red.zero_grad()  # the in-place path: .grad stays a view of the flat bucket
+        for m in (plain, sharded):
+            pred = inferer(inputs=x, diffusion_model=m, noise=noise, timesteps=t)
+            assert pred.requires_grad
+            F.mse_loss(pred.float(), noise.float()).backward()
+        red.finish()
+        torch.cuda.synchronize()
+        overlapped.append(red.launched_in_backward)
+        checked = 0
+        for (name, a), b in zip(plain.named_parameters(), sharded.parameters()):
+            if a.grad is None:
+                assert b.grad is None and "proj_attn" in name, name
+                continue
+            assert b.grad is not None and torch.equal(a.grad, b.grad), f"step {step}: gradient of {name} differs after the RCCL exchange"
+            assert b.grad.data_ptr() == red._view[id(b)].data_ptr()  # the gradient lives in its bucket
+            checked += 1
+        assert checked > 40
+    assert red._side is not None, "the exchange did not run on a side HIP stream"
+    assert overlapped[0] < len(red.buckets) and overlapped[1] == len(red.buckets) == overlapped[2], (overlapped, len(red.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"RCCL_WORKER_OK buckets={len(red.buckets)} overlapped_per_step={overlapped}")
+
+
+if __name__ == "__main__":
+    main()

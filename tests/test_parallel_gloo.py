@@ -79,26 +79,62 @@ def _reducer_worker(rank, world, port, q):
         torch.manual_seed(3)
         model = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 3))
         unused = nn.Linear(4, 4)  # never applied: like the reference's proj_attn it gets no gradient
-        params = list(model.parameters()) + list(unused.parameters())
+        late = nn.Linear(3, 3)    # applied from the third step on only: joins the exchange when its first gradient appears
+        side = nn.Linear(3, 3)    # applied on rank 0 only: every rank must still end up with the same averaged gradient
+        params = list(model.parameters()) + list(unused.parameters()) + list(late.parameters()) + list(side.parameters())
         red = GradientReducer(params, bucket_mb=0.0005)  # ~500-byte buckets: several exchanges per step
         assert red.active and len(red.buckets) >= 3
         data = torch.randn(8, 6, generator=torch.Generator().manual_seed(5))
         target = torch.randn(8, 3, generator=torch.Generator().manual_seed(6))
         lo, hi = shard_range(8, rank, world)
-        for _ in range(2):  # two steps: the reducer re-arms itself
-            for p in params:
-                p.grad = None
-            loss = torch.nn.functional.mse_loss(model(data[lo:hi]), target[lo:hi])
-            loss.backward()
+        overlapped = []
+
+        def loss_of(step, rows):
+            y = model(data[rows])
+            if step >= 2:
+                y = late(y)
+            if rank == 0 and step >= 4:
+                y = y + 0.5 * side(y.detach())
+            return torch.nn.functional.mse_loss(y, target[rows])
+
+        for step in range(6):  # the reducer re-arms itself; step 0 learns the used set, steps 1+ overlap every bucket
+            if step % 2 == 0:
+                red.zero_grad()  # in-place fill: .grad stays a bucket view
+            else:
+                for p in params:
+                    p.grad = None  # optimizer.zero_grad(set_to_none=True): the next gradients are adopted back into the views
+            loss_of(step, slice(lo, hi)).backward()
             red.finish()
-        q.put((rank, [None if p.grad is None else p.grad.clone() for p in params]))
+            overlapped.append(red.launched_in_backward)
+        grads = [None if p.grad is None else p.grad.detach().numpy().copy() for p in params]  # numpy: no shared-memory handles in the queue
+        # gradient accumulation: two micro-batches, the first under no_sync, equals one backward over both
+        mid = (lo + hi) // 2
+        red.zero_grad()
+        with red.no_sync():
+            (0.5 * loss_of(5, slice(lo, mid))).backward()
+        (0.5 * loss_of(5, slice(mid, hi))).backward()
+        red.finish()
+        acc = [None if p.grad is None else p.grad.detach().numpy().copy() for p in params]
+        # a second backward outside no_sync is refused
+        red.zero_grad()
+        loss_of(5, slice(lo, hi)).backward()
+        try:
+            loss_of(5, slice(lo, hi)).backward()
+            refused = False
+        except RuntimeError:
+            refused = True
+        red.finish()
+        q.put((rank, grads, acc, overlapped, len(red.buckets), refused))
     finally:
         dist.destroy_process_group()
 
 
 def test_two_rank_gradient_all_reduce_matches_the_full_batch():
-    """GradientReducer (bucketed, hook-driven all-reduce + averaging) over gloo, world_size 2: the averaged shard gradients equal the
-    single-process gradients of the full batch; a parameter without a gradient stays None."""
+    """GradientReducer over gloo, world_size 2: gradients live in persistent flat buckets, buckets are exchanged from the grad-ready
+    hooks in bucket order; the averaged shard gradients equal the single-process gradients of the full batch; a never-used parameter
+    keeps grad = None and -- once the used set is learned on the first step -- stops delaying its bucket (every bucket overlaps from
+    step 2); a parameter used on one rank only ends with the same averaged gradient on both; a parameter whose first gradient shows up
+    later joins; gradient accumulation under no_sync matches; a second backward outside no_sync raises."""
     import torch.multiprocessing as mp
     import torch.nn as nn
     ctx = mp.get_context("spawn")
@@ -107,18 +143,33 @@ def test_two_rank_gradient_all_reduce_matches_the_full_batch():
     procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=120) for _ in range(2))
+    got = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     torch.manual_seed(3)
     model = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 3))
+    unused, late, side = nn.Linear(4, 4), nn.Linear(3, 3), nn.Linear(3, 3)
     data = torch.randn(8, 6, generator=torch.Generator().manual_seed(5))
     target = torch.randn(8, 3, generator=torch.Generator().manual_seed(6))
-    torch.nn.functional.mse_loss(model(data), target).backward()
-    want = [p.grad for p in model.parameters()]
+    # single-process equivalent of the average over the two ranks' shard losses (rank 0 alone carries the `side` term)
+    y0, y1 = late(model(data[0:4])), late(model(data[4:8]))
+    l0 = torch.nn.functional.mse_loss(y0 + 0.5 * side(y0.detach()), target[0:4])
+    l1 = torch.nn.functional.mse_loss(y1, target[4:8])
+    (0.5 * (l0 + l1)).backward()
+    want = [p.grad for p in list(model.parameters())] + [None, None] + [p.grad for p in list(late.parameters()) + list(side.parameters())]
     for rank in (0, 1):
-        grads = got[rank]
-        assert grads[-1] is None and grads[-2] is None
-        for g, w in zip(grads[:len(want)], want):
-            assert torch.allclose(g, w, atol=1e-6), (g - w).abs().max()
+        grads, acc, overlapped, nbuckets, refused = got[rank]
+        assert refused
+        assert overlapped[0] < nbuckets              # step 0: the never-used parameters hold their buckets back until finish()
+        assert overlapped[1] == nbuckets             # step 1: used set learned -> every bucket is exchanged during backward
+        assert overlapped[3] == nbuckets             # step 3: `late` joined at step 2, everything overlaps again
+        # steps 4-5: `side` is applied on rank 0 only -- rank 1 cannot complete that bucket during backward (nothing arrives), the
+        # exchange still happens in finish() and both ranks hold the same averaged gradient (checked below)
+        for got_list in (grads, acc):
+            assert got_list[len(list(model.parameters()))] is None and got_list[len(list(model.parameters())) + 1] is None
+            for g, w in zip(got_list, want):
+                if w is None:
+                    assert g is None
+                else:
+                    assert g is not None and torch.allclose(torch.from_numpy(g), w, atol=1e-6), (torch.from_numpy(g) - w).abs().max()
