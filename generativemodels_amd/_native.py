@@ -37,7 +37,8 @@ class GmConvDesc(C.Structure):
                 ("in_mode", C.c_int), ("fd", C.c_int), ("fh", C.c_int), ("fw", C.c_int),
                 ("pre_act", C.c_int), ("post_act", C.c_int), ("dtype", C.c_int),
                 ("ltd", C.c_int), ("lth", C.c_int), ("ltw", C.c_int), ("cfg", C.c_int), ("debug_flags", C.c_int), ("stats", c_vp),
-                ("skip_x", c_vp * 2), ("skip_ld", c_ll * 2), ("skip_cin", C.c_int * 2), ("skip_w", c_vp), ("skip_bias", c_vp)]
+                ("skip_x", c_vp * 2), ("skip_ld", c_ll * 2), ("skip_cin", C.c_int * 2), ("skip_w", c_vp), ("skip_bias", c_vp),
+                ("x2", c_vp), ("x2_ld", c_ll), ("cin_split", C.c_int)]
 
 
 class GmDecodeBlock(C.Structure):

@@ -353,7 +353,7 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
-  if (d && d->skip_x[0] && !conv_is_dma(d->cfg)) return -1;  // the fused 1x1 shortcut exists in the LDS-DMA kernel only
+  if (d && (d->skip_x[0] || d->x2) && !conv_is_dma(d->cfg)) return -1;  // the fused 1x1 shortcut / second source exist in the LDS-DMA kernels only
   if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes(gm_conv_dma_variant(d->cfg)) : -1;
   if (d && d->cfg == CONV_CFG_CIN) return gm_conv_cin_eligible(d) ? gm_conv_cin_lds_bytes(d) : -1;
   if (d && d->cfg == CONV_CFG_COUT1) return gm_conv_cout1_eligible(d) ? gm_conv_cout1_lds_bytes() : -1;
@@ -407,6 +407,7 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(!fast || conv_fast_eligible(d), "geometry is not eligible for the fast stride-1 kernel");
   GM_REQUIRE(!dma || gm_conv_dma_eligible(dp), "geometry is not eligible for the LDS-DMA 3x3x3 kernel");
   GM_REQUIRE(dma || d.skip_x[0] == nullptr, "the fused 1x1 shortcut needs the LDS-DMA kernel (cfg 11)");
+  GM_REQUIRE(dma || d.x2 == nullptr, "a second input source (virtual channel concatenation) needs an LDS-DMA configuration");
   GM_REQUIRE(!edge || (d.cfg == CONV_CFG_CIN ? gm_conv_cin_eligible(dp) : gm_conv_cout1_eligible(dp)),
              "geometry is not eligible for the C_in<=4 / C_out==1 kernels");
   const long long smem = gm_conv_lds_bytes(dp);

@@ -35,6 +35,9 @@ struct GmConvDesc {
   const void* skip_x[2]; long long skip_ld[2]; int skip_cin[2];
   const void* skip_w;             // gm_pack_conv_weight of the [Cout][skip_cin[0] + skip_cin[1]] 1x1 kernel
   const float* skip_bias;         // [Cout] or null
+  // optional second input source (LDS-DMA kernels only): the input is the channel concatenation cat(x[..., :cin_split], x2) of two
+  // tensors in the same geometry -- torch.cat([h, skip], dim=1) of the decoder blocks, never materialised.  cin_split % BK == 0.
+  const void* x2; long long x2_ld; int cin_split;
 };
 
 // slot count of the zero-initialised, atomically accumulated statistic tables the BACKWARD kernels still use ([GM_STAT_SLOTS][N][C][2];

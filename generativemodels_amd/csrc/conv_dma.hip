@@ -50,7 +50,9 @@ __device__ __forceinline__ void dma_wait() {
 // padding (1 - parity per axis) and the output sub-lattice the tile is written to.
 // NFR_ = 16-channel output fragments per wave: 4 (BN = 64 output channels per work-group) or 8 (BN = 128: one staged patch feeds
 // twice the output channels -- half the patch traffic per multiply-add, 0.375 instead of 0.5 LDS operand reads per MFMA at MF = 4).
-template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR_ = 4>
+// PRE: the instantiation that applies the fused GroupNorm-apply + activation prologue in LDS (a separate instantiation so that the plain
+// kernel's register allocation -- 128 VGPRs = four waves per SIMD for cfg 11 -- is not disturbed by code it never runs).
+template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR_ = 4, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
@@ -127,20 +129,64 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     pvox[j] = ok ? ((n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
   }
   const long long xrowb = p.x_ld * (long long)sizeof(T);
+  // optional second source: input channels [cin_split, Cin) come from x2 (the never-materialised torch.cat([h, skip]) of the decoder)
+  const char* x2base = reinterpret_cast<const char*>(p.x2);
+  const long long x2rowb = p.x2_ld * (long long)sizeof(T);
+  const int nchunks0 = p.x2 ? p.cin_split / BK : nchunks;
   // (Staging the patch through registers instead -- all loads of a lane in flight, then ds_write_b128 -- was measured 5-7 % slower.)
   auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
 #ifdef GM_CONV_ABLATE
     if (p.debug_flags & 1024) return;  // bench-only: no patch traffic (results are garbage)
 #endif
-    const char* cbase = xbase + (long long)chunk * (BK * (int)sizeof(T)) + pswz;
+    const bool second = chunk >= nchunks0;  // wave-uniform
+    const char* cbase = (second ? x2base + (long long)(chunk - nchunks0) * (BK * (int)sizeof(T)) : xbase + (long long)chunk * (BK * (int)sizeof(T))) + pswz;
+    const long long rowb = second ? x2rowb : xrowb;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       if (wave + NW * j < PPIECES) {  // wave-uniform
-        const char* src = pvox[j] >= 0 ? cbase + pvox[j] * xrowb : zero + ((lane & 3) << 4);
+        const char* src = pvox[j] >= 0 ? cbase + pvox[j] * rowb : zero + ((lane & 3) << 4);
         dma16(src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
       }
     }
   };
+  // ---- fused GroupNorm-apply + activation prologue (pre_scale / pre_shift / pre_act), applied IN LDS to the landed patch ---------------
+  // Each lane transforms exactly the 16-byte pieces it DMA'd itself (piece j, row 16 * (wave + NW * j) + lane / 4, LDS slot lane & 3 =
+  // channel slot cs of the chunk): act(x * scale[n][c] + shift[n][c]) in fp32, rounded back to T -- the same arithmetic and rounding as
+  // gm_gn_apply, so the fused and the two-pass forms are bit-identical.  Rows that came from the zero page stay zero: the reference pads
+  // the ACTIVATED tensor (conv(silu(gn(x))), diffusion_model_unet.py:671-684).  Needs no barrier of its own: a wave's own DMA pieces are
+  // complete after its vmcnt(0), and the barrier that follows publishes the transformed rows.  Each halo row is transformed once per
+  // work-group that stages it (2.1x redundant at the 512-voxel tile) on the VALU -- against a whole extra read + write pass over HBM.
+  constexpr bool pre = PRE;
+  float sc[VECW], sh[VECW];  // this lane's scale / shift for the chunk being staged: loaded next to the patch DMA, consumed after its wait
+  auto load_affine = [&](int chunk) __attribute__((always_inline)) {
+    const int c0 = chunk * BK + (pswz >> 4) * VECW;  // this lane's channels within cat(x, x2): the same slot for every piece
+    const float* ps = p.pre_scale + (long long)n * p.Cin + c0;
+    const float* ph = p.pre_shift + (long long)n * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < VECW; i += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(ps + i), b = *reinterpret_cast<const float4*>(ph + i);
+      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+      sh[i] = b.x; sh[i + 1] = b.y; sh[i + 2] = b.z; sh[i + 3] = b.w;
+    }
+  };
+  auto transform_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (wave + NW * j < PPIECES && pvox[j] >= 0) {
+        char* a = smem + (16 * (wave + NW * j) + (lane >> 2)) * DMA_ROWB + ((lane & 3) << 4);
+        float v[VECW];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a), v);
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) {
+          const float t = v[i] * sc[i] + sh[i];
+          v[i] = p.pre_act == 1 ? (sizeof(T) == 4 ? gm_silu_precise(t) : gm_silu(t)) : (p.pre_act == 2 ? fmaxf(t, 0.f) : t);
+        }
+        *reinterpret_cast<uint4*>(a) = Vec16<T>::pack(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stores are in LDS before the barrier that follows
+  };
+
   // weight panel of global tap group t (chunk = t / 9, taps 3*(t%9) ..): rows r = u*64 + co_local.  Wave w moves rows
   // 16w .. 16w+15 (full piece) and rows 128 + 8w .. +7 (half piece, lanes 0..31).
   const char* wbase = reinterpret_cast<const char*>(p.w) + (long long)par * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;  // parity image
@@ -215,7 +261,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   issue_patch(0);
   issue_w(0, 0);
   if (total > 1) issue_w(1, 1);
+  if (pre) load_affine(0);
   dma_wait<0>();
+  if (pre) transform_patch();
   __builtin_amdgcn_s_barrier();
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -266,7 +314,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
           issue_patch(chunk + 1);
+          if (pre) load_affine(chunk + 1);
           dma_wait<0>();                 // patch + the two panels in flight
+          if (pre) transform_patch();
           __builtin_amdgcn_s_barrier();
         }
       } else {
@@ -414,7 +464,7 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   if (d->cfg == 17) {  // sub-pixel up-sampling convolution: 8 parity images of a 2x2x2 kernel, output = 2x the input grid
     return d->in_mode == 3 && d->kd == 2 && d->kh == 2 && d->kw == 2 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->dd == 1 && d->dh == 1 &&
            d->dw == 1 && d->Do == 2 * d->Ds && d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
-           (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->ltd == 2 && d->lth == 2 &&
+           (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 && d->x2 == nullptr && d->ltd == 2 && d->lth == 2 &&
            d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
            (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) && !d->skip_x[0] &&
            (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31);
@@ -422,7 +472,14 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   if (d->in_mode == 3) return 0;
   return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == s && d->sh == s && d->sw == s && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
          (d->in_mode == 0 || (d->in_mode == 1 && s == 1)) && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
-         (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->pre_scale == nullptr && d->pre_act == 0 &&
+         (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 &&
+         // fused GroupNorm-apply + SiLU / ReLU prologue: applied in LDS by the stride-1 variants (scale and shift together, fp32 [N][Cin])
+         ((d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_act == 0) ||
+          (s == 1 && d->pre_scale != nullptr && d->pre_shift != nullptr && (reinterpret_cast<uintptr_t>(d->pre_scale) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(d->pre_shift) & 15) == 0 && (d->Cin % 4) == 0)) &&
+         // second input source (virtual channel concatenation): same geometry, chunk-aligned split
+         (d->x2 == nullptr || (d->cin_split > 0 && d->cin_split < d->Cin && d->cin_split % bk == 0 && d->x2_ld % vecw == 0 &&
+                               (reinterpret_cast<uintptr_t>(d->x2) & 15) == 0)) &&
          d->ltd == (d->cfg == 16 || d->cfg == 18 || d->cfg == 19 ? 3 : (s == 1 ? 2 : 1)) && d->lth == 2 &&
          d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
          (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) &&
@@ -434,10 +491,10 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
                               (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
 }
 
-template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR = 4>
+template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR = 4, bool PRE = false>
 static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_dma_kernel<T, NW, MF, S, MINW, KS, NFR>;
+  auto kern = conv_dma_kernel<T, NW, MF, S, MINW, KS, NFR, PRE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
@@ -448,13 +505,14 @@ static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
 
 template <typename T>
 static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
-  if (d.cfg == 19) launch_dma<T, 8, 4, 1, 2, 3, 8>(d, nblocks, st);  // 512 voxels x 128 channels: 8 waves x (64 voxels x 128 channels), one work-group per CU
-  else if (d.cfg == 18) launch_dma<T, 8, 4, 1, 2>(d, nblocks, st);   // 512 voxels x 64 channels: 8 waves x (64 voxels x 64 channels), one work-group per CU
+  const bool pre = d.pre_scale != nullptr;  // eligibility (gm_conv_dma_eligible) admits a prologue for the stride-1 3x3x3 variants only
+  if (d.cfg == 19) { if (pre) launch_dma<T, 8, 4, 1, 2, 3, 8, true>(d, nblocks, st); else launch_dma<T, 8, 4, 1, 2, 3, 8>(d, nblocks, st); }  // 512 voxels x 128 channels
+  else if (d.cfg == 18) { if (pre) launch_dma<T, 8, 4, 1, 2, 3, 4, true>(d, nblocks, st); else launch_dma<T, 8, 4, 1, 2>(d, nblocks, st); }  // 512 voxels x 64 channels, 8 waves x 64 voxels
   else if (d.cfg == 17) launch_dma<T, 8, 2, 1, 4, 2>(d, nblocks, st);  // sub-pixel 2x2x2 kernels of an up-sampling convolution
-  else if (d.cfg == 16) launch_dma<T, 16, 2, 1, 4>(d, nblocks, st);  // 512 voxels (8x4x16), 16 waves, one work-group per CU
+  else if (d.cfg == 16) { if (pre) launch_dma<T, 16, 2, 1, 4, 3, 4, true>(d, nblocks, st); else launch_dma<T, 16, 2, 1, 4>(d, nblocks, st); }  // 512 voxels (8x4x16), 16 waves
   else if (d.cfg == 15) launch_dma<T, 8, 1, 2, 2>(d, nblocks, st);   // stride 2: 8 waves x 16 voxels, one work-group per CU
-  else if (d.cfg == 14) launch_dma<T, 4, 4, 1, 2>(d, nblocks, st);   // 4 waves x 64 voxels
-  else launch_dma<T, 8, 2, 1, 4>(d, nblocks, st);                    // cfg 11: 8 waves x 32 voxels, two work-groups per CU
+  else if (d.cfg == 14) { if (pre) launch_dma<T, 4, 4, 1, 2, 3, 4, true>(d, nblocks, st); else launch_dma<T, 4, 4, 1, 2>(d, nblocks, st); }  // 4 waves x 64 voxels
+  else { if (pre) launch_dma<T, 8, 2, 1, 4, 3, 4, true>(d, nblocks, st); else launch_dma<T, 8, 2, 1, 4>(d, nblocks, st); }  // cfg 11: 8 waves x 32 voxels, two work-groups per CU
 }
 
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {

@@ -132,9 +132,10 @@ class ResnetBlock(nn.Module):
     """GN -> SiLU -> conv3 (+ timestep row) -> GN -> SiLU -> conv3 -> + skip(x).
 
     Covers the UNet block (reference diffusion_model_unet.py:589-696; `temb_channels` given) and the AutoencoderKL block
-    (autoencoderkl.py:125-193; no timestep path, shortcut named `nin_shortcut`).  Two fused conv launches (GroupNorm statistics
-    in their epilogues, the 1x1 shortcut inside the second one) + at most two GroupNorm-apply passes replace the reference's
-    2 GN + 2 SiLU + 2-3 conv + 2 add launches."""
+    (autoencoderkl.py:125-193; no timestep path, shortcut named `nin_shortcut`).  Two fused conv launches -- GroupNorm-apply + SiLU in
+    their prologues (applied in LDS to the staged patch), bias / timestep row / residual and the NEXT GroupNorm's statistics in their
+    epilogues, the 1x1 shortcut inside the second one -- plus two microsecond statistic folds replace the reference's 2 GN + 2 SiLU +
+    2-3 conv + 2 add launches: the "fused 3-D ResnetBlock kernel pair" of SURVEY.md 8(a) a5."""
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: Optional[int] = None, temb_channels: Optional[int] = None,
                  norm_num_groups: int = 32, norm_eps: float = 1e-6, up: bool = False, down: bool = False,
@@ -171,19 +172,10 @@ class ResnetBlock(nn.Module):
             x = ops.resample2x(x, mode)
             h = ops.resample2x(h, mode)
             h = self.conv1.run(h, rowvec=temb_row, want_stats=True)
-        elif cat:
-            # the activated operand of conv1 is assembled by one GroupNorm-apply pass per part, straight into channel slices
-            xa = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-            off = 0
-            for part in x.parts:
-                c = part.shape[-1]
-                ops.gn_apply(part, pre1[0][:, off:off + c], pre1[1][:, off:off + c], "silu", out=xa[..., off:off + c])
-                off += c
-            h = self.conv1.run(xa, rowvec=temb_row, want_stats=True)
-        elif ops.fuse_gn_prologue(x):
-            h = self.conv1.run(x, pre=pre1, pre_act="silu", rowvec=temb_row, want_stats=True)
         else:
-            h = self.conv1.run(ops.gn_apply(x, pre1[0], pre1[1], "silu"), rowvec=temb_row, want_stats=True)
+            # GroupNorm-apply + SiLU ride in conv1's prologue; ops.conv places them: in LDS inside the LDS-DMA kernel (which also reads the
+            # two halves of a virtual concat in place), in the register-staged kernels' patch staging, or as one gm_gn_apply pass per part
+            h = self.conv1.run(x, pre=pre1, pre_act="silu", rowvec=temb_row, want_stats=True)
         pre2 = gn_prologue(self.norm2, h)
         shortcut = getattr(self, self.shortcut_name)
         fusion = dict(want_stats=True)
@@ -192,9 +184,7 @@ class ResnetBlock(nn.Module):
         else:
             # the 1x1 shortcut over x -- or over the two halves of the virtual concat -- rides along in conv2 as extra K chunks
             fusion["skip"] = (list(x.parts) if cat else [x], shortcut.conv.weight, shortcut.conv.bias)
-        if ops.fuse_gn_prologue(h):
-            return self.conv2.run(h, pre=pre2, pre_act="silu", **fusion)
-        return self.conv2.run(ops.gn_apply(h, pre2[0], pre2[1], "silu"), **fusion)
+        return self.conv2.run(h, pre=pre2, pre_act="silu", **fusion)
 
     def run_train(self, x: torch.Tensor, temb: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The same block with gradients: x an arena tensor, temb the [N, temb_channels] timestep embedding.

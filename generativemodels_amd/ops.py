@@ -503,6 +503,12 @@ def gn_scale_shift_composed(x, groups: int, eps: float, gamma: Optional[torch.Te
 # Measured on MI355X (tools/bench_conv.py): the in-kernel prologue is applied to every halo row (2.1-2.5x redundant) on the VALU
 # while the work-group's MFMAs wait, and costs ~3x the HBM-bound pass; "auto" therefore un-fuses for large bf16 tensors.
 GN_APPLY_POLICY = "auto"
+# The LDS-DMA 3x3x3 kernels apply the prologue IN LDS to the landed patch (csrc/conv_dma.hip: transform_patch): no activated tensor in
+# HBM and no extra pass; a convolution they cover takes this form whenever the flag is on (the policy above then only governs the
+# register-staged kernels).  They also read a VirtualCat's two parts directly (GmConvDesc.x2), so the decoder's concatenated, activated
+# conv1 operand is never assembled either.
+DMA_FUSED_PROLOGUE = True
+DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
 
 
 def fuse_gn_prologue(x: torch.Tensor) -> bool:
@@ -594,7 +600,8 @@ LDS_SOFT_LIMIT = 80 * 1024   # two workgroups per CU
 LDS_HARD_LIMIT = 160 * 1024
 
 
-def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] = None):
+def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] = None, only: Optional[tuple] = None, exclude: tuple = ()):
+    """Pick the tile configuration (desc.cfg + tile bits) for a built descriptor; `only` / `exclude` restrict the candidates."""
     cout = desc.Cout
     if force_cfg is not None:
         order = [force_cfg]
@@ -616,6 +623,7 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         dma_first = [c for c in order if c in (11, 15, 18, 19)]
         rest = [c for c in order if c not in (11, 15, 18, 19)]
         order = dma_first + [c for c in rest if _cfg_tile(c)[0] <= 64] + [c for c in rest if _cfg_tile(c)[0] > 64]
+    order = [c for c in order if (only is None or c in only) and c not in exclude]
     best = None
     for cfg in order:
         bm, _ = _cfg_tile(cfg)
@@ -707,7 +715,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
          res: Optional[torch.Tensor] = None, post_act: str = "none", out: Optional[torch.Tensor] = None,
          packed: Optional[torch.Tensor] = None, cout: Optional[int] = None, force_cfg: Optional[int] = None,
          want_stats: bool = False, skip: Optional[tuple] = None, allow_subpixel: bool = True) -> torch.Tensor:
-    """Fused convolution over an arena tensor x = (N, *spatial, Cin).
+    """Fused convolution over an arena tensor x = (N, *spatial, Cin) -- or over a VirtualCat of two (their channel concatenation).
 
     kernel/stride/padding/dilation: int or per-axis tuples (len = number of spatial axes). `padding` is the low-side pad,
     `pad_hi` the high side (default: same as low). upsample: nearest 2x folded into the input indexing.
@@ -719,10 +727,32 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     computed by 1x1 launches first and added as the residual (`res` must then be None).
     allow_subpixel: an eligible up-sampling convolution runs as 8 sub-pixel 2x2x2 convolutions on pre-summed weights (cached per weight
     version: right for inference; a training step, whose weights change every iteration, passes False)."""
-    require_device(x, weight, bias, rowvec, res, out)
+    x2 = None
+    if isinstance(x, VirtualCat):
+        x, x2 = x.parts
+    require_device(x, x2, weight, bias, rowvec, res, out)
     nsp = x.dim() - 2
     if nsp < 1 or nsp > 3:
         raise ValueError("conv expects (N, *spatial, C) with 1-3 spatial axes")
+
+    def two_pass():
+        """The operand as ONE activated tensor (gm_gn_apply per part into channel slices / a channel copy), then the plain convolution:
+        the form every kernel covers."""
+        parts = [x] if x2 is None else [x, x2]
+        if pre is None and x2 is None:
+            raise AssertionError
+        xa = torch.empty((*x.shape[:-1], sum(t.shape[-1] for t in parts)), dtype=x.dtype, device=x.device)
+        off = 0
+        for t in parts:
+            c_t = t.shape[-1]
+            if pre is not None:
+                gn_apply(t, pre[0][:, off:off + c_t], pre[1][:, off:off + c_t], pre_act, out=xa[..., off:off + c_t])
+            else:
+                copy_channels(t, xa[..., off:off + c_t])
+            off += c_t
+        return conv(xa, weight, bias, kernel=kernel, stride=stride, padding=padding, dilation=dilation, pad_hi=pad_hi, upsample=upsample,
+                    transposed=transposed, output_padding=output_padding, rowvec=rowvec, res=res, post_act=post_act, out=out, packed=packed,
+                    cout=cout, force_cfg=force_cfg, want_stats=want_stats, skip=skip, allow_subpixel=allow_subpixel)
 
     def tup(v):
         v = tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * nsp
@@ -739,9 +769,11 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     phi = pad3(tup(pad_hi if pad_hi is not None else padding), 0)
     dil = pad3(tup(dilation), 1)
     opad = pad3(tup(output_padding), 0)
-    n, cin = x.shape[0], x.shape[-1]
+    n, cin = x.shape[0], x.shape[-1] + (0 if x2 is None else x2.shape[-1])
     src = pad3(tuple(x.shape[1:-1]), 1)
     dtype = x.dtype
+    if x2 is not None and (x2.shape[:-1] != x.shape[:-1] or x2.dtype != dtype):
+        raise ValueError("the two parts of a concatenated input must agree outside the channel dim")
     if packed is None:
         packed = packed_conv_weight(weight, dtype, transposed)
         cout = weight.shape[1] if transposed else weight.shape[0]
@@ -750,7 +782,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             raise ValueError(f"input has {cin} channels but the weight expects {wcin}")
     rows = n * math.prod(src)
     vecw = 16 // x.element_size()
-    if (rows <= SMALL_LINEAR_ROWS and k == (1, 1, 1) and s == (1, 1, 1) and not transposed and not upsample and pre is None
+    if (rows <= SMALL_LINEAR_ROWS and x2 is None and k == (1, 1, 1) and s == (1, 1, 1) and not transposed and not upsample and pre is None
             and rowvec is None and not want_stats and skip is None and force_cfg is None and cin % vecw == 0
             and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0 and plo == (0, 0, 0) and phi == (0, 0, 0)):
         # a handful of rows (decode steps, the timestep MLP): the barrier-free small-row GEMM instead of the tiled kernel
@@ -767,7 +799,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                                                   out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act], POST_ACT[post_act], dt_code(dtype),
                                                   _stream()), "gm_linear_rows"))
         return out
-    if (upsample and SUBPIXEL_UPSAMPLE and allow_subpixel and nsp == 3 and k == (3, 3, 3) and s == (1, 1, 1) and plo == (1, 1, 1) and phi == (1, 1, 1)
+    if (upsample and x2 is None and SUBPIXEL_UPSAMPLE and allow_subpixel and nsp == 3 and k == (3, 3, 3) and s == (1, 1, 1) and plo == (1, 1, 1) and phi == (1, 1, 1)
             and dil == (1, 1, 1) and pre is None and pre_act == "none" and skip is None and force_cfg is None and weight is not None
             and cin % (64 // x.element_size()) == 0 and cout % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0
             and math.prod(src) * n >= DMA_CONV_MIN_VOXELS):
@@ -804,6 +836,8 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     elif tuple(out.shape) != out_shape or out.dtype != dtype:
         raise ValueError(f"out has shape {tuple(out.shape)}, expected {out_shape}")
     d.x, d.x_ld = x.data_ptr(), arena_ld(x)
+    if x2 is not None:
+        d.x2, d.x2_ld, d.cin_split = x2.data_ptr(), arena_ld(x2), x.shape[-1]
     d.w = packed.data_ptr()
     b32 = as_f32(bias) if bias is not None else None
     d.bias = _ptr(b32)
@@ -857,11 +891,26 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     d.dd, d.dh, d.dw = dil
     d.pre_act, d.post_act, d.dtype = ACT[pre_act], POST_ACT[post_act], dt_code(dtype)
     d.debug_flags = _CONV_DEBUG_FLAGS
-    if skip is not None:
+    nvox = math.prod(out_sp)
+    # ---- which kernel, and how the prologue is applied ------------------------------------------------------------------------------
+    # (1) an LDS-DMA configuration when it covers the geometry: fused shortcut, in-LDS prologue, both parts of a VirtualCat read in place;
+    # (2) else the operand is first reduced to ONE activated tensor where needed (two_pass: gn_apply passes, 1x1 shortcut launches), and
+    # (3) the register-staged / generic kernels take what is left, with their own fused prologue for small tensors.
+    dma_ok = False
+    if force_cfg is not None and force_cfg in DMA_CFGS or (force_cfg is None and DMA_CONV and cout > 16 and nvox * n >= DMA_CONV_MIN_VOXELS
+                                                            and (pre is None or DMA_FUSED_PROLOGUE)):
         try:
-            _choose_conv_cfg(d, math.prod(out_sp), force_cfg if force_cfg is not None else 11)  # only the LDS-DMA kernels fuse the shortcut
+            _choose_conv_cfg(d, nvox, force_cfg, only=DMA_CFGS)
+            dma_ok = True
         except ValueError:
-            # not covered (fused prologue, 2-D, small / ragged channel counts ...): 1x1 launches over the parts, then a residual
+            dma_ok = False
+    if not dma_ok:
+        if force_cfg is not None and force_cfg in DMA_CFGS:
+            raise ValueError(f"configuration {force_cfg} does not cover this convolution")
+        if x2 is not None:
+            return two_pass()  # only the LDS-DMA kernels read a concatenated input in place
+        if skip is not None:
+            # the shortcut as 1x1 launches over the parts first, added as the residual (`res` is None: the shortcut IS the residual)
             parts, sw, sb = skip
             parts = list(parts)
             acc_t, off = None, 0
@@ -874,8 +923,10 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                         upsample=upsample, transposed=transposed, output_padding=output_padding, pre=pre, pre_act=pre_act,
                         rowvec=rowvec, res=acc_t, post_act=post_act, out=out, packed=packed, cout=cout, force_cfg=force_cfg,
                         want_stats=want_stats)
-    else:
-        _choose_conv_cfg(d, math.prod(out_sp), force_cfg)
+        if pre is not None and force_cfg is None and cout > 16 and math.prod(k) > 1 and not fuse_gn_prologue(x):
+            return two_pass()  # a ResnetBlock convolution the LDS-DMA prologue does not cover (2-D, ragged channels, flag off) on a large
+            # tensor: the HBM-bound gm_gn_apply pass + a prologue-free kernel beats the register-staged prologue (GN_APPLY_POLICY)
+        _choose_conv_cfg(d, nvox, force_cfg, exclude=DMA_CFGS if force_cfg is None else ())
     d.stats = None
     if want_stats:  # the fast kernels fuse the output statistics into their epilogue (else: one stand-alone pass when a consumer asks)
         _attach_conv_stats(d, out, n, cout)

@@ -167,6 +167,10 @@ typedef struct GmConvDesc {
   const void* skip_x[2]; long long skip_ld[2]; int skip_cin[2];
   const void* skip_w;        /* gm_pack_conv_weight image of the [Cout][skip_cin[0]+skip_cin[1]] 1x1 kernel */
   const float* skip_bias;    /* [Cout] or NULL */
+  /* optional second input source (LDS-DMA configurations only): the convolution input is cat(x[..., :cin_split], x2) along the channels
+   * -- the decoder's torch.cat([h, skip], dim=1) (diffusion_model_unet.py:1232,1340,1461), never materialised; x2 in x's geometry,
+   * cin_split a multiple of the 64-byte K chunk (32 bf16 / 16 fp32 channels); Cin counts both parts */
+  const void* x2; long long x2_ld; int cin_split;
 } GmConvDesc;
 int gm_conv_cfg_tile(int cfg, int* voxels, int* channels);
 long long gm_conv_lds_bytes(const GmConvDesc* d);

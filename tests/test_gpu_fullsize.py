@@ -140,7 +140,8 @@ def test_groupnorm_statistics_and_apply_at_256_cubed():
         s1 += v.sum(0)
         s2 += (v * v).sum(0)
     st = ops.channel_stats(x).sum(0)[0]
-    assert torch.allclose(st[:, 0], s1, rtol=1e-9, atol=1e-4) and torch.allclose(st[:, 1], s2, rtol=1e-9, atol=1e-4)
+    # (the kernel's per-thread partials over 64 rows are fp32: ~1e-7 relative on 1.7e7-sized sums of squares; everything above is fp64)
+    assert torch.allclose(st[:, 0], s1, rtol=1e-6, atol=1e-2) and torch.allclose(st[:, 1], s2, rtol=1e-6, atol=1e-2)
     scale, shift = ops.gn_scale_shift_composed(x, groups, eps, gamma, beta)
     cnt = flat.shape[0] * (c // groups)
     mean = s1.reshape(groups, -1).sum(1) / cnt
@@ -148,7 +149,7 @@ def test_groupnorm_statistics_and_apply_at_256_cubed():
     rstd = 1.0 / torch.sqrt(var + eps)
     want_scale = (rstd.repeat_interleave(c // groups) * gamma.double()).float()
     want_shift = (beta.double() - mean.repeat_interleave(c // groups) * rstd.repeat_interleave(c // groups) * gamma.double()).float()
-    assert torch.allclose(scale[0], want_scale, rtol=1e-6, atol=1e-7) and torch.allclose(shift[0], want_shift, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(scale[0], want_scale, rtol=1e-5, atol=1e-6) and torch.allclose(shift[0], want_shift, rtol=1e-5, atol=1e-6)
     y = ops.gn_apply(x, scale, shift, "silu")
     worst = 0.0
     for xp, yp in zip(flat.split(1 << 24), y.reshape(-1, c).split(1 << 24)):

@@ -252,7 +252,7 @@ def test_conv_every_tile_configuration(cfg, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [("plain", 32, 64, (8, 8, 16), False), ("ragged", 64, 40, (5, 7, 19), False),
                                   ("wide", 96, 136, (4, 6, 18), False), ("up", 32, 64, (3, 5, 9), True)], ids=lambda c: c[0])
-@pytest.mark.parametrize("cfg", [11, 14, 16])
+@pytest.mark.parametrize("cfg", [11, 14, 16, 18, 19])
 def test_conv_lds_dma_kernel(case, dtype, cfg):
     """cfg 11 (conv_dma.hip): both operands through the LDS-DMA engine, source-side swizzle, zero page for the halo; ragged
     volumes, channel counts that are not tile multiples, folded 2x up-sampling, bias + timestep row + residual epilogue into a
@@ -281,6 +281,55 @@ def test_conv_lds_dma_kernel(case, dtype, cfg):
     # and the automatic choice picks the same kernel for this geometry when nothing is fused into the prologue
     auto = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), kernel=3, padding=1, upsample=up, rowvec=temb.to(DEV), res=_cl(res))
     assert torch.equal(auto, got.contiguous()) or (auto.float() - got.float()).abs().max() <= 2e-2 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [11, 14, 16, 18, 19])
+@pytest.mark.parametrize("case", [("one", 64, 72, None, (6, 9, 19), 2), ("cat", 96, 40, 64, (5, 7, 19), 2), ("cat-wide", 160, 136, 32, (9, 6, 18), 1),
+                                  ("relu", 32, 64, None, (4, 4, 16), 3)], ids=lambda c: c[0] if isinstance(c, tuple) else str(c))
+def test_conv_lds_dma_in_lds_prologue_matches_the_two_pass_form_bitwise(case, cfg, dtype):
+    """The fused GroupNorm-apply + activation prologue of the LDS-DMA kernels (conv_dma.hip transform_patch: applied in LDS to the landed
+    patch, padding rows left at zero, per-sample scale / shift) and their in-place read of a two-part virtual concatenation
+    (GmConvDesc.x2) against (a) the two-pass form -- gm_gn_apply per part, then the plain convolution -- which must agree BIT FOR BIT
+    (same arithmetic, same rounding), output statistics included, and (b) F.conv3d(act(x * scale + shift)) in fp64.
+    Reference: conv(silu(norm(x))) of ResnetBlock, diffusion_model_unet.py:671-684, over torch.cat([h, skip]) in the decoder (:1232)."""
+    ops = _ops()
+    name, cin, cout, split, sp, n = case
+    act = "relu" if name == "relu" else "silu"
+    x = _rand((n, cin, *sp), 171).to(dtype)
+    w = (_rand((cout, cin, 3, 3, 3), 172) / math.sqrt(cin * 27)).to(dtype)
+    b, temb = _rand((cout,), 173) * 0.1, _rand((n, cout), 174) * 0.5
+    scale = (_rand((n, cin), 175) * 0.2 + 1.0).to(DEV)
+    shift = (_rand((n, cin), 176) * 0.3).to(DEV)
+    xa = _cl(x)
+    operand = xa if split is None else ops.VirtualCat([xa[..., :split].contiguous(), xa[..., split:].contiguous()])
+    kw = dict(kernel=3, padding=1, pre=(scale, shift), pre_act=act, rowvec=temb.to(DEV), want_stats=True)
+    fused = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=cfg, **kw)
+    # the two-pass form, spelled out: one gm_gn_apply per part into channel slices of ONE activated tensor, then the plain kernel
+    parts = [xa] if split is None else operand.parts
+    act_t = torch.empty((n, *sp, cin), dtype=dtype, device=DEV)
+    off = 0
+    for part in parts:
+        c = part.shape[-1]
+        ops.gn_apply(part, scale[:, off:off + c], shift[:, off:off + c], act, out=act_t[..., off:off + c])
+        off += c
+    two = ops.conv(act_t, w.to(DEV), b.to(DEV), kernel=3, padding=1, rowvec=temb.to(DEV), want_stats=True, force_cfg=cfg)
+    assert torch.equal(fused, two), f"fused prologue differs from the two-pass form: {(fused.float() - two.float()).abs().max().item():.3e}"
+    assert torch.equal(fused._gm_cstats, two._gm_cstats)
+    keep = ops.DMA_FUSED_PROLOGUE
+    try:  # the automatic choice, flag on and off, computes the same function (possibly on another kernel: not bitwise)
+        for flag in (True, False):
+            ops.DMA_FUSED_PROLOGUE = flag
+            auto = ops.conv(operand, w.to(DEV), b.to(DEV), **kw)
+            assert (auto.float() - two.float()).abs().max().item() <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, two.float().abs().max().item())
+    finally:
+        ops.DMA_FUSED_PROLOGUE = keep
+    f = (lambda t: F.relu(t)) if act == "relu" else F.silu
+    xin = f(x.double() * scale.cpu().double().reshape(n, cin, 1, 1, 1) + shift.cpu().double().reshape(n, cin, 1, 1, 1))
+    if dtype == torch.bfloat16:
+        xin = xin.to(torch.bfloat16).double()  # the activated operand is stored in the compute dtype before it meets the weights
+    want = F.conv3d(xin, w.double(), b.double(), padding=1) + temb.double().reshape(n, cout, 1, 1, 1)
+    _check(_cf(fused), want, dtype, f"in-LDS prologue {name} cfg{cfg}", extra=2.0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
