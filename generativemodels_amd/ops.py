@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import weakref
 from typing import Optional, Sequence
 
@@ -507,7 +508,7 @@ GN_APPLY_POLICY = "auto"
 # HBM and no extra pass; a convolution they cover takes this form whenever the flag is on (the policy above then only governs the
 # register-staged kernels).  They also read a VirtualCat's two parts directly (GmConvDesc.x2), so the decoder's concatenated, activated
 # conv1 operand is never assembled either.
-DMA_FUSED_PROLOGUE = True
+DMA_FUSED_PROLOGUE = os.environ.get("GM_DMA_FUSED_PROLOGUE", "1") != "0"  # (the env switch exists for A/B measurements)
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
 
 

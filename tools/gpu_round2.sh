@@ -20,8 +20,8 @@ if [[ $STAGES == *c* ]]; then
   echo "conv_cfgs rc=$?" >> $LOG; cat $OUT/r2_conv_cfgs.log >> $LOG
 fi
 if [[ $STAGES == *t* ]]; then
-  timeout ${TEST_TIMEOUT:-2400} python -m pytest tests -m gpu -q --maxfail=40 --durations=25 -p no:cacheprovider ${PYTEST_ARGS:-} > $OUT/r2_tests.log 2>&1
-  echo "tests rc=$?" >> $LOG; tail -60 $OUT/r2_tests.log >> $LOG
+  timeout ${TEST_TIMEOUT:-2400} python -m pytest tests -m gpu -q --maxfail=40 --durations=15 -rP -p no:cacheprovider ${PYTEST_ARGS:-} > $OUT/r2_tests.log 2>&1
+  echo "tests rc=$?" >> $LOG; grep -v "^\[parity\]\|^---\|^$\|Captured\|^_____\|PASSED" $OUT/r2_tests.log | tail -60 >> $LOG
   grep "\[parity\]" $OUT/r2_tests.log >> $LOG
 fi
 if [[ $STAGES == *p* ]]; then
@@ -54,6 +54,14 @@ fi
 if [[ $STAGES == *b* ]]; then
   timeout 1500 python bench.py ${BENCH_ARGS:---steps 3 --warmup 1} > $OUT/r2_bench.log 2>&1
   echo "bench rc=$?" >> $LOG; tail -c 6000 $OUT/r2_bench.log >> $LOG
+fi
+if [[ $STAGES == *a* ]]; then  # A/B: the same bench with the two-pass GroupNorm-apply (no in-LDS prologue)
+  GM_DMA_FUSED_PROLOGUE=0 timeout 900 python bench.py --steps 2 --warmup 1 --cpu-baseline off > $OUT/r2_bench_twopass.log 2>&1
+  echo "bench_twopass rc=$?" >> $LOG; tail -c 2500 $OUT/r2_bench_twopass.log >> $LOG
+fi
+if [[ $STAGES == *3* ]]; then
+  timeout 900 python tools/bench_c3.py > $OUT/r2_c3.log 2>&1
+  echo "c3 rc=$?" >> $LOG; tail -c 3000 $OUT/r2_c3.log >> $LOG
 fi
 if [[ $STAGES == *l* ]]; then
   timeout 600 python tools/layer_times.py > $OUT/r2_layer_times.log 2>&1
