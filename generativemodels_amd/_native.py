@@ -120,6 +120,7 @@ PROTOTYPES = {
     "gm_sample_index": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, c_vp, c_vp]),
     "gm_token_log_prob": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, c_vp]),
     "gm_attention_workspace_bytes": (c_ll, [C.POINTER(GmAttnDesc)]),
+    "gm_attention_dma_set_variant": (None, [C.c_int, C.c_int]),
     "gm_attention_forward": (C.c_int, [C.POINTER(GmAttnDesc), c_vp]),
     "gm_conv_wgrad_workspace_bytes": (c_ll, [C.POINTER(GmWgradDesc)]),
     "gm_conv_wgrad": (C.c_int, [C.POINTER(GmWgradDesc), c_vp]),

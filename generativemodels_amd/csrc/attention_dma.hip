@@ -48,9 +48,16 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_raw* __restrict
   }
 }
 
-template <int DH>
-__global__ __launch_bounds__(512, 2) void attn_dma_kernel(const GmAttnDesc p, const bf16_raw* __restrict__ vt, int Lk_pad) {
-  constexpr int KT = 64, KF = KT / 16, NW = 8;
+// QF = 16-query fragments per wave.  QF = 1: 8 waves x 16 queries, one LDS operand read per MFMA (the LDS port bounds the kernel at about
+// half the MFMA rate).  QF = 2: 8 waves x 32 queries -- every K / V^T fragment read feeds two MFMAs (0.5 reads per MFMA), the per-tile
+// barrier and DMA issue are amortised over twice the matrix work, and the O rescale is skipped (wave-uniformly) on tiles where no running
+// maximum moved; the price is registers: Q (64) + O (128) + S (32) accumulators per lane at head dim 256.
+// Split-KV (gridDim.z > 1): work-group z handles the z-th slice of the key tiles and writes its un-normalised O (fp32), running maximum
+// and sum to `part`; attn_combine_kernel merges the slices (the flash-decoding reduction).  One head of 32768 tokens is only 128
+// 256-query tiles -- half the chip -- so the long single-head case of the 3-D UNets runs as 2 slices, short sequences as up to 8.
+template <int DH, int QF, int MINW>
+__global__ __launch_bounds__(512, MINW) void attn_dma_kernel(const GmAttnDesc p, const bf16_raw* __restrict__ vt, int Lk_pad, float* __restrict__ part) {
+  constexpr int KT = 64, KF = KT / 16, NW = 8, QPW = 16 * QF;
   constexpr int STEPS = DH / 32;                 // 64-byte k-steps over the head dim
   constexpr int DF = DH / 16;                    // output channel fragments
   constexpr int KROWB = DH * 2;                  // K tile row bytes
@@ -70,180 +77,293 @@ __global__ __launch_bounds__(512, 2) void attn_dma_kernel(const GmAttnDesc p, co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, qg = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-  const int my_q = blockIdx.x * (NW * 16) + wave * 16 + l15;
-  const bool q_ok = my_q < p.Lq;
+  int my_q[QF];
+  bool q_ok[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    my_q[f] = blockIdx.x * (NW * QPW) + wave * QPW + f * 16 + l15;
+    q_ok[f] = my_q[f] < p.Lq;
+  }
 
   const bf16_raw* Qb = reinterpret_cast<const bf16_raw*>(p.q) + (long long)b * p.Lq * p.q_ld + h * DH;
   const char* Kb = reinterpret_cast<const char*>(reinterpret_cast<const bf16_raw*>(p.k) + (long long)b * p.Lk * p.k_ld + h * DH);
   const char* Vt = reinterpret_cast<const char*>(vt + (long long)bh * DH * Lk_pad);
   const char* zero = reinterpret_cast<const char*>(gm_attn_zero_row);
 
-  // ---- this lane's DMA sources (tile-independent part) ------------------------------------------------------------------------
-  int krow[PPW], kslotb[PPW];
-  long long vsrc[PPW];
-#pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int pc = wave * PPW + j;
-    const int row = pc * KRPP + lane / SPR, slot = lane % SPR;
-    krow[j] = row;
-    kslotb[j] = (slot ^ ((row >> KSH) & (KNB - 1))) * 16;
-    const int vrow = pc * 8 + (lane >> 3), vslot = lane & 7;
-    vsrc[j] = (long long)vrow * Lk_pad * 2 + ((vslot ^ ((vrow >> 1) & 7)) * 16);
-  }
+  // ---- this lane's DMA sources: recomputed per piece from two lane constants (a per-piece table of 64-bit offsets costs 16 registers
+  // the 32-queries-per-wave kernel does not have) ----------------------------------------------------------------------------------
+  const int krow0 = wave * PPW * KRPP + lane / SPR, kslot = lane % SPR;   // piece j: K row krow0 + j * KRPP
+  const int vrow0 = wave * PPW * 8 + (lane >> 3), vslot = lane & 7;       // piece j: V^T channel row vrow0 + 8 j
   const long long k_rowb = p.k_ld * 2;
+  const int v_rowb = Lk_pad * 2;                                          // host-checked: DH * Lk_pad * 2 < 2^31
   auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
     const int key0 = tile * KT;
     const unsigned kdst = lds0 + (unsigned)buf * (KBYTES + VBYTES), vdst = kdst + KBYTES;
+    const char* vt0 = Vt + (long long)key0 * 2;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      const bool ok = key0 + krow[j] < p.Lk;
-      const char* ks = ok ? Kb + (long long)(key0 + krow[j]) * k_rowb + kslotb[j] : zero + ((lane & 3) << 4);
+      const int krow = krow0 + j * KRPP;
+      const int kslotb = (kslot ^ ((krow >> KSH) & (KNB - 1))) * 16;
+      const bool ok = key0 + krow < p.Lk;
+      const char* ks = ok ? Kb + (long long)(key0 + krow) * k_rowb + kslotb : zero + ((lane & 3) << 4);
       attn_dma16(ks, kdst + (unsigned)(wave * PPW + j) * 1024);
-      attn_dma16(Vt + vsrc[j] + (long long)key0 * 2, vdst + (unsigned)(wave * PPW + j) * 1024);
+      const int vrow = vrow0 + 8 * j;
+      attn_dma16(vt0 + vrow * v_rowb + ((vslot ^ ((vrow >> 1) & 7)) * 16), vdst + (unsigned)(wave * PPW + j) * 1024);
     }
   };
 
   // ---- operand read offsets ---------------------------------------------------------------------------------------------------
-  int kaddr[STEPS];  // K fragment (key row l15 of fragment 0, k-step s); fragment kf adds kf*16*KROWB
+  // K fragment (key row l15 of fragment 0, k-step s); fragment kf adds kf*16*KROWB.  The swizzle XORs slot bits 0..3 only, so k-steps
+  // that differ in bit 4 and up of their slot index (s >= 4: +256 bytes per 4 steps) share a register and differ by an immediate.
+  constexpr int KA = STEPS < 4 ? STEPS : 4;
+  int kaddr[KA];
   const int fk = (l15 >> KSH) & (KNB - 1);
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) kaddr[s] = l15 * KROWB + (((s * 4 + qg) ^ fk) << 4);
+  for (int s = 0; s < KA; ++s) kaddr[s] = l15 * KROWB + (((s * 4 + qg) ^ fk) << 4);
   int vaddr[2];      // V^T fragment (channel row l15 of fragment 0, key step s2); fragment d adds d*16*128
   const int fv = (l15 >> 1) & 7;
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) vaddr[s2] = KBYTES + l15 * 128 + (((s2 * 4 + qg) ^ fv) << 4);
 
   // Q fragments (B operand of S^T = K Q^T): lane (query l15, slot qg) holds channels s*32 + qg*8 .. +7
-  uint4 qf[STEPS];
+  uint4 qf[QF][STEPS];
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    const uint4 v = *reinterpret_cast<const uint4*>(Qb + (long long)(q_ok ? my_q : 0) * p.q_ld + s * 32 + qg * 8);
-    qf[s] = make_uint4(q_ok ? v.x : 0u, q_ok ? v.y : 0u, q_ok ? v.z : 0u, q_ok ? v.w : 0u);
-  }
-  f32x4_t oacc[DF];
+  for (int f = 0; f < QF; ++f)
 #pragma unroll
-  for (int d = 0; d < DF; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int s = 0; s < STEPS; ++s) {
+      const uint4 v = *reinterpret_cast<const uint4*>(Qb + (long long)(q_ok[f] ? my_q[f] : 0) * p.q_ld + s * 32 + qg * 8);
+      qf[f][s] = make_uint4(q_ok[f] ? v.x : 0u, q_ok[f] ? v.y : 0u, q_ok[f] ? v.z : 0u, q_ok[f] ? v.w : 0u);
+    }
+  f32x4_t oacc[QF][DF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f)
+#pragma unroll
+    for (int d = 0; d < DF; ++d) oacc[f][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run[QF], l_run[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) { m_run[f] = -INFINITY; l_run[f] = 0.f; }
 
-  const int ntiles = (p.Lk + KT - 1) / KT;
-  issue_tile(0, 0);
+  const int ntiles_all = (p.Lk + KT - 1) / KT;
+  const int tps = (ntiles_all + (int)gridDim.z - 1) / (int)gridDim.z;  // key tiles per slice
+  const int tile0 = (int)blockIdx.z * tps;
+  const int ntiles = min(ntiles_all, tile0 + tps);                    // this slice: tiles [tile0, ntiles) (possibly empty)
+  if (tile0 < ntiles) issue_tile(tile0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  for (int tile = 0; tile < ntiles; ++tile) {
+  for (int tile = tile0; tile < ntiles; ++tile) {
     const int key0 = tile * KT;
-    const char* buf = smem + (size_t)(tile & 1) * (KBYTES + VBYTES);
-    if (tile + 1 < ntiles) issue_tile(tile + 1, (tile + 1) & 1);  // its buffer was last read two barriers ago
+    const char* buf = smem + (size_t)((tile - tile0) & 1) * (KBYTES + VBYTES);
+    if (tile + 1 < ntiles) issue_tile(tile + 1, (tile + 1 - tile0) & 1);  // its buffer was last read two barriers ago
 
-    // ---- S^T = K Q^T ------------------------------------------------------------------------------------------------------
-    f32x4_t sacc[KF];
+    // The 64-key tile is consumed in NH slices of KFH key fragments (QF = 2: two 32-key slices, so that the score / probability
+    // registers of 32 queries stay at 24 per lane -- the kernel sits at the 256-register limit of two waves per SIMD); each slice is
+    // one online-softmax step.
+    constexpr int NH = QF == 2 ? 2 : 1, KFH = KF / NH;
 #pragma unroll
-    for (int kf = 0; kf < KF; ++kf) sacc[kf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int hf = 0; hf < NH; ++hf) {
+      // ---- S^T = K Q^T: one K fragment read feeds QF MFMAs ------------------------------------------------------------------
+      f32x4_t sacc[QF][KFH];
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s)
+      for (int f = 0; f < QF; ++f)
 #pragma unroll
-      for (int kf = 0; kf < KF; ++kf) {
-        const uint4 kfrag = *reinterpret_cast<const uint4*>(buf + kaddr[s] + kf * 16 * KROWB);
-        sacc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kfrag), __builtin_bit_cast(bf16x8_t, qf[s]),
-                                                           sacc[kf], 0, 0, 0);
+        for (int kf = 0; kf < KFH; ++kf) sacc[f][kf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+        for (int kf = 0; kf < KFH; ++kf) {
+          const uint4 kfrag = *reinterpret_cast<const uint4*>(buf + kaddr[s % KA] + (s / KA) * (KA * 64) + (hf * KFH + kf) * 16 * KROWB);
+#pragma unroll
+          for (int f = 0; f < QF; ++f)
+            sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kfrag), __builtin_bit_cast(bf16x8_t, qf[f][s]),
+                                                                  sacc[f][kf], 0, 0, 0);
+        }
+      // ---- online softmax: this lane's queries, keys key0 + (hf * KFH + kf) * 16 + qg * 4 + r ----------------------------------
+      uint4 pf[QF][KFH / 2];
+      float alpha[QF];
+      bool moved = false;
+#pragma unroll
+      for (int f = 0; f < QF; ++f) {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < KFH; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + (hf * KFH + kf) * 16 + qg * 4 + r;
+            const float sv = key < p.Lk ? sacc[f][kf][r] * p.scale : -INFINITY;
+            sacc[f][kf][r] = sv;
+            tmax = fmaxf(tmax, sv);
+          }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run[f], tmax);
+        alpha[f] = __expf(m_run[f] - m_new);
+        moved |= m_new != m_run[f];
+        float psum = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < KFH; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __expf(sacc[f][kf][r] - m_new);
+            sacc[f][kf][r] = pv;
+            psum += pv;
+          }
+        l_run[f] = l_run[f] * alpha[f] + psum;
+        m_run[f] = m_new;
+        // P from the S^T accumulators, key positions as packed by vt_pack_kernel
+#pragma unroll
+        for (int s = 0; s < KFH / 2; ++s)
+          pf[f][s] = make_uint4(pack_bf16x2(sacc[f][2 * s][0], sacc[f][2 * s][1]), pack_bf16x2(sacc[f][2 * s][2], sacc[f][2 * s][3]),
+                                pack_bf16x2(sacc[f][2 * s + 1][0], sacc[f][2 * s + 1][1]), pack_bf16x2(sacc[f][2 * s + 1][2], sacc[f][2 * s + 1][3]));
       }
-    // ---- online softmax: this lane's query, keys key0 + kf*16 + qg*4 + r ----------------------------------------------------
-    float tmax = -INFINITY;
+      // rescale O only when some lane's running maximum moved (alpha == 1 exactly otherwise: skipping the multiply changes nothing);
+      // after the first tiles that is rare, and the 16 x QF x 4 multiplies per step are the largest VALU block of the loop
+      if (__builtin_amdgcn_ballot_w64(moved) != 0) {
 #pragma unroll
-    for (int kf = 0; kf < KF; ++kf)
+        for (int f = 0; f < QF; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + kf * 16 + qg * 4 + r;
-        const float sv = key < p.Lk ? sacc[kf][r] * p.scale : -INFINITY;
-        sacc[kf][r] = sv;
-        tmax = fmaxf(tmax, sv);
+          for (int d = 0; d < DF; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[f][d][r] *= alpha[f];
       }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int kf = 0; kf < KF; ++kf)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = __expf(sacc[kf][r] - m_new);
-        sacc[kf][r] = pv;
-        psum += pv;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < DF; ++d)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha;
 
-    // ---- O^T += V^T P^T: P from the S^T accumulators, key positions as packed by vt_pack_kernel --------------------------------
-    uint4 pf[KF / 2];
+      // ---- O^T += V^T P^T: one V^T fragment read feeds QF MFMAs --------------------------------------------------------------
 #pragma unroll
-    for (int s = 0; s < KF / 2; ++s)
-      pf[s] = make_uint4(pack_bf16x2(sacc[2 * s][0], sacc[2 * s][1]), pack_bf16x2(sacc[2 * s][2], sacc[2 * s][3]),
-                         pack_bf16x2(sacc[2 * s + 1][0], sacc[2 * s + 1][1]), pack_bf16x2(sacc[2 * s + 1][2], sacc[2 * s + 1][3]));
+      for (int d = 0; d < DF; ++d)
 #pragma unroll
-    for (int d = 0; d < DF; ++d)
+        for (int s = 0; s < KFH / 2; ++s) {
+          const uint4 vfrag = *reinterpret_cast<const uint4*>(buf + vaddr[hf * (KFH / 2) + s] + d * 16 * 128);
 #pragma unroll
-      for (int s = 0; s < KF / 2; ++s) {
-        const uint4 vfrag = *reinterpret_cast<const uint4*>(buf + vaddr[s] + d * 16 * 128);
-        oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vfrag), __builtin_bit_cast(bf16x8_t, pf[s]),
-                                                          oacc[d], 0, 0, 0);
-      }
+          for (int f = 0; f < QF; ++f)
+            oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vfrag), __builtin_bit_cast(bf16x8_t, pf[f][s]),
+                                                                 oacc[f][d], 0, 0, 0);
+        }
+    }
     // the next tile has landed (this wave's pieces) and this wave is done reading the current one
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 
-  // ---- finish: 1/l, residual, store ------------------------------------------------------------------------------------------
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (!q_ok) return;
-  bf16_raw* orow = reinterpret_cast<bf16_raw*>(p.o) + ((long long)b * p.Lq + my_q) * p.o_ld + h * DH;
-  const bf16_raw* rrow = p.res ? reinterpret_cast<const bf16_raw*>(p.res) + ((long long)b * p.Lq + my_q) * p.res_ld + h * DH : nullptr;
+  // ---- finish: 1/l, residual, store (or, split-KV: the slice's un-normalised state for attn_combine_kernel) -----------------------
 #pragma unroll
-  for (int d = 0; d < DF; ++d) {
-    float o[4];
+  for (int f = 0; f < QF; ++f) {
+    float l_tot = l_run[f] + __shfl_xor(l_run[f], 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (!q_ok[f]) continue;
+    if (part) {  // [slice][b*H + h][query][DH + 2]: O (fp32, relative to the slice maximum), maximum, sum
+      float* prow = part + (((long long)blockIdx.z * gridDim.y + bh) * p.Lq + my_q[f]) * (DH + 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = oacc[d][r] * inv;
-    const int c = d * 16 + qg * 4;
-    if (rrow) {
-      const uint2 rv = *reinterpret_cast<const uint2*>(rrow + c);
-      o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
-      o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+      for (int d = 0; d < DF; ++d)
+        *reinterpret_cast<float4*>(prow + d * 16 + qg * 4) = make_float4(oacc[f][d][0], oacc[f][d][1], oacc[f][d][2], oacc[f][d][3]);
+      if (qg == 0) { prow[DH] = m_run[f]; prow[DH + 1] = l_tot; }
+      continue;
     }
-    *reinterpret_cast<uint2*>(orow + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    bf16_raw* orow = reinterpret_cast<bf16_raw*>(p.o) + ((long long)b * p.Lq + my_q[f]) * p.o_ld + h * DH;
+    const bf16_raw* rrow = p.res ? reinterpret_cast<const bf16_raw*>(p.res) + ((long long)b * p.Lq + my_q[f]) * p.res_ld + h * DH : nullptr;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) {
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = oacc[f][d][r] * inv;
+      const int c = d * 16 + qg * 4;
+      if (rrow) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(rrow + c);
+        o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+        o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+      }
+      *reinterpret_cast<uint2*>(orow + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    }
+  }
+}
+
+// ---- split-KV merge: out[q] = sum_s e^{m_s - M} O_s / sum_s e^{m_s - M} l_s (+ residual); one thread per (query, 8 channels) ----------
+__global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, const float* __restrict__ part, int nsplit) {
+  const int dv = p.dh / 8;
+  const long long total = (long long)p.B * p.H * p.Lq * dv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dv) * 8;
+    const long long qi = i / dv;                       // (b*H + h) * Lq + q
+    const int q = (int)(qi % p.Lq);
+    const int bh = (int)(qi / p.Lq), b = bh / p.H, h = bh % p.H;
+    const long long stride = (long long)p.B * p.H * p.Lq * (p.dh + 4);
+    const float* row = part + qi * (p.dh + 4);
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, row[s * stride + p.dh]);
+    float L = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+      const float* r = row + s * stride;
+      const float w = __expf(r[p.dh] - M);             // an empty slice has maximum -inf: weight 0
+      L += w * r[p.dh + 1];
+      const float4 a = *reinterpret_cast<const float4*>(r + c), b2 = *reinterpret_cast<const float4*>(r + c + 4);
+      o[0] += w * a.x; o[1] += w * a.y; o[2] += w * a.z; o[3] += w * a.w;
+      o[4] += w * b2.x; o[5] += w * b2.y; o[6] += w * b2.z; o[7] += w * b2.w;
+    }
+    const float inv = 1.0f / L;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] *= inv;
+    if (p.res) {
+      const uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_raw*>(p.res) + ((long long)b * p.Lq + q) * p.res_ld + h * p.dh + c);
+      const uint32_t w4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { o[2 * k] += __uint_as_float(w4[k] << 16); o[2 * k + 1] += __uint_as_float(w4[k] & 0xffff0000u); }
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_raw*>(p.o) + ((long long)b * p.Lq + q) * p.o_ld + h * p.dh + c) =
+        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
   }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
+static int gm_attn_dma_force_qf = 0, gm_attn_dma_force_split = 0;  // 0 = choose by problem size (tests / benchmarks force a variant)
+extern "C" void gm_attention_dma_set_variant(int qf, int nsplit) {
+  gm_attn_dma_force_qf = (qf == 1 || qf == 2) ? qf : 0;
+  gm_attn_dma_force_split = (nsplit >= 1 && nsplit <= 8) ? nsplit : 0;
+}
+
 static bool attn_dma_eligible(const GmAttnDesc& d) {
   auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
   return d.dtype == GM_BF16 && !d.causal && d.k_bs == 0 && d.v_bs == 0 && (d.dh == 64 || d.dh == 128 || d.dh == 256) && d.Lq >= 128 && d.Lk >= 128 &&
+         (long long)d.dh * (((long long)d.Lk + 63) / 64 * 64) * 2 < (1LL << 31) &&  // 32-bit byte offsets inside one head's V^T image
          d.q_ld % 8 == 0 && d.k_ld % 8 == 0 && d.v_ld % 8 == 0 && al(d.q, 16) && al(d.k, 16) && al(d.v, 16) &&
-         d.o_ld % 4 == 0 && al(d.o, 8) && (!d.res || (d.res_ld % 4 == 0 && al(d.res, 8)));
+         d.o_ld % 8 == 0 && al(d.o, 16) && (!d.res || (d.res_ld % 8 == 0 && al(d.res, 16)));
+}
+
+// queries per wave (16 * qf) and key slices: 32 queries per wave when the sequence is long enough to amortise its larger tile; as many
+// key slices (powers of two, at least 8 key tiles each) as it takes to put a work-group on every CU
+static void attn_dma_plan(const GmAttnDesc& d, int* qf, int* nsplit) {
+  const long long tiles = ((long long)d.Lk + 63) / 64;
+  int f = gm_attn_dma_force_qf ? gm_attn_dma_force_qf : ((d.Lq >= 1024 && d.Lk >= 1024) ? 2 : 1);
+  const long long nq = (long long)d.B * d.H * ((d.Lq + 128 * f - 1) / (128 * f));
+  int sp = 1;
+  while (nq * sp < 256 && sp < 8 && tiles / (2 * sp) >= 8) sp *= 2;
+  if (gm_attn_dma_force_split) sp = gm_attn_dma_force_split;
+  *qf = f; *nsplit = sp;
 }
 
 extern "C" long long gm_attention_workspace_bytes(const GmAttnDesc* d) {
   if (!d || !attn_dma_eligible(*d)) return 0;
   const long long lk_pad = ((long long)d->Lk + 63) / 64 * 64;
-  return (long long)d->B * d->H * d->dh * lk_pad * 2;
+  int qf, sp;
+  attn_dma_plan(*d, &qf, &sp);
+  const long long vt_bytes = (long long)d->B * d->H * d->dh * lk_pad * 2;
+  const long long part_bytes = sp > 1 ? (long long)sp * d->B * d->H * d->Lq * (d->dh + 4) * 4 : 0;
+  return ((vt_bytes + 255) & ~255LL) + part_bytes;
 }
 
-template <int DH>
-static void launch_attn_dma(const GmAttnDesc& d, bf16_raw* vt, int lk_pad, hipStream_t st) {
+template <int DH, int QF>
+static void launch_attn_dma(const GmAttnDesc& d, bf16_raw* vt, int lk_pad, float* part, int nsplit, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = attn_dma_kernel<DH>;
+  // waves per SIMD the register allocation must leave room for: the LDS footprint (2 x 512 x DH bytes) admits 160 KiB / that many
+  // 8-wave work-groups per CU
+  constexpr int MINW = (DH == 256 || QF == 2) ? 2 : 4;
+  auto kern = attn_dma_kernel<DH, QF, MINW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  dim3 grid((d.Lq + 127) / 128, d.B * d.H);
-  kern<<<grid, 512, (size_t)2 * (64 * DH * 2 + DH * 128), st>>>(d, vt, lk_pad);
+  dim3 grid((d.Lq + 128 * QF - 1) / (128 * QF), d.B * d.H, nsplit);
+  kern<<<grid, 512, (size_t)2 * (64 * DH * 2 + DH * 128), st>>>(d, vt, lk_pad, nsplit > 1 ? part : nullptr);
 }
 
 // returns 1 if the LDS-DMA path was launched, 0 if the caller should use the register-staged kernel
@@ -252,11 +372,21 @@ extern "C" int gm_attention_dma_try(const GmAttnDesc* dp, void* stream) {
   if (!attn_dma_eligible(d) || !d.workspace || d.workspace_bytes < gm_attention_workspace_bytes(dp)) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int lk_pad = (d.Lk + 63) / 64 * 64;
+  int qf, sp;
+  attn_dma_plan(d, &qf, &sp);
   bf16_raw* vt = reinterpret_cast<bf16_raw*>(d.workspace);
+  const long long vt_bytes = (long long)d.B * d.H * d.dh * lk_pad * 2;
+  float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(d.workspace) + ((vt_bytes + 255) & ~255LL));
   dim3 pg(lk_pad / 64, d.dh / 64, d.B * d.H);
   vt_pack_kernel<<<pg, 256, 0, st>>>(reinterpret_cast<const bf16_raw*>(d.v), d.v_ld, vt, d.H, d.Lk, lk_pad, d.dh);
-  if (d.dh == 64) launch_attn_dma<64>(d, vt, lk_pad, st);
-  else if (d.dh == 128) launch_attn_dma<128>(d, vt, lk_pad, st);
-  else launch_attn_dma<256>(d, vt, lk_pad, st);
+  if (d.dh == 64) { if (qf == 2) launch_attn_dma<64, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<64, 1>(d, vt, lk_pad, part, sp, st); }
+  else if (d.dh == 128) { if (qf == 2) launch_attn_dma<128, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<128, 1>(d, vt, lk_pad, part, sp, st); }
+  else { if (qf == 2) launch_attn_dma<256, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<256, 1>(d, vt, lk_pad, part, sp, st); }
+  if (sp > 1) {
+    const long long items = (long long)d.B * d.H * d.Lq * (d.dh / 8);
+    long long g = (items + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    attn_combine_kernel<<<(unsigned)g, 256, 0, st>>>(d, part, sp);
+  }
   return 1;
 }

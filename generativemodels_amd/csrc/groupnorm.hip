@@ -281,7 +281,7 @@ extern "C" int gm_gn_finalize_channels(const double* stats0, int S0, int C0, con
   GM_LAUNCH_CHECK();
 }
 
-// y[n, v, c] = act(x[n, v, c] * scale[n, c] + shift[n, c]);  act: 0 none, 1 SiLU
+// y[n, v, c] = act(x[n, v, c] * scale[n, c] + shift[n, c]);  act: 0 none, 1 SiLU, 2 ReLU
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y,
                                                       long long y_ld, const float* __restrict__ scale,
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const long long n = row / V;
     float v = ElemIO<T>::ld(x + row * x_ld + c) * scale[n * ss_ld + c] + shift[n * ss_ld + c];
     if (act == 1) v = gm_silu_precise(v);
+    else if (act == 2) v = fmaxf(v, 0.f);
     ElemIO<T>::st(y + row * y_ld + c, v);
   }
 }
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__
     for (int k = 0; k < VEC; ++k) {
       float t = v[k] * sc[k] + sh[k];
       if (act == 1) t = sizeof(T) == 4 ? gm_silu_precise(t) : gm_silu(t);
+      else if (act == 2) t = fmaxf(t, 0.f);
       v[k] = t;
     }
     if (sizeof(T) == 4) {

@@ -504,11 +504,15 @@ def gn_scale_shift_composed(x, groups: int, eps: float, gamma: Optional[torch.Te
 # Measured on MI355X (tools/bench_conv.py): the in-kernel prologue is applied to every halo row (2.1-2.5x redundant) on the VALU
 # while the work-group's MFMAs wait, and costs ~3x the HBM-bound pass; "auto" therefore un-fuses for large bf16 tensors.
 GN_APPLY_POLICY = "auto"
-# The LDS-DMA 3x3x3 kernels apply the prologue IN LDS to the landed patch (csrc/conv_dma.hip: transform_patch): no activated tensor in
-# HBM and no extra pass; a convolution they cover takes this form whenever the flag is on (the policy above then only governs the
-# register-staged kernels).  They also read a VirtualCat's two parts directly (GmConvDesc.x2), so the decoder's concatenated, activated
-# conv1 operand is never assembled either.
-DMA_FUSED_PROLOGUE = os.environ.get("GM_DMA_FUSED_PROLOGUE", "1") != "0"  # (the env switch exists for A/B measurements)
+# The LDS-DMA 3x3x3 kernels can apply the prologue IN LDS to the landed patch (csrc/conv_dma.hip: transform_patch; they then also read a
+# VirtualCat's two parts in place, GmConvDesc.x2): no activated tensor in HBM, no extra pass, one launch less.  Measured on MI355X
+# (profiles/r02_gn_prologue_ab.txt): the transform runs between the patch wait and the barrier of every K chunk, where it is exposed --
+# both work-groups of a CU are then short of MFMA work -- and costs what the HBM-bound pass costs (64->64 at 128^3: 0.60 ms fused vs
+# 0.48 + 0.11 two-pass) or more (deep K: 384->128 at 64^3 0.67 vs 0.54 + 0.08).  It wins where launches, not bytes, set the time: the
+# policy "auto" fuses convolutions below DMA_FUSED_PROLOGUE_MAX_FLOP (the 32^3 / 16^3 / 8^3 levels of the latent UNet: 4.95 -> 4.3 ms per
+# forward) and keeps the two-pass form above.  "always" / "never" pin it (A/B measurements, tests).
+DMA_FUSED_PROLOGUE = os.environ.get("GM_DMA_FUSED_PROLOGUE", "auto")
+DMA_FUSED_PROLOGUE_MAX_FLOP = 3.0e10
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
 
 
@@ -898,8 +902,10 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     # (2) else the operand is first reduced to ONE activated tensor where needed (two_pass: gn_apply passes, 1x1 shortcut launches), and
     # (3) the register-staged / generic kernels take what is left, with their own fused prologue for small tensors.
     dma_ok = False
+    fuse_in_lds = pre is None or DMA_FUSED_PROLOGUE in (True, "always", "1") or (
+        DMA_FUSED_PROLOGUE == "auto" and 2.0 * n * nvox * cout * cin * math.prod(k) <= DMA_FUSED_PROLOGUE_MAX_FLOP)
     if force_cfg is not None and force_cfg in DMA_CFGS or (force_cfg is None and DMA_CONV and cout > 16 and nvox * n >= DMA_CONV_MIN_VOXELS
-                                                            and (pre is None or DMA_FUSED_PROLOGUE)):
+                                                            and fuse_in_lds):
         try:
             _choose_conv_cfg(d, nvox, force_cfg, only=DMA_CFGS)
             dma_ok = True
@@ -910,6 +916,9 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             raise ValueError(f"configuration {force_cfg} does not cover this convolution")
         if x2 is not None:
             return two_pass()  # only the LDS-DMA kernels read a concatenated input in place
+        if pre is not None and force_cfg is None and cout > 16 and math.prod(k) > 1 and not fuse_gn_prologue(x):
+            return two_pass()  # a large ResnetBlock convolution: the HBM-bound gm_gn_apply pass + the prologue-free kernel (which still fuses
+            # the shortcut) beats both the in-LDS and the register-staged prologue (GN_APPLY_POLICY, DMA_FUSED_PROLOGUE)
         if skip is not None:
             # the shortcut as 1x1 launches over the parts first, added as the residual (`res` is None: the shortcut IS the residual)
             parts, sw, sb = skip
@@ -924,9 +933,6 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                         upsample=upsample, transposed=transposed, output_padding=output_padding, pre=pre, pre_act=pre_act,
                         rowvec=rowvec, res=acc_t, post_act=post_act, out=out, packed=packed, cout=cout, force_cfg=force_cfg,
                         want_stats=want_stats)
-        if pre is not None and force_cfg is None and cout > 16 and math.prod(k) > 1 and not fuse_gn_prologue(x):
-            return two_pass()  # a ResnetBlock convolution the LDS-DMA prologue does not cover (2-D, ragged channels, flag off) on a large
-            # tensor: the HBM-bound gm_gn_apply pass + a prologue-free kernel beats the register-staged prologue (GN_APPLY_POLICY)
         _choose_conv_cfg(d, nvox, force_cfg, exclude=DMA_CFGS if force_cfg is None else ())
     d.stats = None
     if want_stats:  # the fast kernels fuse the output statistics into their epilogue (else: one stand-alone pass when a consumer asks)

@@ -201,6 +201,9 @@ typedef struct GmAttnDesc {
 int gm_attention_max_head_dim(void);
 /* bytes of scratch the fastest kernel for this geometry wants (0: none; the descriptor's workspace fields are not read) */
 long long gm_attention_workspace_bytes(const GmAttnDesc* d);
+/* Tests / benchmarks only: pin the LDS-DMA kernel variant -- queries per wave = 16 * qf (qf 1 or 2) and the number of key slices of the
+ * split-KV form (1..8) -- instead of the size-based choice; 0 restores the automatic choice for that knob.  Process-wide. */
+void gm_attention_dma_set_variant(int qf, int nsplit);
 int gm_attention_forward(const GmAttnDesc* d, void* stream);
 
 /* ---- autoregressive transformer helpers (networks/nets/transformer.py, inferers/inferer.py:1126-1330) ------------------------ */

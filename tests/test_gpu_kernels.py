@@ -317,8 +317,8 @@ def test_conv_lds_dma_in_lds_prologue_matches_the_two_pass_form_bitwise(case, cf
     assert torch.equal(fused, two), f"fused prologue differs from the two-pass form: {(fused.float() - two.float()).abs().max().item():.3e}"
     assert torch.equal(fused._gm_cstats, two._gm_cstats)
     keep = ops.DMA_FUSED_PROLOGUE
-    try:  # the automatic choice, flag on and off, computes the same function (possibly on another kernel: not bitwise)
-        for flag in (True, False):
+    try:  # the automatic choice under every policy computes the same function (possibly on another kernel: not bitwise)
+        for flag in ("always", "never", "auto"):
             ops.DMA_FUSED_PROLOGUE = flag
             auto = ops.conv(operand, w.to(DEV), b.to(DEV), **kw)
             assert (auto.float() - two.float()).abs().max().item() <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, two.float().abs().max().item())
@@ -502,11 +502,14 @@ def test_attention(case, dtype):
         _check(got2, want - res.double(), dtype, "attention (sliced qkv)")
 
 
+@pytest.mark.parametrize("variant", [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2), (2, 4), (1, 8)], ids=lambda v: f"qf{v[0]}split{v[1]}")
 @pytest.mark.parametrize("case", [(1, 1, 256, 256, 256), (2, 2, 200, 333, 64), (1, 2, 130, 129, 128), (1, 1, 1000, 700, 256),
-                                  (2, 4, 128, 192, 64)], ids=lambda c: f"B{c[0]}H{c[1]}q{c[2]}k{c[3]}d{c[4]}")
-def test_attention_lds_dma_kernel(case):
+                                  (2, 4, 128, 192, 64), (1, 1, 2100, 2300, 256), (1, 2, 1300, 1100, 128)], ids=lambda c: f"B{c[0]}H{c[1]}q{c[2]}k{c[3]}d{c[4]}")
+def test_attention_lds_dma_kernel(case, variant):
     """attention_dma.hip (bf16, head dims 64/128/256, >= 128 tokens): V transposed once into the scratch image, K / V^T tiles by
-    LDS-DMA with source-side swizzle, ragged query / key counts (zero page + masking), heads as channel slices, residual."""
+    LDS-DMA with source-side swizzle, ragged query / key counts (zero page + masking), heads as channel slices, residual -- for every
+    kernel variant: 16 or 32 queries per wave (qf), 1..8 key slices merged by the split-KV combine kernel (empty slices included:
+    8 slices of a 3-tile sequence), and the size-based automatic choice (0, 0)."""
     ops = _ops()
     b, h, lq, lk, dh = case
     c = h * dh
@@ -521,13 +524,23 @@ def test_attention_lds_dma_kernel(case):
     qd = q.to(DEV)
     d.q = d.k = d.v = d.o = qd.data_ptr()
     d.q_ld = d.k_ld = d.v_ld = d.o_ld = c
-    assert _native.lib().gm_attention_workspace_bytes(d) == b * h * dh * ((lk + 63) // 64 * 64) * 2  # this geometry takes the DMA path
-    got = ops.attention(qd, k.to(DEV), v.to(DEV), h, scale, res=res.to(DEV))
-    _check(got, want, dtype, "attention (LDS-DMA)")
-    if lq == lk:
-        qkv = torch.cat([q, k, v], dim=-1).to(DEV)
-        got2 = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], h, scale)
-        _check(got2, want - res.double(), dtype, "attention (LDS-DMA, sliced qkv)")
+    _native.lib().gm_attention_dma_set_variant(*variant)
+    try:
+        vt_bytes = b * h * dh * ((lk + 63) // 64 * 64) * 2
+        ws = _native.lib().gm_attention_workspace_bytes(d)
+        assert ws >= vt_bytes  # this geometry takes the DMA path (V^T image, plus the slices' partial state when split)
+        if variant[1] > 1:
+            assert ws == (vt_bytes + 255) // 256 * 256 + variant[1] * b * h * lq * (dh + 4) * 4
+        got = ops.attention(qd, k.to(DEV), v.to(DEV), h, scale, res=res.to(DEV))
+        _check(got, want, dtype, f"attention dma {variant}")
+        got_nores = ops.attention(qd, k.to(DEV), v.to(DEV), h, scale)
+        _check(got_nores, want - res.double(), dtype, f"attention dma {variant} without residual")
+        if lq == lk:  # q / k / v as channel slices of one stacked projection buffer (how the blocks call it)
+            qkv = torch.cat([q, k, v], dim=-1).to(DEV)
+            got2 = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], h, scale)
+            _check(got2, want - res.double(), dtype, "attention (LDS-DMA, sliced qkv)")
+    finally:
+        _native.lib().gm_attention_dma_set_variant(0, 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -59,6 +59,10 @@ if [[ $STAGES == *a* ]]; then  # A/B: the same bench with the two-pass GroupNorm
   GM_DMA_FUSED_PROLOGUE=0 timeout 900 python bench.py --steps 2 --warmup 1 --cpu-baseline off > $OUT/r2_bench_twopass.log 2>&1
   echo "bench_twopass rc=$?" >> $LOG; tail -c 2500 $OUT/r2_bench_twopass.log >> $LOG
 fi
+if [[ $STAGES == *n* ]]; then
+  timeout 900 python tools/bench_attention.py > $OUT/r2_attention.log 2>&1
+  echo "attention rc=$?" >> $LOG; cat $OUT/r2_attention.log >> $LOG
+fi
 if [[ $STAGES == *3* ]]; then
   timeout 900 python tools/bench_c3.py > $OUT/r2_c3.log 2>&1
   echo "c3 rc=$?" >> $LOG; tail -c 3000 $OUT/r2_c3.log >> $LOG
