@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_raw* __restrict
 // Split-KV (gridDim.z > 1): work-group z handles the z-th slice of the key tiles and writes its un-normalised O (fp32), running maximum
 // and sum to `part`; attn_combine_kernel merges the slices (the flash-decoding reduction).  One head of 32768 tokens is only 128
 // 256-query tiles -- half the chip -- so the long single-head case of the 3-D UNets runs as 2 slices, short sequences as up to 8.
-template <int DH, int QF, int MINW>
-__global__ __launch_bounds__(512, MINW) void attn_dma_kernel(const GmAttnDesc p, const bf16_raw* __restrict__ vt, int Lk_pad, float* __restrict__ part) {
-  constexpr int KT = 64, KF = KT / 16, NW = 8, QPW = 16 * QF;
+template <int DH, int QF, int NW, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDesc p, const bf16_raw* __restrict__ vt, int Lk_pad, float* __restrict__ part) {
+  constexpr int KT = 64, KF = KT / 16, QPW = 16 * QF;
   constexpr int STEPS = DH / 32;                 // 64-byte k-steps over the head dim
   constexpr int DF = DH / 16;                    // output channel fragments
   constexpr int KROWB = DH * 2;                  // K tile row bytes
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, MINW) void attn_dma_kernel(const GmAttnDesc p,
     // The 64-key tile is consumed in NH slices of KFH key fragments (QF = 2: two 32-key slices, so that the score / probability
     // registers of 32 queries stay at 24 per lane -- the kernel sits at the 256-register limit of two waves per SIMD); each slice is
     // one online-softmax step.
-    constexpr int NH = QF == 2 ? 2 : 1, KFH = KF / NH;
+    constexpr int NH = QF >= 2 ? 2 : 1, KFH = KF / NH;
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
       // ---- S^T = K Q^T: one K fragment read feeds QF MFMAs ------------------------------------------------------------------
@@ -328,14 +328,18 @@ static bool attn_dma_eligible(const GmAttnDesc& d) {
          d.o_ld % 8 == 0 && al(d.o, 16) && (!d.res || (d.res_ld % 8 == 0 && al(d.res, 16)));
 }
 
-// queries per wave (16 * qf) and key slices: 32 queries per wave when the sequence is long enough to amortise its larger tile; as many
-// key slices (powers of two, at least 8 key tiles each) as it takes to put a work-group on every CU
+// Queries per wave (16 * qf) and key slices.  Measured on MI355X (profiles/r02_attention_variants.txt): 32 queries per wave halve the LDS
+// operand reads per MFMA but need 256 registers at head dim 256 (spills inside the tile loop) and run 10-15 % SLOWER than 16 per wave at
+// every shape, so the automatic choice stays at qf = 1; key slices (powers of two, at least 4 key tiles each) are added until every CU has
+// a work-group: 2.7x at 4096 tokens (32 -> 256 work-groups), nothing at 32768.  (Four waves x 64 queries with a SIMD's 512 registers
+// each -- 0.25 reads per MFMA -- does not survive hipcc: 432 spilled registers.)
 static void attn_dma_plan(const GmAttnDesc& d, int* qf, int* nsplit) {
   const long long tiles = ((long long)d.Lk + 63) / 64;
-  int f = gm_attn_dma_force_qf ? gm_attn_dma_force_qf : ((d.Lq >= 1024 && d.Lk >= 1024) ? 2 : 1);
-  const long long nq = (long long)d.B * d.H * ((d.Lq + 128 * f - 1) / (128 * f));
+  const int f = gm_attn_dma_force_qf ? gm_attn_dma_force_qf : 1;
+  const int qpb = 128 * f;
+  const long long nq = (long long)d.B * d.H * ((d.Lq + qpb - 1) / qpb);
   int sp = 1;
-  while (nq * sp < 256 && sp < 8 && tiles / (2 * sp) >= 8) sp *= 2;
+  while (nq * sp < 256 && sp < 8 && tiles / (2 * sp) >= 4) sp *= 2;
   if (gm_attn_dma_force_split) sp = gm_attn_dma_force_split;
   *qf = f; *nsplit = sp;
 }
@@ -350,20 +354,21 @@ extern "C" long long gm_attention_workspace_bytes(const GmAttnDesc* d) {
   return ((vt_bytes + 255) & ~255LL) + part_bytes;
 }
 
-template <int DH, int QF>
+template <int DH, int QF, int NW = 8>
 static void launch_attn_dma(const GmAttnDesc& d, bf16_raw* vt, int lk_pad, float* part, int nsplit, hipStream_t st) {
   static bool attr_set = false;
   // waves per SIMD the register allocation must leave room for: the LDS footprint (2 x 512 x DH bytes) admits 160 KiB / that many
   // 8-wave work-groups per CU
   constexpr int MINW = (DH == 256 || QF == 2) ? 2 : 4;
-  auto kern = attn_dma_kernel<DH, QF, MINW>;
+  auto kern = attn_dma_kernel<DH, QF, NW, MINW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  dim3 grid((d.Lq + 128 * QF - 1) / (128 * QF), d.B * d.H, nsplit);
-  kern<<<grid, 512, (size_t)2 * (64 * DH * 2 + DH * 128), st>>>(d, vt, lk_pad, nsplit > 1 ? part : nullptr);
+  constexpr int QPB = NW * 16 * QF;  // queries per work-group
+  dim3 grid((d.Lq + QPB - 1) / QPB, d.B * d.H, nsplit);
+  kern<<<grid, 64 * NW, (size_t)2 * (64 * DH * 2 + DH * 128), st>>>(d, vt, lk_pad, nsplit > 1 ? part : nullptr);
 }
 
 // returns 1 if the LDS-DMA path was launched, 0 if the caller should use the register-staged kernel

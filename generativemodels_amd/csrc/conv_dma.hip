@@ -266,6 +266,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   if (pre) transform_patch();
   __builtin_amdgcn_s_barrier();
 
+  // debug_flags bit 11 (bench-only A/B, results unaffected): the tap loop runs at wave priority 1, prologue / epilogue at 0, so that the
+  // co-resident work-group's address arithmetic and stores yield issue slots to this one's ds_read / MFMA stream
+  if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(1);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const bool last_chunk = chunk + 1 == nchunks;
 #pragma unroll
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
   }
 
+  if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(0);
   // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
   // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
   // and one piece of the two 4 KiB weight panels into the ring, one wait + barrier, then 2 x 8 MFMAs.

@@ -34,6 +34,7 @@ CASES = [  # name, cin, cout, spatial, features
     ("fp32 64->128@24^3 skip1", 64, 128, (24, 24, 24), dict(skip=(64,), stats=True, fp32=True)),
 ]
 bad = 0
+ops._CONV_DEBUG_FLAGS = int(os.environ.get("CONV_FLAGS", "0"))
 if "--time-only" not in sys.argv:
     for name, cin, cout, sp, f in CASES:
         dt = torch.float32 if f.get("fp32") else torch.bfloat16

@@ -59,6 +59,12 @@ if [[ $STAGES == *a* ]]; then  # A/B: the same bench with the two-pass GroupNorm
   GM_DMA_FUSED_PROLOGUE=0 timeout 900 python bench.py --steps 2 --warmup 1 --cpu-baseline off > $OUT/r2_bench_twopass.log 2>&1
   echo "bench_twopass rc=$?" >> $LOG; tail -c 2500 $OUT/r2_bench_twopass.log >> $LOG
 fi
+if [[ $STAGES == *x* ]]; then  # A/B of conv debug flags (timing only)
+  for FL in 0 2048; do
+    CONV_FLAGS=$FL timeout 600 python tools/check_conv_cfgs.py ${CONV_CFGS:-16} --time-only > $OUT/r2_conv_flags_$FL.log 2>&1
+    echo "conv flags $FL rc=$?" >> $LOG; grep -v amdgpu $OUT/r2_conv_flags_$FL.log >> $LOG
+  done
+fi
 if [[ $STAGES == *n* ]]; then
   timeout 900 python tools/bench_attention.py > $OUT/r2_attention.log 2>&1
   echo "attention rc=$?" >> $LOG; cat $OUT/r2_attention.log >> $LOG
