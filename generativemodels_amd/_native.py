@@ -38,7 +38,7 @@ class GmConvDesc(C.Structure):
                 ("pre_act", C.c_int), ("post_act", C.c_int), ("dtype", C.c_int),
                 ("ltd", C.c_int), ("lth", C.c_int), ("ltw", C.c_int), ("cfg", C.c_int), ("debug_flags", C.c_int), ("stats", c_vp),
                 ("skip_x", c_vp * 2), ("skip_ld", c_ll * 2), ("skip_cin", C.c_int * 2), ("skip_w", c_vp), ("skip_bias", c_vp),
-                ("x2", c_vp), ("x2_ld", c_ll), ("cin_split", C.c_int)]
+                ("x2", c_vp), ("x2_ld", c_ll), ("cin_split", C.c_int), ("ksplit", C.c_int), ("kpartial", c_vp)]
 
 
 class GmDecodeBlock(C.Structure):
@@ -101,11 +101,13 @@ PROTOTYPES = {
     "gm_spade_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_gn_channel_stats": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp, C.c_int, c_vp]),
     "gm_gn_channel_stats_slots": (c_ll, [c_vp, c_ll, c_ll, C.c_int, C.c_int]),
+    "gm_stats_compact": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
     "gm_gn_finalize_channels": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gm_layernorm": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_float, C.c_int, c_vp]),
     "gm_conv_cfg_tile": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gm_conv_lds_bytes": (c_ll, [C.POINTER(GmConvDesc)]),
     "gm_conv_stats_slots": (c_ll, [C.POINTER(GmConvDesc)]),
+    "gm_conv_splitk_workspace_bytes": (c_ll, [C.POINTER(GmConvDesc)]),
     "gm_conv_forward": (C.c_int, [C.POINTER(GmConvDesc), c_vp]),
     "gm_packed_conv_weight_elems": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

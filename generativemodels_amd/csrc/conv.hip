@@ -370,6 +370,94 @@ extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   return pD * pH * pW * CONV_ROWB + 2LL * bn * CONV_ROWB;
 }
 
+// ---- split-K combine: y = act(sum_s partial[s] + bias + skip_bias + timestep row + residual), per-channel output statistics ----------------
+// grid (blocks per sample, N); a block owns SK_ROWS consecutive voxels of one sample; thread = (row in flight r0, 16-byte channel vector cv)
+#define SK_THREADS 256
+#define SK_ITERS 8
+template <typename T>
+__global__ __launch_bounds__(SK_THREADS) void conv_splitk_combine_kernel(const GmConvDesc p, long long V) {
+  constexpr int VECW = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+  const int C = p.Cout, CV = C / VECW, R = SK_THREADS / CV;
+  float* part_s = reinterpret_cast<float*>(sk_smem);  // [R][C]
+  float* part_q = part_s + (size_t)R * C;
+  const int n = blockIdx.y, t = threadIdx.x, cv = t % CV, r0 = t / CV, c = cv * VECW;
+  const long long row_begin = (long long)blockIdx.x * R * SK_ITERS;
+  long long row_end = row_begin + (long long)R * SK_ITERS;
+  if (row_end > V) row_end = V;
+  const long long nv = (long long)p.N * V;
+  float add[VECW], ss[VECW], sq[VECW];
+#pragma unroll
+  for (int i = 0; i < VECW; ++i) {
+    float a = 0.f;
+    if (r0 < R) {
+      if (p.bias) a += p.bias[c + i];
+      if (p.skip_bias) a += p.skip_bias[c + i];
+      if (p.rowvec) a += p.rowvec[(long long)n * p.rowvec_bstride + c + i];
+    }
+    add[i] = a; ss[i] = 0.f; sq[i] = 0.f;
+  }
+  if (r0 < R) {
+    for (long long r = row_begin + r0; r < row_end; r += R) {
+      const long long vox = (long long)n * V + r;
+      float o[VECW];
+#pragma unroll
+      for (int i = 0; i < VECW; ++i) o[i] = add[i];
+      for (int s = 0; s < p.ksplit; ++s) {
+        const float* src = p.kpartial + ((long long)s * nv + vox) * C + c;
+#pragma unroll
+        for (int i = 0; i < VECW; i += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src + i);
+          o[i] += v.x; o[i + 1] += v.y; o[i + 2] += v.z; o[i + 3] += v.w;
+        }
+      }
+      if (p.res) {
+        float rv[VECW];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + vox * p.res_ld + c), rv);
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) o[i] += rv[i];
+      }
+      if (p.post_act) {
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) o[i] = conv_post_act(o[i], p.post_act);
+      }
+      const uint4 raw = Vec16<T>::pack(o);
+      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.y) + vox * p.y_ld + c) = raw;
+      if (p.stats) {  // statistics of the values as stored (rounded to T), like the convolution epilogues
+        Vec16<T>::unpack(raw, o);
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) { ss[i] += o[i]; sq[i] += o[i] * o[i]; }
+      }
+    }
+  }
+  if (!p.stats) return;
+  if (r0 < R) {
+#pragma unroll
+    for (int i = 0; i < VECW; ++i) { part_s[(size_t)r0 * C + c + i] = ss[i]; part_q[(size_t)r0 * C + c + i] = sq[i]; }
+  }
+  __syncthreads();
+  for (int ch = t; ch < C; ch += SK_THREADS) {
+    double a = 0.0, b2 = 0.0;
+    for (int r = 0; r < R; ++r) { a += (double)part_s[(size_t)r * C + ch]; b2 += (double)part_q[(size_t)r * C + ch]; }
+    *reinterpret_cast<double2*>(p.stats + (((long long)blockIdx.x * p.N + n) * C + ch) * 2) = make_double2(a, b2);
+  }
+}
+
+static bool conv_splitk_ok(const GmConvDesc& d) {  // configuration 11 (3x3x3, stride 1), vector epilogue, <= 256 channel vectors per row
+  const int vecw = d.dtype == GM_F32 ? 4 : 8;
+  return d.cfg == CONV_CFG_DMA && d.ksplit > 1 && d.Cout % vecw == 0 && d.Cout / vecw <= SK_THREADS && d.y_ld % vecw == 0 &&
+         (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 && (!d.res || (d.res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d.res) & 15) == 0)) &&
+         d.ksplit <= d.Cin / (d.dtype == GM_F32 ? 16 : 32) && d.in_mode != 3;
+}
+static long long conv_splitk_rows_per_block(const GmConvDesc& d) {
+  const int vecw = d.dtype == GM_F32 ? 4 : 8;
+  return (long long)(SK_THREADS / (d.Cout / vecw)) * SK_ITERS;
+}
+extern "C" long long gm_conv_splitk_workspace_bytes(const GmConvDesc* d) {
+  if (!d || !conv_splitk_ok(*d)) return 0;
+  return (long long)d->ksplit * d->N * d->Do * d->Ho * d->Wo * d->Cout * (long long)sizeof(float);
+}
+
 // Number S of per-tile partials a launch with this descriptor (tile configuration chosen) writes into GmConvDesc.stats, laid out
 // [S][N][Cout][2] fp64 -- or 0 when this configuration does not fuse the output statistics (generic kernels, the C_out = 1 head, a
 // ragged channel count that takes the scalar epilogue): the caller then runs gm_gn_channel_stats over the stored tensor instead.
@@ -381,6 +469,10 @@ extern "C" long long gm_conv_stats_slots(const GmConvDesc* d) {
   const bool lds_epilogue = (d->Cout % vecw == 0) && (d->y_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0) &&
                             (!d->res || ((d->res_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->res) & 15) == 0)));
   if (!lds_epilogue) return 0;
+  if (d->ksplit > 1 && d->kpartial && conv_splitk_ok(*d)) {  // split-K: the combine kernel writes one partial per block of rows
+    const long long rpb = conv_splitk_rows_per_block(*d), V = (long long)d->Do * d->Ho * d->Wo;
+    return (V + rpb - 1) / rpb;
+  }
   const bool subpixel = d->cfg == 17;
   const long long De = subpixel ? d->Ds : d->Do, He = subpixel ? d->Hs : d->Ho, We = subpixel ? d->Ws : d->Wo;
   const long long ntd = (De + (1 << d->ltd) - 1) >> d->ltd, nth = (He + (1 << d->lth) - 1) >> d->lth, ntw = (We + (1 << d->ltw) - 1) >> d->ltw;
@@ -418,7 +510,9 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   const long long De = subpixel ? d.Ds : d.Do, He = subpixel ? d.Hs : d.Ho, We = subpixel ? d.Ws : d.Wo;
   const long long ntd = (De + (1 << d.ltd) - 1) >> d.ltd, nth = (He + (1 << d.lth) - 1) >> d.lth, ntw = (We + (1 << d.ltw) - 1) >> d.ltw;
   const long long ncb = (d.Cout + bn - 1) / bn;
-  const long long nblocks = (long long)d.N * ntd * nth * ntw * ncb * (subpixel ? 8 : 1);
+  const bool splitk = d.ksplit > 1 && d.kpartial != nullptr;
+  GM_REQUIRE(!splitk || conv_splitk_ok(d), "split-K needs configuration 11, a vector epilogue and ksplit <= the number of K chunks");
+  const long long nblocks = (long long)d.N * ntd * nth * ntw * ncb * (subpixel ? 8 : 1) * (splitk ? d.ksplit : 1);
   GM_REQUIRE(nblocks < (1LL << 31), "grid too large");
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -430,6 +524,14 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   if (dma) {
     rc = gm_conv_dma_launch(dp, (unsigned)nblocks, stream);
     GM_REQUIRE(rc == 0, "unsupported dtype");
+    if (splitk) {  // the slices' partial sums -> output (+ bias / row / residual / activation / statistics)
+      const long long V = (long long)d.Do * d.Ho * d.Wo, rpb = conv_splitk_rows_per_block(d);
+      const int vecw = d.dtype == GM_F32 ? 4 : 8;
+      const size_t smem2 = (size_t)(SK_THREADS / (d.Cout / vecw)) * d.Cout * 2 * sizeof(float);
+      dim3 grid((unsigned)((V + rpb - 1) / rpb), (unsigned)d.N);
+      if (d.dtype == GM_F32) conv_splitk_combine_kernel<float><<<grid, SK_THREADS, smem2, st>>>(d, V);
+      else conv_splitk_combine_kernel<bf16_raw><<<grid, SK_THREADS, smem2, st>>>(d, V);
+    }
     GM_LAUNCH_CHECK();
   }
   if (fast) {

@@ -38,6 +38,10 @@ struct GmConvDesc {
   // optional second input source (LDS-DMA kernels only): the input is the channel concatenation cat(x[..., :cin_split], x2) of two
   // tensors in the same geometry -- torch.cat([h, skip], dim=1) of the decoder blocks, never materialised.  cin_split % BK == 0.
   const void* x2; long long x2_ld; int cin_split;
+  // optional split-K (LDS-DMA 3x3x3 stride-1 kernels, small grids): the K chunks are dealt to `ksplit` work-groups per tile, each
+  // writing its fp32 partial accumulators to kpartial[ks][n * V + voxel][Cout]; gm_conv_forward then runs the combine kernel (sum of the
+  // slices + bias / timestep row / residual / activation / output statistics).  ksplit <= 1: off.
+  int ksplit; float* kpartial;
 };
 
 // slot count of the zero-initialised, atomically accumulated statistic tables the BACKWARD kernels still use ([GM_STAT_SLOTS][N][C][2];

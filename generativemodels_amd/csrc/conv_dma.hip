@@ -93,6 +93,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const int ntd = (Dt + TD - 1) / TD, nth = (Ht + TH - 1) / TH, ntw = (Wt + TW - 1) / TW;
   const int ncb = (p.Cout + BN - 1) / BN;
   unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+  // split-K (small grids): the grid holds ksplit copies of the tile list; copy ks computes K chunks [c_begin, c_end) only
+  const int ksplit = (KS == 3 && S == 1 && p.kpartial && p.ksplit > 1) ? p.ksplit : 1;
+  const unsigned tiles_all = gridDim.x / (unsigned)ksplit;
+  const int ks = (int)(b / tiles_all);
+  b -= (unsigned)ks * tiles_all;
   const int cb = b % ncb; b /= ncb;
   const unsigned tile_id = b;  // ((n, td, th, tw)[, parity]): the statistics slot of this work-group is tile_id modulo the tiles per sample
   int par = 0;
@@ -109,7 +114,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
             uw0 = ow0 * S - (KS == 2 ? 1 - (par & 1) : p.pw);
   const int nchunks = p.Cin / BK;                          // host-checked: Cin % BK == 0
   const int cout_pad = (p.Cout + 15) & ~15;
-  const int total = nchunks * NGROUPS;
+  const int cps = (nchunks + ksplit - 1) / ksplit;         // chunks per K slice (host: ksplit <= nchunks, so no slice is empty)
+  const int c_begin = ks * cps, c_end = min(nchunks, c_begin + cps);
+  const int total = (c_end - c_begin) * NGROUPS;
 
   // ---- per-lane DMA sources ---------------------------------------------------------------------------------------------
   // patch piece j of this wave covers LDS rows 16*(wave + NW*j) .. +15; lane -> (row, LDS slot lane&3) <- channel slot swizzled
@@ -258,10 +265,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   // ---- main loop ----------------------------------------------------------------------------------------------------------
-  issue_patch(0);
-  issue_w(0, 0);
-  if (total > 1) issue_w(1, 1);
-  if (pre) load_affine(0);
+  issue_patch(c_begin);
+  issue_w(c_begin * NGROUPS, 0);
+  if (total > 1) issue_w(c_begin * NGROUPS + 1, 1);
+  if (pre) load_affine(c_begin);
   dma_wait<0>();
   if (pre) transform_patch();
   __builtin_amdgcn_s_barrier();
@@ -269,8 +276,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   // debug_flags bit 11 (bench-only A/B, results unaffected): the tap loop runs at wave priority 1, prologue / epilogue at 0, so that the
   // co-resident work-group's address arithmetic and stores yield issue slots to this one's ds_read / MFMA stream
   if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(1);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const bool last_chunk = chunk + 1 == nchunks;
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const bool last_chunk = chunk + 1 == c_end;
 #pragma unroll
     for (int g = 0; g < NGROUPS; ++g) {
       const int t = chunk * NGROUPS + g;
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
   // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
   // and one piece of the two 4 KiB weight panels into the ring, one wait + barrier, then 2 x 8 MFMAs.
-  if (p.skip_x[0]) {
+  if (p.skip_x[0] && ks == ksplit - 1) {  // (split-K: the shortcut's chunks ride with the last K slice)
     const int nsc0 = p.skip_cin[0] / BK, nsc = nsc0 + (p.skip_x[1] ? p.skip_cin[1] / BK : 0);
     int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
 #pragma unroll
@@ -397,6 +404,27 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         }
       }
     }
+  }
+
+  // ---- split-K: this slice's fp32 partial sums -> kpartial[ks][n * V + voxel][Cout]; the combine kernel applies the epilogue ----------
+  if (KS == 3 && S == 1 && ksplit > 1) {
+    const long long nv = (long long)p.N * p.Do * p.Ho * p.Wo;
+    float* part = p.kpartial + (long long)ks * nv * p.Cout;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int m = (wave * MF + mf) * 16 + l15;
+      const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+      if (od < p.Do && oh < p.Ho && ow < p.Wo) {
+        float* row = part + ((((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout;
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) {
+          const int co = cb * BN + nf * 16 + q * 4;
+          if (co < p.Cout)  // host-checked: Cout % 4 == 0
+            *reinterpret_cast<float4*>(row + co) = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
+        }
+      }
+    }
+    return;
   }
 
   // ---- epilogue (shared with conv_fast): LDS transpose -> 16-byte row stores, fused GroupNorm statistics -------------------

@@ -465,6 +465,19 @@ def channel_stats(x: torch.Tensor) -> torch.Tensor:
     return st
 
 
+STATS_COMPACT_ABOVE = 256  # tables with more partials than this are folded to STAT_SLOTS rows right after they are produced
+
+
+def _compact_stats(st: torch.Tensor) -> torch.Tensor:
+    """[S, N, C, 2] -> [64, N, C, 2] (fixed-order fold, gm_stats_compact) when S is large: every later consumer then reads a small table."""
+    s_, n, c, _ = st.shape
+    if s_ <= STATS_COMPACT_ABOVE:
+        return st
+    out = torch.empty((STAT_SLOTS, n, c, 2), dtype=torch.float64, device=st.device)
+    check(lib().gm_stats_compact(st.data_ptr(), s_, n, c, out.data_ptr(), _stream()), "gm_stats_compact")
+    return out
+
+
 def _fresh_channel_stats(x: torch.Tensor) -> torch.Tensor:
     require_device(x)
     n, c = x.shape[0], x.shape[-1]
@@ -476,7 +489,7 @@ def _fresh_channel_stats(x: torch.Tensor) -> torch.Tensor:
     _timed(f"gn_stats<{str(x.dtype).split('.')[-1]}>", dict(flops=0.0, bytes=float(x.element_size() * x.numel()), shape=f"N{n} V{v} C{c}"),
            lambda: check(lib().gm_gn_channel_stats(x.data_ptr(), arena_ld(x), n, v, c, st.data_ptr(), dt_code(x.dtype), _stream()),
                          "gm_gn_channel_stats"))
-    return st
+    return _compact_stats(st)
 
 
 def gn_scale_shift_composed(x, groups: int, eps: float, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor]):
@@ -513,6 +526,13 @@ GN_APPLY_POLICY = "auto"
 # forward) and keeps the two-pass form above.  "always" / "never" pin it (A/B measurements, tests).
 DMA_FUSED_PROLOGUE = os.environ.get("GM_DMA_FUSED_PROLOGUE", "auto")
 DMA_FUSED_PROLOGUE_MAX_FLOP = 3.0e10
+# Split-K for small grids (GmConvDesc.ksplit): a 3x3x3 convolution over a 32^3 .. 8^3 latent has fewer 256-voxel x 64-channel tiles than the
+# chip has CUs, and each tile is a serial chain of K chunks with an exposed LDS-DMA round trip per chunk (256 input channels = 8 chunks:
+# ~35 us for 0.3 us of arithmetic).  Below SPLITK_MAX_TILES work-groups the chunks are dealt to up to SPLITK_MAX slices per tile; a combine
+# kernel sums the fp32 partials and applies the epilogue.
+SPLITK = os.environ.get("GM_CONV_SPLITK", "1") != "0"
+SPLITK_MAX_TILES = 128
+SPLITK_MAX = 8
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
 
 
@@ -711,6 +731,8 @@ def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, c
            dict(flops=2.0 * nvo * cout * cin * 8, bytes=float(es * (n * math.prod(src) * cin + nvo * cout * (2 if res is not None else 1) + 8 * cout * cin * 8)),
                 shape=f"{cin}->{cout} k(3, 3, 3) s(1, 1, 1) out{out_sp} mode3 (executed flops: 8 of the 27 taps)"),
            lambda: check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward"))
+    if d.stats:
+        out._gm_cstats = _compact_stats(out._gm_cstats)
     return out
 
 
@@ -719,7 +741,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
          pre: Optional[tuple] = None, pre_act: str = "none", rowvec: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, post_act: str = "none", out: Optional[torch.Tensor] = None,
          packed: Optional[torch.Tensor] = None, cout: Optional[int] = None, force_cfg: Optional[int] = None,
-         want_stats: bool = False, skip: Optional[tuple] = None, allow_subpixel: bool = True) -> torch.Tensor:
+         want_stats: bool = False, skip: Optional[tuple] = None, allow_subpixel: bool = True, ksplit: Optional[int] = None) -> torch.Tensor:
     """Fused convolution over an arena tensor x = (N, *spatial, Cin) -- or over a VirtualCat of two (their channel concatenation).
 
     kernel/stride/padding/dilation: int or per-axis tuples (len = number of spatial axes). `padding` is the low-side pad,
@@ -757,7 +779,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             off += c_t
         return conv(xa, weight, bias, kernel=kernel, stride=stride, padding=padding, dilation=dilation, pad_hi=pad_hi, upsample=upsample,
                     transposed=transposed, output_padding=output_padding, rowvec=rowvec, res=res, post_act=post_act, out=out, packed=packed,
-                    cout=cout, force_cfg=force_cfg, want_stats=want_stats, skip=skip, allow_subpixel=allow_subpixel)
+                    cout=cout, force_cfg=force_cfg, want_stats=want_stats, skip=skip, allow_subpixel=allow_subpixel, ksplit=ksplit)
 
     def tup(v):
         v = tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * nsp
@@ -934,6 +956,21 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                         rowvec=rowvec, res=acc_t, post_act=post_act, out=out, packed=packed, cout=cout, force_cfg=force_cfg,
                         want_stats=want_stats)
         _choose_conv_cfg(d, nvox, force_cfg, exclude=DMA_CFGS if force_cfg is None else ())
+    kpart = None
+    if dma_ok and d.cfg == 11 and (ksplit is not None or SPLITK):
+        nchunks = cin // (64 // x.element_size())
+        tiles = n * ((out_sp[0] + 3) // 4) * ((out_sp[1] + 3) // 4) * ((out_sp[2] + 15) // 16) * ((cout + 63) // 64)
+        ks = ksplit if ksplit is not None else (min(nchunks, SPLITK_MAX, 256 // tiles) if tiles < SPLITK_MAX_TILES else 1)
+        if ks > 1:
+            d.ksplit = int(ks)
+            nbytes = lib().gm_conv_splitk_workspace_bytes(C.byref(d))
+            if nbytes > 0:
+                kpart = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)  # stream-ordered scratch: freed on return
+                d.kpartial = kpart.data_ptr()
+            elif ksplit is not None:
+                raise ValueError(f"split-K by {ks} is not available for this convolution")
+            else:
+                d.ksplit = 0
     d.stats = None
     if want_stats:  # the fast kernels fuse the output statistics into their epilogue (else: one stand-alone pass when a consumer asks)
         _attach_conv_stats(d, out, n, cout)
@@ -947,8 +984,10 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
         meta = dict(flops=2.0 * nvo * cout * (cin * taps + scin),
                     bytes=float(es * (n * math.prod(src) * cin + nvo * (cout * (2 if res is not None else 1) + scin) + cout * (cin * taps + scin))),
                     shape=f"{cin}->{cout} k{k} s{conv_stride} out{tuple(out_sp)} mode{d.in_mode}")
-        _timed(f"conv_igemm<{str(dtype).split('.')[-1]},cfg{d.cfg}>", meta,
+        _timed(f"conv_igemm<{str(dtype).split('.')[-1]},cfg{d.cfg}{'' if d.ksplit <= 1 else 'k'}>", meta,
                lambda: check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward"))
+    if d.stats:
+        out._gm_cstats = _compact_stats(out._gm_cstats)
     return out
 
 

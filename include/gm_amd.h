@@ -121,6 +121,9 @@ int gm_spade_apply(const void* x, long long x_ld, void* y, long long y_ld, const
  * channel-concatenated sources (S0 / S1 partials each) -- torch.cat([h, skip]) followed by GroupNorm (diffusion_model_unet.py:1232 + 671)
  * without ever materialising the concatenation. */
 long long gm_gn_channel_stats_slots(const void* x, long long ld, long long V, int C, int dtype);
+/* fold a long table [S][N][C][2] (S >= 64: one partial per tile of a large volume) to [64][N][C][2] in a fixed order, so that the
+ * per-group finalisation reads a small table */
+int gm_stats_compact(const double* stats_in, int S, int N, int C, double* stats_out, void* stream);
 int gm_gn_channel_stats(const void* x, long long ld, int N, long long V, int C, double* chan_out, int dtype, void* stream);
 int gm_gn_finalize_channels(const double* stats0, int S0, int C0, const double* stats1, int S1, int C1, int N, long long V, int G, float eps,
                             const float* gamma, const float* beta, float* scale, float* shift, void* stream);
@@ -171,11 +174,18 @@ typedef struct GmConvDesc {
    * -- the decoder's torch.cat([h, skip], dim=1) (diffusion_model_unet.py:1232,1340,1461), never materialised; x2 in x's geometry,
    * cin_split a multiple of the 64-byte K chunk (32 bf16 / 16 fp32 channels); Cin counts both parts */
   const void* x2; long long x2_ld; int cin_split;
+  /* optional split-K for small grids (LDS-DMA 3x3x3 stride-1 configurations): a convolution over a 32^3 .. 8^3 latent has fewer tiles
+   * than the chip has CUs and every tile is a serial chain of K chunks (exposed LDS-DMA round trips), so the chunks are dealt to
+   * `ksplit` work-groups per tile that write fp32 partial sums to `kpartial` (gm_conv_splitk_workspace_bytes) and a combine kernel
+   * applies the epilogue (bias, timestep row, residual, activation, output statistics).  ksplit <= 1 or kpartial NULL: off. */
+  int ksplit; float* kpartial;
 } GmConvDesc;
 int gm_conv_cfg_tile(int cfg, int* voxels, int* channels);
 long long gm_conv_lds_bytes(const GmConvDesc* d);
 /* partials S a launch writes into GmConvDesc.stats ([S][N][Cout][2]); 0 = this configuration does not fuse the output statistics */
 long long gm_conv_stats_slots(const GmConvDesc* d);
+/* bytes of GmConvDesc.kpartial for this descriptor (ksplit set); 0 when the configuration does not support split-K */
+long long gm_conv_splitk_workspace_bytes(const GmConvDesc* d);
 int gm_conv_forward(const GmConvDesc* d, void* stream);
 long long gm_packed_conv_weight_elems(int Cout, int Cin, int kd, int kh, int kw, int dtype);
 /* src: [Cout][Cin][kd][kh][kw] (transposed = 0) or [Cin][Cout][kd][kh][kw] (transposed = 1, nn.ConvTransposeNd) */

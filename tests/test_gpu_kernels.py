@@ -333,6 +333,61 @@ def test_conv_lds_dma_in_lds_prologue_matches_the_two_pass_form_bitwise(case, cf
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ksplit", [2, 3, 8])
+@pytest.mark.parametrize("case", [("res", 256, 256, None, (8, 8, 8), "res", 2), ("skip-cat", 384, 136, 256, (7, 9, 17), "skip", 1),
+                                  ("pre", 128, 64, None, (16, 16, 16), "pre", 1)], ids=lambda c: c[0] if isinstance(c, tuple) else str(c))
+def test_conv_split_k_for_small_grids(case, ksplit, dtype):
+    """GmConvDesc.ksplit: the K chunks of a small-grid 3x3x3 convolution dealt to several work-groups per tile + the combine kernel (sum of
+    the fp32 slices, bias / timestep row / residual or fused shortcut, output statistics) against the unsplit kernel and fp64 -- with the
+    in-LDS prologue and a two-part (virtual concat) input as well; also the automatic choice (ops.SPLITK_MAX_TILES)."""
+    ops = _ops()
+    name, cin, cout, split, sp, mode, n = case
+    es = 4 if dtype == torch.float32 else 2
+    if ksplit > cin // (64 // es):
+        pytest.skip("more slices than K chunks")
+    x = _rand((n, cin, *sp), 271).to(dtype)
+    w = (_rand((cout, cin, 3, 3, 3), 272) / math.sqrt(cin * 27)).to(dtype)
+    b, temb = _rand((cout,), 273) * 0.1, _rand((n, cout), 274) * 0.5
+    xa = _cl(x)
+    operand = xa if split is None else ops.VirtualCat([xa[..., :split].contiguous(), xa[..., split:].contiguous()])
+    kw = dict(kernel=3, padding=1, rowvec=temb.to(DEV), want_stats=True)
+    xin = x.double()
+    want_extra = 0.0
+    if mode == "res":
+        res = _rand((n, cout, *sp), 275).to(dtype)
+        kw["res"] = _cl(res)
+        want_extra = res.double()
+    elif mode == "skip":
+        sw = (_rand((cout, cin, 1, 1, 1), 276) / math.sqrt(cin)).to(dtype)
+        sb = _rand((cout,), 277) * 0.1
+        kw["skip"] = (list(operand.parts), sw.to(DEV), sb.to(DEV))
+        want_extra = F.conv3d(x.double(), sw.double(), sb.double())
+    else:
+        scale, shift = (_rand((n, cin), 278) * 0.2 + 1.0).to(DEV), (_rand((n, cin), 279) * 0.3).to(DEV)
+        kw.update(pre=(scale, shift), pre_act="silu")
+        xin = F.silu(x.double() * scale.cpu().double().reshape(n, cin, 1, 1, 1) + shift.cpu().double().reshape(n, cin, 1, 1, 1))
+        if dtype == torch.bfloat16:
+            xin = xin.to(torch.bfloat16).double()
+    want = F.conv3d(xin, w.double(), b.double(), padding=1) + temb.double().reshape(n, cout, 1, 1, 1) + want_extra
+    keep = ops.DMA_FUSED_PROLOGUE
+    try:
+        ops.DMA_FUSED_PROLOGUE = "always"
+        whole = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=11, ksplit=1, **kw)
+        sliced = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=11, ksplit=ksplit, **kw)
+        auto = ops.conv(operand, w.to(DEV), b.to(DEV), **kw)
+    finally:
+        ops.DMA_FUSED_PROLOGUE = keep
+    _check(_cf(whole), want, dtype, f"unsplit {name}", extra=2.0)
+    _check(_cf(sliced), want, dtype, f"split-K {name} x{ksplit}", extra=2.0)
+    _check(_cf(auto), want, dtype, f"automatic {name}", extra=2.0)
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -7
+    assert (sliced.float() - whole.float()).abs().max().item() <= tol * max(1.0, whole.float().abs().max().item())
+    v = sliced.float().cpu().double().reshape(n, -1, cout)
+    st = sliced._gm_cstats.sum(0).cpu()
+    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(st[..., 1], (v * v).sum(1), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [("even", 32, 64, (8, 16, 32), 1, 1), ("odd", 64, 40, (9, 11, 37), 1, 1), ("asym", 32, 72, (8, 10, 34), 0, 1)],
                          ids=lambda c: c[0])
 def test_conv_lds_dma_stride2_kernel(case, dtype):
