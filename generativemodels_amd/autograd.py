@@ -23,7 +23,7 @@ import torch
 
 from . import ops
 
-__all__ = ["conv", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
+__all__ = ["conv", "conv_transpose", "sigma_from_log_var", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
 
 
 def _tup(v, n):
@@ -79,6 +79,63 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if x.dim() != 3:
         raise ValueError("linear expects (N, L, C)")
     return _Conv.apply(x, weight, bias, None, res, 1, 1, 0, None)
+
+
+class _ConvTranspose(torch.autograd.Function):
+    """nn.ConvTranspose{2,3}d (weight [Cin, Cout, *k]): AutoencoderKL's `use_convtranspose` up-sampling (autoencoderkl.py:54-63: k3 s2 p1 op1).
+    It is the adjoint of the convolution with the same weight read as [out = Cin, in = Cout]: dx is that convolution applied to gy, and
+    dW the weight gradient of that convolution with the roles of input and output gradient exchanged."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kernel, stride, padding, output_padding):
+        y = ops.conv(x, weight, bias, kernel=kernel, stride=stride, padding=padding, transposed=True, output_padding=output_padding,
+                     want_stats=True)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (kernel, stride, padding)
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        kernel, stride, padding = ctx.geom
+        gy = gy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv(gy, weight, None, kernel=kernel, stride=stride, padding=padding)  # [Cin, Cout, *k] read as a Conv weight
+            if dx.shape != x.shape:
+                raise ValueError(f"transposed-convolution geometry is not invertible: {tuple(dx.shape)} vs {tuple(x.shape)}")
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(gy, x, kernel, stride, padding).reshape(weight.shape).to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            db = ops.bias_grad(gy).to(ctx.bias_dtype)
+        return dx, dw, db, None, None, None, None
+
+
+def conv_transpose(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, kernel, stride, padding,
+                   output_padding=0) -> torch.Tensor:
+    """nn.ConvTransposeNd over an arena tensor (weight [Cin, Cout, *k]); differentiable in x, weight, bias (kernel 3, stride 1 or 2)."""
+    return _ConvTranspose.apply(x, weight, bias, kernel, stride, padding, output_padding)
+
+
+class _SigmaFromLogVar(torch.autograd.Function):
+    """z_sigma = exp(clamp(z_log_var, -30, 20) / 2) (autoencoderkl.py:733-734) on the latent; d sigma / d log_var = sigma / 2 inside the clamp."""
+
+    @staticmethod
+    def forward(ctx, log_var):
+        sigma, _ = ops.aekl_sample(None, log_var)
+        ctx.save_for_backward(log_var, sigma)
+        return sigma
+
+    @staticmethod
+    def backward(ctx, g):
+        log_var, sigma = ctx.saved_tensors
+        inside = ((log_var > -30.0) & (log_var < 20.0)).to(g.dtype)
+        return g * sigma * inside * 0.5  # latent-sized (a few thousand elements): left to torch, like _Embedding's scatter
+
+
+def sigma_from_log_var(log_var: torch.Tensor) -> torch.Tensor:
+    return _SigmaFromLogVar.apply(log_var)
 
 
 class _GroupNormAct(torch.autograd.Function):

@@ -26,6 +26,15 @@ def ensure_tuple_rep(v, n: int) -> tuple:
     return (v,) * n
 
 
+def wants_grad(module: nn.Module, x: torch.Tensor) -> bool:
+    """The reference's forward is differentiable whenever autograd records; here that costs a different (activation-saving) kernel
+    sequence, so it is taken when the caller is evidently training: train() mode (or an input that requires grad), gradients enabled
+    and at least one trainable parameter.  eval() / torch.no_grad() / frozen parameters run the fused inference path."""
+    if not torch.is_grad_enabled() or not (module.training or x.requires_grad):
+        return False
+    return any(p.requires_grad for p in module.parameters())
+
+
 def zero_module(module: nn.Module) -> nn.Module:
     for p in module.parameters():
         p.detach().zero_()

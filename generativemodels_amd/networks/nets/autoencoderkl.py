@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ._blocks import AttentionBlock, ConvP, ResnetBlock, SPADEResnetBlock, ensure_tuple_rep, gn_prologue
+from ._blocks import AttentionBlock, ConvP, ResnetBlock, SPADEResnetBlock, ensure_tuple_rep, gn_prologue, wants_grad
 
 __all__ = ["AutoencoderKL"]
 
@@ -62,6 +62,32 @@ def _run_blocks(blocks: nn.ModuleList, h: torch.Tensor, seg: Optional[torch.Tens
     return h
 
 
+def _run_blocks_train(blocks: nn.ModuleList, h: torch.Tensor) -> torch.Tensor:
+    """The same block list with gradients (generativemodels_amd.autograd: native kernels in both directions) -- what the reference's
+    autoencoder training loops differentiate through torch autograd (tutorials/generative/3d_autoencoderkl, engines/trainer.py:258-270)."""
+    from ... import autograd as A
+
+    for blk in blocks:
+        if isinstance(blk, nn.GroupNorm):
+            h = A.group_norm_act(h, blk.weight, blk.bias, blk.num_groups, blk.eps, "none")  # no SiLU before the last conv (:433-446)
+        elif isinstance(blk, ConvP):
+            h = A.conv(h, blk.conv.weight, blk.conv.bias, kernel=blk.kernel_size, stride=1, padding=blk.padding)
+        elif isinstance(blk, SPADEResnetBlock):
+            raise NotImplementedError("the SPADE decoder is inference-only")
+        elif isinstance(blk, _Down):
+            c = blk.conv
+            h = A.conv(h, c.conv.weight, c.conv.bias, kernel=3, stride=2, padding=0, pad_hi=1)
+        elif isinstance(blk, _Up):
+            c = blk.conv
+            if blk.use_convtranspose:
+                h = A.conv_transpose(h, c.conv.weight, c.conv.bias, kernel=3, stride=2, padding=1, output_padding=1)
+            else:
+                h = A.upsample_conv(h, c.conv.weight, c.conv.bias)
+        else:
+            h = blk.run_train(h)  # ResnetBlock (no timestep path), AttentionBlock
+    return h
+
+
 class Encoder(nn.Module):
     """conv_in, per level [ResBlock (+Attention)] x r and an asymmetric-pad stride-2 conv, optional non-local
     (ResBlock, Attention, ResBlock), GroupNorm, conv to the latent width (reference autoencoderkl.py:315-453)."""
@@ -90,6 +116,9 @@ class Encoder(nn.Module):
 
     def run(self, x):
         return _run_blocks(self.blocks, x)
+
+    def run_train(self, x):
+        return _run_blocks_train(self.blocks, x)
 
 
 class Decoder(nn.Module):
@@ -130,6 +159,9 @@ class Decoder(nn.Module):
     def run(self, x, seg: Optional[torch.Tensor] = None):
         return _run_blocks(self.blocks, x, seg)
 
+    def run_train(self, x):
+        return _run_blocks_train(self.blocks, x)
+
 
 class AutoencoderKL(nn.Module):
     """Drop-in for generative.networks.nets.AutoencoderKL (same arguments, state_dict keys and methods)."""
@@ -158,7 +190,7 @@ class AutoencoderKL(nn.Module):
         self.quant_conv_log_sigma = ConvP(spatial_dims, latent_channels, latent_channels, 1, 1, 0)
         self.post_quant_conv = ConvP(spatial_dims, latent_channels, latent_channels, 1, 1, 0)
         self.latent_channels = latent_channels
-        self.use_checkpointing = use_checkpointing  # accepted for API parity; inference path keeps no activations anyway
+        self.use_checkpointing = use_checkpointing  # accepted for API parity (the training path below saves what its backward kernels read)
 
     def _dtype(self):
         return self.post_quant_conv.conv.weight.dtype
@@ -173,6 +205,13 @@ class AutoencoderKL(nn.Module):
     def encode(self, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """-> (z_mu, z_sigma), sigma = exp(clamp(log_var, -30, 20) / 2) (reference autoencoderkl.py:718-736)."""
         self._check(x)
+        if wants_grad(self, x):  # a training step: differentiable (z_mu, z_sigma), native kernels in both directions
+            from ... import autograd as A
+
+            h = self.encoder.run_train(A.to_arena(x))
+            mu_c, ls_c = self.quant_conv_mu.conv, self.quant_conv_log_sigma.conv
+            z_mu = A.from_arena(A.conv(h, mu_c.weight, mu_c.bias, kernel=1))
+            return z_mu, A.sigma_from_log_var(A.from_arena(A.conv(h, ls_c.weight, ls_c.bias, kernel=1)))
         with torch.no_grad():
             h = self.encoder.run(ops.to_channels_last(x))
             z_mu = ops.to_channels_first(self.quant_conv_mu.run(h))
@@ -184,6 +223,8 @@ class AutoencoderKL(nn.Module):
         """z = mu + eps * sigma, eps ~ N(0, I) from the device generator (reference autoencoderkl.py:738-753)."""
         ops.require_device(z_mu, z_sigma)
         eps = torch.randn_like(z_sigma)
+        if torch.is_grad_enabled() and (z_mu.requires_grad or z_sigma.requires_grad):
+            return z_mu + eps * z_sigma  # the reparameterisation on the (latent-sized) training graph: torch autograd, like the loss
         return ops.addcmul(z_mu, eps, z_sigma)
 
     def reconstruct(self, x: torch.Tensor) -> torch.Tensor:
@@ -193,6 +234,11 @@ class AutoencoderKL(nn.Module):
     def decode(self, z: torch.Tensor) -> torch.Tensor:
         """post_quant_conv -> Decoder (reference autoencoderkl.py:769-784)."""
         self._check(z)
+        if wants_grad(self, z):
+            from ... import autograd as A
+
+            pq = self.post_quant_conv.conv
+            return A.from_arena(self.decoder.run_train(A.conv(A.to_arena(z.contiguous()), pq.weight, pq.bias, kernel=1)))
         with torch.no_grad():
             h = self.post_quant_conv.run(ops.to_channels_last(z))
             return ops.to_channels_first(self.decoder.run(h))

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ._blocks import SPADEResnetBlock, AttentionBlock, ConvP, ResnetBlock, ensure_tuple_rep, gn_prologue, lin, tokens, zero_module
+from ._blocks import SPADEResnetBlock, AttentionBlock, ConvP, ResnetBlock, ensure_tuple_rep, gn_prologue, lin, tokens, wants_grad, zero_module
 
 __all__ = ["DiffusionModelUNet"]
 
@@ -371,9 +371,7 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
         """The reference's forward is differentiable whenever autograd records; here that costs a different (activation-saving) kernel
         sequence, so it is taken when the caller is evidently training: train() mode (or an input that requires grad), gradients enabled and
         at least one trainable parameter."""
-        if not torch.is_grad_enabled() or not (self.training or x.requires_grad):
-            return False
-        return self.supports_training() and any(p.requires_grad for p in self.parameters())
+        return self.supports_training() and wants_grad(self, x)
 
     def _forward_impl(self, x, timesteps, context, class_labels, down_block_additional_residuals, mid_block_additional_residual,
                       seg: torch.Tensor | None = None) -> torch.Tensor:
