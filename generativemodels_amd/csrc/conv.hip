@@ -443,11 +443,17 @@ __global__ __launch_bounds__(SK_THREADS) void conv_splitk_combine_kernel(const G
   }
 }
 
+static bool conv_splitk_no_empty_slice(const GmConvDesc& d) {  // the kernel deals ceil(nchunks / ksplit) chunks to each slice
+  const int nchunks = d.Cin / (d.dtype == GM_F32 ? 16 : 32);
+  if (d.ksplit < 2 || d.ksplit > nchunks) return false;
+  const int cps = (nchunks + d.ksplit - 1) / d.ksplit;
+  return (d.ksplit - 1) * cps < nchunks;
+}
 static bool conv_splitk_ok(const GmConvDesc& d) {  // configuration 11 (3x3x3, stride 1), vector epilogue, <= 256 channel vectors per row
   const int vecw = d.dtype == GM_F32 ? 4 : 8;
   return d.cfg == CONV_CFG_DMA && d.ksplit > 1 && d.Cout % vecw == 0 && d.Cout / vecw <= SK_THREADS && d.y_ld % vecw == 0 &&
          (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 && (!d.res || (d.res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d.res) & 15) == 0)) &&
-         d.ksplit <= d.Cin / (d.dtype == GM_F32 ? 16 : 32) && d.in_mode != 3;
+         conv_splitk_no_empty_slice(d) && d.in_mode != 3;
 }
 static long long conv_splitk_rows_per_block(const GmConvDesc& d) {
   const int vecw = d.dtype == GM_F32 ? 4 : 8;

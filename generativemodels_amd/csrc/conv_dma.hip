@@ -114,9 +114,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
             uw0 = ow0 * S - (KS == 2 ? 1 - (par & 1) : p.pw);
   const int nchunks = p.Cin / BK;                          // host-checked: Cin % BK == 0
   const int cout_pad = (p.Cout + 15) & ~15;
-  const int cps = (nchunks + ksplit - 1) / ksplit;         // chunks per K slice (host: ksplit <= nchunks, so no slice is empty)
-  const int c_begin = ks * cps, c_end = min(nchunks, c_begin + cps);
-  const int total = (c_end - c_begin) * NGROUPS;
+  const int cps = (nchunks + ksplit - 1) / ksplit;         // chunks per K slice (host-checked: (ksplit - 1) * cps < nchunks, no slice is empty)
+  const int c_begin = min(nchunks, ks * cps), c_end = min(nchunks, c_begin + cps);
+  const int total = (c_end - c_begin) * NGROUPS;            // an empty slice (never launched by the host) would touch nothing: total == 0
 
   // ---- per-lane DMA sources ---------------------------------------------------------------------------------------------
   // patch piece j of this wave covers LDS rows 16*(wave + NW*j) .. +15; lane -> (row, LDS slot lane&3) <- channel slot swizzled
@@ -265,12 +265,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   // ---- main loop ----------------------------------------------------------------------------------------------------------
-  issue_patch(c_begin);
-  issue_w(c_begin * NGROUPS, 0);
-  if (total > 1) issue_w(c_begin * NGROUPS + 1, 1);
-  if (pre) load_affine(c_begin);
-  dma_wait<0>();
-  if (pre) transform_patch();
+  if (total > 0) {
+    issue_patch(c_begin);
+    issue_w(c_begin * NGROUPS, 0);
+    if (total > 1) issue_w(c_begin * NGROUPS + 1, 1);
+    if (pre) load_affine(c_begin);
+    dma_wait<0>();
+    if (pre) transform_patch();
+  }
   __builtin_amdgcn_s_barrier();
 
   // debug_flags bit 11 (bench-only A/B, results unaffected): the tap loop runs at wave priority 1, prologue / epilogue at 0, so that the

@@ -962,6 +962,8 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
         tiles = n * ((out_sp[0] + 3) // 4) * ((out_sp[1] + 3) // 4) * ((out_sp[2] + 15) // 16) * ((cout + 63) // 64)
         ks = ksplit if ksplit is not None else (min(nchunks, SPLITK_MAX, 256 // tiles) if tiles < SPLITK_MAX_TILES else 1)
         if ks > 1:
+            ks = -(-nchunks // -(-nchunks // ks))  # ceil(nchunks / chunks per slice): 12 chunks over "8" slices = 6 slices of 2, none empty
+        if ks > 1:
             d.ksplit = int(ks)
             nbytes = lib().gm_conv_splitk_workspace_bytes(C.byref(d))
             if nbytes > 0:
