@@ -531,7 +531,8 @@ DMA_FUSED_PROLOGUE_MAX_FLOP = 3.0e10
 # ~35 us for 0.3 us of arithmetic).  Below SPLITK_MAX_TILES work-groups the chunks are dealt to up to SPLITK_MAX slices per tile; a combine
 # kernel sums the fp32 partials and applies the epilogue.
 SPLITK = os.environ.get("GM_CONV_SPLITK", "1") != "0"
-SPLITK_MAX_TILES = 128
+SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups than this ...
+SPLITK_TARGET_WGS = 512  # ... into as many slices as it takes to reach about this many (two per CU)
 SPLITK_MAX = 8
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
 
@@ -644,6 +645,12 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             order = [12] + order  # taps-as-K kernel of the 1..4-channel input convolutions
     if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
         order = ([15] if desc.sd == 2 else [11]) + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
+        # 512-voxel tiles (16 waves, one work-group per CU, half the weight-panel traffic) measure 4-5 % faster than two 256-voxel
+        # work-groups where the weight stream dominates -- the 32^3 level of C2 (Cin >= 128: 1 004-1 317 vs 968-1 253 TFLOP/s) -- and on
+        # the 64 -> 64 layers at 128^3 (782 vs 747); 3-9 % slower elsewhere (profiles/r02_conv_tile_configs.txt)
+        vox = n_vox_out * desc.N
+        if desc.sd == 1 and ((desc.Cin >= 128 and 16384 < vox <= 65536 and cout >= 256) or (desc.Cin == 64 and cout == 64 and (1 << 21) <= vox < (1 << 23))):
+            order = [16] + order
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups (the LDS-DMA kernels stay first)
         dma_first = [c for c in order if c in (11, 15, 18, 19)]
         rest = [c for c in order if c not in (11, 15, 18, 19)]
@@ -960,7 +967,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     if dma_ok and d.cfg == 11 and (ksplit is not None or SPLITK):
         nchunks = cin // (64 // x.element_size())
         tiles = n * ((out_sp[0] + 3) // 4) * ((out_sp[1] + 3) // 4) * ((out_sp[2] + 15) // 16) * ((cout + 63) // 64)
-        ks = ksplit if ksplit is not None else (min(nchunks, SPLITK_MAX, 256 // tiles) if tiles < SPLITK_MAX_TILES else 1)
+        ks = ksplit if ksplit is not None else (min(nchunks, SPLITK_MAX, SPLITK_TARGET_WGS // tiles) if tiles < SPLITK_MAX_TILES else 1)
         if ks > 1:
             ks = -(-nchunks // -(-nchunks // ks))  # ceil(nchunks / chunks per slice): 12 chunks over "8" slices = 6 slices of 2, none empty
         if ks > 1:
