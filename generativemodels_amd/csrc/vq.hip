@@ -116,3 +116,104 @@ extern "C" int gm_vq_gather(const long long* indices, const float* embedding, vo
   if (sq_err_mean) vq_sum_partials_kernel<<<1, 64, 0, st>>>(part, (int)g, 1.0 / ((double)tokens * dim), sq_err_mean);
   GM_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// EMA codebook update of EMAQuantizer.forward in training mode (reference: networks/layers/vector_quantizer.py:166-180).
+//   gm_vq_ema_stats : stats[e] = number of tokens assigned to code e, stats[K + e*D + d] = sum of their vectors ("encodings_sum" and
+//                     "dw" of the reference, :168-169) -- ONE flat fp32 buffer, so that data-parallel ranks exchange it with ONE
+//                     all-reduce instead of the reference's two (:155-157).  One work-group per code scans the indices; per-thread
+//                     partial sums are merged in a fixed tree order: deterministic.
+//   gm_vq_ema_update: ema_cluster_size = decay * ema_cluster_size + (1 - decay) * counts; Laplace-smoothed weights; ema_w likewise;
+//                     embedding = ema_w / weights (:173-180).  One work-group (the codebook is K x D <= a few hundred thousand floats).
+// ---------------------------------------------------------------------------------------------------------------------
+#define VQ_EMA_THREADS 256
+#define VQ_EMA_DCHUNK 32
+template <typename T>
+__global__ __launch_bounds__(VQ_EMA_THREADS) void vq_ema_stats_kernel(const T* __restrict__ x, long long x_ld, const long long* __restrict__ idx,
+                                                                     long long tokens, int K, int D, float* __restrict__ stats) {
+  __shared__ float red[VQ_EMA_THREADS];
+  const int e = blockIdx.x, t = threadIdx.x;
+  auto block_sum = [&](float v) {  // fixed-order tree over the 256 threads
+    red[t] = v;
+    __syncthreads();
+    for (int s = VQ_EMA_THREADS / 2; s > 0; s >>= 1) {
+      if (t < s) red[t] += red[t + s];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float cnt = 0.f;
+  for (long long i = t; i < tokens; i += VQ_EMA_THREADS) cnt += idx[i] == e ? 1.f : 0.f;
+  cnt = block_sum(cnt);
+  if (t == 0) stats[e] = cnt;
+  for (int d0 = 0; d0 < D; d0 += VQ_EMA_DCHUNK) {
+    float acc[VQ_EMA_DCHUNK];
+#pragma unroll
+    for (int d = 0; d < VQ_EMA_DCHUNK; ++d) acc[d] = 0.f;
+    if (cnt > 0.f) {  // block-uniform
+      for (long long i = t; i < tokens; i += VQ_EMA_THREADS) {
+        if (idx[i] == e) {
+          const T* row = x + i * x_ld + d0;
+#pragma unroll
+          for (int d = 0; d < VQ_EMA_DCHUNK; ++d)
+            if (d0 + d < D) acc[d] += ElemIO<T>::ld(row + d);
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < VQ_EMA_DCHUNK; ++d) {
+      if (d0 + d < D) {  // block-uniform
+        const float s = cnt > 0.f ? block_sum(acc[d]) : 0.f;
+        if (t == 0) stats[K + (long long)e * D + d0 + d] = s;
+      }
+    }
+  }
+}
+
+extern "C" int gm_vq_ema_stats(const void* x, long long x_ld, const long long* indices, long long tokens, int num_embeddings, int dim,
+                               float* stats, int dtype, void* stream) {
+  GM_REQUIRE(x && indices && stats, "null pointer");
+  GM_REQUIRE(num_embeddings > 0 && dim > 0, "bad codebook shape");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32) vq_ema_stats_kernel<float><<<num_embeddings, VQ_EMA_THREADS, 0, st>>>((const float*)x, x_ld, indices, tokens, num_embeddings, dim, stats);
+  else if (dtype == GM_BF16) vq_ema_stats_kernel<bf16_raw><<<num_embeddings, VQ_EMA_THREADS, 0, st>>>((const bf16_raw*)x, x_ld, indices, tokens, num_embeddings, dim, stats);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(VQ_EMA_THREADS) void vq_ema_update_kernel(const float* __restrict__ stats, float* __restrict__ cluster, float* __restrict__ ema_w,
+                                                                      float* __restrict__ embedding, int K, int D, float decay, float epsilon) {
+  __shared__ float red[VQ_EMA_THREADS];
+  const int t = threadIdx.x;
+  const float om = 1.0f - decay;
+  float part = 0.f;
+  for (int e = t; e < K; e += VQ_EMA_THREADS) {
+    const float c = cluster[e] * decay + stats[e] * om;   // ema_cluster_size.mul_(decay).add_(encodings_sum * (1 - decay))
+    cluster[e] = c;
+    part += c;
+  }
+  red[t] = part;
+  __syncthreads();
+  for (int s = VQ_EMA_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  const float n = red[0];
+  for (long long i = t; i < (long long)K * D; i += VQ_EMA_THREADS) {
+    const int e = (int)(i / D);
+    const float weight = (cluster[e] + epsilon) / (n + K * epsilon) * n;   // Laplace smoothing of the cluster size
+    const float w = ema_w[i] * decay + stats[K + i] * om;
+    ema_w[i] = w;
+    embedding[i] = w / weight;
+  }
+}
+
+// stats: the (all-reduced) buffer of gm_vq_ema_stats; cluster [K], ema_w / embedding [K][D]: fp32, updated in place
+extern "C" int gm_vq_ema_update(const float* stats, float* cluster, float* ema_w, float* embedding, int num_embeddings, int dim, float decay,
+                                float epsilon, void* stream) {
+  GM_REQUIRE(stats && cluster && ema_w && embedding, "null pointer");
+  vq_ema_update_kernel<<<1, VQ_EMA_THREADS, 0, (hipStream_t)stream>>>(stats, cluster, ema_w, embedding, num_embeddings, dim, decay, epsilon);
+  GM_LAUNCH_CHECK();
+}

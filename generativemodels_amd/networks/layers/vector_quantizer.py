@@ -1,10 +1,13 @@
-"""Vector quantiser (inference): constructor / buffers / method contract of the reference's
+"""Vector quantiser: constructor / buffers / method contract of the reference's
 generative/networks/layers/vector_quantizer.py:20-228 (`EMAQuantizer`, `VectorQuantizer`).
 
 Nearest-code search and the codebook lookup run in HIP (gm_vq_argmin / gm_vq_gather) directly on NC[D]HW inputs (converted
 once to the N[D]HWC arena, which makes the reference's permute+flatten free).  Distances are fp32 for every storage dtype
-(vector_quantizer.py:102-103).  The EMA codebook update (training only, vector_quantizer.py:140-180) is not part of the
-sampling path and raises."""
+(vector_quantizer.py:102-103).  In train() mode the forward also performs the EMA codebook update (vector_quantizer.py:166-180):
+per-code token counts and vector sums in ONE flat buffer (gm_vq_ema_stats) -- exchanged between data-parallel ranks by ONE all-reduce
+where the reference issues two (:155-157) -- then the decayed update + Laplace smoothing + embedding rewrite (gm_vq_ema_update); the
+one-hot matrix of the reference is never materialised.  The straight-through estimator and the commitment loss are differentiable in
+the input (an autograd.Function with a latent-sized backward)."""
 from __future__ import annotations
 
 from typing import Sequence, Tuple
@@ -57,18 +60,67 @@ class EMAQuantizer(nn.Module):
         with torch.no_grad():
             return ops.to_channels_first(self.lookup(embedding_indices, self.embedding.weight.dtype))
 
+    @torch.no_grad()
+    def ema_update(self, z_arena: torch.Tensor, indices: torch.Tensor) -> None:
+        """The training-mode codebook update (vector_quantizer.py:166-180) from the arena view of the inputs and their code indices."""
+        k, d = self.num_embeddings, self.embedding_dim
+        stats = torch.empty(k + k * d, dtype=torch.float32, device=z_arena.device)
+        idx = indices.reshape(-1).contiguous()
+        ops.check(ops.lib().gm_vq_ema_stats(z_arena.data_ptr(), ops.arena_ld(z_arena), idx.data_ptr(), idx.numel(), k, d, stats.data_ptr(),
+                                            ops.dt_code(z_arena.dtype), ops._stream()), "gm_vq_ema_stats")
+        if self.ddp_sync and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)  # counts and vector sums together: one exchange
+        # the kernels update fp32 state in place; a module cast to bf16 keeps fp32 master copies of its three tables for the update
+        bufs = [self.ema_cluster_size, self.ema_w, self.embedding.weight]
+        f32 = [b if b.dtype == torch.float32 else b.float() for b in bufs]
+        ops.check(ops.lib().gm_vq_ema_update(stats.data_ptr(), f32[0].data_ptr(), f32[1].data_ptr(), f32[2].data_ptr(), k, d, float(self.decay),
+                                             float(self.epsilon), ops._stream()), "gm_vq_ema_update")
+        for b, f in zip(bufs, f32):
+            if f is not b:
+                b.copy_(f)
+        ops.invalidate_param_cache(self.embedding.weight)
+
     def forward(self, inputs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """-> (quantized, commitment loss, indices).  Eval semantics of vector_quantizer.py:161-188: the straight-through
-        expression x + (q - x).detach() is returned as q itself (identical up to one rounding, no autograd here)."""
-        if self.training:
-            raise RuntimeError("the EMA codebook update (training) is outside the MI355X sampling path; call .eval()")
+        """-> (quantized, commitment loss, indices) (vector_quantizer.py:161-188).  eval(): no autograd, the straight-through expression
+        x + (q - x).detach() is returned as q itself (identical up to one rounding).  train(): the codes are looked up BEFORE the EMA
+        update rewrites the embedding (as in the reference, :162-163 precede :166-180), the update runs, and (quantized, loss) are
+        differentiable in the input: d quantized / d x = identity, d loss / d x = 2 * commitment_cost * (x - q) / numel."""
         ops.require_device(inputs)
+        if self.training:
+            with torch.no_grad():
+                za = ops.to_channels_last(inputs.detach())
+                idx = self.indices_of(za)
+                q, mse = self.lookup(idx, inputs.dtype, za)
+                self.ema_update(za, idx)
+                q = ops.to_channels_first(q)
+                loss = self.commitment_cost * mse.to(inputs.dtype)
+            if torch.is_grad_enabled() and inputs.requires_grad:
+                return (*_StraightThrough.apply(inputs, q, loss, float(self.commitment_cost)), idx)
+            return q, loss, idx
         with torch.no_grad():
             za = ops.to_channels_last(inputs)
             idx = self.indices_of(za)
             q, mse = self.lookup(idx, inputs.dtype, za)
             loss = self.commitment_cost * mse.to(inputs.dtype)
             return ops.to_channels_first(q), loss, idx
+
+
+class _StraightThrough(torch.autograd.Function):
+    """(quantized, loss) as functions of the input x: quantized = x + (q - x).detach(), loss = cc * mse(q.detach(), x)."""
+
+    @staticmethod
+    def forward(ctx, x, q, loss, cc):
+        ctx.save_for_backward(x, q)
+        ctx.cc = cc
+        return q.clone(), loss.clone()
+
+    @staticmethod
+    def backward(ctx, gq, gloss):
+        x, q = ctx.saved_tensors
+        dx = gq
+        if gloss is not None:  # latent-sized element-wise expression: left to torch, like autograd._Embedding
+            dx = dx + gloss * (2.0 * ctx.cc / x.numel()) * (x - q)
+        return dx, None, None, None
 
 
 class VectorQuantizer(nn.Module):

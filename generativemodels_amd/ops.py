@@ -135,6 +135,13 @@ def _cached(param: torch.Tensor, tag, make):
     return val
 
 
+def invalidate_param_cache(param: torch.Tensor) -> None:
+    """Drop every cached derivative (fp32 copy, packed panel) of a parameter a native kernel has just rewritten in place (such writes do
+    not bump `param._version`, the key the caches are validated against)."""
+    for key in [k for k in _param_cache if k[0] == id(param)]:
+        _param_cache.pop(key, None)
+
+
 def as_f32(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """fp32 device copy of a small parameter vector (bias / gamma / beta); identity when it already is fp32."""
     if param is None:
@@ -645,12 +652,9 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             order = [12] + order  # taps-as-K kernel of the 1..4-channel input convolutions
     if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
         order = ([15] if desc.sd == 2 else [11]) + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
-        # 512-voxel tiles (16 waves, one work-group per CU, half the weight-panel traffic) measure 4-5 % faster than two 256-voxel
-        # work-groups where the weight stream dominates -- the 32^3 level of C2 (Cin >= 128: 1 004-1 317 vs 968-1 253 TFLOP/s) -- and on
-        # the 64 -> 64 layers at 128^3 (782 vs 747); 3-9 % slower elsewhere (profiles/r02_conv_tile_configs.txt)
-        vox = n_vox_out * desc.N
-        if desc.sd == 1 and ((desc.Cin >= 128 and 16384 < vox <= 65536 and cout >= 256) or (desc.Cin == 64 and cout == 64 and (1 << 21) <= vox < (1 << 23))):
-            order = [16] + order
+        # (512-voxel tiles -- cfg 16 / 18, one work-group per CU, half the weight-panel traffic -- measure within +-5 % of two 256-voxel
+        # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,
+        # r02_layer_times_cfg16_rule.txt.  They stay available through force_cfg.)
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups (the LDS-DMA kernels stay first)
         dma_first = [c for c in order if c in (11, 15, 18, 19)]
         rest = [c for c in order if c not in (11, 15, 18, 19)]

@@ -340,6 +340,14 @@ int gm_geglu_bwd(const void* x, long long x_ld, const void* gy, long long gy_ld,
 /* ---- vector quantiser (networks/layers/vector_quantizer.py:86-138,183) ------------------------------------------------ */
 int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long long* indices, long long tokens,
                  int num_embeddings, int dim, int dtype, void* stream);
+/* EMA codebook update of EMAQuantizer.forward in training mode (vector_quantizer.py:166-180).  gm_vq_ema_stats fills ONE flat fp32 buffer
+ * stats[K + K*D] = (tokens per code | sum of the token vectors per code) -- the reference's `encodings_sum` and `dw`, exchanged between
+ * data-parallel ranks by ONE all-reduce instead of two (:155-157); gm_vq_ema_update applies the decayed update, the Laplace smoothing and
+ * rewrites the embedding (fp32 buffers, in place). */
+int gm_vq_ema_stats(const void* x, long long x_ld, const long long* indices, long long tokens, int num_embeddings, int dim, float* stats,
+                    int dtype, void* stream);
+int gm_vq_ema_update(const float* stats, float* cluster, float* ema_w, float* embedding, int num_embeddings, int dim, float decay,
+                     float epsilon, void* stream);
 long long gm_vq_gather_workspace_bytes(void);
 int gm_vq_gather(const long long* indices, const float* embedding, void* out, long long out_ld, const void* x,
                  long long x_ld, float* sq_err_mean, void* workspace, long long tokens, int num_embeddings, int dim,

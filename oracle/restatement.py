@@ -567,6 +567,32 @@ def vq_quantize(sd, cfg, z):
     return q.to(z.dtype), loss
 
 
+def vq_ema_forward(state, args, x):
+    """EMAQuantizer.forward in train() mode, layers/vector_quantizer.py:161-188, functionally: -> (quantized, loss, indices, new state).
+    state: dict(embedding.weight, ema_cluster_size, ema_w) (not modified); args: num_embeddings, embedding_dim, commitment_cost, decay,
+    epsilon.  The lookup (:162-163) precedes the EMA update (:166-180); quantized / loss are differentiable in x (:183-186)."""
+    k, decay, eps = args["num_embeddings"], args["decay"], args["epsilon"]
+    emb = state["embedding.weight"].float()
+    perm = [0] + list(range(2, x.ndim)) + [1]
+    flat = x.detach().float().permute(perm).contiguous().view(-1, emb.shape[1])
+    dist = (flat**2).sum(dim=1, keepdim=True) + (emb.t() ** 2).sum(dim=0, keepdim=True) - 2 * torch.mm(flat, emb.t())
+    idx = torch.max(-dist, dim=1)[1]
+    enc = F.one_hot(idx, k).float()
+    shape = list(x.shape)
+    del shape[1]
+    idx = idx.view(shape)
+    back = [0, x.ndim - 1] + list(range(1, x.ndim - 1))
+    q = F.embedding(idx, emb).permute(back).contiguous()
+    enc_sum, dw = enc.sum(0), torch.mm(enc.t(), flat)                                   # :168-169
+    cluster = state["ema_cluster_size"].float() * decay + enc_sum * (1 - decay)           # :174
+    n = cluster.sum()                                                                     # :177
+    weights = (cluster + eps) / (n + k * eps) * n                                         # :178
+    ema_w = state["ema_w"].float() * decay + dw * (1 - decay)                             # :179
+    new_state = {"embedding.weight": ema_w / weights.unsqueeze(1), "ema_cluster_size": cluster, "ema_w": ema_w}  # :180
+    loss = args["commitment_cost"] * F.mse_loss(q.detach(), x)                            # :183
+    return x + (q - x).detach(), loss, idx, new_state                                     # :186
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # Schedulers (networks/schedulers/{scheduler,ddim,ddpm}.py). Tables are fp32 CPU tensors like the reference's.
 # --------------------------------------------------------------------------------------------------------------------

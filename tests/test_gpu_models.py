@@ -142,6 +142,43 @@ def test_vqvae_matches_reference_golden(name):
     assert float(m.quantizer.perplexity) >= 1.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ema_quantizer_training_forward_matches_reference(dtype):
+    """EMAQuantizer in train() mode: code lookup, commitment loss, the EMA codebook update (gm_vq_ema_stats -> one flat buffer ->
+    gm_vq_ema_update) carried over two steps, and the straight-through / loss gradient in the input -- against the outputs of the
+    unmodified reference (tests/golden/vq_ema.pt; vector_quantizer.py:161-188).  bf16: the module keeps bf16 tables like the reference
+    would; checked against the fp32 golden with a bf16-sized tolerance."""
+    from generativemodels_amd.networks.layers.vector_quantizer import EMAQuantizer
+    fx = load_fixture("vq_ema")
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    for name, case in fx["cases"].items():
+        layer = EMAQuantizer(**case["args"])
+        layer.load_state_dict(case["init"])
+        layer = layer.to(DEV, dtype).train()
+        for s, st in enumerate(case["steps"]):
+            x = st["x"].to(DEV, dtype).requires_grad_(True)
+            q, loss, idx = layer(x)
+            ((q.float() * st["gq"].to(DEV)).sum() + 3.0 * loss.float()).backward()
+            if dtype == torch.float32:
+                assert torch.equal(idx.cpu(), st["indices"]), (name, s)
+            scale = max(1.0, st["quantized"].abs().max().item())
+            if dtype == torch.float32:
+                assert (q.float().cpu() - st["quantized"]).abs().max().item() <= tol * scale
+                assert abs(loss.item() - st["loss"].item()) <= tol
+                assert (x.grad.float().cpu() - st["dx"]).abs().max().item() <= tol * max(1.0, st["dx"].abs().max().item())
+                for k, v in layer.state_dict().items():
+                    assert (v.float().cpu() - st["state"][k]).abs().max().item() <= tol * max(1.0, st["state"][k].abs().max().item()), (name, s, k)
+            else:  # bf16 inputs / tables: near-ties may pick another code; the statistics stay close
+                assert (idx.cpu() == st["indices"]).float().mean().item() > 0.9
+                assert abs(loss.item() - st["loss"].item()) <= 0.1 * max(st["loss"].item(), 1e-3)
+                assert torch.isfinite(x.grad.float()).all() and torch.isfinite(layer.embedding.weight.float()).all()
+        # eval() afterwards: the plain inference path on the updated codebook, no state change
+        layer.eval()
+        before = {k: v.clone() for k, v in layer.state_dict().items()}
+        layer(case["steps"][0]["x"].to(DEV, dtype))
+        assert all(torch.equal(before[k], v) for k, v in layer.state_dict().items())
+
+
 def test_ddim_chain_free_running_matches_reference():
     """10-step free-running DDIM chain (clip_sample=False) of the literal reference test model; the reference's own fp32
     self-noise on this chain is ~2e-5 * scale (tests/test_oracle_golden.py)."""

@@ -48,6 +48,24 @@ def test_vqvae_matches_reference(name):
     assert_close(R.vqvae_decode(sd, cfg, R.vq_embed(sd, o["indices"])), o["reconstruction"], 2e-5, what="decode_samples")
 
 
+def test_vq_ema_training_forward_matches_reference():
+    """The restated EMA codebook update against two consecutive train() forwards of the unmodified reference EMAQuantizer
+    (tests/golden/vq_ema.pt, oracle/make_golden_vq_ema.py): outputs, updated buffers, input gradient."""
+    fx = load_fixture("vq_ema")
+    for name, case in fx["cases"].items():
+        state = {k: v.clone() for k, v in case["init"].items()}
+        for s, st in enumerate(case["steps"]):
+            x = st["x"].clone().requires_grad_(True)
+            q, loss, idx, state = R.vq_ema_forward(state, case["args"], x)
+            ((q * st["gq"]).sum() + 3.0 * loss).backward()
+            assert torch.equal(idx, st["indices"]), (name, s)
+            assert_close(q, st["quantized"], 1e-6, what=f"{name} step {s} quantized")
+            assert_close(loss, st["loss"], 1e-6, what=f"{name} step {s} loss")
+            assert_close(x.grad, st["dx"], 1e-6, what=f"{name} step {s} dx")
+            for k in ("embedding.weight", "ema_cluster_size", "ema_w"):
+                assert_close(state[k], st["state"][k], 1e-6, what=f"{name} step {s} {k}")
+
+
 def _eq(a, b):
     return torch.allclose(a, b, rtol=0, atol=0, equal_nan=True)
 

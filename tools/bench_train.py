@@ -27,9 +27,13 @@ world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 local = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
-if world > 1:
+force_reducer = os.environ.get("GM_FORCE_REDUCER", "0") == "1"  # one rank, but the whole RCCL exchange path (side stream, buckets) runs
+if world > 1 or force_reducer:
     import torch.distributed as dist
-    dist.init_process_group("nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 dev = f"cuda:{local}"
 torch.manual_seed(0)
 ae = AutoencoderKL(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4, num_channels=(64, 128, 128, 128), num_res_blocks=2,
@@ -43,7 +47,7 @@ unet = unet.to(dev, dt)
 sched = DDPMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205)
 inf = LatentDiffusionInferer(sched, scale_factor=1.0)
 opt = torch.optim.Adam(unet.parameters(), lr=1e-5)
-red = GradientReducer(unet.parameters())
+red = GradientReducer(unet.parameters(), force=force_reducer)
 g = torch.Generator().manual_seed(100 + rank)
 imgs = torch.randn((batch, 1, size, size, size), generator=g).to(dev, dt)
 lat = size // 8
@@ -52,7 +56,7 @@ lat = size // 8
 def step():
     noise = torch.randn((batch, 4, lat, lat, lat), generator=g).to(dev, dt)
     t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
-    opt.zero_grad(set_to_none=True)
+    red.zero_grad() if red.active else opt.zero_grad(set_to_none=True)  # one fill per bucket: .grad stays a view of its flat bucket
     pred = inf(inputs=imgs, autoencoder_model=ae, diffusion_model=unet, noise=noise, timesteps=t)
     loss = F.mse_loss(pred.float(), noise.float())
     loss.backward()
@@ -107,6 +111,8 @@ for name, meta, ms in ops.stop_profile():
 if rank == 0:
     print(json.dumps(dict(config=f"C4 per-rank training step: {batch} x 1 x {size}^3 volumes -> {batch} x 4 x {lat}^3 latents, 41.7 M-parameter UNet",
                           dtype=str(dt).split(".")[-1], n_gpus=world, step_ms=round(dt_step * 1e3, 2),
+                          gradient_exchange=(f"RCCL all-reduce, {len(red.buckets)} buckets, {red.launched_in_backward} launched during backward "
+                                             f"(world_size {world})" if red.active else "off (one rank)"),
                           volumes_per_s=round(world * batch / dt_step, 3), losses=[round(v, 4) for v in losses], phases=phases,
                           unet_fwd_bwd_breakdown={k: dict(launches=v["launches"], ms=round(v["ms"], 3), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1))
                                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]})))
