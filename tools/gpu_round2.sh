@@ -73,6 +73,20 @@ if [[ $STAGES == *3* ]]; then
   timeout 900 python tools/bench_c3.py > $OUT/r2_c3.log 2>&1
   echo "c3 rc=$?" >> $LOG; tail -c 3000 $OUT/r2_c3.log >> $LOG
 fi
+if [[ $STAGES == *4* ]]; then  # C4: per-rank training step, plain and with the RCCL gradient exchange forced on one rank
+  timeout 900 python tools/bench_train.py 256 1 bf16 3 > $OUT/r2_c4.log 2>&1
+  echo "c4 rc=$?" >> $LOG; tail -c 3500 $OUT/r2_c4.log >> $LOG
+  GM_FORCE_REDUCER=1 timeout 900 python tools/bench_train.py 256 1 bf16 3 > $OUT/r2_c4_rccl.log 2>&1
+  echo "c4_rccl rc=$?" >> $LOG; tail -c 1200 $OUT/r2_c4_rccl.log >> $LOG
+fi
+if [[ $STAGES == *5* ]]; then
+  timeout 900 python tools/bench_c5.py > $OUT/r2_c5.log 2>&1
+  echo "c5 rc=$?" >> $LOG; tail -c 1500 $OUT/r2_c5.log >> $LOG
+fi
+if [[ $STAGES == *1* ]]; then
+  timeout 900 python tools/bench_c1b.py > $OUT/r2_c1b.log 2>&1
+  echo "c1b rc=$?" >> $LOG; tail -c 1500 $OUT/r2_c1b.log >> $LOG
+fi
 if [[ $STAGES == *l* ]]; then
   timeout 600 python tools/layer_times.py > $OUT/r2_layer_times.log 2>&1
   echo "layer_times rc=$?" >> $LOG; tail -1 $OUT/r2_layer_times.log >> $LOG

@@ -24,7 +24,8 @@ out = [dict(kernel=k, launches=n, fetch_kib_per_launch=round(f, 1), write_kib_pe
 import subprocess, sys
 sys.path.insert(0, ".")
 from bench import kernel_source_sha
-head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None  # no .git on the GPU box
+import os
+head = os.environ.get("GM_GIT_HEAD") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None  # no .git on the GPU box
 doc = dict(source_sha=kernel_source_sha(), git_head=head, command="bench.py --steps 1 --warmup 0 --graph 0 --cpu-baseline off --inference-steps 1",
            note="FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE 1:1; separate --pmc passes", rows=out)
 json.dump(doc, open("gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
