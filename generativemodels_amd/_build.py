@@ -57,12 +57,17 @@ def _stale(target: str, deps: list[str]) -> bool:
 EXTRA_FLAGS = {"elementwise.hip": ["-ffp-contract=off"]}
 
 
+# bench-only variants: extra defines, their own object directory and library name (the product library is never built with them)
+VARIANTS = {"timeline": ["-DGM_CONV_TIMELINE"], "ablate": ["-DGM_CONV_ABLATE"]}
+_variant = None
+
+
 def _compile(src: str) -> str:
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    obj = os.path.join(OBJDIR if _variant is None else OBJDIR + "_" + _variant, os.path.splitext(src)[0] + ".o")
     srcp = os.path.join(CSRC, src)
     deps = [srcp, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     if _stale(obj, deps):
-        extra = os.environ.get("GM_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DGM_CONV_ABLATE for tools/ablate_conv.py (bench-only builds)
+        extra = os.environ.get("GM_EXTRA_HIPCC_FLAGS", "").split() + (VARIANTS[_variant] if _variant else [])
         cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), *extra, "-x", "hip", "-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -70,14 +75,27 @@ def _compile(src: str) -> str:
     return obj
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJDIR, exist_ok=True)
+def build_native(force: bool = False, verbose: bool = False, variant: str | None = None) -> str:
+    """variant: None = the product library lib/libgmamd.so; "timeline" / "ablate" = bench-only builds lib/libgmamd_<variant>.so
+    (loaded through GM_NATIVE_LIB by the tools that need them)."""
+    global _variant
+    _variant = variant
+    objdir = OBJDIR if variant is None else OBJDIR + "_" + variant
+    libpath = LIBPATH if variant is None else os.path.join(LIBDIR, f"libgmamd_{variant}.so")
+    os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     if force:
-        for f in os.listdir(OBJDIR):
-            os.remove(os.path.join(OBJDIR, f))
-    with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(_compile, SOURCES))
+        for f in os.listdir(objdir):
+            os.remove(os.path.join(objdir, f))
+    try:
+        with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+            objs = list(ex.map(_compile, SOURCES))
+    finally:
+        _variant = None
+    return _link(objs, libpath, force, verbose)
+
+
+def _link(objs, LIBPATH, force, verbose) -> str:
     if force or _stale(LIBPATH, objs):
         rt = hip_runtime_library()
         linker = shutil.which("g++") or shutil.which("c++") or _hipcc()
@@ -91,4 +109,4 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    build_native(force="--force" in sys.argv, verbose=True)
+    build_native(force="--force" in sys.argv, verbose=True, variant=sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None)

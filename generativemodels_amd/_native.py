@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgmamd.so")
+# GM_NATIVE_LIB: a bench-only build of the same library (e.g. lib/libgmamd_timeline.so from `_build.py --variant timeline`); never set in production
+LIB_PATH = os.environ.get("GM_NATIVE_LIB") or os.path.join(_HERE, "lib", "libgmamd.so")
 
 c_ll = C.c_longlong
 c_vp = C.c_void_p

@@ -17,6 +17,17 @@
 #include "conv_epilogue.h"
 
 #define DMA_ROWB 64
+// bench-only build (-DGM_CONV_TIMELINE, tools/conv_timeline.py): thread 0 of every work-group stamps the shader clock at phase boundaries
+// into GmConvDesc.kpartial (64 slots per work-group) when debug_flags bit 12 is set; compiled out of the shipped library
+#ifdef GM_CONV_TIMELINE
+#define TL_STAMP(k)                                                                                                              \
+  do {                                                                                                                           \
+    if ((p.debug_flags & 4096) && threadIdx.x == 0)                                                                              \
+      reinterpret_cast<unsigned long long*>(p.kpartial)[(long long)blockIdx.x * 64 + (k)] = __builtin_readcyclecounter();        \
+  } while (0)
+#else
+#define TL_STAMP(k)
+#endif
 __device__ __forceinline__ int dma_swz(int row) { return (row ^ (row >> 1)) & 3; }  // period 8 rows
 
 __device__ __attribute__((aligned(64))) unsigned int gm_zero_row[16] = {0};  // the source of every padding row
@@ -82,6 +93,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB]
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  TL_STAMP(0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -265,6 +277,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   // ---- main loop ----------------------------------------------------------------------------------------------------------
+  TL_STAMP(1);
   if (total > 0) {
     issue_patch(c_begin);
     issue_w(c_begin * NGROUPS, 0);
@@ -274,6 +287,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     if (pre) transform_patch();
   }
   __builtin_amdgcn_s_barrier();
+  TL_STAMP(2);
 
   // debug_flags bit 11 (bench-only A/B, results unaffected): the tap loop runs at wave priority 1, prologue / epilogue at 0, so that the
   // co-resident work-group's address arithmetic and stores yield issue slots to this one's ds_read / MFMA stream
@@ -337,8 +351,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         __builtin_amdgcn_s_barrier();
       }
       mma_step(NSTEPS - 1);
+      if (chunk - c_begin < 5) TL_STAMP(3 + (chunk - c_begin) * 10 + g);  // after the barrier that ends group g (g = 8: incl. the chunk boundary)
     }
   }
+  TL_STAMP(60);
 
   if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(0);
   // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
@@ -408,6 +424,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
   }
 
+  TL_STAMP(61);
   // ---- split-K: this slice's fp32 partial sums -> kpartial[ks][n * V + voxel][Cout]; the combine kernel applies the epilogue ----------
   if (KS == 3 && S == 1 && ksplit > 1) {
     const long long nv = (long long)p.N * p.Do * p.Ho * p.Wo;
@@ -444,6 +461,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const ConvOutMap om = {p.Ds, p.Hs, p.Ws, (par >> 2) & 1, (par >> 1) & 1, par & 1};
   conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wave * MF * 16, cb * BN, od0, oh0, ow0, lane, st_s, st_q,
                                 KS == 2 ? &om : nullptr);
+  TL_STAMP(62);
   if (p.stats) {
     float* sst = reinterpret_cast<float*>(smem);  // [NW][BN channels][2]
     __syncthreads();
@@ -477,6 +495,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       }
     }
   }
+  TL_STAMP(63);
 }
 
 // variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile; 4 = sub-pixel 2x2x2 (5 planes of 5 x 17 -> 96 rows,

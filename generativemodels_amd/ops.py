@@ -625,6 +625,7 @@ def _cfg_tile(cfg: int):
 
 
 _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
+_CONV_TIMELINE_BUFFER = None  # tools/conv_timeline.py (bench-only -DGM_CONV_TIMELINE build): int64 [work-groups, 64] stamp table
 
 SMALL_LINEAR_ROWS = 64       # 1x1 "convolutions" over at most this many rows take gm_linear_rows
 DMA_CONV = True              # route eligible 3x3x3 convolutions through conv_dma.hip (cfg 11)
@@ -984,6 +985,8 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                 raise ValueError(f"split-K by {ks} is not available for this convolution")
             else:
                 d.ksplit = 0
+    if _CONV_TIMELINE_BUFFER is not None and kpart is None:
+        d.kpartial = _CONV_TIMELINE_BUFFER.data_ptr()  # ksplit stays 0: the kernel only stamps into it (debug_flags bit 12)
     d.stats = None
     if want_stats:  # the fast kernels fuse the output statistics into their epilogue (else: one stand-alone pass when a consumer asks)
         _attach_conv_stats(d, out, n, cout)

@@ -1,0 +1,77 @@
+"""GPU, bench-only build (GM_EXTRA_HIPCC_FLAGS=-DGM_CONV_TIMELINE python -m generativemodels_amd._build --force): where the cycles of one
+LDS-DMA convolution tile go.  Thread 0 of every work-group stamps the shader clock at phase boundaries (conv_dma.hip TL_STAMP); this
+script launches one convolution per shape / configuration and prints the median duration of every phase over the work-groups, split
+into the first wave of work-groups on the chip (cold start) and the steady state.   usage: python tools/conv_timeline.py"""
+import math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ctypes as C
+import torch
+from generativemodels_amd import ops
+
+dev = "cuda"
+
+
+def run(cin, cout, size, cfg, with_res=True):
+    x = torch.randn((1, size, size, size, cin), device=dev).bfloat16()
+    w = (torch.randn((cout, cin, 3, 3, 3), device=dev) / math.sqrt(cin * 27)).bfloat16()
+    b = torch.randn((cout,), device=dev)
+    res = torch.randn((1, size, size, size, cout), device=dev).bfloat16() if with_res else None
+    kw = dict(kernel=3, padding=1, force_cfg=cfg, want_stats=True, res=res, ksplit=1)
+    ops.conv(x, w, b, **kw)
+    bm = 512 if cfg in (16, 18, 19) else 256
+    bn = 128 if cfg == 19 else 64
+    nwg = (size ** 3 // bm) * ((cout + bn - 1) // bn)
+    buf = torch.zeros((nwg, 64), dtype=torch.int64, device=dev)
+    # smuggle the timeline buffer through GmConvDesc.kpartial (ksplit stays 0): patch ops.conv's descriptor via the debug hook
+    ops._CONV_DEBUG_FLAGS = 4096
+    ops._CONV_TIMELINE_BUFFER = buf
+    try:
+        ops.conv(x, w, b, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops._CONV_DEBUG_FLAGS = 0
+        ops._CONV_TIMELINE_BUFFER = None
+    t = buf.cpu().numpy().astype("int64")
+    return t, nwg
+
+
+def report(name, t, nchunks):
+    import numpy as np
+    ok = t[:, 63] > 0
+    t = t[ok]
+    order = np.argsort(t[:, 0])
+    t = t[order]
+    t0 = t[:, 0].min()
+    span = t[:, 63].max() - t0
+    print(f"--- {name}: {len(t)} work-groups, kernel span {span} cycles")
+    for label, sel in (("first 512 work-groups (cold)", slice(0, 512)), ("steady state", slice(512, None))):
+        tt = t[sel]
+        if len(tt) == 0:
+            continue
+        med = lambda a: int(np.median(a))  # noqa: E731
+        rows = [("address setup (entry -> first DMA issue)", tt[:, 1] - tt[:, 0]),
+                ("first patch + 2 panels landed (+ barrier)", tt[:, 2] - tt[:, 1])]
+        prev = tt[:, 2]
+        for c in range(min(nchunks, 5)):
+            groups = []
+            for g in range(9):
+                cur = tt[:, 3 + c * 10 + g]
+                groups.append(cur - prev)
+                prev = cur
+            g_first8 = np.stack(groups[:8], 1)
+            rows.append((f"chunk {c}: tap groups 0-7 (each 24 MFMAs / wave), median of per-group medians", np.median(g_first8, 1)))
+            rows.append((f"chunk {c}: tap group 8" + (" + chunk boundary (patch reload)" if c + 1 < nchunks else " (last)"), groups[8]))
+        if nchunks <= 5:
+            rows.append(("main loop end -> shortcut / split done", tt[:, 61] - tt[:, 60]))
+            rows.append(("epilogue: LDS transpose, residual, stores", tt[:, 62] - tt[:, 61]))
+            rows.append(("statistics reduce + store", tt[:, 63] - tt[:, 62]))
+        rows.append(("work-group life", tt[:, 63] - tt[:, 0]))
+        print(f"  [{label}]")
+        for lab, a in rows:
+            print(f"    {lab:78s} {med(a):8d} cycles")
+
+
+for cin, cout, size, cfg in [(64, 64, 128, 11), (64, 64, 128, 18), (192, 64, 128, 11), (384, 128, 64, 11), (256, 256, 32, 11)]:
+    t, nwg = run(cin, cout, size, cfg)
+    report(f"{cin}->{cout} @ {size}^3 cfg{cfg}", t, cin // 32)
