@@ -48,6 +48,142 @@ __device__ __forceinline__ void dma_wait() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
+// ---- epilogue of the LDS-DMA kernels ---------------------------------------------------------------------------------------------
+// What the cycle stamps of tools/conv_timeline.py showed for the shared conv_epilogue_lds() on a 64 -> 64 channel tile (63.6 k cycles of
+// work-group life, 27 k of them in the tap loop): 15.5 k cycles in the epilogue and 6.9 k in the statistics.  The ISA had (1) 16 x 3
+// dependent, individually branched global_load_dword for bias / shortcut bias / timestep row, (2) the residual load of row group it + 1
+// ordered behind the output store of row group it (res and y may alias: hipcc cannot hoist it), i.e. a load round trip plus a store
+// acknowledge per 8 rows, (3) 48 ds_bpermute round trips for the cross-lane statistic sums and a modulo by the tile count.  Here:
+//   * the per-channel addend (bias + shortcut bias + timestep row, same order of additions) is staged ONCE per work-group into LDS
+//     while the first patch is in flight (dma_addv) and read back with one ds_read_b128 per channel fragment;
+//   * all residual rows of a pass are requested before the first LDS write, so their latency overlaps the transpose;
+//   * the transpose scratch is wave-private: a wave-level fence replaces the work-group barrier between its write and read halves;
+//   * statistics: lane sums over its rows -> one DPP row rotate (lane ^ 8) -> per-(wave, 16-lane row) partials in LDS -> one fixed-order
+//     fp64 sum per channel.  Deterministic, no atomics.
+// The tile geometry is the kernel's (TH = 4, TW = 16): a wave's rows m_base + v are MF W-lines, (depth, height) of a line are wave-uniform.
+__device__ __forceinline__ float dpp_row_ror8(float v) {  // value of lane ^ 8 (rotate by 8 inside each row of 16 lanes)
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));
+}
+
+template <typename T, int MF, int NFR, int KS, int PASS>
+__device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, const float* addv, int n, int line0,
+                                                  int od0, int oh0, int ow0, int co_base, int lane, int par,
+                                                  float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
+                                                  float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)]) {
+  constexpr int VECW = 16 / (int)sizeof(T);
+  constexpr int ROWB_E = 144;                                   // 128 B of channels + 16 B pad
+  constexpr int NF_PER_PASS = 128 / (16 * (int)sizeof(T));      // 4 (bf16) or 2 (fp32) channel fragments per pass
+  constexpr int NIT = MF * 2;                                   // 8 rows x 8 segments per wave instruction
+  const int l15 = lane & 15, q = lane >> 4, seg = lane & 7, lw = lane >> 3;
+  T* yout = reinterpret_cast<T*>(p.y);
+  const T* res = reinterpret_cast<const T*>(p.res);
+  const int co = co_base + PASS * NF_PER_PASS * 16 + seg * VECW;
+  const bool co_ok = co < p.Cout;
+  // KS = 2: the tile walks the low-resolution grid and lands on the (pd, ph, pw) sub-lattice of the 2x output
+  const int Dl = KS == 2 ? p.Ds : p.Do, Hl = KS == 2 ? p.Hs : p.Ho, Wl = KS == 2 ? p.Ws : p.Wo;
+  // ---- addresses + residual requests of all row groups (no output activation: the hot form) ---------------------------------------
+  const bool fast = p.post_act == 0;  // wave-uniform; the activation form below is compact, sequential code (VQ-VAE / discriminator convolutions)
+  long long yoff[NIT];
+  bool inside[NIT];
+  uint4 rv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    yoff[it] = 0;
+    inside[it] = false;
+    rv[it] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  auto place = [&](int it, bool& in, long long& vox) __attribute__((always_inline)) {
+    const int line = line0 + (it >> 1);                         // wave-uniform: W-line of the tile, (depth, height) = (line / 4, line % 4)
+    const int od = od0 + (line >> 2), oh = oh0 + (line & 3), ow = ow0 + (it & 1) * 8 + lw;
+    in = co_ok && od < Dl && oh < Hl && ow < Wl;
+    vox = KS == 2 ? (((long long)n * p.Do + 2 * od + ((par >> 2) & 1)) * p.Ho + 2 * oh + ((par >> 1) & 1)) * p.Wo + 2 * ow + (par & 1)
+                  : (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+  };
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      long long vox;
+      place(it, inside[it], vox);
+      yoff[it] = vox * p.y_ld + co;
+      if (res && inside[it]) rv[it] = *reinterpret_cast<const uint4*>(res + vox * p.res_ld + co);
+    }
+  }
+  // ---- accumulators + addend -> LDS, row = voxel, 4 channels per lane ---------------------------------------------------------------
+#pragma unroll
+  for (int nl = 0; nl < NF_PER_PASS; ++nl) {
+    constexpr int NF0 = PASS * NF_PER_PASS;
+    if (NF0 + nl < NFR) {
+      const int nf = NF0 + nl < NFR ? NF0 + nl : NFR - 1;
+      const float4 add = *reinterpret_cast<const float4*>(addv + nf * 16 + q * 4);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        char* dst = lds + (mf * 16 + l15) * ROWB_E + (nl * 16 + q * 4) * (int)sizeof(T);
+        const float o0 = acc[nf][mf][0] + add.x, o1 = acc[nf][mf][1] + add.y, o2 = acc[nf][mf][2] + add.z, o3 = acc[nf][mf][3] + add.w;
+        if (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = make_float4(o0, o1, o2, o3);
+        else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+      }
+    }
+  }
+  // the scratch is this wave's own and a wave's LDS instructions execute in order: order the two halves for the compiler, no s_barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- LDS -> global: lane = (row it*8 + lane/8, 16-byte segment lane%8) -------------------------------------------------------------
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      uint4 raw = *reinterpret_cast<const uint4*>(lds + (it * 8 + lw) * ROWB_E + seg * 16);
+      if (inside[it]) {
+        if (res) {
+          float o[VECW], r[VECW];
+          Vec16<T>::unpack(raw, o);
+          Vec16<T>::unpack(rv[it], r);
+#pragma unroll
+          for (int i = 0; i < VECW; ++i) o[i] += r[i];
+          raw = Vec16<T>::pack(o);
+        }
+        *reinterpret_cast<uint4*>(yout + yoff[it]) = raw;
+        if (p.stats) {  // statistics of the values as stored (rounded to T), like a separate pass over the tensor would see them
+          float o[VECW];
+          Vec16<T>::unpack(raw, o);
+#pragma unroll
+          for (int i = 0; i < VECW; ++i) { st_s[PASS][i] += o[i]; st_q[PASS][i] += o[i] * o[i]; }
+        }
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+      bool in;
+      long long vox;
+      place(it, in, vox);
+      if (in) {
+        float o[VECW];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(lds + (it * 8 + lw) * ROWB_E + seg * 16), o);
+        if (res) {
+          float r[VECW];
+          Vec16<T>::unpack(*reinterpret_cast<const uint4*>(res + vox * p.res_ld + co), r);
+#pragma unroll
+          for (int i = 0; i < VECW; ++i) o[i] += r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) o[i] = conv_post_act(o[i], p.post_act);
+        const uint4 raw = Vec16<T>::pack(o);
+        *reinterpret_cast<uint4*>(yout + vox * p.y_ld + co) = raw;
+        if (p.stats) {
+          Vec16<T>::unpack(raw, o);
+#pragma unroll
+          for (int i = 0; i < VECW; ++i) { st_s[PASS][i] += o[i]; st_q[PASS][i] += o[i] * o[i]; }
+        }
+      }
+    }
+  }
+  // the next pass overwrites the scratch this one read
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // NW waves per work-group, each owning MF voxel fragments (16 voxels) x 64 channels of the 256-voxel tile: <8, 2> = 16 waves / CU,
 // 0.75 LDS operand reads per MFMA; <4, 4> = 8 waves / CU with 256 VGPRs each, 0.5 reads per MFMA (the LDS port is the next limit
 // after latency: 16 waves x 6 KiB per tap = 768 LDS clocks against 512 MFMA clocks per SIMD)
@@ -91,7 +227,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   static_assert(WROWS == (KS == 3 ? 3 : 2) * BN, "G taps per weight panel");
   static_assert(NGROUPS % RING == 0, "the ring slot of a group is a compile-time constant");
 
-  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB]
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB][addend vector 512 B]
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   TL_STAMP(0);
 
@@ -107,11 +243,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   unsigned b = xcd_remap(blockIdx.x, gridDim.x);
   // split-K (small grids): the grid holds ksplit copies of the tile list; copy ks computes K chunks [c_begin, c_end) only
   const int ksplit = (KS == 3 && S == 1 && p.kpartial && p.ksplit > 1) ? p.ksplit : 1;
-  const unsigned tiles_all = gridDim.x / (unsigned)ksplit;
-  const int ks = (int)(b / tiles_all);
-  b -= (unsigned)ks * tiles_all;
+  int ks = 0;
+  if (ksplit > 1) {  // (the divisions stay off the common path)
+    const unsigned tiles_all = gridDim.x / (unsigned)ksplit;
+    ks = (int)(b / tiles_all);
+    b -= (unsigned)ks * tiles_all;
+  }
   const int cb = b % ncb; b /= ncb;
-  const unsigned tile_id = b;  // ((n, td, th, tw)[, parity]): the statistics slot of this work-group is tile_id modulo the tiles per sample
   int par = 0;
   if (KS == 2) { par = b & 7; b >>= 3; }
   const int tw_i = b % ntw; b /= ntw;
@@ -126,10 +264,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
             uw0 = ow0 * S - (KS == 2 ? 1 - (par & 1) : p.pw);
   const int nchunks = p.Cin / BK;                          // host-checked: Cin % BK == 0
   const int cout_pad = (p.Cout + 15) & ~15;
-  const int cps = (nchunks + ksplit - 1) / ksplit;         // chunks per K slice (host-checked: (ksplit - 1) * cps < nchunks, no slice is empty)
+  const int cps = ksplit > 1 ? (nchunks + ksplit - 1) / ksplit : nchunks;         // chunks per K slice (host-checked: (ksplit - 1) * cps < nchunks, no slice is empty)
   const int c_begin = min(nchunks, ks * cps), c_end = min(nchunks, c_begin + cps);
   const int total = (c_end - c_begin) * NGROUPS;            // an empty slice (never launched by the host) would touch nothing: total == 0
 
+  TL_STAMP(53);
   // ---- per-lane DMA sources ---------------------------------------------------------------------------------------------
   // patch piece j of this wave covers LDS rows 16*(wave + NW*j) .. +15; lane -> (row, LDS slot lane&3) <- channel slot swizzled
   const char* zero = reinterpret_cast<const char*>(gm_zero_row);
@@ -147,6 +286,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
     pvox[j] = ok ? ((n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
   }
+  TL_STAMP(54);
   const long long xrowb = p.x_ld * (long long)sizeof(T);
   // optional second source: input channels [cin_split, Cin) come from x2 (the never-materialised torch.cat([h, skip]) of the decoder)
   const char* x2base = reinterpret_cast<const char*>(p.x2);
@@ -244,6 +384,27 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
   };
 
+  // ---- first DMAs out as early as possible: everything below that does not feed them runs while they are in flight ------------------
+  TL_STAMP(1);
+  if (total > 0) {
+    issue_patch(c_begin);
+    issue_w(c_begin * NGROUPS, 0);
+    if (total > 1) issue_w(c_begin * NGROUPS + 1, 1);
+    if (pre) load_affine(c_begin);
+  }
+  // per-channel epilogue addend of this work-group's BN output channels: bias + shortcut bias + timestep row (this order), fp32, in LDS
+  float* addv = reinterpret_cast<float*>(smem + PATCH_BYTES + RING * WBUF_BYTES);
+  float addend = 0.f;
+  if (tid < BN) {
+    const int co = cb * BN + tid;
+    if (co < p.Cout) {
+      if (p.bias) addend += p.bias[co];
+      if (p.skip_bias) addend += p.skip_bias[co];
+      if (p.rowvec) addend += p.rowvec[(long long)n * p.rowvec_bstride + co];
+    }
+  }
+
+  TL_STAMP(55);
   // ---- per-lane operand read addresses (bytes from smem) ------------------------------------------------------------------
   // A wave's MF fragments are MF consecutive H rows of one tile plane ((wave * MF + mf) * 16 + l15 with TH = 4, TW = 16), so fragment mf
   // at tap row kh reads patch row S * (bb0 + mf) + kh: the addresses depend on hk = S * mf + kh only -- HK x KS registers, not MF x KS x KS.
@@ -276,18 +437,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // ---- main loop ----------------------------------------------------------------------------------------------------------
-  TL_STAMP(1);
+  TL_STAMP(56);
+  if (tid < BN) addv[tid] = addend;
   if (total > 0) {
-    issue_patch(c_begin);
-    issue_w(c_begin * NGROUPS, 0);
-    if (total > 1) issue_w(c_begin * NGROUPS + 1, 1);
-    if (pre) load_affine(c_begin);
     dma_wait<0>();
     if (pre) transform_patch();
   }
   __builtin_amdgcn_s_barrier();
   TL_STAMP(2);
+
+  // ---- main loop ----------------------------------------------------------------------------------------------------------
 
   // debug_flags bit 11 (bench-only A/B, results unaffected): the tap loop runs at wave priority 1, prologue / epilogue at 0, so that the
   // co-resident work-group's address arithmetic and stores yield issue slots to this one's ds_read / MFMA stream
@@ -450,47 +609,51 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #ifdef GM_CONV_ABLATE
   if (p.debug_flags & 256) return;  // bench-only: main loop without the epilogue
 #endif
-  __syncthreads();
+  __syncthreads();  // every wave is done with the operand buffers: the transpose scratch overlays them
   constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
   constexpr int CH_PER_PASS = 128 / (int)sizeof(T);
+  constexpr int SCRATCH_BYTES = NW * MF * 16 * 144;                                         // wave-private transpose scratch, from smem + 0
+  constexpr int SST_OFF = SCRATCH_BYTES > PATCH_BYTES ? SCRATCH_BYTES : PATCH_BYTES;      // statistic partials: clear of every wave's scratch
+  static_assert(SST_OFF + NW * 4 * BN * 8 <= PATCH_BYTES + RING * WBUF_BYTES, "scratch + statistic partials fit under the addend vector");
   float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
 #pragma unroll
   for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
     for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
-  const ConvOutMap om = {p.Ds, p.Hs, p.Ws, (par >> 2) & 1, (par >> 1) & 1, par & 1};
-  conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wave * MF * 16, cb * BN, od0, oh0, ow0, lane, st_s, st_q,
-                                KS == 2 ? &om : nullptr);
+  {
+    char* scratch = smem + (size_t)wave * (MF * 16 * 144);
+    dma_epilogue_pass<T, MF, NFR, KS, 0>(p, acc, scratch, addv, n, wave * MF, od0, oh0, ow0, cb * BN, lane, par, st_s, st_q);
+    if constexpr (EPASSES > 1) dma_epilogue_pass<T, MF, NFR, KS, 1>(p, acc, scratch, addv, n, wave * MF, od0, oh0, ow0, cb * BN, lane, par, st_s, st_q);
+    if constexpr (EPASSES > 2) dma_epilogue_pass<T, MF, NFR, KS, 2>(p, acc, scratch, addv, n, wave * MF, od0, oh0, ow0, cb * BN, lane, par, st_s, st_q);
+    if constexpr (EPASSES > 3) dma_epilogue_pass<T, MF, NFR, KS, 3>(p, acc, scratch, addv, n, wave * MF, od0, oh0, ow0, cb * BN, lane, par, st_s, st_q);
+    static_assert(EPASSES <= 4, "at most 4 epilogue passes (128 output channels in fp32)");
+  }
   TL_STAMP(62);
   if (p.stats) {
-    float* sst = reinterpret_cast<float*>(smem);  // [NW][BN channels][2]
-    __syncthreads();
+    float* sst = reinterpret_cast<float*>(smem + SST_OFF);  // [NW][4 lane rows][BN channels][2]
 #pragma unroll
     for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
       for (int i = 0; i < VECW; ++i) {
-        float a = st_s[e][i], b2 = st_q[e][i];
-        a += __shfl_xor(a, 8, 64); b2 += __shfl_xor(b2, 8, 64);
-        a += __shfl_xor(a, 16, 64); b2 += __shfl_xor(b2, 16, 64);
-        a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64);
-        if (lane < 8) {
-          const int ch = e * CH_PER_PASS + lane * VECW + i;
-          sst[(wave * BN + ch) * 2] = a;
-          sst[(wave * BN + ch) * 2 + 1] = b2;
+        const float a = st_s[e][i] + dpp_row_ror8(st_s[e][i]), b2 = st_q[e][i] + dpp_row_ror8(st_q[e][i]);
+        if ((lane & 8) == 0) {
+          const int ch = e * CH_PER_PASS + (lane & 7) * VECW + i;
+          *reinterpret_cast<float2*>(sst + ((wave * 4 + (lane >> 4)) * BN + ch) * 2) = make_float2(a, b2);
         }
       }
     __syncthreads();
     if (tid < BN) {
       double a = 0.0, b2 = 0.0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        a += (double)sst[(w * BN + tid) * 2];
-        b2 += (double)sst[(w * BN + tid) * 2 + 1];
+      for (int w = 0; w < NW * 4; ++w) {
+        const float2 v = *reinterpret_cast<const float2*>(sst + (w * BN + tid) * 2);
+        a += (double)v.x;
+        b2 += (double)v.y;
       }
       const int co = cb * BN + tid;
       if (co < p.Cout) {
-        const long long slot = tile_id % (unsigned)(ntd * nth * ntw * (KS == 2 ? 8 : 1));  // one plain store per (tile, channel): fixed-order
-        double* dst = p.stats + ((slot * p.N + n) * p.Cout + co) * 2;                       // reduction by the consumers, no atomics
+        const long long slot = ((long long)(td_i * nth + th_i) * ntw + tw_i) * (KS == 2 ? 8 : 1) + par;  // = tile_id modulo the tiles per sample
+        double* dst = p.stats + ((slot * p.N + n) * p.Cout + co) * 2;  // one plain store per (tile, channel): fixed-order reduction by the consumers
         *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
       }
     }
@@ -501,10 +664,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 // variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile; 4 = sub-pixel 2x2x2 (5 planes of 5 x 17 -> 96 rows,
 // four 128-row weight panels); 5 = 8x4x16 tile x 128 output channels (three 384-row weight panels)
 extern "C" long long gm_conv_dma_lds_bytes(int variant) {
-  if (variant == 4) return 5LL * 96 * DMA_ROWB + 4LL * 128 * DMA_ROWB;
-  if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB;
+  const long long addv = 512;  // the epilogue addend vector (up to 128 floats) behind the operand buffers
+  if (variant == 4) return 5LL * 96 * DMA_ROWB + 4LL * 128 * DMA_ROWB + addv;
+  if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB + addv;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
-  return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB;
+  return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB + addv;
 }
 
 // geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)

@@ -1,4 +1,4 @@
-"""GPU, bench-only build (GM_EXTRA_HIPCC_FLAGS=-DGM_CONV_TIMELINE python -m generativemodels_amd._build --force): where the cycles of one
+"""GPU, bench-only build (python -m generativemodels_amd._build --variant timeline; run with GM_NATIVE_LIB=.../lib/libgmamd_timeline.so): where the cycles of one
 LDS-DMA convolution tile go.  Thread 0 of every work-group stamps the shader clock at phase boundaries (conv_dma.hip TL_STAMP); this
 script launches one convolution per shape / configuration and prints the median duration of every phase over the work-groups, split
 into the first wave of work-groups on the chip (cold start) and the steady state.   usage: python tools/conv_timeline.py"""
@@ -50,8 +50,12 @@ def report(name, t, nchunks):
         if len(tt) == 0:
             continue
         med = lambda a: int(np.median(a))  # noqa: E731
-        rows = [("address setup (entry -> first DMA issue)", tt[:, 1] - tt[:, 0]),
-                ("first patch + 2 panels landed (+ barrier)", tt[:, 2] - tt[:, 1])]
+        rows = [("entry -> tile decoded", tt[:, 53] - tt[:, 0]),
+                ("patch source addresses", tt[:, 54] - tt[:, 53]),
+                ("weight source addresses (-> first DMA issue)", tt[:, 1] - tt[:, 54]),
+                ("issue of the first patch + 2 panels, addend loads", tt[:, 55] - tt[:, 1]),
+                ("operand read addresses, accumulator init", tt[:, 56] - tt[:, 55]),
+                ("rest of the wait for the first DMAs (+ barrier)", tt[:, 2] - tt[:, 56])]
         prev = tt[:, 2]
         for c in range(min(nchunks, 5)):
             groups = []

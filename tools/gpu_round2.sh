@@ -1,5 +1,6 @@
 #!/bin/bash
 # One gpurun visit (round 2): stages t(ests) c(onv cfg check) p(mc of the conv kernel) b(ench) s(moke) k(ernel-trace profile) f(etch/write traffic)
+# m = cycle timeline of the conv kernel (needs lib/libgmamd_timeline.so: python -m generativemodels_amd._build --variant timeline)
 # usage: tools/gpu_round2.sh [stages] ; logs in gpurun_out/r2_*.log
 set -u
 cd "$(dirname "$0")/.."
@@ -14,6 +15,10 @@ nproc >> $LOG
 if [[ $STAGES == *s* ]]; then
   timeout 300 python __graft_entry__.py smoke > $OUT/r2_smoke.log 2>&1
   echo "smoke rc=$?" >> $LOG; tail -2 $OUT/r2_smoke.log >> $LOG
+fi
+if [[ $STAGES == *m* ]]; then
+  GM_NATIVE_LIB=$PWD/generativemodels_amd/lib/libgmamd_timeline.so timeout 300 python tools/conv_timeline.py > $OUT/r2_timeline.log 2>&1
+  echo "timeline rc=$?" >> $LOG; grep -A24 "64->64 @ 128^3 cfg11" $OUT/r2_timeline.log | grep -A14 "steady" >> $LOG
 fi
 if [[ $STAGES == *c* ]]; then
   timeout 900 python tools/check_conv_cfgs.py ${CONV_CFGS:-16,18,19} > $OUT/r2_conv_cfgs.log 2>&1
