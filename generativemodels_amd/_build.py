@@ -58,7 +58,7 @@ EXTRA_FLAGS = {"elementwise.hip": ["-ffp-contract=off"]}
 
 
 # bench-only variants: extra defines, their own object directory and library name (the product library is never built with them)
-VARIANTS = {"timeline": ["-DGM_CONV_TIMELINE"], "ablate": ["-DGM_CONV_ABLATE"]}
+VARIANTS = {"timeline": ["-DGM_CONV_TIMELINE"], "ablate": ["-DGM_CONV_ABLATE"], "timeline_ablate": ["-DGM_CONV_TIMELINE", "-DGM_CONV_ABLATE"]}
 _variant = None
 
 

@@ -22,7 +22,7 @@
 #ifdef GM_CONV_TIMELINE
 #define TL_STAMP(k)                                                                                                              \
   do {                                                                                                                           \
-    if ((p.debug_flags & 4096) && threadIdx.x == 0)                                                                              \
+    if ((p.debug_flags & 4096) && threadIdx.x == 0 && tl_on)                                                                            \
       reinterpret_cast<unsigned long long*>(p.kpartial)[(long long)blockIdx.x * 64 + (k)] = __builtin_readcyclecounter();        \
   } while (0)
 #else
@@ -65,9 +65,58 @@ __device__ __forceinline__ float dpp_row_ror8(float v) {  // value of lane ^ 8 (
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));
 }
 
+// sum over the four lanes {l, l ^ 8, l ^ 16, l ^ 32} ... of a wave: the rows (lane / 8) of one 16-byte output segment.  One DPP rotate and
+// the two gfx950 lane-swap instructions, no LDS round trip; every lane ends with the same value (fixed order of additions).
+__device__ __forceinline__ float wave_segment_sum(float v) {
+  v += dpp_row_ror8(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);  // rows 1 <-> 0, 3 <-> 2
+  v = __int_as_float(a[0]) + __int_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);  // lanes 32.. <-> ..31
+  return __int_as_float(b[0]) + __int_as_float(b[1]);
+}
+
+// output rows of one epilogue pass: element offset into y, inside-the-volume flag and the residual values of this lane's 16-byte segment
+template <int NIT> struct EpRows { long long yoff[NIT]; bool inside[NIT]; uint4 rv[NIT]; };
+
+struct EpTile { int n, od0, oh0, ow0, co_base, par; };  // (wave-uniform) output tile of the work-group
+
+template <typename T, int MF, int KS>
+__device__ __forceinline__ void dma_epilogue_place(const GmConvDesc& p, const EpTile& t, int line0, int lane, int co, int it, bool& in, long long& vox) {
+  const int Dl = KS == 2 ? p.Ds : p.Do, Hl = KS == 2 ? p.Hs : p.Ho, Wl = KS == 2 ? p.Ws : p.Wo;  // KS = 2: the tile walks the low-resolution grid
+  const int line = line0 + (it >> 1);                         // wave-uniform: W-line of the tile, (depth, height) = (line / 4, line % 4)
+  const int od = t.od0 + (line >> 2), oh = t.oh0 + (line & 3), ow = t.ow0 + (it & 1) * 8 + (lane >> 3);
+  in = co < p.Cout && od < Dl && oh < Hl && ow < Wl;
+  vox = KS == 2 ? (((long long)t.n * p.Do + 2 * od + ((t.par >> 2) & 1)) * p.Ho + 2 * oh + ((t.par >> 1) & 1)) * p.Wo + 2 * ow + (t.par & 1)
+                : (((long long)t.n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+}
+
+// addresses + residual requests of all row groups of pass PASS (no output activation: the hot form).  Called ahead of the transpose -- for
+// pass 0 right after the tap loop -- so that the residual's latency is covered by whatever runs in between.
+template <typename T, int MF, int KS, int PASS>
+__device__ __forceinline__ void dma_epilogue_rows(const GmConvDesc& p, const EpTile& t, int line0, int lane, EpRows<MF * 2>& R) {
+  constexpr int VECW = 16 / (int)sizeof(T), NF_PER_PASS = 128 / (16 * (int)sizeof(T)), NIT = MF * 2;
+  const T* res = reinterpret_cast<const T*>(p.res);
+  const int co = t.co_base + PASS * NF_PER_PASS * 16 + (lane & 7) * VECW;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    R.yoff[it] = 0;
+    R.inside[it] = false;
+    R.rv[it] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (p.post_act == 0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      long long vox;
+      dma_epilogue_place<T, MF, KS>(p, t, line0, lane, co, it, R.inside[it], vox);
+      R.yoff[it] = vox * p.y_ld + co;
+      if (res && R.inside[it]) R.rv[it] = *reinterpret_cast<const uint4*>(res + vox * p.res_ld + co);
+    }
+  }
+}
+
 template <typename T, int MF, int NFR, int KS, int PASS>
-__device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, const float* addv, int n, int line0,
-                                                  int od0, int oh0, int ow0, int co_base, int lane, int par,
+__device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, const float* addv, const EpTile& t, int line0,
+                                                  int lane, const EpRows<MF * 2>& R,
                                                   float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
                                                   float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)]) {
   constexpr int VECW = 16 / (int)sizeof(T);
@@ -77,37 +126,8 @@ __device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (
   const int l15 = lane & 15, q = lane >> 4, seg = lane & 7, lw = lane >> 3;
   T* yout = reinterpret_cast<T*>(p.y);
   const T* res = reinterpret_cast<const T*>(p.res);
-  const int co = co_base + PASS * NF_PER_PASS * 16 + seg * VECW;
-  const bool co_ok = co < p.Cout;
-  // KS = 2: the tile walks the low-resolution grid and lands on the (pd, ph, pw) sub-lattice of the 2x output
-  const int Dl = KS == 2 ? p.Ds : p.Do, Hl = KS == 2 ? p.Hs : p.Ho, Wl = KS == 2 ? p.Ws : p.Wo;
-  // ---- addresses + residual requests of all row groups (no output activation: the hot form) ---------------------------------------
+  const int co = t.co_base + PASS * NF_PER_PASS * 16 + seg * VECW;
   const bool fast = p.post_act == 0;  // wave-uniform; the activation form below is compact, sequential code (VQ-VAE / discriminator convolutions)
-  long long yoff[NIT];
-  bool inside[NIT];
-  uint4 rv[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    yoff[it] = 0;
-    inside[it] = false;
-    rv[it] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  auto place = [&](int it, bool& in, long long& vox) __attribute__((always_inline)) {
-    const int line = line0 + (it >> 1);                         // wave-uniform: W-line of the tile, (depth, height) = (line / 4, line % 4)
-    const int od = od0 + (line >> 2), oh = oh0 + (line & 3), ow = ow0 + (it & 1) * 8 + lw;
-    in = co_ok && od < Dl && oh < Hl && ow < Wl;
-    vox = KS == 2 ? (((long long)n * p.Do + 2 * od + ((par >> 2) & 1)) * p.Ho + 2 * oh + ((par >> 1) & 1)) * p.Wo + 2 * ow + (par & 1)
-                  : (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
-  };
-  if (fast) {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      long long vox;
-      place(it, inside[it], vox);
-      yoff[it] = vox * p.y_ld + co;
-      if (res && inside[it]) rv[it] = *reinterpret_cast<const uint4*>(res + vox * p.res_ld + co);
-    }
-  }
   // ---- accumulators + addend -> LDS, row = voxel, 4 channels per lane ---------------------------------------------------------------
 #pragma unroll
   for (int nl = 0; nl < NF_PER_PASS; ++nl) {
@@ -133,16 +153,16 @@ __device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       uint4 raw = *reinterpret_cast<const uint4*>(lds + (it * 8 + lw) * ROWB_E + seg * 16);
-      if (inside[it]) {
+      if (R.inside[it]) {
         if (res) {
           float o[VECW], r[VECW];
           Vec16<T>::unpack(raw, o);
-          Vec16<T>::unpack(rv[it], r);
+          Vec16<T>::unpack(R.rv[it], r);
 #pragma unroll
           for (int i = 0; i < VECW; ++i) o[i] += r[i];
           raw = Vec16<T>::pack(o);
         }
-        *reinterpret_cast<uint4*>(yout + yoff[it]) = raw;
+        *reinterpret_cast<uint4*>(yout + R.yoff[it]) = raw;
         if (p.stats) {  // statistics of the values as stored (rounded to T), like a separate pass over the tensor would see them
           float o[VECW];
           Vec16<T>::unpack(raw, o);
@@ -156,7 +176,7 @@ __device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (
     for (int it = 0; it < NIT; ++it) {
       bool in;
       long long vox;
-      place(it, in, vox);
+      dma_epilogue_place<T, MF, KS>(p, t, line0, lane, co, it, in, vox);
       if (in) {
         float o[VECW];
         Vec16<T>::unpack(*reinterpret_cast<const uint4*>(lds + (it * 8 + lw) * ROWB_E + seg * 16), o);
@@ -178,7 +198,7 @@ __device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (
       }
     }
   }
-  // the next pass overwrites the scratch this one read
+  // the next pass (or the statistic partials) overwrites the scratch this one read
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -229,64 +249,82 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB][addend vector 512 B]
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  TL_STAMP(0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
 
+  // ---- launch constants -------------------------------------------------------------------------------------------------------------------
   // KS = 2: the tiles walk the low-resolution grid (= the input grid); p.Do/Ho/Wo are the full-resolution output extents
   const int Dt = KS == 2 ? p.Ds : p.Do, Ht = KS == 2 ? p.Hs : p.Ho, Wt = KS == 2 ? p.Ws : p.Wo;
   const int ntd = (Dt + TD - 1) / TD, nth = (Ht + TH - 1) / TH, ntw = (Wt + TW - 1) / TW;
   const int ncb = (p.Cout + BN - 1) / BN;
-  unsigned b = xcd_remap(blockIdx.x, gridDim.x);
-  // split-K (small grids): the grid holds ksplit copies of the tile list; copy ks computes K chunks [c_begin, c_end) only
+  // split-K (small grids): the work list holds ksplit copies of the tile list; copy ks computes K chunks [c_begin, c_end) only
   const int ksplit = (KS == 3 && S == 1 && p.kpartial && p.ksplit > 1) ? p.ksplit : 1;
-  int ks = 0;
-  if (ksplit > 1) {  // (the divisions stay off the common path)
-    const unsigned tiles_all = gridDim.x / (unsigned)ksplit;
-    ks = (int)(b / tiles_all);
-    b -= (unsigned)ks * tiles_all;
-  }
-  const int cb = b % ncb; b /= ncb;
-  int par = 0;
-  if (KS == 2) { par = b & 7; b >>= 3; }
-  const int tw_i = b % ntw; b /= ntw;
-  const int th_i = b % nth; b /= nth;
-  const int td_i = b % ntd; b /= ntd;
-  const int n = b;
-  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
   int Dv = p.Ds, Hv = p.Hs, Wv = p.Ws;
   if (p.in_mode == 1) { Dv *= p.fd; Hv *= p.fh; Wv *= p.fw; }
-  // KS = 2: output parity 0 reads inputs (i - 1, i), parity 1 reads (i, i + 1): low-side padding 1 - parity
-  const int ud0 = od0 * S - (KS == 2 ? 1 - ((par >> 2) & 1) : p.pd), uh0 = oh0 * S - (KS == 2 ? 1 - ((par >> 1) & 1) : p.ph),
-            uw0 = ow0 * S - (KS == 2 ? 1 - (par & 1) : p.pw);
   const int nchunks = p.Cin / BK;                          // host-checked: Cin % BK == 0
   const int cout_pad = (p.Cout + 15) & ~15;
-  const int cps = ksplit > 1 ? (nchunks + ksplit - 1) / ksplit : nchunks;         // chunks per K slice (host-checked: (ksplit - 1) * cps < nchunks, no slice is empty)
-  const int c_begin = min(nchunks, ks * cps), c_end = min(nchunks, c_begin + cps);
-  const int total = (c_end - c_begin) * NGROUPS;            // an empty slice (never launched by the host) would touch nothing: total == 0
+  const int cps = ksplit > 1 ? (nchunks + ksplit - 1) / ksplit : nchunks;  // chunks per K slice (host-checked: (ksplit - 1) * cps < nchunks, no slice is empty)
 
-  TL_STAMP(53);
+  // ---- the work list of this work-group ---------------------------------------------------------------------------------------------------
+  // nwork = tiles x channel blocks (x 8 parities) (x K slices) work items.  The dispatcher deals consecutive work-groups round-robin to the 8
+  // XCDs (each with a private L2): XCD x owns the contiguous item range [sx, sx + cx) -- neighbouring halo patches meet in one L2 -- and its
+  // gx work-groups walk it with stride gx.  A grid of nwork work-groups (gx == cx) is the one-tile-per-work-group launch; the host caps the
+  // grid at the number of co-resident work-groups (gm_conv_dma_launch), and a work-group then runs several tiles back to back: the tile-
+  // independent address tables are built once and the first patch of the next tile is requested BEFORE the epilogue of the current one.
+  const unsigned nwork = (unsigned)p.N * ntd * nth * ntw * ncb * (KS == 2 ? 8u : 1u) * (unsigned)ksplit;
+  const unsigned xcd = blockIdx.x & 7, gx = (gridDim.x >> 3) + (xcd < (gridDim.x & 7) ? 1u : 0u);
+  const unsigned q8 = nwork >> 3, r8 = nwork & 7, cx = q8 + (xcd < r8 ? 1u : 0u), sx = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  unsigned pos = blockIdx.x >> 3;
+  if (pos >= cx) return;  // (never for gridDim.x <= nwork)
+#ifdef GM_CONV_TIMELINE
+  const unsigned tl_pos = pos + gx < cx ? pos + gx : pos;  // stamp the second tile of a persistent work-group (steady state), else its only one
+#endif
+
+  struct Tile { int cb, par, n, td_i, th_i, tw_i, ks; };
+  auto decode = [&](unsigned wi) __attribute__((always_inline)) {
+    Tile t;
+    unsigned b = wi;
+    t.ks = 0;
+    if (ksplit > 1) {  // (the divisions stay off the common path)
+      const unsigned tiles_all = nwork / (unsigned)ksplit;
+      t.ks = (int)(b / tiles_all);
+      b -= (unsigned)t.ks * tiles_all;
+    }
+    t.cb = b % ncb; b /= ncb;
+    t.par = 0;
+    if (KS == 2) { t.par = b & 7; b >>= 3; }
+    t.tw_i = b % ntw; b /= ntw;
+    t.th_i = b % nth; b /= nth;
+    t.td_i = b % ntd; b /= ntd;
+    t.n = b;
+    return t;
+  };
+
   // ---- per-lane DMA sources ---------------------------------------------------------------------------------------------
   // patch piece j of this wave covers LDS rows 16*(wave + NW*j) .. +15; lane -> (row, LDS slot lane&3) <- channel slot swizzled
   const char* zero = reinterpret_cast<const char*>(gm_zero_row);
   const char* xbase = reinterpret_cast<const char*>(p.x);
-  int pvox[PPW];  // source voxel of this lane's patch row per piece, or -1 for a padding row (32-bit: host checks N*V < 2^31)
   const int pswz = ((lane & 3) ^ dma_swz(lane >> 2)) << 4;  // piece bases are multiples of 16 rows: the swizzle term is per lane
+  int pvox[PPW];  // source voxel of this lane's patch row per piece, or -1 for a padding row (32-bit: host checks N*V < 2^31)
+  auto place_patch = [&](const Tile& t) __attribute__((always_inline)) {
+    // KS = 2: output parity 0 reads inputs (i - 1, i), parity 1 reads (i, i + 1): low-side padding 1 - parity
+    const int ud0 = t.td_i * TD * S - (KS == 2 ? 1 - ((t.par >> 2) & 1) : p.pd), uh0 = t.th_i * TH * S - (KS == 2 ? 1 - ((t.par >> 1) & 1) : p.ph),
+              uw0 = t.tw_i * TW * S - (KS == 2 ? 1 - (t.par & 1) : p.pw);
 #pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int row = 16 * (wave + NW * j) + (lane >> 2);
-    const int pa = row / PLANE, rr = row - pa * PLANE;
-    const int pb = rr / PW, lc = rr - pb * PW;
-    const int pc = S == 1 ? lc : (lc < EW ? 2 * lc : 2 * (lc - EW) + 1);  // S = 2: even columns first, then the odd ones
-    int ud = ud0 + pa, uh = uh0 + pb, uw = uw0 + pc;
-    const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv);
-    if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
-    pvox[j] = ok ? ((n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
-  }
-  TL_STAMP(54);
+    for (int j = 0; j < PPW; ++j) {
+      const int row = 16 * (wave + NW * j) + (lane >> 2);  // (the row's place in the patch is recomputed per tile: two constant divisions
+      const int pa = row / PLANE, rr = row - pa * PLANE;   //  are cheaper than six more live registers across the tap loop)
+      const int pb = rr / PW, lc = rr - pb * PW;
+      const int pc = S == 1 ? lc : (lc < EW ? 2 * lc : 2 * (lc - EW) + 1);  // S = 2: even columns first, then the odd ones
+      int ud = ud0 + pa, uh = uh0 + pb, uw = uw0 + pc;
+      const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv);
+      if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
+      pvox[j] = ok ? ((t.n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
+    }
+  };
   const long long xrowb = p.x_ld * (long long)sizeof(T);
   // optional second source: input channels [cin_split, Cin) come from x2 (the never-materialised torch.cat([h, skip]) of the decoder)
   const char* x2base = reinterpret_cast<const char*>(p.x2);
@@ -308,6 +346,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       }
     }
   };
+
+  Tile cur = decode(sx + pos);
+  place_patch(cur);
+  if (min(nchunks, cur.ks * cps) < nchunks) issue_patch(min(nchunks, cur.ks * cps));  // the first patch of the first tile
+
   // ---- fused GroupNorm-apply + activation prologue (pre_scale / pre_shift / pre_act), applied IN LDS to the landed patch ---------------
   // Each lane transforms exactly the 16-byte pieces it DMA'd itself (piece j, row 16 * (wave + NW * j) + lane / 4, LDS slot lane & 3 =
   // channel slot cs of the chunk): act(x * scale[n][c] + shift[n][c]) in fp32, rounded back to T -- the same arithmetic and rounding as
@@ -319,8 +362,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   float sc[VECW], sh[VECW];  // this lane's scale / shift for the chunk being staged: loaded next to the patch DMA, consumed after its wait
   auto load_affine = [&](int chunk) __attribute__((always_inline)) {
     const int c0 = chunk * BK + (pswz >> 4) * VECW;  // this lane's channels within cat(x, x2): the same slot for every piece
-    const float* ps = p.pre_scale + (long long)n * p.Cin + c0;
-    const float* ph = p.pre_shift + (long long)n * p.Cin + c0;
+    const float* ps = p.pre_scale + (long long)cur.n * p.Cin + c0;
+    const float* ph = p.pre_shift + (long long)cur.n * p.Cin + c0;
 #pragma unroll
     for (int i = 0; i < VECW; i += 4) {
       const float4 a = *reinterpret_cast<const float4*>(ps + i), b = *reinterpret_cast<const float4*>(ph + i);
@@ -346,20 +389,24 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stores are in LDS before the barrier that follows
   };
 
+
   // weight panel of global tap group t (chunk = t / 9, taps 3*(t%9) ..): rows r = u*64 + co_local.  Wave w moves rows
   // 16w .. 16w+15 (full piece) and rows 128 + 8w .. +7 (half piece, lanes 0..31).
-  const char* wbase = reinterpret_cast<const char*>(p.w) + (long long)par * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;  // parity image
-  int wsrc[WPW];  // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
+  const char* wbase = nullptr;  // parity image of the current tile
+  int wsrc[WPW];                // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
+  auto place_weights = [&](const Tile& t) __attribute__((always_inline)) {
+    wbase = reinterpret_cast<const char*>(p.w) + (long long)t.par * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;
 #pragma unroll
-  for (int h = 0; h < WPW; ++h) {
-    const int row = WGEN ? 16 * (wave + NW * h) + (lane >> 2)
-                  : KS == 2 ? 16 * wave + (lane >> 2)
-                            : NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2))
-                                      : (NW == 4 ? 16 * (wave + NW * h) + (lane >> 2) : 16 * (wave < 12 ? wave : 0) + (lane >> 2));
-    const int u = row / BN, col = row % BN;
-    const int co = cb * BN + col;
-    wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
-  }
+    for (int h = 0; h < WPW; ++h) {
+      const int row = WGEN ? 16 * (wave + NW * h) + (lane >> 2)
+                    : KS == 2 ? 16 * wave + (lane >> 2)
+                              : NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2))
+                                        : (NW == 4 ? 16 * (wave + NW * h) + (lane >> 2) : 16 * (wave < 12 ? wave : 0) + (lane >> 2));
+      const int u = row / BN, col = row % BN;
+      const int co = t.cb * BN + col;
+      wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
+    }
+  };
   auto issue_w = [&](int t, int buf) __attribute__((always_inline)) {  // WPW instructions per wave, every wave
 #ifdef GM_CONV_ABLATE
     if (p.debug_flags & 512) return;  // bench-only: no weight traffic (results are garbage)
@@ -384,27 +431,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
   };
 
-  // ---- first DMAs out as early as possible: everything below that does not feed them runs while they are in flight ------------------
-  TL_STAMP(1);
-  if (total > 0) {
-    issue_patch(c_begin);
-    issue_w(c_begin * NGROUPS, 0);
-    if (total > 1) issue_w(c_begin * NGROUPS + 1, 1);
-    if (pre) load_affine(c_begin);
-  }
-  // per-channel epilogue addend of this work-group's BN output channels: bias + shortcut bias + timestep row (this order), fp32, in LDS
-  float* addv = reinterpret_cast<float*>(smem + PATCH_BYTES + RING * WBUF_BYTES);
-  float addend = 0.f;
-  if (tid < BN) {
-    const int co = cb * BN + tid;
-    if (co < p.Cout) {
-      if (p.bias) addend += p.bias[co];
-      if (p.skip_bias) addend += p.skip_bias[co];
-      if (p.rowvec) addend += p.rowvec[(long long)n * p.rowvec_bstride + co];
-    }
-  }
 
-  TL_STAMP(55);
   // ---- per-lane operand read addresses (bytes from smem) ------------------------------------------------------------------
   // A wave's MF fragments are MF consecutive H rows of one tile plane ((wave * MF + mf) * 16 + l15 with TH = 4, TW = 16), so fragment mf
   // at tap row kh reads patch row S * (bb0 + mf) + kh: the addresses depend on hk = S * mf + kh only -- HK x KS registers, not MF x KS x KS.
@@ -431,244 +458,339 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     waddr[nf] = PATCH_BYTES + r * DMA_ROWB + ((q ^ dma_swz(r)) << 4);
   }
 
-  f32x4_t acc[NFR][MF];
-#pragma unroll
-  for (int nf = 0; nf < NFR; ++nf)
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  TL_STAMP(56);
-  if (tid < BN) addv[tid] = addend;
-  if (total > 0) {
-    dma_wait<0>();
-    if (pre) transform_patch();
-  }
-  __builtin_amdgcn_s_barrier();
-  TL_STAMP(2);
-
-  // ---- main loop ----------------------------------------------------------------------------------------------------------
-
-  // debug_flags bit 11 (bench-only A/B, results unaffected): the tap loop runs at wave priority 1, prologue / epilogue at 0, so that the
-  // co-resident work-group's address arithmetic and stores yield issue slots to this one's ds_read / MFMA stream
-  if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(1);
-  for (int chunk = c_begin; chunk < c_end; ++chunk) {
-    const bool last_chunk = chunk + 1 == c_end;
-#pragma unroll
-    for (int g = 0; g < NGROUPS; ++g) {
-      const int t = chunk * NGROUPS + g;
-      // panel t+2 goes into the ring slot group t-1 read from (every wave is past the barrier that ended it)
-      if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % RING);
-      // The last tap's operand reads are issued before the end-of-group wait and its MFMAs after the barrier.  The wait retires
-      // every LDS read of the group (lgkmcnt(0)): the barrier releases other waves to DMA into the ring slot this group read.
-      // (Measured against an ordering that keeps the two patch reads of the last tap in flight across the barrier: 2-3 % slower.)
-      // BN = 128 splits a tap into NH = 2 half-steps of four channel fragments each (16 + 16 operand registers instead of 48).
-      constexpr int NH = NFR / 4, NSTEPS = G * NH;
-      uint4 xf[MF], wf[4];
-      auto read_step = [&](int st) __attribute__((always_inline)) {
-        const int u = st / NH, hf = st % NH;
-        const int tap = g * G + u;
-        const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
-          wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + hf * (64 * DMA_ROWB) + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
-        if (hf == 0) {
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf)
-            xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[S * mf + kh][kw] + kd * (PLANE * DMA_ROWB));
-        }
-      };
-      auto mma_step = [&](int st) __attribute__((always_inline)) {
-        const int hf = st % NH;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[hf * 4 + nf][mf]);
-      };
-      constexpr int NMMA = MF * 4 * (sizeof(T) == 2 ? 1 : 4);
-#pragma unroll
-      for (int st = 0; st < NSTEPS - 1; ++st) {
-        read_step(st);
-        mma_step(st);
-        if (st % NH == 0) __builtin_amdgcn_sched_group_barrier(0x100, MF + 4, 0);  // all operand reads of a step before its MFMAs
-        else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
-      }
-      read_step(NSTEPS - 1);
-      if (g == NGROUPS - 1) {
-        if (!last_chunk) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
-          issue_patch(chunk + 1);
-          if (pre) load_affine(chunk + 1);
-          dma_wait<0>();                 // patch + the two panels in flight
-          if (pre) transform_patch();
-          __builtin_amdgcn_s_barrier();
-        }
-      } else {
-        // panel t+1 (issued a group ago) must have landed; panel t+2 (WPW instructions, just issued) may stay in flight
-        if ((g < NGROUPS - 2 || !last_chunk) && (NW != 16 || wave < 12)) dma_wait<WPW>(); else dma_wait<0>();
-        __builtin_amdgcn_s_barrier();
-      }
-      mma_step(NSTEPS - 1);
-      if (chunk - c_begin < 5) TL_STAMP(3 + (chunk - c_begin) * 10 + g);  // after the barrier that ends group g (g = 8: incl. the chunk boundary)
-    }
-  }
-  TL_STAMP(60);
-
-  if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(0);
-  // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
-  // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
-  // and one piece of the two 4 KiB weight panels into the ring, one wait + barrier, then 2 x 8 MFMAs.
-  if (p.skip_x[0] && ks == ksplit - 1) {  // (split-K: the shortcut's chunks ride with the last K slice)
-    const int nsc0 = p.skip_cin[0] / BK, nsc = nsc0 + (p.skip_x[1] ? p.skip_cin[1] / BK : 0);
-    int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
-#pragma unroll
-    for (int h = 0; h < MF; ++h) {
-      const int m = wave * (MF * 16) + h * 16 + (lane >> 2);  // (a, bb, c) below assume TH = 4, TW = 16
-      const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
-      svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
-    }
-    const int wpiece = WGEN ? wave : (wave & 3);        // BN = 64: piece wave&3 of a 4-piece panel; BN = 128 (8 waves): piece wave of 8
-    const int wcol = wpiece * 16 + (lane >> 2);         // weight row of this lane's panel piece
-    const int wco = cb * BN + wcol;
-    const int wswz = ((lane & 3) ^ dma_swz(wcol)) << 4;
-    int caddr[MF];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      const int m = (wave * MF + mf) * 16 + l15;
-      caddr[mf] = m * DMA_ROWB + ((q ^ dma_swz(m)) << 4);
-    }
-    const char* wsk = reinterpret_cast<const char*>(p.skip_w);
-    for (int sc0 = 0; sc0 < nsc; sc0 += 2) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // patch buffer and ring are free
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int sc = sc0 + j;
-        if (sc < nsc) {  // wave-uniform
-          const int part = sc >= nsc0 ? 1 : 0, cip = sc - (part ? nsc0 : 0);
-          const char* xb = reinterpret_cast<const char*>(p.skip_x[part]) + (long long)cip * (BK * (int)sizeof(T)) + pswz;
-          const long long rowb = p.skip_ld[part] * (long long)sizeof(T);
-#pragma unroll
-          for (int h = 0; h < MF; ++h) {
-            const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
-            dma16(src, lds0 + (unsigned)(j * BM + wave * (MF * 16) + h * 16) * DMA_ROWB);
-          }
-          if (WGEN || NW == 4 || (wave >> 2) == j) {  // 8 waves: waves 0-3 move panel 0, waves 4-7 panel 1; 4 waves / BN = 128: every wave moves both
-            const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane & 3) << 4);
-            dma16(src, lds0 + PATCH_BYTES + (unsigned)(j * BN + wpiece * 16) * DMA_ROWB);
-          }
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (sc0 + j < nsc) {
-          uint4 xf[MF], wf[4];
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(smem + caddr[mf] + j * (BM * DMA_ROWB));
-#pragma unroll
-          for (int hf = 0; hf < NFR / 4; ++hf) {
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-              wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + hf * (64 * DMA_ROWB) + j * (BN * DMA_ROWB));
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-              for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[hf * 4 + nf][mf]);
-          }
-        }
-      }
-    }
-  }
-
-  TL_STAMP(61);
-  // ---- split-K: this slice's fp32 partial sums -> kpartial[ks][n * V + voxel][Cout]; the combine kernel applies the epilogue ----------
-  if (KS == 3 && S == 1 && ksplit > 1) {
-    const long long nv = (long long)p.N * p.Do * p.Ho * p.Wo;
-    float* part = p.kpartial + (long long)ks * nv * p.Cout;
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      const int m = (wave * MF + mf) * 16 + l15;
-      const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
-      if (od < p.Do && oh < p.Ho && ow < p.Wo) {
-        float* row = part + ((((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout;
-#pragma unroll
-        for (int nf = 0; nf < NFR; ++nf) {
-          const int co = cb * BN + nf * 16 + q * 4;
-          if (co < p.Cout)  // host-checked: Cout % 4 == 0
-            *reinterpret_cast<float4*>(row + co) = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
-        }
-      }
-    }
-    return;
-  }
-
-  // ---- epilogue (shared with conv_fast): LDS transpose -> 16-byte row stores, fused GroupNorm statistics -------------------
-#ifdef GM_CONV_ABLATE
-  if (p.debug_flags & 256) return;  // bench-only: main loop without the epilogue
-#endif
-  __syncthreads();  // every wave is done with the operand buffers: the transpose scratch overlays them
+  // ---- LDS regions of the epilogue ---------------------------------------------------------------------------------------------------------
+  // Transpose scratch: NW wave-private blocks of MF*16 rows x 144 B.  When they fit into the weight ring (EARLY: cfg 11 / 14 / 15 / 17 / 19) the
+  // patch buffer is free from the last tap on, and the next tile's first patch is requested before the epilogue; otherwise (the 512-voxel x
+  // 64-channel tiles) the scratch overlays the patch buffer and the request follows the epilogue.
+  constexpr int SCRATCH_WAVE = MF * 16 * 144, SCRATCH_BYTES = NW * SCRATCH_WAVE;
+  constexpr int RING_BYTES = KS == 2 ? (RING * WBUF_BYTES > 36864 ? RING * WBUF_BYTES : 36864) : RING * WBUF_BYTES;  // KS = 2: padded to hold the scratch
+  constexpr bool EARLY = SCRATCH_BYTES <= RING_BYTES;
+  constexpr int SCRATCH_OFF = EARLY ? PATCH_BYTES : 0;
+  static_assert(EARLY || SCRATCH_BYTES <= PATCH_BYTES + RING_BYTES, "the transpose scratch fits under the addend vector");
+  static_assert(BN * 8 <= SCRATCH_WAVE, "a wave's statistic partials fit into its scratch block");
+  float* addv = reinterpret_cast<float*>(smem + PATCH_BYTES + RING_BYTES);  // per-channel epilogue addend of this work-group's BN output channels
   constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
   constexpr int CH_PER_PASS = 128 / (int)sizeof(T);
-  constexpr int SCRATCH_BYTES = NW * MF * 16 * 144;                                         // wave-private transpose scratch, from smem + 0
-  constexpr int SST_OFF = SCRATCH_BYTES > PATCH_BYTES ? SCRATCH_BYTES : PATCH_BYTES;      // statistic partials: clear of every wave's scratch
-  static_assert(SST_OFF + NW * 4 * BN * 8 <= PATCH_BYTES + RING * WBUF_BYTES, "scratch + statistic partials fit under the addend vector");
-  float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
+  static_assert(EPASSES <= 4, "at most 4 epilogue passes (128 output channels in fp32)");
+
+  for (;;) {
+#ifdef GM_CONV_TIMELINE
+    const bool tl_on = pos == tl_pos;
+#endif
+    TL_STAMP(0);
+    const int c_begin = min(nchunks, cur.ks * cps), c_end = min(nchunks, c_begin + cps);
+    const int total = (c_end - c_begin) * NGROUPS;            // an empty slice (never launched by the host) would touch nothing: total == 0
+    const int od0 = cur.td_i * TD, oh0 = cur.th_i * TH, ow0 = cur.tw_i * TW;
+    // ---- the first panels go out behind the patch already in flight; everything below that does not feed them runs under the DMA ------------
+    TL_STAMP(1);
+    place_weights(cur);
+    if (total > 0) {
+      issue_w(c_begin * NGROUPS, 0);
+      if (total > 1) issue_w(c_begin * NGROUPS + 1, 1);
+      if (pre) load_affine(c_begin);
+    }
+    // bias + shortcut bias + timestep row (this order), fp32
+    float addend = 0.f;
+    if (tid < BN) {
+      const int co = cur.cb * BN + tid;
+      if (co < p.Cout) {
+        if (p.bias) addend += p.bias[co];
+        if (p.skip_bias) addend += p.skip_bias[co];
+        if (p.rowvec) addend += p.rowvec[(long long)cur.n * p.rowvec_bstride + co];
+      }
+    }
+    TL_STAMP(55);
+    f32x4_t acc[NFR][MF];
 #pragma unroll
-  for (int e = 0; e < EPASSES; ++e)
+    for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-    for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
-  {
-    char* scratch = smem + (size_t)wave * (MF * 16 * 144);
-    dma_epilogue_pass<T, MF, NFR, KS, 0>(p, acc, scratch, addv, n, wave * MF, od0, oh0, ow0, cb * BN, lane, par, st_s, st_q);
-    if constexpr (EPASSES > 1) dma_epilogue_pass<T, MF, NFR, KS, 1>(p, acc, scratch, addv, n, wave * MF, od0, oh0, ow0, cb * BN, lane, par, st_s, st_q);
-    if constexpr (EPASSES > 2) dma_epilogue_pass<T, MF, NFR, KS, 2>(p, acc, scratch, addv, n, wave * MF, od0, oh0, ow0, cb * BN, lane, par, st_s, st_q);
-    if constexpr (EPASSES > 3) dma_epilogue_pass<T, MF, NFR, KS, 3>(p, acc, scratch, addv, n, wave * MF, od0, oh0, ow0, cb * BN, lane, par, st_s, st_q);
-    static_assert(EPASSES <= 4, "at most 4 epilogue passes (128 output channels in fp32)");
-  }
-  TL_STAMP(62);
-  if (p.stats) {
-    float* sst = reinterpret_cast<float*>(smem + SST_OFF);  // [NW][4 lane rows][BN channels][2]
+      for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (tid < BN) addv[tid] = addend;
+    TL_STAMP(56);
+    if (total > 0) {
+      dma_wait<0>();
+      if (pre) transform_patch();
+    }
+    __builtin_amdgcn_s_barrier();
+    TL_STAMP(2);
+
+    // ---- main loop ----------------------------------------------------------------------------------------------------------
+    // debug_flags bit 11 (bench-only A/B, results unaffected): the tap loop runs at wave priority 1, prologue / epilogue at 0, so that the
+    // co-resident work-group's address arithmetic and stores yield issue slots to this one's ds_read / MFMA stream
+    if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(1);
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+      const bool last_chunk = chunk + 1 == c_end;
+  #pragma unroll
+      for (int g = 0; g < NGROUPS; ++g) {
+        const int t = chunk * NGROUPS + g;
+        // panel t+2 goes into the ring slot group t-1 read from (every wave is past the barrier that ended it)
+        if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % RING);
+        // The last tap's operand reads are issued before the end-of-group wait and its MFMAs after the barrier.  The wait retires
+        // every LDS read of the group (lgkmcnt(0)): the barrier releases other waves to DMA into the ring slot this group read.
+        // (Measured against an ordering that keeps the two patch reads of the last tap in flight across the barrier: 2-3 % slower.)
+        // BN = 128 splits a tap into NH = 2 half-steps of four channel fragments each (16 + 16 operand registers instead of 48).
+        constexpr int NH = NFR / 4, NSTEPS = G * NH;
+        uint4 xf[MF], wf[4];
+        auto read_step = [&](int st) __attribute__((always_inline)) {
+          const int u = st / NH, hf = st % NH;
+          const int tap = g * G + u;
+          const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+  #pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+            wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + hf * (64 * DMA_ROWB) + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
+          if (hf == 0) {
+  #pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+              xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[S * mf + kh][kw] + kd * (PLANE * DMA_ROWB));
+          }
+        };
+        auto mma_step = [&](int st) __attribute__((always_inline)) {
+          const int hf = st % NH;
+  #pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+  #pragma unroll
+            for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[hf * 4 + nf][mf]);
+        };
+        constexpr int NMMA = MF * 4 * (sizeof(T) == 2 ? 1 : 4);
+  #pragma unroll
+        for (int st = 0; st < NSTEPS - 1; ++st) {
+          read_step(st);
+          mma_step(st);
+          if (st % NH == 0) __builtin_amdgcn_sched_group_barrier(0x100, MF + 4, 0);  // all operand reads of a step before its MFMAs
+          else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+        }
+        read_step(NSTEPS - 1);
+        if (g == NGROUPS - 1) {
+          if (!last_chunk) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
+            issue_patch(chunk + 1);
+            if (pre) load_affine(chunk + 1);
+            dma_wait<0>();                 // patch + the two panels in flight
+            if (pre) transform_patch();
+            __builtin_amdgcn_s_barrier();
+          }
+        } else {
+          // panel t+1 (issued a group ago) must have landed; panel t+2 (WPW instructions, just issued) may stay in flight
+          if ((g < NGROUPS - 2 || !last_chunk) && (NW != 16 || wave < 12)) dma_wait<WPW>(); else dma_wait<0>();
+          __builtin_amdgcn_s_barrier();
+        }
+        mma_step(NSTEPS - 1);
+        if (chunk - c_begin < 5) TL_STAMP(3 + (chunk - c_begin) * 10 + g);  // after the barrier that ends group g (g = 8: incl. the chunk boundary)
+      }
+    }
+  TL_STAMP(60);
+    if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(0);
+
+    const EpTile et = {cur.n, od0, oh0, ow0, cur.cb * BN, cur.par};
+    const bool partial = KS == 3 && S == 1 && ksplit > 1;
+    EpRows<MF * 2> rows0;
+    if (!partial) dma_epilogue_rows<T, MF, KS, 0>(p, et, wave * MF, lane, rows0);  // residual rows of the first pass: requested now, used after the transpose
+
+    // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
+    // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
+    // and one piece of the two 4 KiB weight panels into the ring, one wait + barrier, then 2 x 8 MFMAs.
+    if (p.skip_x[0] && cur.ks == ksplit - 1) {  // (split-K: the shortcut's chunks ride with the last K slice)
+      const int nsc0 = p.skip_cin[0] / BK, nsc = nsc0 + (p.skip_x[1] ? p.skip_cin[1] / BK : 0);
+      int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
+  #pragma unroll
+      for (int h = 0; h < MF; ++h) {
+        const int m = wave * (MF * 16) + h * 16 + (lane >> 2);  // (a, bb, c) below assume TH = 4, TW = 16
+        const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+        svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((cur.n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
+      }
+      const int wpiece = WGEN ? wave : (wave & 3);        // BN = 64: piece wave&3 of a 4-piece panel; BN = 128 (8 waves): piece wave of 8
+      const int wcol = wpiece * 16 + (lane >> 2);         // weight row of this lane's panel piece
+      const int wco = cur.cb * BN + wcol;
+      const int wswz = ((lane & 3) ^ dma_swz(wcol)) << 4;
+      int caddr[MF];
+  #pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int m = (wave * MF + mf) * 16 + l15;
+        caddr[mf] = m * DMA_ROWB + ((q ^ dma_swz(m)) << 4);
+      }
+      const char* wsk = reinterpret_cast<const char*>(p.skip_w);
+      for (int sc0 = 0; sc0 < nsc; sc0 += 2) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // patch buffer and ring are free
+  #pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int sc = sc0 + j;
+          if (sc < nsc) {  // wave-uniform
+            const int part = sc >= nsc0 ? 1 : 0, cip = sc - (part ? nsc0 : 0);
+            const char* xb = reinterpret_cast<const char*>(p.skip_x[part]) + (long long)cip * (BK * (int)sizeof(T)) + pswz;
+            const long long rowb = p.skip_ld[part] * (long long)sizeof(T);
+  #pragma unroll
+            for (int h = 0; h < MF; ++h) {
+              const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
+              dma16(src, lds0 + (unsigned)(j * BM + wave * (MF * 16) + h * 16) * DMA_ROWB);
+            }
+            if (WGEN || NW == 4 || (wave >> 2) == j) {  // 8 waves: waves 0-3 move panel 0, waves 4-7 panel 1; 4 waves / BN = 128: every wave moves both
+              const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane & 3) << 4);
+              dma16(src, lds0 + PATCH_BYTES + (unsigned)(j * BN + wpiece * 16) * DMA_ROWB);
+            }
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+  #pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (sc0 + j < nsc) {
+            uint4 xf[MF], wf[4];
+  #pragma unroll
+            for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(smem + caddr[mf] + j * (BM * DMA_ROWB));
+  #pragma unroll
+            for (int hf = 0; hf < NFR / 4; ++hf) {
+  #pragma unroll
+              for (int nf = 0; nf < 4; ++nf)
+                wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + hf * (64 * DMA_ROWB) + j * (BN * DMA_ROWB));
+  #pragma unroll
+              for (int nf = 0; nf < 4; ++nf)
+  #pragma unroll
+                for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[hf * 4 + nf][mf]);
+            }
+          }
+        }
+      }
+    }
+
+
+    TL_STAMP(61);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the operand buffers (patch + ring) of this tile
+    // ---- next tile: its first patch is on the way while this tile's epilogue runs ------------------------------------------------------------
+    const bool has_next = pos + gx < cx;
+    Tile nxt = cur;
+    if (has_next) {
+      nxt = decode(sx + pos + gx);
+      place_patch(nxt);
+      if (EARLY && min(nchunks, nxt.ks * cps) < nchunks) issue_patch(min(nchunks, nxt.ks * cps));
+    }
+    TL_STAMP(57);
+    // ---- split-K: this slice's fp32 partial sums -> kpartial[ks][n * V + voxel][Cout]; the combine kernel applies the epilogue ----------
+    if (KS == 3 && S == 1 && ksplit > 1) {
+      const long long nv = (long long)p.N * p.Do * p.Ho * p.Wo;
+      float* part = p.kpartial + (long long)cur.ks * nv * p.Cout;
+  #pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int m = (wave * MF + mf) * 16 + l15;
+        const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+        if (od < p.Do && oh < p.Ho && ow < p.Wo) {
+          float* row = part + ((((long long)cur.n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout;
+  #pragma unroll
+          for (int nf = 0; nf < NFR; ++nf) {
+            const int co = cur.cb * BN + nf * 16 + q * 4;
+            if (co < p.Cout)  // host-checked: Cout % 4 == 0
+              *reinterpret_cast<float4*>(row + co) = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
+          }
+        }
+      }
+    } else {
+
+    // ---- epilogue: LDS transpose -> 16-byte row stores, fused GroupNorm statistics ------------------------------------------------------------
+#ifdef GM_CONV_ABLATE
+    if (!(p.debug_flags & 256)) {  // bench-only: main loop without the epilogue
+#endif
+    float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
 #pragma unroll
     for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
-      for (int i = 0; i < VECW; ++i) {
-        const float a = st_s[e][i] + dpp_row_ror8(st_s[e][i]), b2 = st_q[e][i] + dpp_row_ror8(st_q[e][i]);
-        if ((lane & 8) == 0) {
-          const int ch = e * CH_PER_PASS + (lane & 7) * VECW + i;
-          *reinterpret_cast<float2*>(sst + ((wave * 4 + (lane >> 4)) * BN + ch) * 2) = make_float2(a, b2);
+      for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
+    char* scratch = smem + SCRATCH_OFF + (size_t)wave * SCRATCH_WAVE;
+    dma_epilogue_pass<T, MF, NFR, KS, 0>(p, acc, scratch, addv, et, wave * MF, lane, rows0, st_s, st_q);
+    if constexpr (EPASSES > 1) {
+      EpRows<MF * 2> rows;
+      dma_epilogue_rows<T, MF, KS, 1>(p, et, wave * MF, lane, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 1>(p, acc, scratch, addv, et, wave * MF, lane, rows, st_s, st_q);
+    }
+    if constexpr (EPASSES > 2) {
+      EpRows<MF * 2> rows;
+      dma_epilogue_rows<T, MF, KS, 2>(p, et, wave * MF, lane, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 2>(p, acc, scratch, addv, et, wave * MF, lane, rows, st_s, st_q);
+    }
+    if constexpr (EPASSES > 3) {
+      EpRows<MF * 2> rows;
+      dma_epilogue_rows<T, MF, KS, 3>(p, et, wave * MF, lane, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 3>(p, acc, scratch, addv, et, wave * MF, lane, rows, st_s, st_q);
+    }
+    TL_STAMP(62);
+    if (p.stats) {
+      // lane sums over its rows -> sum over the 8 row lanes of a segment (registers) -> one partial per (wave, channel) in the wave's own
+      // scratch block -> fixed-order fp64 sum over the waves: deterministic, one plain store per (tile, channel)
+      float2* part = reinterpret_cast<float2*>(scratch);
+#pragma unroll
+      for (int e = 0; e < EPASSES; ++e)
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) {
+          const float a = wave_segment_sum(st_s[e][i]), b2 = wave_segment_sum(st_q[e][i]);
+          if (lane < 8) part[e * CH_PER_PASS + lane * VECW + i] = make_float2(a, b2);
+        }
+      __syncthreads();
+      if (tid < BN) {
+        double a = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const float2 v = *reinterpret_cast<const float2*>(smem + SCRATCH_OFF + w * SCRATCH_WAVE + tid * 8);
+          a += (double)v.x;
+          b2 += (double)v.y;
+        }
+        const int co = cur.cb * BN + tid;
+        if (co < p.Cout) {
+          const long long slot = ((long long)(cur.td_i * nth + cur.th_i) * ntw + cur.tw_i) * (KS == 2 ? 8 : 1) + cur.par;  // the tile within its sample
+          double* dst = p.stats + ((slot * p.N + cur.n) * p.Cout + co) * 2;  // fixed-order reduction over the slots by the consumers, no atomics
+          *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
         }
       }
-    __syncthreads();
-    if (tid < BN) {
-      double a = 0.0, b2 = 0.0;
-#pragma unroll
-      for (int w = 0; w < NW * 4; ++w) {
-        const float2 v = *reinterpret_cast<const float2*>(sst + (w * BN + tid) * 2);
-        a += (double)v.x;
-        b2 += (double)v.y;
-      }
-      const int co = cb * BN + tid;
-      if (co < p.Cout) {
-        const long long slot = ((long long)(td_i * nth + th_i) * ntw + tw_i) * (KS == 2 ? 8 : 1) + par;  // = tile_id modulo the tiles per sample
-        double* dst = p.stats + ((slot * p.N + n) * p.Cout + co) * 2;  // one plain store per (tile, channel): fixed-order reduction by the consumers
-        *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
-      }
     }
+#ifdef GM_CONV_ABLATE
+    }
+#endif
+    }  // (not a split-K slice)
+    TL_STAMP(63);
+    if (!has_next) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // scratch, statistic partials and the addend vector of this tile have been read: ring and patch buffer are free
+    if (!EARLY && min(nchunks, nxt.ks * cps) < nchunks) issue_patch(min(nchunks, nxt.ks * cps));
+    cur = nxt;
+    pos += gx;
   }
-  TL_STAMP(63);
 }
 
 // variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile; 4 = sub-pixel 2x2x2 (5 planes of 5 x 17 -> 96 rows,
-// four 128-row weight panels); 5 = 8x4x16 tile x 128 output channels (three 384-row weight panels)
+// four 128-row weight panels, padded to the 36 KiB of the epilogue's transpose scratch); 5 = 8x4x16 tile x 128 output channels (three 384-row
+// weight panels).  Every variant ends with the 512-byte epilogue addend vector.
 extern "C" long long gm_conv_dma_lds_bytes(int variant) {
-  const long long addv = 512;  // the epilogue addend vector (up to 128 floats) behind the operand buffers
-  if (variant == 4) return 5LL * 96 * DMA_ROWB + 4LL * 128 * DMA_ROWB + addv;
+  const long long addv = 512;
+  if (variant == 4) return 5LL * 96 * DMA_ROWB + 36864 + addv;
   if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB + addv;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
   return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB + addv;
+}
+
+// Grid policy: -1 (default) = at most as many work-groups as the device holds at once (CUs x work-groups per CU by LDS and wave count): a
+// work-group then walks several tiles (see the kernel's work list); 0 = one work-group per tile; n > 0 = at most n work-groups (tests).
+static int g_dma_grid_cap = -1;
+extern "C" void gm_conv_dma_set_persistent(int max_work_groups) { g_dma_grid_cap = max_work_groups; }
+
+static unsigned dma_grid(unsigned nwork, long long lds_bytes, int by_waves, bool splitk) {
+  if (splitk || g_dma_grid_cap == 0) return nwork;  // split-K launches are small by construction
+  long long cap = g_dma_grid_cap;
+  if (cap < 0) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      cus = n;
+    }
+    long long per_cu = (160LL * 1024) / lds_bytes;  // co-resident work-groups per CU: by LDS and by the waves per SIMD the kernel was built for
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    cap = per_cu * cus;
+  }
+  if (cap < 8) cap = 8;  // every XCD's item range needs a work-group (the kernel deals ranges to blockIdx.x & 7)
+  return nwork < (unsigned)cap ? nwork : (unsigned)cap;
 }
 
 // geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)
@@ -717,11 +839,18 @@ static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  kern<<<dim3(nblocks), 64 * NW, (size_t)gm_conv_dma_lds_bytes(gm_conv_dma_variant(d.cfg)), st>>>(d);
+  const long long lds = gm_conv_dma_lds_bytes(gm_conv_dma_variant(d.cfg));
+  const bool splitk = d.ksplit > 1 && d.kpartial != nullptr;
+  constexpr int BY_WAVES = MINW * 4 / NW >= 1 ? MINW * 4 / NW : 1;  // __launch_bounds__(64 * NW, MINW): MINW waves per SIMD = MINW * 4 / NW work-groups per CU
+  kern<<<dim3(dma_grid(nblocks, lds, BY_WAVES, splitk)), 64 * NW, (size_t)lds, st>>>(d);
 }
 
 template <typename T>
 static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
+#ifdef GM_DMA_QUICK  // ISA studies only: one instantiation (bf16 cfg 11) compiles in seconds
+  if (sizeof(T) == 2) launch_dma<bf16_raw, 8, 2, 1, 4>(d, nblocks, st);
+  return;
+#endif
   const bool pre = d.pre_scale != nullptr;  // eligibility (gm_conv_dma_eligible) admits a prologue for the stride-1 3x3x3 variants only
   if (d.cfg == 19) { if (pre) launch_dma<T, 8, 4, 1, 2, 3, 8, true>(d, nblocks, st); else launch_dma<T, 8, 4, 1, 2, 3, 8>(d, nblocks, st); }  // 512 voxels x 128 channels
   else if (d.cfg == 18) { if (pre) launch_dma<T, 8, 4, 1, 2, 3, 4, true>(d, nblocks, st); else launch_dma<T, 8, 4, 1, 2>(d, nblocks, st); }  // 512 voxels x 64 channels, 8 waves x 64 voxels

@@ -333,6 +333,55 @@ def test_conv_lds_dma_in_lds_prologue_matches_the_two_pass_form_bitwise(case, cf
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("grid", [8, 11, 29])
+def test_conv_lds_dma_multi_tile_walk_is_bitwise_the_one_tile_per_work_group_launch(grid, dtype):
+    """The LDS-DMA kernels run a work LIST per work-group (conv_dma.hip: the launch is capped at the co-resident work-groups and the next
+    tile's first patch is requested before the current tile's epilogue).  gm_conv_dma_set_persistent(n) caps the grid at n work-groups, so
+    that every work-group of these small problems walks many tiles (n = 11, 29: XCDs with unequal work-group counts); output AND
+    per-tile statistics must be bit-identical to the one-work-group-per-tile launch (policy 0) for every tile configuration and every
+    fused feature: residual + timestep row + channel-sliced output, in-LDS GroupNorm prologue over a virtual concat, fused 1x1 shortcut,
+    stride 2, the sub-pixel up-sampling form, output activation."""
+    ops = _ops()
+    from generativemodels_amd._native import lib
+    n, sp = 2, (9, 10, 37)
+    runs = []
+    x64 = _cl(_rand((n, 64, *sp), 501).to(dtype))
+    x96 = _cl(_rand((n, 96, *sp), 502).to(dtype))
+    scale = (_rand((n, 96), 503) * 0.2 + 1.0).to(DEV)
+    shift = (_rand((n, 96), 504) * 0.3).to(DEV)
+    for cfg in (11, 14, 16, 18, 19):
+        cout = 136 if cfg in (11, 19) else 72
+        w = (_rand((cout, 64, 3, 3, 3), 510 + cfg) / math.sqrt(64 * 27)).to(dtype).to(DEV)
+        b, temb = (_rand((cout,), 511) * 0.1).to(DEV), (_rand((n, cout), 512) * 0.5).to(DEV)
+        res = _cl(_rand((n, cout, *sp), 513).to(dtype))
+        runs.append((f"cfg{cfg} res+row", lambda w=w, b=b, temb=temb, res=res, cfg=cfg: ops.conv(x64, w, b, kernel=3, padding=1, rowvec=temb, res=res,
+                                                                                               force_cfg=cfg, want_stats=True)))
+        w96 = (_rand((cout, 96, 3, 3, 3), 520 + cfg) / math.sqrt(96 * 27)).to(dtype).to(DEV)
+        cat = ops.VirtualCat([x96[..., :64].contiguous(), x96[..., 64:].contiguous()])
+        runs.append((f"cfg{cfg} prologue+cat", lambda w96=w96, b=b, cat=cat, cfg=cfg: ops.conv(cat, w96, b, kernel=3, padding=1, pre=(scale, shift), pre_act="silu",
+                                                                                           force_cfg=cfg, want_stats=True)))
+    w = (_rand((72, 64, 3, 3, 3), 531) / math.sqrt(64 * 27)).to(dtype).to(DEV)
+    ws = (_rand((72, 96, 1, 1, 1), 532) / math.sqrt(96)).to(dtype).to(DEV)
+    b = (_rand((72,), 533) * 0.1).to(DEV)
+    runs.append(("shortcut", lambda: ops.conv(x64, w, b, kernel=3, padding=1, skip=([x96[..., :64].contiguous(), x96[..., 64:].contiguous()], ws, b), want_stats=True)))
+    runs.append(("stride 2", lambda: ops.conv(x64, w, b, kernel=3, stride=2, padding=1, force_cfg=15, want_stats=True)))
+    runs.append(("sub-pixel", lambda: ops.conv(x64, w, b, kernel=3, padding=1, upsample=True, want_stats=True)))
+    runs.append(("relu out", lambda: ops.conv(x64, w, b, kernel=3, padding=1, post_act="relu", force_cfg=11, want_stats=True)))
+    try:
+        for name, run in runs:
+            lib().gm_conv_dma_set_persistent(0)
+            one = run()
+            one_stats = one._gm_cstats.clone()
+            lib().gm_conv_dma_set_persistent(grid)
+            walk = run()
+            assert torch.isfinite(one.float()).all()
+            assert torch.equal(one, walk), f"{name}: {(one.float() - walk.float()).abs().max().item():.3e}"
+            assert torch.equal(one_stats, walk._gm_cstats), name
+    finally:
+        lib().gm_conv_dma_set_persistent(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ksplit", [2, 3, 8])
 @pytest.mark.parametrize("case", [("res", 256, 256, None, (8, 8, 8), "res", 2), ("skip-cat", 384, 136, 256, (7, 9, 17), "skip", 1),
                                   ("pre", 128, 64, None, (16, 16, 16), "pre", 1)], ids=lambda c: c[0] if isinstance(c, tuple) else str(c))

@@ -1,7 +1,7 @@
 """GPU, bench-only build (python -m generativemodels_amd._build --variant timeline; run with GM_NATIVE_LIB=.../lib/libgmamd_timeline.so): where the cycles of one
 LDS-DMA convolution tile go.  Thread 0 of every work-group stamps the shader clock at phase boundaries (conv_dma.hip TL_STAMP); this
 script launches one convolution per shape / configuration and prints the median duration of every phase over the work-groups, split
-into the first wave of work-groups on the chip (cold start) and the steady state.   usage: python tools/conv_timeline.py"""
+over the work-groups (a persistent work-group stamps its second tile: the steady state).   usage: python tools/conv_timeline.py"""
 import math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,7 +24,7 @@ def run(cin, cout, size, cfg, with_res=True):
     nwg = (size ** 3 // bm) * ((cout + bn - 1) // bn)
     buf = torch.zeros((nwg, 64), dtype=torch.int64, device=dev)
     # smuggle the timeline buffer through GmConvDesc.kpartial (ksplit stays 0): patch ops.conv's descriptor via the debug hook
-    ops._CONV_DEBUG_FLAGS = 4096
+    ops._CONV_DEBUG_FLAGS = 4096 | int(os.environ.get("GM_TL_FLAGS", "0"))  # + 512: no weight traffic, + 1024: no patch traffic (timeline_ablate build)
     ops._CONV_TIMELINE_BUFFER = buf
     try:
         ops.conv(x, w, b, **kw)
@@ -45,17 +45,14 @@ def report(name, t, nchunks):
     t0 = t[:, 0].min()
     span = t[:, 63].max() - t0
     print(f"--- {name}: {len(t)} work-groups, kernel span {span} cycles")
-    for label, sel in (("first 512 work-groups (cold)", slice(0, 512)), ("steady state", slice(512, None))):
+    for label, sel in (("all stamped work-groups", slice(0, None)),):
         tt = t[sel]
         if len(tt) == 0:
             continue
         med = lambda a: int(np.median(a))  # noqa: E731
-        rows = [("entry -> tile decoded", tt[:, 53] - tt[:, 0]),
-                ("patch source addresses", tt[:, 54] - tt[:, 53]),
-                ("weight source addresses (-> first DMA issue)", tt[:, 1] - tt[:, 54]),
-                ("issue of the first patch + 2 panels, addend loads", tt[:, 55] - tt[:, 1]),
-                ("operand read addresses, accumulator init", tt[:, 56] - tt[:, 55]),
-                ("rest of the wait for the first DMAs (+ barrier)", tt[:, 2] - tt[:, 56])]
+        rows = [("tile top -> first panels + addend loads issued", tt[:, 55] - tt[:, 0]),
+                ("accumulator init, addend -> LDS", tt[:, 56] - tt[:, 55]),
+                ("wait for the first DMAs (+ barrier)", tt[:, 2] - tt[:, 56])]
         prev = tt[:, 2]
         for c in range(min(nchunks, 5)):
             groups = []
@@ -67,15 +64,19 @@ def report(name, t, nchunks):
             rows.append((f"chunk {c}: tap groups 0-7 (each 24 MFMAs / wave), median of per-group medians", np.median(g_first8, 1)))
             rows.append((f"chunk {c}: tap group 8" + (" + chunk boundary (patch reload)" if c + 1 < nchunks else " (last)"), groups[8]))
         if nchunks <= 5:
-            rows.append(("main loop end -> shortcut / split done", tt[:, 61] - tt[:, 60]))
-            rows.append(("epilogue: LDS transpose, residual, stores", tt[:, 62] - tt[:, 61]))
+            rows.append(("main loop end -> residual requests, shortcut", tt[:, 61] - tt[:, 60]))
+            rows.append(("barrier, next tile decoded + its patch requested", tt[:, 57] - tt[:, 61]))
+            rows.append(("epilogue: LDS transpose, residual, stores", tt[:, 62] - tt[:, 57]))
             rows.append(("statistics reduce + store", tt[:, 63] - tt[:, 62]))
-        rows.append(("work-group life", tt[:, 63] - tt[:, 0]))
+        rows.append(("tile top -> tile end (the stamped tile: the second of a persistent work-group)", tt[:, 63] - tt[:, 0]))
         print(f"  [{label}]")
         for lab, a in rows:
             print(f"    {lab:78s} {med(a):8d} cycles")
 
 
-for cin, cout, size, cfg in [(64, 64, 128, 11), (64, 64, 128, 18), (192, 64, 128, 11), (384, 128, 64, 11), (256, 256, 32, 11)]:
+SHAPES = [(64, 64, 128, 11), (64, 64, 128, 18), (192, 64, 128, 11), (384, 128, 64, 11), (256, 256, 32, 11)]
+if os.environ.get("GM_TL_SHAPES"):  # e.g. "192,64,128,11;384,128,64,11"
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["GM_TL_SHAPES"].split(";")]
+for cin, cout, size, cfg in SHAPES:
     t, nwg = run(cin, cout, size, cfg)
     report(f"{cin}->{cout} @ {size}^3 cfg{cfg}", t, cin // 32)
