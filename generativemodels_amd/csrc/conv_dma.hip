@@ -28,6 +28,11 @@
 #else
 #define TL_STAMP(k)
 #endif
+// A per-lane value that is invariant over the tiles of a work-group (an address built from the lane id) is hoisted out of the tile loop by
+// the optimiser and then LIVE across every phase of the tile -- with 128 registers per wave that pushed such values into scratch memory, and
+// a scratch reload issued behind the next tile's patch request returns only after the patch (vector memory returns in order).  Each phase
+// therefore derives its addresses from its own opaque copy of the lane id: one live register instead of a table.
+#define OPAQUE_LANE(name) int name = lane; asm volatile("" : "+v"(name))
 __device__ __forceinline__ int dma_swz(int row) { return (row ^ (row >> 1)) & 3; }  // period 8 rows
 
 __device__ __attribute__((aligned(64))) unsigned int gm_zero_row[16] = {0};  // the source of every padding row
@@ -75,8 +80,8 @@ __device__ __forceinline__ float wave_segment_sum(float v) {
   return __int_as_float(b[0]) + __int_as_float(b[1]);
 }
 
-// output rows of one epilogue pass: element offset into y, inside-the-volume flag and the residual values of this lane's 16-byte segment
-template <int NIT> struct EpRows { long long yoff[NIT]; bool inside[NIT]; uint4 rv[NIT]; };
+// output rows of one epilogue pass: inside-the-volume flag and the residual values of this lane's 16-byte segment
+template <int NIT> struct EpRows { bool inside[NIT]; uint4 rv[NIT]; };
 
 struct EpTile { int n, od0, oh0, ow0, co_base, par; };  // (wave-uniform) output tile of the work-group
 
@@ -99,7 +104,6 @@ __device__ __forceinline__ void dma_epilogue_rows(const GmConvDesc& p, const EpT
   const int co = t.co_base + PASS * NF_PER_PASS * 16 + (lane & 7) * VECW;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    R.yoff[it] = 0;
     R.inside[it] = false;
     R.rv[it] = make_uint4(0u, 0u, 0u, 0u);
   }
@@ -108,7 +112,6 @@ __device__ __forceinline__ void dma_epilogue_rows(const GmConvDesc& p, const EpT
     for (int it = 0; it < NIT; ++it) {
       long long vox;
       dma_epilogue_place<T, MF, KS>(p, t, line0, lane, co, it, R.inside[it], vox);
-      R.yoff[it] = vox * p.y_ld + co;
       if (res && R.inside[it]) R.rv[it] = *reinterpret_cast<const uint4*>(res + vox * p.res_ld + co);
     }
   }
@@ -162,7 +165,10 @@ __device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (
           for (int i = 0; i < VECW; ++i) o[i] += r[i];
           raw = Vec16<T>::pack(o);
         }
-        *reinterpret_cast<uint4*>(yout + R.yoff[it]) = raw;
+        bool in;
+        long long vox;
+        dma_epilogue_place<T, MF, KS>(p, t, line0, lane, co, it, in, vox);  // (recomputed: cheaper than 2 live registers per row group)
+        *reinterpret_cast<uint4*>(yout + vox * p.y_ld + co) = raw;
         if (p.stats) {  // statistics of the values as stored (rounded to T), like a separate pass over the tensor would see them
           float o[VECW];
           Vec16<T>::unpack(raw, o);
@@ -313,9 +319,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     // KS = 2: output parity 0 reads inputs (i - 1, i), parity 1 reads (i, i + 1): low-side padding 1 - parity
     const int ud0 = t.td_i * TD * S - (KS == 2 ? 1 - ((t.par >> 2) & 1) : p.pd), uh0 = t.th_i * TH * S - (KS == 2 ? 1 - ((t.par >> 1) & 1) : p.ph),
               uw0 = t.tw_i * TW * S - (KS == 2 ? 1 - (t.par & 1) : p.pw);
+    OPAQUE_LANE(lane_p);
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      const int row = 16 * (wave + NW * j) + (lane >> 2);  // (the row's place in the patch is recomputed per tile: two constant divisions
+      const int row = 16 * (wave + NW * j) + (lane_p >> 2);  // (the row's place in the patch is recomputed per tile: two constant divisions
       const int pa = row / PLANE, rr = row - pa * PLANE;   //  are cheaper than six more live registers across the tap loop)
       const int pb = rr / PW, lc = rr - pb * PW;
       const int pc = S == 1 ? lc : (lc < EW ? 2 * lc : 2 * (lc - EW) + 1);  // S = 2: even columns first, then the odd ones
@@ -396,15 +403,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   int wsrc[WPW];                // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
   auto place_weights = [&](const Tile& t) __attribute__((always_inline)) {
     wbase = reinterpret_cast<const char*>(p.w) + (long long)t.par * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;
+    OPAQUE_LANE(lane_w);
 #pragma unroll
     for (int h = 0; h < WPW; ++h) {
-      const int row = WGEN ? 16 * (wave + NW * h) + (lane >> 2)
-                    : KS == 2 ? 16 * wave + (lane >> 2)
-                              : NW == 8 ? (h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2))
-                                        : (NW == 4 ? 16 * (wave + NW * h) + (lane >> 2) : 16 * (wave < 12 ? wave : 0) + (lane >> 2));
+      const int row = WGEN ? 16 * (wave + NW * h) + (lane_w >> 2)
+                    : KS == 2 ? 16 * wave + (lane_w >> 2)
+                              : NW == 8 ? (h == 0 ? 16 * wave + (lane_w >> 2) : 128 + 8 * wave + ((lane_w & 31) >> 2))
+                                        : (NW == 4 ? 16 * (wave + NW * h) + (lane_w >> 2) : 16 * (wave < 12 ? wave : 0) + (lane_w >> 2));
       const int u = row / BN, col = row % BN;
       const int co = t.cb * BN + col;
-      wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
+      wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane_w & 3) ^ dma_swz(row)) << 4)) : -1;
     }
   };
   auto issue_w = [&](int t, int buf) __attribute__((always_inline)) {  // WPW instructions per wave, every wave
@@ -430,33 +438,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       }
     }
   };
-
-
-  // ---- per-lane operand read addresses (bytes from smem) ------------------------------------------------------------------
-  // A wave's MF fragments are MF consecutive H rows of one tile plane ((wave * MF + mf) * 16 + l15 with TH = 4, TW = 16), so fragment mf
-  // at tap row kh reads patch row S * (bb0 + mf) + kh: the addresses depend on hk = S * mf + kh only -- HK x KS registers, not MF x KS x KS.
-  constexpr int HK = S * (MF - 1) + KS;
-  static_assert(MF <= 4 && (4 % MF) == 0, "a wave's fragments stay inside one 4-row tile plane");
-  int xaddr[HK][KS];  // patch row (hk, kw) of this lane's voxel column; depth taps add kd * PLANE * 64 as an immediate
-  {
-    const int m0 = wave * MF * 16 + l15;
-    const int a = m0 >> 6, bb0 = (m0 >> 4) & 3, c = m0 & 15;
-#pragma unroll
-    for (int hk = 0; hk < HK; ++hk)
-#pragma unroll
-      for (int kw = 0; kw < KS; ++kw) {
-        const int col = S == 1 ? c + kw : (kw == 1 ? EW + c : c + (kw >> 1));  // patch column S*c + kw in the split layout
-        const int row = S * a * PLANE + (S * bb0 + hk) * PW + col;
-        xaddr[hk][kw] = row * DMA_ROWB + ((q ^ dma_swz(row)) << 4);
-      }
-  }
-  // weight rows nf * 16 + l15: the swizzle has period 8 rows, so fragments 4..7 (BN = 128) are fragments 0..3 plus 64 rows -- an immediate
-  int waddr[4];
-#pragma unroll
-  for (int nf = 0; nf < 4; ++nf) {
-    const int r = nf * 16 + l15;
-    waddr[nf] = PATCH_BYTES + r * DMA_ROWB + ((q ^ dma_swz(r)) << 4);
-  }
 
 
   // ---- LDS regions of the epilogue ---------------------------------------------------------------------------------------------------------
@@ -492,8 +473,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
     // bias + shortcut bias + timestep row (this order), fp32
     float addend = 0.f;
-    if (tid < BN) {
-      const int co = cur.cb * BN + tid;
+    OPAQUE_LANE(lane_a);
+    const int tid_a = wave * 64 + lane_a;  // (= threadIdx.x, from the phase's own lane id)
+    if (tid_a < BN) {
+      const int co = cur.cb * BN + tid_a;
       if (co < p.Cout) {
         if (p.bias) addend += p.bias[co];
         if (p.skip_bias) addend += p.skip_bias[co];
@@ -501,12 +484,40 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       }
     }
     TL_STAMP(55);
+    // ---- per-lane operand read addresses (bytes from smem): rebuilt per tile under the DMA flight -- 16 registers that are NOT live across the
+    // epilogue, where they would push the allocation into scratch (a scratch reload behind the next tile's patch request waits for the patch)
+    // A wave's MF fragments are MF consecutive H rows of one tile plane ((wave * MF + mf) * 16 + l15 with TH = 4, TW = 16), so fragment mf
+    // at tap row kh reads patch row S * (bb0 + mf) + kh: the addresses depend on hk = S * mf + kh only -- HK x KS registers, not MF x KS x KS.
+    constexpr int HK = S * (MF - 1) + KS;
+    static_assert(MF <= 4 && (4 % MF) == 0, "a wave's fragments stay inside one 4-row tile plane");
+    OPAQUE_LANE(lane_t);  // keeps the two tables out of loop-invariant code motion (= out of the epilogue's live set)
+    const int l15t = lane_t & 15, qt = lane_t >> 4;
+    int xaddr[HK][KS];  // patch row (hk, kw) of this lane's voxel column; depth taps add kd * PLANE * 64 as an immediate
+    {
+      const int m0 = wave * MF * 16 + l15t;
+      const int a = m0 >> 6, bb0 = (m0 >> 4) & 3, c = m0 & 15;
+#pragma unroll
+      for (int hk = 0; hk < HK; ++hk)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const int col = S == 1 ? c + kw : (kw == 1 ? EW + c : c + (kw >> 1));  // patch column S*c + kw in the split layout
+          const int row = S * a * PLANE + (S * bb0 + hk) * PW + col;
+          xaddr[hk][kw] = row * DMA_ROWB + ((qt ^ dma_swz(row)) << 4);
+        }
+    }
+    // weight rows nf * 16 + l15: the swizzle has period 8 rows, so fragments 4..7 (BN = 128) are fragments 0..3 plus 64 rows -- an immediate
+    int waddr[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int r = nf * 16 + l15t;
+      waddr[nf] = PATCH_BYTES + r * DMA_ROWB + ((qt ^ dma_swz(r)) << 4);
+    }
     f32x4_t acc[NFR][MF];
 #pragma unroll
     for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (tid < BN) addv[tid] = addend;
+    if (tid_a < BN) addv[tid_a] = addend;
     TL_STAMP(56);
     if (total > 0) {
       dma_wait<0>();
@@ -587,29 +598,31 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     const EpTile et = {cur.n, od0, oh0, ow0, cur.cb * BN, cur.par};
     const bool partial = KS == 3 && S == 1 && ksplit > 1;
     EpRows<MF * 2> rows0;
-    if (!partial) dma_epilogue_rows<T, MF, KS, 0>(p, et, wave * MF, lane, rows0);  // residual rows of the first pass: requested now, used after the transpose
+    OPAQUE_LANE(lane_e);
+    if (!partial) dma_epilogue_rows<T, MF, KS, 0>(p, et, wave * MF, lane_e, rows0);  // residual rows of the first pass: requested now, used after the transpose
 
     // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
     // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
     // and one piece of the two 4 KiB weight panels into the ring, one wait + barrier, then 2 x 8 MFMAs.
     if (p.skip_x[0] && cur.ks == ksplit - 1) {  // (split-K: the shortcut's chunks ride with the last K slice)
       const int nsc0 = p.skip_cin[0] / BK, nsc = nsc0 + (p.skip_x[1] ? p.skip_cin[1] / BK : 0);
+      OPAQUE_LANE(lane_k);
       int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
   #pragma unroll
       for (int h = 0; h < MF; ++h) {
-        const int m = wave * (MF * 16) + h * 16 + (lane >> 2);  // (a, bb, c) below assume TH = 4, TW = 16
+        const int m = wave * (MF * 16) + h * 16 + (lane_k >> 2);  // (a, bb, c) below assume TH = 4, TW = 16
         const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
         svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((cur.n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
       }
       const int wpiece = WGEN ? wave : (wave & 3);        // BN = 64: piece wave&3 of a 4-piece panel; BN = 128 (8 waves): piece wave of 8
-      const int wcol = wpiece * 16 + (lane >> 2);         // weight row of this lane's panel piece
+      const int wcol = wpiece * 16 + (lane_k >> 2);         // weight row of this lane's panel piece
       const int wco = cur.cb * BN + wcol;
-      const int wswz = ((lane & 3) ^ dma_swz(wcol)) << 4;
+      const int wswz = ((lane_k & 3) ^ dma_swz(wcol)) << 4;
       int caddr[MF];
   #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        const int m = (wave * MF + mf) * 16 + l15;
-        caddr[mf] = m * DMA_ROWB + ((q ^ dma_swz(m)) << 4);
+        const int m = (wave * MF + mf) * 16 + (lane_k & 15);
+        caddr[mf] = m * DMA_ROWB + (((lane_k >> 4) ^ dma_swz(m)) << 4);
       }
       const char* wsk = reinterpret_cast<const char*>(p.skip_w);
       for (int sc0 = 0; sc0 < nsc; sc0 += 2) {
@@ -624,11 +637,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
             const long long rowb = p.skip_ld[part] * (long long)sizeof(T);
   #pragma unroll
             for (int h = 0; h < MF; ++h) {
-              const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
+              const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane_k & 3) << 4);
               dma16(src, lds0 + (unsigned)(j * BM + wave * (MF * 16) + h * 16) * DMA_ROWB);
             }
             if (WGEN || NW == 4 || (wave >> 2) == j) {  // 8 waves: waves 0-3 move panel 0, waves 4-7 panel 1; 4 waves / BN = 128: every wave moves both
-              const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane & 3) << 4);
+              const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane_k & 3) << 4);
               dma16(src, lds0 + PATCH_BYTES + (unsigned)(j * BN + wpiece * 16) * DMA_ROWB);
             }
           }
@@ -675,13 +688,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       float* part = p.kpartial + (long long)cur.ks * nv * p.Cout;
   #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        const int m = (wave * MF + mf) * 16 + l15;
+        const int m = (wave * MF + mf) * 16 + (lane_e & 15);
         const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
         if (od < p.Do && oh < p.Ho && ow < p.Wo) {
           float* row = part + ((((long long)cur.n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout;
   #pragma unroll
           for (int nf = 0; nf < NFR; ++nf) {
-            const int co = cur.cb * BN + nf * 16 + q * 4;
+            const int co = cur.cb * BN + nf * 16 + (lane_e >> 4) * 4;
             if (co < p.Cout)  // host-checked: Cout % 4 == 0
               *reinterpret_cast<float4*>(row + co) = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
           }
@@ -699,44 +712,46 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
       for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
     char* scratch = smem + SCRATCH_OFF + (size_t)wave * SCRATCH_WAVE;
-    dma_epilogue_pass<T, MF, NFR, KS, 0>(p, acc, scratch, addv, et, wave * MF, lane, rows0, st_s, st_q);
+    dma_epilogue_pass<T, MF, NFR, KS, 0>(p, acc, scratch, addv, et, wave * MF, lane_e, rows0, st_s, st_q);
     if constexpr (EPASSES > 1) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 1>(p, et, wave * MF, lane, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 1>(p, acc, scratch, addv, et, wave * MF, lane, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 1>(p, et, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 1>(p, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     if constexpr (EPASSES > 2) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 2>(p, et, wave * MF, lane, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 2>(p, acc, scratch, addv, et, wave * MF, lane, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 2>(p, et, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 2>(p, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     if constexpr (EPASSES > 3) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 3>(p, et, wave * MF, lane, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 3>(p, acc, scratch, addv, et, wave * MF, lane, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 3>(p, et, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 3>(p, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     TL_STAMP(62);
     if (p.stats) {
       // lane sums over its rows -> sum over the 8 row lanes of a segment (registers) -> one partial per (wave, channel) in the wave's own
       // scratch block -> fixed-order fp64 sum over the waves: deterministic, one plain store per (tile, channel)
+      OPAQUE_LANE(lane_s);
       float2* part = reinterpret_cast<float2*>(scratch);
 #pragma unroll
       for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
         for (int i = 0; i < VECW; ++i) {
           const float a = wave_segment_sum(st_s[e][i]), b2 = wave_segment_sum(st_q[e][i]);
-          if (lane < 8) part[e * CH_PER_PASS + lane * VECW + i] = make_float2(a, b2);
+          if (lane_s < 8) part[e * CH_PER_PASS + lane_s * VECW + i] = make_float2(a, b2);
         }
       __syncthreads();
-      if (tid < BN) {
+      const int ch = wave * 64 + lane_s;  // (= threadIdx.x, from the phase's own lane id)
+      if (ch < BN) {
         double a = 0.0, b2 = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-          const float2 v = *reinterpret_cast<const float2*>(smem + SCRATCH_OFF + w * SCRATCH_WAVE + tid * 8);
+          const float2 v = *reinterpret_cast<const float2*>(smem + SCRATCH_OFF + w * SCRATCH_WAVE + ch * 8);
           a += (double)v.x;
           b2 += (double)v.y;
         }
-        const int co = cur.cb * BN + tid;
+        const int co = cur.cb * BN + ch;
         if (co < p.Cout) {
           const long long slot = ((long long)(cur.td_i * nth + cur.th_i) * ntw + cur.tw_i) * (KS == 2 ? 8 : 1) + cur.par;  // the tile within its sample
           double* dst = p.stats + ((slot * p.N + cur.n) * p.Cout + co) * 2;  // fixed-order reduction over the slots by the consumers, no atomics
