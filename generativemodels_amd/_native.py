@@ -167,6 +167,8 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("GM_CONV_DMA_GRID"):  # A/B of the LDS-DMA grid policy (gm_conv_dma_set_persistent): -1 auto, 0 one tile per work-group
+            handle.gm_conv_dma_set_persistent(int(os.environ["GM_CONV_DMA_GRID"]))
         _lib = handle
     return _lib
 
