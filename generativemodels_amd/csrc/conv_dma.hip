@@ -66,6 +66,17 @@ __device__ __forceinline__ void dma_wait() {
 //   * statistics: lane sums over its rows -> one DPP row rotate (lane ^ 8) -> per-(wave, 16-lane row) partials in LDS -> one fixed-order
 //     fp64 sum per channel.  Deterministic, no atomics.
 // The tile geometry is the kernel's (TH = 4, TW = 16): a wave's rows m_base + v are MF W-lines, (depth, height) of a line are wave-uniform.
+// The descriptor is a by-value kernel argument (~300 bytes = 75 SGPRs if every field is kept live).  In the tile loop the optimiser hoists every
+// field read out of the loop; with ~100 SGPRs per wave that spilled ~170 of them into VGPR lanes (v_writelane / v_readlane around every phase).
+// The phases outside the tap loop therefore read their fields through an opaque pointer to the kernarg segment: a scalar load next to the
+// use (scalar cache hit), nothing live across the tap loop.
+typedef const __attribute__((address_space(4))) GmConvDesc KDesc;
+__device__ __forceinline__ KDesc& cold_desc() {
+  KDesc* k = (KDesc*)__builtin_amdgcn_kernarg_segment_ptr();  // the descriptor is the kernel's only argument: offset 0
+  asm volatile("" : "+s"(k));
+  return *k;
+}
+
 __device__ __forceinline__ float dpp_row_ror8(float v) {  // value of lane ^ 8 (rotate by 8 inside each row of 16 lanes)
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));
 }
@@ -85,8 +96,8 @@ template <int NIT> struct EpRows { bool inside[NIT]; uint4 rv[NIT]; };
 
 struct EpTile { int n, od0, oh0, ow0, co_base, par; };  // (wave-uniform) output tile of the work-group
 
-template <typename T, int MF, int KS>
-__device__ __forceinline__ void dma_epilogue_place(const GmConvDesc& p, const EpTile& t, int line0, int lane, int co, int it, bool& in, long long& vox) {
+template <typename T, int MF, int KS, typename D>
+__device__ __forceinline__ void dma_epilogue_place(const D& p, const EpTile& t, int line0, int lane, int co, int it, bool& in, long long& vox) {
   const int Dl = KS == 2 ? p.Ds : p.Do, Hl = KS == 2 ? p.Hs : p.Ho, Wl = KS == 2 ? p.Ws : p.Wo;  // KS = 2: the tile walks the low-resolution grid
   const int line = line0 + (it >> 1);                         // wave-uniform: W-line of the tile, (depth, height) = (line / 4, line % 4)
   const int od = t.od0 + (line >> 2), oh = t.oh0 + (line & 3), ow = t.ow0 + (it & 1) * 8 + (lane >> 3);
@@ -97,8 +108,8 @@ __device__ __forceinline__ void dma_epilogue_place(const GmConvDesc& p, const Ep
 
 // addresses + residual requests of all row groups of pass PASS (no output activation: the hot form).  Called ahead of the transpose -- for
 // pass 0 right after the tap loop -- so that the residual's latency is covered by whatever runs in between.
-template <typename T, int MF, int KS, int PASS>
-__device__ __forceinline__ void dma_epilogue_rows(const GmConvDesc& p, const EpTile& t, int line0, int lane, EpRows<MF * 2>& R) {
+template <typename T, int MF, int KS, int PASS, typename D>
+__device__ __forceinline__ void dma_epilogue_rows(const D& p, const EpTile& t, int line0, int lane, EpRows<MF * 2>& R) {
   constexpr int VECW = 16 / (int)sizeof(T), NF_PER_PASS = 128 / (16 * (int)sizeof(T)), NIT = MF * 2;
   const T* res = reinterpret_cast<const T*>(p.res);
   const int co = t.co_base + PASS * NF_PER_PASS * 16 + (lane & 7) * VECW;
@@ -117,8 +128,8 @@ __device__ __forceinline__ void dma_epilogue_rows(const GmConvDesc& p, const EpT
   }
 }
 
-template <typename T, int MF, int NFR, int KS, int PASS>
-__device__ __forceinline__ void dma_epilogue_pass(const GmConvDesc& p, f32x4_t (&acc)[NFR][MF], char* lds, const float* addv, const EpTile& t, int line0,
+template <typename T, int MF, int NFR, int KS, int PASS, typename D>
+__device__ __forceinline__ void dma_epilogue_pass(const D& p, f32x4_t (&acc)[NFR][MF], char* lds, const float* addv, const EpTile& t, int line0,
                                                   int lane, const EpRows<MF * 2>& R,
                                                   float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
                                                   float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)]) {
@@ -316,9 +327,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const int pswz = ((lane & 3) ^ dma_swz(lane >> 2)) << 4;  // piece bases are multiples of 16 rows: the swizzle term is per lane
   int pvox[PPW];  // source voxel of this lane's patch row per piece, or -1 for a padding row (32-bit: host checks N*V < 2^31)
   auto place_patch = [&](const Tile& t) __attribute__((always_inline)) {
+    KDesc& pk = cold_desc();
     // KS = 2: output parity 0 reads inputs (i - 1, i), parity 1 reads (i, i + 1): low-side padding 1 - parity
-    const int ud0 = t.td_i * TD * S - (KS == 2 ? 1 - ((t.par >> 2) & 1) : p.pd), uh0 = t.th_i * TH * S - (KS == 2 ? 1 - ((t.par >> 1) & 1) : p.ph),
-              uw0 = t.tw_i * TW * S - (KS == 2 ? 1 - (t.par & 1) : p.pw);
+    const int ud0 = t.td_i * TD * S - (KS == 2 ? 1 - ((t.par >> 2) & 1) : pk.pd), uh0 = t.th_i * TH * S - (KS == 2 ? 1 - ((t.par >> 1) & 1) : pk.ph),
+              uw0 = t.tw_i * TW * S - (KS == 2 ? 1 - (t.par & 1) : pk.pw);
     OPAQUE_LANE(lane_p);
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
@@ -328,8 +340,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       const int pc = S == 1 ? lc : (lc < EW ? 2 * lc : 2 * (lc - EW) + 1);  // S = 2: even columns first, then the odd ones
       int ud = ud0 + pa, uh = uh0 + pb, uw = uw0 + pc;
       const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv);
-      if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
-      pvox[j] = ok ? ((t.n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
+      if (pk.in_mode == 1) { ud /= pk.fd; uh /= pk.fh; uw /= pk.fw; }
+      pvox[j] = ok ? ((t.n * pk.Ds + ud) * pk.Hs + uh) * pk.Ws + uw : -1;
     }
   };
   const long long xrowb = p.x_ld * (long long)sizeof(T);
@@ -355,6 +367,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   };
 
   Tile cur = decode(sx + pos);
+  const Tile stride = decode(gx);  // the digits of the walk's stride (gx <= cx <= nwork / 8 + 1: a valid work item index, K slice 0)
   place_patch(cur);
   if (min(nchunks, cur.ks * cps) < nchunks) issue_patch(min(nchunks, cur.ks * cps));  // the first patch of the first tile
 
@@ -402,7 +415,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const char* wbase = nullptr;  // parity image of the current tile
   int wsrc[WPW];                // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
   auto place_weights = [&](const Tile& t) __attribute__((always_inline)) {
-    wbase = reinterpret_cast<const char*>(p.w) + (long long)t.par * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;
+    KDesc& pk = cold_desc();
+    wbase = reinterpret_cast<const char*>(pk.w) + (long long)t.par * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;
     OPAQUE_LANE(lane_w);
 #pragma unroll
     for (int h = 0; h < WPW; ++h) {
@@ -473,14 +487,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
     // bias + shortcut bias + timestep row (this order), fp32
     float addend = 0.f;
+    KDesc& pa = cold_desc();
     OPAQUE_LANE(lane_a);
     const int tid_a = wave * 64 + lane_a;  // (= threadIdx.x, from the phase's own lane id)
     if (tid_a < BN) {
       const int co = cur.cb * BN + tid_a;
-      if (co < p.Cout) {
-        if (p.bias) addend += p.bias[co];
-        if (p.skip_bias) addend += p.skip_bias[co];
-        if (p.rowvec) addend += p.rowvec[(long long)cur.n * p.rowvec_bstride + co];
+      if (co < pa.Cout) {
+        if (pa.bias) addend += pa.bias[co];
+        if (pa.skip_bias) addend += pa.skip_bias[co];
+        if (pa.rowvec) addend += pa.rowvec[(long long)cur.n * pa.rowvec_bstride + co];
       }
     }
     TL_STAMP(55);
@@ -527,9 +542,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     TL_STAMP(2);
 
     // ---- main loop ----------------------------------------------------------------------------------------------------------
-    // debug_flags bit 11 (bench-only A/B, results unaffected): the tap loop runs at wave priority 1, prologue / epilogue at 0, so that the
-    // co-resident work-group's address arithmetic and stores yield issue slots to this one's ds_read / MFMA stream
-    if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(1);
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
       const bool last_chunk = chunk + 1 == c_end;
   #pragma unroll
@@ -593,26 +605,26 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       }
     }
   TL_STAMP(60);
-    if (p.debug_flags & 2048) __builtin_amdgcn_s_setprio(0);
 
     const EpTile et = {cur.n, od0, oh0, ow0, cur.cb * BN, cur.par};
     const bool partial = KS == 3 && S == 1 && ksplit > 1;
     EpRows<MF * 2> rows0;
     OPAQUE_LANE(lane_e);
-    if (!partial) dma_epilogue_rows<T, MF, KS, 0>(p, et, wave * MF, lane_e, rows0);  // residual rows of the first pass: requested now, used after the transpose
+    if (!partial) dma_epilogue_rows<T, MF, KS, 0>(cold_desc(), et, wave * MF, lane_e, rows0);  // residual rows of the first pass: requested now, used after the transpose
 
     // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
     // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
     // and one piece of the two 4 KiB weight panels into the ring, one wait + barrier, then 2 x 8 MFMAs.
-    if (p.skip_x[0] && cur.ks == ksplit - 1) {  // (split-K: the shortcut's chunks ride with the last K slice)
-      const int nsc0 = p.skip_cin[0] / BK, nsc = nsc0 + (p.skip_x[1] ? p.skip_cin[1] / BK : 0);
+    KDesc& ps = cold_desc();
+    if (ps.skip_x[0] && cur.ks == ksplit - 1) {  // (split-K: the shortcut's chunks ride with the last K slice)
+      const int nsc0 = ps.skip_cin[0] / BK, nsc = nsc0 + (ps.skip_x[1] ? ps.skip_cin[1] / BK : 0);
       OPAQUE_LANE(lane_k);
       int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
   #pragma unroll
       for (int h = 0; h < MF; ++h) {
         const int m = wave * (MF * 16) + h * 16 + (lane_k >> 2);  // (a, bb, c) below assume TH = 4, TW = 16
         const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
-        svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((cur.n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
+        svox[h] = (od < ps.Do && oh < ps.Ho && ow < ps.Wo) ? ((cur.n * ps.Do + od) * ps.Ho + oh) * ps.Wo + ow : -1;
       }
       const int wpiece = WGEN ? wave : (wave & 3);        // BN = 64: piece wave&3 of a 4-piece panel; BN = 128 (8 waves): piece wave of 8
       const int wcol = wpiece * 16 + (lane_k >> 2);         // weight row of this lane's panel piece
@@ -624,7 +636,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         const int m = (wave * MF + mf) * 16 + (lane_k & 15);
         caddr[mf] = m * DMA_ROWB + (((lane_k >> 4) ^ dma_swz(m)) << 4);
       }
-      const char* wsk = reinterpret_cast<const char*>(p.skip_w);
+      const char* wsk = reinterpret_cast<const char*>(ps.skip_w);
       for (int sc0 = 0; sc0 < nsc; sc0 += 2) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // patch buffer and ring are free
@@ -633,8 +645,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
           const int sc = sc0 + j;
           if (sc < nsc) {  // wave-uniform
             const int part = sc >= nsc0 ? 1 : 0, cip = sc - (part ? nsc0 : 0);
-            const char* xb = reinterpret_cast<const char*>(p.skip_x[part]) + (long long)cip * (BK * (int)sizeof(T)) + pswz;
-            const long long rowb = p.skip_ld[part] * (long long)sizeof(T);
+            const char* xb = reinterpret_cast<const char*>(ps.skip_x[part]) + (long long)cip * (BK * (int)sizeof(T)) + pswz;
+            const long long rowb = ps.skip_ld[part] * (long long)sizeof(T);
   #pragma unroll
             for (int h = 0; h < MF; ++h) {
               const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane_k & 3) << 4);
@@ -677,25 +689,36 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     const bool has_next = pos + gx < cx;
     Tile nxt = cur;
     if (has_next) {
-      nxt = decode(sx + pos + gx);
+      if (ksplit > 1) {
+        nxt = decode(sx + pos + gx);
+      } else {  // work item + gx by mixed-radix addition of the stride's digits: a few scalar compares instead of four integer divisions
+        int c;
+        nxt.cb = cur.cb + stride.cb; c = nxt.cb >= ncb ? 1 : 0; nxt.cb -= c ? ncb : 0;
+        if (KS == 2) { nxt.par = cur.par + stride.par + c; c = nxt.par >> 3; nxt.par &= 7; }
+        nxt.tw_i = cur.tw_i + stride.tw_i + c; c = nxt.tw_i >= ntw ? 1 : 0; nxt.tw_i -= c ? ntw : 0;
+        nxt.th_i = cur.th_i + stride.th_i + c; c = nxt.th_i >= nth ? 1 : 0; nxt.th_i -= c ? nth : 0;
+        nxt.td_i = cur.td_i + stride.td_i + c; c = nxt.td_i >= ntd ? 1 : 0; nxt.td_i -= c ? ntd : 0;
+        nxt.n = cur.n + stride.n + c;
+      }
       place_patch(nxt);
       if (EARLY && min(nchunks, nxt.ks * cps) < nchunks) issue_patch(min(nchunks, nxt.ks * cps));
     }
     TL_STAMP(57);
     // ---- split-K: this slice's fp32 partial sums -> kpartial[ks][n * V + voxel][Cout]; the combine kernel applies the epilogue ----------
+    KDesc& pe = cold_desc();
     if (KS == 3 && S == 1 && ksplit > 1) {
-      const long long nv = (long long)p.N * p.Do * p.Ho * p.Wo;
-      float* part = p.kpartial + (long long)cur.ks * nv * p.Cout;
+      const long long nv = (long long)pe.N * pe.Do * pe.Ho * pe.Wo;
+      float* part = pe.kpartial + (long long)cur.ks * nv * pe.Cout;
   #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         const int m = (wave * MF + mf) * 16 + (lane_e & 15);
         const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
-        if (od < p.Do && oh < p.Ho && ow < p.Wo) {
-          float* row = part + ((((long long)cur.n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout;
+        if (od < pe.Do && oh < pe.Ho && ow < pe.Wo) {
+          float* row = part + ((((long long)cur.n * pe.Do + od) * pe.Ho + oh) * pe.Wo + ow) * pe.Cout;
   #pragma unroll
           for (int nf = 0; nf < NFR; ++nf) {
             const int co = cur.cb * BN + nf * 16 + (lane_e >> 4) * 4;
-            if (co < p.Cout)  // host-checked: Cout % 4 == 0
+            if (co < pe.Cout)  // host-checked: Cout % 4 == 0
               *reinterpret_cast<float4*>(row + co) = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
           }
         }
@@ -704,7 +727,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 
     // ---- epilogue: LDS transpose -> 16-byte row stores, fused GroupNorm statistics ------------------------------------------------------------
 #ifdef GM_CONV_ABLATE
-    if (!(p.debug_flags & 256)) {  // bench-only: main loop without the epilogue
+    if (!(pe.debug_flags & 256)) {  // bench-only: main loop without the epilogue
 #endif
     float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
 #pragma unroll
@@ -712,35 +735,40 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
       for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
     char* scratch = smem + SCRATCH_OFF + (size_t)wave * SCRATCH_WAVE;
-    dma_epilogue_pass<T, MF, NFR, KS, 0>(p, acc, scratch, addv, et, wave * MF, lane_e, rows0, st_s, st_q);
+    dma_epilogue_pass<T, MF, NFR, KS, 0>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows0, st_s, st_q);
     if constexpr (EPASSES > 1) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 1>(p, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 1>(p, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 1>(pe, et, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 1>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     if constexpr (EPASSES > 2) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 2>(p, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 2>(p, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 2>(pe, et, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 2>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     if constexpr (EPASSES > 3) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 3>(p, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 3>(p, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 3>(pe, et, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 3>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     TL_STAMP(62);
-    if (p.stats) {
+    if (pe.stats) {
       // lane sums over its rows -> sum over the 8 row lanes of a segment (registers) -> one partial per (wave, channel) in the wave's own
       // scratch block -> fixed-order fp64 sum over the waves: deterministic, one plain store per (tile, channel)
       OPAQUE_LANE(lane_s);
-      float2* part = reinterpret_cast<float2*>(scratch);
+      float ra[EPASSES][VECW], rb[EPASSES][VECW];
 #pragma unroll
       for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
-        for (int i = 0; i < VECW; ++i) {
-          const float a = wave_segment_sum(st_s[e][i]), b2 = wave_segment_sum(st_q[e][i]);
-          if (lane_s < 8) part[e * CH_PER_PASS + lane_s * VECW + i] = make_float2(a, b2);
-        }
+        for (int i = 0; i < VECW; ++i) { ra[e][i] = wave_segment_sum(st_s[e][i]); rb[e][i] = wave_segment_sum(st_q[e][i]); }
+      if (lane_s < 8) {  // lanes 0..7 hold the wave's sums of VECW consecutive channels each: (sum, sum of squares) pairs, 16 bytes per two channels
+        float* part = reinterpret_cast<float*>(scratch);
+#pragma unroll
+        for (int e = 0; e < EPASSES; ++e)
+#pragma unroll
+          for (int i = 0; i < VECW; i += 2)
+            *reinterpret_cast<float4*>(part + 2 * (e * CH_PER_PASS + lane_s * VECW + i)) = make_float4(ra[e][i], rb[e][i], ra[e][i + 1], rb[e][i + 1]);
+      }
       __syncthreads();
       const int ch = wave * 64 + lane_s;  // (= threadIdx.x, from the phase's own lane id)
       if (ch < BN) {
@@ -752,9 +780,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
           b2 += (double)v.y;
         }
         const int co = cur.cb * BN + ch;
-        if (co < p.Cout) {
+        if (co < pe.Cout) {
           const long long slot = ((long long)(cur.td_i * nth + cur.th_i) * ntw + cur.tw_i) * (KS == 2 ? 8 : 1) + cur.par;  // the tile within its sample
-          double* dst = p.stats + ((slot * p.N + cur.n) * p.Cout + co) * 2;  // fixed-order reduction over the slots by the consumers, no atomics
+          double* dst = pe.stats + ((slot * pe.N + cur.n) * pe.Cout + co) * 2;  // fixed-order reduction over the slots by the consumers, no atomics
           *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
         }
       }
