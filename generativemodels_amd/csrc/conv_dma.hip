@@ -812,9 +812,14 @@ extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB + addv;
 }
 
-// Grid policy: -1 (default) = at most as many work-groups as the device holds at once (CUs x work-groups per CU by LDS and wave count): a
-// work-group then walks several tiles (see the kernel's work list); 0 = one work-group per tile; n > 0 = at most n work-groups (tests).
-static int g_dma_grid_cap = -1;
+// Grid policy: 0 (default) = one work-group per tile; -1 = at most as many work-groups as the device holds at once (CUs x work-groups per CU
+// by LDS and wave count): a work-group then walks several tiles (see the kernel's work list); n > 0 = at most n work-groups (tests).
+// Measured on MI355X (profiles/r02_conv_timeline_grid_policy_ab.txt, C2 bench): the walk hides the first patch's latency (wait 340 vs 1 350-2 450
+// cycles) and drops the per-tile address setup, but its next-tile placement + patch request sit on the tile's critical path (5 700 cycles)
+// and the epilogue's stores queue behind the six patch requests of the wave (LDS-DMA requests are consumed at ~16 B/clk per CU): 1.238 vs
+// 1.252 volumes/s -- the hardware dispatcher's own overlap of a finishing and a starting work-group is as good, so one tile per work-group stays
+// the default and the walk is kept as a tested option.
+static int g_dma_grid_cap = 0;
 extern "C" void gm_conv_dma_set_persistent(int max_work_groups) { g_dma_grid_cap = max_work_groups; }
 
 static unsigned dma_grid(unsigned nwork, long long lds_bytes, int by_waves, bool splitk) {

@@ -187,9 +187,10 @@ long long gm_conv_stats_slots(const GmConvDesc* d);
 /* bytes of GmConvDesc.kpartial for this descriptor (ksplit set); 0 when the configuration does not support split-K */
 long long gm_conv_splitk_workspace_bytes(const GmConvDesc* d);
 int gm_conv_forward(const GmConvDesc* d, void* stream);
-/* Grid policy of the LDS-DMA configurations (process-wide; results do not depend on it).  -1 (default): the launch holds at most as many
- * work-groups as the device runs at once and every work-group walks several tiles, requesting the next tile's first input patch before the
- * epilogue of the current one; 0: one work-group per tile; n > 0: at most n work-groups (tests: forces the multi-tile walk on small inputs). */
+/* Grid policy of the LDS-DMA configurations (process-wide; results do not depend on it).  0 (default): one work-group per tile.  -1: the launch
+ * holds at most as many work-groups as the device runs at once and every work-group walks several tiles, requesting the next tile's first input
+ * patch before the epilogue of the current one (measured 1 % slower on MI355X: DESIGN.md 4.1).  n > 0: at most n work-groups (tests: forces
+ * the multi-tile walk on small inputs). */
 void gm_conv_dma_set_persistent(int max_work_groups);
 long long gm_packed_conv_weight_elems(int Cout, int Cin, int kd, int kh, int kw, int dtype);
 /* src: [Cout][Cin][kd][kh][kw] (transposed = 0) or [Cin][Cout][kd][kh][kw] (transposed = 1, nn.ConvTransposeNd) */

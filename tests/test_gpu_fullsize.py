@@ -81,6 +81,29 @@ def test_conv_full_size_spot_checks_and_linearity(cin, cout, size, up):
     assert lin.max().item() <= 4e-2 * scale and lin.mean().item() <= 4e-3 * scale, (lin.max().item(), lin.mean().item(), scale)
 
 
+@pytest.mark.parametrize("cin,cout,size,up", [(64, 64, 128, False), (192, 64, 128, False), (128, 128, 64, True)])
+def test_conv_work_list_launch_is_bitwise_the_default_launch_at_full_size(cin, cout, size, up):
+    """conv_dma.hip under grid policy -1 (512 / 256 co-resident work-groups walking 16 / 32 tiles each, the next tile's patch requested before
+    the epilogue) against the default one-tile-per-work-group launch at configuration C2's real sizes: output and per-tile statistics bit for bit."""
+    ops = _ops()
+    from generativemodels_amd._native import lib
+    x = _randn((1, size, size, size, cin), 11)
+    w = _randn((cout, cin, 3, 3, 3), 12, scale=1 / math.sqrt(cin * 27))
+    b = _randn((cout,), 13, torch.float32, 0.1)
+    osz = size * 2 if up else size
+    res = _randn((1, osz, osz, osz, cout), 14)
+    try:
+        lib().gm_conv_dma_set_persistent(0)
+        one = ops.conv(x, w, b, kernel=3, padding=1, upsample=up, res=res, want_stats=True)
+        one_stats = ops.channel_stats(one).clone()
+        lib().gm_conv_dma_set_persistent(-1)
+        walk = ops.conv(x, w, b, kernel=3, padding=1, upsample=up, res=res, want_stats=True)
+        assert torch.equal(one, walk)
+        assert torch.equal(one_stats, ops.channel_stats(walk))
+    finally:
+        lib().gm_conv_dma_set_persistent(0)
+
+
 def test_attention_full_size_rows_match_a_host_softmax():
     ops = _ops()
     L, dh = 32768, 256

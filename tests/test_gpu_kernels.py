@@ -335,8 +335,8 @@ def test_conv_lds_dma_in_lds_prologue_matches_the_two_pass_form_bitwise(case, cf
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("grid", [8, 11, 29])
 def test_conv_lds_dma_multi_tile_walk_is_bitwise_the_one_tile_per_work_group_launch(grid, dtype):
-    """The LDS-DMA kernels run a work LIST per work-group (conv_dma.hip: the launch is capped at the co-resident work-groups and the next
-    tile's first patch is requested before the current tile's epilogue).  gm_conv_dma_set_persistent(n) caps the grid at n work-groups, so
+    """The LDS-DMA kernels run a work LIST per work-group (conv_dma.hip: under grid policy -1 the launch is capped at the co-resident work-groups and the
+    next tile's first patch is requested before the current tile's epilogue).  gm_conv_dma_set_persistent(n) caps the grid at n work-groups, so
     that every work-group of these small problems walks many tiles (n = 11, 29: XCDs with unequal work-group counts); output AND
     per-tile statistics must be bit-identical to the one-work-group-per-tile launch (policy 0) for every tile configuration and every
     fused feature: residual + timestep row + channel-sliced output, in-LDS GroupNorm prologue over a virtual concat, fused 1x1 shortcut,
@@ -378,7 +378,7 @@ def test_conv_lds_dma_multi_tile_walk_is_bitwise_the_one_tile_per_work_group_lau
             assert torch.equal(one, walk), f"{name}: {(one.float() - walk.float()).abs().max().item():.3e}"
             assert torch.equal(one_stats, walk._gm_cstats), name
     finally:
-        lib().gm_conv_dma_set_persistent(-1)
+        lib().gm_conv_dma_set_persistent(0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
