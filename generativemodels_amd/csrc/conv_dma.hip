@@ -17,6 +17,9 @@
 #include "conv_epilogue.h"
 
 #define DMA_ROWB 64
+#ifndef GM_CONV_PIPE2
+#define GM_CONV_PIPE2 0  // 1: two operand register sets, software-pipelined tap loop (see the main loop); needs more registers than cfg 11 has
+#endif
 // bench-only build (-DGM_CONV_TIMELINE, tools/conv_timeline.py): thread 0 of every work-group stamps the shader clock at phase boundaries
 // into GmConvDesc.kpartial (64 slots per work-group) when debug_flags bit 12 is set; compiled out of the shipped library
 #ifdef GM_CONV_TIMELINE
@@ -324,7 +327,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   // patch piece j of this wave covers LDS rows 16*(wave + NW*j) .. +15; lane -> (row, LDS slot lane&3) <- channel slot swizzled
   const char* zero = reinterpret_cast<const char*>(gm_zero_row);
   const char* xbase = reinterpret_cast<const char*>(p.x);
-  const int pswz = ((lane & 3) ^ dma_swz(lane >> 2)) << 4;  // piece bases are multiples of 16 rows: the swizzle term is per lane
+  // The bank swizzle of a patch row is keyed on the row's COLUMN within its W line (lc), not on the row index: a tap's operand address is
+  // then (lane base for kw) + (line, plane) * constant -- KS address registers per lane instead of KS x (S (MF - 1) + KS) -- and conflict-free
+  // for the same reason (the 16 lanes of a fragment read 16 consecutive columns).  psw: the 2-bit swizzle of this lane's row, per piece.
+  int psw = 0;
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int row = 16 * (wave + NW * j) + (lane >> 2);
+    const int rr = row % PLANE;
+    psw |= dma_swz(rr % PW) << (2 * j);
+  }
   int pvox[PPW];  // source voxel of this lane's patch row per piece, or -1 for a padding row (32-bit: host checks N*V < 2^31)
   auto place_patch = [&](const Tile& t) __attribute__((always_inline)) {
     KDesc& pk = cold_desc();
@@ -355,12 +367,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     if (p.debug_flags & 1024) return;  // bench-only: no patch traffic (results are garbage)
 #endif
     const bool second = chunk >= nchunks0;  // wave-uniform
-    const char* cbase = (second ? x2base + (long long)(chunk - nchunks0) * (BK * (int)sizeof(T)) : xbase + (long long)chunk * (BK * (int)sizeof(T))) + pswz;
+    const char* cbase = second ? x2base + (long long)(chunk - nchunks0) * (BK * (int)sizeof(T)) : xbase + (long long)chunk * (BK * (int)sizeof(T));
     const long long rowb = second ? x2rowb : xrowb;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       if (wave + NW * j < PPIECES) {  // wave-uniform
-        const char* src = pvox[j] >= 0 ? cbase + pvox[j] * rowb : zero + ((lane & 3) << 4);
+        const char* src = pvox[j] >= 0 ? cbase + pvox[j] * rowb + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4) : zero + ((lane & 3) << 4);
         dma16(src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
       }
     }
@@ -372,8 +384,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   if (min(nchunks, cur.ks * cps) < nchunks) issue_patch(min(nchunks, cur.ks * cps));  // the first patch of the first tile
 
   // ---- fused GroupNorm-apply + activation prologue (pre_scale / pre_shift / pre_act), applied IN LDS to the landed patch ---------------
-  // Each lane transforms exactly the 16-byte pieces it DMA'd itself (piece j, row 16 * (wave + NW * j) + lane / 4, LDS slot lane & 3 =
-  // channel slot cs of the chunk): act(x * scale[n][c] + shift[n][c]) in fp32, rounded back to T -- the same arithmetic and rounding as
+  // Each lane transforms 16-byte pieces of its own wave's DMA instructions (piece j, row 16 * (wave + NW * j) + lane / 4, the LDS slot that holds
+  // channel slot lane & 3 of the chunk): act(x * scale[n][c] + shift[n][c]) in fp32, rounded back to T -- the same arithmetic and rounding as
   // gm_gn_apply, so the fused and the two-pass forms are bit-identical.  Rows that came from the zero page stay zero: the reference pads
   // the ACTIVATED tensor (conv(silu(gn(x))), diffusion_model_unet.py:671-684).  Needs no barrier of its own: a wave's own DMA pieces are
   // complete after its vmcnt(0), and the barrier that follows publishes the transformed rows.  Each halo row is transformed once per
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   constexpr bool pre = PRE;
   float sc[VECW], sh[VECW];  // this lane's scale / shift for the chunk being staged: loaded next to the patch DMA, consumed after its wait
   auto load_affine = [&](int chunk) __attribute__((always_inline)) {
-    const int c0 = chunk * BK + (pswz >> 4) * VECW;  // this lane's channels within cat(x, x2): the same slot for every piece
+    const int c0 = chunk * BK + (lane & 3) * VECW;   // this lane's channels within cat(x, x2): channel slot lane & 3 of every row it transforms
     const float* ps = p.pre_scale + (long long)cur.n * p.Cin + c0;
     const float* ph = p.pre_shift + (long long)cur.n * p.Cin + c0;
 #pragma unroll
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       if (wave + NW * j < PPIECES && pvox[j] >= 0) {
-        char* a = smem + (16 * (wave + NW * j) + (lane >> 2)) * DMA_ROWB + ((lane & 3) << 4);
+        char* a = smem + (16 * (wave + NW * j) + (lane >> 2)) * DMA_ROWB + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4);  // (a piece of this wave's own DMA instruction)
         float v[VECW];
         Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a), v);
 #pragma unroll
@@ -507,26 +519,20 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     static_assert(MF <= 4 && (4 % MF) == 0, "a wave's fragments stay inside one 4-row tile plane");
     OPAQUE_LANE(lane_t);  // keeps the two tables out of loop-invariant code motion (= out of the epilogue's live set)
     const int l15t = lane_t & 15, qt = lane_t >> 4;
-    int xaddr[HK][KS];  // patch row (hk, kw) of this lane's voxel column; depth taps add kd * PLANE * 64 as an immediate
+    int xa[KS];  // patch row of this lane's voxel column for tap column kw (line 0 of the wave's fragments); lines / planes are immediates
     {
       const int m0 = wave * MF * 16 + l15t;
       const int a = m0 >> 6, bb0 = (m0 >> 4) & 3, c = m0 & 15;
 #pragma unroll
-      for (int hk = 0; hk < HK; ++hk)
-#pragma unroll
-        for (int kw = 0; kw < KS; ++kw) {
-          const int col = S == 1 ? c + kw : (kw == 1 ? EW + c : c + (kw >> 1));  // patch column S*c + kw in the split layout
-          const int row = S * a * PLANE + (S * bb0 + hk) * PW + col;
-          xaddr[hk][kw] = row * DMA_ROWB + ((qt ^ dma_swz(row)) << 4);
-        }
+      for (int kw = 0; kw < KS; ++kw) {
+        const int col = S == 1 ? c + kw : (kw == 1 ? EW + c : c + (kw >> 1));  // patch column S*c + kw in the split layout
+        xa[kw] = (S * a * PLANE + S * bb0 * PW + col) * DMA_ROWB + ((qt ^ dma_swz(col)) << 4);
+      }
     }
-    // weight rows nf * 16 + l15: the swizzle has period 8 rows, so fragments 4..7 (BN = 128) are fragments 0..3 plus 64 rows -- an immediate
-    int waddr[4];
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      const int r = nf * 16 + l15t;
-      waddr[nf] = PATCH_BYTES + r * DMA_ROWB + ((qt ^ dma_swz(r)) << 4);
-    }
+    // weight rows nf * 16 + l15: the swizzle has period 8 rows, so every further fragment is fragment 0 plus 16 rows -- an immediate
+    const int wa0 = PATCH_BYTES + l15t * DMA_ROWB + ((qt ^ dma_swz(l15t)) << 4);
+#define XADDR(hk, kw) (xa[kw] + (hk) * (PW * DMA_ROWB))
+#define WADDR(nf) (wa0 + (nf) * (16 * DMA_ROWB))
     f32x4_t acc[NFR][MF];
 #pragma unroll
     for (int nf = 0; nf < NFR; ++nf)
@@ -539,44 +545,125 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       if (pre) transform_patch();
     }
     __builtin_amdgcn_s_barrier();
+#ifdef GM_CONV_TIMELINE
+    // bench-only experiment (debug_flags bit 11): the work-groups of a CU start in pairs and stay in lock step (equal lifetimes), every wave
+    // wanting the LDS port and then the MFMA pipe at the same moment; skew the odd work-group slot (HW_ID.TG_ID) by bits 16..23 x 64 cycles
+    if (p.debug_flags & 2048) {
+      const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);  // HW_REG_HW_ID[19:16]
+      if (tg & 1) {
+        for (int k = (p.debug_flags >> 16) & 255; k > 0; --k) __builtin_amdgcn_s_sleep(1);
+      }
+    }
+#endif
     TL_STAMP(2);
 
     // ---- main loop ----------------------------------------------------------------------------------------------------------
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
       const bool last_chunk = chunk + 1 == c_end;
-  #pragma unroll
+      constexpr int NH = NFR / 4;
+      if constexpr (NH == 1 && GM_CONV_PIPE2) {
+        // Two operand register sets, software-pipelined over the taps AND over the group barrier (ISA of the single-set form: the last tap's
+        // four weight fragments went through ONE register quad -- read, wait, 2 MFMAs, four times -- and every group began with ~45 address
+        // instructions of the panel request in front of its first LDS read: a wave alone on its SIMD pair ran a group in 1 370 cycles against
+        // 384 cycles of MFMA issue).  Group g: tap 0 is already in set X (read right after the barrier that ended group g - 1, whose wait made
+        // panel g visible); tap 1 -> set Y under tap 0's MFMAs, the panel request's address arithmetic in the shadow of those MFMAs, tap 2 -> X
+        // under tap 1's MFMAs, end-of-group wait + barrier, next group's tap 0 -> Y under tap 2's MFMAs.  A chunk's first group reads its own tap 0
+        // (the patch has just been replaced).
+        uint4 xf[2][MF], wf[2][4];
+        auto read_tap = [&](int g, int u, int set) __attribute__((always_inline)) {
+          const int tap = g * G + u;
+          const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+            wf[set][nf] = *reinterpret_cast<const uint4*>(smem + WADDR(nf) + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+            xf[set][mf] = *reinterpret_cast<const uint4*>(smem + XADDR(S * mf + kh, kw) + kd * (PLANE * DMA_ROWB));
+        };
+        auto mma_tap = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[set][nf], xf[set][mf], acc[nf][mf]);
+        };
+        constexpr int NMMA = MF * 4 * (sizeof(T) == 2 ? 1 : 4), NRD = MF + 4;
+        static_assert(G == 3 || G == 2, "taps per panel");
+#pragma unroll
+        for (int g = 0; g < NGROUPS; ++g) {
+          const int t = chunk * NGROUPS + g;
+          const int X = (g * G) & 1, Y = X ^ 1;                              // operand set of a tap = (tap index) & 1
+          const int LASTSET = (g * G + G - 1) & 1, NEXTSET = ((g + 1) * G) & 1;  // ... of the group's last tap / the next group's first
+          if (g == 0) read_tap(0, 0, X);
+          read_tap(g, 1, Y);
+          mma_tap(X);
+          if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);  // the operand reads first, then the tap's MFMAs
+          else __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+          // panel t+2 goes into the ring slot group t-1 read from (every wave is past the barrier that ended it)
+          if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % RING);
+          if (G == 3) {
+            read_tap(g, 2, X);
+            mma_tap(Y);
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+          }
+          if (g == NGROUPS - 1) {
+            if (!last_chunk) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
+              issue_patch(chunk + 1);
+              if (pre) load_affine(chunk + 1);
+              dma_wait<0>();                 // patch + the two panels in flight
+              if (pre) transform_patch();
+              __builtin_amdgcn_s_barrier();
+            }
+          } else {
+            // panel t+1 (issued a group ago) must have landed; panel t+2 (WPW instructions, just issued) may stay in flight.  The wait also
+            // retires every LDS read of the group: the barrier releases other waves to DMA into the ring slot this group read.
+            if ((g < NGROUPS - 2 || !last_chunk) && (NW != 16 || wave < 12)) dma_wait<WPW>(); else dma_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            read_tap(g + 1, 0, NEXTSET);
+          }
+          mma_tap(LASTSET);
+          if (g < NGROUPS - 1) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+          }
+          if (chunk - c_begin < 5) TL_STAMP(3 + (chunk - c_begin) * 10 + g);  // after the barrier that ends group g (g = 8: incl. the chunk boundary)
+        }
+      } else {
+#pragma unroll
       for (int g = 0; g < NGROUPS; ++g) {
         const int t = chunk * NGROUPS + g;
         // panel t+2 goes into the ring slot group t-1 read from (every wave is past the barrier that ended it)
         if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % RING);
         // The last tap's operand reads are issued before the end-of-group wait and its MFMAs after the barrier.  The wait retires
         // every LDS read of the group (lgkmcnt(0)): the barrier releases other waves to DMA into the ring slot this group read.
-        // (Measured against an ordering that keeps the two patch reads of the last tap in flight across the barrier: 2-3 % slower.)
         // BN = 128 splits a tap into NH = 2 half-steps of four channel fragments each (16 + 16 operand registers instead of 48).
-        constexpr int NH = NFR / 4, NSTEPS = G * NH;
+        constexpr int NSTEPS = G * NH;
         uint4 xf[MF], wf[4];
         auto read_step = [&](int st) __attribute__((always_inline)) {
           const int u = st / NH, hf = st % NH;
           const int tap = g * G + u;
           const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
-  #pragma unroll
+#pragma unroll
           for (int nf = 0; nf < 4; ++nf)
-            wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + hf * (64 * DMA_ROWB) + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
+            wf[nf] = *reinterpret_cast<const uint4*>(smem + WADDR(nf) + hf * (64 * DMA_ROWB) + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
           if (hf == 0) {
-  #pragma unroll
+#pragma unroll
             for (int mf = 0; mf < MF; ++mf)
-              xf[mf] = *reinterpret_cast<const uint4*>(smem + xaddr[S * mf + kh][kw] + kd * (PLANE * DMA_ROWB));
+              xf[mf] = *reinterpret_cast<const uint4*>(smem + XADDR(S * mf + kh, kw) + kd * (PLANE * DMA_ROWB));
           }
         };
         auto mma_step = [&](int st) __attribute__((always_inline)) {
           const int hf = st % NH;
-  #pragma unroll
+#pragma unroll
           for (int nf = 0; nf < 4; ++nf)
-  #pragma unroll
+#pragma unroll
             for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[nf], xf[mf], acc[hf * 4 + nf][mf]);
         };
         constexpr int NMMA = MF * 4 * (sizeof(T) == 2 ? 1 : 4);
-  #pragma unroll
+#pragma unroll
         for (int st = 0; st < NSTEPS - 1; ++st) {
           read_step(st);
           mma_step(st);
@@ -603,6 +690,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         mma_step(NSTEPS - 1);
         if (chunk - c_begin < 5) TL_STAMP(3 + (chunk - c_begin) * 10 + g);  // after the barrier that ends group g (g = 8: incl. the chunk boundary)
       }
+      }
     }
   TL_STAMP(60);
 
@@ -619,6 +707,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     if (ps.skip_x[0] && cur.ks == ksplit - 1) {  // (split-K: the shortcut's chunks ride with the last K slice)
       const int nsc0 = ps.skip_cin[0] / BK, nsc = nsc0 + (ps.skip_x[1] ? ps.skip_cin[1] / BK : 0);
       OPAQUE_LANE(lane_k);
+      const int pswz = ((lane_k & 3) ^ dma_swz(lane_k >> 2)) << 4;  // (the shortcut's rows are voxels: row-keyed swizzle, one term per lane)
       int svox[MF];  // output voxel of this lane's centre rows (piece h covers rows wave*32 + h*16 + lane/4), -1 outside the volume
   #pragma unroll
       for (int h = 0; h < MF; ++h) {
@@ -670,7 +759,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
             for (int hf = 0; hf < NFR / 4; ++hf) {
   #pragma unroll
               for (int nf = 0; nf < 4; ++nf)
-                wf[nf] = *reinterpret_cast<const uint4*>(smem + waddr[nf] + hf * (64 * DMA_ROWB) + j * (BN * DMA_ROWB));
+                wf[nf] = *reinterpret_cast<const uint4*>(smem + WADDR(nf) + hf * (64 * DMA_ROWB) + j * (BN * DMA_ROWB));
   #pragma unroll
               for (int nf = 0; nf < 4; ++nf)
   #pragma unroll
@@ -800,6 +889,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     pos += gx;
   }
 }
+
+#undef XADDR
+#undef WADDR
 
 // variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile; 4 = sub-pixel 2x2x2 (5 planes of 5 x 17 -> 96 rows,
 // four 128-row weight panels, padded to the 36 KiB of the epilogue's transpose scratch); 5 = 8x4x16 tile x 128 output channels (three 384-row
