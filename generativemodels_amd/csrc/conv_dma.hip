@@ -17,9 +17,6 @@
 #include "conv_epilogue.h"
 
 #define DMA_ROWB 64
-#ifndef GM_CONV_PIPE2
-#define GM_CONV_PIPE2 0  // 1: two operand register sets, software-pipelined tap loop (see the main loop); needs more registers than cfg 11 has
-#endif
 // bench-only build (-DGM_CONV_TIMELINE, tools/conv_timeline.py): thread 0 of every work-group stamps the shader clock at phase boundaries
 // into GmConvDesc.kpartial (64 slots per work-group) when debug_flags bit 12 is set; compiled out of the shipped library
 #ifdef GM_CONV_TIMELINE
@@ -372,7 +369,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       if (wave + NW * j < PPIECES) {  // wave-uniform
-        const char* src = pvox[j] >= 0 ? cbase + pvox[j] * rowb + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4) : zero + ((lane & 3) << 4);
+        int pv = pvox[j];
+        asm volatile("" : "+v"(pv));  // opaque: keeps the 64-bit row offsets pvox[j] * rowb (x and x2: 24 registers) out of the chunk loop's live set
+        const char* src = pv >= 0 ? cbase + pv * rowb + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4) : zero + ((lane & 3) << 4);
         dma16(src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
       }
     }
@@ -561,7 +560,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
       const bool last_chunk = chunk + 1 == c_end;
       constexpr int NH = NFR / 4;
-      if constexpr (NH == 1 && GM_CONV_PIPE2) {
+      // two operand sets where they fit without scratch (hipcc 7.2: the sub-pixel, stride-2 and the 256-register tiles without a fused prologue; the
+      // 128-register tiles -- cfg 11 / 16 -- and the prologue forms would spill 70-350 registers)
+      constexpr bool PIPE2 = NH == 1 && !PRE && (KS == 2 || S == 2 || MINW == 2);
+      if constexpr (PIPE2) {
         // Two operand register sets, software-pipelined over the taps AND over the group barrier (ISA of the single-set form: the last tap's
         // four weight fragments went through ONE register quad -- read, wait, 2 MFMAs, four times -- and every group began with ~45 address
         // instructions of the panel request in front of its first LDS read: a wave alone on its SIMD pair ran a group in 1 370 cycles against

@@ -542,6 +542,8 @@ SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups t
 SPLITK_TARGET_WGS = 512  # ... into as many slices as it takes to reach about this many (two per CU)
 SPLITK_MAX = 8
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
+DMA_WIDE_WAVES = os.environ.get("GM_CONV_WIDE_WAVES", "1") != "0"  # prefer cfg 14 (4 waves x 64 voxels) for large prologue-free stride-1 convolutions
+DMA_WIDE_WAVE_MIN_TILES = 512                                       # ... from one full wave of work-groups on (2 per CU)
 
 
 def fuse_gn_prologue(x: torch.Tensor) -> bool:
@@ -652,7 +654,13 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         if desc.Cin <= 4:
             order = [12] + order  # taps-as-K kernel of the 1..4-channel input convolutions
     if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
-        order = ([15] if desc.sd == 2 else [11]) + order  # LDS-DMA 3x3x3 kernel: the C side rejects (lds = -1) whatever it does not cover
+        # LDS-DMA 3x3x3 kernels: the C side rejects (lds = -1) whatever a configuration does not cover.  Stride 1: the 4-wave x 64-voxel form
+        # (cfg 14: two operand register sets, software-pipelined tap loop -- 256 registers per wave) is 2-9 % faster than the 8-wave x 32-voxel
+        # form (cfg 11, 128 registers: one operand set) on every C2 / C3 shape once the grid fills the chip (profiles/r02_conv_tile_configs_v2.txt);
+        # cfg 11 keeps the fused-prologue instantiation (the cfg 14 one spills) and the small grids (its split-K form).
+        tiles = desc.N * -(-desc.Do // 4) * -(-desc.Ho // 4) * -(-desc.Wo // 16) * -(-cout // 64)
+        wide = bool(desc.pre_scale is None or not desc.pre_scale) and tiles >= DMA_WIDE_WAVE_MIN_TILES and DMA_WIDE_WAVES
+        order = ([15] if desc.sd == 2 else ([14, 11] if wide else [11])) + order
         # (512-voxel tiles -- cfg 16 / 18, one work-group per CU, half the weight-panel traffic -- measure within +-5 % of two 256-voxel
         # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,
         # r02_layer_times_cfg16_rule.txt.  They stay available through force_cfg.)
