@@ -168,16 +168,30 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
       for (int f = 0; f < QF; ++f)
 #pragma unroll
         for (int kf = 0; kf < KFH; ++kf) sacc[f][kf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      // K fragments are read PD ahead of the MFMAs that consume them (ISA of the straightforward loop: wait - MFMA - read, one read in flight:
+      // a wave issued one MFMA per LDS round trip and two waves per SIMD reached 31 % of the MFMA rate with 90 registers to spare)
+      {
+        constexpr int NKQ = STEPS * KFH, PDW = (QF == 1 && MINW <= 2) ? 8 : (QF == 1 ? 4 : 2), PD = NKQ < PDW ? NKQ : PDW;  // as deep as the registers allow
+        uint4 kq[PD];
+        auto kread = [&](int i) __attribute__((always_inline)) {
+          const int s = i / KFH, kf = i % KFH;
+          return *reinterpret_cast<const uint4*>(buf + kaddr[s % KA] + (s / KA) * (KA * 64) + (hf * KFH + kf) * 16 * KROWB);
+        };
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s)
+        for (int i = 0; i < PD; ++i) kq[i] = kread(i);
+        __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
 #pragma unroll
-        for (int kf = 0; kf < KFH; ++kf) {
-          const uint4 kfrag = *reinterpret_cast<const uint4*>(buf + kaddr[s % KA] + (s / KA) * (KA * 64) + (hf * KFH + kf) * 16 * KROWB);
+        for (int i = 0; i < NKQ; ++i) {
+          const int s = i / KFH, kf = i % KFH;
 #pragma unroll
           for (int f = 0; f < QF; ++f)
-            sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kfrag), __builtin_bit_cast(bf16x8_t, qf[f][s]),
+            sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kq[i % PD]), __builtin_bit_cast(bf16x8_t, qf[f][s]),
                                                                   sacc[f][kf], 0, 0, 0);
+          if (i + PD < NKQ) kq[i % PD] = kread(i + PD);
+          __builtin_amdgcn_sched_group_barrier(0x008, QF, 0);
+          if (i + PD < NKQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+      }
       // ---- online softmax: this lane's queries, keys key0 + (hf * KFH + kf) * 16 + qg * 4 + r ----------------------------------
       uint4 pf[QF][KFH / 2];
       float alpha[QF];
@@ -228,16 +242,28 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
       }
 
       // ---- O^T += V^T P^T: one V^T fragment read feeds QF MFMAs --------------------------------------------------------------
+      {
+        constexpr int NVQ = DF * (KFH / 2), PDW = (QF == 1 && MINW <= 2) ? 8 : (QF == 1 ? 4 : 2), PD = NVQ < PDW ? NVQ : PDW;
+        uint4 vq[PD];
+        auto vread = [&](int i) __attribute__((always_inline)) {
+          const int d = i / (KFH / 2), s = i % (KFH / 2);
+          return *reinterpret_cast<const uint4*>(buf + vaddr[hf * (KFH / 2) + s] + d * 16 * 128);
+        };
 #pragma unroll
-      for (int d = 0; d < DF; ++d)
+        for (int i = 0; i < PD; ++i) vq[i] = vread(i);
+        __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
 #pragma unroll
-        for (int s = 0; s < KFH / 2; ++s) {
-          const uint4 vfrag = *reinterpret_cast<const uint4*>(buf + vaddr[hf * (KFH / 2) + s] + d * 16 * 128);
+        for (int i = 0; i < NVQ; ++i) {
+          const int d = i / (KFH / 2), s = i % (KFH / 2);
 #pragma unroll
           for (int f = 0; f < QF; ++f)
-            oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vfrag), __builtin_bit_cast(bf16x8_t, pf[f][s]),
+            oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vq[i % PD]), __builtin_bit_cast(bf16x8_t, pf[f][s]),
                                                                  oacc[f][d], 0, 0, 0);
+          if (i + PD < NVQ) vq[i % PD] = vread(i + PD);
+          __builtin_amdgcn_sched_group_barrier(0x008, QF, 0);
+          if (i + PD < NVQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+      }
     }
     // the next tile has landed (this wave's pieces) and this wave is done reading the current one
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
