@@ -14,6 +14,10 @@
 //   * 8 waves x 16 queries per work-group share each tile (halves the L2 -> LDS traffic of the 4-wave kernel).
 #include "attn_common.h"
 
+#ifndef GM_ATTN_PD
+#define GM_ATTN_PD 8  // operand fragments in flight ahead of the MFMAs (256-register kernels); bench-only builds override it
+#endif
+
 __device__ __attribute__((aligned(64))) unsigned int gm_attn_zero_row[16] = {0};
 
 __device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
       // K fragments are read PD ahead of the MFMAs that consume them (ISA of the straightforward loop: wait - MFMA - read, one read in flight:
       // a wave issued one MFMA per LDS round trip and two waves per SIMD reached 31 % of the MFMA rate with 90 registers to spare)
       {
-        constexpr int NKQ = STEPS * KFH, PDW = (QF == 1 && MINW <= 2) ? 8 : (QF == 1 ? 4 : 2), PD = NKQ < PDW ? NKQ : PDW;  // as deep as the registers allow
+        constexpr int NKQ = STEPS * KFH, PDW = (QF == 1 && MINW <= 2) ? GM_ATTN_PD : (QF == 1 ? 4 : 2), PD = NKQ < PDW ? NKQ : PDW;  // as deep as the registers allow
         uint4 kq[PD];
         auto kread = [&](int i) __attribute__((always_inline)) {
           const int s = i / KFH, kf = i % KFH;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
 
       // ---- O^T += V^T P^T: one V^T fragment read feeds QF MFMAs --------------------------------------------------------------
       {
-        constexpr int NVQ = DF * (KFH / 2), PDW = (QF == 1 && MINW <= 2) ? 8 : (QF == 1 ? 4 : 2), PD = NVQ < PDW ? NVQ : PDW;
+        constexpr int NVQ = DF * (KFH / 2), PDW = (QF == 1 && MINW <= 2) ? GM_ATTN_PD : (QF == 1 ? 4 : 2), PD = NVQ < PDW ? NVQ : PDW;
         uint4 vq[PD];
         auto vread = [&](int i) __attribute__((always_inline)) {
           const int d = i / (KFH / 2), s = i % (KFH / 2);
