@@ -81,7 +81,7 @@ def measured_hbm_traffic(label: str, dtype) -> dict:
         return dict(traffic=None, traffic_note=f"stale: the committed PMC pass measured kernel sources {doc.get('source_sha')}, "
                                                f"this build is {kernel_source_sha()} -- re-run tools/pmc_traffic.sh")
     elem = "unsigned short" if dtype == torch.bfloat16 else "float"
-    sym = f"conv_dma_kernel<{elem}, {DMA_CFG_TEMPLATE[cfg]}>" if cfg in DMA_CFG_TEMPLATE else None
+    sym = f"conv_dma_kernel<{elem}, {DMA_CFG_TEMPLATE[cfg]}, false>" if cfg in DMA_CFG_TEMPLATE else None  # (last argument: no fused prologue)
     for r in doc.get("rows", []):
         if sym is not None and sym in r["kernel"]:
             return dict(traffic=round(r["hbm_mb_per_launch_corrected"] * 1e6), traffic_unit="bytes/launch (avg over the same launches)",
