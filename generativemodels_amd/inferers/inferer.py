@@ -61,7 +61,9 @@ class _GraphedUNet:
             model(self.x, self.t, self.context)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: HIP calls of OTHER host threads (DataLoader pin-memory, the RCCL watchdog, a GradientReducer side stream
+        # during in-training validation sampling) do not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = model(self.x, self.t, self.context)
 
     def __call__(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
@@ -74,7 +76,8 @@ class _GraphedUNet:
 class DiffusionInferer(Inferer):
     """Drop-in for generative.inferers.DiffusionInferer. `diffusion_model` may be any callable `(x, timesteps=, context=)`."""
 
-    GRAPH_AUTO_MAX_ELEMENTS = 1 << 19  # use_hip_graph=None: replay a HIP graph when the model input is at most this many elements
+    GRAPH_AUTO_MAX_ELEMENTS = 1 << 19  # use_hip_graph=None: replay a HIP graph when the model input is at most this many elements ...
+    GRAPH_AUTO_MIN_STEPS = 20          # ... and the chain is long enough to repay the capture (a warm-up forward, a capture forward, instantiation)
 
     def __init__(self, scheduler: nn.Module, use_hip_graph: bool | None = None) -> None:
         """use_hip_graph: True / False, or None = decide per call: small problems are host-launch-bound and replaying the forward from
@@ -123,7 +126,8 @@ class DiffusionInferer(Inferer):
                 model_input, ctx = ops.concat_dim1([image, conditioning]), None
             else:
                 model_input, ctx = image, conditioning
-            use_graph = self.use_hip_graph if self.use_hip_graph is not None else model_input.numel() <= self.GRAPH_AUTO_MAX_ELEMENTS
+            use_graph = self.use_hip_graph if self.use_hip_graph is not None else (
+                model_input.numel() <= self.GRAPH_AUTO_MAX_ELEMENTS and len(steps) >= self.GRAPH_AUTO_MIN_STEPS)
             if use_graph and graphable:
                 if graphed is None:
                     graphed = _GraphedUNet(diffusion_model, model_input, tt, ctx)
@@ -463,7 +467,7 @@ class VQVAETransformerInferer(Inferer):
         body()  # draw 0 eagerly: first-use initialisation of every kernel happens outside the capture
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             body()  # captured, not executed: draw 1 happens at the first replay
         for _ in range(n_graph - 1):
             graph.replay()
