@@ -539,8 +539,8 @@ DMA_FUSED_PROLOGUE_MAX_FLOP = 3.0e10
 # kernel sums the fp32 partials and applies the epilogue.
 SPLITK = os.environ.get("GM_CONV_SPLITK", "1") != "0"
 SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups than this ...
-SPLITK_TARGET_WGS = 512  # ... into as many slices as it takes to reach about this many (two per CU)
-SPLITK_MAX = 8
+SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "512"))  # ... into as many slices as it takes to reach about this many (two per CU)
+SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
 DMA_WIDE_WAVES = os.environ.get("GM_CONV_WIDE_WAVES", "1") != "0"  # prefer cfg 14 (4 waves x 64 voxels) for large prologue-free stride-1 convolutions
 DMA_WIDE_WAVE_MIN_TILES = 512                                       # ... from one full wave of work-groups on (2 per CU)
