@@ -61,3 +61,6 @@ def test_pure_host_entry_points_run_without_a_gpu():
     assert lib.gm_packed_conv_weight_elems(64, 64, 3, 3, 3, 1) == 2 * 27 * 64 * 32
     assert lib.gm_gn_workspace_bytes(1, 128 ** 3, 64, 32, 1) > 0
     assert lib.gm_attention_max_head_dim() == 256
+    for policy in (-1, 0, 16, 0):  # grid policy of the LDS-DMA convolutions: process-wide host state, no device call; leave the default (0)
+        lib.gm_conv_dma_set_persistent(policy)
+    lib.gm_attention_dma_set_variant(0, 0)
