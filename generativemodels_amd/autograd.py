@@ -55,7 +55,12 @@ class _Conv(torch.autograd.Function):
             opad = tuple(x.shape[1 + i] - ((gy.shape[1 + i] - 1) * s[i] - p[i] - phi[i] + k[i]) for i in range(nsp))
             if any(o < 0 or o >= s[i] for i, o in enumerate(opad)):
                 raise ValueError(f"convolution geometry is not invertible: output_padding {opad}")
-            dx = ops.conv(gy, weight, None, kernel=k, stride=s, padding=p, pad_hi=phi, transposed=True, output_padding=opad)
+            dx = None
+            if nsp == 3 and k == (3, 3, 3) and s == (2, 2, 2) and p[0] == p[1] == p[2] and phi == (1, 1, 1):
+                # stride 2 (the Downsample convolutions): one sub-pixel launch on gy instead of a convolution over its zero-inserted image
+                dx = ops.conv_stride2_dgrad(gy, weight, x.shape[1:4], p[0])
+            if dx is None:
+                dx = ops.conv(gy, weight, None, kernel=k, stride=s, padding=p, pad_hi=phi, transposed=True, output_padding=opad)
         if ctx.needs_input_grad[1]:
             dw = ops.conv_wgrad(x, gy, k, s, p).reshape(weight.shape).to(weight.dtype)
         if ctx.needs_input_grad[2]:

@@ -211,6 +211,41 @@ def packed_subpixel_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Te
     return _cached(weight, ("subpixel", dtype), make)
 
 
+def packed_stride2_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype, pad_lo: int) -> torch.Tensor:
+    """The data gradient of a stride-2 3x3x3 convolution as the 8 parity images of 2x2x2 kernels the sub-pixel kernel (configuration 17)
+    consumes.  Forward: y[o] = sum_k W[k] x[2 o + k - pad_lo].  Gradient: dx[u] = sum_{o, k: 2 o + k - pad_lo = u} W[k]^T dy[o], i.e. per axis
+      pad_lo = 1 (symmetric padding, DiffusionModelUNet Downsample):  dx[2i] = W[1]^T dy[i];  dx[2i + 1] = W[2]^T dy[i] + W[0]^T dy[i + 1]
+      pad_lo = 0 (pad-high-only, AutoencoderKL Downsample):          dx[2i] = W[2]^T dy[i - 1] + W[0]^T dy[i];  dx[2i + 1] = W[1]^T dy[i]
+    -- exactly the access pattern of that kernel (output parity 0 reads inputs (i - 1, i), parity 1 reads (i, i + 1)) with at most two
+    taps per axis, so a stride-2 data gradient is one launch of it on dy with these weights: no zero-insertion, 8 of 8 MFMA taps issued of
+    which 27/8 per output voxel on average carry weight (reference: torch autograd through nn.Conv3d(stride=2),
+    diffusion_model_unet.py:510-518, autoencoderkl.py:107-121).  [Cout, Cin, 3, 3, 3] -> packed, rounded to `dtype`."""
+    require_device(weight)
+    if pad_lo not in (0, 1):
+        raise ValueError("pad_lo must be 0 or 1")
+    taps = {1: {0: (None, 1), 1: (2, 0)}, 0: {0: (2, 0), 1: (1, None)}}[pad_lo]  # parity -> forward tap index at the (first, second) input
+
+    def make():
+        wt = weight.detach().float().transpose(0, 1)  # [Cin, Cout, 3, 3, 3]: the gradient maps Cout channels of dy to Cin channels of dx
+        cin_f, cout_f = wt.shape[0], wt.shape[1]
+        n = lib().gm_packed_conv_weight_elems(cin_f, cout_f, 2, 2, 2, dt_code(dtype))
+        out = torch.empty(8 * n, dtype=dtype, device=wt.device)
+        for par in range(8):
+            sel = (taps[(par >> 2) & 1], taps[(par >> 1) & 1], taps[par & 1])
+            w2 = torch.zeros((cin_f, cout_f, 2, 2, 2), dtype=torch.float32, device=wt.device)
+            for a in range(2):
+                for b in range(2):
+                    for c in range(2):
+                        ka, kb, kc = sel[0][a], sel[1][b], sel[2][c]
+                        if ka is not None and kb is not None and kc is not None:
+                            w2[:, :, a, b, c] = wt[:, :, ka, kb, kc]
+            check(lib().gm_pack_conv_weight(w2.data_ptr(), dt_code(w2.dtype), out[par * n:].data_ptr(), dt_code(dtype), cin_f, cout_f, 2, 2, 2, 0,
+                                            _stream()), "gm_pack_conv_weight")
+        return out
+
+    return _cached(weight, ("stride2_dgrad", dtype, pad_lo), make)
+
+
 def packed_cat_weight(weights: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
     """Linear weights [Cout_i, Cin] stacked along Cout and packed as one panel (fused q/k/v projections etc.)."""
 
@@ -698,7 +733,7 @@ def _attach_conv_stats(d: GmConvDesc, out: torch.Tensor, n: int, cout: int) -> N
         out._gm_cstats = cst
 
 
-def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, cin, cout, src):
+def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, cin, cout, src, packed=None, label="mode3 (executed flops: 8 of the 27 taps)"):
     """Nearest-2x up-sampling + 3x3x3 convolution as 8 sub-pixel 2x2x2 convolutions (GmConvDesc.in_mode 3, configuration 17).
     Returns None when the geometry is not covered (the caller falls back to the folded up-sampling path)."""
     dtype = x.dtype
@@ -709,7 +744,8 @@ def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, c
     elif tuple(out.shape) != out_shape or out.dtype != dtype:
         raise ValueError(f"out has shape {tuple(out.shape)}, expected {out_shape}")
     d = GmConvDesc()
-    packed = packed_subpixel_weight(weight, dtype)
+    if packed is None:
+        packed = packed_subpixel_weight(weight, dtype)
     d.in_mode, d.fd, d.fh, d.fw = 3, 2, 2, 2
     d.x, d.x_ld, d.w = x.data_ptr(), arena_ld(x), packed.data_ptr()
     b32 = as_f32(bias) if bias is not None else None
@@ -749,11 +785,31 @@ def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, c
     es = x.element_size()
     _timed(f"conv_igemm<{str(dtype).split('.')[-1]},cfg17>",
            dict(flops=2.0 * nvo * cout * cin * 8, bytes=float(es * (n * math.prod(src) * cin + nvo * cout * (2 if res is not None else 1) + 8 * cout * cin * 8)),
-                shape=f"{cin}->{cout} k(3, 3, 3) s(1, 1, 1) out{out_sp} mode3 (executed flops: 8 of the 27 taps)"),
+                shape=f"{cin}->{cout} k(3, 3, 3) s(1, 1, 1) out{out_sp} {label}"),
            lambda: check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward"))
     if d.stats:
         out._gm_cstats = _compact_stats(out._gm_cstats)
     return out
+
+
+STRIDE2_DGRAD_SUBPIXEL = os.environ.get("GM_CONV_STRIDE2_DGRAD", "1") != "0"
+
+
+def conv_stride2_dgrad(gy: torch.Tensor, weight: torch.Tensor, x_spatial: Sequence[int], pad_lo: int) -> Optional[torch.Tensor]:
+    """dx of y = conv3d(x, weight, stride=2, padding=(pad_lo low, 1 high)) for even x extents, as ONE sub-pixel launch on gy
+    (packed_stride2_dgrad_weight).  Returns None when the geometry is not covered: the caller takes the transposed-convolution path."""
+    if not STRIDE2_DGRAD_SUBPIXEL or gy.dim() != 5 or weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or pad_lo not in (0, 1):
+        return None
+    n, src, cg = gy.shape[0], tuple(gy.shape[1:4]), gy.shape[4]
+    if tuple(x_spatial) != tuple(2 * v for v in src) or cg != weight.shape[0]:
+        return None
+    vec = 16 // gy.element_size()
+    if cg % (64 // gy.element_size()) != 0 or weight.shape[1] % vec != 0 or n * math.prod(x_spatial) >= 2 ** 31:
+        return None
+    require_device(gy, weight)
+    packed = packed_stride2_dgrad_weight(weight, gy.dtype, pad_lo)
+    return _conv_subpixel(gy, weight, None, None, None, "none", None, False, n, cg, weight.shape[1], src, packed=packed,
+                          label="stride-2 data gradient as 8 sub-pixel 2x2x2 convolutions")
 
 
 def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *, kernel, stride=1, padding=0, dilation=1,

@@ -122,6 +122,40 @@ def test_conv_autograd_function(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("sym", (8, 6, 32), 2, 64, 64, 1), ("asym", (4, 8, 16), 1, 64, 32, 0), ("wide", (6, 4, 48), 2, 32, 96, 1),
+                                  ("asym-rag", (10, 6, 34), 1, 96, 64, 0)], ids=lambda c: c[0])
+def test_stride2_data_gradient_as_sub_pixel_convolutions(case, dtype):
+    """dx of a stride-2 3x3x3 convolution (the Downsample convolutions: symmetric padding in the UNet, pad-high-only in the AutoencoderKL)
+    evaluated as ONE launch of the sub-pixel kernel on dy with the per-parity 2x2x2 weights of ops.packed_stride2_dgrad_weight, against torch
+    autograd in fp64 and against the transposed-convolution path it replaces; and the autograd Function takes it."""
+    ops = _ops()
+    from generativemodels_amd import autograd as ag
+    name, sp, n, cin, cout, pad_lo = case  # sp = x extents (even), y = sp / 2
+    x = _rand((n, cin, *sp), 801).to(dtype)
+    w = (_rand((cout, cin, 3, 3, 3), 802) / math.sqrt(cin * 27)).to(dtype)
+    ysp = tuple(v // 2 for v in sp)
+    gy = _rand((n, cout, *ysp), 803).to(dtype)
+    x64 = x.double().requires_grad_(True)
+    y64 = F.conv3d(F.pad(x64, (pad_lo, 1) * 3), w.double(), None, stride=2)
+    assert tuple(y64.shape[2:]) == ysp
+    y64.backward(gy.double())
+    want = x64.grad
+    got = ops.conv_stride2_dgrad(_cl(gy), w.to(DEV), sp, pad_lo)
+    assert got is not None, "geometry should be covered"
+    tol = 1e-4 if dtype == torch.float32 else 1.5e-2
+    _close(_cf(got), want, tol, f"stride-2 dgrad {name}")
+    old = ops.conv(_cl(gy), w.to(DEV), None, kernel=3, stride=2, padding=pad_lo, pad_hi=1, transposed=True, output_padding=pad_lo)
+    _close(_cf(got), _cf(old).double(), tol, f"stride-2 dgrad {name} vs the transposed-convolution path")
+    xa = _cl(x).requires_grad_(True)
+    ya = ag.conv(xa, w.to(DEV), None, kernel=3, stride=2, padding=pad_lo, pad_hi=1)
+    ops.start_profile()
+    ya.backward(_cl(gy))
+    names = [nm for nm, _, _ in ops.stop_profile()]
+    assert any("cfg17" in nm for nm in names), names
+    _close(_cf(xa.grad), want, tol, f"autograd stride-2 dgrad {name}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", ["silu", "none"])
 @pytest.mark.parametrize("shape,groups", [((2, 64, 5, 6, 7), 32), ((1, 96, 9, 11), 8), ((3, 32, 4, 4, 4), 32)])
 def test_group_norm_backward(shape, groups, act, dtype):

@@ -27,7 +27,7 @@ def timeit(fn, reps=5, warm=2):
 
 def main():
     dtype = torch.bfloat16
-    shapes = [(64, 64, 128, 1), (128, 64, 128, 1), (128, 128, 64, 1), (256, 256, 32, 1), (64, 128, 128, 2), (32, 32, 32, 1)]
+    shapes = [(64, 64, 128, 1), (128, 64, 128, 1), (128, 128, 64, 1), (256, 256, 32, 1), (64, 128, 128, 2), (64, 64, 128, 2), (128, 128, 64, 2), (32, 32, 32, 1)]
     if len(sys.argv) > 1:
         shapes = shapes[: int(sys.argv[1])]
     out = []
@@ -41,10 +41,16 @@ def main():
         opad = size - ((so - 1) * stride - 2 + 3)
         t_d = timeit(lambda: ops.conv(gy, w, None, kernel=3, stride=stride, padding=1, transposed=True, output_padding=opad))
         t_f = timeit(lambda: ops.conv(x, w, None, kernel=3, stride=stride, padding=1))
+        t_d2 = None
+        if stride == 2:  # the path autograd takes: one sub-pixel launch on gy (ops.conv_stride2_dgrad); t_d above is the transposed-convolution path
+            t_d2 = timeit(lambda: ops.conv_stride2_dgrad(gy, w, (size, size, size), 1))
         rec = dict(op="conv3x3x3", cin=cin, cout=cout, size=size, stride=stride, gflop=round(flops / 1e9, 1),
                    fwd_ms=round(t_f, 3), fwd_tflops=round(flops / t_f / 1e9, 1),
                    dgrad_ms=round(t_d, 3), dgrad_tflops=round(flops / t_d / 1e9, 1),
                    wgrad_ms=round(t_w, 3), wgrad_tflops=round(flops / t_w / 1e9, 1))
+        if t_d2 is not None:
+            rec["dgrad_subpixel_ms"] = round(t_d2, 3)
+            rec["dgrad_subpixel_tflops"] = round(flops / t_d2 / 1e9, 1)
         if stride == 1:
             scale, shift = ops.gn_scale_shift_composed(x, 32, 1e-6, None, None)
             gx = torch.randn_like(x)
