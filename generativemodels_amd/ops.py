@@ -221,9 +221,15 @@ def packed_stride2_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype, pad_lo
     which 27/8 per output voxel on average carry weight (reference: torch autograd through nn.Conv3d(stride=2),
     diffusion_model_unet.py:510-518, autoencoderkl.py:107-121).  [Cout, Cin, 3, 3, 3] -> packed, rounded to `dtype`."""
     require_device(weight)
-    if pad_lo not in (0, 1):
-        raise ValueError("pad_lo must be 0 or 1")
-    taps = {1: {0: (None, 1), 1: (2, 0)}, 0: {0: (2, 0), 1: (1, None)}}[pad_lo]  # parity -> forward tap index at the (first, second) input
+    K = weight.shape[2]
+    if K not in (3, 4) or tuple(weight.shape[2:]) != (K, K, K) or not 0 <= pad_lo <= 1:
+        raise ValueError("stride-2 sub-pixel weights: kernel 3 or 4 (cubic), padding 0 or 1")
+    # As a transposed convolution with weight [C_in_t, C_out_t, K, K, K] (a forward weight [C_out, C_in, ...] IS its gradient's transposed weight):
+    # out[u] = sum x[o] W[k], u = 2 o - pad_lo + k.  Output parity pi reads the inputs i + delta, delta = (-1, 0) for pi = 0 and (0, +1) for
+    # pi = 1, through tap k = pi + pad_lo - 2 delta (when it exists): K = 4, pad 1 (the VQ-VAE up-sampling) uses all eight taps of every parity.
+    def tap(kk):
+        return kk if 0 <= kk < K else None
+    taps = {0: (tap(pad_lo + 2), tap(pad_lo)), 1: (tap(pad_lo + 1), tap(pad_lo - 1))}  # parity -> tap index at the (first, second) input
 
     def make():
         wt = weight.detach().float().transpose(0, 1)  # [Cin, Cout, 3, 3, 3]: the gradient maps Cout channels of dy to Cin channels of dx
@@ -793,6 +799,7 @@ def _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, c
 
 
 STRIDE2_DGRAD_SUBPIXEL = os.environ.get("GM_CONV_STRIDE2_DGRAD", "1") != "0"
+TRANSPOSED_S2_SUBPIXEL = os.environ.get("GM_CONV_TRANSPOSED_S2_SUBPIXEL", "1") != "0"
 
 
 def conv_stride2_dgrad(gy: torch.Tensor, weight: torch.Tensor, x_spatial: Sequence[int], pad_lo: int) -> Optional[torch.Tensor]:
@@ -907,6 +914,19 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             and cin % (64 // x.element_size()) == 0 and cout % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0
             and math.prod(src) * n >= DMA_CONV_MIN_VOXELS):
         got = _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, cin, cout, src)
+        if got is not None:
+            return got
+    if (transposed and TRANSPOSED_S2_SUBPIXEL and x2 is None and nsp == 3 and s == (2, 2, 2) and k in ((3, 3, 3), (4, 4, 4)) and dil == (1, 1, 1)
+            and plo[0] == plo[1] == plo[2] and plo[0] in (0, 1) and pre is None and pre_act == "none" and skip is None and force_cfg is None
+            and weight is not None and all((src[i] - 1) * 2 - plo[i] - phi[i] + k[i] + opad[i] == 2 * src[i] for i in range(3))
+            and cin % (64 // x.element_size()) == 0 and cout % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0
+            and math.prod(src) * n >= DMA_CONV_MIN_VOXELS):
+        # nn.ConvTranspose3d(stride 2) whose output is exactly twice the input (VQ-VAE up-sampling k = 4 / pad 1, the AutoencoderKL's optional
+        # ConvTranspose k = 3 / pad 1 / output_padding 1, the data gradient of the Downsample convolutions): 8 sub-pixel 2x2x2 convolutions,
+        # one launch of configuration 17 -- no zero-inserted operand, no gather
+        got = _conv_subpixel(x, weight, bias, rowvec, res, post_act, out, want_stats, n, cin, cout, src,
+                             packed=packed_stride2_dgrad_weight(weight, dtype, plo[0]),
+                             label=f"transposed k{k[0]} s2 as 8 sub-pixel 2x2x2 convolutions")
         if got is not None:
             return got
     d = GmConvDesc()

@@ -144,7 +144,11 @@ def test_stride2_data_gradient_as_sub_pixel_convolutions(case, dtype):
     assert got is not None, "geometry should be covered"
     tol = 1e-4 if dtype == torch.float32 else 1.5e-2
     _close(_cf(got), want, tol, f"stride-2 dgrad {name}")
-    old = ops.conv(_cl(gy), w.to(DEV), None, kernel=3, stride=2, padding=pad_lo, pad_hi=1, transposed=True, output_padding=pad_lo)
+    ops.TRANSPOSED_S2_SUBPIXEL = False  # the zero-insertion path this replaces
+    try:
+        old = ops.conv(_cl(gy), w.to(DEV), None, kernel=3, stride=2, padding=pad_lo, pad_hi=1, transposed=True, output_padding=pad_lo)
+    finally:
+        ops.TRANSPOSED_S2_SUBPIXEL = True
     _close(_cf(got), _cf(old).double(), tol, f"stride-2 dgrad {name} vs the transposed-convolution path")
     xa = _cl(x).requires_grad_(True)
     ya = ag.conv(xa, w.to(DEV), None, kernel=3, stride=2, padding=pad_lo, pad_hi=1)

@@ -831,6 +831,35 @@ def test_fused_output_statistics_and_virtual_concat_groupnorm(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("vqvae k4", 4, 1, 0, (6, 5, 18), 64, 96), ("aekl k3", 3, 1, 1, (4, 8, 16), 32, 64), ("k4 wide", 4, 1, 0, (8, 8, 8), 96, 32)],
+                         ids=lambda c: c[0])
+def test_transposed_stride2_conv_as_subpixel_convolutions(case, dtype):
+    """nn.ConvTranspose3d(stride 2) with an output of exactly twice the input -- the VQ-VAE up-sampling (k = 4, padding 1; vqvae.py:204-237)
+    and the AutoencoderKL's optional ConvTranspose (k = 3, padding 1, output_padding 1) -- evaluated as ONE launch of the sub-pixel kernel
+    (8 parity classes of 2x2x2 kernels picked from the transposed weight: every tap of every parity is a real weight for k = 4), with bias and
+    the ReLU epilogue, against torch in fp64 and against the gather-form transposed convolution it replaces."""
+    ops = _ops()
+    name, k, pad, opad, sp, cin, cout = case
+    n = 2
+    x = _rand((n, cin, *sp), 451).to(dtype)
+    w = (_rand((cin, cout, k, k, k), 452) / math.sqrt(cin * k ** 3 / 8)).to(dtype)
+    b = _rand((cout,), 453) * 0.1
+    want = F.relu(F.conv_transpose3d(x.double(), w.double(), b.double(), stride=2, padding=pad, output_padding=opad))
+    assert tuple(want.shape[2:]) == tuple(2 * v for v in sp)
+    ops.start_profile()
+    got = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=k, stride=2, padding=pad, transposed=True, output_padding=opad, post_act="relu")
+    names = [nm for nm, _, _ in ops.stop_profile()]
+    assert any("cfg17" in nm for nm in names), names
+    _check(_cf(got), want, dtype, f"transposed stride-2 conv {name}", extra=2.0)
+    ops.TRANSPOSED_S2_SUBPIXEL = False
+    try:
+        old = ops.conv(_cl(x), w.to(DEV), b.to(DEV), kernel=k, stride=2, padding=pad, transposed=True, output_padding=opad, post_act="relu")
+    finally:
+        ops.TRANSPOSED_S2_SUBPIXEL = True
+    _check(_cf(got), _cf(old).double(), dtype, f"sub-pixel vs gather-form transposed conv {name}", extra=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape,cin,cout", [((5, 6, 19), 32, 64), ((8, 8, 8), 64, 32), ((4, 9, 33), 128, 96)])
 def test_upsample_conv_as_subpixel_convolutions(shape, cin, cout, dtype):
     """Nearest-2x + 3x3x3 convolution evaluated as 8 sub-pixel 2x2x2 convolutions with pre-summed weights (in_mode 3, cfg 17: 8/27 of the
