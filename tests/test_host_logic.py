@@ -319,6 +319,42 @@ def test_transformer_state_dict_ordering_and_errors():
         m(torch.zeros((1, 4), dtype=torch.long))
 
 
+def test_tile_configuration_policy_of_the_lds_dma_convolutions():
+    """ops._choose_conv_cfg on descriptors only (no GPU): large prologue-free stride-1 3x3x3 convolutions take the 4-wave x 64-voxel tile
+    (cfg 14, the two-operand-set tap loop), a fused GroupNorm prologue or a grid below one wave of work-groups keeps cfg 11 (its
+    fused-prologue instantiation / split-K form), stride 2 takes cfg 15; GM_CONV_WIDE_WAVES=0 restores cfg 11 everywhere."""
+    from generativemodels_amd import _native as nat
+    from generativemodels_amd import ops
+
+    def desc(size, cin, cout, stride=1, pre=False):
+        d = nat.GmConvDesc()
+        out = size // stride
+        vals = dict(N=1, Cin=cin, Cout=cout, Ds=size, Hs=size, Ws=size, Do=out, Ho=out, Wo=out, kd=3, kh=3, kw=3, sd=stride, sh=stride, sw=stride,
+                    pd=1, ph=1, pw=1, dd=1, dh=1, dw=1, in_mode=0, fd=1, fh=1, fw=1, dtype=1, x_ld=cin, y_ld=cout)
+        for k, v in vals.items():
+            setattr(d, k, v)
+        d.x, d.y, d.w = 0x1000, 0x2000, 0x3000
+        if pre:
+            d.pre_scale, d.pre_shift, d.pre_act = 0x4000, 0x5000, 1
+        return d
+
+    def chosen(size, cin, cout, **kw):
+        d = desc(size, cin, cout, **kw)
+        ops._choose_conv_cfg(d, (size // kw.get("stride", 1)) ** 3, only=ops.DMA_CFGS)
+        return d.cfg
+
+    assert chosen(128, 64, 64) == 14 and chosen(64, 384, 128) == 14 and chosen(32, 256, 256) == 14   # >= 512 tiles x channel blocks
+    assert chosen(32, 64, 64) == 11 and chosen(16, 512, 512) == 11                                     # small grids: cfg 11 (+ split-K)
+    assert chosen(128, 64, 64, pre=True) == 11                                                         # fused prologue
+    assert chosen(128, 64, 64, stride=2) == 15
+    keep = ops.DMA_WIDE_WAVES
+    try:
+        ops.DMA_WIDE_WAVES = False
+        assert chosen(128, 64, 64) == 11
+    finally:
+        ops.DMA_WIDE_WAVES = keep
+
+
 def test_native_planners_accept_and_reject_geometries_without_a_gpu():
     """Host-side planning of the C-ABI library runs without a GPU: tile-configuration eligibility (gm_conv_lds_bytes: > 0 = bytes of LDS,
     -1 = configuration does not cover the geometry) for the LDS-DMA kernels incl. the sub-pixel up-sampling variant, and the weight-gradient
