@@ -211,6 +211,14 @@ def packed_subpixel_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Te
     return _cached(weight, ("subpixel", dtype), make)
 
 
+def stride2_subpixel_taps(K: int, pad: int) -> dict:
+    """Per axis: {output parity: (tap read at input i - 1 + parity, tap read at input i + parity)} of a stride-2 transposed convolution
+    out[u] = sum_o x[o] W[u + pad - 2 o] whose output is twice its input; None = no such tap (a zero weight).  Pure host logic (tested on CPU)."""
+    def tap(kk):
+        return kk if 0 <= kk < K else None
+    return {0: (tap(pad + 2), tap(pad)), 1: (tap(pad + 1), tap(pad - 1))}
+
+
 def packed_stride2_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype, pad_lo: int) -> torch.Tensor:
     """The data gradient of a stride-2 3x3x3 convolution as the 8 parity images of 2x2x2 kernels the sub-pixel kernel (configuration 17)
     consumes.  Forward: y[o] = sum_k W[k] x[2 o + k - pad_lo].  Gradient: dx[u] = sum_{o, k: 2 o + k - pad_lo = u} W[k]^T dy[o], i.e. per axis
@@ -227,9 +235,7 @@ def packed_stride2_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype, pad_lo
     # As a transposed convolution with weight [C_in_t, C_out_t, K, K, K] (a forward weight [C_out, C_in, ...] IS its gradient's transposed weight):
     # out[u] = sum x[o] W[k], u = 2 o - pad_lo + k.  Output parity pi reads the inputs i + delta, delta = (-1, 0) for pi = 0 and (0, +1) for
     # pi = 1, through tap k = pi + pad_lo - 2 delta (when it exists): K = 4, pad 1 (the VQ-VAE up-sampling) uses all eight taps of every parity.
-    def tap(kk):
-        return kk if 0 <= kk < K else None
-    taps = {0: (tap(pad_lo + 2), tap(pad_lo)), 1: (tap(pad_lo + 1), tap(pad_lo - 1))}  # parity -> tap index at the (first, second) input
+    taps = stride2_subpixel_taps(K, pad_lo)
 
     def make():
         wt = weight.detach().float().transpose(0, 1)  # [Cin, Cout, 3, 3, 3]: the gradient maps Cout channels of dy to Cin channels of dx

@@ -319,6 +319,33 @@ def test_transformer_state_dict_ordering_and_errors():
         m(torch.zeros((1, 4), dtype=torch.long))
 
 
+def test_stride2_subpixel_tap_tables_reproduce_a_transposed_convolution():
+    """ops.stride2_subpixel_taps (the per-parity 2-tap kernels behind the stride-2 data gradient and the VQ-VAE / AutoencoderKL transposed
+    convolutions) against a brute-force 1-D transposed convolution: out[2i + parity] = t0 * x[i - 1 + parity] + t1 * x[i + parity]."""
+    import numpy as np
+
+    from generativemodels_amd import ops
+
+    rng = np.random.default_rng(0)
+    for K, pad, opad in ((3, 1, 1), (3, 0, 0), (4, 1, 0)):
+        n = 7
+        x, w = rng.standard_normal(n), rng.standard_normal(K)
+        full = np.zeros(2 * n + K + 2)
+        for o in range(n):
+            for k in range(K):
+                full[2 * o + k] += x[o] * w[k]           # out[u + pad] with u = 2 o - pad + k
+        want = full[pad:pad + 2 * n]
+        assert (n - 1) * 2 - pad - 1 + K + opad == 2 * n  # (padding high = 1: the geometries the sub-pixel path accepts)
+        taps = ops.stride2_subpixel_taps(K, pad)
+        xp = np.concatenate([[0.0], x, [0.0]])            # zero rows outside the volume
+        got = np.zeros(2 * n)
+        for i in range(n):
+            for par in (0, 1):
+                t0, t1 = taps[par]
+                got[2 * i + par] = (0.0 if t0 is None else w[t0] * xp[i + par]) + (0.0 if t1 is None else w[t1] * xp[i + 1 + par])
+        assert np.allclose(got, want), (K, pad)
+
+
 def test_tile_configuration_policy_of_the_lds_dma_convolutions():
     """ops._choose_conv_cfg on descriptors only (no GPU): large prologue-free stride-1 3x3x3 convolutions take the 4-wave x 64-voxel tile
     (cfg 14, the two-operand-set tap loop), a fused GroupNorm prologue or a grid below one wave of work-groups keeps cfg 11 (its
