@@ -12,6 +12,16 @@ import sys
 
 __version__ = "0.1.0"
 
+
+def __getattr__(name):
+    # `generativemodels_amd.autocast(torch.bfloat16)`: fp32 master parameters, bf16 compute (ops.autocast); resolved lazily so that importing
+    # the package does not import torch
+    if name in ("autocast", "autocast_dtype"):
+        from . import ops
+
+        return getattr(ops, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
 _MIRRORED = ["", ".networks", ".networks.nets", ".networks.blocks", ".networks.blocks.spade_norm", ".networks.schedulers", ".networks.layers",
              ".inferers", ".utils"]
 

@@ -23,11 +23,26 @@ import torch
 
 from . import ops
 
-__all__ = ["conv", "conv_transpose", "sigma_from_log_var", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
+__all__ = ["cast", "scale", "conv", "conv_transpose", "sigma_from_log_var", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
 
 
 def _tup(v, n):
     return tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * n
+
+
+def _weight_grad(weight: torch.Tensor, shape, run):
+    """The weight gradient of one layer: `run(out, accumulate)` launches gm_conv_wgrad (fp32 [Cout, Cin, *k] result).  When the parameter's
+    `.grad` is a GradientReducer bucket view (fp32 master parameters: parallel.direct_grad_hook), the kernel's final reduction ADDS INTO IT
+    and the reducer's grad-ready hook is called here -- autograd gets None and launches no `add_` for this parameter; otherwise the fresh
+    tensor goes back to autograd in the parameter's dtype."""
+    from .parallel import direct_grad_hook
+
+    hook = direct_grad_hook(weight)
+    if hook is not None:
+        run(weight.grad.view(shape), True)
+        hook(weight)
+        return None
+    return run(None, False).reshape(weight.shape).to(weight.dtype)
 
 
 class _Conv(torch.autograd.Function):
@@ -62,7 +77,7 @@ class _Conv(torch.autograd.Function):
             if dx is None:
                 dx = ops.conv(gy, weight, None, kernel=k, stride=s, padding=p, pad_hi=phi, transposed=True, output_padding=opad)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(x, gy, k, s, p).reshape(weight.shape).to(weight.dtype)
+            dw = _weight_grad(weight, (weight.shape[0], weight.shape[1], *k), lambda out, acc: ops.conv_wgrad(x, gy, k, s, p, out=out, accumulate=acc))
         if ctx.needs_input_grad[2]:
             db = ops.bias_grad(gy).to(ctx.bias_dtype)
         if ctx.needs_input_grad[3]:
@@ -111,7 +126,9 @@ class _ConvTranspose(torch.autograd.Function):
             if dx.shape != x.shape:
                 raise ValueError(f"transposed-convolution geometry is not invertible: {tuple(dx.shape)} vs {tuple(x.shape)}")
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(gy, x, kernel, stride, padding).reshape(weight.shape).to(weight.dtype)
+            kt = _tup(kernel, x.dim() - 2)
+            dw = _weight_grad(weight, (weight.shape[0], weight.shape[1], *kt),
+                              lambda out, acc: ops.conv_wgrad(gy, x, kernel, stride, padding, out=out, accumulate=acc))
         if ctx.needs_input_grad[2]:
             db = ops.bias_grad(gy).to(ctx.bias_dtype)
         return dx, dw, db, None, None, None, None
@@ -231,7 +248,8 @@ class _UpsampleConv(torch.autograd.Function):
             du = ops.conv(gy, weight, None, kernel=3, stride=1, padding=1, transposed=True)  # gradient on the upsampled grid
             dx = ops.scale(ops.resample2x(du, "down"), float(2 ** nsp))                        # sum over each 2^d cell
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(ops.resample2x(x, "up"), gy, 3, 1, 1).reshape(weight.shape).to(weight.dtype)
+            xu = ops.resample2x(x, "up")
+            dw = _weight_grad(weight, tuple(weight.shape), lambda out, acc: ops.conv_wgrad(xu, gy, 3, 1, 1, out=out, accumulate=acc))
         if ctx.needs_input_grad[2]:
             db = ops.bias_grad(gy).to(ctx.bias_dtype)
         return dx, dw, db
@@ -439,17 +457,51 @@ class _Embedding(torch.autograd.Function):
     N gradient rows into a [num_classes, C] table -- left to torch (N rows)."""
 
     @staticmethod
-    def forward(ctx, labels, weight):
+    def forward(ctx, labels, weight, dtype):
         ctx.save_for_backward(labels)
         ctx.shape, ctx.dtype = weight.shape, weight.dtype
-        return ops.vq_gather(labels, weight, weight.dtype)
+        return ops.vq_gather(labels, weight, dtype or weight.dtype)
 
     @staticmethod
     def backward(ctx, g):
         (labels,) = ctx.saved_tensors
         dw = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device).index_add_(0, labels, g.float())
-        return None, dw.to(ctx.dtype)
+        return None, dw.to(ctx.dtype), None
 
 
-def embedding(labels: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    return _Embedding.apply(labels, weight)
+def embedding(labels: torch.Tensor, weight: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """weight[labels] in `dtype` (default: the table's); differentiable in the table."""
+    return _Embedding.apply(labels, weight, dtype)
+
+
+class _Scale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return ops.scale(x, s, False).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.scale(g.contiguous(), ctx.s, False).reshape(g.shape), None
+
+
+def scale(x: torch.Tensor, s: float) -> torch.Tensor:
+    """x * s (a Python scalar); differentiable in x."""
+    return x if s == 1.0 else _Scale.apply(x, float(s))
+
+
+class _Cast(torch.autograd.Function):
+    """dtype conversion of an activation (the entry of a network inside an ops.autocast region); the gradient is cast back."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.cast(g.contiguous(), ctx.src), None
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)

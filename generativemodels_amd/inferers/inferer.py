@@ -322,7 +322,10 @@ class _Controlled:
         self.diffusion_model, self.controlnet, self.cn_cond = _bind_seg(diffusion_model, seg), controlnet, cn_cond
 
     def supports_training(self) -> bool:
-        return False  # the ControlNet path is inference-only here: DiffusionInferer.__call__ then takes the no-grad forward
+        # DiffusionInferer.__call__ then simply calls this object; the two networks decide for themselves (`_blocks.wants_grad`): a ControlNet
+        # in train() mode returns differentiable residuals, and residuals that require grad put the (usually frozen) UNet on its
+        # differentiable forward -- the ControlNet training step of the reference's tutorials
+        return False
 
     def parameters(self):
         return iter(())

@@ -26,13 +26,34 @@ def ensure_tuple_rep(v, n: int) -> tuple:
     return (v,) * n
 
 
+_warned_eval_grad = False
+
+
 def wants_grad(module: nn.Module, x: torch.Tensor) -> bool:
-    """The reference's forward is differentiable whenever autograd records; here that costs a different (activation-saving) kernel
-    sequence, so it is taken when the caller is evidently training: train() mode (or an input that requires grad), gradients enabled
-    and at least one trainable parameter.  eval() / torch.no_grad() / frozen parameters run the fused inference path."""
-    if not torch.is_grad_enabled() or not (module.training or x.requires_grad):
+    """Which forward a network runs.  The reference's forward is differentiable whenever autograd records; here that costs a different
+    (activation-saving) kernel sequence, so the differentiable path is taken when gradients are enabled AND
+      * the input requires grad -- whatever the mode and even through frozen parameters: a pixel-space loss through a frozen decoder, latent
+        optimisation, a frozen UNet under ControlNet training all need d(output)/d(input) (dropping it silently would lose that loss term), or
+      * the module is in train() mode and has a trainable parameter.
+    eval() / torch.no_grad() / an input without grad through frozen parameters run the fused inference path.  The one case where this differs
+    observably from the reference -- eval() mode, gradients enabled, trainable parameters, input without grad: the output has no grad_fn --
+    warns once instead of detaching silently."""
+    if not torch.is_grad_enabled():
         return False
-    return any(p.requires_grad for p in module.parameters())
+    if x.requires_grad:
+        return True
+    trainable = any(p.requires_grad for p in module.parameters())
+    if module.training:
+        return trainable
+    global _warned_eval_grad
+    if trainable and not _warned_eval_grad:
+        _warned_eval_grad = True
+        import warnings
+
+        warnings.warn(f"{type(module).__name__}: forward in eval() mode with gradients enabled runs the fused inference path and returns a tensor "
+                      "without grad_fn (the differentiable forward is taken in train() mode, or when the input requires grad); wrap inference "
+                      "in torch.no_grad() to silence this", stacklevel=3)
+    return False
 
 
 def zero_module(module: nn.Module) -> nn.Module:

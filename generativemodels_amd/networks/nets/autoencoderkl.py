@@ -195,16 +195,21 @@ class AutoencoderKL(nn.Module):
     def _dtype(self):
         return self.post_quant_conv.conv.weight.dtype
 
-    def _check(self, x: torch.Tensor) -> None:
+    def _check(self, x: torch.Tensor) -> torch.Tensor:
+        """-> x in the compute dtype: the parameters' (the input must match), or the active autocast region's (ops.autocast: the input is cast --
+        differentiably when the differentiable path is taken)."""
         ops.require_device(x)
-        if x.dtype != self._dtype():
-            raise TypeError(f"input dtype {x.dtype} does not match the model dtype {self._dtype()}")
         if x.dim() != self.spatial_dims + 2:
             raise ValueError(f"expected a (N, C, *{self.spatial_dims} spatial dims) tensor, got {tuple(x.shape)}")
+        if ops.autocast_dtype() is not None and x.dtype != ops.autocast_dtype() and wants_grad(self, x):
+            from ... import autograd as A
+
+            return A.cast(x, ops.autocast_dtype())
+        return ops.entry_cast(x, self._dtype())
 
     def encode(self, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """-> (z_mu, z_sigma), sigma = exp(clamp(log_var, -30, 20) / 2) (reference autoencoderkl.py:718-736)."""
-        self._check(x)
+        x = self._check(x)
         if wants_grad(self, x):  # a training step: differentiable (z_mu, z_sigma), native kernels in both directions
             from ... import autograd as A
 
@@ -233,7 +238,7 @@ class AutoencoderKL(nn.Module):
 
     def decode(self, z: torch.Tensor) -> torch.Tensor:
         """post_quant_conv -> Decoder (reference autoencoderkl.py:769-784)."""
-        self._check(z)
+        z = self._check(z)
         if wants_grad(self, z):
             from ... import autograd as A
 

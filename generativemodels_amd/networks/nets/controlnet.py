@@ -11,8 +11,8 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ._blocks import _CONV, ConvP, ResnetBlock, ensure_tuple_rep, zero_module
-from .diffusion_model_unet import _MidBlock, _Stage, _TimestepPath
+from ._blocks import _CONV, ConvP, ResnetBlock, ensure_tuple_rep, wants_grad, zero_module
+from .diffusion_model_unet import _MidBlock, _Stage, _TimestepPath, _train_encoder, _train_entry, _train_timestep_embedding
 
 __all__ = ["ControlNet", "ControlNetConditioningEmbedding", "copy_weights_to_controlnet"]
 
@@ -36,8 +36,25 @@ class ControlNetConditioningEmbedding(nn.Module):
             e = blk.run(e, post_act="silu")
         return self.conv_out.run(e)
 
+    def run_train(self, cond: torch.Tensor) -> torch.Tensor:
+        """The same stack with gradients (arena in, arena out): convolution + SiLU as separate differentiable ops."""
+        from ... import autograd as A
+
+        def cv(blk, t):
+            c = blk.conv
+            return A.conv(t, c.weight, c.bias, kernel=3, stride=blk.strides, padding=1)
+
+        e = A.silu(cv(self.conv_in, cond))
+        for blk in self.blocks:
+            e = A.silu(cv(blk, e))
+        return cv(self.conv_out, e)
+
     def forward(self, conditioning: torch.Tensor) -> torch.Tensor:
         ops.require_device(conditioning)
+        if wants_grad(self, conditioning):
+            from ... import autograd as A
+
+            return A.from_arena(self.run_train(A.to_arena(conditioning)))
         with torch.no_grad():
             return ops.to_channels_first(self.run(ops.to_channels_last(conditioning)))
 
@@ -130,9 +147,11 @@ class ControlNet(_TimestepPath, nn.Module):
         if context is not None and self.with_conditioning is False:
             raise ValueError("model should have with_conditioning = True if context is provided")
         ops.require_device(x, controlnet_cond)
-        dtype = self.conv_in.conv.weight.dtype
-        if x.dtype != dtype or controlnet_cond.dtype != dtype:
-            raise TypeError(f"input dtypes {x.dtype} / {controlnet_cond.dtype} do not match the model dtype {dtype}")
+        if wants_grad(self, x) or (torch.is_grad_enabled() and controlnet_cond.requires_grad):
+            return self.forward_train(x, timesteps, controlnet_cond, conditioning_scale, context, class_labels)
+        x = ops.entry_cast(x, self.conv_in.conv.weight.dtype, "input")
+        controlnet_cond = ops.entry_cast(controlnet_cond, self.conv_in.conv.weight.dtype, "conditioning image")
+        dtype = x.dtype
         with torch.no_grad():
             rows = self._temb_rows(timesteps.to(x.device), class_labels)
             if context is not None:
@@ -164,3 +183,34 @@ class ControlNet(_TimestepPath, nn.Module):
             down = tuple(ops.to_channels_first(zero_conv(blk, s)) for s, blk in zip(skips, self.controlnet_down_blocks))
             mid = ops.to_channels_first(zero_conv(self.controlnet_mid_block, h))
             return down, mid
+
+    def forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, controlnet_cond: torch.Tensor, conditioning_scale: float = 1.0,
+                      context: torch.Tensor | None = None, class_labels: torch.Tensor | None = None):
+        """`forward` with gradients (reference: torch autograd through controlnet.py:367-436 -- the ControlNet tutorials train this network
+        against a frozen DiffusionModelUNet): the conditioning embedding, the UNet encoder half it shares with DiffusionModelUNet
+        (`_train_encoder`) and the zero convolutions, native kernels in both directions (generativemodels_amd.autograd).  Returns the
+        differentiable (down-block residuals, mid-block residual) that DiffusionModelUNet.forward takes."""
+        from ... import autograd as A
+
+        if context is not None and self.with_conditioning is False:
+            raise ValueError("model should have with_conditioning = True if context is provided")
+        x, dtype = _train_entry(self, x)
+        controlnet_cond, _ = _train_entry(self, controlnet_cond, "conditioning image")
+        emb = _train_timestep_embedding(self, timesteps, class_labels, dtype, x.device, x.shape[0])
+        if context is not None:
+            ops.require_device(context)
+            context = ops.cast(context.contiguous(), dtype)
+        ce = self.controlnet_cond_embedding.run_train(A.to_arena(controlnet_cond))
+        ci = self.conv_in.conv
+        h = A.conv(A.to_arena(x), ci.weight, ci.bias, kernel=3, stride=1, padding=1, res=ce)
+        skips, h = _train_encoder(self, h, emb, context)
+
+        def zero_conv(blk, t):
+            conv = blk.conv if isinstance(blk, ConvP) else blk
+            return A.from_arena(A.scale(A.conv(t, conv.weight, conv.bias, kernel=1), float(conditioning_scale)))
+
+        down = tuple(zero_conv(blk, s) for s, blk in zip(skips, self.controlnet_down_blocks))
+        return down, zero_conv(self.controlnet_mid_block, h)
+
+    def supports_training(self) -> bool:
+        return True

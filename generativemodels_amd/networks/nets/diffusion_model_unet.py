@@ -358,13 +358,14 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
                 class_labels: torch.Tensor | None = None, down_block_additional_residuals: tuple[torch.Tensor] | None = None,
                 mid_block_additional_residual: torch.Tensor | None = None) -> torch.Tensor:
         """x: (N, C, *spatial); timesteps: (N,) or (1,); context: (N, L_ctx, cross_attention_dim). Returns (N, C_out, *spatial).
-        A module in train() mode called with gradients enabled returns a differentiable prediction (forward_train); everything else --
-        eval(), torch.no_grad(), frozen parameters -- runs the fused inference path and returns a tensor without grad_fn."""
-        if self._wants_grad(x):
-            if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
-                raise NotImplementedError("DiffusionModelUNet: the training forward does not take ControlNet residuals (inference-only); "
-                                          "call under torch.no_grad() or in eval() mode")
-            return self.forward_train(x, timesteps, context=context, class_labels=class_labels)
+        A module in train() mode called with gradients enabled -- or any call whose input (or ControlNet residuals) requires grad -- returns
+        a differentiable prediction (forward_train); eval() / torch.no_grad() run the fused inference path (`_blocks.wants_grad`)."""
+        residuals = list(down_block_additional_residuals or ()) + ([] if mid_block_additional_residual is None else [mid_block_additional_residual])
+        if self._wants_grad(x) or (self.supports_training() and torch.is_grad_enabled() and any(r.requires_grad for r in residuals)):
+            # (ControlNet residuals that require grad: a ControlNet training against this -- usually frozen -- network)
+            return self.forward_train(x, timesteps, context=context, class_labels=class_labels,
+                                      down_block_additional_residuals=down_block_additional_residuals,
+                                      mid_block_additional_residual=mid_block_additional_residual)
         return self._forward_impl(x, timesteps, context, class_labels, down_block_additional_residuals, mid_block_additional_residual)
 
     def _wants_grad(self, x: torch.Tensor) -> bool:
@@ -381,9 +382,8 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
         if context is not None and self.with_conditioning is False:
             raise ValueError("model should have with_conditioning = True if context is provided")
         ops.require_device(x)
-        dtype = self.conv_in.conv.weight.dtype
-        if x.dtype != dtype:
-            raise TypeError(f"input dtype {x.dtype} does not match the model dtype {dtype}")
+        x = ops.entry_cast(x, self.conv_in.conv.weight.dtype)  # the compute dtype: the parameters', or the active autocast region's
+        dtype = x.dtype
         if x.shape[1] != self.in_channels or x.dim() != self.spatial_dims + 2:
             raise ValueError(f"expected input of shape (N, {self.in_channels}, *{self.spatial_dims} spatial dims), got {tuple(x.shape)}")
         if timesteps.shape[0] not in (1, x.shape[0]):
@@ -442,13 +442,83 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
             return ops.to_channels_first(y)
 
 
+def _train_timestep_embedding(self, timesteps: torch.Tensor, class_labels, dtype, device, batch: int):
+    """[B_t, 4 C0] timestep (+ class) embedding with gradients: the head of DiffusionModelUNet / ControlNet training forwards
+    (reference diffusion_model_unet.py:1888-1902, controlnet.py:386-400)."""
+    from ... import autograd as A
+
+    if timesteps.ndim != 1 or timesteps.shape[0] not in (1, batch):
+        raise ValueError("timesteps must be 1-D with one entry, or one per batch element")
+    t_emb = ops.timestep_embedding(timesteps.to(device), self.block_out_channels[0], dtype=dtype)
+    l0, l2 = self.time_embed[0], self.time_embed[2]
+    emb = A.linear(A.silu(A.linear(t_emb[None], l0.weight, l0.bias)), l2.weight, l2.bias)[0]  # [B_t, 4 C0]
+    if self.num_class_embeds is not None:
+        if class_labels is None:
+            raise ValueError("class_labels should be provided when num_class_embeds > 0")
+        ce = A.embedding(class_labels.to(device), self.class_embedding.weight, dtype)
+        if ce.shape[0] != emb.shape[0]:
+            raise ValueError("class_labels and timesteps must have the same batch size")
+        emb = A.add(emb[None], ce[None])[0]
+    return emb
+
+
+def _train_resample(blk, h, emb):
+    from ... import autograd as A
+
+    if isinstance(blk, ResnetBlock):
+        return blk.run_train(h, emb)
+    if isinstance(blk, _Downsample):
+        c = blk.op
+        return A.conv(h, c.conv.weight, c.conv.bias, kernel=3, stride=2, padding=c.padding)
+    return A.upsample_conv(h, blk.conv.conv.weight, blk.conv.conv.bias)
+
+
+def _train_attend(blk, h, context):
+    return blk.run_train(h, context) if isinstance(blk, SpatialTransformer) else blk.run_train(h)
+
+
+def _train_encoder(self, h: torch.Tensor, emb: torch.Tensor, context):
+    """conv_in output -> (skip list, mid-block output), with gradients: the half DiffusionModelUNet and ControlNet share
+    (reference diffusion_model_unet.py:1905-1925, controlnet.py:404-425)."""
+    skips = [h]
+    for st in self.down_blocks:
+        for j, rb in enumerate(st.resnets):
+            h = rb.run_train(h, emb)
+            if st.attentions is not None:
+                h = _train_attend(st.attentions[j], h, context)
+            skips.append(h)
+        if st.resampler_name == "downsampler":
+            h = _train_resample(st.downsampler, h, emb)
+            skips.append(h)
+    mb = self.middle_block
+    h = mb.resnet_2.run_train(_train_attend(mb.attention, mb.resnet_1.run_train(h, emb), context), emb)
+    return skips, h
+
+
+def _train_entry(self, x: torch.Tensor, what: str = "input"):
+    """-> (x in the compute dtype, compute dtype): mixed precision (ops.autocast: fp32 master parameters, bf16 activations / MFMA operands, fp32
+    parameter gradients) casts the input at the entry like autocast's first convolution would -- differentiably when it requires grad."""
+    from ... import autograd as A
+
+    ops.require_device(x)
+    pdtype = self.conv_in.conv.weight.dtype
+    dtype = ops.compute_dtype(pdtype)
+    if x.dtype != dtype:
+        if ops.autocast_dtype() is None:
+            raise TypeError(f"{what} dtype {x.dtype} does not match the model dtype {pdtype}")
+        x = A.cast(x, dtype)
+    return x, dtype
+
+
 def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor | None = None,
-                   class_labels: torch.Tensor | None = None) -> torch.Tensor:
+                   class_labels: torch.Tensor | None = None, down_block_additional_residuals: tuple[torch.Tensor] | None = None,
+                   mid_block_additional_residual: torch.Tensor | None = None) -> torch.Tensor:
     """DiffusionModelUNet.forward with gradients (the reference's training step differentiates the same
     forward through torch autograd: ddpm_training_ddp.py:249-270).  Every layer runs native kernels in both directions
     (generativemodels_amd.autograd).  Covered: every DiffusionModelUNet configuration -- AttentionBlock or SpatialTransformer levels
     (cross-attention on `context`, LayerNorm / GEGLU backward kernels), class embeddings, strided-convolution / nearest + convolution or
-    resblock_updown resampling.  ControlNet residuals and the SPADE variant are inference-only."""
+    resblock_updown resampling, and the ControlNet residual hooks (diffusion_model_unet.py:1917-1932: gradients flow into the residuals, so a
+    ControlNet trains against a frozen UNet).  The SPADE variant is inference-only."""
     from ... import autograd as A
 
     if self._spade is not None:
@@ -460,56 +530,28 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, context: torc
         raise ValueError("model should have with_conditioning = True if context is provided")
     if timesteps.ndim != 1 or timesteps.shape[0] not in (1, x.shape[0]):
         raise ValueError("timesteps must be 1-D with one entry, or one per batch element")
-    ops.require_device(x)
-    dtype = self.conv_in.conv.weight.dtype
-    if x.dtype != dtype:
-        raise TypeError(f"input dtype {x.dtype} does not match the model dtype {dtype}")
-    t_emb = ops.timestep_embedding(timesteps.to(x.device), self.block_out_channels[0], dtype=dtype)
-    l0, l2 = self.time_embed[0], self.time_embed[2]
-    emb = A.linear(A.silu(A.linear(t_emb[None], l0.weight, l0.bias)), l2.weight, l2.bias)[0]  # [B_t, 4 C0]
-    if self.num_class_embeds is not None:
-        if class_labels is None:
-            raise ValueError("class_labels should be provided when num_class_embeds > 0")
-        ce = A.embedding(class_labels.to(x.device), self.class_embedding.weight)
-        if ce.shape[0] != emb.shape[0]:
-            raise ValueError("class_labels and timesteps must have the same batch size")
-        emb = A.add(emb[None], ce[None])[0]
+    x, dtype = _train_entry(self, x)
+    emb = _train_timestep_embedding(self, timesteps, class_labels, dtype, x.device, x.shape[0])
     if context is not None:
         ops.require_device(context)
         context = ops.cast(context.contiguous(), dtype)
 
-    def attend(blk, h):
-        return blk.run_train(h, context) if isinstance(blk, SpatialTransformer) else blk.run_train(h)
-
-    def resample(blk, h):
-        if isinstance(blk, ResnetBlock):
-            return blk.run_train(h, emb)
-        if isinstance(blk, _Downsample):
-            c = blk.op
-            return A.conv(h, c.conv.weight, c.conv.bias, kernel=3, stride=2, padding=c.padding)
-        return A.upsample_conv(h, blk.conv.conv.weight, blk.conv.conv.bias)
-
     ci = self.conv_in
     h = A.conv(A.to_arena(x), ci.conv.weight, ci.conv.bias, kernel=3, stride=1, padding=1)
-    skips = [h]
-    for st in self.down_blocks:
-        for j, rb in enumerate(st.resnets):
-            h = rb.run_train(h, emb)
-            if st.attentions is not None:
-                h = attend(st.attentions[j], h)
-            skips.append(h)
-        if st.resampler_name == "downsampler":
-            h = resample(st.downsampler, h)
-            skips.append(h)
-    mb = self.middle_block
-    h = mb.resnet_2.run_train(attend(mb.attention, mb.resnet_1.run_train(h, emb)), emb)
+    skips, h = _train_encoder(self, h, emb, context)
+    if down_block_additional_residuals is not None:
+        if len(down_block_additional_residuals) != len(skips):
+            raise ValueError(f"expected {len(skips)} down-block residuals, got {len(down_block_additional_residuals)}")
+        skips = [A.add(s, A.to_arena(A.cast(r, dtype))) for s, r in zip(skips, down_block_additional_residuals)]
+    if mid_block_additional_residual is not None:
+        h = A.add(h, A.to_arena(A.cast(mid_block_additional_residual, dtype)))
     for st in self.up_blocks:
         for j, rb in enumerate(st.resnets):
             h = rb.run_train(A.cat(h, skips.pop()), emb)
             if st.attentions is not None:
-                h = attend(st.attentions[j], h)
+                h = _train_attend(st.attentions[j], h, context)
         if st.resampler_name == "upsampler":
-            h = resample(st.upsampler, h)
+            h = _train_resample(st.upsampler, h, emb)
     n = self.out[0]
     h = A.group_norm_act(h, n.weight, n.bias, n.num_groups, n.eps, "silu")
     co = self.out[2]

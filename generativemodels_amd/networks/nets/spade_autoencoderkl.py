@@ -46,8 +46,8 @@ class SPADEAutoencoderKL(AutoencoderKL):
 
     def decode(self, z: torch.Tensor, seg: torch.Tensor) -> torch.Tensor:
         """post_quant_conv -> SPADEDecoder (reference spade_autoencoderkl.py:457-469)."""
-        self._check(z)
-        with torch.no_grad():
+        with torch.no_grad():  # (the SPADE decoder is inference-only)
+            z = self._check(z)
             h = self.post_quant_conv.run(ops.to_channels_last(z))
             return ops.to_channels_first(self.decoder.run(h, self._seg(seg, z)))
 

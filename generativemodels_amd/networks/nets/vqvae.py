@@ -147,14 +147,16 @@ class VQVAE(nn.Module):
         self.quantizer = VectorQuantizer(quantizer=EMAQuantizer(spatial_dims, num_embeddings, embedding_dim, commitment_cost,
                                                                 decay, epsilon, embedding_init, ddp_sync))
 
-    def _check(self, x: torch.Tensor) -> None:
+    def _dtype(self) -> torch.dtype:
+        return self.encoder.blocks[0].conv.weight.dtype
+
+    def _check(self, x: torch.Tensor) -> torch.Tensor:
+        """-> x in the compute dtype: the parameters' (the input must match), or the active ops.autocast region's (the input is cast)."""
         ops.require_device(x)
-        want = self.encoder.blocks[0].conv.weight.dtype
-        if x.dtype != want:
-            raise TypeError(f"input dtype {x.dtype} does not match the model dtype {want}")
+        return ops.entry_cast(x, self._dtype())
 
     def encode(self, images: torch.Tensor) -> torch.Tensor:
-        self._check(images)
+        images = self._check(images)
         with torch.no_grad():
             return ops.to_channels_first(self.encoder.run(ops.to_channels_last(images)))
 
@@ -163,19 +165,19 @@ class VQVAE(nn.Module):
         return x, x_loss
 
     def decode(self, quantizations: torch.Tensor) -> torch.Tensor:
-        self._check(quantizations)
+        quantizations = self._check(quantizations)
         with torch.no_grad():
             return ops.to_channels_first(self.decoder.run(ops.to_channels_last(quantizations)))
 
     def index_quantize(self, images: torch.Tensor) -> torch.Tensor:
-        self._check(images)
+        images = self._check(images)
         with torch.no_grad():  # encoder output stays in the arena: no layout round trip before the code search
             return self.quantizer.quantizer.indices_of(self.encoder.run(ops.to_channels_last(images)))
 
     def decode_samples(self, embedding_indices: torch.Tensor) -> torch.Tensor:
         ops.require_device(embedding_indices)
         with torch.no_grad():
-            q = self.quantizer.quantizer.lookup(embedding_indices, self.encoder.blocks[0].conv.weight.dtype)
+            q = self.quantizer.quantizer.lookup(embedding_indices, ops.compute_dtype(self._dtype()))
             return ops.to_channels_first(self.decoder.run(q))
 
     def forward(self, images: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:

@@ -101,12 +101,14 @@ class Scheduler(nn.Module):
     def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
         """sqrt(abar_t) * x0 + sqrt(1 - abar_t) * eps, one timestep per sample (reference scheduler.py:169-189)."""
         ops.require_device(original_samples, noise)
+        original_samples, noise = _promote(original_samples, noise)
         a, b = self._mix_coefficients(timesteps, original_samples.device, original_samples.dtype)
         return ops.axpby_rows(original_samples, noise, a, b)
 
     def get_velocity(self, sample: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
         """sqrt(abar_t) * eps - sqrt(1 - abar_t) * x (reference scheduler.py:191-200)."""
         ops.require_device(sample, noise)
+        sample, noise = _promote(sample, noise)
         a, b = self._mix_coefficients(timesteps, sample.device, sample.dtype)
         return ops.axpby_rows(noise, sample, a, -b)
 
@@ -117,6 +119,15 @@ class Scheduler(nn.Module):
     @staticmethod
     def _f(x) -> float:
         return float(x.item()) if torch.is_tensor(x) else float(x)
+
+
+def _promote(a: torch.Tensor, b: torch.Tensor):
+    """Operands of a mixing op in their promoted dtype, as torch's type promotion gives the reference (a bf16 latent of an autocast'ed
+    auto-encoder mixed with fp32 noise is an fp32 result: scheduler.py:186-189)."""
+    if a.dtype == b.dtype:
+        return a, b
+    dt = torch.promote_types(a.dtype, b.dtype)
+    return ops.cast(a, dt), ops.cast(b, dt)
 
 
 def x0_prediction_code(prediction_type: str) -> int:

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 import weakref
 from typing import Optional, Sequence
 
@@ -30,6 +31,66 @@ def dt_code(dtype: torch.dtype) -> int:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- mixed precision: fp32 master parameters, bf16 compute -------------------------------------------------------------------------------
+# The reference's training loops keep fp32 parameters and run the forward under torch.autocast + GradScaler
+# (tutorials/generative/distributed_training/ddpm_training_ddp.py:129,253-270; generative/engines/trainer.py:155-156,258).  torch.autocast wraps
+# torch ops and cannot see a ctypes kernel, so the switch is explicit: inside `with generativemodels_amd.autocast(torch.bfloat16):` -- or inside
+# a `torch.autocast("cuda", dtype=torch.bfloat16)` region, which is honoured too -- a network casts its input to the compute dtype at its
+# entry, every activation is stored in it, the MFMA panels are packed from the fp32 parameters once per parameter version
+# (gm_pack_conv_weight converts while packing: packed_conv_weight), GroupNorm / bias / timestep vectors are read in fp32 as always, and the
+# weight / bias / affine gradients come back in fp32 -- the dtype of the parameters -- so the optimizer steps the fp32 master copy.
+_AUTOCAST = threading.local()
+
+
+class autocast:
+    """Context manager: run the networks of this package with `dtype` activations / MFMA operands over parameters kept in their own
+    (fp32) dtype.  Re-entrant and thread-local; `enabled=False` switches an enclosing region (this one or torch.autocast's) off."""
+
+    def __init__(self, dtype: torch.dtype = torch.bfloat16, enabled: bool = True) -> None:
+        if enabled:
+            dt_code(dtype)  # fp32 / bf16 only
+        self.dtype, self.enabled = dtype, enabled
+
+    def __enter__(self):
+        stack = getattr(_AUTOCAST, "stack", None)
+        if stack is None:
+            stack = _AUTOCAST.stack = []
+        stack.append(self.dtype if self.enabled else False)
+        return self
+
+    def __exit__(self, *exc):
+        _AUTOCAST.stack.pop()
+        return False
+
+
+def autocast_dtype() -> Optional[torch.dtype]:
+    """The active mixed-precision compute dtype, or None: the innermost generativemodels_amd.autocast region, else torch.autocast("cuda")."""
+    stack = getattr(_AUTOCAST, "stack", None)
+    if stack:
+        return stack[-1] or None
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        dt_code(dt)  # torch.autocast defaults to float16 on "cuda": not a dtype of these kernels -- say so instead of computing in another one
+        return dt
+    return None
+
+
+def compute_dtype(param_dtype: torch.dtype) -> torch.dtype:
+    """dtype a network computes in: the autocast dtype when a region is active, else the dtype of its parameters."""
+    return autocast_dtype() or param_dtype
+
+
+def entry_cast(x: torch.Tensor, param_dtype: torch.dtype, what: str = "input") -> torch.Tensor:
+    """A network's input in its compute dtype.  Outside an autocast region the input must already have the parameters' dtype (as before);
+    inside one it is cast (not differentiable: the differentiable form is autograd.cast)."""
+    ac = autocast_dtype()
+    if ac is None:
+        if x.dtype != param_dtype:
+            raise TypeError(f"{what} dtype {x.dtype} does not match the model dtype {param_dtype}")
+        return x
+    return x if x.dtype == ac else cast(x, ac)
 
 
 def require_device(*ts: Optional[torch.Tensor]) -> None:
@@ -219,6 +280,13 @@ def stride2_subpixel_taps(K: int, pad: int) -> dict:
     return {0: (tap(pad + 2), tap(pad)), 1: (tap(pad + 1), tap(pad - 1))}
 
 
+def stride2_subpixel_covers(K: int, pad: int) -> bool:
+    """True when EVERY tap of a stride-2 transposed convolution with kernel K and low padding `pad` is one of the two taps per parity the
+    sub-pixel kernel reads (stride2_subpixel_taps): taps pad - 1 .. pad + 2.  K = 4 with pad = 0 is not: for odd outputs tap W[3] belongs to
+    input i - 1, which parity 1 does not read -- the tap would be dropped silently."""
+    return K in (3, 4) and 0 <= pad <= 1 and K <= pad + 3
+
+
 def packed_stride2_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype, pad_lo: int) -> torch.Tensor:
     """The data gradient of a stride-2 3x3x3 convolution as the 8 parity images of 2x2x2 kernels the sub-pixel kernel (configuration 17)
     consumes.  Forward: y[o] = sum_k W[k] x[2 o + k - pad_lo].  Gradient: dx[u] = sum_{o, k: 2 o + k - pad_lo = u} W[k]^T dy[o], i.e. per axis
@@ -228,10 +296,10 @@ def packed_stride2_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype, pad_lo
     taps per axis, so a stride-2 data gradient is one launch of it on dy with these weights: no zero-insertion, 8 of 8 MFMA taps issued of
     which 27/8 per output voxel on average carry weight (reference: torch autograd through nn.Conv3d(stride=2),
     diffusion_model_unet.py:510-518, autoencoderkl.py:107-121).  [Cout, Cin, 3, 3, 3] -> packed, rounded to `dtype`."""
-    require_device(weight)
     K = weight.shape[2]
-    if K not in (3, 4) or tuple(weight.shape[2:]) != (K, K, K) or not 0 <= pad_lo <= 1:
-        raise ValueError("stride-2 sub-pixel weights: kernel 3 or 4 (cubic), padding 0 or 1")
+    if tuple(weight.shape[2:]) != (K, K, K) or not stride2_subpixel_covers(K, pad_lo):
+        raise ValueError("stride-2 sub-pixel weights: cubic kernel 3 (padding 0 or 1) or 4 (padding 1): every tap within pad - 1 .. pad + 2")
+    require_device(weight)
     # As a transposed convolution with weight [C_in_t, C_out_t, K, K, K] (a forward weight [C_out, C_in, ...] IS its gradient's transposed weight):
     # out[u] = sum x[o] W[k], u = 2 o - pad_lo + k.  Output parity pi reads the inputs i + delta, delta = (-1, 0) for pi = 0 and (0, +1) for
     # pi = 1, through tap k = pi + pad_lo - 2 delta (when it exists): K = 4, pad 1 (the VQ-VAE up-sampling) uses all eight taps of every parity.
@@ -536,6 +604,8 @@ def _fresh_channel_stats(x: torch.Tensor) -> torch.Tensor:
     require_device(x)
     n, c = x.shape[0], x.shape[-1]
     v = rows_of(x) // max(n, 1)
+    if v == 0 or n == 0:  # an empty tensor: the kernel launches nothing, so the (otherwise uninitialised) table is zeros by construction
+        return torch.zeros((1, n, c, 2), dtype=torch.float64, device=x.device)
     slots = lib().gm_gn_channel_stats_slots(x.data_ptr(), arena_ld(x), v, c, dt_code(x.dtype))
     if slots <= 0:
         raise ValueError(f"per-channel statistics over {c} channels are not supported by the gfx950 kernel")
@@ -923,7 +993,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
         if got is not None:
             return got
     if (transposed and TRANSPOSED_S2_SUBPIXEL and x2 is None and nsp == 3 and s == (2, 2, 2) and k in ((3, 3, 3), (4, 4, 4)) and dil == (1, 1, 1)
-            and plo[0] == plo[1] == plo[2] and plo[0] in (0, 1) and pre is None and pre_act == "none" and skip is None and force_cfg is None
+            and plo[0] == plo[1] == plo[2] and stride2_subpixel_covers(k[0], plo[0]) and pre is None and pre_act == "none" and skip is None and force_cfg is None
             and weight is not None and all((src[i] - 1) * 2 - plo[i] - phi[i] + k[i] + opad[i] == 2 * src[i] for i in range(3))
             and cin % (64 // x.element_size()) == 0 and cout % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0
             and math.prod(src) * n >= DMA_CONV_MIN_VOXELS):
@@ -1139,10 +1209,17 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, kernel, stride=1, padding=0, o
             z = torch.zeros((*t.shape[:-1], cp), dtype=t.dtype, device=t.device)
             copy_channels(t, z[..., :t.shape[-1]])
             return z
-        if out is not None or accumulate:
-            raise ValueError("conv_wgrad: out / accumulate need channel counts that are multiples of a 16-byte vector")
+        if accumulate and out is None:
+            raise ValueError("accumulate needs an existing gradient tensor")
         full = conv_wgrad(padded(x), padded(gy), kernel, stride, padding)
-        return full[:gy.shape[-1], :x.shape[-1]].contiguous()
+        res = full[:gy.shape[-1], :x.shape[-1]].contiguous()
+        if out is None:
+            return res
+        if tuple(out.shape) != tuple(res.shape) or out.dtype != torch.float32:
+            raise ValueError("conv_wgrad: out must be a contiguous fp32 [Cout, Cin, *kernel] tensor")
+        with torch.no_grad():  # (the two edge convolutions of a network: a few thousand elements)
+            out.add_(res) if accumulate else out.copy_(res)
+        return out
     cin, cout = x.shape[-1], gy.shape[-1]
     d = GmWgradDesc()
     d.x, d.x_ld, d.gy, d.gy_ld = x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy)

@@ -73,6 +73,26 @@ def gather_units(ids: List[int], outs: List[torch.Tensor], n_units: int, group=N
     return [table[i] for i in range(n_units)]
 
 
+# Parameters whose weight-gradient kernels may ACCUMULATE STRAIGHT INTO `.grad` (a GradientReducer's persistent bucket view) instead of
+# returning a fresh tensor for autograd's AccumulateGrad node to add in -- one `add_` launch per parameter and step otherwise, which is what
+# a launch-bound backward (the 41.7 M-parameter latent UNet on 32^3 latents: 320 parameters) pays for having its gradients live in buckets.
+# id(param) -> callable(param): the reducer's grad-ready hook, called by the backward function after its kernel has been enqueued.
+_DIRECT_GRAD: dict = {}
+
+
+def direct_grad_hook(param: torch.Tensor):
+    """The callback to run after a backward kernel has accumulated `param`'s gradient in place into `param.grad`, or None when the parameter's
+    gradient must be returned to autograd as usual (no reducer, `.grad` not an fp32 bucket view, inside `no_sync()` bookkeeping is the same)."""
+    ent = _DIRECT_GRAD.get(id(param))
+    if ent is None:
+        return None
+    ref, view_ptr, hook = ent
+    g = param.grad
+    if ref() is not param or g is None or g.dtype != torch.float32 or g.data_ptr() != view_ptr:
+        return None
+    return hook
+
+
 class GradientReducer:
     """Batch-sharded data-parallel training (BASELINE config C4): every rank holds a replica, runs forward / backward on
     its own shard of the batch, and the gradients are averaged with ONE exchange per step -- a bucketed all-reduce over
@@ -98,8 +118,14 @@ class GradientReducer:
     With world_size 1 (or torch.distributed uninitialised) every call is a no-op unless `force=True` (single-rank exercise of the whole
     path: the `-m gpu` test runs it on backend nccl = RCCL with one rank)."""
 
-    def __init__(self, params, bucket_mb: float = 25.0, group=None, force: bool = False) -> None:
+    def __init__(self, params, bucket_mb: float = 25.0, group=None, force: bool = False, usage_check_every: int = 1) -> None:
+        """usage_check_every: 1 (default) = DDP's find_unused_parameters semantics exactly, the usage mask is exchanged and read every step
+        (one host synchronisation per step); k > 1 = only every k-th step after the first (a late-joining parameter starts training up to
+        k - 1 steps late, identically on every rank)."""
         import torch.distributed as dist
+
+        self.usage_check_every = int(usage_check_every)
+        self._step = 0
 
         self._dist = dist
         self.group = group
@@ -136,8 +162,12 @@ class GradientReducer:
                 for p in b:
                     self._view[id(p)] = flat[off:off + p.numel()].view_as(p)
                     off += p.numel()
+            import weakref
+
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+                if p.dtype == torch.float32:  # fp32 master parameters (mixed precision): the weight-gradient kernels write fp32
+                    _DIRECT_GRAD[id(p)] = (weakref.ref(p), self._view[id(p)].data_ptr(), self._on_grad)
         # parameters waited for before a bucket launches: all of them until the first step has shown which ones ever get a gradient
         self._expected = [True] * len(self.params)
         self._learned = False
@@ -154,14 +184,18 @@ class GradientReducer:
         self._in_backward_launches = 0
 
     def zero_grad(self) -> None:
-        """Zero every gradient with one fill per bucket and keep `.grad` pointing into the buckets (the cheap path; an optimizer's
-        zero_grad(set_to_none=True) also works -- the next gradient is then copied back into its view)."""
+        """Zero every gradient with one fill per bucket and make `.grad` of every expected parameter its bucket view BEFORE backward: autograd
+        (or, for fp32 parameters, the weight-gradient kernel itself: `direct_grad_hook`) then accumulates in place and no gradient is ever
+        copied into a bucket.  An optimizer's zero_grad(set_to_none=True) also works -- the next gradient is then copied into its view on arrival."""
         if not self.active:
             for p in self.params:
                 p.grad = None
             return
         for flat in self._flat:
             flat.zero_()
+        for j, p in enumerate(self.params):
+            if self._expected[j] and self._learned:  # (before the first step nobody knows which parameters ever get a gradient: a view installed
+                p.grad = self._view[id(p)]           #  on a never-used one would make the optimizer step it with zeros -- DDP leaves it None)
 
     def no_sync(self):
         """Context manager for gradient accumulation: backward passes inside it only accumulate locally (like DDP.no_sync)."""
@@ -202,7 +236,8 @@ class GradientReducer:
         if not self._expected[j]:
             # first gradient of a parameter that had none so far: it is not part of its bucket's exchange this step (the bucket may be
             # in flight already); finish() exchanges it on its own once every rank knows, and it is expected from then on
-            self._late[j] = p.grad
+            # (under no_sync() several backward passes may deliver it: the contributions add up -- ADVICE r2)
+            self._late[j] = p.grad if j not in self._late else self._late[j] + p.grad
             p.grad = None
             self._seen[j] = True
             return
@@ -249,16 +284,24 @@ class GradientReducer:
             self._launch(self._next)
             self._next += 1
         # usage mask: which parameters got a gradient on ANY rank this step (DDP's unused-parameter bitmap)
+        # Exchanged (and read on the host: the one synchronisation of a step, behind the bucket exchanges the optimizer waits for anyway) every
+        # `usage_check_every`-th step once the expected set is learned; in between every rank assumes the set unchanged -- a parameter that
+        # starts producing gradients in such a step keeps `.grad = None` on EVERY rank (replicas stay identical) until the next check admits it.
         dev = self._flat[0].device if self._flat else torch.device("cpu")
-        mask = torch.tensor([1 if s else 0 for s in self._seen], dtype=torch.int32, device=dev)
-        with self._side_ctx(dev):
-            mwork = dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        self._step += 1
+        check = (not self._learned) or self.usage_check_every <= 1 or self._step % self.usage_check_every == 0
+        mwork = mask = None
+        if check:
+            mask = torch.tensor([1 if s else 0 for s in self._seen], dtype=torch.int32).to(dev)
+            with self._side_ctx(dev):
+                mwork = dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for i, flat in enumerate(self._flat):
             self._work[i].wait()  # on CUDA: the current stream waits for the collective
-        mwork.wait()
+        if mwork is not None:
+            mwork.wait()
         if self._side is not None:
             torch.cuda.current_stream(dev).wait_stream(self._side)
-        used = [bool(v) for v in mask.cpu().tolist()]
+        used = [bool(v) for v in mask.cpu().tolist()] if check else [e and s_ for e, s_ in zip(self._expected, self._seen)]
         if not self._learned:  # first step: from now on only parameters that ever produced a gradient (on any rank) are waited for
             self._expected = list(used)
         for flat in self._flat:

@@ -382,6 +382,76 @@ def test_three_optimizer_steps_follow_the_reference_training_trajectory():
         _close(p, ref[name], 5e-4, f"after 3 steps: {name}")
 
 
+def test_three_optimizer_steps_in_mixed_precision_follow_the_reference_autocast_trajectory():
+    """The reference's C4 arithmetic (ddpm_training_ddp.py:129,249-270; engines/trainer.py:155-156,258): fp32 master parameters, forward under
+    autocast, fp32 gradients into the optimizer.  Same three-step loop as above, here with `generativemodels_amd.autocast(torch.bfloat16)`
+    around the inferer call: parameters and gradients stay fp32 (so an lr-sized update is never lost to bf16 rounding of the weight), the
+    activations / MFMA operands are bf16.  Checked against (a) the fp64 oracle trajectory -- losses within the bf16 bar -- and (b) the oracle
+    run under torch.autocast("cpu", bfloat16), the reference's own mixed-precision arithmetic: after three updates this path is no further
+    from the fp64 trajectory than a small multiple of what the reference's autocast is."""
+    import generativemodels_amd as gm
+    import restatement as R
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    from generativemodels_amd.networks.schedulers import DDPMScheduler
+    cfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 64), attention_levels=(False, True),
+               num_head_channels=32, norm_num_groups=32)
+    torch.manual_seed(21)
+    model = DiffusionModelUNet(**cfg)
+    R.derandomize_zeros(model, seed=6)
+    _, _, acp = R.noise_schedule("linear_beta", 1000)
+    images = _rand((4, 1, 16, 16), 391)
+    batches = [(_rand((4, 1, 16, 16), 392 + it), torch.tensor([11 + 200 * it, 950 - 300 * it, 500, 3 + it])) for it in range(3)]
+
+    def oracle_run(dt, ac):
+        ref = {k: v.detach().to(dt).clone().requires_grad_("proj_attn" not in k) for k, v in model.state_dict().items()}
+        opt = torch.optim.SGD([v for v in ref.values() if v.requires_grad], lr=0.05, momentum=0.9)
+        losses = []
+        for noise, t in batches:
+            opt.zero_grad()
+            with torch.autocast("cpu", dtype=torch.bfloat16, enabled=ac):
+                pred = R.unet_forward(ref, cfg, R.add_noise(acp, images, noise, t).to(dt), t)
+            loss = F.mse_loss(pred.to(dt), noise.to(dt))
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return ref, losses
+
+    ref64, loss64 = oracle_run(torch.float64, False)
+    refac, _ = oracle_run(torch.float32, True)
+
+    def deviation(params):
+        return max(((params[k].detach().double().cpu() - ref64[k].detach()).abs().max() / max(1.0, ref64[k].detach().abs().max().item())).item()
+                   for k in ref64 if ref64[k].requires_grad)
+
+    model = model.to(DEV)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    inf = DiffusionInferer(DDPMScheduler(1000))
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    for it, (noise, t) in enumerate(batches):
+        opt.zero_grad(set_to_none=True)
+        with gm.autocast(torch.bfloat16):
+            pred = inf(inputs=images.to(DEV), diffusion_model=model, noise=noise.to(DEV), timesteps=t.to(DEV))
+        assert pred.requires_grad and pred.dtype == torch.bfloat16
+        loss = F.mse_loss(pred.float(), noise.to(DEV))
+        loss.backward()
+        for name, p in model.named_parameters():
+            assert p.dtype == torch.float32 and (p.grad is None or p.grad.dtype == torch.float32), name
+        opt.step()
+        lv = float(loss.detach())
+        assert abs(lv - loss64[it]) <= 2e-2 * max(1.0, loss64[it]), (it, lv, loss64[it])
+    moved = sum(int(not torch.equal(p.detach(), before[k])) for k, p in model.named_parameters() if "proj_attn" not in k)
+    assert moved == sum(1 for k, _ in model.named_parameters() if "proj_attn" not in k), "every trained parameter moved"
+    ours, refdev = deviation(dict(model.named_parameters())), deviation(refac)
+    print(f"[parity] mixed-precision 3-step trajectory: max relative parameter deviation from the fp64 oracle {ours:.3e} "
+          f"(reference under torch.autocast(cpu, bf16): {refdev:.3e})")
+    assert ours <= max(8.0 * refdev, 1e-3) and ours <= 1e-2, (ours, refdev)
+    # outside the region the same fp32 module computes in fp32 again
+    with torch.no_grad():
+        y = model.eval()(images.to(DEV), batches[0][1].to(DEV))
+    assert y.dtype == torch.float32
+
+
 COND_TRAIN_CASES = {
     # cross-attention (2 transformer layers, context of 3 tokens), class embedding, resblock_updown, 2 -> 3 channels
     "cond2d": dict(cfg=dict(spatial_dims=2, in_channels=2, out_channels=3, num_channels=(8, 16, 16), attention_levels=(False, True, True),
@@ -526,3 +596,54 @@ def test_autoencoderkl_training_gradients_match_the_oracle_autograd(dtype, convt
         assert not mu_i.requires_grad
         _close(mu_i, mu_r, tol, "z_mu (inference)")
         _close(model.decode((mu_r + eps.double() * sig_r).to(DEV, dtype)), rec_r, tol, "reconstruction (inference)")
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_controlnet_trains_against_a_frozen_unet_gradients_match_the_oracle_autograd(dims):
+    """The ControlNet training step of the reference (tutorials: ControlNetDiffusionInferer.__call__ -> F.mse_loss -> backward, with the
+    DiffusionModelUNet frozen; nets/controlnet.py:367-436, nets/diffusion_model_unet.py:1917-1932): every ControlNet parameter gradient -- the
+    conditioning embedding, the shared encoder half, the zero convolutions -- flows through the frozen UNet's residual hooks and is compared
+    with torch autograd in fp64 through the oracle.  The UNet's parameters get no gradient; its output is differentiable."""
+    import restatement as R
+    from generativemodels_amd.inferers import ControlNetDiffusionInferer
+    from generativemodels_amd.networks.nets import ControlNet, DiffusionModelUNet
+    from generativemodels_amd.networks.schedulers import DDPMScheduler
+    common = dict(spatial_dims=dims, in_channels=1, num_res_blocks=1, num_channels=(16, 32), attention_levels=(False, True), num_head_channels=16,
+                  norm_num_groups=8)
+    ucfg = dict(common, out_channels=1)
+    ccfg = dict(common, conditioning_embedding_in_channels=1, conditioning_embedding_num_channels=(8, 16))
+    torch.manual_seed(31)
+    unet = DiffusionModelUNet(**ucfg)
+    cnet = ControlNet(**ccfg)
+    R.derandomize_zeros(unet, seed=7)
+    R.derandomize_zeros(cnet, seed=9)
+    sp = (8,) * dims
+    x, noise = _rand((2, 1, *sp), 501), _rand((2, 1, *sp), 502)
+    cond = _rand((2, 1, *(2 * v for v in sp)), 503)  # the conditioning image: 2x the grid (one stride-2 level in the embedding)
+    t = torch.tensor([33, 871])
+    usd = {k: v.detach().double() for k, v in unet.state_dict().items()}
+    csd = {k: v.detach().double().requires_grad_(True) for k, v in cnet.state_dict().items()}
+    _, _, acp = R.noise_schedule("linear_beta", 1000)
+    noisy = R.add_noise(acp, x, noise, t).double()
+    down, mid = R.controlnet_forward(csd, ccfg, noisy, t, cond.double())
+    y_ref = R.unet_forward(usd, ucfg, noisy, t, down_block_additional_residuals=down, mid_block_additional_residual=mid)
+    F.mse_loss(y_ref, noise.double()).backward()
+
+    unet, cnet = unet.to(DEV).eval(), cnet.to(DEV).train()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    inf = ControlNetDiffusionInferer(DDPMScheduler(1000))
+    pred = inf(inputs=x.to(DEV), diffusion_model=unet, controlnet=cnet, noise=noise.to(DEV), timesteps=t.to(DEV), cn_cond=cond.to(DEV))
+    assert pred.requires_grad
+    _close(pred, y_ref, 2e-4, "controlnet-conditioned prediction (train path)")
+    F.mse_loss(pred, noise.to(DEV)).backward()
+    assert all(p.grad is None for p in unet.parameters())
+    checked = 0
+    for name, p in cnet.named_parameters():
+        if "proj_attn" in name:
+            assert p.grad is None
+            continue
+        assert p.grad is not None, name
+        _close(p.grad, csd[name].grad, 6e-4, f"d controlnet.{name}")
+        checked += 1
+    assert checked > 40

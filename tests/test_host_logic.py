@@ -344,6 +344,24 @@ def test_stride2_subpixel_tap_tables_reproduce_a_transposed_convolution():
                 t0, t1 = taps[par]
                 got[2 * i + par] = (0.0 if t0 is None else w[t0] * xp[i + par]) + (0.0 if t1 is None else w[t1] * xp[i + 1 + par])
         assert np.allclose(got, want), (K, pad)
+        assert ops.stride2_subpixel_covers(K, pad)
+    # K = 4 with padding 0 also doubles the extent (padding high 2), but for odd outputs tap W[3] belongs to input i - 1, which the
+    # sub-pixel kernel's parity 1 never reads: the geometry must be refused (it takes the generic transposed path), not mis-computed
+    assert not ops.stride2_subpixel_covers(4, 0)
+    n, K, pad = 7, 4, 0
+    x, w = rng.standard_normal(n), rng.standard_normal(K)
+    full = np.zeros(2 * n + K + 2)
+    for o in range(n):
+        for k in range(K):
+            full[2 * o + k] += x[o] * w[k]
+    taps = ops.stride2_subpixel_taps(K, pad)
+    xp = np.concatenate([[0.0], x, [0.0]])
+    got = np.array([(0.0 if taps[u & 1][0] is None else w[taps[u & 1][0]] * xp[(u >> 1) + (u & 1)])
+                    + (0.0 if taps[u & 1][1] is None else w[taps[u & 1][1]] * xp[(u >> 1) + 1 + (u & 1)]) for u in range(2 * n)])
+    assert not np.allclose(got, full[:2 * n])   # (what the two-tap form would have produced: wrong -- hence the guard)
+    with pytest.raises(ValueError):
+        ops.packed_stride2_dgrad_weight(torch.zeros(8, 8, 4, 4, 4), torch.float32, 0)
+    assert not ops.stride2_subpixel_covers(5, 1) and not ops.stride2_subpixel_covers(3, 2)
 
 
 def test_tile_configuration_policy_of_the_lds_dma_convolutions():
@@ -460,3 +478,51 @@ def test_training_api_has_no_cpu_fallback_and_checks_its_arguments():
         unet.forward_train(torch.zeros(1, 1, 8, 8), torch.tensor([[3]]))
     with pytest.raises(ValueError):
         unet.forward_train(torch.zeros(1, 1, 8, 8), torch.tensor([3]), context=torch.zeros(1, 2, 4))   # no conditioning in this network
+
+
+def test_autocast_region_selects_the_compute_dtype_and_wants_grad_follows_the_input():
+    """Host logic of the mixed-precision switch (ops.autocast: fp32 master parameters, bf16 compute -- the reference's autocast training,
+    ddpm_training_ddp.py:129,253-270) and of the train / inference dispatch (`_blocks.wants_grad`)."""
+    import threading
+    import warnings
+
+    import generativemodels_amd as gm
+    from generativemodels_amd import ops
+    from generativemodels_amd.networks.nets import _blocks
+
+    assert ops.autocast_dtype() is None and ops.compute_dtype(torch.float32) == torch.float32
+    with gm.autocast(torch.bfloat16):
+        assert ops.autocast_dtype() == torch.bfloat16 and ops.compute_dtype(torch.float32) == torch.bfloat16
+        with gm.autocast(enabled=False):  # an inner region switches it off
+            assert ops.autocast_dtype() is None
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(ops.autocast_dtype()))  # thread-local, like torch.autocast
+        th.start(); th.join()
+        assert seen == [None]
+        assert ops.autocast_dtype() == torch.bfloat16
+    assert ops.autocast_dtype() is None
+    with pytest.raises(TypeError):
+        gm.autocast(torch.float16)  # fp32 / bf16 kernels only
+    # outside a region a dtype mismatch at a network's entry is an error, as before
+    with pytest.raises(TypeError):
+        ops.entry_cast(torch.zeros(2, dtype=torch.bfloat16), torch.float32)
+    assert ops.entry_cast(torch.zeros(2), torch.float32).dtype == torch.float32
+
+    m = DiffusionModelUNet(2, 1, 1, num_channels=(8,), attention_levels=(False,), num_res_blocks=1, norm_num_groups=8)
+    x = torch.zeros(1, 1, 8, 8)
+    xg = torch.zeros(1, 1, 8, 8, requires_grad=True)
+    assert _blocks.wants_grad(m.train(), x) and _blocks.wants_grad(m.train(), xg)
+    with torch.no_grad():
+        assert not _blocks.wants_grad(m, xg)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    # frozen network: the gradient still has to reach an input that asks for it (a pixel loss through a frozen decoder, ControlNet training)
+    assert _blocks.wants_grad(m, xg) and _blocks.wants_grad(m.eval(), xg) and not _blocks.wants_grad(m.train(), x)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    _blocks._warned_eval_grad = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert not _blocks.wants_grad(m.eval(), x)   # eval + trainable parameters + gradients enabled: inference path, said out loud once
+        assert not _blocks.wants_grad(m.eval(), x)
+    assert len([i for i in w if "without grad_fn" in str(i.message)]) == 1

@@ -1,7 +1,11 @@
 """GPU: one training step of BASELINE config C4 on ONE MI355X (the per-rank work of the batch-sharded DDP job): a frozen AutoencoderKL
 encodes B x 1 x S^3 volumes to B x 4 x (S/8)^3 latents, DiffusionInferer.__call__ noises them and runs the 41.7 M-parameter latent UNet
 forward WITH gradients (native kernels in both directions), MSE loss, backward, GradientReducer.finish(), Adam.
-usage: python tools/bench_train.py [size=256] [batch=1] [dtype=bf16|fp32] [steps=3]     (under torchrun: one process per GPU, RCCL)"""
+dtype "mixed" (the default) is the reference's own arithmetic for this loop (ddpm_training_ddp.py:129,249-270: fp32 parameters, forward under
+autocast, GradScaler): fp32 master parameters and fp32 gradients / Adam state, bf16 activations and MFMA operands inside
+`generativemodels_amd.autocast(torch.bfloat16)`.  "bf16" casts the parameters themselves (narrower than the reference: an lr-sized Adam update
+is below half a bf16 ulp of most weights), "fp32" runs the exact-fp32 MFMA kernels.
+usage: python tools/bench_train.py [size=256] [batch=1] [dtype=mixed|bf16|fp32] [steps=3]     (under torchrun: one process per GPU, RCCL)"""
 import json
 import os
 import sys
@@ -9,9 +13,12 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
+import generativemodels_amd as gm
 from bench import rerandomize_zero_params
 from generativemodels_amd import ops
 from generativemodels_amd.inferers import LatentDiffusionInferer
@@ -21,7 +28,11 @@ from generativemodels_amd.parallel import GradientReducer
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "fp32") else torch.bfloat16
+mode = sys.argv[3] if len(sys.argv) > 3 else "mixed"
+if mode not in ("mixed", "bf16", "fp32"):
+    raise SystemExit("dtype must be mixed, bf16 or fp32")
+dt = torch.bfloat16 if mode == "bf16" else torch.float32          # dtype of the parameters (and of the optimizer state)
+region = (lambda: gm.autocast(torch.bfloat16)) if mode == "mixed" else contextlib.nullcontext
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
@@ -57,7 +68,8 @@ def step():
     noise = torch.randn((batch, 4, lat, lat, lat), generator=g).to(dev, dt)
     t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
     red.zero_grad() if red.active else opt.zero_grad(set_to_none=True)  # one fill per bucket: .grad stays a view of its flat bucket
-    pred = inf(inputs=imgs, autoencoder_model=ae, diffusion_model=unet, noise=noise, timesteps=t)
+    with region():
+        pred = inf(inputs=imgs, autoencoder_model=ae, diffusion_model=unet, noise=noise, timesteps=t)
     loss = F.mse_loss(pred.float(), noise.float())
     loss.backward()
     red.finish()
@@ -72,11 +84,12 @@ def phase_times():
     t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
     opt.zero_grad(set_to_none=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    with torch.no_grad():
+    with torch.no_grad(), region():
         z = ae.encode_stage_2_inputs(imgs)
     torch.cuda.synchronize(); out["encode_ms"] = (time.perf_counter() - t0) * 1e3; t0 = time.perf_counter()
     noisy = sched.add_noise(z, noise, t)
-    pred = unet.forward_train(noisy, t)
+    with region():
+        pred = unet.forward_train(noisy, t)
     loss = F.mse_loss(pred.float(), noise.float())
     torch.cuda.synchronize(); out["forward_ms"] = (time.perf_counter() - t0) * 1e3; t0 = time.perf_counter()
     loss.backward()
@@ -102,7 +115,8 @@ phases = phase_times()
 ops.start_profile()
 noise = torch.randn((batch, 4, lat, lat, lat), generator=g).to(dev, dt)
 tt = torch.randint(0, 1000, (batch,), generator=g).to(dev)
-pred = unet.forward_train(sched.add_noise(torch.randn_like(noise), noise, tt), tt)
+with region():
+    pred = unet.forward_train(sched.add_noise(torch.randn_like(noise), noise, tt), tt)
 F.mse_loss(pred.float(), noise.float()).backward()
 agg = {}
 for name, meta, ms in ops.stop_profile():
@@ -110,7 +124,8 @@ for name, meta, ms in ops.stop_profile():
     a["launches"] += 1; a["ms"] += ms; a["flops"] += meta["flops"]
 if rank == 0:
     print(json.dumps(dict(config=f"C4 per-rank training step: {batch} x 1 x {size}^3 volumes -> {batch} x 4 x {lat}^3 latents, 41.7 M-parameter UNet",
-                          dtype=str(dt).split(".")[-1], n_gpus=world, step_ms=round(dt_step * 1e3, 2),
+                          dtype=("mixed: fp32 parameters / gradients / Adam state, bf16 compute" if mode == "mixed" else str(dt).split(".")[-1]),
+                          gradient_bucket_bytes=sum(p.numel() * p.element_size() for p in unet.parameters()), n_gpus=world, step_ms=round(dt_step * 1e3, 2),
                           gradient_exchange=(f"RCCL all-reduce, {len(red.buckets)} buckets, {red.launched_in_backward} launched during backward "
                                              f"(world_size {world})" if red.active else "off (one rank)"),
                           volumes_per_s=round(world * batch / dt_step, 3), losses=[round(v, 4) for v in losses], phases=phases,
