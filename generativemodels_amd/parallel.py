@@ -167,7 +167,7 @@ class GradientReducer:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
                 if p.dtype == torch.float32:  # fp32 master parameters (mixed precision): the weight-gradient kernels write fp32
-                    _DIRECT_GRAD[id(p)] = (weakref.ref(p), self._view[id(p)].data_ptr(), self._on_grad)
+                    _DIRECT_GRAD[id(p)] = (weakref.ref(p), self._view[id(p)].data_ptr(), self._on_grad_direct)
         # parameters waited for before a bucket launches: all of them until the first step has shown which ones ever get a gradient
         self._expected = [True] * len(self.params)
         self._learned = False
@@ -181,6 +181,7 @@ class GradientReducer:
         self._work: List[Optional[object]] = [None] * len(self.buckets)
         self._next = 0
         self._late = {}
+        self._direct_done = set()
         self._in_backward_launches = 0
 
     def zero_grad(self) -> None:
@@ -231,7 +232,17 @@ class GradientReducer:
             view.copy_(g)
         p.grad = view
 
+    def _on_grad_direct(self, p) -> None:
+        """Called by a backward function that accumulated p's gradient in place itself (autograd.py: _weight_grad).  The autograd engine still
+        runs the parameter's AccumulateGrad node with an undefined gradient afterwards and fires its post-accumulate hooks: that second call is
+        swallowed (`_direct_done`)."""
+        self._on_grad(p)
+        self._direct_done.add(id(p))
+
     def _on_grad(self, p) -> None:
+        if id(p) in self._direct_done:  # the engine's own hook call for a gradient the backward kernel already delivered (see above)
+            self._direct_done.discard(id(p))
+            return
         j = self._index[id(p)]
         if not self._expected[j]:
             # first gradient of a parameter that had none so far: it is not part of its bucket's exchange this step (the bucket may be
