@@ -129,7 +129,10 @@ PROTOTYPES = {
     "gm_conv_wgrad_workspace_bytes": (c_ll, [C.POINTER(GmWgradDesc)]),
     "gm_conv_wgrad": (C.c_int, [C.POINTER(GmWgradDesc), c_vp]),
     "gm_gn_bwd_stats": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
-    "gm_gn_bwd_finalize": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gm_gn_bwd_stats_slots": (c_ll, [C.c_int, c_ll]),
+    "gm_gn_bwd_finalize": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_ll, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gm_layernorm_bwd_slots": (C.c_int, [c_ll]),
+    "gm_likelihood_workspace_elems": (c_ll, [c_ll, c_ll]),
     "gm_gn_bwd_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, C.c_int, c_ll, C.c_int, C.c_int,
                                   C.c_int, c_vp]),
     "gm_stats_colsum": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),

@@ -454,9 +454,11 @@ __device__ __forceinline__ float silu_grad(float z) {
   return s * (1.0f + z * (1.0f - s));
 }
 
-// out[slot][n][c] += {sum_v g, sum_v g * x} (fp64 atomics, table zeroed by the caller); grid (nblk, N).
+// out[blk][n][c] = {sum_v g, sum_v g * x} over the rows of block blk: ONE plain fp64 store per (block, sample, channel) -- no atomics, no zero
+// fill; gm_gn_bwd_finalize adds the gm_gn_bwd_stats_slots(N, V) partials in a fixed order, so a training step is bit-reproducible (round 2
+// accumulated them with fp64 atomics into 64 slots: run-to-run differences in the last bit).  grid (nblk, N).
 // Lane <-> 16-byte channel vector, 256 / CV rows in flight per block, fp32 partial sums over <= rows_per_block / R rows, LDS reduction
-// over the rows in flight, one fp64 atomic pair per channel and block (HBM-bound: x and gy read once).
+// over the rows in flight (HBM-bound: x and gy read once).
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ gy, long long gy_ld,
                                                           const float* __restrict__ scale, const float* __restrict__ shift, long long ss_ld,
@@ -504,21 +506,35 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
   for (int c = t; c < C; c += 256) {
     double da = 0.0, db = 0.0;
     for (int r = 0; r < R; ++r) { da += (double)part_a[(size_t)r * C + c]; db += (double)part_b[(size_t)r * C + c]; }
-    double* dst = out + (((long long)(blk % GM_STAT_SLOTS) * gridDim.y + n) * C + c) * 2;
-    atomicAdd(dst, da);
-    atomicAdd(dst + 1, db);
+    double* dst = out + (((long long)blk * gridDim.y + n) * C + c) * 2;
+    *reinterpret_cast<double2*>(dst) = make_double2(da, db);
   }
+}
+
+// the launch geometry of gm_gn_bwd_stats = the number of partial rows its table holds (>= 256 rows per block, at most ~4 blocks per CU and sample)
+static void gn_bwd_stats_geometry(int N, long long V, long long& nblk, int& rpb) {
+  nblk = (V + 255) / 256;
+  const long long cap = 1024 / (N < 1 ? 1 : (N > 8 ? 8 : N)) + 1;
+  if (nblk > cap) nblk = cap;
+  if (nblk < 1) nblk = 1;
+  rpb = (int)((V + nblk - 1) / nblk);
+  if (rpb < 1) rpb = 1;
+  nblk = (V + rpb - 1) / rpb;
+  if (nblk < 1) nblk = 1;
+}
+
+extern "C" long long gm_gn_bwd_stats_slots(int N, long long V) {
+  long long nblk; int rpb;
+  gn_bwd_stats_geometry(N, V, nblk, rpb);
+  return nblk;
 }
 
 template <typename T, int VEC>
 static void launch_gn_bwd_stats(const void* x, long long x_ld, const void* gy, long long gy_ld, const float* scale, const float* shift,
                                 long long ss_ld, int N, long long V, int C, int act, double* out, hipStream_t st) {
   const int CV = C / VEC, R = 256 / CV;
-  long long nblk = (V + 255) / 256;            // >= 256 rows per block, at most ~4 blocks per CU and sample
-  const long long cap = 1024 / (N < 1 ? 1 : (N > 8 ? 8 : N)) + 1;
-  if (nblk > cap) nblk = cap;
-  const int rpb = (int)((V + nblk - 1) / nblk);
-  nblk = (V + rpb - 1) / rpb;
+  long long nblk; int rpb;
+  gn_bwd_stats_geometry(N, V, nblk, rpb);
   dim3 grid((unsigned)nblk, N);
   const size_t smem = (size_t)R * C * 2 * sizeof(float);
   gn_bwd_stats_kernel<T, VEC><<<grid, 256, smem, st>>>((const T*)x, x_ld, (const T*)gy, gy_ld, scale, shift, ss_ld, V, C, act, rpb, out);
@@ -546,39 +562,49 @@ extern "C" int gm_gn_bwd_stats(const void* x, long long x_ld, const void* gy, lo
 }
 
 // one wave per group; fwd = forward per-channel statistics {sum x, sum x^2} [S_fwd][N][C][2] (gm_gn_channel_stats / a convolution epilogue),
-// bwd = {sum g, sum g x} [GM_STAT_SLOTS][N][C][2] (gm_gn_bwd_stats), both fp64
-__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const double* __restrict__ fwd, int S_fwd, const double* __restrict__ bwd, int N, int C, int G,
-                                                            long long V, float eps, const float* __restrict__ gamma, float* __restrict__ A,
+// bwd = {sum g, sum g x} [S_bwd][N][C][2] (gm_gn_bwd_stats: one partial per block), both fp64.  Every table sum runs over the slots with all 64
+// lanes (lane l takes slots l, l + 64, ...) followed by an xor-shuffle tree: a fixed order of additions whatever the hardware schedules.
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const double* __restrict__ fwd, int S_fwd, const double* __restrict__ bwd, int S_bwd, int N, int C,
+                                                            int G, long long V, float eps, const float* __restrict__ gamma, float* __restrict__ A,
                                                             float* __restrict__ B, float* __restrict__ Cc, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const int cpg = C / G;
   const double m = (double)cpg * (double)V;
-  auto slot_sum = [&](const double* t, int n, int c, int which, int slots = GM_STAT_SLOTS) {
-    double s = 0.0;
-    for (int sl = 0; sl < slots; ++sl) s += t[(((long long)sl * N + n) * C + c) * 2 + which];
-    return s;
+  auto slot_sum2 = [&](const double* t, int slots, int n, int c, double& s0, double& s1) {  // wave-uniform (n, c): both components at once
+    double a = 0.0, b = 0.0;
+    for (int sl = lane; sl < slots; sl += 64) {
+      const double2 v = *reinterpret_cast<const double2*>(t + (((long long)sl * N + n) * C + c) * 2);
+      a += v.x; b += v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    s0 = a; s1 = b;
   };
   for (int n = 0; n < N; ++n) {
     double sx = 0.0, sxx = 0.0;
-    for (int j = lane; j < cpg; j += 64) { sx += slot_sum(fwd, n, g * cpg + j, 0, S_fwd); sxx += slot_sum(fwd, n, g * cpg + j, 1, S_fwd); }
-    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sxx += __shfl_xor(sxx, o, 64); }
+    for (int j = 0; j < cpg; ++j) {
+      double a, b;
+      slot_sum2(fwd, S_fwd, n, g * cpg + j, a, b);
+      sx += a; sxx += b;
+    }
     const double mean = sx / m;
     double var = sxx / m - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     double s1 = 0.0, s2 = 0.0;
-    for (int j = lane; j < cpg; j += 64) {
+    for (int j = 0; j < cpg; ++j) {
       const int c = g * cpg + j;
       const double ga = gamma ? (double)gamma[c] : 1.0;
-      const double sg = slot_sum(bwd, n, c, 0), sgx = slot_sum(bwd, n, c, 1);
+      double sg, sgx;
+      slot_sum2(bwd, S_bwd, n, c, sg, sgx);
       s1 += ga * sg;
       s2 += ga * (sgx - mean * sg);
       const double dg = rstd * (sgx - mean * sg);
-      if (dgamma) dgamma[c] = (float)((n == 0 ? 0.0 : (double)dgamma[c]) + dg);   // the same lane owns channel c for every n
-      if (dbeta) dbeta[c] = (float)((n == 0 ? 0.0 : (double)dbeta[c]) + sg);
+      if (lane == 0) {
+        if (dgamma) dgamma[c] = (float)((n == 0 ? 0.0 : (double)dgamma[c]) + dg);   // lane 0 owns every channel of the group for every n
+        if (dbeta) dbeta[c] = (float)((n == 0 ? 0.0 : (double)dbeta[c]) + sg);
+      }
     }
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     const double M1 = s1 / m, M2 = rstd * s2 / m;
     for (int j = lane; j < cpg; j += 64) {
       const int c = g * cpg + j;
@@ -590,12 +616,12 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const double* __res
   }
 }
 
-extern "C" int gm_gn_bwd_finalize(const double* fwd_stats, int fwd_slots, const double* bwd_stats, int N, int C, int G, long long V, float eps,
-                                  const float* gamma, float* A, float* B, float* Cc, float* dgamma, float* dbeta, void* stream) {
-  GM_REQUIRE(fwd_stats && bwd_stats && A && B && Cc && fwd_slots > 0, "null pointer");
+extern "C" int gm_gn_bwd_finalize(const double* fwd_stats, int fwd_slots, const double* bwd_stats, int bwd_slots, int N, int C, int G, long long V,
+                                  float eps, const float* gamma, float* A, float* B, float* Cc, float* dgamma, float* dbeta, void* stream) {
+  GM_REQUIRE(fwd_stats && bwd_stats && A && B && Cc && fwd_slots > 0 && bwd_slots > 0, "null pointer");
   GM_REQUIRE(G > 0 && C % G == 0, "channels must be divisible by groups");
   if (N == 0) return 0;
-  gn_bwd_finalize_kernel<<<G, 64, 0, (hipStream_t)stream>>>(fwd_stats, fwd_slots, bwd_stats, N, C, G, V, eps, gamma, A, B, Cc, dgamma, dbeta);
+  gn_bwd_finalize_kernel<<<G, 64, 0, (hipStream_t)stream>>>(fwd_stats, fwd_slots, bwd_stats, bwd_slots, N, C, G, V, eps, gamma, A, B, Cc, dgamma, dbeta);
   GM_LAUNCH_CHECK();
 }
 
@@ -723,18 +749,20 @@ extern "C" int gm_softmax_bwd(const float* probs, const float* dprobs, float* ds
 // ---------------------------------------------------------------------------------------------------------------------------------
 // LayerNorm backward (nn.LayerNorm of the transformer blocks, diffusion_model_unet.py:219-223): one wave per row.
 //   xhat = (x - mean) rstd,  g = gy gamma,  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat));
-//   param_stats[slot][c] += {sum_rows gy xhat, sum_rows gy}  (fp64, GM_STAT_SLOTS slots, zeroed by the caller; nullable)
+//   param_stats[block][c] = {sum_rows gy xhat, sum_rows gy} over the rows the block walks  (fp64 [gm_layernorm_bwd_slots(rows)][C][2], one plain
+//   store each -- no atomics, nothing to zero; nullable)
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ gy, long long gy_ld,
                                                            T* __restrict__ dx, long long dx_ld, const float* __restrict__ gamma, long long rows,
                                                            int C, float eps, double* __restrict__ param_stats) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* acc = reinterpret_cast<float*>(smem_raw);  // [4 waves][C][2]
+  float* acc = reinterpret_cast<float*>(smem_raw);  // [4 waves][C][2]: this wave's sums over the rows it walks (its own lanes' channels only)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long row = (long long)blockIdx.x * 4 + wave;
   for (int c = lane; c < C; c += 64) { acc[(wave * C + c) * 2] = 0.f; acc[(wave * C + c) * 2 + 1] = 0.f; }
-  if (row < rows) {
+  // block b walks rows 4 b + wave, + 4 gridDim.x, ...: a fixed assignment, so every partial -- and the fixed-order sum over the partials -- is
+  // the same on every run (round 2: one block per 4 rows, fp64 atomics into 64 slots)
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
     const T* xr = x + row * x_ld;
     const T* gr = gy + row * gy_ld;
     float s = 0.f;
@@ -756,8 +784,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int c = lane; c < C; c += 64) {
       const float xh = (ElemIO<T>::ld(xr + c) - mean) * rstd, gv = ElemIO<T>::ld(gr + c);
       ElemIO<T>::st(dr + c, rstd * (gv * (gamma ? gamma[c] : 1.f) - m1 - xh * m2));
-      acc[(wave * C + c) * 2] = gv * xh;
-      acc[(wave * C + c) * 2 + 1] = gv;
+      acc[(wave * C + c) * 2] += gv * xh;
+      acc[(wave * C + c) * 2 + 1] += gv;
     }
   }
   if (!param_stats) return;
@@ -765,10 +793,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int c = threadIdx.x; c < C; c += 256) {
     double a = 0.0, b = 0.0;
     for (int w = 0; w < 4; ++w) { a += (double)acc[(w * C + c) * 2]; b += (double)acc[(w * C + c) * 2 + 1]; }
-    double* dst = param_stats + (((long long)(blockIdx.x % GM_STAT_SLOTS)) * C + c) * 2;
-    atomicAdd(dst, a);
-    atomicAdd(dst + 1, b);
+    *reinterpret_cast<double2*>(param_stats + ((long long)blockIdx.x * C + c) * 2) = make_double2(a, b);  // one plain store per (block, channel)
   }
+}
+
+// blocks of gm_layernorm_bwd = rows of its [slots][C][2] partial table: one block per 4 rows up to 256 blocks, which then walk the rows
+extern "C" int gm_layernorm_bwd_slots(long long rows) {
+  const long long g = (rows + 3) / 4;
+  return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
 }
 
 extern "C" int gm_layernorm_bwd(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, const float* gamma,
@@ -777,7 +809,7 @@ extern "C" int gm_layernorm_bwd(const void* x, long long x_ld, const void* gy, l
   GM_REQUIRE(C > 0 && C <= 4096, "LayerNorm width out of range");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const unsigned grid = (unsigned)gm_layernorm_bwd_slots(rows);
   const size_t smem = (size_t)4 * C * 2 * sizeof(float);
   if (dtype == GM_F32)
     layernorm_bwd_kernel<float><<<grid, 256, smem, st>>>((const float*)x, x_ld, (const float*)gy, gy_ld, (float*)dx, dx_ld, gamma, rows, C, eps, param_stats);

@@ -240,16 +240,26 @@ __global__ __launch_bounds__(256) void likelihood_kl_kernel(const T* __restrict_
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(rowsum + n, part[0] + part[1] + part[2] + part[3]);
+  // one partial per (sample, block), stored -- the fold below adds them in block order: the bound is bit-reproducible (round 2: fp64 atomics)
+  if (threadIdx.x == 0) rowsum[n * gridDim.x + blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-__global__ void likelihood_fold_kernel(double* __restrict__ rowsum, float* __restrict__ total, long long batch, double inv_inner) {
+__global__ void likelihood_fold_kernel(const double* __restrict__ rowsum, float* __restrict__ total, long long batch, int parts, double inv_inner) {
   const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (n < batch) {
-    total[n] += (float)(rowsum[n] * inv_inner);
-    rowsum[n] = 0.0;  // ready for the next term
+    double s = 0.0;
+    for (int j = 0; j < parts; ++j) s += rowsum[n * parts + j];
+    total[n] += (float)(s * inv_inner);
   }
 }
+
+static long long likelihood_blocks(long long inner) {
+  long long gx = (inner + 255) / 256;
+  return gx > 2048 ? 2048 : (gx < 1 ? 1 : gx);
+}
+
+// doubles of gm_likelihood_term's workspace: one partial per (sample, block); needs no initialisation
+extern "C" long long gm_likelihood_workspace_elems(long long batch, long long inner) { return batch * likelihood_blocks(inner); }
 
 extern "C" int gm_likelihood_term(const void* x0, const void* xt, const void* model_output, void* kl, float* total,
                                   double* workspace, long long batch, long long inner, long long mo_bstride, int dtype,
@@ -259,8 +269,7 @@ extern "C" int gm_likelihood_term(const void* x0, const void* xt, const void* mo
   GM_REQUIRE(batch <= 65535, "batch too large");
   hipStream_t st = (hipStream_t)stream;
   const float cdf_c = sqrtf((float)(2.0 / 3.14159265358979323846));  // torch.sqrt(torch.Tensor([2.0 / math.pi]))
-  long long gx = (inner + 255) / 256;
-  if (gx > 2048) gx = 2048;
+  const long long gx = likelihood_blocks(inner);
   dim3 grid((unsigned)gx, (unsigned)batch);
   if (dtype == GM_F32)
     likelihood_kl_kernel<float><<<grid, 256, 0, st>>>((const float*)x0, (const float*)xt, (const float*)model_output,
@@ -270,7 +279,7 @@ extern "C" int gm_likelihood_term(const void* x0, const void* xt, const void* mo
                                                          (bf16_raw*)kl, workspace, inner, mo_bstride, *p, cdf_c);
   else
     GM_FAIL(-2, "unsupported dtype");
-  likelihood_fold_kernel<<<(unsigned)((batch + 63) / 64), 64, 0, st>>>(workspace, total, batch, 1.0 / (double)inner);
+  likelihood_fold_kernel<<<(unsigned)((batch + 63) / 64), 64, 0, st>>>(workspace, total, batch, (int)gx, 1.0 / (double)inner);
   GM_LAUNCH_CHECK();
 }
 

@@ -164,7 +164,7 @@ class DiffusionInferer(Inferer):
         noise = torch.randn_like(inputs) if _noise is None else _noise
         n = inputs.shape[0]
         total_kl = torch.zeros(n, dtype=torch.float32, device=inputs.device)
-        workspace = torch.zeros(n, dtype=torch.float64, device=inputs.device)
+        workspace = torch.empty(ops.likelihood_workspace_elems(n, inputs.numel() // max(n, 1)), dtype=torch.float64, device=inputs.device)
         acp, betas, alphas = (scheduler._host_table(k) for k in ("alphas_cumprod", "betas", "alphas"))
         one = scheduler.one.detach().to("cpu", torch.float32)
         bin_width = (scaled_input_range[1] - scaled_input_range[0]) / (original_input_range[1] - original_input_range[0])

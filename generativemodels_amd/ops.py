@@ -527,28 +527,7 @@ def spade_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, g: to
     return out
 
 
-STAT_SLOTS = 64  # GM_STAT_SLOTS of include/gm_amd.h: the zero-filled, atomically accumulated tables of the BACKWARD kernels only
-
-_STATS_CHUNK = 1 << 20  # doubles per zero-filled chunk (8 MB): one memset serves ~40 statistic tables of a C2 forward
-_stats_pool: dict = {}
-
-
-def _zero_stats(n: int, c: int, device) -> torch.Tensor:
-    """A zeroed fp64 [STAT_SLOTS, N, C, 2] table carved out of a pooled zero-filled chunk (each table is used once): the accumulator of
-    gm_gn_bwd_stats.  (The forward statistics need no zero fill: one stored partial per tile, see channel_stats.)"""
-    need = STAT_SLOTS * n * c * 2
-    if need > _STATS_CHUNK // 4 or torch.cuda.is_current_stream_capturing():
-        # under HIP-graph capture every table needs its own captured fill: a pooled chunk zeroed before the capture would be
-        # stale on replay
-        return torch.zeros((STAT_SLOTS, n, c, 2), dtype=torch.float64, device=device)
-    key = (device.type, device.index)
-    ent = _stats_pool.get(key)
-    if ent is None or ent[1] + need > _STATS_CHUNK:
-        ent = [torch.zeros(_STATS_CHUNK, dtype=torch.float64, device=device), 0]
-        _stats_pool[key] = ent
-    view = ent[0][ent[1]:ent[1] + need].view(STAT_SLOTS, n, c, 2)
-    ent[1] += need
-    return view
+STAT_SLOTS = 64  # GM_STAT_SLOTS of include/gm_amd.h: rows of a compacted statistic table (gm_stats_compact)
 
 
 class VirtualCat:
@@ -1282,14 +1261,15 @@ def gn_backward(x: torch.Tensor, gy: torch.Tensor, scale: torch.Tensor, shift: t
         raise ValueError("gn_backward: scale/shift must be matching fp32 [N, C] tables")
     ss_ld = scale.stride(0) if n > 1 else max(scale.stride(0), c)
     fwd = channel_stats(x)
-    bwd = _zero_stats(n, c, x.device)
+    # one stored fp64 partial per (block, sample, channel): no atomics, nothing to zero, summed in a fixed order by the finalize kernel
+    bwd = torch.empty((max(int(lib().gm_gn_bwd_stats_slots(n, v)), 1), n, c, 2), dtype=torch.float64, device=x.device)
     a = ACT[act]
     check(lib().gm_gn_bwd_stats(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), scale.data_ptr(), shift.data_ptr(), ss_ld, n, v, c, a,
                                 bwd.data_ptr(), dt_code(x.dtype), _stream()), "gm_gn_bwd_stats")
     coef = torch.empty((3, n, c), dtype=torch.float32, device=x.device)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
-    check(lib().gm_gn_bwd_finalize(fwd.data_ptr(), fwd.shape[0], bwd.data_ptr(), n, c, groups, v, float(eps), _ptr(as_f32(gamma)), coef[0].data_ptr(),
+    check(lib().gm_gn_bwd_finalize(fwd.data_ptr(), fwd.shape[0], bwd.data_ptr(), bwd.shape[0], n, c, groups, v, float(eps), _ptr(as_f32(gamma)), coef[0].data_ptr(),
                                    coef[1].data_ptr(), coef[2].data_ptr(), _ptr(dgamma), _ptr(dbeta), _stream()), "gm_gn_bwd_finalize")
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     check(lib().gm_gn_bwd_apply(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), scale.data_ptr(),
@@ -1338,7 +1318,8 @@ def layernorm_backward(x: torch.Tensor, gy: torch.Tensor, gamma: Optional[torch.
         raise ValueError("layernorm_backward: gy must match x")
     c = x.shape[-1]
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    st = torch.zeros((STAT_SLOTS, c, 2), dtype=torch.float64, device=x.device) if want_param_grads else None
+    slots = int(lib().gm_layernorm_bwd_slots(rows_of(x)))  # one stored partial per block (no atomics, nothing to zero)
+    st = torch.empty((slots, c, 2), dtype=torch.float64, device=x.device) if want_param_grads else None
     check(lib().gm_layernorm_bwd(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), _ptr(as_f32(gamma)),
                                  rows_of(x), c, float(eps), _ptr(st), dt_code(x.dtype), _stream()), "gm_layernorm_bwd")
     if not want_param_grads:
@@ -1346,8 +1327,8 @@ def layernorm_backward(x: torch.Tensor, gy: torch.Tensor, gamma: Optional[torch.
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     flat = st.view(-1)
-    check(lib().gm_stats_colsum(flat.data_ptr(), STAT_SLOTS, 1, c, dgamma.data_ptr(), 0, _stream()), "gm_stats_colsum")
-    check(lib().gm_stats_colsum(flat[1:].data_ptr(), STAT_SLOTS, 1, c, dbeta.data_ptr(), 0, _stream()), "gm_stats_colsum")
+    check(lib().gm_stats_colsum(flat.data_ptr(), slots, 1, c, dgamma.data_ptr(), 0, _stream()), "gm_stats_colsum")
+    check(lib().gm_stats_colsum(flat[1:].data_ptr(), slots, 1, c, dbeta.data_ptr(), 0, _stream()), "gm_stats_colsum")
     return dx, dgamma, dbeta
 
 
@@ -1533,6 +1514,11 @@ def sched_step(sample: torch.Tensor, model_output: torch.Tensor, params: GmStepP
     return prev, x0
 
 
+def likelihood_workspace_elems(batch: int, inner: int) -> int:
+    """fp64 elements of likelihood_term's workspace: one partial per (sample, block); needs no initialisation."""
+    return int(lib().gm_likelihood_workspace_elems(int(batch), int(inner)))
+
+
 def likelihood_term(x0: torch.Tensor, xt: torch.Tensor, model_output: torch.Tensor, params: GmKlParams, total: torch.Tensor,
                     workspace: torch.Tensor, want_map: bool = False) -> Optional[torch.Tensor]:
     """One term of get_likelihood's bound: adds mean_over_elements(KL or decoder NLL) to total[n]; returns the map if asked."""
@@ -1541,6 +1527,8 @@ def likelihood_term(x0: torch.Tensor, xt: torch.Tensor, model_output: torch.Tens
         raise ValueError("inputs, noised inputs and model output must share dtype; inputs and noised inputs share shape")
     if total.dtype != torch.float32 or workspace.dtype != torch.float64:
         raise TypeError("total must be fp32 and workspace fp64")
+    if workspace.numel() < likelihood_workspace_elems(x0.shape[0], x0.numel() // max(x0.shape[0], 1)):
+        raise ValueError("workspace too small (ops.likelihood_workspace_elems)")
     x0, xt, model_output = x0.contiguous(), xt.contiguous(), model_output.contiguous()
     batch = x0.shape[0]
     inner = x0.numel() // max(batch, 1)

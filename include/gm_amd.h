@@ -66,6 +66,9 @@ typedef struct GmKlParams {
   float e;           /* KL: exp(-log_pred_var); NLL: exp(-log_scales) */
   float half_bin;    /* NLL: bin_width / 2 */
 } GmKlParams;
+/* workspace: gm_likelihood_workspace_elems(batch, inner) doubles (one partial per sample and block, summed in block order: no atomics,
+ * no initialisation needed) */
+long long gm_likelihood_workspace_elems(long long batch, long long inner);
 int gm_likelihood_term(const void* x0, const void* xt, const void* model_output, void* kl, float* total, double* workspace,
                        long long batch, long long inner, long long mo_bstride, int dtype, const GmKlParams* p, void* stream);
 /* out[n,i] = a[n]*x[n,i] + b[n]*y[n,i]: Scheduler.add_noise / get_velocity (networks/schedulers/scheduler.py:169-200) */
@@ -294,14 +297,16 @@ long long gm_conv_wgrad_workspace_bytes(const GmWgradDesc* d);
 int gm_conv_wgrad(const GmWgradDesc* d, void* stream);
 /* GroupNorm (+ SiLU when act = 1) backward for y = act(x * scale[n][c] + shift[n][c]) (nn.GroupNorm + nn.SiLU,
  * diffusion_model_unet.py:623-690).  With g = gy * act'(x * scale + shift):
- *   gm_gn_bwd_stats     out[slot][n][c] += {sum_v g, sum_v g x}  (fp64, GM_STAT_SLOTS slots, zeroed by the caller)
+ *   gm_gn_bwd_stats     out[block][n][c] = {sum_v g, sum_v g x} over the rows of the block: fp64 [gm_gn_bwd_stats_slots(N, V)][N][C][2],
+ *                       one plain store each (no atomics, no zero fill; summed in a fixed order by gm_gn_bwd_finalize: bit-reproducible)
  *   gm_gn_bwd_finalize  per-(n, c) coefficients A, B, Cc of dx = A g + B x + Cc, and dgamma[c], dbeta[c] (nullable);
  *                       fwd_stats = the [fwd_slots][N][C][2] forward table of x (gm_gn_channel_stats or a convolution epilogue)
  *   gm_gn_bwd_apply     dx = g * A + x * B + Cc */
 int gm_gn_bwd_stats(const void* x, long long x_ld, const void* gy, long long gy_ld, const float* scale, const float* shift, long long ss_ld,
                     int N, long long V, int C, int act, double* out, int dtype, void* stream);
-int gm_gn_bwd_finalize(const double* fwd_stats, int fwd_slots, const double* bwd_stats, int N, int C, int G, long long V, float eps, const float* gamma,
-                       float* A, float* B, float* Cc, float* dgamma, float* dbeta, void* stream);
+long long gm_gn_bwd_stats_slots(int N, long long V);
+int gm_gn_bwd_finalize(const double* fwd_stats, int fwd_slots, const double* bwd_stats, int bwd_slots, int N, int C, int G, long long V, float eps,
+                       const float* gamma, float* A, float* B, float* Cc, float* dgamma, float* dbeta, void* stream);
 int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, const float* scale,
                     const float* shift, long long ss_ld, const float* A, const float* B, const float* Cc, int N, long long V, int C, int act,
                     int dtype, void* stream);
@@ -334,8 +339,10 @@ int gm_attention_backward(const GmAttnBwdDesc* d, void* stream);
  * (the softmax of diffusion_model_unet.py:143-153 / 407-415 under torch autograd) */
 int gm_softmax_bwd(const float* probs, const float* dprobs, float* dscores, long long rows, int V, float scale, void* stream);
 
-/* nn.LayerNorm backward (diffusion_model_unet.py:219-223 under autograd): dx per row; param_stats[slot][c] += {sum_rows gy xhat, sum_rows gy}
- * (fp64 [GM_STAT_SLOTS][C][2], zeroed by the caller, nullable): dgamma / dbeta = gm_stats_colsum over the two components */
+/* nn.LayerNorm backward (diffusion_model_unet.py:219-223 under autograd): dx per row; param_stats[block][c] = {sum_rows gy xhat, sum_rows gy}
+ * over the rows a block walks (fp64 [gm_layernorm_bwd_slots(rows)][C][2], plain stores -- no atomics, nothing to zero; nullable):
+ * dgamma / dbeta = gm_stats_colsum over the two components, a fixed-order sum (bit-reproducible) */
+int gm_layernorm_bwd_slots(long long rows);
 int gm_layernorm_bwd(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, const float* gamma,
                      long long rows, int C, float eps, double* param_stats, int dtype, void* stream);
 /* GEGLU backward: x = [a | gate] (2 * inner channels), y = a * gelu(gate) -> dx = [gy gelu(gate) | gy a gelu'(gate)] */
