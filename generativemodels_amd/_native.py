@@ -90,6 +90,7 @@ PROTOTYPES = {
     "gm_nhwc_to_nchw": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_vp]),
     "gm_resample2x": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, c_vp]),
+    "gm_phase2x": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_timestep_embedding": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_float, C.c_int, c_vp]),
     "gm_geglu": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_ll, C.c_int, C.c_int, c_vp]),
     "gm_aekl_sample": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, c_vp]),

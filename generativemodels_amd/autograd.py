@@ -47,11 +47,15 @@ def _weight_grad(weight: torch.Tensor, shape, run):
 
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, rowvec, res, kernel, stride, padding, pad_hi):
+    def forward(ctx, x, weight, bias, rowvec, res, kernel, stride, padding, pad_hi, post_act="none"):
         # want_stats: the fast kernels leave the per-channel statistics of y on the tensor, so the GroupNorm that follows needs no pass
         y = ops.conv(x, weight, bias, kernel=kernel, stride=stride, padding=padding, pad_hi=pad_hi, rowvec=rowvec, res=res,
-                     want_stats=x.dim() >= 4)
-        ctx.save_for_backward(x, weight)
+                     want_stats=x.dim() >= 4 and post_act == "none", post_act=post_act)
+        ctx.post_act = post_act
+        if post_act != "none":  # the epilogue activation is differentiated from its OUTPUT (ReLU: y > 0 <=> z > 0): y is all the backward needs
+            ctx.save_for_backward(x, weight, y)
+        else:
+            ctx.save_for_backward(x, weight)
         ctx.geom = (kernel, stride, padding, pad_hi)
         ctx.bias_dtype = None if bias is None else bias.dtype
         ctx.row_shape = None if rowvec is None else tuple(rowvec.shape)
@@ -59,9 +63,11 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         kernel, stride, padding, pad_hi = ctx.geom
         gy = gy.contiguous()
+        if ctx.post_act != "none":
+            gy = ops.act_backward(ctx.saved_tensors[2], gy, ctx.post_act)
         nsp = x.dim() - 2
         k, s, p = _tup(kernel, nsp), _tup(stride, nsp), _tup(padding, nsp)
         phi = _tup(pad_hi, nsp) if pad_hi is not None else p
@@ -84,14 +90,15 @@ class _Conv(torch.autograd.Function):
             drow = ops.bias_grad(gy, per_sample=True) if ctx.row_shape[0] != 1 else ops.bias_grad(gy)[None]
         if ctx.needs_input_grad[4]:
             dres = gy
-        return dx, dw, db, drow, dres, None, None, None, None
+        return dx, dw, db, drow, dres, None, None, None, None, None
 
 
 def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, kernel, stride=1, padding=0, pad_hi=None,
-         rowvec: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = conv(x, weight) + bias + rowvec[n] + res over an arena tensor; differentiable in x, weight, bias, rowvec (fp32 [N or 1,
-    Cout]) and res."""
-    return _Conv.apply(x, weight, bias, rowvec, res, kernel, stride, padding, pad_hi)
+         rowvec: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, post_act: str = "none") -> torch.Tensor:
+    """y = post_act(conv(x, weight) + bias + rowvec[n] + res) over an arena tensor; differentiable in x, weight, bias, rowvec (fp32 [N or 1,
+    Cout]) and res.  post_act: "none" or "relu" (fused into the epilogue; the VQ-VAE's convolution + ReLU layers).  Kernel 1 or 3 at stride 1 / 2,
+    and kernel 4 at stride 2 (the VQ-VAE down-sampling convolutions: weight gradient over the phase images of x, ops.conv_wgrad)."""
+    return _Conv.apply(x, weight, bias, rowvec, res, kernel, stride, padding, pad_hi, post_act)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -107,19 +114,25 @@ class _ConvTranspose(torch.autograd.Function):
     dW the weight gradient of that convolution with the roles of input and output gradient exchanged."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, kernel, stride, padding, output_padding):
+    def forward(ctx, x, weight, bias, kernel, stride, padding, output_padding, post_act="none"):
         y = ops.conv(x, weight, bias, kernel=kernel, stride=stride, padding=padding, transposed=True, output_padding=output_padding,
-                     want_stats=True)
-        ctx.save_for_backward(x, weight)
+                     want_stats=post_act == "none", post_act=post_act)
+        ctx.post_act = post_act
+        if post_act != "none":
+            ctx.save_for_backward(x, weight, y)
+        else:
+            ctx.save_for_backward(x, weight)
         ctx.geom = (kernel, stride, padding)
         ctx.bias_dtype = None if bias is None else bias.dtype
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         kernel, stride, padding = ctx.geom
         gy = gy.contiguous()
+        if ctx.post_act != "none":
+            gy = ops.act_backward(ctx.saved_tensors[2], gy, ctx.post_act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv(gy, weight, None, kernel=kernel, stride=stride, padding=padding)  # [Cin, Cout, *k] read as a Conv weight
@@ -131,13 +144,14 @@ class _ConvTranspose(torch.autograd.Function):
                               lambda out, acc: ops.conv_wgrad(gy, x, kernel, stride, padding, out=out, accumulate=acc))
         if ctx.needs_input_grad[2]:
             db = ops.bias_grad(gy).to(ctx.bias_dtype)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def conv_transpose(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, kernel, stride, padding,
-                   output_padding=0) -> torch.Tensor:
-    """nn.ConvTransposeNd over an arena tensor (weight [Cin, Cout, *k]); differentiable in x, weight, bias (kernel 3, stride 1 or 2)."""
-    return _ConvTranspose.apply(x, weight, bias, kernel, stride, padding, output_padding)
+                   output_padding=0, post_act: str = "none") -> torch.Tensor:
+    """post_act(nn.ConvTransposeNd) over an arena tensor (weight [Cin, Cout, *k]); differentiable in x, weight, bias (kernel 3 at stride 1 or 2,
+    kernel 4 at stride 2: the VQ-VAE up-sampling); post_act "none" or "relu"."""
+    return _ConvTranspose.apply(x, weight, bias, kernel, stride, padding, output_padding, post_act)
 
 
 class _SigmaFromLogVar(torch.autograd.Function):

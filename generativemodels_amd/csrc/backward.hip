@@ -453,6 +453,8 @@ __device__ __forceinline__ float silu_grad(float z) {
   const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-z));  // v_exp_f32 + v_rcp_f32: ~1 ulp each
   return s * (1.0f + z * (1.0f - s));
 }
+// act'(z) for the activation codes of the forward prologue (0 none, 1 SiLU, 2 ReLU: torch's relu backward passes the gradient where z > 0)
+__device__ __forceinline__ float act_grad(float z, int act) { return act == 1 ? silu_grad(z) : (act == 2 ? (z > 0.f ? 1.f : 0.f) : 1.f); }
 
 // out[blk][n][c] = {sum_v g, sum_v g * x} over the rows of block blk: ONE plain fp64 store per (block, sample, channel) -- no atomics, no zero
 // fill; gm_gn_bwd_finalize adds the gm_gn_bwd_stats_slots(N, V) partials in a fixed order, so a training step is bit-reproducible (round 2
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         float g = gv[i];
-        if (act == 1) g *= silu_grad(xv[i] * sc[i] + sh[i]);
+        if (act) g *= act_grad(xv[i] * sc[i] + sh[i], act);
         a[i] += g; b2[i] += g * xv[i];
       }
     }
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       float g = gv[k];
-      if (act == 1) g *= silu_grad(xv[k] * sc[k] + sh[k]);
+      if (act) g *= act_grad(xv[k] * sc[k] + sh[k], act);
       o[k] = g * ca[k] + xv[k] * cb[k] + cc[k];
     }
     if constexpr (VEC == 1) ElemIO<T>::st(db + r * dx_ld, o[0]);

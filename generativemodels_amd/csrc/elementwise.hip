@@ -511,6 +511,45 @@ extern "C" int gm_resample2x(const void* src, long long src_ld, void* dst, long 
   GM_LAUNCH_CHECK();
 }
 
+// Phase image of a 2x sub-lattice: dst[n][d][h][w][c] = src[n][2 d + rd][2 h + rh][2 w + rw][c], phase = (rd << 2) | (rh << 1) | rw, output
+// extents (X - r + 1) / 2 per active axis.  The weight gradient of a stride-2 convolution with an EVEN kernel (the k = 4 / s = 2 / p = 1
+// down- and up-sampling convolutions of the VQ-VAE, vqvae.py:127-150,244-261) is assembled from stride-1 weight gradients over the 2^d
+// phase images of its input (ops.conv_wgrad).  dims are D, H, W of the input; a 2-D tensor passes D = 1 and act_d = 0.
+template <typename T>
+__global__ __launch_bounds__(256) void phase2x_kernel(const T* __restrict__ src, long long src_ld, T* __restrict__ dst, long long dst_ld, int N, int C,
+                                                     int Di, int Hi, int Wi, int act_d, int phase) {
+  const int rd = act_d ? (phase >> 2) & 1 : 0, rh = (phase >> 1) & 1, rw = phase & 1;
+  const int Do = act_d ? (Di - rd + 1) / 2 : Di, Ho = (Hi - rh + 1) / 2, Wo = (Wi - rw + 1) / 2;
+  const long long total = (long long)N * Do * Ho * Wo * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int w = (int)(r % Wo); r /= Wo;
+    const int h = (int)(r % Ho); r /= Ho;
+    const int d = (int)(r % Do);
+    const long long n = r / Do;
+    const long long sv = ((n * Di + (act_d ? 2 * d + rd : d)) * Hi + 2 * h + rh) * Wi + 2 * w + rw;
+    const long long ov = ((n * Do + d) * Ho + h) * Wo + w;
+    dst[ov * dst_ld + c] = src[sv * src_ld + c];
+  }
+}
+
+extern "C" int gm_phase2x(const void* src, long long src_ld, void* dst, long long dst_ld, int N, int C, int Di, int Hi, int Wi, int act_d,
+                          int phase, int dtype, void* stream) {
+  GM_REQUIRE(src && dst, "null pointer");
+  GM_REQUIRE(phase >= 0 && phase < 8, "phase is a 3-bit (d, h, w) parity");
+  const int rd = act_d ? (phase >> 2) & 1 : 0, rh = (phase >> 1) & 1, rw = phase & 1;
+  const long long total = (long long)N * C * (act_d ? (Di - rd + 1) / 2 : Di) * ((Hi - rh + 1) / 2) * ((Wi - rw + 1) / 2);
+  if (total <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32)
+    phase2x_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)src, src_ld, (float*)dst, dst_ld, N, C, Di, Hi, Wi, act_d, phase);
+  else if (dtype == GM_BF16)
+    phase2x_kernel<bf16_raw><<<ew_grid(total), 256, 0, st>>>((const bf16_raw*)src, src_ld, (bf16_raw*)dst, dst_ld, N, C, Di, Hi, Wi, act_d, phase);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Sinusoidal timestep embedding: out[b, :half] = cos(t_b * f_i), out[b, half:2*half] = sin(t_b * f_i),
 // f_i = exp(-ln(max_period) * i / half); zero pad when dim is odd.  (reference diffusion_model_unet.py:461-485)

@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from ... import ops
 from ..layers.vector_quantizer import EMAQuantizer, VectorQuantizer
-from ._blocks import ConvP, ensure_tuple_rep
+from ._blocks import ConvP, ensure_tuple_rep, wants_grad
 
 __all__ = ["VQVAE"]
 
@@ -46,6 +46,23 @@ class _ConvAct(nn.Module):
                         dilation=self.dilation, transposed=self.transposed, output_padding=self.output_padding,
                         post_act=fusion.pop("post_act", self.act), **fusion)
 
+    def run_train(self, x):
+        """The same layer with gradients (generativemodels_amd.autograd): convolution / transposed convolution with the activation in its epilogue."""
+        from ... import autograd as A
+
+        _trainable_act(self.act)
+        if self.dilation != 1:
+            raise NotImplementedError("VQVAE training: dilated down- / up-sampling convolutions have no weight-gradient kernel")
+        if self.transposed:
+            return A.conv_transpose(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding,
+                                    output_padding=self.output_padding, post_act=self.act)
+        return A.conv(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding, post_act=self.act)
+
+
+def _trainable_act(act: str) -> None:
+    if act not in ("none", "relu"):
+        raise NotImplementedError(f"VQVAE training covers act / output_act in (None, 'RELU'): '{act}' has no backward kernel")
+
 
 class VQVAEResidualUnit(nn.Module):
     """relu(x + conv2(act(conv1(x)))) (reference vqvae.py:27-80): two launches, add + ReLU in the second epilogue."""
@@ -58,6 +75,14 @@ class VQVAEResidualUnit(nn.Module):
 
     def run(self, x):
         return self.conv2.run(self.conv1.run(x, post_act=self.act), res=x, post_act="relu")
+
+    def run_train(self, x):
+        from ... import autograd as A
+
+        _trainable_act(self.act)
+        c1, c2 = self.conv1.conv, self.conv2.conv
+        h = A.conv(x, c1.weight, c1.bias, kernel=3, stride=1, padding=1, post_act=self.act)
+        return A.conv(h, c2.weight, c2.bias, kernel=3, stride=1, padding=1, res=x, post_act="relu")
 
 
 class Encoder(nn.Module):
@@ -75,6 +100,11 @@ class Encoder(nn.Module):
     def run(self, x):
         for b in self.blocks:
             x = b.run(x)
+        return x
+
+    def run_train(self, x):
+        for b in self.blocks:
+            x = b.run_train(x)
         return x
 
 
@@ -98,9 +128,17 @@ class Decoder(nn.Module):
             x = b.run(x)
         return x
 
+    def run_train(self, x):
+        for b in self.blocks:
+            x = b.run_train(x)
+        return x
+
 
 class VQVAE(nn.Module):
-    """Drop-in for generative.networks.nets.VQVAE (same arguments, state_dict keys and methods; inference only)."""
+    """Drop-in for generative.networks.nets.VQVAE (same arguments, state_dict keys and methods).  In train() mode with gradients enabled
+    `encode` / `decode` / `forward` are differentiable (native kernels in both directions; the quantiser performs the EMA codebook update and
+    passes the gradient straight through, vector_quantizer.py:161-188): the VQ-VAE training loop of the reference's tutorials
+    (engines/trainer.py:258-270) runs unchanged.  Covered: act / output_act in (None, "RELU"), dropout = 0, undilated resampling convolutions."""
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, num_channels: Sequence[int] | int = (96, 96, 192),
                  num_res_layers: int = 3, num_res_channels: Sequence[int] | int = (96, 96, 192),
@@ -146,6 +184,7 @@ class VQVAE(nn.Module):
                                upsample_parameters, dropout, a, oa)
         self.quantizer = VectorQuantizer(quantizer=EMAQuantizer(spatial_dims, num_embeddings, embedding_dim, commitment_cost,
                                                                 decay, epsilon, embedding_init, ddp_sync))
+        self.dropout = float(dropout)
 
     def _dtype(self) -> torch.dtype:
         return self.encoder.blocks[0].conv.weight.dtype
@@ -155,7 +194,25 @@ class VQVAE(nn.Module):
         ops.require_device(x)
         return ops.entry_cast(x, self._dtype())
 
+    def _train_entry(self, x: torch.Tensor) -> torch.Tensor:
+        from ... import autograd as A
+
+        ops.require_device(x)
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("VQVAE training with dropout > 0 is not implemented (the fused convolution epilogues have no dropout mask); "
+                                      "construct the model with dropout=0")
+        dt = ops.compute_dtype(self._dtype())
+        if x.dtype != dt:
+            if ops.autocast_dtype() is None:
+                raise TypeError(f"input dtype {x.dtype} does not match the model dtype {self._dtype()}")
+            x = A.cast(x, dt)
+        return x
+
     def encode(self, images: torch.Tensor) -> torch.Tensor:
+        if wants_grad(self, images):
+            from ... import autograd as A
+
+            return A.from_arena(self.encoder.run_train(A.to_arena(self._train_entry(images))))
         images = self._check(images)
         with torch.no_grad():
             return ops.to_channels_first(self.encoder.run(ops.to_channels_last(images)))
@@ -165,6 +222,10 @@ class VQVAE(nn.Module):
         return x, x_loss
 
     def decode(self, quantizations: torch.Tensor) -> torch.Tensor:
+        if wants_grad(self, quantizations):
+            from ... import autograd as A
+
+            return A.from_arena(self.decoder.run_train(A.to_arena(self._train_entry(quantizations).contiguous())))
         quantizations = self._check(quantizations)
         with torch.no_grad():
             return ops.to_channels_first(self.decoder.run(ops.to_channels_last(quantizations)))

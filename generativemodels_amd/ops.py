@@ -442,6 +442,24 @@ def resample2x(x: torch.Tensor, mode: str) -> torch.Tensor:
     return out
 
 
+def phase2x(x: torch.Tensor, phase: Sequence[int]) -> torch.Tensor:
+    """x[:, r0::2, r1::2, ...] of an arena tensor (N, *spatial, C) as a dense arena tensor: the phase image `phase` = one parity per spatial axis
+    of the 2x sub-lattice (2-D or 3-D)."""
+    require_device(x)
+    sp = list(x.shape[1:-1])
+    nd = len(sp)
+    if nd not in (2, 3) or len(phase) != nd or any(r not in (0, 1) for r in phase):
+        raise ValueError("phase2x needs 2-D or 3-D data and one parity (0 / 1) per spatial axis")
+    d, h, w = ([1] * (3 - nd) + sp)
+    r = [0] * (3 - nd) + [int(v) for v in phase]
+    osp = [(s_ - r_ + 1) // 2 for s_, r_ in zip(sp, phase)]
+    x = x if arena_ld(x) >= x.shape[-1] else x.contiguous()
+    out = torch.empty((x.shape[0], *osp, x.shape[-1]), dtype=x.dtype, device=x.device)
+    check(lib().gm_phase2x(x.data_ptr(), arena_ld(x), out.data_ptr(), arena_ld(out), x.shape[0], x.shape[-1], d, h, w, 1 if nd == 3 else 0,
+                           (r[0] << 2) | (r[1] << 1) | r[2], dt_code(x.dtype), _stream()), "gm_phase2x")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # normalisation
 # ------------------------------------------------------------------------------------------------------------------------
@@ -1180,6 +1198,8 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, kernel, stride=1, padding=0, o
     k, s_, p_ = tup(kernel), tup(stride), tup(padding)
     if len(set(k)) != 1 or len(set(s_)) != 1:
         raise ValueError("conv_wgrad: kernel and stride must be the same on every axis")
+    if k[0] == 4 and s_[0] == 2 and nsp in (2, 3) and all(0 <= v <= 2 for v in p_):
+        return _conv_wgrad_k4s2(x, gy, p_, out, accumulate)
     vec = 16 // x.element_size()
     if x.shape[-1] % vec or gy.shape[-1] % vec or arena_ld(x) % vec or arena_ld(gy) % vec or x.data_ptr() % 16 or gy.data_ptr() % 16:
         # ragged channel counts (the 1-channel input / output convolutions): zero-pad the channels to one 16-byte vector
@@ -1232,6 +1252,68 @@ def conv_wgrad(x: torch.Tensor, gy: torch.Tensor, kernel, stride=1, padding=0, o
                                                           shape=f"{cin}->{cout} k{k} s{s_} out{tuple(gy.shape[1:-1])}"),
            lambda: check(lib().gm_conv_wgrad(C.byref(d), _stream()), "gm_conv_wgrad"))
     return out
+
+
+def stride2_phase_taps(pad: int) -> dict:
+    """Kernel 4, stride 2, low padding `pad` (0..2), per axis: {tap parity r: (input phase rho, tap index t of a 3-tap / padding-1 stride-1
+    weight gradient over that phase image that holds kernel tap k = r, the one that holds k = r + 2)}.  y[o] = sum_k W[k] x[2 o + k - pad]; with
+    k = 2 j + r the input index is 2 (o + j + sigma) + rho, rho = (r - pad) mod 2, sigma = (r - pad - rho) / 2 in {-1, 0}: tap j of phase image
+    rho at offset o + j + sigma = tap t = j + sigma + 1 of a 3-tap stride-1 stencil around o.  Pure host logic (tested on CPU)."""
+    out = {}
+    for r in (0, 1):
+        e = r - pad
+        rho = e % 2
+        sigma = (e - rho) // 2
+        assert sigma in (-1, 0)
+        out[r] = (rho, sigma + 1, sigma + 2)
+    return out
+
+
+def _conv_wgrad_k4s2(x, gy, pads, out, accumulate):
+    """Weight gradient of a k = 4 / stride-2 convolution (the VQ-VAE down-sampling convolutions and, with the operands exchanged, its
+    ConvTranspose up-sampling: vqvae.py:127-150,244-261) from the MFMA weight-gradient kernel of 3-tap stride-1 convolutions: per tap-parity
+    class r (2^d of them) ONE launch over the phase image x[rho::2] (gm_phase2x) yields the 2^d taps k = 2 j + r of that class as a sub-block of
+    its 3^d result (stride2_phase_taps).  27/8 of the minimal multiply-adds on a 600-700 TFLOP/s kernel; fixed-order sums (deterministic)."""
+    nsp = x.dim() - 2
+    cin, cout = x.shape[-1], gy.shape[-1]
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing gradient tensor")
+        res = torch.empty((cout, cin) + (4,) * nsp, dtype=torch.float32, device=x.device)
+    else:
+        if tuple(out.shape) != (cout, cin) + (4,) * nsp or out.dtype != torch.float32:
+            raise ValueError("conv_wgrad: out must be a contiguous fp32 [Cout, Cin, *kernel] tensor")
+        res = out
+    taps = [stride2_phase_taps(p) for p in pads]
+    with torch.no_grad():
+        for cls in range(1 << nsp):
+            r = [(cls >> (nsp - 1 - a)) & 1 for a in range(nsp)]
+            xp = phase2x(x, [taps[a][r[a]][0] for a in range(nsp)])
+            g3 = conv_wgrad(xp, gy, 3, 1, 1)  # [Cout, Cin, 3 (x nsp)]
+            src = g3[(slice(None), slice(None)) + tuple(slice(taps[a][r[a]][1], taps[a][r[a]][2] + 1) for a in range(nsp))]
+            dst = res[(slice(None), slice(None)) + tuple(slice(r[a], 4, 2) for a in range(nsp))]
+            # (the 2^d strided sub-blocks of a [Cout, Cin, 4, 4(, 4)] tensor: a scatter of the kernel's outputs into the parameter layout)
+            dst.add_(src) if (accumulate and out is not None) else dst.copy_(src)
+    return res
+
+
+def act_backward(y: torch.Tensor, gy: torch.Tensor, act: str) -> torch.Tensor:
+    """gy * act'(z) from the activation's OUTPUT y = act(z) for activations whose derivative is a function of the output sign: ReLU
+    (y > 0 <=> z > 0).  The fused convolution epilogues store only y; this is the first step of their backward."""
+    if act != "relu":
+        raise NotImplementedError(f"activation '{act}' has no backward kernel (training covers none / relu epilogues)")
+    require_device(y, gy)
+    if y.shape != gy.shape or y.dtype != gy.dtype:
+        raise ValueError("act_backward: gy must match y")
+    y, gy = y.contiguous(), gy.contiguous()
+    n, c = y.shape[0], y.shape[-1]
+    v = rows_of(y) // max(n, 1)
+    one = torch.ones((n, c), dtype=torch.float32, device=y.device)
+    zero = torch.zeros((n, c), dtype=torch.float32, device=y.device)
+    dx = torch.empty_like(y)
+    check(lib().gm_gn_bwd_apply(y.data_ptr(), arena_ld(y), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), one.data_ptr(), zero.data_ptr(), c,
+                                one.data_ptr(), zero.data_ptr(), zero.data_ptr(), n, v, c, ACT[act], dt_code(y.dtype), _stream()), "gm_gn_bwd_apply")
+    return dx
 
 
 def bias_grad(gy: torch.Tensor, per_sample: bool = False) -> torch.Tensor:

@@ -89,6 +89,11 @@ int gm_nearest_resize(const void* x, long long x_ld, void* y, long long y_ld, in
 /* mode 0: nearest 2x up, mode 1: 2x average pool (ResnetBlock up/down path, diffusion_model_unet.py:635-639,674-682) */
 int gm_resample2x(const void* src, long long src_ld, void* dst, long long dst_ld, int N, int C, int Di, int Hi, int Wi,
                   int act_d, int mode, int dtype, void* stream);
+/* dst[n][d][h][w][c] = src[n][2 d + rd][2 h + rh][2 w + rw][c], phase = (rd << 2) | (rh << 1) | rw, extents (X - r + 1) / 2: the 2^d phase
+ * images of a stride-2 sub-lattice.  The weight gradient of an EVEN-kernel stride-2 convolution (VQ-VAE k = 4 / s = 2 / p = 1 down- and
+ * up-sampling, vqvae.py:127-150,244-261, under torch autograd) is assembled from stride-1 weight gradients over them. */
+int gm_phase2x(const void* src, long long src_ld, void* dst, long long dst_ld, int N, int C, int Di, int Hi, int Wi, int act_d, int phase,
+               int dtype, void* stream);
 /* get_timestep_embedding (diffusion_model_unet.py:461-485): [cos | sin], zero pad if dim is odd */
 int gm_timestep_embedding(const float* timesteps, void* out, int B, int dim, float max_period, int dtype, void* stream);
 /* MONAI MLPBlock(act="GEGLU") gate (diffusion_model_unet.py:211): out = x[:, :inner] * gelu(x[:, inner:]) */
@@ -295,7 +300,7 @@ long long gm_conv_wgrad_workspace_bytes(const GmWgradDesc* d);
 /* dW[co][ci][tap] = sum_v gy[v][co] * x[v * stride - pad + tap][ci] (torch.nn.grad.conv*_weight); split-K partial sums reduced in
  * a fixed order: deterministic */
 int gm_conv_wgrad(const GmWgradDesc* d, void* stream);
-/* GroupNorm (+ SiLU when act = 1) backward for y = act(x * scale[n][c] + shift[n][c]) (nn.GroupNorm + nn.SiLU,
+/* GroupNorm (+ SiLU when act = 1, ReLU when act = 2) backward for y = act(x * scale[n][c] + shift[n][c]) (nn.GroupNorm + nn.SiLU,
  * diffusion_model_unet.py:623-690).  With g = gy * act'(x * scale + shift):
  *   gm_gn_bwd_stats     out[block][n][c] = {sum_v g, sum_v g x} over the rows of the block: fp64 [gm_gn_bwd_stats_slots(N, V)][N][C][2],
  *                       one plain store each (no atomics, no zero fill; summed in a fixed order by gm_gn_bwd_finalize: bit-reproducible)

@@ -61,8 +61,9 @@ def main():
             if a.grad is None:
                 assert b.grad is None and "proj_attn" in name, name
                 continue
-            # (not torch.equal: the GroupNorm-backward statistics are fp64 atomics, two replicas may differ in the last fp32 bit)
-            assert b.grad is not None and torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6), f"step {step}: gradient of {name} differs after the RCCL exchange"
+            # bitwise: the backward pass has no atomics (stored per-block partials, fixed-order sums), the sum over ONE rank and the division
+            # by 1 are exact, and a gradient accumulated by the kernel into a zeroed bucket view is the kernel's value
+            assert b.grad is not None and torch.equal(a.grad, b.grad), f"step {step}: gradient of {name} differs after the RCCL exchange"
             assert b.grad.data_ptr() == red._view[id(b)].data_ptr()  # the gradient lives in its bucket
             checked += 1
         assert checked > 40

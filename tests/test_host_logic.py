@@ -526,3 +526,37 @@ def test_autocast_region_selects_the_compute_dtype_and_wants_grad_follows_the_in
         assert not _blocks.wants_grad(m.eval(), x)   # eval + trainable parameters + gradients enabled: inference path, said out loud once
         assert not _blocks.wants_grad(m.eval(), x)
     assert len([i for i in w if "without grad_fn" in str(i.message)]) == 1
+
+
+def test_stride2_phase_tap_tables_reproduce_a_k4_stride2_weight_gradient():
+    """ops.stride2_phase_taps (the weight gradient of a kernel-4 / stride-2 convolution assembled from 3-tap stride-1 weight gradients over the
+    phase images of its input: VQ-VAE down- / up-sampling, vqvae.py:127-150,244-261) against a brute-force 1-D weight gradient, every
+    padding the decomposition admits, even and odd extents."""
+    import numpy as np
+
+    from generativemodels_amd import ops
+
+    rng = np.random.default_rng(1)
+    for pad in (0, 1, 2):
+        for X in (10, 11):
+            O = (X + 2 * pad - 4) // 2 + 1
+            x, gy = rng.standard_normal(X), rng.standard_normal(O)
+            want = np.zeros(4)
+            for o in range(O):
+                for k in range(4):
+                    i = 2 * o + k - pad
+                    if 0 <= i < X:
+                        want[k] += gy[o] * x[i]
+            got = np.zeros(4)
+            taps = ops.stride2_phase_taps(pad)
+            for r in (0, 1):
+                rho, t0, t1 = taps[r]
+                ph = x[rho::2]
+                g3 = np.zeros(3)   # a 3-tap, padding-1, stride-1 weight gradient over the phase image
+                for o in range(O):
+                    for t in range(3):
+                        i = o + t - 1
+                        if 0 <= i < len(ph):
+                            g3[t] += gy[o] * ph[i]
+                got[r], got[r + 2] = g3[t0], g3[t1]
+            assert np.allclose(got, want), (pad, X)
