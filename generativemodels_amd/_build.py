@@ -57,8 +57,9 @@ def _stale(target: str, deps: list[str]) -> bool:
 EXTRA_FLAGS = {"elementwise.hip": ["-ffp-contract=off"]}
 
 
-# bench-only variants: extra defines, their own object directory and library name (the product library is never built with them)
-VARIANTS = {"timeline": ["-DGM_CONV_TIMELINE"], "ablate": ["-DGM_CONV_ABLATE"], "timeline_ablate": ["-DGM_CONV_TIMELINE", "-DGM_CONV_ABLATE"]}
+# bench-only variants: extra defines, their own object directory and library name (the product library is never built with them).  The table
+# lives in _build_variants.py, which is NOT a dependency of the objects: adding an experiment does not rebuild the product library.
+from ._build_variants import VARIANTS  # noqa: E402
 _variant = None
 
 

@@ -1,0 +1,10 @@
+"""Bench-only build variants of libgmamd.so (python -m generativemodels_amd._build --variant NAME -> lib/libgmamd_NAME.so, loaded through
+GM_NATIVE_LIB by the tools that need them): extra defines per variant.  The product library is never built with any of them."""
+VARIANTS = {
+    "timeline": ["-DGM_CONV_TIMELINE"],                      # tools/conv_timeline.py: cycle stamps per phase of the LDS-DMA convolution
+    "ablate": ["-DGM_CONV_ABLATE"],                          # tools/ablate_conv.py: operand traffic / epilogue removable by debug flags
+    "timeline_ablate": ["-DGM_CONV_TIMELINE", "-DGM_CONV_ABLATE"],
+    "eb": ["-DGM_CONV_EARLY_BARRIER"],                       # round 3 A/B: the tap-group barrier one tap earlier (conv_dma.hip)
+    "eb_timeline": ["-DGM_CONV_EARLY_BARRIER", "-DGM_CONV_TIMELINE"],
+    "ebi": ["-DGM_CONV_EARLY_BARRIER", "-DGM_CONV_DMA_INTERLEAVE"],  # ... plus the panel request's DMA instructions spread over a tap's MFMAs
+}

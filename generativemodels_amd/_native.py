@@ -103,6 +103,7 @@ PROTOTYPES = {
     "gm_spade_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_gn_channel_stats": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp, C.c_int, c_vp]),
     "gm_gn_channel_stats_slots": (c_ll, [c_vp, c_ll, c_ll, C.c_int, C.c_int]),
+    "gm_stats_compact_slots": (C.c_int, []),
     "gm_stats_compact": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
     "gm_gn_finalize_channels": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gm_layernorm": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_float, C.c_int, c_vp]),
@@ -115,6 +116,7 @@ PROTOTYPES = {
     "gm_packed_conv_weight_elems": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       c_vp]),
+    "gm_pack_subpixel_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_attention_max_head_dim": (C.c_int, []),
     "gm_linear_rows": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_decode_scratch_bytes": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -301,7 +301,12 @@ extern "C" int gm_conv_cin_launch(const GmConvDesc* dp, unsigned nblocks, void* 
 extern "C" int gm_conv_cout1_eligible(const GmConvDesc* d);
 extern "C" long long gm_conv_cout1_lds_bytes();
 extern "C" int gm_conv_cout1_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
-static inline bool conv_is_edge(int cfg) { return cfg == CONV_CFG_CIN || cfg == CONV_CFG_COUT1; }
+// cfg 20 = C_out == 1, marching along depth: a work-group walks 2^ltd planes of an 8 x 2^ltw output column (conv_edge.hip)
+#define CONV_CFG_COUT1M 20
+extern "C" int gm_conv_cout1m_eligible(const GmConvDesc* d);
+extern "C" long long gm_conv_cout1m_lds_bytes(const GmConvDesc* d);
+extern "C" int gm_conv_cout1m_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
+static inline bool conv_is_edge(int cfg) { return cfg == CONV_CFG_CIN || cfg == CONV_CFG_COUT1 || cfg == CONV_CFG_COUT1M; }
 
 static bool conv_fast_eligible(const GmConvDesc& d) {
   const int vecw = d.dtype == GM_F32 ? 4 : 8;
@@ -319,6 +324,7 @@ extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
   if (cfg == 19) { *bm = 512; *bn = 128; return 0; }
   if (conv_is_dma(cfg) || cfg == CONV_CFG_CIN) { *bm = 256; *bn = 64; return 0; }
   if (cfg == CONV_CFG_COUT1) { *bm = 256; *bn = 16; return 0; }
+  if (cfg == CONV_CFG_COUT1M) { *bm = 256; *bn = 16; return 0; }  // (per plane; the depth extent of a work-group is GmConvDesc.ltd)
   if (conv_is_fast(cfg)) { int t = 0; return gm_conv_fast_variant_geometry(conv_fast_variant(cfg), bm, bn, &t); }
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
   *bm = kCfgs[cfg].WM * kCfgs[cfg].MF * 16;
@@ -357,6 +363,7 @@ extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes(gm_conv_dma_variant(d->cfg)) : -1;
   if (d && d->cfg == CONV_CFG_CIN) return gm_conv_cin_eligible(d) ? gm_conv_cin_lds_bytes(d) : -1;
   if (d && d->cfg == CONV_CFG_COUT1) return gm_conv_cout1_eligible(d) ? gm_conv_cout1_lds_bytes() : -1;
+  if (d && d->cfg == CONV_CFG_COUT1M) return gm_conv_cout1m_eligible(d) ? gm_conv_cout1m_lds_bytes(d) : -1;
   if (d && conv_is_fast(d->cfg)) {
     if (!conv_fast_eligible(*d)) return -1;
     return gm_conv_fast_lds_bytes(d, conv_fast_bn(d->cfg));
@@ -501,12 +508,12 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   if (d.N == 0 || d.Do == 0 || d.Ho == 0 || d.Wo == 0) return 0;
   int bm = 0, bn = 0;
   gm_conv_cfg_tile(d.cfg, &bm, &bn);
-  GM_REQUIRE((1 << (d.ltd + d.lth + d.ltw)) == bm, "tile dims do not match the configuration");
+  GM_REQUIRE(d.cfg == CONV_CFG_COUT1M || (1 << (d.ltd + d.lth + d.ltw)) == bm, "tile dims do not match the configuration");
   GM_REQUIRE(!fast || conv_fast_eligible(d), "geometry is not eligible for the fast stride-1 kernel");
   GM_REQUIRE(!dma || gm_conv_dma_eligible(dp), "geometry is not eligible for the LDS-DMA 3x3x3 kernel");
   GM_REQUIRE(dma || d.skip_x[0] == nullptr, "the fused 1x1 shortcut needs the LDS-DMA kernel (cfg 11)");
   GM_REQUIRE(dma || d.x2 == nullptr, "a second input source (virtual channel concatenation) needs an LDS-DMA configuration");
-  GM_REQUIRE(!edge || (d.cfg == CONV_CFG_CIN ? gm_conv_cin_eligible(dp) : gm_conv_cout1_eligible(dp)),
+  GM_REQUIRE(!edge || (d.cfg == CONV_CFG_CIN ? gm_conv_cin_eligible(dp) : (d.cfg == CONV_CFG_COUT1M ? gm_conv_cout1m_eligible(dp) : gm_conv_cout1_eligible(dp))),
              "geometry is not eligible for the C_in<=4 / C_out==1 kernels");
   const long long smem = gm_conv_lds_bytes(dp);
   GM_REQUIRE(smem > 0 && smem <= 160 * 1024, "tile needs more than 160 KiB of LDS");
@@ -523,7 +530,8 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (edge) {
-    rc = d.cfg == CONV_CFG_CIN ? gm_conv_cin_launch(dp, (unsigned)nblocks, stream) : gm_conv_cout1_launch(dp, (unsigned)nblocks, stream);
+    rc = d.cfg == CONV_CFG_CIN ? gm_conv_cin_launch(dp, (unsigned)nblocks, stream)
+                               : (d.cfg == CONV_CFG_COUT1M ? gm_conv_cout1m_launch(dp, (unsigned)nblocks, stream) : gm_conv_cout1_launch(dp, (unsigned)nblocks, stream));
     GM_REQUIRE(rc == 0, "unsupported dtype");
     GM_LAUNCH_CHECK();
   }
@@ -606,3 +614,62 @@ extern "C" int gm_pack_conv_weight(const void* src, int src_dtype, void* dst, in
   else GM_FAIL(-2, "unsupported dtype");
   GM_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 8 parity images of 2x2x2 kernels of a sub-pixel convolution (conv_dma.hip, in_mode 3), packed back to back, in ONE launch straight
+// from the parameter: image par = (pd << 2) | (ph << 1) | pw, sub-tap (a, b, c) of an image = the SUM of the source taps selected by the
+// per-axis bit masks m[parity][sub-tap] (bit k = source tap k of the K-tap kernel; fp32 sum, rounded once to the compute dtype):
+//   nearest-2x + 3x3x3 (Upsample, diffusion_model_unet.py:572-585): parity 0 -> ({0}, {1, 2}), parity 1 -> ({0, 1}, {2});
+//   stride-2 transposed convolution / stride-2 data gradient (vqvae.py:244-261, autoencoderkl.py:54-63, torch autograd through a stride-2
+//   nn.Conv3d): one tap or none per sub-tap (ops.stride2_subpixel_taps), swap_io = 1: the source is [Cin][Cout][K][K][K].
+// Round 2 built every image with torch slicing + one pack launch per parity (~80 tiny launches per strided convolution and training step).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void pack_subpixel_weight_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int Cout, int Cin, int K, int swap_io,
+                                                                  int m00, int m01, int m10, int m11, int BK, long long per_image, long long total) {
+  const int cout_pad = (Cout + 15) & ~15;
+  const int K3 = K * K * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int par = (int)(i / per_image);
+    long long r = i - (long long)par * per_image;
+    const int kk = (int)(r % BK); r /= BK;
+    const int co = (int)(r % cout_pad); r /= cout_pad;
+    const int tap = (int)(r % 8);
+    const int chunk = (int)(r / 8);
+    const int ci = chunk * BK + kk;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+      const int pd = (par >> 2) & 1, ph = (par >> 1) & 1, pw = par & 1;
+      const int a = (tap >> 2) & 1, b = (tap >> 1) & 1, c = tap & 1;
+      const int md = pd ? (a ? m11 : m10) : (a ? m01 : m00), mh = ph ? (b ? m11 : m10) : (b ? m01 : m00), mw = pw ? (c ? m11 : m10) : (c ? m01 : m00);
+      const long long base = (swap_io ? ((long long)ci * Cout + co) : ((long long)co * Cin + ci)) * K3;
+      for (int kd = 0; kd < K; ++kd)
+        if ((md >> kd) & 1)
+          for (int kh = 0; kh < K; ++kh)
+            if ((mh >> kh) & 1)
+              for (int kw = 0; kw < K; ++kw)
+                if ((mw >> kw) & 1) v += ElemIO<TS>::ld(src + base + (kd * K + kh) * K + kw);
+    }
+    ElemIO<TD>::st(dst + i, v);
+  }
+}
+
+extern "C" int gm_pack_subpixel_weight(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin, int K, int swap_io, int m00,
+                                       int m01, int m10, int m11, void* stream) {
+  GM_REQUIRE(src && dst, "null pointer");
+  GM_REQUIRE(K >= 1 && K <= 4 && ((m00 | m01 | m10 | m11) >> K) == 0, "kernel extent 1..4, masks over its taps");
+  const int BK = dst_dtype == GM_F32 ? 16 : 32;
+  const long long per_image = gm_packed_conv_weight_elems(Cout, Cin, 2, 2, 2, dst_dtype), total = 8 * per_image;
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipStream_t st = (hipStream_t)stream;
+#define GM_PSW(TS, TD) pack_subpixel_weight_kernel<TS, TD><<<(int)g, 256, 0, st>>>((const TS*)src, (TD*)dst, Cout, Cin, K, swap_io, m00, m01, m10, m11, BK, per_image, total)
+  if (src_dtype == GM_F32 && dst_dtype == GM_F32) GM_PSW(float, float);
+  else if (src_dtype == GM_F32 && dst_dtype == GM_BF16) GM_PSW(float, bf16_raw);
+  else if (src_dtype == GM_BF16 && dst_dtype == GM_F32) GM_PSW(bf16_raw, float);
+  else if (src_dtype == GM_BF16 && dst_dtype == GM_BF16) GM_PSW(bf16_raw, bf16_raw);
+  else GM_FAIL(-2, "unsupported dtype");
+#undef GM_PSW
+  GM_LAUNCH_CHECK();
+}
+

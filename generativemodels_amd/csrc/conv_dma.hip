@@ -440,14 +440,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane_w & 3) ^ dma_swz(row)) << 4)) : -1;
     }
   };
-  auto issue_w = [&](int t, int buf) __attribute__((always_inline)) {  // WPW instructions per wave, every wave
+  auto issue_w_pieces = [&](int t, int buf, int h0, int h1) __attribute__((always_inline)) {  // pieces [h0, h1) of the WPW instructions per wave
 #ifdef GM_CONV_ABLATE
     if (p.debug_flags & 512) return;  // bench-only: no weight traffic (results are garbage)
 #endif
     const char* panel = wbase + (long long)t * G * cout_pad * DMA_ROWB;  // (chunk*27 + 3*grp) * cout_pad rows
     const unsigned dst = lds0 + PATCH_BYTES + (unsigned)buf * WBUF_BYTES;
 #pragma unroll
-    for (int h = 0; h < WPW; ++h) {
+    for (int h = h0; h < h1; ++h) {
       const char* src = wsrc[h] >= 0 ? panel + wsrc[h] : zero + ((lane & 3) << 4);
       if (WGEN) {
         dma16(src, dst + (unsigned)(16 * (wave + NW * h)) * DMA_ROWB);
@@ -463,6 +463,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       }
     }
   };
+  auto issue_w = [&](int t, int buf) __attribute__((always_inline)) { issue_w_pieces(t, buf, 0, WPW); };  // WPW instructions per wave, every wave
 
 
   // ---- LDS regions of the epilogue ---------------------------------------------------------------------------------------------------------
@@ -590,6 +591,76 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         };
         constexpr int NMMA = MF * 4 * (sizeof(T) == 2 ? 1 : 4), NRD = MF + 4;
         static_assert(G == 3 || G == 2, "taps per panel");
+#ifdef GM_CONV_EARLY_BARRIER
+        // Round 3: the group barrier one tap EARLIER.  The MFMA pipe holds no queue -- a wave's instruction stream advances in step with its
+        // MFMAs -- so whatever a wave waits for at the end-of-group barrier is exposed unless the partner work-group's wave has MFMAs to issue.
+        // The round-2 order (below) reached the barrier right after issuing the last tap's eight operand reads and had to retire them there
+        // (`lgkmcnt(0)`: ~100-150 cycles of LDS latency per group), because the panel request that followed the barrier overwrote the ring slot
+        // those reads came from one group later.  Here the barrier sits between the MFMAs of tap 0 and the reads of tap 2: the only reads in
+        // flight are tap 1's, issued a whole tap (256 MFMA cycles) earlier, the wait is free, and the panel request moves behind it:
+        //   read tap 1 | MFMA tap 0 | wait panel t+1 + barrier B_g | request panel t+2 -> slot (g-1) % RING | read tap 2 | MFMA tap 1 |
+        //   read tap 0 of group g+1 | MFMA tap 2
+        // B_g: every wave has retired its reads of group g-1 (program order + lgkmcnt(0)), so slot (g-1) % RING is free; panel t+1 (requested
+        // behind B_{g-1}, one full group ago) has landed for every wave (vmcnt(0): nothing newer is in flight) and is visible behind the barrier.
+#pragma unroll
+        for (int g = 0; g < NGROUPS; ++g) {
+          const int t = chunk * NGROUPS + g;
+          const int X = (g * G) & 1, Y = X ^ 1;
+          const int LASTSET = (g * G + G - 1) & 1, NEXTSET = ((g + 1) * G) & 1;
+          if (g == 0) read_tap(0, 0, X);
+          read_tap(g, 1, Y);
+          mma_tap(X);
+          if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+          dma_wait<0>();
+          __builtin_amdgcn_s_barrier();
+#ifdef GM_CONV_DMA_INTERLEAVE
+          // the panel request's WPW LDS-DMA instructions (each ~8 issue slots with its address select and M0 hand-over) one at a time between the
+          // quarters of tap 1's MFMAs instead of in one lump of ~24 instructions during which the matrix pipe -- which holds no queue -- runs dry
+          const bool want_w = g < NGROUPS - 2 || !last_chunk;
+          if (G == 3) {
+            read_tap(g, 2, X);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[Y][nf], xf[Y][mf], acc[nf][mf]);
+              if (want_w && nf < WPW) issue_w_pieces(t + 2, (g + 2) % RING, nf, nf + 1);
+            }
+            if (want_w && WPW > 4) issue_w_pieces(t + 2, (g + 2) % RING, 4, WPW);
+          } else if (want_w) {
+            issue_w(t + 2, (g + 2) % RING);
+          }
+#else
+          if (g < NGROUPS - 2 || !last_chunk) issue_w(t + 2, (g + 2) % RING);
+          if (G == 3) {
+            read_tap(g, 2, X);
+            mma_tap(Y);
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+          }
+#endif
+          if (g == NGROUPS - 1) {
+            if (!last_chunk) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
+              issue_patch(chunk + 1);
+              if (pre) load_affine(chunk + 1);
+              dma_wait<0>();                 // patch + the panel in flight
+              if (pre) transform_patch();
+              __builtin_amdgcn_s_barrier();
+            }
+          } else {
+            read_tap(g + 1, 0, NEXTSET);     // panel t+1: landed and published by B_g
+          }
+          mma_tap(LASTSET);
+          if (g < NGROUPS - 1) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+          }
+          if (chunk - c_begin < 5) TL_STAMP(3 + (chunk - c_begin) * 10 + g);
+        }
+#else
 #pragma unroll
         for (int g = 0; g < NGROUPS; ++g) {
           const int t = chunk * NGROUPS + g;
@@ -633,6 +704,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
           }
           if (chunk - c_begin < 5) TL_STAMP(3 + (chunk - c_begin) * 10 + g);  // after the barrier that ends group g (g = 8: incl. the chunk boundary)
         }
+#endif
       } else {
 #pragma unroll
       for (int g = 0; g < NGROUPS; ++g) {

@@ -287,6 +287,199 @@ __global__ __launch_bounds__(256, 2) void conv_cout1_kernel(const GmConvDesc p) 
 }
 
 // -----------------------------------------------------------------------------------------------------------------------
+// C_out == 1, marching along depth (round 3; configuration 20).  conv_cout1_kernel above reads a 6x6x18 halo per 4x4x16 tile -- every
+// input row 2.5 times -- straight into registers with at most two fragment batches in flight and 8 waves per CU: 1.0 TB/s, 13 % of the HBM roof
+// it is graded against.  Here a work-group owns an 8 x TWO column of the output and walks a segment of DS planes:
+//   * input plane d (its (8 + 2) x (TWO + 2) halo rows, whole channel rows) is staged by the LDS-DMA engine into one of two raw buffers while
+//     plane d - 1 is processed: every row is fetched once per work-group (1.33x halo in H / W, (DS + 2) / DS in depth), whole 128-byte rows
+//     per DMA piece, nothing waits for HBM inside the plane loop;
+//   * phase 1: GroupNorm-apply + SiLU on the raw rows (each halo voxel once per work-group) -> Z[tap][row] = sum_c w[tap][c] a[row][c] for all
+//     27 taps by MFMA (taps = the GEMM M dimension, as above);
+//   * phase 2: output plane o needs Z of input planes o - 1 (kd = 0), o (kd = 1), o + 1 (kd = 2): two running sums per output voxel live in
+//     registers across the walk, each plane adds its nine-tap gathers in the ORDER of the 27-point sum of the tile kernel (bias, taps 0..26), so
+//     the two kernels are bit-identical.
+// LDS: 2 raw planes + Z = 128 KiB (TWO = 32, 128-byte rows) / 119 KiB (TWO = 16, 256-byte rows): one work-group of 4 waves per CU; the grid is
+// sized by the host (depth segments of 2^ltd planes) to at least one work-group per CU.  (reference: diffusion_model_unet.py:1853-1867)
+__device__ __attribute__((aligned(64))) unsigned int gm_edge_zero_row[16] = {0};  // the source of every padding row of the marching kernel
+
+template <typename T, int KS, int LTW>  // KS = C_in / BK 64-byte channel steps (row = KS x 64 bytes); 8 x 2^LTW outputs per plane
+__global__ __launch_bounds__(256, 1) void conv_cout1_march_kernel(const GmConvDesc p) {
+  constexpr int VECW = ConvTraits<T>::VECW;
+  constexpr int BK = ConvTraits<T>::BK;
+  constexpr int TH = 8, TWO = 1 << LTW, PH = TH + 2, PW = TWO + 2, PROWS = PH * PW;
+  constexpr int NFRAG = (PROWS + 15) / 16, PROWS_PAD = NFRAG * 16;   // 22 fragments / 352 rows (TWO = 32), 12 / 192 (TWO = 16)
+  constexpr int ROWB = KS * 64, SLOTS = ROWB / 16, RPP = 1024 / ROWB;  // bytes / 16-byte slots per row, rows per 1 KiB DMA piece
+  static_assert(ROWB == 128 || ROWB == 256, "whole rows of 128 or 256 bytes");
+  constexpr int NPIECE = PROWS_PAD / RPP, PPW = (NPIECE + 3) / 4;    // DMA pieces per plane / per wave
+  constexpr int RAW_BYTES = PROWS_PAD * ROWB;
+  constexpr int ZP = PROWS_PAD + 4;                                  // floats per Z row: 4 ZP = 16 (mod 32): the four tap rows of a store hit distinct banks
+  constexpr int NTAP = 27, FPW = (NFRAG + 3) / 4;
+  constexpr bool PRECISE = sizeof(T) == 4;
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  float* Z = reinterpret_cast<float*>(smem + 2 * RAW_BYTES);         // [27][ZP]
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int DS = 1 << p.ltd;
+  const int ntd = (p.Do + DS - 1) / DS, nth = (p.Ho + TH - 1) / TH, ntw = (p.Wo + TWO - 1) / TWO;
+  unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+  const int tw_i = b % ntw; b /= ntw;
+  const int th_i = b % nth; b /= nth;
+  const int td_i = b % ntd; b /= ntd;
+  const int n = b;
+  const int d_begin = td_i * DS, d_end = min(p.Do, d_begin + DS), oh0 = th_i * TH, ow0 = tw_i * TWO;
+  const int D = p.Ds, H = p.Hs, W = p.Ws;  // stride 1, padding 1: output extents = input extents (host-checked)
+
+  // ---- weights: A fragments [tap fragment 0/1][channel step], rows = taps (27 of 32) ------------------------------------------------
+  const T* wsrc = reinterpret_cast<const T*>(p.w);  // packed [chunk][tap][cout_pad = 16][BK], output channel 0
+  uint4 wf[2][KS];
+#pragma unroll
+  for (int tf = 0; tf < 2; ++tf)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int tap = tf * 16 + l15;
+      const bool ok = tap < NTAP;
+      const uint4 v = *reinterpret_cast<const uint4*>(wsrc + ((long long)(s * NTAP + (ok ? tap : 0)) * 16) * BK + q * VECW);
+      wf[tf][s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+  float sc[KS][VECW], sh[KS][VECW];
+  if (p.pre_scale) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int i = 0; i < VECW; ++i) {
+        const int c = s * BK + q * VECW + i;
+        sc[s][i] = p.pre_scale[(long long)n * p.Cin + c];
+        sh[s][i] = p.pre_shift[(long long)n * p.Cin + c];
+      }
+  }
+
+  // ---- this lane's DMA sources: piece i = wave + 4 jj covers rows i RPP .. + RPP - 1, lane -> (row, LDS slot); the bank swizzle is applied to
+  // the SOURCE (LDS slot s of row r receives channel slot s ^ swz(r)), padding rows read a zero page -----------------------------------
+  auto swz = [](int r) { return ROWB == 128 ? (r >> 1) & 7 : r & 15; };
+  int hw_off[PPW];   // voxel offset of this lane's row within an input plane, -1 for a padding row
+  int csl[PPW];      // byte offset of the channel slot this lane fetches
+#pragma unroll
+  for (int jj = 0; jj < PPW; ++jj) {
+    const int piece = wave + 4 * jj;
+    const int r = piece * RPP + lane / SLOTS, slot = lane % SLOTS;
+    const int ph = r / PW, pw = r - ph * PW;
+    const int h = oh0 - 1 + ph, w = ow0 - 1 + pw;
+    const bool ok = (piece < NPIECE) & (r < PROWS) & (h >= 0) & (h < H) & (w >= 0) & (w < W);
+    hw_off[jj] = ok ? h * W + w : -1;
+    csl[jj] = (slot ^ swz(r)) << 4;
+  }
+  const char* zero = reinterpret_cast<const char*>(gm_edge_zero_row);
+  const char* xbase = reinterpret_cast<const char*>(p.x);
+  const long long rowb = p.x_ld * (long long)sizeof(T);
+  auto issue_plane = [&](int d, int buf) __attribute__((always_inline)) {
+    const long long plane0 = ((long long)n * D + d) * H * W;
+#pragma unroll
+    for (int jj = 0; jj < PPW; ++jj) {
+      if (wave + 4 * jj < NPIECE) {  // wave-uniform
+        const char* src = hw_off[jj] >= 0 ? xbase + (plane0 + hw_off[jj]) * rowb + csl[jj] : zero + ((lane & 3) << 4);
+        unsigned keep;
+        const unsigned dst = lds0 + (unsigned)buf * RAW_BYTES + (unsigned)(wave + 4 * jj) * 1024u;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+      }
+    }
+  };
+
+  // ---- this lane's fragment rows (phase 1): validity of the (h, w) position per fragment, LDS offsets ------------------------------------
+  unsigned okm = 0;
+#pragma unroll
+  for (int j = 0; j < FPW; ++j) {
+    const int r = (wave + 4 * j) * 16 + l15;
+    const int ph = r / PW, pw = r - ph * PW;
+    const int h = oh0 - 1 + ph, w = ow0 - 1 + pw;
+    if ((wave + 4 * j < NFRAG) & (r < PROWS) & (h >= 0) & (h < H) & (w >= 0) & (w < W)) okm |= 1u << j;
+  }
+  const int sw_l = swz(l15);  // fragment bases are multiples of 16 rows: the swizzle of a fragment row depends on l15 only
+
+  // ---- phase 2 bookkeeping: thread -> output (oh, ow) of the tile plane ---------------------------------------------------------------
+  const bool gth = tid < TH * TWO;
+  const int gh = tid >> LTW, gw = tid & (TWO - 1);
+  const int oh = oh0 + gh, ow = ow0 + gw;
+  const bool out_ok = gth && oh < p.Ho && ow < p.Wo;
+  float add0 = p.bias ? p.bias[0] : 0.f;
+  if (p.rowvec) add0 += p.rowvec[(long long)n * p.rowvec_bstride];
+  float s_prev = add0, s_cur = add0;  // partial sums of output planes ip - 1 and ip (see the rotation below)
+
+  const int ip0 = d_begin - 1, ip1 = d_end;  // input planes walked (inclusive)
+  auto plane_valid = [&](int d) { return d >= 0 && d < D; };
+  if (plane_valid(ip0)) issue_plane(ip0, 0);
+  for (int ip = ip0; ip <= ip1; ++ip) {
+    const int buf = (ip - ip0) & 1;
+    const bool valid = plane_valid(ip);  // block-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of plane ip have landed (and its output stores have left)
+    __syncthreads();                                  // ... everyone's; the previous plane's gather is over (Z is free), raw[buf ^ 1] has been read
+    if (ip + 1 <= ip1 && plane_valid(ip + 1)) issue_plane(ip + 1, buf ^ 1);
+    if (valid) {
+      const char* raw = smem + (size_t)buf * RAW_BYTES;
+#pragma unroll
+      for (int j = 0; j < FPW; ++j) {
+        const int f = wave + 4 * j;
+        if (f >= NFRAG) continue;  // wave-uniform
+        const int row = f * 16 + l15;
+        const bool ok = (okm >> j) & 1u;
+        f32x4_t z0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, z1 = z0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          uint4 xf = *reinterpret_cast<const uint4*>(raw + (size_t)row * ROWB + (((s * 4 + q) ^ sw_l) << 4));
+          if (p.pre_scale || p.pre_act) {
+            float v[VECW];
+            Vec16<T>::unpack(xf, v);
+            if (p.pre_scale) {
+#pragma unroll
+              for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[s][i] + sh[s][i];
+            }
+            if (p.pre_act) {
+#pragma unroll
+              for (int i = 0; i < VECW; ++i) v[i] = conv_act(v[i], p.pre_act, PRECISE);
+            }
+            xf = Vec16<T>::pack(v);
+          }
+          xf = make_uint4(ok ? xf.x : 0u, ok ? xf.y : 0u, ok ? xf.z : 0u, ok ? xf.w : 0u);  // zero padding of the ACTIVATED tensor
+          Mma<T>::run(wf[0][s], xf, z0);
+          Mma<T>::run(wf[1][s], xf, z1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Z[(4 * q + r) * ZP + row] = z0[r];
+          if (16 + 4 * q + r < NTAP) Z[(16 + 4 * q + r) * ZP + row] = z1[r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: this input plane's contribution to output planes ip + 1 (kd = 0), ip (kd = 1), ip - 1 (kd = 2, which completes it) ------
+    if (gth) {
+      float out_v = s_prev, mid = s_cur, nxt = add0;
+      if (valid) {
+        const float* zb = Z + (gh * PW + gw);
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) nxt += zb[t9 * ZP + (t9 / 3) * PW + (t9 % 3)];
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) mid += zb[(9 + t9) * ZP + (t9 / 3) * PW + (t9 % 3)];
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) out_v += zb[(18 + t9) * ZP + (t9 / 3) * PW + (t9 % 3)];
+      }
+      const int o = ip - 1;
+      if (out_ok && o >= d_begin && o < d_end) {
+        const long long vox = (((long long)n * p.Do + o) * p.Ho + oh) * p.Wo + ow;
+        float sum = out_v;
+        if (p.res) sum += ElemIO<T>::ld(reinterpret_cast<const T*>(p.res) + vox * p.res_ld);
+        ElemIO<T>::st(reinterpret_cast<T*>(p.y) + vox * p.y_ld, conv_post_act(sum, p.post_act));
+      }
+      s_prev = mid;
+      s_cur = nxt;
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------------
 static bool edge_common(const GmConvDesc* d) {
   return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
          d->in_mode == 0 && d->ltd == 2 && d->lth == 2 && d->ltw == 4 && (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 40);
@@ -311,6 +504,24 @@ extern "C" int gm_conv_cout1_eligible(const GmConvDesc* d) {
          d->x_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->stats == nullptr;
 }
 extern "C" long long gm_conv_cout1_lds_bytes() { return 27LL * 660 * 4; }
+
+// configuration 20: the marching C_out == 1 kernel.  Rows of 128 bytes walk 8 x 32 output columns (ltw = 5), rows of 256 bytes 8 x 16 (ltw = 4);
+// ltd = log2 of the planes per depth segment (2 .. 5), chosen by the host so that the grid has at least one work-group per CU.
+extern "C" int gm_conv_cout1m_eligible(const GmConvDesc* d) {
+  const int es = d->dtype == GM_F32 ? 4 : 2, vecw = 16 / es;
+  const long long rowbytes = (long long)d->Cin * es;
+  return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
+         d->pd == 1 && d->ph == 1 && d->pw == 1 && d->in_mode == 0 && d->Cout == 1 && d->Do == d->Ds && d->Ho == d->Hs && d->Wo == d->Ws && d->Ds >= 4 &&
+         (rowbytes == 128 || rowbytes == 256) && d->lth == 3 && d->ltw == (rowbytes == 128 ? 5 : 4) && d->ltd >= 2 && d->ltd <= 5 &&
+         d->x_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->stats == nullptr && d->x2 == nullptr && !d->skip_x[0] &&
+         ((d->pre_scale == nullptr) == (d->pre_shift == nullptr)) && (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 40);
+}
+extern "C" long long gm_conv_cout1m_lds_bytes(const GmConvDesc* d) {
+  const int es = d->dtype == GM_F32 ? 4 : 2;
+  const long long rowb = (long long)d->Cin * es, two = rowb == 128 ? 32 : 16;
+  const long long prows = 10 * (two + 2), pad = (prows + 15) / 16 * 16;
+  return 2 * pad * rowb + 27LL * (pad + 4) * 4;
+}
 
 template <typename KernT>
 static void edge_launch(KernT kern, const GmConvDesc& d, unsigned nblocks, size_t smem, hipStream_t st) {
@@ -352,3 +563,21 @@ extern "C" int gm_conv_cout1_launch(const GmConvDesc* dp, unsigned nblocks, void
   }
   return -2;
 }
+
+extern "C" int gm_conv_cout1m_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t smem = (size_t)gm_conv_cout1m_lds_bytes(dp);
+  const long long rowb = (long long)dp->Cin * (dp->dtype == GM_F32 ? 4 : 2);
+  if (dp->dtype == GM_F32) {
+    if (rowb == 128) edge_launch(conv_cout1_march_kernel<float, 2, 5>, *dp, nblocks, smem, st);
+    else edge_launch(conv_cout1_march_kernel<float, 4, 4>, *dp, nblocks, smem, st);
+    return 0;
+  }
+  if (dp->dtype == GM_BF16) {
+    if (rowb == 128) edge_launch(conv_cout1_march_kernel<bf16_raw, 2, 5>, *dp, nblocks, smem, st);
+    else edge_launch(conv_cout1_march_kernel<bf16_raw, 4, 4>, *dp, nblocks, smem, st);
+    return 0;
+  }
+  return -2;
+}
+

@@ -247,29 +247,26 @@ def packed_conv_weight(weight: torch.Tensor, dtype: torch.dtype, transposed: boo
 SUBPIXEL_UPSAMPLE = True  # nearest-2x + 3x3x3 convolutions run as 8 sub-pixel 2x2x2 convolutions (8/27 of the multiply-adds)
 
 
+def _pack_subpixel(weight: torch.Tensor, dtype: torch.dtype, cout: int, cin: int, k: int, swap_io: bool, masks) -> torch.Tensor:
+    """The 8 parity images of 2x2x2 kernels in ONE launch straight from the parameter (gm_pack_subpixel_weight): sub-tap s of parity p along an
+    axis = the sum of the source taps in bit mask masks[p][s]."""
+    w = weight.detach().contiguous()
+    n = lib().gm_packed_conv_weight_elems(cout, cin, 2, 2, 2, dt_code(dtype))
+    out = torch.empty(8 * n, dtype=dtype, device=w.device)
+    check(lib().gm_pack_subpixel_weight(w.data_ptr(), dt_code(w.dtype), out.data_ptr(), dt_code(dtype), cout, cin, k, int(swap_io), masks[0][0], masks[0][1],
+                                        masks[1][0], masks[1][1], _stream()), "gm_pack_subpixel_weight")
+    return out
+
+
 def packed_subpixel_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """[Cout, Cin, 3, 3, 3] -> the 8 parity images of 2x2x2 kernels (packed back to back) of `Upsample(nearest 2x) -> conv3x3x3`.  Output
     voxel 2i + p sees the up-sampled taps (2i + p - 1, 2i + p, 2i + p + 1) = input voxels (i - 1, i, i) for p = 0 and (i, i, i + 1)
     for p = 1: per axis the three weights collapse to (w0, w1 + w2) resp. (w0 + w1, w2).  Summed in fp32, then rounded to `dtype`."""
     require_device(weight)
-
-    def make():
-        w = weight.detach().float()
-
-        def collapse(t, axis, parity):  # three taps -> two along `axis`: (w0, w1 + w2) for parity 0, (w0 + w1, w2) for parity 1
-            t0, t1, t2 = t.select(axis, 0), t.select(axis, 1), t.select(axis, 2)
-            return torch.stack((t0, t1 + t2) if parity == 0 else (t0 + t1, t2), dim=axis)
-
-        cout, cin = w.shape[0], w.shape[1]
-        n = lib().gm_packed_conv_weight_elems(cout, cin, 2, 2, 2, dt_code(dtype))
-        out = torch.empty(8 * n, dtype=dtype, device=w.device)
-        for par in range(8):
-            w2 = collapse(collapse(collapse(w, 2, (par >> 2) & 1), 3, (par >> 1) & 1), 4, par & 1).contiguous()
-            check(lib().gm_pack_conv_weight(w2.data_ptr(), dt_code(w2.dtype), out[par * n:].data_ptr(), dt_code(dtype), cout, cin, 2, 2, 2, 0,
-                                            _stream()), "gm_pack_conv_weight")
-        return out
-
-    return _cached(weight, ("subpixel", dtype), make)
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError("sub-pixel up-sampling weights: a [Cout, Cin, 3, 3, 3] kernel")
+    return _cached(weight, ("subpixel", dtype),
+                   lambda: _pack_subpixel(weight, dtype, weight.shape[0], weight.shape[1], 3, False, ((0b001, 0b110), (0b011, 0b100))))
 
 
 def stride2_subpixel_taps(K: int, pad: int) -> dict:
@@ -304,24 +301,12 @@ def packed_stride2_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype, pad_lo
     # out[u] = sum x[o] W[k], u = 2 o - pad_lo + k.  Output parity pi reads the inputs i + delta, delta = (-1, 0) for pi = 0 and (0, +1) for
     # pi = 1, through tap k = pi + pad_lo - 2 delta (when it exists): K = 4, pad 1 (the VQ-VAE up-sampling) uses all eight taps of every parity.
     taps = stride2_subpixel_taps(K, pad_lo)
+    masks = tuple(tuple(0 if t is None else 1 << t for t in taps[p]) for p in (0, 1))
 
     def make():
-        wt = weight.detach().float().transpose(0, 1)  # [Cin, Cout, 3, 3, 3]: the gradient maps Cout channels of dy to Cin channels of dx
-        cin_f, cout_f = wt.shape[0], wt.shape[1]
-        n = lib().gm_packed_conv_weight_elems(cin_f, cout_f, 2, 2, 2, dt_code(dtype))
-        out = torch.empty(8 * n, dtype=dtype, device=wt.device)
-        for par in range(8):
-            sel = (taps[(par >> 2) & 1], taps[(par >> 1) & 1], taps[par & 1])
-            w2 = torch.zeros((cin_f, cout_f, 2, 2, 2), dtype=torch.float32, device=wt.device)
-            for a in range(2):
-                for b in range(2):
-                    for c in range(2):
-                        ka, kb, kc = sel[0][a], sel[1][b], sel[2][c]
-                        if ka is not None and kb is not None and kc is not None:
-                            w2[:, :, a, b, c] = wt[:, :, ka, kb, kc]
-            check(lib().gm_pack_conv_weight(w2.data_ptr(), dt_code(w2.dtype), out[par * n:].data_ptr(), dt_code(dtype), cin_f, cout_f, 2, 2, 2, 0,
-                                            _stream()), "gm_pack_conv_weight")
-        return out
+        # the gradient maps Cout channels of dy to Cin channels of dx: packed with (out, in) = (weight.shape[1], weight.shape[0]), the source
+        # read as [in][out][K][K][K] (swap_io) -- one launch for the 8 images (round 2: torch slicing + a pack launch per parity)
+        return _pack_subpixel(weight, dtype, weight.shape[1], weight.shape[0], K, True, masks)
 
     return _cached(weight, ("stride2_dgrad", dtype, pad_lo), make)
 
@@ -545,9 +530,6 @@ def spade_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, g: to
     return out
 
 
-STAT_SLOTS = 64  # GM_STAT_SLOTS of include/gm_amd.h: rows of a compacted statistic table (gm_stats_compact)
-
-
 class VirtualCat:
     """Channel concatenation that is never materialised (reference: torch.cat([h, skip], dim=1), diffusion_model_unet.py:1232,
     1340,1461): its consumers read the parts directly."""
@@ -584,15 +566,15 @@ def channel_stats(x: torch.Tensor) -> torch.Tensor:
     return st
 
 
-STATS_COMPACT_ABOVE = 256  # tables with more partials than this are folded to STAT_SLOTS rows right after they are produced
+STATS_COMPACT_ABOVE = 256  # tables with more partials than this are folded to gm_stats_compact_slots() rows right after they are produced
 
 
 def _compact_stats(st: torch.Tensor) -> torch.Tensor:
-    """[S, N, C, 2] -> [64, N, C, 2] (fixed-order fold, gm_stats_compact) when S is large: every later consumer then reads a small table."""
+    """[S, N, C, 2] -> [256, N, C, 2] (fixed-order fold, gm_stats_compact) when S is large: every later consumer then reads a small table."""
     s_, n, c, _ = st.shape
     if s_ <= STATS_COMPACT_ABOVE:
         return st
-    out = torch.empty((STAT_SLOTS, n, c, 2), dtype=torch.float64, device=st.device)
+    out = torch.empty((int(lib().gm_stats_compact_slots()), n, c, 2), dtype=torch.float64, device=st.device)
     check(lib().gm_stats_compact(st.data_ptr(), s_, n, c, out.data_ptr(), _stream()), "gm_stats_compact")
     return out
 
@@ -656,6 +638,7 @@ SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups t
 SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "512"))  # ... into as many slices as it takes to reach about this many (two per CU)
 SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
+COUT1_MARCH = os.environ.get("GM_CONV_COUT1_MARCH", "1") != "0"  # C_out == 1 heads: the depth-marching kernel (cfg 20) before the tile kernel (cfg 13)
 DMA_WIDE_WAVES = os.environ.get("GM_CONV_WIDE_WAVES", "1") != "0"  # prefer cfg 14 (4 waves x 64 voxels) for large prologue-free stride-1 convolutions
 DMA_WIDE_WAVE_MIN_TILES = 512                                       # ... from one full wave of work-groups on (2 per CU)
 
@@ -764,7 +747,9 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         order = [10, 9, 6, 1, 4, 2] if n_vox_out * desc.N >= (1 << 20) else [9, 6, 1, 4, 2]
     if force_cfg is None and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
         if cout == 1:
-            order = [13] + order  # taps-as-N kernel of the single-channel output heads (conv_edge.hip)
+            # taps-as-N kernels of the single-channel output heads (conv_edge.hip): 20 = marching along depth (every input row staged once per
+            # work-group by LDS-DMA, planes double-buffered), 13 = one 4x4x16 tile per work-group (what 20 does not cover)
+            order = ([20, 13] if COUT1_MARCH else [13]) + order
         if desc.Cin <= 4:
             order = [12] + order  # taps-as-K kernel of the 1..4-channel input convolutions
     if force_cfg is None and cout > 16 and DMA_CONV and n_vox_out * desc.N >= DMA_CONV_MIN_VOXELS:
@@ -788,6 +773,15 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         bm, _ = _cfg_tile(cfg)
         tb = _tile_bits_fast if cfg >= 5 else _tile_bits
         bits = tb(bm.bit_length() - 1, (desc.Do, desc.Ho, desc.Wo))
+        if cfg == 20:
+            # rows of 128 bytes walk 8 x 32 output columns, rows of 256 bytes 8 x 16; the depth segment of a work-group (2^ltd planes, halo
+            # overhead (2^ltd + 2) / 2^ltd) is the longest that still gives every CU a work-group
+            ltw = 5 if desc.Cin * (4 if desc.dtype == 0 else 2) == 128 else 4
+            cols = desc.N * -(-desc.Ho // 8) * -(-desc.Wo // (1 << ltw))
+            ltd = 5
+            while ltd > 2 and cols * -(-desc.Do // (1 << ltd)) < 256:
+                ltd -= 1
+            bits = [ltd, 3, ltw]
         if cfg in (11, 14, 15, 16, 18, 19):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
             bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
@@ -958,11 +952,13 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     if x2 is not None and (x2.shape[:-1] != x.shape[:-1] or x2.dtype != dtype):
         raise ValueError("the two parts of a concatenated input must agree outside the channel dim")
     if packed is None:
-        packed = packed_conv_weight(weight, dtype, transposed)
         cout = weight.shape[1] if transposed else weight.shape[0]
         wcin = weight.shape[0] if transposed else weight.shape[1]
         if wcin != cin:
             raise ValueError(f"input has {cin} channels but the weight expects {wcin}")
+
+    def panel():  # the generic MFMA panel, packed on first use: the sub-pixel paths below bring their own images (no wasted pack per step)
+        return packed if packed is not None else packed_conv_weight(weight, dtype, transposed)
     rows = n * math.prod(src)
     vecw = 16 // x.element_size()
     if (rows <= SMALL_LINEAR_ROWS and x2 is None and k == (1, 1, 1) and s == (1, 1, 1) and not transposed and not upsample and pre is None
@@ -978,7 +974,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             raise ValueError(f"residual has shape {tuple(res.shape)} / {res.dtype}, expected {out_shape} / {dtype}")
         b32 = as_f32(bias) if bias is not None else None
         _timed(f"linear_rows<{str(dtype).split('.')[-1]}>", dict(flops=2.0 * rows * cin * cout, bytes=float(x.element_size() * cin * cout), shape=f"{rows}x{cin}->{cout}"),
-               lambda: check(lib().gm_linear_rows(x.data_ptr(), arena_ld(x), packed.data_ptr(), _ptr(b32), _ptr(res), 0 if res is None else arena_ld(res),
+               lambda: check(lib().gm_linear_rows(x.data_ptr(), arena_ld(x), panel().data_ptr(), _ptr(b32), _ptr(res), 0 if res is None else arena_ld(res),
                                                   out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act], POST_ACT[post_act], dt_code(dtype),
                                                   _stream()), "gm_linear_rows"))
         return out
@@ -1034,6 +1030,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
     d.x, d.x_ld = x.data_ptr(), arena_ld(x)
     if x2 is not None:
         d.x2, d.x2_ld, d.cin_split = x2.data_ptr(), arena_ld(x2), x.shape[-1]
+    packed = panel()
     d.w = packed.data_ptr()
     b32 = as_f32(bias) if bias is not None else None
     d.bias = _ptr(b32)

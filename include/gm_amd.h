@@ -20,7 +20,6 @@ extern "C" {
 
 #define GM_F32 0
 #define GM_BF16 1
-#define GM_STAT_SLOTS 64   /* copies of a per-channel statistics table (spreads atomic contention); summed by the finaliser */
 
 int gm_abi_version(void);
 const char* gm_last_error(void);
@@ -129,8 +128,10 @@ int gm_spade_apply(const void* x, long long x_ld, void* y, long long y_ld, const
  * channel-concatenated sources (S0 / S1 partials each) -- torch.cat([h, skip]) followed by GroupNorm (diffusion_model_unet.py:1232 + 671)
  * without ever materialising the concatenation. */
 long long gm_gn_channel_stats_slots(const void* x, long long ld, long long V, int C, int dtype);
-/* fold a long table [S][N][C][2] (S >= 64: one partial per tile of a large volume) to [64][N][C][2] in a fixed order, so that the
- * per-group finalisation reads a small table */
+/* fold a long table [S][N][C][2] (S >= gm_stats_compact_slots() = 256: one partial per tile of a large volume) to
+ * [gm_stats_compact_slots()][N][C][2] in a fixed order (output row b = input rows b, b + 256, ...), so that the per-group finalisation
+ * reads a small table */
+int gm_stats_compact_slots(void);
 int gm_stats_compact(const double* stats_in, int S, int N, int C, double* stats_out, void* stream);
 int gm_gn_channel_stats(const void* x, long long ld, int N, long long V, int C, double* chan_out, int dtype, void* stream);
 int gm_gn_finalize_channels(const double* stats0, int S0, int C0, const double* stats1, int S1, int C1, int N, long long V, int G, float eps,
@@ -204,6 +205,13 @@ long long gm_packed_conv_weight_elems(int Cout, int Cin, int kd, int kh, int kw,
 /* src: [Cout][Cin][kd][kh][kw] (transposed = 0) or [Cin][Cout][kd][kh][kw] (transposed = 1, nn.ConvTransposeNd) */
 int gm_pack_conv_weight(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin, int kd, int kh, int kw,
                         int transposed, void* stream);
+/* The 8 parity images of 2x2x2 kernels of a sub-pixel convolution (GmConvDesc.in_mode 3), packed back to back (8 x gm_packed_conv_weight_elems(
+ * Cout, Cin, 2, 2, 2)), in one launch from the parameter: sub-tap s of parity p along an axis = the sum of the source taps in bit mask
+ * m<p><s> (bit k = tap k of the K-tap kernel).  swap_io = 0: src [Cout][Cin][K][K][K] (Upsample = nearest 2x + 3x3x3 convolution,
+ * diffusion_model_unet.py:572-585: masks 1, 6, 3, 4); swap_io = 1: src [Cin][Cout][K][K][K] (stride-2 transposed convolutions and the data
+ * gradient of stride-2 convolutions: one tap or none per sub-tap, vqvae.py:244-261, autoencoderkl.py:54-63). */
+int gm_pack_subpixel_weight(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin, int K, int swap_io, int m00, int m01,
+                            int m10, int m11, void* stream);
 
 /* ---- attention (diffusion_model_unet.py:143-153,407-415; autoencoderkl.py:261-269) ------------------------------------
  * O = softmax(scale * Q K^T) V (+ residual) per (batch, head); q/k/v/o rows are tokens, head h at element offset h*dh. */

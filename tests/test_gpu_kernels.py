@@ -890,3 +890,82 @@ def test_upsample_conv_as_subpixel_convolutions(shape, cin, cout, dtype):
     finally:
         ops.SUBPIXEL_UPSAMPLE = True
     _check(_cf(got), _cf(folded).double(), dtype, "sub-pixel vs folded up-sampling", extra=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_subpixel_weight_images_packed_in_one_launch_match_the_per_parity_construction(dtype):
+    """gm_pack_subpixel_weight (the 8 parity images of 2x2x2 kernels straight from the parameter) against the construction it replaces: torch
+    slicing / summing per parity + one gm_pack_conv_weight launch each -- bit-equal for the single-tap images (stride-2 data gradient /
+    transposed convolutions, k = 3 with padding 0 and 1, k = 4 with padding 1), equal up to the fp32 summation order for the pre-summed
+    up-sampling images (diffusion_model_unet.py:572-585; vqvae.py:244-261; autoencoderkl.py:54-63)."""
+    from generativemodels_amd import ops
+    from generativemodels_amd._native import check, lib
+
+    def pack(w2, cout, cin):
+        n = lib().gm_packed_conv_weight_elems(cout, cin, 2, 2, 2, ops.dt_code(dtype))
+        out = torch.empty(n, dtype=dtype, device=DEV)
+        check(lib().gm_pack_conv_weight(w2.data_ptr(), ops.dt_code(w2.dtype), out.data_ptr(), ops.dt_code(dtype), cout, cin, 2, 2, 2, 0,
+                                        torch.cuda.current_stream().cuda_stream), "gm_pack_conv_weight")
+        return out
+
+    g = torch.Generator().manual_seed(77)
+    for K, pad in ((3, 1), (3, 0), (4, 1)):
+        w = torch.randn((48, 40, K, K, K), generator=g).to(DEV)  # a forward weight [Cout, Cin, ...]: ragged against the 16 / 32 paddings
+        got = ops.packed_stride2_dgrad_weight(w, dtype, pad)
+        taps = ops.stride2_subpixel_taps(K, pad)
+        wt = w.transpose(0, 1)
+        want = []
+        for par in range(8):
+            sel = (taps[(par >> 2) & 1], taps[(par >> 1) & 1], taps[par & 1])
+            w2 = torch.zeros((40, 48, 2, 2, 2), device=DEV)
+            for a in range(2):
+                for b in range(2):
+                    for c in range(2):
+                        if None not in (sel[0][a], sel[1][b], sel[2][c]):
+                            w2[:, :, a, b, c] = wt[:, :, sel[0][a], sel[1][b], sel[2][c]]
+            want.append(pack(w2.contiguous(), 40, 48))
+        assert torch.equal(got, torch.cat(want)), (K, pad)
+    w = torch.randn((48, 64, 3, 3, 3), generator=g).to(DEV)
+    got = ops.packed_subpixel_weight(w, dtype)
+
+    def collapse(t, axis, parity):
+        t0, t1, t2 = t.select(axis, 0), t.select(axis, 1), t.select(axis, 2)
+        return torch.stack((t0, t1 + t2) if parity == 0 else (t0 + t1, t2), dim=axis)
+
+    want = torch.cat([pack(collapse(collapse(collapse(w, 2, (p >> 2) & 1), 3, (p >> 1) & 1), 4, p & 1).contiguous(), 48, 64) for p in range(8)])
+    assert got.shape == want.shape
+    tol = 2e-6 if dtype == torch.float32 else 1.6e-2  # fp32: summation order; bf16: at most one ulp where the fp32 sums straddle a rounding boundary
+    assert (got.float() - want.float()).abs().max().item() <= tol * max(1.0, want.float().abs().max().item())
+    assert (got != want).float().mean().item() < (1e-2 if dtype == torch.bfloat16 else 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,sp,pro", [(64, (8, 8, 32), True), (64, (37, 21, 45), True), (128, (9, 17, 18), False), (32, (6, 5, 17), True), (64, (4, 40, 70), True)])
+def test_conv_single_output_channel_marching_kernel(cin, sp, pro, dtype):
+    """cfg 20 (conv_edge.hip: conv_cout1_march_kernel -- a work-group walks a depth segment of an 8 x 32 / 8 x 16 output column, input planes
+    double-buffered by LDS-DMA, two running sums per output voxel): against torch in fp64, and BIT-IDENTICAL to the tile kernel (cfg 13), whose
+    summation order it keeps.  Ragged volumes (partial columns, depth segments that end inside the volume), channel-sliced input, residual,
+    several depth-segment lengths.  Reference op: the `out` head GN -> SiLU -> conv C -> 1 (diffusion_model_unet.py:1853-1867)."""
+    ops = _ops()
+    es = 4 if dtype == torch.float32 else 2
+    if cin * es not in (128, 256):
+        pytest.skip("the marching kernel stages whole rows of 128 or 256 bytes")
+    n = 2
+    x = (_rand((n, cin, *sp), 191) * 1.2 + 0.1).to(dtype)
+    w = (_rand((1, cin, 3, 3, 3), 192) / math.sqrt(cin * 27)).to(dtype)
+    b = _rand((1,), 193) * 0.1
+    res = _rand((n, 1, *sp), 196).to(dtype)
+    scale, shift = _rand((n, cin), 194) * 0.2 + 1.0, _rand((n, cin), 195) * 0.1
+    xin = x.double()
+    if pro:
+        xin = F.silu(xin * scale.double().reshape(n, cin, 1, 1, 1) + shift.double().reshape(n, cin, 1, 1, 1))
+    want = F.conv3d(xin, w.double(), b.double(), padding=1) + res.double()
+    wide_in = torch.zeros((n, *sp, cin + 8), dtype=dtype, device=DEV)
+    wide_in[..., 8:] = _cl(x)
+    kw = dict(kernel=3, padding=1, pre=(scale.to(DEV), shift.to(DEV)) if pro else None, pre_act="silu" if pro else "none", res=_cl(res))
+    got = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), force_cfg=20, **kw)
+    _check(_cf(got), want, dtype, f"cout1 marching cin{cin}")
+    tile = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), force_cfg=13, **kw)
+    assert torch.equal(got, tile), "the marching kernel keeps the 27-point summation order of the tile kernel: bit-identical"
+    auto = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), **kw)
+    assert torch.equal(auto, got)
