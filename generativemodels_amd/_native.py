@@ -138,6 +138,7 @@ PROTOTYPES = {
     "gm_likelihood_workspace_elems": (c_ll, [c_ll, c_ll]),
     "gm_gn_bwd_apply": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, C.c_int, c_ll, C.c_int, C.c_int,
                                   C.c_int, c_vp]),
+    "gm_spade_bwd": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_stats_colsum": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
     "gm_attention_backward_workspace_bytes": (c_ll, [C.POINTER(GmAttnBwdDesc)]),
     "gm_attention_backward": (C.c_int, [C.POINTER(GmAttnBwdDesc), c_vp]),

@@ -23,7 +23,7 @@ import torch
 
 from . import ops
 
-__all__ = ["cast", "scale", "conv", "conv_transpose", "sigma_from_log_var", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
+__all__ = ["cast", "scale", "spade_modulate", "conv", "conv_transpose", "sigma_from_log_var", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
 
 
 def _tup(v, n):
@@ -486,6 +486,27 @@ class _Embedding(torch.autograd.Function):
 def embedding(labels: torch.Tensor, weight: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """weight[labels] in `dtype` (default: the table's); differentiable in the table."""
     return _Embedding.apply(labels, weight, dtype)
+
+
+class _SpadeModulate(torch.autograd.Function):
+    """y = act(xn * g + bm): the SPADE modulation of a parameter-free-normalised tensor (blocks/spade_norm.py:79-96); differentiable in all three."""
+
+    @staticmethod
+    def forward(ctx, xn, g, bm, act):
+        n, c = xn.shape[0], xn.shape[-1]
+        one = torch.ones((n, c), dtype=torch.float32, device=xn.device)
+        ctx.save_for_backward(xn, g, bm)
+        ctx.act = act
+        return ops.spade_apply(xn, one, torch.zeros_like(one), g, bm, act)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, g, bm = ctx.saved_tensors
+        return (*ops.spade_backward(xn, g, bm, gy, ctx.act), None)
+
+
+def spade_modulate(xn: torch.Tensor, g: torch.Tensor, bm: torch.Tensor, act: str = "none") -> torch.Tensor:
+    return _SpadeModulate.apply(xn, g, bm, act)
 
 
 class _Scale(torch.autograd.Function):

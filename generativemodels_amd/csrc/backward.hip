@@ -454,7 +454,10 @@ __device__ __forceinline__ float silu_grad(float z) {
   return s * (1.0f + z * (1.0f - s));
 }
 // act'(z) for the activation codes of the forward prologue (0 none, 1 SiLU, 2 ReLU: torch's relu backward passes the gradient where z > 0)
-__device__ __forceinline__ float act_grad(float z, int act) { return act == 1 ? silu_grad(z) : (act == 2 ? (z > 0.f ? 1.f : 0.f) : 1.f); }
+// and 3 = LeakyReLU(0.01) (MONAI's default slope: the SPADE map convolutions, spade_norm.py:56-66)
+__device__ __forceinline__ float act_grad(float z, int act) {
+  return act == 1 ? silu_grad(z) : (act == 2 ? (z > 0.f ? 1.f : 0.f) : (act == 3 ? (z > 0.f ? 1.f : 0.01f) : 1.f));
+}
 
 // out[blk][n][c] = {sum_v g, sum_v g * x} over the rows of block blk: ONE plain fp64 store per (block, sample, channel) -- no atomics, no zero
 // fill; gm_gn_bwd_finalize adds the gm_gn_bwd_stats_slots(N, V) partials in a fixed order, so a training step is bit-reproducible (round 2
@@ -696,6 +699,43 @@ extern "C" int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, lo
   else if (dtype == GM_BF16) { if (vec_ok) GM_GNB_LAUNCH(bf16_raw, 8); else GM_GNB_LAUNCH(bf16_raw, 1); }
   else GM_FAIL(-2, "unsupported dtype");
 #undef GM_GNB_LAUNCH
+  GM_LAUNCH_CHECK();
+}
+
+// SPADE modulation backward (generative/networks/blocks/spade_norm.py:79-96 under torch autograd): y = act(xn * g + bm) with xn the
+// parameter-free-normalised tensor and g = 1 + gamma(seg), bm = beta(seg) per-voxel maps.  With gu = gy * act'(xn * g + bm):
+//   dxn = gu * g,  dg = gu * xn,  dbm = gu       (dg / dbm share the row pitch gb_ld, like g / bm).  Element-wise, HBM-bound.
+template <typename T>
+__global__ __launch_bounds__(256) void spade_bwd_kernel(const T* __restrict__ xn, long long x_ld, const T* __restrict__ g, const T* __restrict__ bm,
+                                                       long long gb_ld, const T* __restrict__ gy, long long gy_ld, T* __restrict__ dxn, long long dx_ld,
+                                                       T* __restrict__ dg, T* __restrict__ dbm, long long dgb_ld, int C, long long total, int act) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / C;
+    const int c = (int)(i - row * C);
+    const float x = ElemIO<T>::ld(xn + row * x_ld + c), gv = ElemIO<T>::ld(g + row * gb_ld + c), bv = ElemIO<T>::ld(bm + row * gb_ld + c);
+    float gu = ElemIO<T>::ld(gy + row * gy_ld + c);
+    if (act) gu *= act_grad(x * gv + bv, act);
+    ElemIO<T>::st(dxn + row * dx_ld + c, gu * gv);
+    ElemIO<T>::st(dg + row * dgb_ld + c, gu * x);
+    ElemIO<T>::st(dbm + row * dgb_ld + c, gu);
+  }
+}
+
+extern "C" int gm_spade_bwd(const void* xn, long long x_ld, const void* g, const void* bm, long long gb_ld, const void* gy, long long gy_ld, void* dxn,
+                            long long dx_ld, void* dg, void* dbm, long long dgb_ld, long long rows, int C, int act, int dtype, void* stream) {
+  GM_REQUIRE(xn && g && bm && gy && dxn && dg && dbm, "null pointer");
+  const long long total = rows * C;
+  if (total == 0) return 0;
+  long long grid = (total + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32)
+    spade_bwd_kernel<float><<<(int)grid, 256, 0, st>>>((const float*)xn, x_ld, (const float*)g, (const float*)bm, gb_ld, (const float*)gy, gy_ld,
+                                                       (float*)dxn, dx_ld, (float*)dg, (float*)dbm, dgb_ld, C, total, act);
+  else if (dtype == GM_BF16)
+    spade_bwd_kernel<bf16_raw><<<(int)grid, 256, 0, st>>>((const bf16_raw*)xn, x_ld, (const bf16_raw*)g, (const bf16_raw*)bm, gb_ld, (const bf16_raw*)gy,
+                                                          gy_ld, (bf16_raw*)dxn, dx_ld, (bf16_raw*)dg, (bf16_raw*)dbm, dgb_ld, C, total, act);
+  else GM_FAIL(-2, "unsupported dtype");
   GM_LAUNCH_CHECK();
 }
 

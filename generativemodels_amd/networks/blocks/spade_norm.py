@@ -91,6 +91,27 @@ class SPADE(nn.Module):
             off += c
         return out
 
+    def run_train(self, x: torch.Tensor, seg: torch.Tensor, act: str = "none") -> torch.Tensor:
+        """`run` with gradients (generativemodels_amd.autograd; reference: torch autograd through spade_norm.py:79-96): x an arena tensor (a
+        concatenation is materialised by the caller), seg the arena segmentation.  The (1 + gamma, beta) maps are recomputed every call -- their
+        convolutions are being trained -- : nearest resize -> mlp_shared + LeakyReLU -> mlp_gamma / mlp_beta -> InstanceNorm (+ 1 on gamma), then
+        the parameter-free GroupNorm of x and the modulation, every step a differentiable native op."""
+        from ... import autograd as A
+
+        c, k, pad = self.norm_nc, self.kernel_size, self.kernel_size // 2
+        size = tuple(x.shape[1:-1])
+        segr = seg if tuple(seg.shape[1:-1]) == size else ops.nearest_resize(seg, size)  # (the segmentation itself takes no gradient)
+        sh_, ga, be = self.mlp_shared.conv, self.mlp_gamma.conv, self.mlp_beta.conv
+        actv = A.conv(segr, sh_.weight, sh_.bias, kernel=k, stride=1, padding=pad, post_act="leakyrelu")
+        zero = torch.zeros(c, dtype=torch.float32, device=x.device)
+        # InstanceNorm (affine-free, eps 1e-5) of each map = GroupNorm with one channel per group; the `1 +` of the modulation is gamma's shift
+        g = A.group_norm_act(A.conv(actv, ga.weight, ga.bias, kernel=k, stride=1, padding=pad), None, zero + 1.0, c, 1e-5, "none")
+        bm = A.group_norm_act(A.conv(actv, be.weight, be.bias, kernel=k, stride=1, padding=pad), None, zero, c, 1e-5, "none")
+        n = self.param_free_norm.N
+        gamma, beta = (n.weight, n.bias) if getattr(n, "affine", False) else (None, None)
+        xn = A.group_norm_act(x, gamma, beta, self.groups, self.eps, "none")
+        return A.spade_modulate(xn, g, bm, act)
+
     def forward(self, x: torch.Tensor, segmap: torch.Tensor) -> torch.Tensor:
         """NC[D]HW in / out, like the reference module."""
         ops.require_device(x, segmap)

@@ -269,5 +269,20 @@ class SPADEResnetBlock(ResnetBlock):
             fusion["skip"] = (list(x.parts) if cat else [x], shortcut.conv.weight, shortcut.conv.bias)
         return self.conv2.run(self.norm2.run(h, seg, "silu"), want_stats=True, **fusion)
 
-    def run_train(self, x, temb=None):  # pragma: no cover
-        raise NotImplementedError("SPADE blocks are inference-only")
+    def run_train(self, x: torch.Tensor, temb: Optional[torch.Tensor] = None, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same block with gradients: SPADE.run_train in place of the two GroupNorm + SiLU steps of ResnetBlock.run_train (reference: torch
+        autograd through spade_diffusion_model_unet.py:173-200 / spade_autoencoderkl.py:105-134)."""
+        from ... import autograd as A
+
+        if seg is None:
+            raise ValueError("SPADEResnetBlock needs the segmentation map")
+        h = self.norm1.run_train(x, seg, "silu")
+        row = None
+        if temb is not None:
+            row = A.linear(A.silu(temb[None]), self.time_emb_proj.weight, self.time_emb_proj.bias)[0].float()
+        c1, c2 = self.conv1, self.conv2
+        h = A.conv(h, c1.conv.weight, c1.conv.bias, kernel=c1.kernel_size, stride=1, padding=c1.padding, rowvec=row)
+        h = self.norm2.run_train(h, seg, "silu")
+        shortcut = getattr(self, self.shortcut_name)
+        xs = A.conv(x, shortcut.conv.weight, shortcut.conv.bias, kernel=1) if isinstance(shortcut, ConvP) else x
+        return A.conv(h, c2.conv.weight, c2.conv.bias, kernel=c2.kernel_size, stride=1, padding=c2.padding, res=xs)

@@ -62,7 +62,7 @@ def _run_blocks(blocks: nn.ModuleList, h: torch.Tensor, seg: Optional[torch.Tens
     return h
 
 
-def _run_blocks_train(blocks: nn.ModuleList, h: torch.Tensor) -> torch.Tensor:
+def _run_blocks_train(blocks: nn.ModuleList, h: torch.Tensor, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The same block list with gradients (generativemodels_amd.autograd: native kernels in both directions) -- what the reference's
     autoencoder training loops differentiate through torch autograd (tutorials/generative/3d_autoencoderkl, engines/trainer.py:258-270)."""
     from ... import autograd as A
@@ -73,7 +73,7 @@ def _run_blocks_train(blocks: nn.ModuleList, h: torch.Tensor) -> torch.Tensor:
         elif isinstance(blk, ConvP):
             h = A.conv(h, blk.conv.weight, blk.conv.bias, kernel=blk.kernel_size, stride=1, padding=blk.padding)
         elif isinstance(blk, SPADEResnetBlock):
-            raise NotImplementedError("the SPADE decoder is inference-only")
+            h = blk.run_train(h, None, seg)  # SPADE decoder (spade_autoencoderkl.py:283-289): seg = the arena segmentation
         elif isinstance(blk, _Down):
             c = blk.conv
             h = A.conv(h, c.conv.weight, c.conv.bias, kernel=3, stride=2, padding=0, pad_hi=1)
@@ -159,8 +159,8 @@ class Decoder(nn.Module):
     def run(self, x, seg: Optional[torch.Tensor] = None):
         return _run_blocks(self.blocks, x, seg)
 
-    def run_train(self, x):
-        return _run_blocks_train(self.blocks, x)
+    def run_train(self, x, seg: Optional[torch.Tensor] = None):
+        return _run_blocks_train(self.blocks, x, seg)
 
 
 class AutoencoderKL(nn.Module):

@@ -512,17 +512,18 @@ def _train_entry(self, x: torch.Tensor, what: str = "input"):
 
 def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor | None = None,
                    class_labels: torch.Tensor | None = None, down_block_additional_residuals: tuple[torch.Tensor] | None = None,
-                   mid_block_additional_residual: torch.Tensor | None = None) -> torch.Tensor:
+                   mid_block_additional_residual: torch.Tensor | None = None, seg: torch.Tensor | None = None) -> torch.Tensor:
     """DiffusionModelUNet.forward with gradients (the reference's training step differentiates the same
     forward through torch autograd: ddpm_training_ddp.py:249-270).  Every layer runs native kernels in both directions
     (generativemodels_amd.autograd).  Covered: every DiffusionModelUNet configuration -- AttentionBlock or SpatialTransformer levels
     (cross-attention on `context`, LayerNorm / GEGLU backward kernels), class embeddings, strided-convolution / nearest + convolution or
     resblock_updown resampling, and the ControlNet residual hooks (diffusion_model_unet.py:1917-1932: gradients flow into the residuals, so a
-    ControlNet trains against a frozen UNet).  The SPADE variant is inference-only."""
+    ControlNet trains against a frozen UNet), and the SPADE variant (`seg`: the decoder ResnetBlocks are SPADEResnetBlocks, their gamma / beta map
+    convolutions train with the rest: spade_diffusion_model_unet.py:836-912)."""
     from ... import autograd as A
 
-    if self._spade is not None:
-        raise NotImplementedError("forward_train: the SPADE variant is inference-only")
+    if (self._spade is not None) != (seg is not None):
+        raise ValueError("forward_train: `seg` is the segmentation of a SPADEDiffusionModelUNet (and only of one)")
     if self.training and getattr(self, "dropout_cattn", 0.0) > 0.0:
         raise NotImplementedError("forward_train: dropout_cattn > 0 in train() mode is not implemented (the fused attention / MLP kernels have no "
                                   "dropout mask); call .eval() to train without dropout, or construct the model with dropout_cattn=0")
@@ -545,9 +546,16 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, context: torc
         skips = [A.add(s, A.to_arena(A.cast(r, dtype))) for s, r in zip(skips, down_block_additional_residuals)]
     if mid_block_additional_residual is not None:
         h = A.add(h, A.to_arena(A.cast(mid_block_additional_residual, dtype)))
+    seg_a = None
+    if seg is not None:
+        ops.require_device(seg)
+        if seg.shape[0] != x.shape[0] or seg.dim() != x.dim():
+            raise ValueError("seg must be (N, label_nc, *spatial) with the batch size of x")
+        seg_a = ops.to_channels_last(ops.cast(seg.detach().contiguous(), dtype))
     for st in self.up_blocks:
         for j, rb in enumerate(st.resnets):
-            h = rb.run_train(A.cat(h, skips.pop()), emb)
+            cat = A.cat(h, skips.pop())
+            h = rb.run_train(cat, emb) if seg_a is None else rb.run_train(cat, emb, seg_a)
             if st.attentions is not None:
                 h = _train_attend(st.attentions[j], h, context)
         if st.resampler_name == "upsampler":
@@ -559,8 +567,8 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, context: torc
 
 
 def _supports_training(self) -> bool:
-    """True when forward_train covers this configuration (DiffusionInferer.__call__ then returns a differentiable prediction)."""
-    return self._spade is None
+    """True when forward_train covers this configuration (DiffusionInferer.__call__ then returns a differentiable prediction): every one."""
+    return True
 
 
 DiffusionModelUNet.forward_train = _forward_train

@@ -8,6 +8,7 @@ from typing import Sequence
 import torch
 
 from ... import ops
+from ._blocks import wants_grad
 from .autoencoderkl import AutoencoderKL, Decoder
 
 __all__ = ["SPADEAutoencoderKL"]
@@ -46,8 +47,14 @@ class SPADEAutoencoderKL(AutoencoderKL):
 
     def decode(self, z: torch.Tensor, seg: torch.Tensor) -> torch.Tensor:
         """post_quant_conv -> SPADEDecoder (reference spade_autoencoderkl.py:457-469)."""
-        with torch.no_grad():  # (the SPADE decoder is inference-only)
-            z = self._check(z)
+        z = self._check(z)
+        if wants_grad(self, z):  # a training step: differentiable decode, the SPADE map convolutions train with the decoder
+            from ... import autograd as A
+
+            pq = self.post_quant_conv.conv
+            seg_a = self._seg(seg.detach(), z)
+            return A.from_arena(self.decoder.run_train(A.conv(A.to_arena(z.contiguous()), pq.weight, pq.bias, kernel=1), seg_a))
+        with torch.no_grad():
             h = self.post_quant_conv.run(ops.to_channels_last(z))
             return ops.to_channels_first(self.decoder.run(h, self._seg(seg, z)))
 

@@ -43,4 +43,9 @@ class SPADEDiffusionModelUNet(DiffusionModelUNet):
             raise ValueError("SPADEDiffusionModelUNet needs the segmentation map `seg`")
         if seg.shape[1] != self.label_nc:
             raise ValueError(f"seg has {seg.shape[1]} channels, the network was built for label_nc = {self.label_nc}")
+        residuals = list(down_block_additional_residuals or ()) + ([] if mid_block_additional_residual is None else [mid_block_additional_residual])
+        if self._wants_grad(x) or (torch.is_grad_enabled() and any(r.requires_grad for r in residuals)):
+            return self.forward_train(x, timesteps, context=context, class_labels=class_labels,
+                                      down_block_additional_residuals=down_block_additional_residuals,
+                                      mid_block_additional_residual=mid_block_additional_residual, seg=seg)
         return self._forward_impl(x, timesteps, context, class_labels, down_block_additional_residuals, mid_block_additional_residual, seg=seg)

@@ -19,6 +19,7 @@ from ._native import GmAttnBwdDesc, GmAttnDesc, GmConvDesc, GmKlParams, GmStepPa
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 ACT = {"none": 0, "silu": 1, "relu": 2}
+ACT_BWD = {"none": 0, "silu": 1, "relu": 2, "leakyrelu": 3}  # activation codes of the backward kernels (act' evaluated from the pre-activation)
 POST_ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "swish": 4, "leakyrelu": 5, "gelu": 6}
 
 
@@ -1297,8 +1298,8 @@ def _conv_wgrad_k4s2(x, gy, pads, out, accumulate):
 def act_backward(y: torch.Tensor, gy: torch.Tensor, act: str) -> torch.Tensor:
     """gy * act'(z) from the activation's OUTPUT y = act(z) for activations whose derivative is a function of the output sign: ReLU
     (y > 0 <=> z > 0).  The fused convolution epilogues store only y; this is the first step of their backward."""
-    if act != "relu":
-        raise NotImplementedError(f"activation '{act}' has no backward kernel (training covers none / relu epilogues)")
+    if act not in ("relu", "leakyrelu"):
+        raise NotImplementedError(f"activation '{act}' has no backward kernel (training covers none / relu / leakyrelu epilogues)")
     require_device(y, gy)
     if y.shape != gy.shape or y.dtype != gy.dtype:
         raise ValueError("act_backward: gy must match y")
@@ -1309,8 +1310,24 @@ def act_backward(y: torch.Tensor, gy: torch.Tensor, act: str) -> torch.Tensor:
     zero = torch.zeros((n, c), dtype=torch.float32, device=y.device)
     dx = torch.empty_like(y)
     check(lib().gm_gn_bwd_apply(y.data_ptr(), arena_ld(y), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), one.data_ptr(), zero.data_ptr(), c,
-                                one.data_ptr(), zero.data_ptr(), zero.data_ptr(), n, v, c, ACT[act], dt_code(y.dtype), _stream()), "gm_gn_bwd_apply")
+                                one.data_ptr(), zero.data_ptr(), zero.data_ptr(), n, v, c, ACT_BWD[act], dt_code(y.dtype), _stream()), "gm_gn_bwd_apply")
     return dx
+
+
+def spade_backward(xn: torch.Tensor, g: torch.Tensor, bm: torch.Tensor, gy: torch.Tensor, act: str):
+    """Backward of y = act(xn * g + bm) (ops.spade_apply with an identity affine): -> (dxn, dg, dbm), dg / dbm channel slices of one buffer."""
+    require_device(xn, g, bm, gy)
+    if not (xn.shape == g.shape == bm.shape == gy.shape) or len({xn.dtype, g.dtype, bm.dtype, gy.dtype}) != 1 or arena_ld(g) != arena_ld(bm):
+        raise ValueError("spade_backward operands must match in shape / dtype (g and bm share a row pitch)")
+    gy = gy.contiguous()
+    c = xn.shape[-1]
+    dxn = torch.empty(xn.shape, dtype=xn.dtype, device=xn.device)
+    dgb = torch.empty((*xn.shape[:-1], 2 * c), dtype=xn.dtype, device=xn.device)
+    dg, dbm = dgb[..., :c], dgb[..., c:]
+    check(lib().gm_spade_bwd(xn.data_ptr(), arena_ld(xn), g.data_ptr(), bm.data_ptr(), arena_ld(g), gy.data_ptr(), arena_ld(gy), dxn.data_ptr(),
+                             arena_ld(dxn), dg.data_ptr(), dbm.data_ptr(), arena_ld(dg), rows_of(xn), c, ACT_BWD[act], dt_code(xn.dtype), _stream()),
+          "gm_spade_bwd")
+    return dxn, dg, dbm
 
 
 def bias_grad(gy: torch.Tensor, per_sample: bool = False) -> torch.Tensor:

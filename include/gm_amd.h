@@ -308,7 +308,7 @@ long long gm_conv_wgrad_workspace_bytes(const GmWgradDesc* d);
 /* dW[co][ci][tap] = sum_v gy[v][co] * x[v * stride - pad + tap][ci] (torch.nn.grad.conv*_weight); split-K partial sums reduced in
  * a fixed order: deterministic */
 int gm_conv_wgrad(const GmWgradDesc* d, void* stream);
-/* GroupNorm (+ SiLU when act = 1, ReLU when act = 2) backward for y = act(x * scale[n][c] + shift[n][c]) (nn.GroupNorm + nn.SiLU,
+/* GroupNorm (+ SiLU when act = 1, ReLU when act = 2, LeakyReLU(0.01) when act = 3) backward for y = act(x * scale[n][c] + shift[n][c]) (nn.GroupNorm + nn.SiLU,
  * diffusion_model_unet.py:623-690).  With g = gy * act'(x * scale + shift):
  *   gm_gn_bwd_stats     out[block][n][c] = {sum_v g, sum_v g x} over the rows of the block: fp64 [gm_gn_bwd_stats_slots(N, V)][N][C][2],
  *                       one plain store each (no atomics, no zero fill; summed in a fixed order by gm_gn_bwd_finalize: bit-reproducible)
@@ -323,6 +323,10 @@ int gm_gn_bwd_finalize(const double* fwd_stats, int fwd_slots, const double* bwd
 int gm_gn_bwd_apply(const void* x, long long x_ld, const void* gy, long long gy_ld, void* dx, long long dx_ld, const float* scale,
                     const float* shift, long long ss_ld, const float* A, const float* B, const float* Cc, int N, long long V, int C, int act,
                     int dtype, void* stream);
+/* SPADE modulation backward (blocks/spade_norm.py:79-96 under torch autograd): y = act(xn * g + bm); with gu = gy * act'(xn * g + bm):
+ * dxn = gu * g, dg = gu * xn, dbm = gu (act: 0 none, 1 SiLU); g / bm share the row pitch gb_ld, dg / dbm share dgb_ld */
+int gm_spade_bwd(const void* xn, long long x_ld, const void* g, const void* bm, long long gb_ld, const void* gy, long long gy_ld, void* dxn,
+                 long long dx_ld, void* dg, void* dbm, long long dgb_ld, long long rows, int C, int act, int dtype, void* stream);
 /* per_sample = 0: out[c] = sum over slots and samples of stats[slot][n][c][0] (a bias gradient from the gm_gn_channel_stats table of
  * gy); per_sample = 1: out[n][c] = sum over slots (gradient of the per-sample row vector a convolution epilogue adds: the timestep
  * embedding projection, diffusion_model_unet.py:684-686) */

@@ -269,7 +269,9 @@ def test_spade_state_dicts_constructor_errors_and_no_cpu_fallback():
         u(x, torch.tensor([1]), torch.zeros(1, 2, 8, 8))   # label_nc mismatch
     with pytest.raises(RuntimeError, match="MI355X"):
         u(x, torch.tensor([1]), torch.zeros(1, 3, 8, 8))
-    assert not u.supports_training()
+    assert u.supports_training()  # round 3: the SPADE variant trains natively too (forward_train takes `seg`)
+    with pytest.raises(ValueError):
+        u.forward_train(x, torch.tensor([1]))   # ... and refuses to run without its segmentation
 
 
 def test_transformer_state_dict_ordering_and_errors():
