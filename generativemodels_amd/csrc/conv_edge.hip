@@ -416,8 +416,8 @@ __global__ __launch_bounds__(256, 1) void conv_cout1_march_kernel(const GmConvDe
     const bool valid = plane_valid(ip);  // block-uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of plane ip have landed (and its output stores have left)
     __syncthreads();                                  // ... everyone's; the previous plane's gather is over (Z is free), raw[buf ^ 1] has been read
-    if (ip + 1 <= ip1 && plane_valid(ip + 1)) issue_plane(ip + 1, buf ^ 1);
-    if (valid) {
+    if (ip + 1 <= ip1 && plane_valid(ip + 1) && !(p.debug_flags & 4)) issue_plane(ip + 1, buf ^ 1);  // (debug_flags 1 / 2 / 4: bench-only ablations --
+    if (valid && !(p.debug_flags & 1)) {                                                                  //  no phase 1 / no phase 2 / no DMA; results are garbage)
       const char* raw = smem + (size_t)buf * RAW_BYTES;
 #pragma unroll
       for (int j = 0; j < FPW; ++j) {
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void conv_cout1_march_kernel(const GmConvDe
     }
     __syncthreads();
     // ---- phase 2: this input plane's contribution to output planes ip + 1 (kd = 0), ip (kd = 1), ip - 1 (kd = 2, which completes it) ------
-    if (gth) {
+    if (gth && !(p.debug_flags & 2)) {
       float out_v = s_prev, mid = s_cur, nxt = add0;
       if (valid) {
         const float* zb = Z + (gh * PW + gw);

@@ -724,6 +724,9 @@ def _cfg_tile(cfg: int):
     return _CFG_TILES[cfg]
 
 
+COUT1_MARCH_LTD = os.environ.get("GM_CONV_COUT1_LTD")  # bench only: pin the depth-segment length (log2 planes) of configuration 20
+
+
 _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
 _CONV_TIMELINE_BUFFER = None  # tools/conv_timeline.py (bench-only -DGM_CONV_TIMELINE build): int64 [work-groups, 64] stamp table
 
@@ -782,6 +785,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             ltd = 5
             while ltd > 2 and cols * -(-desc.Do // (1 << ltd)) < 256:
                 ltd -= 1
+            if COUT1_MARCH_LTD is not None:
+                ltd = int(COUT1_MARCH_LTD)
             bits = [ltd, 3, ltw]
         if cfg in (11, 14, 15, 16, 18, 19):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
             bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
