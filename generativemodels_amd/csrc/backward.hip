@@ -458,6 +458,21 @@ __device__ __forceinline__ float silu_grad(float z) {
 __device__ __forceinline__ float act_grad(float z, int act) {
   return act == 1 ? silu_grad(z) : (act == 2 ? (z > 0.f ? 1.f : 0.f) : (act == 3 ? (z > 0.f ? 1.f : 0.01f) : 1.f));
 }
+// g[i] *= act'(z[i]) for a register vector, the (wave-uniform) activation kind tested once: N independent chains in one basic block (a per-element
+// test serialises them -- see conv_act_vec in conv_common.h)
+template <int N>
+__device__ __forceinline__ void act_grad_mul(float (&g)[N], const float (&z)[N], int act) {
+  if (act == 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] *= silu_grad(z[i]);
+  } else if (act == 2) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = z[i] > 0.f ? g[i] : 0.f;
+  } else if (act == 3) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = z[i] > 0.f ? g[i] : 0.01f * g[i];
+  }
+}
 
 // out[blk][n][c] = {sum_v g, sum_v g * x} over the rows of block blk: ONE plain fp64 store per (block, sample, channel) -- no atomics, no zero
 // fill; gm_gn_bwd_finalize adds the gm_gn_bwd_stats_slots(N, V) partials in a fixed order, so a training step is bit-reproducible (round 2
@@ -494,12 +509,14 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
         Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + r * x_ld), xv);
         Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gb + r * gy_ld), gv);
       }
+      if (act) {
+        float z[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float g = gv[i];
-        if (act) g *= act_grad(xv[i] * sc[i] + sh[i], act);
-        a[i] += g; b2[i] += g * xv[i];
+        for (int i = 0; i < VEC; ++i) z[i] = xv[i] * sc[i] + sh[i];
+        act_grad_mul(gv, z, act);
       }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { a[i] += gv[i]; b2[i] += gv[i] * xv[i]; }
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -663,12 +680,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + r * x_ld), xv);
       Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gb + r * gy_ld), gv);
     }
+    if (act) {
+      float z[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      float g = gv[k];
-      if (act) g *= act_grad(xv[k] * sc[k] + sh[k], act);
-      o[k] = g * ca[k] + xv[k] * cb[k] + cc[k];
+      for (int k = 0; k < VEC; ++k) z[k] = xv[k] * sc[k] + sh[k];
+      act_grad_mul(gv, z, act);
     }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = gv[k] * ca[k] + xv[k] * cb[k] + cc[k];
     if constexpr (VEC == 1) ElemIO<T>::st(db + r * dx_ld, o[0]);
     else *reinterpret_cast<uint4*>(db + r * dx_ld) = Vec16<T>::pack(o);
   }

@@ -154,8 +154,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GmConvDesc p) {
           for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[i] + sh[i];
         }
         if (p.pre_act) {
-#pragma unroll
-          for (int i = 0; i < VECW; ++i) v[i] = conv_act(v[i], p.pre_act, PRECISE);
+          conv_act_vec(v, p.pre_act, PRECISE);
         }
         if (!vec_ok || p.pre_scale || p.pre_act) {
 #pragma unroll

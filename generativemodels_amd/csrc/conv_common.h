@@ -61,6 +61,26 @@ __device__ __forceinline__ float conv_act(float v, int act, bool precise) {
     default: return v;
   }
 }
+// The activation of a whole register vector with the (wave-uniform, run-time) kind tested ONCE.  `for i: v[i] = conv_act(v[i], act, ..)` made
+// hipcc emit the switch PER ELEMENT: every element became its own basic block -- s_cmp / s_cbranch, then the fully dependent chain v_mul ->
+// v_exp -> v_add -> v_rcp -> v_mul with the transcendental latencies exposed and nothing to interleave (round-3 ISA read: the out head's fused
+// GroupNorm + SiLU prologue cost 0.15 of its 0.26 ms, the in-LDS prologue of the LDS-DMA convolution as much as a separate pass over HBM).  Here
+// the N chains of a vector sit in one straight-line block and the scheduler interleaves them.
+template <int N>
+__device__ __forceinline__ void conv_act_vec(float (&v)[N], int act, bool precise) {
+  if (act == 1) {
+    if (precise) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = gm_silu_precise(v[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = gm_silu(v[i]);
+    }
+  } else if (act == 2) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+}
 __device__ __forceinline__ float conv_post_act(float v, int act) {
   switch (act) {
     case 1: return fmaxf(v, 0.f);

@@ -410,10 +410,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         float v[VECW];
         Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a), v);
 #pragma unroll
-        for (int i = 0; i < VECW; ++i) {
-          const float t = v[i] * sc[i] + sh[i];
-          v[i] = p.pre_act == 1 ? (sizeof(T) == 4 ? gm_silu_precise(t) : gm_silu(t)) : (p.pre_act == 2 ? fmaxf(t, 0.f) : t);
-        }
+        for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[i] + sh[i];
+        // the activation kind is tested once per vector (conv_act_vec): a per-element ternary on p.pre_act compiled to one basic block per
+        // element with the v_exp -> v_rcp chain of each SiLU fully exposed -- what made this prologue cost as much as a pass over HBM in round 2
+        conv_act_vec(v, p.pre_act, sizeof(T) == 4);
         *reinterpret_cast<uint4*>(a) = Vec16<T>::pack(v);
       }
     }

@@ -249,8 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_cout1_kernel(const GmConvDesc p) 
             for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[s][i] + sh[s][i];
           }
           if (p.pre_act) {
-#pragma unroll
-            for (int i = 0; i < VECW; ++i) v[i] = conv_act(v[i], p.pre_act, PRECISE);
+            conv_act_vec(v, p.pre_act, PRECISE);
           }
           xf = Vec16<T>::pack(v);
         }
@@ -437,8 +436,7 @@ __global__ __launch_bounds__(256, 1) void conv_cout1_march_kernel(const GmConvDe
               for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[s][i] + sh[s][i];
             }
             if (p.pre_act) {
-#pragma unroll
-              for (int i = 0; i < VECW; ++i) v[i] = conv_act(v[i], p.pre_act, PRECISE);
+              conv_act_vec(v, p.pre_act, PRECISE);
             }
             xf = Vec16<T>::pack(v);
           }

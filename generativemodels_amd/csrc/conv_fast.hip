@@ -194,8 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_fast_kernel(const GmC
             for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[i] + sh[i];
           }
           if (p.pre_act) {
-#pragma unroll
-            for (int i = 0; i < VECW; ++i) v[i] = conv_act(v[i], p.pre_act, PRECISE);
+            conv_act_vec(v, p.pre_act, PRECISE);
           }
           outv = Vec16<T>::pack(v);
         }

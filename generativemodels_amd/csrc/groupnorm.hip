@@ -420,10 +420,10 @@ __global__ __launch_bounds__(256) void spade_apply_kernel(const T* __restrict__ 
     const float* sc = scale + n * ss_ld + c;
     const float* sh = shift + n * ss_ld + c;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      float t = (v[k] * sc[k] + sh[k]) * gv[k] + bv[k];
-      if (act == 1) t = sizeof(T) == 4 ? gm_silu_precise(t) : gm_silu(t);
-      v[k] = t;
+    for (int k = 0; k < VEC; ++k) v[k] = (v[k] * sc[k] + sh[k]) * gv[k] + bv[k];
+    if (act == 1) {  // (tested once per vector: a per-element test compiles to one basic block per element, every SiLU's v_exp -> v_rcp chain exposed)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[k] = sizeof(T) == 4 ? gm_silu_precise(v[k]) : gm_silu(v[k]);
     }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) ElemIO<T>::st(y + row * y_ld + c + k, v[k]);

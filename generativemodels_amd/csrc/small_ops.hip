@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
           for (int i = 0; i < VECW; ++i) v[i] = ok ? (v[i] - mean) * rstd * ex.ln_g[cbase + i] + (ex.ln_b ? ex.ln_b[cbase + i] : 0.f) : 0.f;
         }
         if (pre_act) {
-#pragma unroll
-          for (int i = 0; i < VECW; ++i) v[i] = conv_act(v[i], pre_act, PRECISE);
+          conv_act_vec(v, pre_act, PRECISE);
         }
         b = Vec16<T>::pack(v);
       }

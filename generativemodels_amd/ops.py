@@ -641,6 +641,7 @@ SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
 COUT1_MARCH = os.environ.get("GM_CONV_COUT1_MARCH", "1") != "0"  # C_out == 1 heads: the depth-marching kernel (cfg 20) before the tile kernel (cfg 13)
 DMA_WIDE_WAVES = os.environ.get("GM_CONV_WIDE_WAVES", "1") != "0"  # prefer cfg 14 (4 waves x 64 voxels) for large prologue-free stride-1 convolutions
+DMA_WIDE_WAVES_PRE = os.environ.get("GM_CONV_WIDE_WAVES_PRE", "0") != "0"  # ... also with the fused in-LDS prologue (its cfg 14 instantiation)
 DMA_WIDE_WAVE_MIN_TILES = 512                                       # ... from one full wave of work-groups on (2 per CU)
 
 
@@ -762,7 +763,7 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         # form (cfg 11, 128 registers: one operand set) on every C2 / C3 shape once the grid fills the chip (profiles/r02_conv_tile_configs_v2.txt);
         # cfg 11 keeps the fused-prologue instantiation (the cfg 14 one spills) and the small grids (its split-K form).
         tiles = desc.N * -(-desc.Do // 4) * -(-desc.Ho // 4) * -(-desc.Wo // 16) * -(-cout // 64)
-        wide = bool(desc.pre_scale is None or not desc.pre_scale) and tiles >= DMA_WIDE_WAVE_MIN_TILES and DMA_WIDE_WAVES
+        wide = (bool(desc.pre_scale is None or not desc.pre_scale) or DMA_WIDE_WAVES_PRE) and tiles >= DMA_WIDE_WAVE_MIN_TILES and DMA_WIDE_WAVES
         order = ([15] if desc.sd == 2 else ([14, 11] if wide else [11])) + order
         # (512-voxel tiles -- cfg 16 / 18, one work-group per CU, half the weight-panel traffic -- measure within +-5 % of two 256-voxel
         # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,

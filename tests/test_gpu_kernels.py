@@ -967,5 +967,5 @@ def test_conv_single_output_channel_marching_kernel(cin, sp, pro, dtype):
     _check(_cf(got), want, dtype, f"cout1 marching cin{cin}")
     tile = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), force_cfg=13, **kw)
     assert torch.equal(got, tile), "the marching kernel keeps the 27-point summation order of the tile kernel: bit-identical"
-    auto = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), **kw)
-    assert torch.equal(auto, got)
+    auto = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), **kw)  # whatever the chooser picks (small problems: the 64-voxel generic tiles) agrees
+    _check(_cf(auto), want, dtype, f"cout1 cin{cin} auto")
