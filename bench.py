@@ -61,7 +61,7 @@ def kernel_source_sha() -> str:
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "generativemodels_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name == "conv_dma.hip" or name.endswith(".h"):  # the roofline kernel's translation unit and every header it can include
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
@@ -69,8 +69,11 @@ def kernel_source_sha() -> str:
 
 def measured_hbm_traffic(label: str, dtype) -> dict:
     """HBM bytes per launch of the roofline kernel from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs of this same bench command; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md,
-    WRITE_SIZE calibrated 1:1 on the copy kernel).  The file is stamped with the fingerprint of the kernel sources it measured: when the
+    --pmc WRITE_SIZE in separate runs of this same bench command).  Correction as the guide's HBM section asks -- calibrated on known byte
+    counts in this kernel's own access pattern (profiles/r03_fetch_size_calibration.json): FETCH_SIZE counts 64 B per request, so the
+    64-byte activation pieces these convolutions fetch are counted exactly while a wide streaming read is counted at half; WRITE_SIZE is
+    exact.  `traffic` = FETCH_SIZE + WRITE_SIZE for this kernel, `traffic_bracket` = [F + W, 2F + W] (the upper end would hold if every
+    read were a wide one).  The file is stamped with the fingerprint of the kernel sources it measured: when the
     sources have changed since, the figure is stale and `traffic` is null (with the reason) instead of a number from another kernel."""
     try:
         cfg = int(label.split("cfg")[1].rstrip(">"))
@@ -85,6 +88,7 @@ def measured_hbm_traffic(label: str, dtype) -> dict:
     for r in doc.get("rows", []):
         if sym is not None and sym in r["kernel"]:
             return dict(traffic=round(r["hbm_mb_per_launch_corrected"] * 1e6), traffic_unit="bytes/launch (avg over the same launches)",
+                        traffic_bracket=[round(v * 1e6) for v in r.get("hbm_mb_per_launch_bracket", [])] or None,
                         traffic_source=os.path.relpath(TRAFFIC_FILE, ROOT), traffic_launches_sampled=r["launches"], traffic_git_head=doc.get("git_head"))
     return dict(traffic=None, traffic_note=f"the committed PMC pass holds no row for {sym}")
 

@@ -2,6 +2,9 @@
 #pragma once
 #include "gm_common.h"
 
+// key ranges of the split-KV single-query attention of the decode step (small_ops.hip; the merge code unrolls over it)
+#define GM_DECODE_KV_SPLITS 16
+
 struct GmAttnDesc {
   const void* q; long long q_ld;
   const void* k; long long k_ld;

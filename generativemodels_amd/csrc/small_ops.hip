@@ -6,6 +6,7 @@
 //   gm_attention_decode softmax(scale q K^T) V for ONE query per (batch, head) over a KV cache: keys spread over the 256 threads,
 //                       scores through LDS, the PV sum parallel over (channel, key slice)
 //                       (reference: blocks/selfattention.py:117-147 evaluated for the last position only)
+#include <cstdlib>
 #include "attn_common.h"
 #include "conv_common.h"
 
@@ -15,7 +16,33 @@ struct LinearRowsExtra {
   const float* ln_g; const float* ln_b; float ln_eps;  // ln_g != null: x <- LayerNorm(x) * g + b before the GEMM
   void* y1; void* y2; long long y12_ld; int split;     // split > 0: channels [split, 2*split) -> y1, [2*split, 3*split) -> y2 (row pitch y12_ld)
   const int* off_dev; long long off_mul;               // y1 / y2 are advanced by (*off_dev) * off_mul elements at run time (KV-cache row = position)
+  const float* kv_ws; int kv_dh;                       // K-split kernel STAGE 1: x = merge of the split-KV attention partials (head size kv_dh)
+  const float* mlp_p; int mlp_nj; const void* mlp_x1; const float* mlp_b2; void* mlp_x0;  // K-split kernel STAGE 2: x = x1 + b2 + sum_j P[j]
 };
+
+// One channel of the split-KV single-query attention, merged from its GM_DECODE_KV_SPLITS partials in range order.  Workspace =
+// o[BH][NS][dh], then m[BH][NS], l[BH][NS].  The split count is a compile-time constant so that all 3 NS loads are in flight at once (a
+// run-time loop waits for every load in turn: 16 dependent L2 round trips, measured +22 us per call).
+__device__ __forceinline__ float kv_merge_one(const float* __restrict__ ws, int BH, int dh, int bh, int c) {
+  constexpr int NS = GM_DECODE_KV_SPLITS;
+  const float* o = ws + (long long)bh * NS * dh + c;
+  const float* m = ws + (long long)BH * NS * dh + (long long)bh * NS;
+  const float* l = m + (long long)BH * NS;
+  float ms[NS], ls[NS], os[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { ms[s] = m[s]; ls[s] = l[s]; os[s] = o[(long long)s * dh]; }
+  float M = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) M = fmaxf(M, ms[s]);
+  float L = 0.f, acc = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {  // range order
+    const float e = ms[s] == -INFINITY ? 0.f : expf(ms[s] - M);
+    L += ls[s] * e;
+    acc += os[s] * e;
+  }
+  return acc * (1.0f / L);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ w,
@@ -118,17 +145,348 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 3: the decode step's GEMMs re-built around ONE rule -- every global load of a launch is issued before the first wait.  A launch of
+// these kernels is a handful of work-groups on an idle chip; its duration is the ~4.3 us every launch costs on this stack plus one L2 round
+// trip (0.2-0.5 us at the clocks such a load runs at) per DEPENDENT load.  The round-2 kernel above spends 17-25 round trips per launch:
+// hipcc branches around every conditional load (`ok ? p[i] : 0`, `bias ? bias[co] : 0`, the per-element LayerNorm gamma / beta) and waits
+// at each join, and the LayerNorm statistics loops wait for each chunk in turn (rocprofv3: 8.7 us with the LayerNorm prologue, 5.3 without).
+// Here: loads go to clamped / substitute addresses unconditionally and the VALUE is selected; the x rows are staged in LDS once per
+// work-group (LayerNorm / activation applied there by one wave per row, not re-done by every wave); the first batch of weight fragments, the
+// bias and the residual are requested at kernel entry, ahead of the staging.
+//
+// linear_rows_ksplit_kernel: the K chunks of one 16-channel output group are dealt to the FOUR waves of a work-group (the M -> C projection
+// of the MLP, K = 1024, was eight dependent batches on 16 waves of the whole chip); the four partial accumulators meet in LDS in a fixed order.
+// STAGE selects where the x rows come from.  0: global memory.  1 / 2: assembled in LDS from the partial results of the producing launch,
+// which takes that producer's merge launch off the token's dependent chain:
+//   1  x = merge of the split-KV single-query attention partials (kv_merge_one; out-projection of the decode step);
+//   2  x = x1 + b2 + sum_j P[j]  -- the residual stream after the MLP whose down-projection left NJ K-slice partials (mlp_rows_kernel);
+//      work-group 0 also stores the assembled rows (the out-projection two launches later reads them as its residual).
+// The assembled rows are rounded to T, exactly what the un-fused chain stores and re-reads.  XF: 0 = rows used as they are (STAGE 0: straight
+// from global memory, no LDS), 1 = LayerNorm and / or pre-activation applied to the staged rows.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define GM_ROWS_KCH 4  // 16-byte vectors per lane and row in the staging pass: cin <= 64 * VECW * GM_ROWS_KCH (2048 bf16 / 1024 fp32)
+
+// rows [rows][cin] -> xs (LDS, as T), one wave per row: optional LayerNorm (two-pass statistics from registers, like the reference's fp32
+// computation) and optional pre-activation.  SRC_LDS: the rows already sit in xs (assembled there), otherwise they come from global memory.
+template <typename T, bool SRC_LDS>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ x, long long x_ld, T* xs, int rows, int cin, const float* __restrict__ ln_g,
+                                           const float* __restrict__ ln_b, float ln_eps, int pre_act) {
+  constexpr int VECW = ConvTraits<T>::VECW;
+  constexpr bool PRECISE = sizeof(T) == 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* gsrc = ln_g ? ln_g : reinterpret_cast<const float*>(x ? (const void*)x : (const void*)xs);  // never dereferenced without ln_g
+  const float* bsrc = ln_b ? ln_b : gsrc;
+  const float bmul = ln_b ? 1.f : 0.f;
+  for (int r = wave; r < rows; r += 4) {
+    float v[GM_ROWS_KCH][VECW], g[GM_ROWS_KCH][VECW], bb[GM_ROWS_KCH][VECW];
+    bool ok[GM_ROWS_KCH];
+#pragma unroll
+    for (int k = 0; k < GM_ROWS_KCH; ++k) {
+      const int ch = (k * 64 + lane) * VECW;
+      ok[k] = ch + VECW <= cin;
+      const int c = ok[k] ? ch : 0;
+      const uint4 raw = SRC_LDS ? *reinterpret_cast<const uint4*>(xs + (long long)r * cin + c) : *reinterpret_cast<const uint4*>(x + (long long)r * x_ld + c);
+      Vec16<T>::unpack(raw, v[k]);
+      if (ln_g) {  // (uniform; the loads inside are unconditional per lane)
+#pragma unroll
+        for (int i = 0; i < VECW; i += 4) {
+          const float4 tg = *reinterpret_cast<const float4*>(gsrc + c + i), tb = *reinterpret_cast<const float4*>(bsrc + c + i);
+          g[k][i] = tg.x; g[k][i + 1] = tg.y; g[k][i + 2] = tg.z; g[k][i + 3] = tg.w;
+          bb[k][i] = tb.x; bb[k][i + 1] = tb.y; bb[k][i + 2] = tb.z; bb[k][i + 3] = tb.w;
+        }
+      }
+    }
+    if (ln_g) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < GM_ROWS_KCH; ++k)
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) sum += ok[k] ? v[k][i] : 0.f;
+      const float mean = wave_sum(sum) / (float)cin;
+      float sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < GM_ROWS_KCH; ++k)
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) sq += ok[k] ? (v[k][i] - mean) * (v[k][i] - mean) : 0.f;
+      const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)cin + ln_eps);
+#pragma unroll
+      for (int k = 0; k < GM_ROWS_KCH; ++k)
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) v[k][i] = (v[k][i] - mean) * rstd * g[k][i] + bb[k][i] * bmul;
+    }
+#pragma unroll
+    for (int k = 0; k < GM_ROWS_KCH; ++k) {
+      if (pre_act) conv_act_vec(v[k], pre_act, PRECISE);
+      if (ok[k]) *reinterpret_cast<uint4*>(xs + (long long)r * cin + (k * 64 + lane) * VECW) = Vec16<T>::pack(v[k]);
+    }
+  }
+}
+
+template <typename T, int STAGE, int XF>
+__global__ __launch_bounds__(256) void linear_rows_ksplit_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ w,
+                                                                const float* __restrict__ bias, const T* __restrict__ res, long long res_ld,
+                                                                T* __restrict__ y, long long y_ld, int rows, int cin, int cout, int pre_act,
+                                                                int post_act, LinearRowsExtra ex) {
+  constexpr int BK = ConvTraits<T>::BK, VECW = ConvTraits<T>::VECW;
+  constexpr bool STAGED = STAGE != 0 || XF != 0;
+  __shared__ float part[3][64][4];
+  extern __shared__ __attribute__((aligned(16))) char staged_raw[];
+  T* xs = reinterpret_cast<T*>(staged_raw);  // STAGED: [rows][cin]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int cout_pad = (cout + 15) & ~15;
+  const int co0 = blockIdx.x * 16;
+  const int row = l15;  // one row block (host: rows <= 16)
+  const bool row_ok = row < rows;
+  const int nchunks = (cin + BK - 1) / BK;
+  const T* wrow = w + ((long long)(co0 + l15)) * BK + q * VECW;
+  constexpr int U = 4;
+  uint4 wf[U], xf[U];
+  // ---- requested at entry: this wave's first batch of weight fragments (chunks wave, wave + 4, ...), bias and residual of its outputs ----------
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int cc = wave + 4 * u;
+    wf[u] = *reinterpret_cast<const uint4*>(wrow + (long long)(cc < nchunks ? cc : nchunks - 1) * cout_pad * BK);
+  }
+  float bia[4], rsd[4];
+  {
+    const float* bsrc = bias ? bias : reinterpret_cast<const float*>(w);
+    const T* rsrc = res ? res + (long long)(row_ok ? row : 0) * res_ld : w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = co0 + 4 * q + i;
+      bia[i] = bsrc[bias ? (co < cout ? co : cout - 1) : 0];
+      rsd[i] = ElemIO<T>::ld(rsrc + (res ? (co < cout ? co : cout - 1) : 0));
+    }
+  }
+  // this lane's 16-byte vector of chunk c (zero beyond the row / the last channel)
+  auto xvec = [&](int c) __attribute__((always_inline)) -> uint4 {
+    const bool ok = row_ok & (c * BK + q * VECW + VECW <= cin);
+    const uint4 v = STAGED ? *reinterpret_cast<const uint4*>(xs + (ok ? (long long)row * cin + c * BK + q * VECW : 0))
+                           : *reinterpret_cast<const uint4*>(ok ? x + (long long)row * x_ld + q * VECW + c * BK : x);
+    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+  };
+  if (!STAGED) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) xf[u] = xvec(wave + 4 * u < nchunks ? wave + 4 * u : nchunks - 1);
+  }
+  // ---- the x rows into LDS ---------------------------------------------------------------------------------------------------------------
+  if (STAGE == 1) {
+    const int H = cin / ex.kv_dh;
+    for (int idx = threadIdx.x; idx < rows * cin; idx += 256) {
+      const int r = idx / cin, ch = idx - r * cin;
+      ElemIO<T>::st(xs + idx, kv_merge_one(ex.kv_ws, rows * H, ex.kv_dh, r * H + ch / ex.kv_dh, ch % ex.kv_dh));
+    }
+  } else if (STAGE == 2) {
+    const float* b2 = ex.mlp_b2 ? ex.mlp_b2 : ex.mlp_p;
+    const float b2mul = ex.mlp_b2 ? 1.f : 0.f;
+    for (int idx = threadIdx.x; idx < rows * cin; idx += 256) {
+      const int ch = idx % cin;
+      constexpr int PB = 8;  // partials in flight per batch
+      float v = ElemIO<T>::ld(reinterpret_cast<const T*>(ex.mlp_x1) + idx) + b2[ex.mlp_b2 ? ch : 0] * b2mul;
+      const float* pp = ex.mlp_p + idx;
+      const long long pstride = (long long)rows * cin;
+      for (int j0 = 0; j0 < ex.mlp_nj; j0 += PB) {
+        float t[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) t[j] = pp[(j0 + j < ex.mlp_nj ? j0 + j : j0) * pstride];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) v += j0 + j < ex.mlp_nj ? t[j] : 0.f;  // slice order
+      }
+      ElemIO<T>::st(xs + idx, v);
+      if (blockIdx.x == 0 && ex.mlp_x0) reinterpret_cast<T*>(ex.mlp_x0)[idx] = xs[idx];
+    }
+  }
+  if (STAGE != 0 && XF != 0) __syncthreads();
+  if (XF != 0) {
+    if (STAGE == 0) stage_rows<T, false>(x, x_ld, xs, rows, cin, ex.ln_g, ex.ln_b, ex.ln_eps, pre_act);
+    else stage_rows<T, true>(nullptr, 0, xs, rows, cin, ex.ln_g, ex.ln_b, ex.ln_eps, pre_act);
+  }
+  if (STAGED) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) xf[u] = xvec(wave + 4 * u < nchunks ? wave + 4 * u : nchunks - 1);
+  }
+  // ---- GEMM over this wave's chunks ---------------------------------------------------------------------------------------------------------
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = wave; c0 < nchunks; c0 += 4 * U) {
+    if (c0 != wave) {  // (the first batch was requested at entry)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + 4 * u < nchunks ? c0 + 4 * u : nchunks - 1;
+        wf[u] = *reinterpret_cast<const uint4*>(wrow + (long long)c * cout_pad * BK);
+        xf[u] = xvec(c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (c0 + 4 * u < nchunks) Mma<T>::run(wf[u], xf[u], acc);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[wave - 1][lane][i] = acc[i];
+  }
+  __syncthreads();
+  if (wave > 0 || !row_ok) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = ((acc[i] + part[0][lane][i]) + part[1][lane][i]) + part[2][lane][i];  // fixed order: waves 0, 1, 2, 3
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = co0 + 4 * q + i;
+    if (co < cout) {
+      float v = acc[i] + (bias ? bia[i] : 0.f);
+      v = conv_post_act(v, post_act);
+      if (res) v += rsd[i];
+      if (ex.split > 0 && co >= ex.split) {
+        T* dst = reinterpret_cast<T*>(co < 2 * ex.split ? ex.y1 : ex.y2) + (ex.off_dev ? (long long)(*ex.off_dev) * ex.off_mul : 0);
+        ElemIO<T>::st(dst + (long long)row * ex.y12_ld + (co - (co < 2 * ex.split ? ex.split : 2 * ex.split)), v);
+      } else {
+        ElemIO<T>::st(y + (long long)row * y_ld + co, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The MLP of a decode step in ONE launch (round 3): LayerNorm -> up-projection [C -> M] -> GELU -> down-projection [M -> C].  Work-group j
+// owns the hidden slice [64 j, 64 j + 64): the LayerNorm'ed rows are staged in LDS once (stage_rows), its four waves each compute 16 hidden
+// channels over all of K = C, the activated slice goes to LDS as T, and the work-group multiplies it with ITS 64-row K-slice of the
+// down-projection: a [rows][C] fp32 partial P[j] -- no bias, no residual.  The M / 64 partials are summed (slice order) with the residual row
+// and the bias by the consumer's prologue (linear_rows_ksplit_kernel STAGE 2).  Both projections' weight fragments are requested at kernel
+// entry (C <= 256 bf16: all of them), so the launch has one exposed round trip.  One launch instead of two on the token's dependent chain,
+// and the M -> C product runs on M / 64 work-groups.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mlp_rows_kernel(const T* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                      float ln_eps, const T* __restrict__ w1, const float* __restrict__ b1,
+                                                      const T* __restrict__ w2, float* __restrict__ P, int rows, int C, int M, int act) {
+  constexpr int BK = ConvTraits<T>::BK, VECW = ConvTraits<T>::VECW;
+  constexpr int HC = 64 / BK;      // K chunks of the down-projection per hidden slice
+  constexpr int GMAX = 8;          // output groups of the down-projection per wave held in registers: C <= 4 * 16 * GMAX = 512
+  constexpr int U = 8;             // up-projection chunks in flight
+  __shared__ __attribute__((aligned(16))) T hs[16][64 + VECW];  // activated hidden slice, [row][hidden]; + VECW: rows on different banks
+  extern __shared__ __attribute__((aligned(16))) char staged_raw[];
+  T* xs = reinterpret_cast<T*>(staged_raw);  // [rows][C] LayerNorm'ed rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int j = blockIdx.x;
+  const int row = l15;
+  const bool row_ok = row < rows;
+  const int nchunks = (C + BK - 1) / BK;
+  const int cpad = (C + 15) & ~15, mpad = (M + 15) & ~15;
+  const int ngroups = cpad / 16;
+  const int hc0 = j * 64 + wave * 16;  // this wave's hidden channels
+  const T* w1row = w1 + ((long long)(hc0 + l15)) * BK + q * VECW;
+  // ---- requested at entry: the up-projection's first U chunks, the bias of this lane's hidden channels, the down-projection fragments of this
+  //      wave's output groups (wave, wave + 4, ...) for the slice's HC chunks -------------------------------------------------------------------
+  uint4 wf[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) wf[u] = *reinterpret_cast<const uint4*>(w1row + (long long)(u < nchunks ? u : nchunks - 1) * mpad * BK);
+  float b1v[4];
+  {
+    const float* bsrc = b1 ? b1 : reinterpret_cast<const float*>(w1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b1v[i] = bsrc[b1 ? hc0 + 4 * q + i : 0];
+  }
+  uint4 w2f[GMAX][HC];
+#pragma unroll
+  for (int g = 0; g < GMAX; ++g) {
+    const int grp = wave + 4 * g < ngroups ? wave + 4 * g : ngroups - 1;
+#pragma unroll
+    for (int c = 0; c < HC; ++c) w2f[g][c] = *reinterpret_cast<const uint4*>(w2 + ((long long)(j * HC + c) * cpad + grp * 16 + l15) * BK + q * VECW);
+  }
+  // ---- LayerNorm'ed rows into LDS ------------------------------------------------------------------------------------------------------------
+  stage_rows<T, false>(x, C, xs, rows, C, ln_g, ln_b, ln_eps, 0);
+  __syncthreads();
+  auto xvec = [&](int c) __attribute__((always_inline)) -> uint4 {
+    const bool ok = row_ok & (c * BK + q * VECW + VECW <= C);
+    const uint4 v = *reinterpret_cast<const uint4*>(xs + (ok ? (long long)row * C + c * BK + q * VECW : 0));
+    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+  };
+  // ---- phase 1: up-projection of hidden channels 64 j + 16 wave .. + 16, GELU ---------------------------------------------------------------
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < nchunks; c0 += U) {
+    if (c0 != 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) wf[u] = *reinterpret_cast<const uint4*>(w1row + (long long)(c0 + u < nchunks ? c0 + u : nchunks - 1) * mpad * BK);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (c0 + u < nchunks) Mma<T>::run(wf[u], xvec(c0 + u), acc);
+  }
+  // D layout: column = row l15, rows = hidden channels hc0 + 4 q + i  ->  hs[row][16 wave + 4 q + i] (rows beyond `rows` hold zeros)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v = acc[i] + (b1 ? b1v[i] : 0.f);
+    v = conv_post_act(v, act);
+    ElemIO<T>::st(&hs[l15][wave * 16 + 4 * q + i], row_ok ? v : 0.f);
+  }
+  __syncthreads();
+  // ---- phase 2: P[j][row][co] = sum over the slice's 64 hidden channels -------------------------------------------------------------------
+  uint4 hf[HC];
+#pragma unroll
+  for (int c = 0; c < HC; ++c) hf[c] = *reinterpret_cast<const uint4*>(&hs[l15][c * BK + q * VECW]);
+  float* Pj = P + (long long)j * rows * C;
+#pragma unroll
+  for (int g = 0; g < GMAX; ++g) {
+    const int grp = wave + 4 * g;
+    if (grp < ngroups) {
+      f32x4_t a2 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < HC; ++c) Mma<T>::run(w2f[g][c], hf[c], a2);
+      if (row_ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int co = grp * 16 + 4 * q + i;
+          if (co < C) Pj[(long long)row * C + co] = a2[i];
+        }
+      }
+    }
+  }
+}
+
+// one row block and a long K: the K chunks of an output group are dealt to the four waves of a work-group
+static bool linear_rows_takes_ksplit(int rows, int cin, int dtype) {
+  static const bool ksplit = !(getenv("GM_LINEAR_KSPLIT") && getenv("GM_LINEAR_KSPLIT")[0] == '0');  // bench switch (tools/diag_c5.py)
+  const int bk = dtype == GM_F32 ? 16 : 32, vecw = dtype == GM_F32 ? 4 : 8;
+  // (its staging pass holds GM_ROWS_KCH vectors per lane and row, and the staged rows live in <= 48 KiB of LDS)
+  return ksplit && (cin + bk - 1) / bk >= 8 && rows <= 16 && cin <= 64 * vecw * GM_ROWS_KCH && (long long)rows * cin * (dtype == GM_F32 ? 4 : 2) <= 48 * 1024;
+}
+
 static int linear_rows_launch(const void* x, long long x_ld, const void* w, const float* bias, const void* res, long long res_ld, void* y,
                               long long y_ld, int rows, int cin, int cout, int pre_act, int post_act, int dtype, const LinearRowsExtra& ex,
                               void* stream) {
-  GM_REQUIRE(x && w && y, "null pointer");
+  GM_REQUIRE((x || ex.kv_ws || ex.mlp_p) && w && y, "null pointer");
   GM_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "bad geometry");
   if (rows == 0) return 0;
   const int vecw = dtype == GM_F32 ? 4 : 8;
   GM_REQUIRE(cin % vecw == 0 && x_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x rows must be 16-byte vectors");
+  GM_REQUIRE(!(ex.kv_ws || ex.mlp_p) || linear_rows_takes_ksplit(rows, cin, dtype), "the partial-merging prologues live in the K-split kernel");
   GM_REQUIRE(ex.split == 0 || (ex.y1 && ex.y2 && cout == 3 * ex.split), "split output needs two extra destinations and cout = 3 * split");
   hipStream_t st = (hipStream_t)stream;
   const int cout_pad = (cout + 15) & ~15;
+  if (linear_rows_takes_ksplit(rows, cin, dtype)) {
+    dim3 gk(cout_pad / 16, 1);
+    const int stage = ex.kv_ws ? 1 : ex.mlp_p ? 2 : 0;
+    const int xf = (ex.ln_g || pre_act) ? 1 : 0;
+    const size_t smem = (stage || xf) ? (size_t)rows * cin * (dtype == GM_F32 ? 4 : 2) : 0;  // the staged rows
+#define GM_KSPLIT_LAUNCH(T, STAGE, XF)                                                                                                         \
+  linear_rows_ksplit_kernel<T, STAGE, XF><<<gk, 256, smem, st>>>((const T*)x, x_ld, (const T*)w, bias, (const T*)res, res_ld, (T*)y, y_ld, rows, \
+                                                                 cin, cout, pre_act, post_act, ex)
+#define GM_KSPLIT_DISPATCH(T)                                                         \
+  do {                                                                                \
+    if (stage == 0) { if (xf) GM_KSPLIT_LAUNCH(T, 0, 1); else GM_KSPLIT_LAUNCH(T, 0, 0); } \
+    else if (stage == 1) { if (xf) GM_KSPLIT_LAUNCH(T, 1, 1); else GM_KSPLIT_LAUNCH(T, 1, 0); } \
+    else { if (xf) GM_KSPLIT_LAUNCH(T, 2, 1); else GM_KSPLIT_LAUNCH(T, 2, 0); }       \
+  } while (0)
+    if (dtype == GM_F32) GM_KSPLIT_DISPATCH(float);
+    else if (dtype == GM_BF16) GM_KSPLIT_DISPATCH(bf16_raw);
+    else GM_FAIL(-2, "unsupported dtype");
+#undef GM_KSPLIT_DISPATCH
+#undef GM_KSPLIT_LAUNCH
+    GM_LAUNCH_CHECK();
+  }
   dim3 grid((cout_pad / 16 + 3) / 4, (rows + 15) / 16);
   if (dtype == GM_F32)
     linear_rows_kernel<float><<<grid, 256, 0, st>>>((const float*)x, x_ld, (const float*)w, bias, (const float*)res, res_ld, (float*)y, y_ld,
@@ -156,6 +514,50 @@ extern "C" int gm_linear_rows_ln(const void* x, long long x_ld, const float* ln_
   ex.y1 = y1; ex.y2 = y2; ex.y12_ld = y12_ld; ex.split = split;
   ex.off_dev = off_dev; ex.off_mul = off_mul;
   return linear_rows_launch(x, x_ld, w, bias, nullptr, 0, y, y_ld, rows, cin, cout, 0, post_act, dtype, ex, stream);
+}
+
+// out_proj of the decode step reading the split-KV attention partials directly (the merge is this GEMM's prologue: one launch fewer per
+// block).  1 = launched, 0 = not this kernel's case (the caller merges with attn_decode_combine_kernel and calls gm_linear_rows), < 0 = error.
+extern "C" int gm_linear_rows_kvmerge(const float* kv_ws, int kv_ns, int kv_dh, const void* w, const float* bias, const void* res, long long res_ld,
+                                      void* y, long long y_ld, int rows, int cin, int cout, int dtype, void* stream) {
+  if (!kv_ws || kv_ns != GM_DECODE_KV_SPLITS || kv_dh <= 0 || cin % kv_dh || !linear_rows_takes_ksplit(rows, cin, dtype)) return 0;
+  LinearRowsExtra ex = {};
+  ex.kv_ws = kv_ws; ex.kv_dh = kv_dh;
+  const int rc = linear_rows_launch(nullptr, 0, w, bias, res, res_ld, y, y_ld, rows, cin, cout, 0, 0, dtype, ex, stream);
+  return rc ? (rc > 0 ? -rc : rc) : 1;
+}
+
+// The decode step's MLP as one launch leaving K-slice partials, and the consumer form of the small-row GEMM that sums them (see mlp_rows_kernel).
+// gm_mlp_rows_fusable: 1 when both kernels take this geometry.  P holds (M / 64) * rows * C floats.
+extern "C" int gm_mlp_rows_fusable(int rows, int C, int M, int dtype) {
+  static const bool on = !(getenv("GM_DECODE_MLP_FUSE") && getenv("GM_DECODE_MLP_FUSE")[0] == '0');  // bench switch (tools/diag_c5.py)
+  const int vecw = dtype == GM_F32 ? 4 : 8;
+  return on && (dtype == GM_F32 || dtype == GM_BF16) && rows >= 1 && rows <= 16 && C % vecw == 0 && C <= 512 && M % 64 == 0 &&
+         linear_rows_takes_ksplit(rows, C, dtype);
+}
+extern "C" int gm_mlp_rows(const void* x, const float* ln_g, const float* ln_b, float ln_eps, const void* w1, const float* b1, const void* w2,
+                           float* P, int rows, int C, int M, int act, int dtype, void* stream) {
+  GM_REQUIRE(x && w1 && w2 && P && ln_g, "null pointer");
+  GM_REQUIRE(gm_mlp_rows_fusable(rows, C, M, dtype), "geometry outside the fused MLP kernel");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32)
+    mlp_rows_kernel<float><<<M / 64, 256, (size_t)rows * C * 4, st>>>((const float*)x, ln_g, ln_b, ln_eps, (const float*)w1, b1, (const float*)w2, P, rows, C, M, act);
+  else
+    mlp_rows_kernel<bf16_raw><<<M / 64, 256, (size_t)rows * C * 2, st>>>((const bf16_raw*)x, ln_g, ln_b, ln_eps, (const bf16_raw*)w1, b1, (const bf16_raw*)w2, P, rows, C, M, act);
+  GM_LAUNCH_CHECK();
+}
+// y = act(LN(x0) W^T + b) with x0 = x1 + b2 + sum_j P[j] assembled in the prologue (and stored to `x0_out` when given); split outputs as gm_linear_rows_ln
+extern "C" int gm_linear_rows_mlpmerge(const float* P, int nj, const void* x1, const float* b2, void* x0_out, const float* ln_g, const float* ln_b,
+                                       float ln_eps, const void* w, const float* bias, void* y, long long y_ld, void* y1, void* y2, long long y12_ld,
+                                       int split, int rows, int cin, int cout, int post_act, int dtype, const int* off_dev, long long off_mul,
+                                       void* stream) {
+  GM_REQUIRE(P && x1 && nj > 0, "null pointer");
+  LinearRowsExtra ex = {};
+  ex.ln_g = ln_g; ex.ln_b = ln_b; ex.ln_eps = ln_eps;
+  ex.y1 = y1; ex.y2 = y2; ex.y12_ld = y12_ld; ex.split = split;
+  ex.off_dev = off_dev; ex.off_mul = off_mul;
+  ex.mlp_p = P; ex.mlp_nj = nj; ex.mlp_x1 = x1; ex.mlp_b2 = b2; ex.mlp_x0 = x0_out;
+  return linear_rows_launch(nullptr, 0, w, bias, nullptr, 0, y, y_ld, rows, cin, cout, 0, post_act, dtype, ex, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -279,6 +681,164 @@ extern "C" int gm_attention_decode_dev(const GmAttnDesc* dp, const int* lk_dev, 
 }
 
 extern "C" int gm_attention_decode_try(const GmAttnDesc* dp, void* stream) { return gm_attention_decode_dev(dp, nullptr, stream); }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Split-KV form of the single-query attention (round 3).  `attn_decode_kernel` gives one (batch, head) to ONE work-group: at 4096 cached
+// keys each thread walks 16 keys one dependent L2 round trip after the other and then 16 value rows -- 20-25 us per layer on 8 of the
+// chip's 256 CUs.  Here the keys of a (batch, head) are cut into NS contiguous ranges (a multiple of 64 keys each, so a range is one key
+// per thread at NS = 16 and 4096 keys); work-group (bh, s) writes its range's (running max m, sum l of exp(score - m), un-normalised
+// output sum_j exp(score_j - m) v_j) to the workspace and the consumer -- `attn_decode_combine_kernel`, or the out-projection GEMM's
+// prologue (`kv_merge_vec`) -- merges the NS partials in range order:
+//     M = max_s m_s,   out = (sum_s e^{m_s - M} o_s) / (sum_s e^{m_s - M} l_s)   (+ residual).
+// The partition depends on the key count only (host value, or `*lk_dev + 1` under graph replay), every sum has a fixed order: the eager
+// and the replayed step give identical bits.  Workspace: B * H * NS * (dh + 2) floats.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(GmAttnDesc p, const int* __restrict__ lk_dev, float* __restrict__ ws, int NS,
+                                                               int sc_elems, int chunk, int cap) {
+  if (!p.k_bs) p.k_bs = (long long)cap * p.k_ld;  // dense caches: `cap` rows per batch entry
+  if (!p.v_bs) p.v_bs = (long long)cap * p.v_ld;
+  if (lk_dev) p.Lk = *lk_dev + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = reinterpret_cast<float*>(smem);  // [chunk] scores, then probabilities; later the [KL][dh] partial table
+  float* qs = sc + sc_elems;                   // [dh]
+  float* red = qs + p.dh;                      // [4]
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, sp = blockIdx.y;
+  const int dh = p.dh;
+  const int k0 = sp * chunk, k1 = min(p.Lk, k0 + chunk);
+  const long long BH = (long long)gridDim.x;
+  float* wsp = ws + ((long long)bh * NS + sp) * dh;              // o[BH][NS][dh]
+  float* wm = ws + BH * NS * dh + (long long)bh * NS + sp;       // m[BH][NS]
+  float* wl = wm + BH * NS;                                      // l[BH][NS]
+  if (k0 >= p.Lk) {  // an empty range: weight zero in the merge
+    if (tid < dh) wsp[tid] = 0.f;
+    if (tid == 0) { *wm = -INFINITY; *wl = 0.f; }
+    return;
+  }
+  const int n = k1 - k0;
+  const T* Q = reinterpret_cast<const T*>(p.q) + (long long)b * p.q_ld + h * dh;
+  const T* K = reinterpret_cast<const T*>(p.k) + (long long)b * (p.k_bs ? p.k_bs : (long long)p.Lk * p.k_ld) + h * dh + (long long)k0 * p.k_ld;
+  const T* V = reinterpret_cast<const T*>(p.v) + (long long)b * (p.v_bs ? p.v_bs : (long long)p.Lk * p.v_ld) + h * dh + (long long)k0 * p.v_ld;
+  for (int c = tid; c < dh; c += 256) qs[c] = ElemIO<T>::ld(Q + c) * p.scale;
+  __syncthreads();
+  float mx = -INFINITY;
+  constexpr int VECW = 16 / (int)sizeof(T);
+  const bool kvec = (dh % VECW == 0) && (p.k_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0);
+  for (int j = tid; j < n; j += 256) {
+    const T* kr = K + (long long)j * p.k_ld;
+    float s = 0.f;
+    if (kvec) {
+      for (int c = 0; c < dh; c += VECW) {
+        float kv[VECW];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(kr + c), kv);
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) s += qs[c + i] * kv[i];
+      }
+    } else {
+      for (int c = 0; c < dh; ++c) s += qs[c] * ElemIO<T>::ld(kr + c);
+    }
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < n; j += 256) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float tot_l = ((red[0] + red[1]) + red[2]) + red[3];
+  const bool vvec = (dh % VECW == 0) && (p.v_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(V) & 15) == 0);
+  float o[VECW];
+#pragma unroll
+  for (int i = 0; i < VECW; ++i) o[i] = 0.f;
+  const int nv = vvec ? dh / VECW : dh;
+  const int KL = 256 / nv > 0 ? 256 / nv : 1;
+  const int cv = tid % nv, kl = tid / nv;
+  if (kl < KL) {
+    if (vvec) {
+      int j = kl;
+      for (; j + 3 * KL < n; j += 4 * KL) {
+        uint4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(V + (long long)(j + u * KL) * p.v_ld + cv * VECW);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float vv[VECW];
+          Vec16<T>::unpack(r[u], vv);
+          const float pj = sc[j + u * KL];
+#pragma unroll
+          for (int i = 0; i < VECW; ++i) o[i] += pj * vv[i];
+        }
+      }
+      for (; j < n; j += KL) {
+        float vv[VECW];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(V + (long long)j * p.v_ld + cv * VECW), vv);
+        const float pj = sc[j];
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) o[i] += pj * vv[i];
+      }
+    } else {
+      for (int j = kl; j < n; j += KL) o[0] += sc[j] * ElemIO<T>::ld(V + (long long)j * p.v_ld + cv);
+    }
+  }
+  __syncthreads();
+  const int per = vvec ? VECW : 1;
+  if (kl < KL)
+    for (int i = 0; i < per; ++i) sc[kl * dh + cv * per + i] = o[i];
+  __syncthreads();
+  if (tid < dh) {
+    float tot = 0.f;
+    for (int s2 = 0; s2 < KL; ++s2) tot += sc[s2 * dh + tid];
+    wsp[tid] = tot;
+  }
+  if (tid == 0) { *wm = mx; *wl = tot_l; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_decode_combine_kernel(GmAttnDesc p, const float* __restrict__ ws) {
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, dh = p.dh;
+  for (int c = threadIdx.x; c < dh; c += 64) {
+    float out = kv_merge_one(ws, gridDim.x, dh, bh, c);
+    if (p.res) out += ElemIO<T>::ld(reinterpret_cast<const T*>(p.res) + (long long)b * p.res_ld + h * dh + c);
+    ElemIO<T>::st(reinterpret_cast<T*>(p.o) + (long long)b * p.o_ld + h * dh + c, out);
+  }
+}
+
+// 1 = launched, 0 = not this kernel's case.  `ws` holds gm_attention_decode_split_ws_elems(B, H, dh, nsplit) floats.
+extern "C" long long gm_attention_decode_split_ws_elems(int B, int H, int dh, int nsplit) { return (long long)B * H * nsplit * (dh + 2); }
+// `merge`: 1 = partials + merge; 0 = partials only, for a consumer that merges them itself (gm_linear_rows_kvmerge); 2 = the merge launch only.
+// `cap` = rows of the K / V caches per batch entry (>= the key count): the key ranges are cut from it, so they are the same for every position.
+extern "C" int gm_attention_decode_split(const GmAttnDesc* dp, const int* lk_dev, float* ws, int nsplit, int merge, int cap, void* stream) {
+  const GmAttnDesc& d = *dp;
+  if (d.Lq != 1 || d.dh > 256 || d.Lk < 1 || cap < d.Lk || nsplit != GM_DECODE_KV_SPLITS || !ws) return 0;  // (the merge code unrolls over the split count)
+  if (d.dtype != GM_F32 && d.dtype != GM_BF16) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int vecw = d.dtype == GM_F32 ? 4 : 8;
+  const int chunk = ((cap + nsplit - 1) / nsplit + 63) & ~63;
+  const int sc_elems = chunk > 256 * vecw ? chunk : 256 * vecw;  // the score buffer doubles as the [KL][dh] partial table
+  if (sc_elems > 32768) return 0;
+  const size_t smem = (size_t)(sc_elems + d.dh + 4) * sizeof(float);
+  // (measured and removed: a variant issuing the key row, the value vectors, the query and the key count before its first wait -- one exposed
+  //  round trip instead of four -- ran 6.4 vs 6.5 us: these launches are bound by their ~4.5 us floor and their instruction count, not by loads)
+  dim3 grid(d.B * d.H, nsplit);
+  if (d.dtype == GM_F32) {
+    if (merge != 2) attn_decode_split_kernel<float><<<grid, 256, smem, st>>>(d, lk_dev, ws, nsplit, sc_elems, chunk, cap);
+    if (merge) attn_decode_combine_kernel<float><<<d.B * d.H, 64, 0, st>>>(d, ws);
+  } else {
+    if (merge != 2) attn_decode_split_kernel<bf16_raw><<<grid, 256, smem, st>>>(d, lk_dev, ws, nsplit, sc_elems, chunk, cap);
+    if (merge) attn_decode_combine_kernel<bf16_raw><<<d.B * d.H, 64, 0, st>>>(d, ws);
+  }
+  return 1;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // One categorical draw per row by inverse CDF: idx = min{ j : sum_{i <= j} p_i >= u * sum_i p_i }, u uniform in [0, 1) supplied by

@@ -4,14 +4,17 @@ over an N[D]HWC activation arena (see generativemodels_amd/csrc).
 
 What runs per forward (vs. the reference's ~51 conv + 36 GroupNorm + SiLU/add/cat/interpolate launches at config C2):
   * one fp32 micro-GEMM chain for the timestep MLP and *all* per-block `time_emb_proj` rows at once;
-  * per ResnetBlock: 2 GroupNorm-statistics passes + 2 fused convolutions (GN-apply+SiLU prologue, bias + timestep row /
-    residual epilogue) (+ a 1x1 skip conv when the width changes);
+  * per ResnetBlock: 2 fused convolutions (bias + timestep row / residual epilogue, and the per-(sample, channel) GroupNorm statistics of
+    their OUTPUT accumulated in the same epilogue, so no statistics pass reads the tensor again) and one GN-apply + SiLU pass in front of
+    each (a separate 16-byte-vector pass at C2's sizes; folded into the convolution's LDS staging where the chooser finds that cheaper,
+    ops.gn_prologue) (+ a 1x1 skip conv when the width changes; the decoder's skip concatenations are never materialised: ops.VirtualCat);
   * Upsample = nearest-2x folded into the following convolution's input indexing; Downsample = strided convolution;
   * attention = GN stats + one stacked q|k|v GEMM + flash attention with the residual in its epilogue.
-`forward` in eval mode (or under torch.no_grad) is this inference path; in train() mode with gradients enabled it dispatches to
-`forward_train` (native backward kernels behind torch.autograd.Functions, generativemodels_amd/autograd.py), as the reference's training
+`forward` under torch.no_grad (or with nothing that requires a gradient) is this inference path; with gradients enabled and a trainable
+parameter in train() mode, an input that requires grad, or ControlNet residuals that do, it dispatches to `forward_train` (native backward kernels behind torch.autograd.Functions, generativemodels_amd/autograd.py), as the reference's training
 loops call `model(x, timesteps)` directly (tutorials/generative/distributed_training/ddpm_training_ddp.py:249-270).  Dropout
-(`dropout_cattn` > 0) is the identity at inference, like nn.Dropout in eval mode; training with it raises (not implemented)."""
+(`dropout_cattn` > 0) is the identity at inference, like nn.Dropout in eval mode; training with it raises (not implemented).  Mixed
+precision: fp32 parameters under `generativemodels_amd.autocast(torch.bfloat16)` (or torch.autocast("cuda")) compute in bf16."""
 from __future__ import annotations
 
 import math

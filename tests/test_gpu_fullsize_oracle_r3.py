@@ -311,3 +311,40 @@ def test_c4_latent_unet_parameter_gradients_at_real_dims_match_the_oracle_autogr
     for p in model.parameters():
         assert p.grad is None or p.grad.dtype == p.dtype
     _grad_check(model, ref_grads, 6e-4 if mode == "fp32" else 0.18, f"C4 latent UNet parameter gradients at real dims ({mode})")
+
+
+# ---- C5: the KV-cache decode step over a LONG prefix (split-KV single-query attention, K-split small-row GEMMs) ------------------------
+@pytest.mark.parametrize("name,cfg,batch,ntok", [
+    ("C5 transformer 12 x 256 x 8 heads, window 4096", dict(num_tokens=257, max_seq_len=4096, attn_layers_dim=256, attn_layers_depth=12,
+                                                          attn_layers_heads=8), 1, 1100),
+    ("odd geometry: 2 x 72 x 3 heads (dh 24), window 700, batch 2", dict(num_tokens=50, max_seq_len=700, attn_layers_dim=72,
+                                                                        attn_layers_depth=2, attn_layers_heads=3), 2, 700),
+])
+def test_c5_decode_step_over_a_long_prefix_matches_the_oracle_forward(name, cfg, batch, ntok):
+    """Every position's step logits against the oracle's full causal forward of the same tokens (transformer.py:98-106): past 64 keys more than
+    one key range of the split-KV attention is live, past 1024 every one of the 16; the step with a device-side position (the form a HIP graph
+    replays) must give the same bits as the step with a host position."""
+    from generativemodels_amd.networks.nets import DecoderOnlyTransformer
+
+    tr = DecoderOnlyTransformer(**cfg).eval()
+    tsd = R.synthetic_state_dict({k: tuple(v.shape) for k, v in tr.state_dict().items() if v.is_floating_point()}, seed=23)
+    tsd = {**{k: v.clone() for k, v in tr.state_dict().items()}, **tsd}
+    tr.load_state_dict(tsd)
+    toks = torch.randint(0, cfg["num_tokens"], (batch, ntok), generator=torch.Generator().manual_seed(9))
+    want = _oracle(lambda: R.transformer_forward(tsd, cfg, toks))  # (B, T, V)
+    for dtype in (torch.float32, torch.bfloat16):
+        m = DecoderOnlyTransformer(**cfg).eval()
+        m.load_state_dict(tsd)
+        m = m.to(DEV, dtype)
+        cache = m.new_cache(batch, DEV)
+        td = toks.to(DEV)
+        got = torch.stack([m.step(td[:, t:t + 1].contiguous(), t, cache) for t in range(ntok)], dim=1)
+        bar = _fp32_bar if dtype == torch.float32 else _bf16_bar
+        for lo, hi in ((0, 64), (64, 256), (256, ntok)):
+            bar(got[:, lo:hi], want[:, lo:hi], f"{name}: step logits at positions {lo}..{hi - 1} ({str(dtype)[6:]})")
+        pos_dev = torch.zeros(1, dtype=torch.int32, device=DEV)
+        lg = torch.empty((batch, cfg["num_tokens"]), dtype=dtype, device=DEV)
+        for p in (0, 63, 64, 300, ntok - 1):  # rewrites cache row p with the values it already holds
+            pos_dev.fill_(p)
+            m.step_from_device_state(td[:, p:p + 1].contiguous(), pos_dev, cache, lg)
+            assert torch.equal(lg, got[:, p]), (name, dtype, p)

@@ -1,7 +1,7 @@
 """GPU: configuration C5 of SURVEY.md 8(d): VQVAE (8x down, 256 codes x 32) + DecoderOnlyTransformer(257, 4096, 256, 12, 8), raster-scan
 ordering, sampling the 16^3 = 4096 latent tokens of one 128^3 volume with the KV-cache decoder, bf16, random-init weights.
 Prints tokens/s, time per token, the decode time, and -- for a short prefix -- the cost of the reference's recompute-everything loop
-on the same kernels (quadratic in the prefix length).   usage: python tools/bench_c5.py [tokens=4096]"""
+on the same kernels (quadratic in the prefix length).   usage: python tools/bench_c5.py [tokens=4096] [graph]   ("graph": one HIP-graph replay per token, VQVAETransformerInferer(use_hip_graph=True))"""
 import json
 import os
 import sys
@@ -23,7 +23,8 @@ torch.manual_seed(0)
 vq = VQVAE(spatial_dims=3, in_channels=1, out_channels=1, num_embeddings=256, embedding_dim=32).eval().to(dev, dt)
 tr = DecoderOnlyTransformer(num_tokens=257, max_seq_len=ntok, attn_layers_dim=256, attn_layers_depth=12, attn_layers_heads=8).eval().to(dev, dt)
 order = Ordering("raster_scan", 3, (1, side, side, side))
-inf = VQVAETransformerInferer()
+use_graph = len(sys.argv) > 2 and sys.argv[2] == "graph"
+inf = VQVAETransformerInferer(use_hip_graph=use_graph)
 start = torch.full((1, 1), 256, device=dev)
 torch.manual_seed(1)
 inf.sample((2, 2, 2), start, vq, tr, Ordering("raster_scan", 3, (1, 2, 2, 2)), verbose=False)  # warm-up: packs weights
@@ -43,7 +44,7 @@ for n in (256, 1024, min(4096, ntok)):
     tr(x); torch.cuda.synchronize()
     t0 = time.perf_counter(); tr(x); torch.cuda.synchronize()
     recompute[n] = round((time.perf_counter() - t0) * 1e3, 3)
-print(json.dumps(dict(config=f"C5: {ntok} tokens ({side}^3 latent of a {side * 8}^3 volume), transformer 12 x 256 x 8 heads", dtype="bf16",
+print(json.dumps(dict(config=f"C5: {ntok} tokens ({side}^3 latent of a {side * 8}^3 volume), transformer 12 x 256 x 8 heads", dtype="bf16", hip_graph=use_graph,
                       sample_s=round(t_total, 3), tokens_per_s=round(ntok / (t_total - t_dec), 1), ms_per_token=round((t_total - t_dec) * 1e3 / ntok, 4),
                       vqvae_decode_ms=round(t_dec * 1e3, 2), output_finite=bool(torch.isfinite(img.float()).all()),
                       full_forward_ms_at_prefix=recompute,
