@@ -502,21 +502,30 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
     }
     const T* xb = x + ((long long)n * V) * x_ld + (long long)cv * VEC;
     const T* gb = gy + ((long long)n * V) * gy_ld + (long long)cv * VEC;
-    for (long long r = row_begin + r0; r < row_end; r += R) {
-      float xv[VEC], gv[VEC];
-      if constexpr (VEC == 1) { xv[0] = ElemIO<T>::ld(xb + r * x_ld); gv[0] = ElemIO<T>::ld(gb + r * gy_ld); }
-      else {
-        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + r * x_ld), xv);
-        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gb + r * gy_ld), gv);
-      }
-      if (act) {
-        float z[VEC];
+    constexpr int UB = 4;  // rows requested per wait (clamped addresses, masked sums: the additions keep the row order)
+    for (long long r = row_begin + r0; r < row_end; r += (long long)UB * R) {
+      float xv[UB][VEC], gv[UB][VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) z[i] = xv[i] * sc[i] + sh[i];
-        act_grad_mul(gv, z, act);
+      for (int u = 0; u < UB; ++u) {
+        const long long rr = r + (long long)u * R < row_end ? r + (long long)u * R : r;
+        if constexpr (VEC == 1) { xv[u][0] = ElemIO<T>::ld(xb + rr * x_ld); gv[u][0] = ElemIO<T>::ld(gb + rr * gy_ld); }
+        else {
+          Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + rr * x_ld), xv[u]);
+          Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gb + rr * gy_ld), gv[u]);
+        }
       }
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { a[i] += gv[i]; b2[i] += gv[i] * xv[i]; }
+      for (int u = 0; u < UB; ++u) {
+        const bool ok = r + (long long)u * R < row_end;
+        if (act) {
+          float z[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) z[i] = xv[u][i] * sc[i] + sh[i];
+          act_grad_mul(gv[u], z, act);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { a[i] += ok ? gv[u][i] : 0.f; b2[i] += ok ? gv[u][i] * xv[u][i] : 0.f; }
+      }
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -673,23 +682,35 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   const T* xb = x + ((long long)n * V) * x_ld + (long long)cv * VEC;
   const T* gb = gy + ((long long)n * V) * gy_ld + (long long)cv * VEC;
   T* db = dx + ((long long)n * V) * dx_ld + (long long)cv * VEC;
-  for (long long r = row_begin + r0; r < row_end; r += R) {
-    float xv[VEC], gv[VEC], o[VEC];
-    if constexpr (VEC == 1) { xv[0] = ElemIO<T>::ld(xb + r * x_ld); gv[0] = ElemIO<T>::ld(gb + r * gy_ld); }
-    else {
-      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + r * x_ld), xv);
-      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gb + r * gy_ld), gv);
-    }
-    if (act) {
-      float z[VEC];
+  constexpr int UB = 4;  // rows requested per wait
+  for (long long r = row_begin + r0; r < row_end; r += (long long)UB * R) {
+    float xv[UB][VEC], gv[UB][VEC];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) z[k] = xv[k] * sc[k] + sh[k];
-      act_grad_mul(gv, z, act);
+    for (int u = 0; u < UB; ++u) {
+      const long long rr = r + (long long)u * R < row_end ? r + (long long)u * R : r;
+      if constexpr (VEC == 1) { xv[u][0] = ElemIO<T>::ld(xb + rr * x_ld); gv[u][0] = ElemIO<T>::ld(gb + rr * gy_ld); }
+      else {
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xb + rr * x_ld), xv[u]);
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(gb + rr * gy_ld), gv[u]);
+      }
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) o[k] = gv[k] * ca[k] + xv[k] * cb[k] + cc[k];
-    if constexpr (VEC == 1) ElemIO<T>::st(db + r * dx_ld, o[0]);
-    else *reinterpret_cast<uint4*>(db + r * dx_ld) = Vec16<T>::pack(o);
+    for (int u = 0; u < UB; ++u) {
+      const long long rr = r + (long long)u * R;
+      float o[VEC];
+      if (act) {
+        float z[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) z[k] = xv[u][k] * sc[k] + sh[k];
+        act_grad_mul(gv[u], z, act);
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o[k] = gv[u][k] * ca[k] + xv[u][k] * cb[k] + cc[k];
+      if (rr < row_end) {
+        if constexpr (VEC == 1) ElemIO<T>::st(db + rr * dx_ld, o[0]);
+        else *reinterpret_cast<uint4*>(db + rr * dx_ld) = Vec16<T>::pack(o);
+      }
+    }
   }
 }
 

@@ -392,34 +392,56 @@ __global__ __launch_bounds__(SK_THREADS) void conv_splitk_combine_kernel(const G
   long long row_end = row_begin + (long long)R * SK_ITERS;
   if (row_end > V) row_end = V;
   const long long nv = (long long)p.N * V;
+  // Every load of a row is requested before the first wait (round 3): the per-channel addends come through substitute pointers (a branch per
+  // `if (p.bias)` element made 24 dependent round trips), the slices of a row are read with a compile-time bound (a run-time slice loop
+  // waited for each slice in turn) and the residual row with them.  Same order of additions as before: bit-identical results.
+  constexpr int SK_MAX = 8;  // host: ksplit <= 8 (ops.SPLITK_MAX)
   float add[VECW], ss[VECW], sq[VECW];
+  {
+    const float* dummy = p.kpartial;  // any readable address
+    const float* b0 = p.bias ? p.bias + c : dummy;
+    const float* b1 = p.skip_bias ? p.skip_bias + c : dummy;
+    const float* b2 = p.rowvec ? p.rowvec + (long long)n * p.rowvec_bstride + c : dummy;
+    const bool lanes = r0 < R;
+    float t0[VECW], t1[VECW], t2[VECW];
 #pragma unroll
-  for (int i = 0; i < VECW; ++i) {
-    float a = 0.f;
-    if (r0 < R) {
-      if (p.bias) a += p.bias[c + i];
-      if (p.skip_bias) a += p.skip_bias[c + i];
-      if (p.rowvec) a += p.rowvec[(long long)n * p.rowvec_bstride + c + i];
+    for (int i = 0; i < VECW; ++i) { t0[i] = b0[p.bias && lanes ? i : 0]; t1[i] = b1[p.skip_bias && lanes ? i : 0]; t2[i] = b2[p.rowvec && lanes ? i : 0]; }
+#pragma unroll
+    for (int i = 0; i < VECW; ++i) {
+      float a = 0.f;
+      if (lanes) {
+        if (p.bias) a += t0[i];
+        if (p.skip_bias) a += t1[i];
+        if (p.rowvec) a += t2[i];
+      }
+      add[i] = a; ss[i] = 0.f; sq[i] = 0.f;
     }
-    add[i] = a; ss[i] = 0.f; sq[i] = 0.f;
   }
   if (r0 < R) {
+    const T* resp = p.res ? reinterpret_cast<const T*>(p.res) : reinterpret_cast<const T*>(p.y);
+    const long long res_ld = p.res ? p.res_ld : p.y_ld;
     for (long long r = row_begin + r0; r < row_end; r += R) {
       const long long vox = (long long)n * V + r;
+      float4 part[SK_MAX][VECW / 4];
+#pragma unroll
+      for (int s = 0; s < SK_MAX; ++s) {
+        const float* src = p.kpartial + ((long long)(s < p.ksplit ? s : 0) * nv + vox) * C + c;
+#pragma unroll
+        for (int i = 0; i < VECW / 4; ++i) part[s][i] = *reinterpret_cast<const float4*>(src + 4 * i);
+      }
+      float rv[VECW];
+      Vec16<T>::unpack(*reinterpret_cast<const uint4*>(resp + vox * res_ld + c), rv);  // (without a residual: the output row, not used)
       float o[VECW];
 #pragma unroll
       for (int i = 0; i < VECW; ++i) o[i] = add[i];
-      for (int s = 0; s < p.ksplit; ++s) {
-        const float* src = p.kpartial + ((long long)s * nv + vox) * C + c;
 #pragma unroll
-        for (int i = 0; i < VECW; i += 4) {
-          const float4 v = *reinterpret_cast<const float4*>(src + i);
-          o[i] += v.x; o[i + 1] += v.y; o[i + 2] += v.z; o[i + 3] += v.w;
+      for (int s = 0; s < SK_MAX; ++s) {
+        if (s < p.ksplit) {
+#pragma unroll
+          for (int i = 0; i < VECW / 4; ++i) { o[4 * i] += part[s][i].x; o[4 * i + 1] += part[s][i].y; o[4 * i + 2] += part[s][i].z; o[4 * i + 3] += part[s][i].w; }
         }
       }
       if (p.res) {
-        float rv[VECW];
-        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + vox * p.res_ld + c), rv);
 #pragma unroll
         for (int i = 0; i < VECW; ++i) o[i] += rv[i];
       }
@@ -524,6 +546,7 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   const long long ncb = (d.Cout + bn - 1) / bn;
   const bool splitk = d.ksplit > 1 && d.kpartial != nullptr;
   GM_REQUIRE(!splitk || conv_splitk_ok(d), "split-K needs configuration 11, a vector epilogue and ksplit <= the number of K chunks");
+  GM_REQUIRE(!splitk || d.ksplit <= 8, "split-K: at most 8 slices (the combine kernel reads them with a compile-time bound)");
   const long long nblocks = (long long)d.N * ntd * nth * ntw * ncb * (subpixel ? 8 : 1) * (splitk ? d.ksplit : 1);
   GM_REQUIRE(nblocks < (1LL << 31), "grid too large");
   hipStream_t st = (hipStream_t)stream;

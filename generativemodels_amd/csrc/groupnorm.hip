@@ -64,11 +64,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
   for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q[i] = 0.f; }
   if (r0 < R) {
     const T* base = x + ((long long)n * V) * ld + (long long)cv * VEC;
-    for (long long r = row_begin + r0; r < row_end; r += R) {
-      float v[VEC];
-      VecLd<T, VEC>::ld(base + r * ld, v);
+    // eight rows requested per wait (clamped addresses, masked sums: same order of additions as a row-by-row walk).  The walk used to wait for
+    // every row in turn -- 64 dependent round trips per block: 20 us for ANY tensor (rocprofv3, C3 latent UNet / C4 training step)
+    constexpr int UB = 8;
+    for (long long r = row_begin + r0; r < row_end; r += (long long)UB * R) {
+      float v[UB][VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
+      for (int u = 0; u < UB; ++u) {
+        const long long rr = r + (long long)u * R;
+        VecLd<T, VEC>::ld(base + (rr < row_end ? rr : r) * ld, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const bool ok = r + (long long)u * R < row_end;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { s[i] += ok ? v[u][i] : 0.f; q[i] += ok ? v[u][i] * v[u][i] : 0.f; }
+      }
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -129,10 +140,19 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double2* __restri
   }
 }
 
+// rows per block of the statistics pass: 8 .. GN_ROWS_PER_THREAD rows per lane (a multiple of 8: the walk requests 8 rows per wait), as few as
+// still give ~1024 blocks -- a 32^3 tensor got 16 blocks of 2048 rows with the fixed 64 rows per lane
+static long long gn_rows_per_block(long long V, int R) {
+  long long rpt = (V + (long long)R * 1024 - 1) / ((long long)R * 1024);
+  rpt = (rpt + 7) / 8 * 8;
+  if (rpt < 8) rpt = 8;
+  if (rpt > GN_ROWS_PER_THREAD) rpt = GN_ROWS_PER_THREAD;
+  return (long long)R * rpt;
+}
 static long long gn_nblk(long long V, int C, int vec) {
   const int CV = C / vec;
   const int R = GN_THREADS / CV;
-  const long long rpb = (long long)R * GN_ROWS_PER_THREAD;
+  const long long rpb = gn_rows_per_block(V, R);
   return (V + rpb - 1) / rpb;
 }
 
@@ -154,7 +174,7 @@ static int launch_gn_stats(const void* x, long long ld, int N, long long V, int 
                            hipStream_t st, double* chan_out = nullptr) {
   const int CV = C / VEC;
   const int R = GN_THREADS / CV;
-  const int rpb = R * GN_ROWS_PER_THREAD;
+  const int rpb = (int)gn_rows_per_block(V, R);
   const int nblk = gm_cdiv(V, rpb);
   const size_t smem = (size_t)R * C * 2 * sizeof(float) + (size_t)C * 2 * sizeof(double);
   *nblk_out = nblk;
