@@ -20,6 +20,10 @@ def __getattr__(name):
         from . import ops
 
         return getattr(ops, name)
+    if name == "GraphedForwardBackward":  # HIP-graph replay of a training step's forward + backward (graphs.py)
+        from .graphs import GraphedForwardBackward
+
+        return GraphedForwardBackward
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 _MIRRORED = ["", ".networks", ".networks.nets", ".networks.blocks", ".networks.blocks.spade_norm", ".networks.schedulers", ".networks.layers",

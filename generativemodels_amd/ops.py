@@ -5,6 +5,7 @@ unit stride on C and an arbitrary leading dimension (so a channel slice of a wid
 No fallback: a CPU tensor, a missing library or an unsupported geometry raises."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 import os
@@ -183,7 +184,24 @@ def new_arena(n: int, spatial: Sequence[int], c: int, dtype, device) -> torch.Te
 _param_cache: dict = {}
 
 
+# While a training step is being captured into a HIP graph (graphs.GraphedForwardBackward) the derivatives of TRAINABLE parameters are re-made
+# inside the capture instead of served from the cache: the replays must read the weights the optimizer has updated since, and a panel packed
+# before the capture would be baked into the graph as a constant.  (Inference graphs keep the cache: their weights do not change.)
+_REFRESH_TRAINABLE = [False]
+
+
+@contextlib.contextmanager
+def refresh_trainable_derivatives():
+    keep, _REFRESH_TRAINABLE[0] = _REFRESH_TRAINABLE[0], True
+    try:
+        yield
+    finally:
+        _REFRESH_TRAINABLE[0] = keep
+
+
 def _cached(param: torch.Tensor, tag, make):
+    if _REFRESH_TRAINABLE[0] and param.requires_grad:
+        return make()
     key = (id(param), tag)
     ent = _param_cache.get(key)
     ver = (param._version, param.data_ptr(), param.dtype, param.device)

@@ -69,9 +69,42 @@ def main():
         assert checked > 40
     assert red._side is not None, "the exchange did not run on a side HIP stream"
     assert overlapped[0] < len(red.buckets) and overlapped[1] == len(red.buckets) == overlapped[2], (overlapped, len(red.buckets))
+    # ---- the same step replayed from ONE HIP graph (generativemodels_amd.GraphedForwardBackward with the reducer): bucket fills + forward +
+    #      backward inside the graph, gradients accumulated straight into the bucket views, the RCCL exchange in finish() after the replay ----
+    import generativemodels_amd as gm
+
+    def loss_fn(m):
+        return lambda x, noise, t: F.mse_loss(inferer(inputs=x, diffusion_model=m, noise=noise, timesteps=t).float(), noise.float())
+
+    x0 = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+    n0 = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+    t0 = torch.randint(0, 1000, (2,), generator=g).to(dev)
+    # (a fresh replica: a graphed step is set up before the model's first eager step -- the gradient accumulators of parameters that have
+    #  already run a backward on the default stream remember that stream, which a capture on a side stream cannot follow)
+    replica = build()
+    red2 = GradientReducer(replica.parameters(), bucket_mb=0.25, force=True)
+    graphed = gm.GraphedForwardBackward(loss_fn(replica), (x0, n0, t0), replica.parameters(), reducer=red2)
+    for step in range(2):
+        x = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+        noise = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+        t = torch.randint(0, 1000, (2,), generator=g).to(dev)
+        for p_ in plain.parameters():
+            p_.grad = None
+        want = loss_fn(plain)(x, noise, t)
+        want.backward()
+        got = graphed(x, noise, t)
+        red2.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want.detach()), (step, float(got), float(want))
+        for (name, a), b in zip(plain.named_parameters(), replica.parameters()):
+            if a.grad is None:
+                assert b.grad is None, name
+                continue
+            assert torch.equal(a.grad, b.grad), f"graphed step {step}: gradient of {name} differs"
+            assert b.grad.data_ptr() == red2._view[id(b)].data_ptr()
     dist.barrier()
     dist.destroy_process_group()
-    print(f"RCCL_WORKER_OK buckets={len(red.buckets)} overlapped_per_step={overlapped}")
+    print(f"RCCL_WORKER_OK buckets={len(red.buckets)} overlapped_per_step={overlapped} graphed_steps=2")
 
 
 if __name__ == "__main__":

@@ -772,3 +772,67 @@ def test_spade_networks_train_gradients_match_the_oracle_autograd(kind):
         _close(p.grad, want, 1e-3, f"d spade {kind}.{name}")
         checked += 1
     assert checked > 30
+
+
+@pytest.mark.parametrize("dims,mixed", [(2, False), (3, True)])
+def test_graphed_training_step_is_bitwise_the_eager_step(dims, mixed):
+    """generativemodels_amd.GraphedForwardBackward (graphs.py): the reference training step (ddpm_training_ddp.py:249-270: inferer -> mse_loss ->
+    backward) captured once into a HIP graph and replayed.  Three optimizer steps (Adam, eager, between replays) on fresh batches give bit for bit
+    the losses, gradients and parameters of the same three steps issued eagerly -- also when the optimizer drops the gradients
+    (zero_grad(set_to_none=True)) between replays -- and the replayed weights are the CURRENT ones (the bf16 panels are re-derived in the graph)."""
+    import contextlib
+
+    import generativemodels_amd as gm
+    import restatement as R
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    from generativemodels_amd.networks.schedulers import DDPMScheduler
+    cfg = dict(spatial_dims=dims, in_channels=2, out_channels=2, num_res_blocks=1, num_channels=(32, 64), attention_levels=(False, True),
+               num_head_channels=32, norm_num_groups=32)
+    shape = (2, 2) + (16,) * dims
+    region = (lambda: gm.autocast(torch.bfloat16)) if mixed else contextlib.nullcontext
+    inf = DiffusionInferer(DDPMScheduler(1000))
+    images = _rand(shape, 501).to(DEV)
+    batches = [(_rand(shape, 502 + it).to(DEV), torch.tensor([40 + 300 * it, 900 - 250 * it]).to(DEV)) for it in range(3)]
+
+    def build():
+        torch.manual_seed(33)
+        m = DiffusionModelUNet(**cfg)
+        R.derandomize_zeros(m, seed=9)
+        m = m.to(DEV)
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3)
+
+    def loss_of(m):
+        def fn(x, noise, t):
+            with region():
+                pred = inf(inputs=x, diffusion_model=m, noise=noise, timesteps=t)
+            return F.mse_loss(pred.float(), noise.float())
+        return fn
+
+    m0, opt0 = build()
+    f0 = loss_of(m0)
+    eager_losses, eager_grads = [], []
+    for noise, t in batches:
+        opt0.zero_grad(set_to_none=True)
+        loss = f0(images, noise, t)
+        loss.backward()
+        eager_losses.append(loss.detach().clone())
+        eager_grads.append({k: None if p.grad is None else p.grad.clone() for k, p in m0.named_parameters()})
+        opt0.step()
+
+    m1, opt1 = build()
+    step = gm.GraphedForwardBackward(loss_of(m1), (images, batches[0][0], batches[0][1]), m1.parameters())
+    for it, (noise, t) in enumerate(batches):
+        opt1.zero_grad(set_to_none=True)  # the step re-attaches its static gradient tensors
+        loss = step(images, noise, t)
+        assert torch.equal(loss, eager_losses[it]), (it, float(loss), float(eager_losses[it]))
+        for k, p in m1.named_parameters():
+            want = eager_grads[it][k]
+            assert (p.grad is None) == (want is None), (it, k)
+            if want is not None:
+                assert torch.equal(p.grad, want), (it, k)
+        opt1.step()
+    for (k, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(a, b), k
+    with pytest.raises(ValueError):
+        step(images[:1], batches[0][0], batches[0][1])

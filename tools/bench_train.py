@@ -5,7 +5,9 @@ dtype "mixed" (the default) is the reference's own arithmetic for this loop (ddp
 autocast, GradScaler): fp32 master parameters and fp32 gradients / Adam state, bf16 activations and MFMA operands inside
 `generativemodels_amd.autocast(torch.bfloat16)`.  "bf16" casts the parameters themselves (narrower than the reference: an lr-sized Adam update
 is below half a bf16 ulp of most weights), "fp32" runs the exact-fp32 MFMA kernels.
-usage: python tools/bench_train.py [size=256] [batch=1] [dtype=mixed|bf16|fp32] [steps=3]     (under torchrun: one process per GPU, RCCL)"""
+"graph" replays encode + forward + loss + backward from ONE HIP graph (generativemodels_amd.GraphedForwardBackward): the eager step is host-bound
+(~620 launches at ~50 us of Python each against ~19 ms of kernels).
+usage: python tools/bench_train.py [size=256] [batch=1] [dtype=mixed|bf16|fp32] [steps=3] [eager|graph]     (under torchrun: one process per GPU, RCCL)"""
 import json
 import os
 import sys
@@ -34,6 +36,7 @@ if mode not in ("mixed", "bf16", "fp32"):
 dt = torch.bfloat16 if mode == "bf16" else torch.float32          # dtype of the parameters (and of the optimizer state)
 region = (lambda: gm.autocast(torch.bfloat16)) if mode == "mixed" else contextlib.nullcontext
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+use_graph = len(sys.argv) > 5 and sys.argv[5] == "graph"
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -64,14 +67,27 @@ imgs = torch.randn((batch, 1, size, size, size), generator=g).to(dev, dt)
 lat = size // 8
 
 
+def loss_fn(images, noise, t):
+    with region():
+        pred = inf(inputs=images, autoencoder_model=ae, diffusion_model=unet, noise=noise, timesteps=t)
+    return F.mse_loss(pred.float(), noise.float())
+
+
+graphed = None
+if use_graph:
+    graphed = gm.GraphedForwardBackward(loss_fn, (imgs, torch.randn((batch, 4, lat, lat, lat), device=dev, dtype=dt),
+                                                  torch.randint(0, 1000, (batch,), device=dev)), unet.parameters(), reducer=red)
+
+
 def step():
     noise = torch.randn((batch, 4, lat, lat, lat), generator=g).to(dev, dt)
     t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
-    red.zero_grad() if red.active else opt.zero_grad(set_to_none=True)  # one fill per bucket: .grad stays a view of its flat bucket
-    with region():
-        pred = inf(inputs=imgs, autoencoder_model=ae, diffusion_model=unet, noise=noise, timesteps=t)
-    loss = F.mse_loss(pred.float(), noise.float())
-    loss.backward()
+    if graphed is not None:
+        loss = graphed(imgs, noise, t)
+    else:
+        red.zero_grad() if red.active else opt.zero_grad(set_to_none=True)  # one fill per bucket: .grad stays a view of its flat bucket
+        loss = loss_fn(imgs, noise, t)
+        loss.backward()
     red.finish()
     opt.step()
     return loss
@@ -125,7 +141,7 @@ for name, meta, ms in ops.stop_profile():
 if rank == 0:
     print(json.dumps(dict(config=f"C4 per-rank training step: {batch} x 1 x {size}^3 volumes -> {batch} x 4 x {lat}^3 latents, 41.7 M-parameter UNet",
                           dtype=("mixed: fp32 parameters / gradients / Adam state, bf16 compute" if mode == "mixed" else str(dt).split(".")[-1]),
-                          gradient_bucket_bytes=sum(p.numel() * p.element_size() for p in unet.parameters()), n_gpus=world, step_ms=round(dt_step * 1e3, 2),
+                          gradient_bucket_bytes=sum(p.numel() * p.element_size() for p in unet.parameters()), n_gpus=world, step_ms=round(dt_step * 1e3, 2), hip_graph=use_graph,
                           gradient_exchange=(f"RCCL all-reduce, {len(red.buckets)} buckets, {red.launched_in_backward} launched during backward "
                                              f"(world_size {world})" if red.active else "off (one rank)"),
                           volumes_per_s=round(world * batch / dt_step, 3), losses=[round(v, 4) for v in losses], phases=phases,
