@@ -8,6 +8,7 @@
 //
 // HBM-bound: one read of the tensor (C*V*elt bytes per sample).  Reductions: per-thread fp32 partials over <= 64 rows,
 // wave/LDS tree in fp64, block partials merged in fp64 in a fixed order -> deterministic and fp32-parity safe.
+#include <cstdlib>
 #include "gm_common.h"
 
 #define GM_STAT_SLOTS 64  // see conv_common.h
@@ -390,6 +391,63 @@ __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__
   }
 }
 
+// The same pass with the lane <-> channel-vector assignment fixed (round 3): a block walks `rows_per_block` rows of one sample, thread t owns
+// channel vector t % CV of rows r0 + k * R, so its scale / shift vectors are loaded ONCE and the addresses are 32-bit increments.  The
+// grid-stride form above spends two 64-bit divisions and four 16-byte table loads per 16-byte vector -- as many VALU slots as the SiLU -- and
+// the pass is VALU-bound, not HBM-bound, at 5.0 TB/s (2.5 T elements/s x ~26 lane-operations against 31 T lane-operations/s).  Four rows are
+// requested per wait.  grid (nblk, N); host: CV <= 256.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y, long long y_ld,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, long long ss_ld,
+                                                           long long V, int C, int rows_per_block, int act) {
+  const int CV = C / VEC, R = 256 / CV;
+  const int n = blockIdx.y, t = threadIdx.x;
+  const int cv = t % CV, r0 = t / CV;
+  if (r0 >= R) return;
+  const long long row_begin = (long long)blockIdx.x * rows_per_block;
+  long long row_end = row_begin + rows_per_block;
+  if (row_end > V) row_end = V;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; k += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(scale + n * ss_ld + cv * VEC + k), b = *reinterpret_cast<const float4*>(shift + n * ss_ld + cv * VEC + k);
+    sc[k] = a.x; sc[k + 1] = a.y; sc[k + 2] = a.z; sc[k + 3] = a.w;
+    sh[k] = b.x; sh[k + 1] = b.y; sh[k + 2] = b.z; sh[k + 3] = b.w;
+  }
+  const T* xb = x + ((long long)n * V) * x_ld + (long long)cv * VEC;
+  T* yb = y + ((long long)n * V) * y_ld + (long long)cv * VEC;
+  constexpr int UB = 4;
+  for (long long r = row_begin + r0; r < row_end; r += (long long)UB * R) {
+    float v[UB][VEC];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const long long rr = r + (long long)u * R < row_end ? r + (long long)u * R : r;
+      VecLd<T, VEC>::ld(xb + rr * x_ld, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[u][k] = v[u][k] * sc[k] + sh[k];
+      if (act == 1) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[u][k] = sizeof(T) == 4 ? gm_silu_precise(v[u][k]) : gm_silu(v[u][k]);
+      } else if (act == 2) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[u][k] = fmaxf(v[u][k], 0.f);
+      }
+      const long long rr = r + (long long)u * R;
+      if (rr < row_end) {
+        if (sizeof(T) == 4) {
+          *reinterpret_cast<float4*>(yb + rr * y_ld) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+        } else {
+          *reinterpret_cast<uint4*>(yb + rr * y_ld) = make_uint4(pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], v[u][3]),
+                                                                 pack_bf16x2(v[u][4 % VEC], v[u][5 % VEC]), pack_bf16x2(v[u][6 % VEC], v[u][7 % VEC]));
+        }
+      }
+    }
+  }
+}
+
 // scale/shift rows are ss_ld floats apart (ss_ld >= C: a channel slice of a wider [N][C_total] table is a valid operand)
 extern "C" int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_ld, const float* scale, const float* shift,
                            long long ss_ld, int N, long long V, int C, int act, int dtype, void* stream) {
@@ -400,6 +458,21 @@ extern "C" int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_l
   const int vec = dtype == GM_F32 ? 4 : 8;
   const bool vec_ok = (C % vec == 0) && (x_ld % vec == 0) && (y_ld % vec == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
                       (ss_ld % 4 == 0) && (((uintptr_t)scale & 15) == 0) && (((uintptr_t)shift & 15) == 0);
+  static const bool rows_form = !(getenv("GM_GN_APPLY_ROWS") && getenv("GM_GN_APPLY_ROWS")[0] == '0');  // bench switch (tools/layer_times.py)
+  if (rows_form && vec_ok && (dtype == GM_F32 || dtype == GM_BF16) && C / vec <= 256 && N <= 65535) {
+    const int R = 256 / (C / vec);
+    long long iters = (V + (long long)R * 2048 - 1) / ((long long)R * 2048);  // rows per lane: 4 .. 16, about 2048+ blocks per sample
+    iters = (iters + 3) / 4 * 4;
+    if (iters < 4) iters = 4;
+    if (iters > 16) iters = 16;
+    const int rpb = (int)(R * iters);
+    dim3 grid((unsigned)((V + rpb - 1) / rpb), (unsigned)N);
+    if (dtype == GM_F32)
+      gn_apply_rows_kernel<float, 4><<<grid, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, ss_ld, V, C, rpb, act);
+    else
+      gn_apply_rows_kernel<bf16_raw, 8><<<grid, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, ss_ld, V, C, rpb, act);
+    GM_LAUNCH_CHECK();
+  }
   if (vec_ok && (dtype == GM_F32 || dtype == GM_BF16)) {
     const long long tv = total / vec;
     long long g = (tv + 255) / 256;
