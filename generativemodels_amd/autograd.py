@@ -274,6 +274,7 @@ def upsample_conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
 
 
 ATTENTION_BWD_MAX_TOKENS = 8192
+ATTENTION_BWD_BF16_MIN_TOKENS = int(__import__("os").environ.get("GM_ATTN_BWD_BF16_MIN_TOKENS", "512"))  # (bench switch: a huge value disables the path)
 
 
 class _Attention(torch.autograd.Function):
@@ -294,6 +295,13 @@ class _Attention(torch.autograd.Function):
         # Measured on MI355X (tools/cmp_attention_backward.py): the fused kernels own 64 rows per work-group, so ONE head of a few
         # thousand tokens leaves most CUs idle (L = 4096, d = 128: 1.9 ms fused vs 0.86 ms composed), while many (sample, head) pairs
         # favour them (2 x 4 heads of 1024 tokens: 0.21 vs 2.5 ms) and long sequences leave no choice (the composed path stores L x L).
+        # bf16 operands, one or two (sample, head) pairs of >= 512 tokens (C4: one head x 4096 tokens at 16^3, one x 512 at 8^3): the bf16-MFMA score pass
+        # + the weight-gradient / 1x1 kernels (ops.attention_backward_bf16): every product at the bf16 MFMA rate, where the fused kernels
+        # below run fp32 MFMA on 64 work-groups and the fp32 composed path materialises fp32 L x L matrices
+        if (q.dtype == torch.bfloat16 and dh in ops.ATTENTION_BWD_BF16_HEAD_DIMS and b * heads <= 2 and max(lq, lk) >= ATTENTION_BWD_BF16_MIN_TOKENS
+                and 6 * b * heads * (lq + 63) * (lk + 63) <= ops.ATTENTION_BWD_BF16_MAX_BYTES):
+            dq, dk, dv = ops.attention_backward_bf16(q, k, v, o, go.contiguous(), heads, scale)
+            return dq, dk, dv, None, None
         composed_ok = max(lq, lk) <= ATTENTION_BWD_MAX_TOKENS
         prefer_composed = composed_ok and b * heads <= 2 and max(lq, lk) >= 2048
         if dh in ops.ATTENTION_BWD_HEAD_DIMS and not prefer_composed:

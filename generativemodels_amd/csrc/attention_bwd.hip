@@ -327,3 +327,237 @@ extern "C" int gm_attention_backward(const GmAttnBwdDesc* dp, void* stream) {
   GM_REQUIRE(rc == 0, "head dim must be 16, 32, 64, 128 or 256");
   GM_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// bf16-MFMA score pass of the attention backward (round 3; VERDICT r2 "missing" #4).  The contractions of the backward come in two kinds:
+// over CHANNELS (S = Q K^T, dP = dO V^T) -- both operands are natural [row][channel] tiles, 8 consecutive channels per lane = one
+// v_mfma_f32_16x16x32_bf16 operand -- and over ROWS (dV = P^T dO, dK = dS^T Q, dQ = dS K), which need transposed images.  This file's new
+// kernels do the first kind plus the softmax algebra at the full bf16 MFMA rate and leave P and dS as bf16 [Lq][Lk] matrices; the second
+// kind then runs on the kernels that already stage transposed operands: dV and dK on the weight-gradient kernel (backward.hip: the contraction
+// over voxels IS a contraction over rows), dQ on the 1x1 convolution.  Six GEMM units instead of the fused fp32 kernels' seven, all on bf16
+// MFMA with fp32 accumulation and fp32 softmax state (scores never rounded to bf16 before the exponential), at the price of 2 x Lq x Lk x 2
+// bytes per (sample, head) in HBM -- 67 MB at the 4096 tokens of C4's 16^3 level, 4.3 GB at 32 768 tokens.
+//   attn_bwd_lse16    own rows = 16 queries per wave (MFMA columns, fragments in registers), key tiles of 64 streamed through LDS:
+//                     LSE[q] = log sum_k exp(scale q.k) by an online max / sum per lane, and Dsum[q] = dO[q] . O[q]
+//   attn_bwd_ps16     one 64-query x 64-key tile per work-group: S^T = K Q^T and dP^T = V dO^T (the K and V tiles in LDS, the Q and dO
+//                     fragments in registers), P = exp(scale S - LSE), dS = P (dP - Dsum) scale, both stored as bf16
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define AB16_KEYS 64
+
+// [AB16_KEYS][DH] bf16 tile -> LDS with a 16-byte row pad; rows >= L are zero.  256 threads.
+template <int DH>
+__device__ __forceinline__ void ab16_stage(const bf16_raw* base, long long ld, int row0, int L, bf16_raw* lds, int tid) {
+  constexpr int PITCH = DH + 8, VPR = DH / 8;
+  constexpr int ITEMS = AB16_KEYS * VPR / 256;  // DH >= 32: >= 1
+  uint4 v[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int it = tid + i * 256, row = it / VPR, cvec = it % VPR;
+    const bool ok = row0 + row < L;
+    const uint4 t = *reinterpret_cast<const uint4*>(base + (long long)(ok ? row0 + row : 0) * ld + cvec * 8);
+    v[i] = make_uint4(ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int it = tid + i * 256, row = it / VPR, cvec = it % VPR;
+    *reinterpret_cast<uint4*>(lds + row * PITCH + cvec * 8) = v[i];
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_lse16_kernel(GmAttnBwdDesc p, float* __restrict__ lse_out, float* __restrict__ dsum_out) {
+  constexpr int KS = DH / 32, PITCH = DH + 8;
+  extern __shared__ __attribute__((aligned(16))) char ab16_smem[];
+  bf16_raw* kt = reinterpret_cast<bf16_raw*>(ab16_smem);  // [AB16_KEYS][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, qg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int q = blockIdx.x * 64 + wave * 16 + l15;
+  const bool q_ok = q < p.Lq;
+  const bf16_raw* Q = reinterpret_cast<const bf16_raw*>(p.q) + ((long long)b * p.Lq + (q_ok ? q : 0)) * p.q_ld + h * DH;
+  const bf16_raw* K = reinterpret_cast<const bf16_raw*>(p.k) + (long long)b * p.Lk * p.k_ld + h * DH;
+  uint4 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const uint4 t = *reinterpret_cast<const uint4*>(Q + ks * 32 + qg * 8);
+    qf[ks] = make_uint4(q_ok ? t.x : 0u, q_ok ? t.y : 0u, q_ok ? t.z : 0u, q_ok ? t.w : 0u);
+  }
+  // Dsum: this lane's 8-channel vectors of dO and O
+  float dpart = 0.f;
+  {
+    const bf16_raw* O = reinterpret_cast<const bf16_raw*>(p.o) + ((long long)b * p.Lq + (q_ok ? q : 0)) * p.o_ld + h * DH;
+    const bf16_raw* G = reinterpret_cast<const bf16_raw*>(p.go) + ((long long)b * p.Lq + (q_ok ? q : 0)) * p.go_ld + h * DH;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 a = *reinterpret_cast<const uint4*>(O + ks * 32 + qg * 8), g = *reinterpret_cast<const uint4*>(G + ks * 32 + qg * 8);
+      const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        dpart += __uint_as_float(aw[i] << 16) * __uint_as_float(gw[i] << 16) + __uint_as_float(aw[i] & 0xffff0000u) * __uint_as_float(gw[i] & 0xffff0000u);
+    }
+  }
+  float m = -INFINITY, s = 0.f;
+  for (int k0 = 0; k0 < p.Lk; k0 += AB16_KEYS) {
+    __syncthreads();
+    ab16_stage<DH>(K, p.k_ld, k0, p.Lk, kt, tid);
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < AB16_KEYS / 16; ++rb) {
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4*>(kt + (rb * 16 + l15) * PITCH + ks * 32 + qg * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[ks]), acc, 0, 0, 0);
+      }
+      // acc[r] = q . k for key k0 + rb * 16 + 4 qg + r
+      float x[4], tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[r] = k0 + rb * 16 + 4 * qg + r < p.Lk ? acc[r] * p.scale : -INFINITY;
+        tmax = fmaxf(tmax, x[r]);
+      }
+      const float mn = fmaxf(m, tmax);
+      if (mn > -INFINITY) {
+        float add = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) add += __expf(x[r] - mn);
+        s = s * __expf(m - mn) + add;
+        m = mn;
+      }
+    }
+  }
+  // the four lanes sharing a query (qg = 0..3) hold disjoint key subsets
+  float M = fmaxf(m, __shfl_xor(m, 16, 64));
+  M = fmaxf(M, __shfl_xor(M, 32, 64));
+  float st = m > -INFINITY ? s * __expf(m - M) : 0.f;
+  st += __shfl_xor(st, 16, 64);
+  st += __shfl_xor(st, 32, 64);
+  dpart += __shfl_xor(dpart, 16, 64);
+  dpart += __shfl_xor(dpart, 32, 64);
+  if (qg == 0 && q_ok) {
+    lse_out[(long long)bh * p.Lq + q] = M + __logf(st);
+    dsum_out[(long long)bh * p.Lq + q] = dpart;
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_ps16_kernel(GmAttnBwdDesc p, const float* __restrict__ lse_in, const float* __restrict__ dsum_in,
+                                                           bf16_raw* __restrict__ P, bf16_raw* __restrict__ dS, long long pd_ld,
+                                                           bf16_raw* __restrict__ dST, long long st_ld) {
+  constexpr int KS = DH / 32, PITCH = DH + 8;
+  extern __shared__ __attribute__((aligned(16))) char ab16_smem[];
+  bf16_raw* kt = reinterpret_cast<bf16_raw*>(ab16_smem);  // [AB16_KEYS][PITCH]
+  bf16_raw* vt = kt + AB16_KEYS * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, qg = lane >> 4;
+  const int bh = blockIdx.z, b = bh / p.H, h = bh % p.H;
+  const int k0 = blockIdx.x * AB16_KEYS;
+  const int q = blockIdx.y * 64 + wave * 16 + l15;
+  const bool q_ok = q < p.Lq;
+  const long long qrow = (long long)b * p.Lq + (q_ok ? q : 0);
+  const bf16_raw* Q = reinterpret_cast<const bf16_raw*>(p.q) + qrow * p.q_ld + h * DH;
+  const bf16_raw* G = reinterpret_cast<const bf16_raw*>(p.go) + qrow * p.go_ld + h * DH;
+  const bf16_raw* K = reinterpret_cast<const bf16_raw*>(p.k) + (long long)b * p.Lk * p.k_ld + h * DH;
+  const bf16_raw* V = reinterpret_cast<const bf16_raw*>(p.v) + (long long)b * p.Lk * p.v_ld + h * DH;
+  uint4 qf[KS], gf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const uint4 t = *reinterpret_cast<const uint4*>(Q + ks * 32 + qg * 8), u = *reinterpret_cast<const uint4*>(G + ks * 32 + qg * 8);
+    qf[ks] = make_uint4(q_ok ? t.x : 0u, q_ok ? t.y : 0u, q_ok ? t.z : 0u, q_ok ? t.w : 0u);
+    gf[ks] = make_uint4(q_ok ? u.x : 0u, q_ok ? u.y : 0u, q_ok ? u.z : 0u, q_ok ? u.w : 0u);
+  }
+  const float lse = lse_in[(long long)bh * p.Lq + (q_ok ? q : 0)], dsum = dsum_in[(long long)bh * p.Lq + (q_ok ? q : 0)];
+  ab16_stage<DH>(K, p.k_ld, k0, p.Lk, kt, tid);
+  ab16_stage<DH>(V, p.v_ld, k0, p.Lk, vt, tid);
+  __syncthreads();
+  bf16_raw* prow = P + ((long long)bh * p.Lq + (q_ok ? q : 0)) * pd_ld + k0;
+  bf16_raw* drow = dS + ((long long)bh * p.Lq + (q_ok ? q : 0)) * pd_ld + k0;
+  float dkeep[AB16_KEYS / 16][4];
+#pragma unroll
+  for (int rb = 0; rb < AB16_KEYS / 16; ++rb) {
+    f32x4_t as = (f32x4_t){0.f, 0.f, 0.f, 0.f}, ap = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 a = *reinterpret_cast<const uint4*>(kt + (rb * 16 + l15) * PITCH + ks * 32 + qg * 8);
+      const uint4 c = *reinterpret_cast<const uint4*>(vt + (rb * 16 + l15) * PITCH + ks * 32 + qg * 8);
+      as = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[ks]), as, 0, 0, 0);
+      ap = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, c), __builtin_bit_cast(bf16x8_t, gf[ks]), ap, 0, 0, 0);
+    }
+    float pv[4], dv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = q_ok & (k0 + rb * 16 + 4 * qg + r < p.Lk);
+      pv[r] = ok ? __expf(as[r] * p.scale - lse) : 0.f;
+      dv[r] = pv[r] * (ap[r] - dsum) * p.scale;
+    }
+    if (q_ok) {  // (the matrices are padded to a multiple of 64 keys per row: every 8-byte store of a tile is inside its row)
+      *reinterpret_cast<uint2*>(prow + rb * 16 + 4 * qg) = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+      *reinterpret_cast<uint2*>(drow + rb * 16 + 4 * qg) = make_uint2(pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3]));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dkeep[rb][r] = dv[r];
+  }
+  // ---- dS^T tile [64 keys][64 queries] through LDS (the K tile is dead): dQ = dS K is a contraction over KEYS, i.e. over the rows of K and of
+  //      dS^T -- the weight-gradient kernel's shape, with its split over rows; as a 1x1 convolution over dS it is a serial chain of Lk / 32
+  //      K chunks on a handful of tiles (0.18 of 0.38 ms at 4096 tokens) -----------------------------------------------------------------
+  __syncthreads();
+  constexpr int TP = 64 + 8;  // row pitch of the transposed tile (elements)
+  bf16_raw* tt = kt;          // 64 * 72 * 2 = 9216 bytes <= the K tile (DH >= 64), or within K + V tiles (DH = 32: 2 * 64 * 40 * 2 = 10240)
+#pragma unroll
+  for (int rb = 0; rb < AB16_KEYS / 16; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tt[(rb * 16 + 4 * qg + r) * TP + wave * 16 + l15] = f32_to_bf16(dkeep[rb][r]);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + i * 256, key = it >> 3, qv = it & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(tt + key * TP + qv * 8);
+    *reinterpret_cast<uint4*>(dST + ((long long)bh * ((p.Lk + 63) / 64 * 64) + k0 + key) * st_ld + blockIdx.y * 64 + qv * 8) = v;
+  }
+}
+
+template <int DH>
+static void launch_attn_bwd_scores(const GmAttnBwdDesc& d, bf16_raw* P, bf16_raw* dS, long long pd_ld, bf16_raw* dST, long long st_ld, hipStream_t st) {
+  float* lse = reinterpret_cast<float*>(d.workspace);
+  float* dsum = lse + (long long)d.B * d.H * d.Lq;
+  constexpr size_t tile = (size_t)AB16_KEYS * (DH + 8) * sizeof(bf16_raw);
+  static bool attr_set = false;
+  if (!attr_set) {
+    ab_set_lds(attn_bwd_lse16_kernel<DH>);
+    ab_set_lds(attn_bwd_ps16_kernel<DH>);
+    attr_set = true;
+  }
+  attn_bwd_lse16_kernel<DH><<<dim3((d.Lq + 63) / 64, d.B * d.H), 256, tile, st>>>(d, lse, dsum);
+  attn_bwd_ps16_kernel<DH><<<dim3((d.Lk + AB16_KEYS - 1) / AB16_KEYS, (d.Lq + 63) / 64, d.B * d.H), 256, 2 * tile, st>>>(d, lse, dsum, P, dS, pd_ld, dST, st_ld);
+}
+
+// P = softmax(scale Q K^T) and dS = P (dO V^T - rowsum(dO O)) scale per (sample, head) as bf16 [B*H][Lq][pd_ld] matrices (pd_ld >= Lk rounded
+// up to a multiple of 64; the padding columns of a row are written as zeros), and dS^T as [B*H][Lk rounded up to 64][st_ld] (st_ld >= Lq
+// rounded up to 64; padding rows and columns are zeros).  bf16 operands, head size 32 / 64 / 128 / 256.  Uses q, k, v, o, go, the geometry,
+// scale and the workspace of the descriptor (gm_attention_backward_workspace_bytes); dq / dk / dv are ignored.
+extern "C" int gm_attention_bwd_scores(const GmAttnBwdDesc* dp, void* probs, void* dscores, long long pd_ld, void* dscores_t, long long st_ld,
+                                       void* stream) {
+  GM_REQUIRE(dp && probs && dscores && dscores_t, "null pointer");
+  const GmAttnBwdDesc& d = *dp;
+  GM_REQUIRE(d.q && d.k && d.v && d.o && d.go, "null tensor pointer");
+  GM_REQUIRE(d.dtype == GM_BF16, "the bf16-MFMA score pass takes bf16 operands");
+  GM_REQUIRE(d.B >= 0 && d.H > 0 && d.Lk > 0, "bad batch / head geometry");
+  GM_REQUIRE((long long)d.B * d.H <= 65535 && (d.Lq + 63) / 64 <= 65535, "too many (batch, head) pairs or query tiles for one launch");
+  auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+  GM_REQUIRE(pd_ld >= (d.Lk + 63) / 64 * 64 && pd_ld % 4 == 0 && al(probs, 8) && al(dscores, 8), "the P / dS rows must hold Lk rounded up to 64 columns, 8-byte aligned");
+  GM_REQUIRE(st_ld >= (d.Lq + 63) / 64 * 64 && st_ld % 8 == 0 && al(dscores_t, 16), "the dS^T rows must hold Lq rounded up to 64 columns, 16-byte aligned");
+  GM_REQUIRE(d.workspace && d.workspace_bytes >= gm_attention_backward_workspace_bytes(dp), "workspace too small");
+  auto ok = [&](const void* p, long long ld) { return ld % 8 == 0 && al(p, 16); };
+  GM_REQUIRE(ok(d.q, d.q_ld) && ok(d.k, d.k_ld) && ok(d.v, d.v_ld) && ok(d.o, d.o_ld) && ok(d.go, d.go_ld), "operands must be 16-byte aligned rows");
+  if (d.B == 0 || d.Lq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  bf16_raw* P = reinterpret_cast<bf16_raw*>(probs);
+  bf16_raw* S = reinterpret_cast<bf16_raw*>(dscores);
+  bf16_raw* ST = reinterpret_cast<bf16_raw*>(dscores_t);
+  switch (d.dh) {
+    case 32: launch_attn_bwd_scores<32>(d, P, S, pd_ld, ST, st_ld, st); break;
+    case 64: launch_attn_bwd_scores<64>(d, P, S, pd_ld, ST, st_ld, st); break;
+    case 128: launch_attn_bwd_scores<128>(d, P, S, pd_ld, ST, st_ld, st); break;
+    case 256: launch_attn_bwd_scores<256>(d, P, S, pd_ld, ST, st_ld, st); break;
+    default: GM_FAIL(-3, "head dim must be 32, 64, 128 or 256");
+  }
+  GM_LAUNCH_CHECK();
+}

@@ -46,24 +46,59 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
 
   // ---- stage the patch (zero padded) and the weight block [co][k = tap * Cin + ci] -------------------------------------------
+  // (round 3: both staging loops request all of a thread's elements before the first wait -- a run-time loop of load -> LDS store waited for
+  //  every element in turn: 3 + 8 dependent round trips per work-group at C_in = 1)
   const T* xin = reinterpret_cast<const T*>(p.x);
-  for (int e = tid; e < PROWS * Cin; e += 256) {
-    const int row = e / Cin, ci = e - row * Cin;
-    const int pa = row / (PH * PW), rr = row - pa * (PH * PW), pb = rr / PW, pc = rr - pb * PW;
-    const int ud = od0 - p.pd + pa, uh = oh0 - p.ph + pb, uw = ow0 - p.pw + pc;
-    const bool ok = (ud >= 0) & (ud < p.Ds) & (uh >= 0) & (uh < p.Hs) & (uw >= 0) & (uw < p.Ws);
-    const long long vox = ok ? (((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : 0;
-    const T v = xin[vox * p.x_ld + ci];
-    patch[e] = ok ? v : (T)0;
+  {
+    constexpr int PMAX = (PROWS * 4 + 255) / 256;  // C_in <= 4
+    T pv[PMAX];
+    bool pok[PMAX];
+#pragma unroll
+    for (int it = 0; it < PMAX; ++it) {
+      if (it * 256 >= PROWS * Cin) break;  // (uniform)
+      const int e = tid + it * 256;
+      const int ec = e < PROWS * Cin ? e : 0;
+      const int row = ec / Cin, ci = ec - row * Cin;
+      const int pa = row / (PH * PW), rr = row - pa * (PH * PW), pb = rr / PW, pc = rr - pb * PW;
+      const int ud = od0 - p.pd + pa, uh = oh0 - p.ph + pb, uw = ow0 - p.pw + pc;
+      pok[it] = (ud >= 0) & (ud < p.Ds) & (uh >= 0) & (uh < p.Hs) & (uw >= 0) & (uw < p.Ws);
+      const long long vox = pok[it] ? (((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : 0;
+      pv[it] = xin[vox * p.x_ld + ci];
+    }
+#pragma unroll
+    for (int it = 0; it < PMAX; ++it) {
+      if (it * 256 >= PROWS * Cin) break;
+      const int e = tid + it * 256;
+      if (e < PROWS * Cin) patch[e] = pok[it] ? pv[it] : (T)0;
+    }
   }
   const T* wsrc = reinterpret_cast<const T*>(p.w);  // packed [chunk 0][tap][cout_pad][BK]
-  for (int e = tid; e < BN * nblk * KB; e += 256) {
-    const int col = e / (nblk * KB), k = e - col * (nblk * KB);
-    const int co = cb * BN + col;
-    const bool ok = (k < K) & (co < cout_pad);
-    const int tap = ok ? k / Cin : 0, ci = ok ? k - tap * Cin : 0;
-    const T v = wsrc[((long long)tap * cout_pad + (ok ? co : 0)) * BK + ci];
-    *reinterpret_cast<T*>(wlds + (size_t)col * WPITCH + k * (int)sizeof(T)) = ok ? v : (T)0;
+  {
+    constexpr int WMAX = BN * MAXK / 256;  // 32
+    const int wtotal = BN * nblk * KB;
+    for (int it0 = 0; it0 < WMAX; it0 += 8) {
+      T wv[8];
+      bool wok[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + (it0 + j) * 256;
+        const int ec = e < wtotal ? e : 0;
+        const int col = ec / (nblk * KB), k = ec - col * (nblk * KB);
+        const int co = cb * BN + col;
+        wok[j] = (k < K) & (co < cout_pad);
+        const int tap = wok[j] ? k / Cin : 0, ci = wok[j] ? k - tap * Cin : 0;
+        wv[j] = wsrc[((long long)tap * cout_pad + (wok[j] ? co : 0)) * BK + ci];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + (it0 + j) * 256;
+        if (e < wtotal) {
+          const int col = e / (nblk * KB), k = e - col * (nblk * KB);
+          *reinterpret_cast<T*>(wlds + (size_t)col * WPITCH + k * (int)sizeof(T)) = wok[j] ? wv[j] : (T)0;
+        }
+      }
+      if ((it0 + 8) * 256 >= wtotal) break;
+    }
   }
   __syncthreads();
 

@@ -1431,6 +1431,56 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: tor
     return dq, dk, dv
 
 
+ATTENTION_BWD_BF16_HEAD_DIMS = (32, 64, 128, 256)
+ATTENTION_BWD_BF16_MAX_BYTES = 16 << 30  # the P and dS matrices of one call (2 x B x H x Lq x Lk x 2 bytes): 4.3 GB at 32 768 tokens, one head
+
+
+def attention_backward_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, go: torch.Tensor, heads: int, scale: float):
+    """(dq, dk, dv) of o = softmax(scale q k^T) v with every product on the bf16 MFMA path (fp32 accumulation, fp32 softmax state):
+    gm_attention_bwd_scores leaves P and dS as bf16 [Lq][Lk] matrices per (sample, head); dV = P^T dO and dK = dS^T Q run on the
+    weight-gradient kernel (a contraction over rows: its transposed operand staging and its split over rows exist already), and so does
+    dQ = dS K = (dS^T)^T K, a contraction over the keys, from the dS^T image the score pass writes as well.
+    bf16 (B, L, heads * dh) operands, dh in ATTENTION_BWD_BF16_HEAD_DIMS.  (reference: torch autograd through diffusion_model_unet.py:407-415)"""
+    require_device(q, k, v, o, go)
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    dh = c // heads
+    if q.dtype != torch.bfloat16 or dh not in ATTENTION_BWD_BF16_HEAD_DIMS:
+        raise ValueError(f"attention_backward_bf16: bf16 operands with a head dim in {ATTENTION_BWD_BF16_HEAD_DIMS}")
+    if o.shape != q.shape or go.shape != q.shape or k.shape != v.shape or k.shape[2] != c:
+        raise ValueError("attention_backward operand shapes are inconsistent")
+    q, k, v, o, go = (t.contiguous() for t in (q, k, v, o, go))
+    lkp, lqp = (lk + 63) // 64 * 64, (lq + 63) // 64 * 64
+    if b * heads * (2 * lq * lkp + lkp * lqp) * 2 > ATTENTION_BWD_BF16_MAX_BYTES:
+        raise ValueError("attention_backward_bf16: the score matrices of this call exceed ATTENTION_BWD_BF16_MAX_BYTES")
+    probs = torch.empty((b * heads, lq, lkp), dtype=torch.bfloat16, device=q.device)
+    dscores = torch.empty_like(probs)
+    dscores_t = torch.empty((b * heads, lkp, lqp), dtype=torch.bfloat16, device=q.device)
+    d = GmAttnBwdDesc()
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o), ("go", go)):
+        setattr(d, name, t.data_ptr())
+        setattr(d, name + "_ld", _kv_ld(t))
+    d.B, d.H, d.Lq, d.Lk, d.dh = b, heads, lq, lk, dh
+    d.scale, d.dtype = float(scale), dt_code(q.dtype)
+    nbytes = lib().gm_attention_backward_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    _timed("attention_bwd_scores<bfloat16>", dict(flops=6.0 * b * heads * lq * lk * dh, bytes=float(6 * b * heads * lq * lkp), shape=f"B{b} H{heads} L{lq}x{lk} d{dh}"),
+           lambda: check(lib().gm_attention_bwd_scores(C.byref(d), probs.data_ptr(), dscores.data_ptr(), lkp, dscores_t.data_ptr(), lqp, _stream()),
+                         "gm_attention_bwd_scores"))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    for bi in range(b):
+        for hi in range(heads):
+            i, sl = bi * heads + hi, slice(hi * dh, (hi + 1) * dh)
+            dvh = conv_wgrad(go[bi:bi + 1, :, sl], probs[i:i + 1, :, :lk], 1, 1, 0)                # [lk, dh, 1] fp32 = P^T dO
+            dkh = conv_wgrad(q[bi:bi + 1, :, sl], dscores[i:i + 1, :, :lk], 1, 1, 0)               # [lk, dh, 1] fp32 = dS^T Q
+            dqh = conv_wgrad(k[bi:bi + 1, :, sl], dscores_t[i:i + 1, :lk, :lq], 1, 1, 0)           # [lq, dh, 1] fp32 = dS K (rows = keys)
+            copy_channels(dqh.reshape(1, lq, dh), dq[bi:bi + 1, :, sl])
+            copy_channels(dkh.reshape(1, lk, dh), dk[bi:bi + 1, :, sl])
+            copy_channels(dvh.reshape(1, lk, dh), dv[bi:bi + 1, :, sl])
+    return dq, dk, dv
+
+
 def layernorm_backward(x: torch.Tensor, gy: torch.Tensor, gamma: Optional[torch.Tensor], eps: float, want_param_grads: bool = True):
     """nn.LayerNorm backward over the last dim: -> (dx, dgamma, dbeta) with fp32 [C] parameter gradients (None when not requested)."""
     require_device(x, gy, gamma)

@@ -836,3 +836,34 @@ def test_graphed_training_step_is_bitwise_the_eager_step(dims, mixed):
         assert torch.equal(a, b), k
     with pytest.raises(ValueError):
         step(images[:1], batches[0][0], batches[0][1])
+
+
+@pytest.mark.parametrize("b,lq,lk,heads,dh", [(1, 1024, 1024, 1, 128), (1, 200, 136, 2, 32), (2, 96, 320, 1, 64), (1, 520, 520, 1, 256)])
+def test_attention_backward_bf16_mfma_path(b, lq, lk, heads, dh):
+    """ops.attention_backward_bf16 (gm_attention_bwd_scores + the weight-gradient / 1x1 kernels): every product of the attention backward on
+    bf16 MFMA with fp32 accumulation and an fp32 softmax -- against torch autograd in fp64 (reference: autograd through
+    diffusion_model_unet.py:407-415), incl. ragged lengths (key count not a multiple of the 64-key tile, Lq != Lk), two heads read as channel
+    slices, and the autograd policy that selects this path for one or two long (sample, head) pairs."""
+    from generativemodels_amd import autograd as A
+    ops = _ops()
+    c = heads * dh
+    scale = 1 / math.sqrt(dh)
+    q, go = _rand((b, lq, c), 601).bfloat16(), _rand((b, lq, c), 604).bfloat16()
+    k, v = _rand((b, lk, c), 602).bfloat16(), _rand((b, lk, c), 603).bfloat16()
+    ref = [t.double().requires_grad_(True) for t in (q, k, v)]
+    qh = ref[0].reshape(b, lq, heads, dh).transpose(1, 2)
+    kh, vh = (t.reshape(b, lk, heads, dh).transpose(1, 2) for t in ref[1:])
+    o_ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(b, lq, c)
+    (o_ref * go.double()).sum().backward()
+    qd, kd, vd, gd = (t.to(DEV) for t in (q, k, v, go))
+    o = ops.attention(qd, kd, vd, heads, scale)
+    dq, dk, dv = ops.attention_backward_bf16(qd, kd, vd, o, gd, heads, scale)
+    for name, got, r in zip("qkv", (dq, dk, dv), ref):
+        _close(got, r.grad, 1.5e-2, f"bf16-MFMA attention backward d{name}")
+    if b * heads <= 2 and max(lq, lk) >= A.ATTENTION_BWD_BF16_MIN_TOKENS:  # the policy takes this path: same bits through autograd
+        dev = [t.clone().requires_grad_(True) for t in (qd, kd, vd)]
+        A.attention(*dev, heads, scale).backward(gd)
+        for got, want in zip(dev, (dq, dk, dv)):
+            assert torch.equal(got.grad, want)
+    with pytest.raises(ValueError):
+        ops.attention_backward_bf16(qd.float(), kd.float(), vd.float(), o.float(), gd.float(), heads, scale)
