@@ -21,6 +21,17 @@
 
 #include "conv_common.h"
 
+// Post-activation of the generic kernels with the transcendental forms OUT OF LINE: conv_post_act inlines tanh / exp / erf expansions at every
+// call site -- 32 copies in the epilogue below, a 12 000-instruction kernel (~70 KB: more than the 64 KB instruction cache two CUs share), and
+// every launch of a small problem paid for streaming that code (rocprofv3: 20-24 us per launch whatever the problem size).
+static __device__ __attribute__((noinline)) float conv_post_act_rare(float v, int act) { return conv_post_act(v, act); }
+__device__ __forceinline__ float conv_post_act_lean(float v, int act) {
+  if (act == 0) return v;
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 5) return v > 0.f ? v : 0.01f * v;
+  return conv_post_act_rare(v, act);
+}
+
 template <typename T, int WM, int WN, int MF, int NFR>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const GmConvDesc p) {
   constexpr int BK = ConvTraits<T>::BK;
@@ -118,64 +129,81 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GmConvDesc p) {
   const int sq = tid & 3;  // this thread's 16-byte slot inside a row (constant over its items)
   auto stage_a = [&](int chunk) {
     const int c0 = chunk * BK + sq * VECW;
+    // (round 3: every load goes to a clamped / substitute address unconditionally and the VALUE is selected -- hipcc branches around a
+    //  conditional load and waits at each join: the 2 * VECW table loads and the patch rows were one dependent round trip each, ~20 us per
+    //  launch of a small 1x1 convolution whatever its size (rocprofv3: C3 latent UNet, C4 training step))
     float sc[VECW], sh[VECW];
-    if (p.pre_scale) {
+    {
+      const float* ps = p.pre_scale ? p.pre_scale + (long long)n * p.Cin : reinterpret_cast<const float*>(p.w);
+      const float* ph = p.pre_scale ? p.pre_shift + (long long)n * p.Cin : reinterpret_cast<const float*>(p.w);
 #pragma unroll
       for (int i = 0; i < VECW; ++i) {
         const int c = c0 + i;
-        sc[i] = c < p.Cin ? p.pre_scale[(long long)n * p.Cin + c] : 0.f;
-        sh[i] = c < p.Cin ? p.pre_shift[(long long)n * p.Cin + c] : 0.f;
+        const int cc = p.pre_scale ? (c < p.Cin ? c : p.Cin - 1) : 0;
+        const float a = ps[cc], b2 = ph[cc];
+        sc[i] = c < p.Cin ? a : 0.f;
+        sh[i] = c < p.Cin ? b2 : 0.f;
       }
     }
-    for (int pv = tid >> 2; pv < P; pv += 64) {
+    constexpr int UA = MF * NFR > 4 ? 1 : 2;  // patch rows requested per wait (the 256-accumulator tiles keep their three waves per SIMD)
+    // geometry of one patch row: source pointer (clamped in range) and validity
+    auto place = [&](int pv, bool& ok) __attribute__((always_inline)) -> const T* {
       const int pc = pv % pW;
       const int t1 = pv / pW;
       const int pb = t1 % pH, pa = t1 / pH;
       int ud = ud0 + pa, uh = uh0 + pb, uw = uw0 + pc;
-      bool ok = (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv) & (c0 < p.Cin);
+      ok = (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv) & (c0 < p.Cin);
       if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
       else if (p.in_mode == 2) {
         ok = ok && (ud % p.fd == 0) && (uh % p.fh == 0) && (uw % p.fw == 0);
         ud /= p.fd; uh /= p.fh; uw /= p.fw;
       }
-      float v[VECW];
+      return ok ? xin + ((((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw) * p.x_ld + c0 : xin;
+    };
+    auto finish = [&](float (&v)[VECW], bool ok, int pv) __attribute__((always_inline)) {
+      if (p.pre_scale) {
 #pragma unroll
-      for (int i = 0; i < VECW; ++i) v[i] = 0.f;
-      if (ok) {
-        const T* src = xin + ((((long long)n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw) * p.x_ld + c0;
-        if (vec_ok) {
-          Vec16<T>::unpack(*reinterpret_cast<const uint4*>(src), v);
-        } else {
-#pragma unroll
-          for (int i = 0; i < VECW; ++i) if (c0 + i < p.Cin) v[i] = ElemIO<T>::ld(src + i);
-        }
-        if (p.pre_scale) {
-#pragma unroll
-          for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[i] + sh[i];
-        }
-        if (p.pre_act) {
-          conv_act_vec(v, p.pre_act, PRECISE);
-        }
-        if (!vec_ok || p.pre_scale || p.pre_act) {
-#pragma unroll
-          for (int i = 0; i < VECW; ++i) if (c0 + i >= p.Cin) v[i] = 0.f;  // padded channels contribute nothing
-        }
+        for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[i] + sh[i];
       }
+      if (p.pre_act) {
+        conv_act_vec(v, p.pre_act, PRECISE);
+      }
+#pragma unroll
+      for (int i = 0; i < VECW; ++i) if (!ok || c0 + i >= p.Cin) v[i] = 0.f;  // padding and padded channels contribute nothing
       *reinterpret_cast<uint4*>(ldsA + (size_t)pv * CONV_ROWB + sq * 16) = Vec16<T>::pack(v);
+    };
+    if (vec_ok) {  // (uniform)
+      for (int pv0 = tid >> 2; pv0 < P; pv0 += 64 * UA) {
+        float v[UA][VECW];
+        bool okk[UA];
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+          const T* src = place(pv0 + 64 * u < P ? pv0 + 64 * u : pv0, okk[u]);
+          Vec16<T>::unpack(*reinterpret_cast<const uint4*>(src), v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UA; ++u)
+          if (pv0 + 64 * u < P) finish(v[u], okk[u], pv0 + 64 * u);
+      }
+    } else {
+      for (int pv = tid >> 2; pv < P; pv += 64) {
+        bool ok;
+        const T* src = place(pv, ok);
+        float v[VECW];
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) v[i] = ElemIO<T>::ld(src + ((ok && c0 + i < p.Cin) ? i : 0));
+        finish(v, ok, pv);
+      }
     }
   };
 
   // ---- main loop ------------------------------------------------------------------------------------------------------
   load_b(0);
-  stage_a(0);
-  store_b(0);
-  __syncthreads();
   long long step = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    if (chunk > 0) {
-      stage_a(chunk);  // every wave passed the barrier that ended the previous chunk's last tap
-      __syncthreads();
-    }
+    stage_a(chunk);  // (one call site: the staging code is instantiated once.)  Every wave passed the barrier that ended the previous chunk's last tap
+    if (chunk == 0) store_b(0);
+    __syncthreads();
     for (int kd_i = 0; kd_i < p.kd; ++kd_i)
       for (int kh_i = 0; kh_i < p.kh; ++kh_i)
         for (int kw_i = 0; kw_i < p.kw; ++kw_i, ++step) {
@@ -202,6 +230,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GmConvDesc p) {
   const T* res = reinterpret_cast<const T*>(p.res);
   const bool st_vec = (p.Cout % 4 == 0) && (p.y_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & (4 * sizeof(T) - 1)) == 0) &&
                       (!res || ((p.res_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.res) & (4 * sizeof(T) - 1)) == 0)));
+  // per-channel addends of this lane's output channels and (vector form) its residual rows: requested up front through substitute pointers
+  constexpr bool RES_ALL = MF * NFR <= 4;
+  constexpr int ANF = RES_ALL ? NFR : 1;
+  float bt[ANF][4], rt[ANF][4];
+  const float* bsrc = p.bias ? p.bias : reinterpret_cast<const float*>(p.w);
+  const float* rsrc = p.rowvec ? p.rowvec + (long long)n * p.rowvec_bstride : reinterpret_cast<const float*>(p.w);
+  auto load_addends = [&](int nf, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cb * BN + (wn * NFR + nf) * 16 + q * 4 + r;
+      const int cc = co < p.Cout ? co : p.Cout - 1;
+      bt[slot][r] = bsrc[p.bias ? cc : 0];
+      rt[slot][r] = rsrc[p.rowvec ? cc : 0];
+    }
+  };
+  if (RES_ALL) {
+#pragma unroll
+    for (int nf = 0; nf < NFR; ++nf) load_addends(nf, nf);
+  }
+  // residual rows (vector form): the small tiles request all of theirs up front; the 256-accumulator tiles keep the element-wise form below
+  // (holding their MF x NFR = 16 vectors cost 110 registers and two of their three waves per SIMD)
+  constexpr int RMF = RES_ALL ? MF : 1;
+  float resv[RMF][NFR][4];
+  auto load_res = [&](int mf, int slot) __attribute__((always_inline)) {
+    const int m = (wm * MF + mf) * 16 + l15;
+    const int a = m >> (p.lth + p.ltw), bb = (m >> p.ltw) & (th - 1), c = m & (tw - 1);
+    const int od = od0 + a, oh = oh0 + bb, ow = ow0 + c;
+    const bool vok = (od < p.Do) & (oh < p.Ho) & (ow < p.Wo);
+    const long long vox = vok ? (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow : 0;
+#pragma unroll
+    for (int nf = 0; nf < NFR; ++nf) {
+      const int co = cb * BN + (wn * NFR + nf) * 16 + q * 4;
+      const T* rp = res + vox * p.res_ld + (co < p.Cout ? co : 0);
+      if (sizeof(T) == 4) {
+        const float4 rv = *reinterpret_cast<const float4*>(rp);
+        resv[slot][nf][0] = rv.x; resv[slot][nf][1] = rv.y; resv[slot][nf][2] = rv.z; resv[slot][nf][3] = rv.w;
+      } else {
+        const uint2 rv = *reinterpret_cast<const uint2*>(rp);
+        resv[slot][nf][0] = __uint_as_float(rv.x << 16); resv[slot][nf][1] = __uint_as_float(rv.x & 0xffff0000u);
+        resv[slot][nf][2] = __uint_as_float(rv.y << 16); resv[slot][nf][3] = __uint_as_float(rv.y & 0xffff0000u);
+      }
+    }
+  };
+  if (RES_ALL && st_vec && res) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) load_res(mf, mf);
+  }
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int m = (wm * MF + mf) * 16 + l15;
@@ -219,13 +294,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GmConvDesc p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (co + r < p.Cout) {
-          if (p.bias) o[r] += p.bias[co + r];
-          if (p.rowvec) o[r] += p.rowvec[(long long)n * p.rowvec_bstride + co + r];
+          if (RES_ALL) {
+            if (p.bias) o[r] += bt[RES_ALL ? nf : 0][r];
+            if (p.rowvec) o[r] += rt[RES_ALL ? nf : 0][r];
+          } else {  // (the 256-accumulator tiles keep the register-lean element-wise form: large problems, throughput-bound)
+            if (p.bias) o[r] += p.bias[co + r];
+            if (p.rowvec) o[r] += p.rowvec[(long long)n * p.rowvec_bstride + co + r];
+          }
         }
       }
       if (st_vec) {
         if (res) {
-          if (sizeof(T) == 4) {
+          if (RES_ALL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += resv[RES_ALL ? mf : 0][nf][r];
+          } else if (sizeof(T) == 4) {
             const float4 rv = *reinterpret_cast<const float4*>(res + vox * p.res_ld + co);
             o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
           } else {
@@ -235,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GmConvDesc p) {
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = conv_post_act(o[r], p.post_act);
+        for (int r = 0; r < 4; ++r) o[r] = conv_post_act_lean(o[r], p.post_act);
         if (sizeof(T) == 4) {
           *reinterpret_cast<float4*>(yout + vox * p.y_ld + co) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
@@ -250,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GmConvDesc p) {
           if (co + r < p.Cout) {
             float v = o[r];
             if (res) v += ElemIO<T>::ld(res + vox * p.res_ld + co + r);
-            ElemIO<T>::st(yout + vox * p.y_ld + co + r, conv_post_act(v, p.post_act));
+            ElemIO<T>::st(yout + vox * p.y_ld + co + r, conv_post_act_lean(v, p.post_act));
           }
         }
       }
@@ -447,7 +530,7 @@ __global__ __launch_bounds__(SK_THREADS) void conv_splitk_combine_kernel(const G
       }
       if (p.post_act) {
 #pragma unroll
-        for (int i = 0; i < VECW; ++i) o[i] = conv_post_act(o[i], p.post_act);
+        for (int i = 0; i < VECW; ++i) o[i] = conv_post_act_lean(o[i], p.post_act);
       }
       const uint4 raw = Vec16<T>::pack(o);
       *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.y) + vox * p.y_ld + c) = raw;
