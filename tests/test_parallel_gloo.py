@@ -11,6 +11,22 @@ import torch.multiprocessing as mp
 from generativemodels_amd import parallel
 
 
+def _retry_once(fn):
+    """The two spawn tests rendezvous over a TCP port picked just before the workers start: on a busy host the port can be taken in between
+    (or a worker can miss the store's timeout).  One retry with a fresh port; a real failure fails twice."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        try:
+            return fn(*a, **k)
+        except AssertionError:
+            raise
+        except Exception:
+            return fn(*a, **k)
+    return wrapper
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -49,6 +65,7 @@ def test_shard_range_is_a_balanced_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+@_retry_once
 def test_two_rank_sampling_matches_single_process():
     n_units, world = 5, 2
     ctx = mp.get_context("spawn")
@@ -129,6 +146,7 @@ def _reducer_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@_retry_once
 def test_two_rank_gradient_all_reduce_matches_the_full_batch():
     """GradientReducer over gloo, world_size 2: gradients live in persistent flat buckets, buckets are exchanged from the grad-ready
     hooks in bucket order; the averaged shard gradients equal the single-process gradients of the full batch; a never-used parameter
