@@ -119,6 +119,8 @@ PROTOTYPES = {
     "gm_pack_subpixel_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_attention_max_head_dim": (C.c_int, []),
     "gm_linear_rows": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_linear_rows_affine": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, c_vp]),
     "gm_decode_scratch_bytes": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "gm_decode_advance": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, c_ll, c_vp]),
     "gm_transformer_decode_step": (C.c_int, [C.POINTER(GmDecodeDesc), c_vp]),

@@ -18,6 +18,7 @@ struct LinearRowsExtra {
   const int* off_dev; long long off_mul;               // y1 / y2 are advanced by (*off_dev) * off_mul elements at run time (KV-cache row = position)
   const float* kv_ws; int kv_dh;                       // K-split kernel STAGE 1: x = merge of the split-KV attention partials (head size kv_dh)
   const float* mlp_p; int mlp_nj; const void* mlp_x1; const float* mlp_b2; void* mlp_x0;  // K-split kernel STAGE 2: x = x1 + b2 + sum_j P[j]
+  const float* pre_scale; const float* pre_shift; long long ss_ld; int rows_per_sample;   // linear_rows_kernel: x <- x * scale[n][c] + shift[n][c], n = row / rows_per_sample
 };
 
 // One channel of the split-KV single-query attention, merged from its GM_DECODE_KV_SPLITS partials in range order.  Workspace =
@@ -91,10 +92,23 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
     sq += __shfl_xor(sq, 32, 64);
     rstd = 1.0f / sqrtf(sq / (float)cin + ex.ln_eps);
   }
+  // bias and residual of this lane's outputs: requested up front through substitute addresses (round 3: a conditional load is a branch + a wait)
+  float bia[4], rsd[4];
+  {
+    const float* bsrc = bias ? bias : reinterpret_cast<const float*>(w);
+    const T* rsrc = res ? res + (long long)(row_ok ? row : 0) * res_ld : w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = co0 + 4 * q + i;
+      bia[i] = bsrc[bias ? (co < cout ? co : cout - 1) : 0];
+      rsd[i] = ElemIO<T>::ld(rsrc + (res ? (co < cout ? co : cout - 1) : 0));
+    }
+  }
   f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   constexpr int U = 4;
   for (int c0 = 0; c0 < nchunks; c0 += U) {
     uint4 wf[U], xf[U];
+    float asc[U][VECW], ash[U][VECW];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;  // clamped: the duplicate is discarded below
@@ -104,14 +118,29 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
       // the last row, beyond the allocation) whenever cin < 4 * VECW -- a faulting read even though its value is discarded
       const uint4 v = *reinterpret_cast<const uint4*>(ok ? xrow + c * BK : x);
       xf[u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      if (ex.pre_scale) {  // (uniform) per-sample GroupNorm affine of this lane's channels: vector loads at a clamped offset, values selected below
+        const int cb = c * BK + q * VECW + VECW <= cin ? c * BK + q * VECW : 0;
+        const long long off = (long long)((row_ok ? row : 0) / ex.rows_per_sample) * ex.ss_ld + cb;
+#pragma unroll
+        for (int i = 0; i < VECW; i += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(ex.pre_scale + off + i), b2 = *reinterpret_cast<const float4*>(ex.pre_shift + off + i);
+          asc[u][i] = a.x; asc[u][i + 1] = a.y; asc[u][i + 2] = a.z; asc[u][i + 3] = a.w;
+          ash[u][i] = b2.x; ash[u][i + 1] = b2.y; ash[u][i + 2] = b2.z; ash[u][i + 3] = b2.w;
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (c0 + u >= nchunks) break;
       uint4 b = xf[u];
-      if (pre_act || ex.ln_g) {
+      if (pre_act || ex.ln_g || ex.pre_scale) {
         float v[VECW];
         Vec16<T>::unpack(b, v);
+        if (ex.pre_scale) {
+          const bool okc = row_ok & ((c0 + u) * BK + q * VECW + VECW <= cin);
+#pragma unroll
+          for (int i = 0; i < VECW; ++i) v[i] = okc ? v[i] * asc[u][i] + ash[u][i] : 0.f;
+        }
         if (ex.ln_g) {
           const int cbase = (c0 + u) * BK + q * VECW;
           const bool ok = row_ok & (cbase + VECW <= cin);
@@ -132,9 +161,9 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
   for (int i = 0; i < 4; ++i) {
     const int co = co0 + 4 * q + i;
     if (co < cout) {
-      float v = acc[i] + (bias ? bias[co] : 0.f);
+      float v = acc[i] + (bias ? bia[i] : 0.f);
       v = conv_post_act(v, post_act);
-      if (res) v += ElemIO<T>::ld(res + (long long)row * res_ld + co);
+      if (res) v += rsd[i];
       if (ex.split > 0 && co >= ex.split) {
         T* dst = reinterpret_cast<T*>(co < 2 * ex.split ? ex.y1 : ex.y2) + (ex.off_dev ? (long long)(*ex.off_dev) * ex.off_mul : 0);
         ElemIO<T>::st(dst + (long long)row * ex.y12_ld + (co - (co < 2 * ex.split ? ex.split : 2 * ex.split)), v);
@@ -466,7 +495,7 @@ static int linear_rows_launch(const void* x, long long x_ld, const void* w, cons
   GM_REQUIRE(ex.split == 0 || (ex.y1 && ex.y2 && cout == 3 * ex.split), "split output needs two extra destinations and cout = 3 * split");
   hipStream_t st = (hipStream_t)stream;
   const int cout_pad = (cout + 15) & ~15;
-  if (linear_rows_takes_ksplit(rows, cin, dtype)) {
+  if (linear_rows_takes_ksplit(rows, cin, dtype) && !ex.pre_scale) {
     dim3 gk(cout_pad / 16, 1);
     const int stage = ex.kv_ws ? 1 : ex.mlp_p ? 2 : 0;
     const int xf = (ex.ln_g || pre_act) ? 1 : 0;
@@ -502,6 +531,21 @@ static int linear_rows_launch(const void* x, long long x_ld, const void* w, cons
 extern "C" int gm_linear_rows(const void* x, long long x_ld, const void* w, const float* bias, const void* res, long long res_ld, void* y,
                               long long y_ld, int rows, int cin, int cout, int pre_act, int post_act, int dtype, void* stream) {
   LinearRowsExtra ex = {};
+  return linear_rows_launch(x, x_ld, w, bias, res, res_ld, y, y_ld, rows, cin, cout, pre_act, post_act, dtype, ex, stream);
+}
+
+// y = post_act(act(x * scale[n] + shift[n]) W^T + b) (+ res) over token rows: the 1x1 convolutions of the latent-resolution attention blocks
+// (GroupNorm prologue + stacked q | k | v projection on a few thousand tokens), for which the tiled convolution kernels are a serial chain of
+// stage -> barrier -> tap -> barrier steps per K chunk (20 us per launch whatever the size); here a wave owns 16 rows x 16 output channels and
+// requests all of its K chunks (4 per wait) straight from L2.  scale / shift: fp32 [N][ss_ld] (nullable), n = row / rows_per_sample.
+extern "C" int gm_linear_rows_affine(const void* x, long long x_ld, const float* pre_scale, const float* pre_shift, long long ss_ld, int rows_per_sample,
+                                     const void* w, const float* bias, const void* res, long long res_ld, void* y, long long y_ld, int rows, int cin,
+                                     int cout, int pre_act, int post_act, int dtype, void* stream) {
+  GM_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr), "scale and shift come together");
+  GM_REQUIRE(!pre_scale || (rows_per_sample > 0 && ss_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(pre_scale) & 15) == 0 &&
+                            (reinterpret_cast<uintptr_t>(pre_shift) & 15) == 0), "the affine tables are 16-byte aligned fp32 rows");
+  LinearRowsExtra ex = {};
+  ex.pre_scale = pre_scale; ex.pre_shift = pre_shift; ex.ss_ld = ss_ld; ex.rows_per_sample = rows_per_sample;
   return linear_rows_launch(x, x_ld, w, bias, res, res_ld, y, y_ld, rows, cin, cout, pre_act, post_act, dtype, ex, stream);
 }
 

@@ -750,6 +750,13 @@ _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
 _CONV_TIMELINE_BUFFER = None  # tools/conv_timeline.py (bench-only -DGM_CONV_TIMELINE build): int64 [work-groups, 64] stamp table
 
 SMALL_LINEAR_ROWS = 64       # 1x1 "convolutions" over at most this many rows take gm_linear_rows
+# 1x1 convolutions over token rows (the GN-prologue q|k|v projections of the latent-resolution attention blocks and their gradients): the tiled
+# kernels cost ~20 us per launch there whatever the size (a stage -> barrier -> tap -> barrier chain per K chunk); gm_linear_rows_affine requests
+# all K chunks of a 16 x 16 output block straight from L2.  Bounds: what was measured (tools/bench_conv1x1.py)
+TOKEN_GEMM = os.environ.get("GM_TOKEN_GEMM", "1") != "0"
+TOKEN_GEMM_MAX_ROWS = 8192
+TOKEN_GEMM_MAX_CIN = 512
+TOKEN_GEMM_MAX_FLOP = 2.0e9
 DMA_CONV = True              # route eligible 3x3x3 convolutions through conv_dma.hip (cfg 11)
 DMA_CONV_MIN_VOXELS = 1 << 8
 LDS_SOFT_LIMIT = 80 * 1024   # two workgroups per CU
@@ -1003,6 +1010,32 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                                                   out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act], POST_ACT[post_act], dt_code(dtype),
                                                   _stream()), "gm_linear_rows"))
         return out
+    if (TOKEN_GEMM and SMALL_LINEAR_ROWS < rows <= TOKEN_GEMM_MAX_ROWS and cin <= TOKEN_GEMM_MAX_CIN and 2.0 * rows * cin * cout <= TOKEN_GEMM_MAX_FLOP
+            and x2 is None and k == (1, 1, 1) and s == (1, 1, 1) and not upsample and rowvec is None and not want_stats and skip is None
+            and force_cfg is None and ksplit is None and cin % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0
+            and plo == (0, 0, 0) and phi == (0, 0, 0) and opad == (0, 0, 0)):
+        out_shape = (*x.shape[:-1], cout)
+        if out is None:
+            out = torch.empty(out_shape, dtype=dtype, device=x.device)
+        elif tuple(out.shape) != out_shape or out.dtype != dtype:
+            raise ValueError(f"out has shape {tuple(out.shape)}, expected {out_shape}")
+        if res is not None and (tuple(res.shape) != out_shape or res.dtype != dtype):
+            raise ValueError(f"residual has shape {tuple(res.shape)} / {res.dtype}, expected {out_shape} / {dtype}")
+        b32 = as_f32(bias) if bias is not None else None
+        sc = sh = None
+        if pre is not None:
+            sc, sh = pre
+            if sc.dtype != torch.float32 or sh.dtype != torch.float32 or sc.shape != (n, cin) or sh.shape != (n, cin) or sc.stride(-1) != 1 or sh.stride(-1) != 1 \
+                    or sc.stride(0) != sh.stride(0):
+                raise ValueError("pre = (scale, shift): fp32 [N, Cin] tables with a common row pitch")
+        if sc is None or (sc.stride(0) % 4 == 0 and sc.data_ptr() % 16 == 0 and sh.data_ptr() % 16 == 0):
+            _timed(f"token_gemm<{str(dtype).split('.')[-1]}>", dict(flops=2.0 * rows * cin * cout, bytes=float(x.element_size() * (rows * (cin + cout) + cin * cout)),
+                                                                  shape=f"{rows}x{cin}->{cout}"),
+                   lambda: check(lib().gm_linear_rows_affine(x.data_ptr(), arena_ld(x), _ptr(sc), _ptr(sh), 0 if sc is None else sc.stride(0), rows // n,
+                                                             panel().data_ptr(), _ptr(b32), _ptr(res), 0 if res is None else arena_ld(res), out.data_ptr(),
+                                                             arena_ld(out), rows, cin, cout, ACT[pre_act], POST_ACT[post_act], dt_code(dtype), _stream()),
+                                 "gm_linear_rows_affine"))
+            return out
     if (upsample and x2 is None and SUBPIXEL_UPSAMPLE and allow_subpixel and nsp == 3 and k == (3, 3, 3) and s == (1, 1, 1) and plo == (1, 1, 1) and phi == (1, 1, 1)
             and dil == (1, 1, 1) and pre is None and pre_act == "none" and skip is None and force_cfg is None and weight is not None
             and cin % (64 // x.element_size()) == 0 and cout % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0

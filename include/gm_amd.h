@@ -257,6 +257,12 @@ int gm_token_log_prob(const void* logits, long long ld, const long long* target,
  * pre_act / post_act as in GmConvDesc; cin and x_ld multiples of 16 bytes. */
 int gm_linear_rows(const void* x, long long x_ld, const void* w, const float* bias, const void* res, long long res_ld, void* y,
                    long long y_ld, int rows, int cin, int cout, int pre_act, int post_act, int dtype, void* stream);
+/* The same over token rows with a per-sample GroupNorm affine in front: y = post_act(pre_act(x * scale[n] + shift[n]) W^T + bias) (+ res),
+ * n = row / rows_per_sample, scale / shift fp32 [N][ss_ld] (both null: no affine).  The GroupNorm -> q | k | v projection of the
+ * latent-resolution AttentionBlocks (diffusion_model_unet.py:395-405) and the other 1x1 convolutions over a few thousand tokens. */
+int gm_linear_rows_affine(const void* x, long long x_ld, const float* pre_scale, const float* pre_shift, long long ss_ld, int rows_per_sample,
+                          const void* w, const float* bias, const void* res, long long res_ld, void* y, long long y_ld, int rows, int cin,
+                          int cout, int pre_act, int post_act, int dtype, void* stream);
 
 /* One KV-cache decoding step of the decoder-only transformer issued natively (~110 launches back to back): embed the fed token at
  * `pos`, per block LayerNorm -> q|k|v -> append k, v to the caches -> 1 x (pos+1) attention -> out_proj + x -> LayerNorm -> MLP(GELU) + x,

@@ -969,3 +969,37 @@ def test_conv_single_output_channel_marching_kernel(cin, sp, pro, dtype):
     assert torch.equal(got, tile), "the marching kernel keeps the 27-point summation order of the tile kernel: bit-identical"
     auto = ops.conv(wide_in[..., 8:], w.to(DEV), b.to(DEV), **kw)  # whatever the chooser picks (small problems: the 64-voxel generic tiles) agrees
     _check(_cf(auto), want, dtype, f"cout1 cin{cin} auto")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,tokens,cin,cout,pre,pre_act,res,transposed", [
+    (1, 4096, 128, 384, True, "none", False, False),   # GroupNorm -> q | k | v of a 16^3 attention block
+    (2, 520, 256, 256, True, "silu", True, False),     # two samples (the table row follows the sample), ragged row count, residual
+    (1, 1000, 64, 72, False, "none", True, True),      # no prologue, output channels not a multiple of 16, ConvTranspose weight layout
+])
+def test_token_gemm_path_of_1x1_convolutions(n, tokens, cin, cout, pre, pre_act, res, transposed, dtype):
+    """gm_linear_rows_affine behind ops.conv(kernel=1) for a few thousand token rows: per-sample GroupNorm affine + activation prologue, bias,
+    residual -- against the same product in fp64, and against the tiled kernel it replaces there (reference op: diffusion_model_unet.py:395-405)."""
+    ops = _ops()
+    x = _rand((n, tokens, cin), 801).to(dtype)
+    w = (_rand((cin, cout) if transposed else (cout, cin), 802) / math.sqrt(cin)).to(dtype)
+    b = _rand((cout,), 803)
+    sc = (torch.rand((n, cin), generator=torch.Generator().manual_seed(804)) + 0.5) if pre else None
+    sh = _rand((n, cin), 805, scale=0.2) if pre else None
+    r = _rand((n, tokens, cout), 806).to(dtype) if res else None
+    xa = x.double()
+    if pre:
+        xa = xa * sc.double()[:, None, :] + sh.double()[:, None, :]
+    if pre_act == "silu":
+        xa = xa * torch.sigmoid(xa)
+    wm = w.double().t() if transposed else w.double()
+    want = xa @ wm.t() + b.double()
+    if res:
+        want = want + r.double()
+    kw = dict(kernel=1, transposed=transposed, pre=None if not pre else (sc.to(DEV), sh.to(DEV)), pre_act=pre_act, res=None if r is None else r.to(DEV))
+    wd = w.to(DEV).reshape(*w.shape, 1)
+    got = ops.conv(x.to(DEV), wd, b.to(DEV), **kw)
+    _check(got, want, dtype, "token GEMM", extra=2.0)
+    tiled = ops.conv(x.to(DEV), wd, b.to(DEV), force_cfg=4, **kw)
+    _check(got, tiled, dtype, "token GEMM vs the tiled kernel", extra=2.0)
+    assert ops.TOKEN_GEMM and tokens * n <= ops.TOKEN_GEMM_MAX_ROWS  # (the un-forced call above took the new path)
