@@ -343,6 +343,7 @@ extern "C" int gm_attention_backward(const GmAttnBwdDesc* dp, void* stream) {
 //                     fragments in registers), P = exp(scale S - LSE), dS = P (dP - Dsum) scale, both stored as bf16
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define AB16_KEYS 64
+#define AB16_MAX_RANGES 16  // key ranges of the LSE pass (the score kernel merges them with a compile-time bound)
 
 // [AB16_KEYS][DH] bf16 tile -> LDS with a 16-byte row pad; rows >= L are zero.  256 threads.
 template <int DH>
@@ -364,8 +365,10 @@ __device__ __forceinline__ void ab16_stage(const bf16_raw* base, long long ld, i
   }
 }
 
+// (grid.z = KSPLIT key ranges of whole 64-key tiles: one head of 4 096 tokens is 64 query tiles -- a quarter of the chip walking 64 key tiles each,
+//  98 us; the ranges leave (max, sum) pairs [bh][range][query] that the score kernel merges while it loads them)
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_lse16_kernel(GmAttnBwdDesc p, float* __restrict__ lse_out, float* __restrict__ dsum_out) {
+__global__ __launch_bounds__(256) void attn_bwd_lse16_kernel(GmAttnBwdDesc p, float* __restrict__ ms_out, float* __restrict__ dsum_out, int tiles_per_range) {
   constexpr int KS = DH / 32, PITCH = DH + 8;
   extern __shared__ __attribute__((aligned(16))) char ab16_smem[];
   bf16_raw* kt = reinterpret_cast<bf16_raw*>(ab16_smem);  // [AB16_KEYS][PITCH]
@@ -396,7 +399,9 @@ __global__ __launch_bounds__(256) void attn_bwd_lse16_kernel(GmAttnBwdDesc p, fl
     }
   }
   float m = -INFINITY, s = 0.f;
-  for (int k0 = 0; k0 < p.Lk; k0 += AB16_KEYS) {
+  const int kbeg = blockIdx.z * tiles_per_range * AB16_KEYS;
+  const int kend = min(p.Lk, kbeg + tiles_per_range * AB16_KEYS);
+  for (int k0 = kbeg; k0 < kend; k0 += AB16_KEYS) {
     __syncthreads();
     ab16_stage<DH>(K, p.k_ld, k0, p.Lk, kt, tid);
     __syncthreads();
@@ -434,13 +439,14 @@ __global__ __launch_bounds__(256) void attn_bwd_lse16_kernel(GmAttnBwdDesc p, fl
   dpart += __shfl_xor(dpart, 16, 64);
   dpart += __shfl_xor(dpart, 32, 64);
   if (qg == 0 && q_ok) {
-    lse_out[(long long)bh * p.Lq + q] = M + __logf(st);
-    dsum_out[(long long)bh * p.Lq + q] = dpart;
+    float* dst = ms_out + (((long long)bh * gridDim.z + blockIdx.z) * p.Lq + q) * 2;  // (an empty range: max -inf, sum 0)
+    dst[0] = M; dst[1] = st;
+    if (blockIdx.z == 0) dsum_out[(long long)bh * p.Lq + q] = dpart;
   }
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_ps16_kernel(GmAttnBwdDesc p, const float* __restrict__ lse_in, const float* __restrict__ dsum_in,
+__global__ __launch_bounds__(256) void attn_bwd_ps16_kernel(GmAttnBwdDesc p, const float* __restrict__ ms_in, int nranges, const float* __restrict__ dsum_in,
                                                            bf16_raw* __restrict__ P, bf16_raw* __restrict__ dS, long long pd_ld,
                                                            bf16_raw* __restrict__ dST, long long st_ld) {
   constexpr int KS = DH / 32, PITCH = DH + 8;
@@ -464,7 +470,21 @@ __global__ __launch_bounds__(256) void attn_bwd_ps16_kernel(GmAttnBwdDesc p, con
     qf[ks] = make_uint4(q_ok ? t.x : 0u, q_ok ? t.y : 0u, q_ok ? t.z : 0u, q_ok ? t.w : 0u);
     gf[ks] = make_uint4(q_ok ? u.x : 0u, q_ok ? u.y : 0u, q_ok ? u.z : 0u, q_ok ? u.w : 0u);
   }
-  const float lse = lse_in[(long long)bh * p.Lq + (q_ok ? q : 0)], dsum = dsum_in[(long long)bh * p.Lq + (q_ok ? q : 0)];
+  const float dsum = dsum_in[(long long)bh * p.Lq + (q_ok ? q : 0)];
+  float lse;
+  {  // LSE of this lane's query from the key ranges' (max, sum) pairs, range order; all loads in flight (<= AB16_MAX_RANGES ranges)
+    float2 msv[AB16_MAX_RANGES];
+#pragma unroll
+    for (int r = 0; r < AB16_MAX_RANGES; ++r)
+      msv[r] = *reinterpret_cast<const float2*>(ms_in + (((long long)bh * nranges + (r < nranges ? r : 0)) * p.Lq + (q_ok ? q : 0)) * 2);
+    float M = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < AB16_MAX_RANGES; ++r) M = fmaxf(M, r < nranges ? msv[r].x : -INFINITY);
+    float tot = 0.f;
+#pragma unroll
+    for (int r = 0; r < AB16_MAX_RANGES; ++r) tot += (r < nranges && msv[r].x > -INFINITY) ? msv[r].y * __expf(msv[r].x - M) : 0.f;
+    lse = M + __logf(tot);
+  }
   ab16_stage<DH>(K, p.k_ld, k0, p.Lk, kt, tid);
   ab16_stage<DH>(V, p.v_ld, k0, p.Lk, vt, tid);
   __syncthreads();
@@ -516,8 +536,8 @@ __global__ __launch_bounds__(256) void attn_bwd_ps16_kernel(GmAttnBwdDesc p, con
 
 template <int DH>
 static void launch_attn_bwd_scores(const GmAttnBwdDesc& d, bf16_raw* P, bf16_raw* dS, long long pd_ld, bf16_raw* dST, long long st_ld, hipStream_t st) {
-  float* lse = reinterpret_cast<float*>(d.workspace);
-  float* dsum = lse + (long long)d.B * d.H * d.Lq;
+  float* dsum = reinterpret_cast<float*>(d.workspace);
+  float* ms = dsum + (long long)d.B * d.H * d.Lq;  // [B*H][ranges][Lq][2]
   constexpr size_t tile = (size_t)AB16_KEYS * (DH + 8) * sizeof(bf16_raw);
   static bool attr_set = false;
   if (!attr_set) {
@@ -525,14 +545,28 @@ static void launch_attn_bwd_scores(const GmAttnBwdDesc& d, bf16_raw* P, bf16_raw
     ab_set_lds(attn_bwd_ps16_kernel<DH>);
     attr_set = true;
   }
-  attn_bwd_lse16_kernel<DH><<<dim3((d.Lq + 63) / 64, d.B * d.H), 256, tile, st>>>(d, lse, dsum);
-  attn_bwd_ps16_kernel<DH><<<dim3((d.Lk + AB16_KEYS - 1) / AB16_KEYS, (d.Lq + 63) / 64, d.B * d.H), 256, 2 * tile, st>>>(d, lse, dsum, P, dS, pd_ld, dST, st_ld);
+  // key ranges of the LSE pass: enough for ~512 work-groups, whole 64-key tiles, no empty range
+  const int qtiles = (d.Lq + 63) / 64, ktiles = (d.Lk + AB16_KEYS - 1) / AB16_KEYS;
+  int want = (512 + qtiles * d.B * d.H - 1) / (qtiles * d.B * d.H);
+  if (want > AB16_MAX_RANGES) want = AB16_MAX_RANGES;
+  if (want > ktiles) want = ktiles;
+  if (want < 1) want = 1;
+  const int tpr = (ktiles + want - 1) / want;
+  const int nranges = (ktiles + tpr - 1) / tpr;
+  attn_bwd_lse16_kernel<DH><<<dim3(qtiles, d.B * d.H, nranges), 256, tile, st>>>(d, ms, dsum, tpr);
+  attn_bwd_ps16_kernel<DH><<<dim3(ktiles, qtiles, d.B * d.H), 256, 2 * tile, st>>>(d, ms, nranges, dsum, P, dS, pd_ld, dST, st_ld);
 }
 
 // P = softmax(scale Q K^T) and dS = P (dO V^T - rowsum(dO O)) scale per (sample, head) as bf16 [B*H][Lq][pd_ld] matrices (pd_ld >= Lk rounded
 // up to a multiple of 64; the padding columns of a row are written as zeros), and dS^T as [B*H][Lk rounded up to 64][st_ld] (st_ld >= Lq
 // rounded up to 64; padding rows and columns are zeros).  bf16 operands, head size 32 / 64 / 128 / 256.  Uses q, k, v, o, go, the geometry,
-// scale and the workspace of the descriptor (gm_attention_backward_workspace_bytes); dq / dk / dv are ignored.
+// scale and the workspace of the descriptor (gm_attention_bwd_scores_workspace_bytes); dq / dk / dv are ignored.
+// workspace of gm_attention_bwd_scores: dO.O per query + (max, sum) per query and key range
+extern "C" long long gm_attention_bwd_scores_workspace_bytes(const GmAttnBwdDesc* d) {
+  if (!d) return -1;
+  return (1LL + 2LL * AB16_MAX_RANGES) * d->B * d->H * d->Lq * (long long)sizeof(float);
+}
+
 extern "C" int gm_attention_bwd_scores(const GmAttnBwdDesc* dp, void* probs, void* dscores, long long pd_ld, void* dscores_t, long long st_ld,
                                        void* stream) {
   GM_REQUIRE(dp && probs && dscores && dscores_t, "null pointer");
@@ -544,7 +578,7 @@ extern "C" int gm_attention_bwd_scores(const GmAttnBwdDesc* dp, void* probs, voi
   auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
   GM_REQUIRE(pd_ld >= (d.Lk + 63) / 64 * 64 && pd_ld % 4 == 0 && al(probs, 8) && al(dscores, 8), "the P / dS rows must hold Lk rounded up to 64 columns, 8-byte aligned");
   GM_REQUIRE(st_ld >= (d.Lq + 63) / 64 * 64 && st_ld % 8 == 0 && al(dscores_t, 16), "the dS^T rows must hold Lq rounded up to 64 columns, 16-byte aligned");
-  GM_REQUIRE(d.workspace && d.workspace_bytes >= gm_attention_backward_workspace_bytes(dp), "workspace too small");
+  GM_REQUIRE(d.workspace && d.workspace_bytes >= gm_attention_bwd_scores_workspace_bytes(dp), "workspace too small");
   auto ok = [&](const void* p, long long ld) { return ld % 8 == 0 && al(p, 16); };
   GM_REQUIRE(ok(d.q, d.q_ld) && ok(d.k, d.k_ld) && ok(d.v, d.v_ld) && ok(d.o, d.o_ld) && ok(d.go, d.go_ld), "operands must be 16-byte aligned rows");
   if (d.B == 0 || d.Lq == 0) return 0;

@@ -1495,7 +1495,7 @@ def attention_backward_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o
         setattr(d, name + "_ld", _kv_ld(t))
     d.B, d.H, d.Lq, d.Lk, d.dh = b, heads, lq, lk, dh
     d.scale, d.dtype = float(scale), dt_code(q.dtype)
-    nbytes = lib().gm_attention_backward_workspace_bytes(C.byref(d))
+    nbytes = lib().gm_attention_bwd_scores_workspace_bytes(C.byref(d))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     _timed("attention_bwd_scores<bfloat16>", dict(flops=6.0 * b * heads * lq * lk * dh, bytes=float(6 * b * heads * lq * lkp), shape=f"B{b} H{heads} L{lq}x{lk} d{dh}"),

@@ -361,8 +361,9 @@ int gm_attention_backward(const GmAttnBwdDesc* d, void* stream);
 /* bf16-MFMA score pass of the attention backward (same autograd node as above; diffusion_model_unet.py:407-415): probs = softmax(scale Q K^T)
  * and dscores = probs (dO V^T - rowsum(dO O)) scale per (sample, head), bf16 [B*H][Lq][pd_ld] with pd_ld >= Lk rounded up to 64, plus
  * dscores_t = dscores^T as [B*H][Lk rounded up to 64][st_ld], st_ld >= Lq rounded up to 64 (padding written as zeros); bf16 operands, head
- * size 32 / 64 / 128 / 256; uses q, k, v, o, go, geometry, scale and workspace of the descriptor.  The row contractions dV = P^T dO,
+ * size 32 / 64 / 128 / 256; uses q, k, v, o, go, geometry, scale and workspace (gm_attention_bwd_scores_workspace_bytes) of the descriptor.  The row contractions dV = P^T dO,
  * dK = dS^T Q, dQ = (dS^T)^T K then run on gm_conv_wgrad (generativemodels_amd/ops.py: attention_backward_bf16). */
+long long gm_attention_bwd_scores_workspace_bytes(const GmAttnBwdDesc* d);
 int gm_attention_bwd_scores(const GmAttnBwdDesc* d, void* probs, void* dscores, long long pd_ld, void* dscores_t, long long st_ld, void* stream);
 /* dscores = scale * probs * (dprobs - rowsum(dprobs * probs)): softmax backward of the attention scores scale * Q K^T, fp32 [rows][V]
  * (the softmax of diffusion_model_unet.py:143-153 / 407-415 under torch autograd) */
