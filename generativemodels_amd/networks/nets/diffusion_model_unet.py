@@ -13,7 +13,8 @@ What runs per forward (vs. the reference's ~51 conv + 36 GroupNorm + SiLU/add/ca
 `forward` under torch.no_grad (or with nothing that requires a gradient) is this inference path; with gradients enabled and a trainable
 parameter in train() mode, an input that requires grad, or ControlNet residuals that do, it dispatches to `forward_train` (native backward kernels behind torch.autograd.Functions, generativemodels_amd/autograd.py), as the reference's training
 loops call `model(x, timesteps)` directly (tutorials/generative/distributed_training/ddpm_training_ddp.py:249-270).  Dropout
-(`dropout_cattn` > 0) is the identity at inference, like nn.Dropout in eval mode; training with it raises (not implemented).  Mixed
+(`dropout_cattn` > 0) is the identity at inference, like nn.Dropout in eval mode; in train() mode the training forward applies torch's dropout op
+at the reference's three places per transformer block (after `to_out`, after GEGLU, after `linear2`).  Mixed
 precision: fp32 parameters under `generativemodels_amd.autocast(torch.bfloat16)` (or torch.autocast("cuda")) compute in bf16."""
 from __future__ import annotations
 
@@ -27,6 +28,14 @@ from ... import ops
 from ._blocks import SPADEResnetBlock, AttentionBlock, ConvP, ResnetBlock, ensure_tuple_rep, gn_prologue, lin, tokens, wants_grad, zero_module
 
 __all__ = ["DiffusionModelUNet"]
+
+
+def _dropout(x: torch.Tensor, p: float) -> torch.Tensor:
+    """nn.Dropout in training (`dropout_cattn` > 0): torch's own dropout op on the token tensor -- the same op, tensor shape and generator the
+    reference uses at this point, so a seeded reference run on the same GPU draws the same masks; autograd differentiates it."""
+    import torch.nn.functional as F
+
+    return F.dropout(x, p=p, training=True)
 
 
 class CrossAttention(nn.Module):
@@ -70,6 +79,9 @@ class CrossAttention(nn.Module):
         k = A.linear(kv_src, self.to_k.weight)
         v = A.linear(kv_src, self.to_v.weight)
         a = A.attention(q, k, v, self.num_heads, self.scale)
+        drop = self.to_out[1]
+        if drop.p > 0.0 and drop.training:  # reference: to_out = Sequential(Linear, Dropout), residual added by the block (diffusion_model_unet.py:155,229-231)
+            return A.add(_dropout(A.linear(a, self.to_out[0].weight, self.to_out[0].bias), drop.p), residual)
         return A.linear(a, self.to_out[0].weight, self.to_out[0].bias, res=residual)
 
 
@@ -90,6 +102,9 @@ class _GEGLUMLP(nn.Module):
         from ... import autograd as A
 
         h = A.geglu(A.linear(x_norm, self.linear1.weight, self.linear1.bias))
+        if self.drop1.p > 0.0 and self.drop1.training:  # MONAI MLPBlock: drop1 after the activation, drop2 after linear2, residual added by the block
+            h = _dropout(h, self.drop1.p)
+            return A.add(_dropout(A.linear(h, self.linear2.weight, self.linear2.bias), self.drop2.p), residual)
         return A.linear(h, self.linear2.weight, self.linear2.bias, res=residual)
 
 
@@ -527,9 +542,6 @@ def _forward_train(self, x: torch.Tensor, timesteps: torch.Tensor, context: torc
 
     if (self._spade is not None) != (seg is not None):
         raise ValueError("forward_train: `seg` is the segmentation of a SPADEDiffusionModelUNet (and only of one)")
-    if self.training and getattr(self, "dropout_cattn", 0.0) > 0.0:
-        raise NotImplementedError("forward_train: dropout_cattn > 0 in train() mode is not implemented (the fused attention / MLP kernels have no "
-                                  "dropout mask); call .eval() to train without dropout, or construct the model with dropout_cattn=0")
     if context is not None and self.with_conditioning is False:
         raise ValueError("model should have with_conditioning = True if context is provided")
     if timesteps.ndim != 1 or timesteps.shape[0] not in (1, x.shape[0]):

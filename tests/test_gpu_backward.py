@@ -867,3 +867,79 @@ def test_attention_backward_bf16_mfma_path(b, lq, lk, heads, dh):
             assert torch.equal(got.grad, want)
     with pytest.raises(ValueError):
         ops.attention_backward_bf16(qd.float(), kd.float(), vd.float(), o.float(), gd.float(), heads, scale)
+
+
+def test_transformer_block_training_with_dropout_matches_autograd_under_the_same_masks(monkeypatch):
+    """`dropout_cattn` > 0 in train() mode (reference: CrossAttention.to_out = Sequential(Linear, Dropout), MONAI MLPBlock drop1 / drop2;
+    diffusion_model_unet.py:155,178-234): the training forward applies a dropout at the reference's three places per block.  With
+    torch.nn.functional.dropout replaced by a deterministic mask (the same function on both sides) the block's output and every gradient match
+    the hand-written composition in fp64; in eval() mode the dropouts are the identity; a whole conditioned UNet trains with it."""
+    import torch.nn.functional as Fn
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    from generativemodels_amd.networks.nets.diffusion_model_unet import BasicTransformerBlock
+    p_drop, calls = 0.25, []
+
+    def fake_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        calls.append(tuple(x.shape))
+        g = torch.Generator().manual_seed(1000 + len(calls))
+        mask = (torch.rand(x.shape, generator=g) >= p).to(x.device, x.dtype) / (1.0 - p)
+        return x * mask
+
+    monkeypatch.setattr(Fn, "dropout", fake_dropout)
+    torch.manual_seed(5)
+    blk = BasicTransformerBlock(64, 2, 32, dropout=p_drop, cross_attention_dim=48).train()
+    x, ctx, go = _rand((2, 40, 64), 701), _rand((2, 7, 48), 702), _rand((2, 40, 64), 703)
+    ref = {k: v.detach().double().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+
+    def attn(t, src, pre, heads=2):
+        q, k, v = t @ ref[pre + "to_q.weight"].t(), src @ ref[pre + "to_k.weight"].t(), src @ ref[pre + "to_v.weight"].t()
+        b, l, c = q.shape
+        sp = lambda u: u.reshape(b, u.shape[1], heads, c // heads).transpose(1, 2)
+        a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(c // heads), dim=-1) @ sp(v)
+        a = a.transpose(1, 2).reshape(b, l, c)
+        return fake_dropout(a @ ref[pre + "to_out.0.weight"].t() + ref[pre + "to_out.0.bias"], p_drop)
+
+    ln = lambda t, pre: Fn.layer_norm(t, (64,), ref[pre + "weight"], ref[pre + "bias"], 1e-5)
+    calls.clear()
+    h = attn(ln(xr, "norm1."), ln(xr, "norm1."), "attn1.") + xr
+    h = attn(ln(h, "norm2."), ctx.double(), "attn2.") + h
+    u = ln(h, "norm3.") @ ref["ff.linear1.weight"].t() + ref["ff.linear1.bias"]
+    a_, gate = u.chunk(2, dim=-1)
+    u = fake_dropout(a_ * Fn.gelu(gate), p_drop)
+    want = fake_dropout(u @ ref["ff.linear2.weight"].t() + ref["ff.linear2.bias"], p_drop) + h
+    (want * go.double()).sum().backward()
+    ref_calls = list(calls)
+
+    blk = blk.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    calls.clear()
+    got = blk.run_train(xd, ctx.to(DEV))
+    assert calls == ref_calls and len(calls) == 4  # to_out of attn1 and attn2, drop1, drop2 -- in the reference's order
+    _close(got, want, 2e-4, "transformer block with dropout: forward")
+    got.backward(go.to(DEV))
+    _close(xd.grad, xr.grad, 2e-4, "transformer block with dropout: dx")
+    for k, prm in blk.named_parameters():
+        _close(prm.grad, ref[k].grad, 5e-4, f"transformer block with dropout: d{k}")
+    calls.clear()
+    blk.eval()
+    blk.run_train(xd.detach(), ctx.to(DEV))
+    assert calls == []  # eval(): identity
+    monkeypatch.undo()
+    # the whole conditioned UNet in train() mode with dropout_cattn > 0: runs, differs from the dropout-free forward, gradients finite
+    torch.manual_seed(6)
+    net = DiffusionModelUNet(spatial_dims=2, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 64), attention_levels=(False, True),
+                             num_head_channels=(0, 32), with_conditioning=True, cross_attention_dim=16, dropout_cattn=0.3).to(DEV)
+    R = __import__("restatement")
+    R.derandomize_zeros(net, seed=3)
+    xi, t, c = _rand((2, 1, 16, 16), 711).to(DEV), torch.tensor([10, 500]).to(DEV), _rand((2, 3, 16), 712).to(DEV)
+    net.train()
+    y1 = net(xi, t, context=c)
+    y1.square().mean().backward()
+    assert all(p_.grad is None or torch.isfinite(p_.grad).all() for p_ in net.parameters())
+    net.eval()
+    with torch.no_grad():
+        y0 = net(xi, t, context=c)
+    assert (y1.detach() - y0).abs().max().item() > 1e-4
