@@ -15,7 +15,9 @@
 // -----------------------------------------------------------------------------------------------------------------------
 // C_in <= 4
 // -----------------------------------------------------------------------------------------------------------------------
-template <typename T>
+// (round 3: C_in is a template constant -- with a run-time C_in the staging loops and the tap tables spent ~2 000 instructions per thread on
+//  integer divisions (element -> row -> (plane, line, column), k -> (tap, channel)), a large part of the 28 k cycles a work-group lives)
+template <typename T, int CIN>
 __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int KB = 4 * VECW;                 // K values one Mma<T>::run consumes (32 bf16 / 16 fp32)
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
   const int td_i = b % ntd; b /= ntd;
   const int n = b;
   const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
-  const int Cin = p.Cin, K = 27 * Cin, nblk = (K + KB - 1) / KB;
+  constexpr int Cin = CIN, K = 27 * Cin, nblk = (K + KB - 1) / KB;
   const int cout_pad = (p.Cout + 15) & ~15;
   constexpr int BK = ConvTraits<T>::BK;
 
@@ -558,7 +560,7 @@ extern "C" long long gm_conv_cout1m_lds_bytes(const GmConvDesc* d) {
 
 template <typename KernT>
 static void edge_launch(KernT kern, const GmConvDesc& d, unsigned nblocks, size_t smem, hipStream_t st) {
-  static const void* seen[16];  // raise the dynamic-LDS limit once per kernel instantiation
+  static const void* seen[64];  // raise the dynamic-LDS limit once per kernel instantiation
   static int nseen = 0;
   const void* key = reinterpret_cast<const void*>(kern);
   bool found = false;
@@ -566,7 +568,7 @@ static void edge_launch(KernT kern, const GmConvDesc& d, unsigned nblocks, size_
   if (!found) {
     hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
-    if (nseen < 16) seen[nseen++] = key;
+    if (nseen < 64) seen[nseen++] = key;
   }
   kern<<<dim3(nblocks), 256, smem, st>>>(d);
 }
@@ -574,8 +576,17 @@ static void edge_launch(KernT kern, const GmConvDesc& d, unsigned nblocks, size_
 extern "C" int gm_conv_cin_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const size_t smem = (size_t)gm_conv_cin_lds_bytes(dp);
-  if (dp->dtype == GM_F32) { edge_launch(conv_cin_kernel<float>, *dp, nblocks, smem, st); return 0; }
-  if (dp->dtype == GM_BF16) { edge_launch(conv_cin_kernel<bf16_raw>, *dp, nblocks, smem, st); return 0; }
+#define GM_CIN_LAUNCH(T)                                                        \
+  switch (dp->Cin) {                                                            \
+    case 1: edge_launch(conv_cin_kernel<T, 1>, *dp, nblocks, smem, st); return 0; \
+    case 2: edge_launch(conv_cin_kernel<T, 2>, *dp, nblocks, smem, st); return 0; \
+    case 3: edge_launch(conv_cin_kernel<T, 3>, *dp, nblocks, smem, st); return 0; \
+    case 4: edge_launch(conv_cin_kernel<T, 4>, *dp, nblocks, smem, st); return 0; \
+    default: return -3;                                                         \
+  }
+  if (dp->dtype == GM_F32) { GM_CIN_LAUNCH(float) }
+  if (dp->dtype == GM_BF16) { GM_CIN_LAUNCH(bf16_raw) }
+#undef GM_CIN_LAUNCH
   return -2;
 }
 
