@@ -101,7 +101,7 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=128, help="volume edge (128 = the BASELINE config)")
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--graph", type=int, default=0, help="replay the UNet forward from a HIP graph (measured slower than eager launches on ROCm 7.2: 32.9 vs 27.7 ms per iteration)")
+    ap.add_argument("--graph", type=int, default=0, help="replay the UNet forward from a HIP graph (measured slower than eager launches on ROCm 7.2 at this size: 18.7-19.5 vs 14.5-14.8 ms per iteration, round 3)")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "small", "off"])
     args = ap.parse_args()
 
