@@ -393,9 +393,9 @@ __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__
 
 // The same pass with the lane <-> channel-vector assignment fixed (round 3): a block walks `rows_per_block` rows of one sample, thread t owns
 // channel vector t % CV of rows r0 + k * R, so its scale / shift vectors are loaded ONCE and the addresses are 32-bit increments.  The
-// grid-stride form above spends two 64-bit divisions and four 16-byte table loads per 16-byte vector -- as many VALU slots as the SiLU -- and
-// the pass is VALU-bound, not HBM-bound, at 5.0 TB/s (2.5 T elements/s x ~26 lane-operations against 31 T lane-operations/s).  Four rows are
-// requested per wait.  grid (nblk, N); host: CV <= 256.
+// grid-stride form above spends two 64-bit divisions and four 16-byte table loads per 16-byte vector -- as many VALU slots as the SiLU (1.25 T
+// elements/s x ~26 lane-operations is most of the chip's 31 T lane-operations/s): 5.0 -> 5.3-5.5 TB/s with them gone.  Four rows are requested
+// per wait.  grid (nblk, N); host: CV <= 256.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y, long long y_ld,
                                                            const float* __restrict__ scale, const float* __restrict__ shift, long long ss_ld,
