@@ -20,6 +20,16 @@ extern "C" int gm_linear_rows_mlpmerge(const float* P, int nj, const void* x1, c
                                        float ln_eps, const void* w, const float* bias, void* y, long long y_ld, void* y1, void* y2, long long y12_ld,
                                        int split, int rows, int cin, int cout, int post_act, int dtype, const int* off_dev, long long off_mul,
                                        void* stream);
+struct QkvAttnArgs {  // small_ops.hip
+  const void* x0;
+  const float* mlp_p; int mlp_nj; const void* mlp_x1; const float* mlp_b2; void* x0_out;
+  const float* ln_g; const float* ln_b; float ln_eps;
+  const void* w; const float* bias;
+  void* kcache; void* vcache;
+  int B, H, C, dh, cap, pos; const int* pos_dev;
+  float scale; float* ws; int chunk, sc_elems;
+};
+extern "C" int gm_qkv_attn_rows(const QkvAttnArgs* ap, int dtype, void* stream);
 extern "C" int gm_linear_rows_kvmerge(const float* kv_ws, int kv_ns, int kv_dh, const void* w, const float* bias, const void* res, long long res_ld,
                                       void* y, long long y_ld, int rows, int cin, int cout, int dtype, void* stream);
 extern "C" int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta, long long rows,
@@ -108,11 +118,31 @@ extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) 
   for (int i = 0; i < d.depth; ++i) {
     const GmDecodeBlock& b = d.blocks[i];
     GM_REQUIRE(b.w_qkv && b.w_o && b.w_1 && b.w_2 && b.k_cache && b.v_cache, "null block parameter");
-    // LayerNorm + stacked q | k | v projection in one launch; the key / value rows land directly in cache row `pos` of every sequence.  Behind a
-    // fused MLP the launch first assembles its input x0 = x1 + b2 + sum_j P[j] (and stores it: the out-projection below adds it as the residual)
+    static const bool kv_split = !(getenv("GM_DECODE_KV_SPLIT") && getenv("GM_DECODE_KV_SPLIT")[0] == '0');  // bench switches (tools/diag_c5.py)
+    static const bool kv_fuse = !(getenv("GM_DECODE_KV_FUSE") && getenv("GM_DECODE_KV_FUSE")[0] == '0');
+    const bool split = kv_split && d.max_len > DECODE_SPLIT_MIN_LEN;
+    // LayerNorm + q | k | v + the attention ranges as ONE launch where that kernel takes the geometry (small_ops.hip: qkv_attn_rows_kernel) ...
+    bool qkv_done = false;
+    if (split) {
+      QkvAttnArgs qa = {};
+      if (mlp_fuse && i > 0) { qa.mlp_p = mlp_p; qa.mlp_nj = mlp_nj; qa.mlp_x1 = x1; qa.mlp_b2 = d.blocks[i - 1].b_2; qa.x0_out = x0; }
+      else qa.x0 = x0;
+      qa.ln_g = b.ln1_g; qa.ln_b = b.ln1_b; qa.ln_eps = d.ln_eps;
+      qa.w = b.w_qkv; qa.bias = b.b_qkv;
+      qa.kcache = b.k_cache; qa.vcache = b.v_cache;
+      qa.B = d.B; qa.H = d.heads; qa.C = C; qa.dh = C / d.heads; qa.cap = d.max_len; qa.pos = hpos; qa.pos_dev = d.pos_dev;
+      qa.scale = scale; qa.ws = kv_ws;
+      rc = gm_qkv_attn_rows(&qa, d.dtype, stream);
+      if (rc < 0) return rc;
+      qkv_done = rc == 1;
+    }
+    // ... otherwise LayerNorm + stacked q | k | v projection in one launch; the key / value rows land directly in cache row `pos` of every sequence.
+    // Behind a fused MLP the launch first assembles its input x0 = x1 + b2 + sum_j P[j] (and stores it: the out-projection below adds it as the residual)
     char* kdst = reinterpret_cast<char*>(b.k_cache) + (long long)hpos * C * es;
     char* vdst = reinterpret_cast<char*>(b.v_cache) + (long long)hpos * C * es;
-    if (mlp_fuse && i > 0)
+    if (qkv_done)
+      rc = 0;
+    else if (mlp_fuse && i > 0)
       rc = gm_linear_rows_mlpmerge(mlp_p, mlp_nj, x1, d.blocks[i - 1].b_2, x0, b.ln1_g, b.ln1_b, d.ln_eps, b.w_qkv, b.b_qkv, qkv, 3 * C, kdst, vdst,
                                    (long long)d.max_len * C, C, d.B, C, 3 * C, 0, d.dtype, d.pos_dev, C, stream);
     else
@@ -126,14 +156,13 @@ extern "C" int gm_transformer_decode_step(const GmDecodeDesc* dp, void* stream) 
     at.o = y; at.o_ld = C;
     at.B = d.B; at.H = d.heads; at.Lq = 1; at.Lk = d.pos_dev ? d.max_len : d.pos + 1; at.dh = C / d.heads;
     at.scale = scale; at.dtype = d.dtype;
-    static const bool kv_split = !(getenv("GM_DECODE_KV_SPLIT") && getenv("GM_DECODE_KV_SPLIT")[0] == '0');  // bench switches (tools/diag_c5.py)
-    static const bool kv_fuse = !(getenv("GM_DECODE_KV_FUSE") && getenv("GM_DECODE_KV_FUSE")[0] == '0');
     bool out_done = false;
-    if (kv_split && d.max_len > DECODE_SPLIT_MIN_LEN) {
+    if (split) {
       // the partials are merged by the out-projection's prologue where its K-split kernel applies, by a combine launch otherwise: the two
       // forms give the same bits, and which one runs depends on the geometry only
       const bool fuse = kv_fuse && at.dh % (d.dtype == GM_F32 ? 4 : 8) == 0;
-      GM_REQUIRE(gm_attention_decode_split(&at, d.pos_dev, kv_ws, DECODE_KV_SPLITS, 0, d.max_len, stream) == 1, "head size beyond the single-query attention kernels");
+      if (!qkv_done)
+        GM_REQUIRE(gm_attention_decode_split(&at, d.pos_dev, kv_ws, DECODE_KV_SPLITS, 0, d.max_len, stream) == 1, "head size beyond the single-query attention kernels");
       rc = fuse ? gm_linear_rows_kvmerge(kv_ws, DECODE_KV_SPLITS, at.dh, b.w_o, b.b_o, x0, C, x1, C, d.B, C, C, d.dtype, stream) : 0;
       if (rc < 0) return rc;
       out_done = rc == 1;

@@ -737,35 +737,13 @@ extern "C" int gm_attention_decode_try(const GmAttnDesc* dp, void* stream) { ret
 // The partition depends on the key count only (host value, or `*lk_dev + 1` under graph replay), every sum has a fixed order: the eager
 // and the replayed step give identical bits.  Workspace: B * H * NS * (dh + 2) floats.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// One key range of the single-query attention: scores over keys K[0 .. n), softmax state, un-normalised output -> the range's partial
+// (shared by attn_decode_split_kernel and the fused q|k|v + attention kernel below).  qs: the scaled query in LDS (published by the caller);
+// sc: LDS scores / probabilities, later the [KL][dh] partial table; red: 4 floats.  K, V point at the range's first key.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_decode_split_kernel(GmAttnDesc p, const int* __restrict__ lk_dev, float* __restrict__ ws, int NS,
-                                                               int sc_elems, int chunk, int cap) {
-  if (!p.k_bs) p.k_bs = (long long)cap * p.k_ld;  // dense caches: `cap` rows per batch entry
-  if (!p.v_bs) p.v_bs = (long long)cap * p.v_ld;
-  if (lk_dev) p.Lk = *lk_dev + 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sc = reinterpret_cast<float*>(smem);  // [chunk] scores, then probabilities; later the [KL][dh] partial table
-  float* qs = sc + sc_elems;                   // [dh]
-  float* red = qs + p.dh;                      // [4]
-  const int tid = threadIdx.x;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, sp = blockIdx.y;
-  const int dh = p.dh;
-  const int k0 = sp * chunk, k1 = min(p.Lk, k0 + chunk);
-  const long long BH = (long long)gridDim.x;
-  float* wsp = ws + ((long long)bh * NS + sp) * dh;              // o[BH][NS][dh]
-  float* wm = ws + BH * NS * dh + (long long)bh * NS + sp;       // m[BH][NS]
-  float* wl = wm + BH * NS;                                      // l[BH][NS]
-  if (k0 >= p.Lk) {  // an empty range: weight zero in the merge
-    if (tid < dh) wsp[tid] = 0.f;
-    if (tid == 0) { *wm = -INFINITY; *wl = 0.f; }
-    return;
-  }
-  const int n = k1 - k0;
-  const T* Q = reinterpret_cast<const T*>(p.q) + (long long)b * p.q_ld + h * dh;
-  const T* K = reinterpret_cast<const T*>(p.k) + (long long)b * (p.k_bs ? p.k_bs : (long long)p.Lk * p.k_ld) + h * dh + (long long)k0 * p.k_ld;
-  const T* V = reinterpret_cast<const T*>(p.v) + (long long)b * (p.v_bs ? p.v_bs : (long long)p.Lk * p.v_ld) + h * dh + (long long)k0 * p.v_ld;
-  for (int c = tid; c < dh; c += 256) qs[c] = ElemIO<T>::ld(Q + c) * p.scale;
-  __syncthreads();
+__device__ __forceinline__ void attn_range_body(const T* __restrict__ K, long long k_ld, const T* __restrict__ V, long long v_ld, int n, int dh,
+                                                const float* qs, float* sc, float* red, float* wsp, float* wm, float* wl, int tid) {
+  struct { long long k_ld, v_ld; } p = {k_ld, v_ld};
   float mx = -INFINITY;
   constexpr int VECW = 16 / (int)sizeof(T);
   const bool kvec = (dh % VECW == 0) && (p.k_ld % VECW == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0);
@@ -846,6 +824,223 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(GmAttnDesc p, co
   }
   if (tid == 0) { *wm = mx; *wl = tot_l; }
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(GmAttnDesc p, const int* __restrict__ lk_dev, float* __restrict__ ws, int NS,
+                                                               int sc_elems, int chunk, int cap) {
+  if (!p.k_bs) p.k_bs = (long long)cap * p.k_ld;  // dense caches: `cap` rows per batch entry
+  if (!p.v_bs) p.v_bs = (long long)cap * p.v_ld;
+  if (lk_dev) p.Lk = *lk_dev + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = reinterpret_cast<float*>(smem);  // [chunk] scores, then probabilities; later the [KL][dh] partial table
+  float* qs = sc + sc_elems;                   // [dh]
+  float* red = qs + p.dh;                      // [4]
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, sp = blockIdx.y;
+  const int dh = p.dh;
+  const int k0 = sp * chunk, k1 = min(p.Lk, k0 + chunk);
+  const long long BH = (long long)gridDim.x;
+  float* wsp = ws + ((long long)bh * NS + sp) * dh;              // o[BH][NS][dh]
+  float* wm = ws + BH * NS * dh + (long long)bh * NS + sp;       // m[BH][NS]
+  float* wl = wm + BH * NS;                                      // l[BH][NS]
+  if (k0 >= p.Lk) {  // an empty range: weight zero in the merge
+    if (tid < dh) wsp[tid] = 0.f;
+    if (tid == 0) { *wm = -INFINITY; *wl = 0.f; }
+    return;
+  }
+  const int n = k1 - k0;
+  const T* Q = reinterpret_cast<const T*>(p.q) + (long long)b * p.q_ld + h * dh;
+  const T* K = reinterpret_cast<const T*>(p.k) + (long long)b * (p.k_bs ? p.k_bs : (long long)p.Lk * p.k_ld) + h * dh + (long long)k0 * p.k_ld;
+  const T* V = reinterpret_cast<const T*>(p.v) + (long long)b * (p.v_bs ? p.v_bs : (long long)p.Lk * p.v_ld) + h * dh + (long long)k0 * p.v_ld;
+  for (int c = tid; c < dh; c += 256) qs[c] = ElemIO<T>::ld(Q + c) * p.scale;
+  __syncthreads();
+  attn_range_body<T>(K, p.k_ld, V, p.v_ld, n, dh, qs, sc, red, wsp, wm, wl, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm + q | k | v projection + one key range of the single-query attention in ONE launch (round 3): work-group (b * H + h, range) assembles
+// the residual-stream row of sample b (plain, or x1 + b2 + sum_j P[j] behind a fused MLP -- work-group (h = 0, range 0) also stores it for the
+// out-projection's residual), normalises it, and multiplies it with head h's 3 * dh rows of the stacked projection: the K chunks are dealt to the
+// four waves, the partial sums meet in LDS in wave order.  q stays in LDS (scaled, rounded through T like the stored q of the two-launch form);
+// the work-group whose range holds the position stores the new k / v rows into the caches and -- after a fence and a barrier -- reads them back
+// with the rest of its range; the others never touch that row.  Every work-group recomputes q (3 * dh x C MACs: nothing) and requests ALL its
+// weight fragments at entry; what the fusion buys is one ~4.5 us launch per block of the token's dependent chain.
+// NG = 3 * dh / 16 output groups, UM = K chunks per wave (host: C % BK == 0, ceil(C / BK / 4) <= UM).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct QkvAttnArgs {
+  const void* x0;                                                       // [B][C] rows, or null with the partial source below
+  const float* mlp_p; int mlp_nj; const void* mlp_x1; const float* mlp_b2; void* x0_out;
+  const float* ln_g; const float* ln_b; float ln_eps;
+  const void* w; const float* bias;                                     // packed [chunk][3C pad 16][BK]; fp32 [3C] or null
+  void* kcache; void* vcache;                                           // [B][cap][C]
+  int B, H, C, dh, cap, pos; const int* pos_dev;
+  float scale; float* ws; int chunk, sc_elems;
+};
+
+template <typename T, int NG, int UM>
+__global__ __launch_bounds__(256) void qkv_attn_rows_kernel(QkvAttnArgs a) {
+  constexpr int BK = ConvTraits<T>::BK, VECW = ConvTraits<T>::VECW, NS = GM_DECODE_KV_SPLITS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int C = a.C, dh = a.dh;
+  float* sc = reinterpret_cast<float*>(smem);      // [sc_elems]
+  float* qs = sc + a.sc_elems;                     // [dh]
+  float* red = qs + dh;                            // [8]
+  float* xrow = red + 8;                           // [C] the assembled row (values already rounded through T)
+  float* part = xrow + C;                          // [4][3 dh]
+  T* xn = reinterpret_cast<T*>(part + 4 * 3 * dh); // [C] LayerNorm'ed row (16-byte aligned: every count above is a multiple of 4 floats)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q4 = lane >> 4;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, sp = blockIdx.y;
+  const int nchunks = C / BK, cout_pad = (3 * C + 15) & ~15;
+  constexpr int GPH = NG / 3;  // output groups per head part (dh / 16)
+  // ---- requested at entry: the position, every weight fragment of this wave, this thread's bias -------------------------------------------
+  const int pos = a.pos_dev ? *a.pos_dev : a.pos;
+  const T* W = reinterpret_cast<const T*>(a.w);
+  uint4 wfr[NG][UM];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int co = (g / GPH) * C + h * dh + (g % GPH) * 16 + l15;
+#pragma unroll
+    for (int u = 0; u < UM; ++u) {
+      const int c = wave + 4 * u < nchunks ? wave + 4 * u : nchunks - 1;
+      wfr[g][u] = *reinterpret_cast<const uint4*>(W + ((long long)c * cout_pad + co) * BK + q4 * VECW);
+    }
+  }
+  const int tt = tid < 3 * dh ? tid : 0;
+  const float bval = (a.bias ? a.bias : reinterpret_cast<const float*>(a.w))[a.bias ? (tt / dh) * C + h * dh + tt % dh : 0];
+  const int Lk = pos + 1;
+  const int k0 = sp * a.chunk, k1 = min(Lk, k0 + a.chunk);
+  const long long BH = (long long)gridDim.x;
+  float* wsp = a.ws + ((long long)bh * NS + sp) * dh;
+  float* wm = a.ws + BH * NS * dh + (long long)bh * NS + sp;
+  float* wl = wm + BH * NS;
+  if (k0 >= Lk) {  // an empty range (never range 0, never the position's range): weight zero in the merge
+    if (tid < dh) wsp[tid] = 0.f;
+    if (tid == 0) { *wm = -INFINITY; *wl = 0.f; }
+    return;
+  }
+  const bool owner = pos >= k0 && pos < k0 + a.chunk;
+  // ---- the residual-stream row of sample b ------------------------------------------------------------------------------------------------
+  for (int idx = tid; idx < C; idx += 256) {
+    float v;
+    if (a.mlp_p) {
+      const float* b2 = a.mlp_b2 ? a.mlp_b2 : a.mlp_p;
+      v = ElemIO<T>::ld(reinterpret_cast<const T*>(a.mlp_x1) + (long long)b * C + idx) + b2[a.mlp_b2 ? idx : 0] * (a.mlp_b2 ? 1.f : 0.f);
+      const float* pp = a.mlp_p + (long long)b * C + idx;
+      const long long pstride = (long long)a.B * C;
+      constexpr int PB = 8;
+      for (int j0 = 0; j0 < a.mlp_nj; j0 += PB) {
+        float t[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) t[j] = pp[(j0 + j < a.mlp_nj ? j0 + j : j0) * pstride];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) v += j0 + j < a.mlp_nj ? t[j] : 0.f;  // slice order
+      }
+    } else {
+      v = ElemIO<T>::ld(reinterpret_cast<const T*>(a.x0) + (long long)b * C + idx);
+    }
+    T r;
+    ElemIO<T>::st(&r, v);
+    xrow[idx] = ElemIO<T>::ld(&r);
+    if (a.mlp_p && a.x0_out && h == 0 && sp == 0) reinterpret_cast<T*>(a.x0_out)[(long long)b * C + idx] = r;
+  }
+  __syncthreads();
+  // ---- LayerNorm (two-pass statistics, like the reference's fp32 computation) -------------------------------------------------------------
+  float part_s = 0.f;
+  for (int idx = tid; idx < C; idx += 256) part_s += xrow[idx];
+  part_s = wave_sum(part_s);
+  if (lane == 0) red[wave] = part_s;
+  __syncthreads();
+  const float mean = (((red[0] + red[1]) + red[2]) + red[3]) / (float)C;
+  float part_q = 0.f;
+  for (int idx = tid; idx < C; idx += 256) part_q += (xrow[idx] - mean) * (xrow[idx] - mean);
+  part_q = wave_sum(part_q);
+  if (lane == 0) red[4 + wave] = part_q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((((red[4] + red[5]) + red[6]) + red[7]) / (float)C + a.ln_eps);
+  for (int idx = tid; idx < C; idx += 256)
+    ElemIO<T>::st(xn + idx, (xrow[idx] - mean) * rstd * a.ln_g[idx] + (a.ln_b ? a.ln_b[idx] : 0.f));
+  __syncthreads();
+  // ---- q | k | v of head h: this wave's K chunks, then the four waves' partial sums in wave order ---------------------------------------------
+  f32x4_t acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < UM; ++u) {
+    const int c = wave + 4 * u;
+    if (c < nchunks) {  // (wave-uniform)
+      const uint4 xv = *reinterpret_cast<const uint4*>(xn + c * BK + q4 * VECW);
+      const uint4 xf = make_uint4(l15 == 0 ? xv.x : 0u, l15 == 0 ? xv.y : 0u, l15 == 0 ? xv.z : 0u, l15 == 0 ? xv.w : 0u);  // MFMA column 0 = the row
+#pragma unroll
+      for (int g = 0; g < NG; ++g) Mma<T>::run(wfr[g][u], xf, acc[g]);
+    }
+  }
+  if (l15 == 0) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[wave * 3 * dh + g * 16 + 4 * q4 + i] = acc[g][i];
+  }
+  __syncthreads();
+  if (tid < 3 * dh) {
+    const float val = (((part[tid] + part[3 * dh + tid]) + part[6 * dh + tid]) + part[9 * dh + tid]) + (a.bias ? bval : 0.f);
+    T r;
+    ElemIO<T>::st(&r, val);
+    const int which = tid / dh, c = tid - which * dh;
+    if (which == 0) {
+      qs[c] = ElemIO<T>::ld(&r) * a.scale;
+    } else if (owner) {
+      T* dst = reinterpret_cast<T*>(which == 1 ? a.kcache : a.vcache) + ((long long)b * a.cap + pos) * C + h * dh + c;
+      *dst = r;
+    }
+  }
+  if (owner) __threadfence();  // the new rows are in L2 before any wave of this work-group reads its range
+  __syncthreads();
+  const T* K = reinterpret_cast<const T*>(a.kcache) + ((long long)b * a.cap + k0) * C + h * dh;
+  const T* V = reinterpret_cast<const T*>(a.vcache) + ((long long)b * a.cap + k0) * C + h * dh;
+  attn_range_body<T>(K, C, V, C, k1 - k0, dh, qs, sc, red, wsp, wm, wl, tid);
+}
+
+// 1 = launched, 0 = not this kernel's case (the caller issues the LayerNorm + q|k|v GEMM and gm_attention_decode_split), < 0 = error.
+extern "C" int gm_qkv_attn_rows(const QkvAttnArgs* ap, int dtype, void* stream) {
+  const QkvAttnArgs& a = *ap;
+  static const bool on = !(getenv("GM_DECODE_QKV_FUSE") && getenv("GM_DECODE_QKV_FUSE")[0] == '0');  // bench switch (tools/diag_c5.py)
+  if (!on || (dtype != GM_F32 && dtype != GM_BF16)) return 0;
+  const int bk = dtype == GM_F32 ? 16 : 32, vecw = dtype == GM_F32 ? 4 : 8;
+  if (!a.ln_g || !a.w || !a.kcache || !a.vcache || !a.ws || (!a.x0 && !a.mlp_p)) return 0;
+  if (a.dh % 16 || a.C % bk || a.C != a.H * a.dh || a.C % vecw) return 0;
+  const int ng = 3 * a.dh / 16, nchunks = a.C / bk, um = (nchunks + 3) / 4;
+  const int chunk = ((a.cap + GM_DECODE_KV_SPLITS - 1) / GM_DECODE_KV_SPLITS + 63) & ~63;
+  const int sc_elems = chunk > 256 * vecw ? chunk : 256 * vecw;
+  if (sc_elems > 32768 || (long long)a.B * a.H > 65535) return 0;
+  QkvAttnArgs k = a;
+  k.chunk = chunk; k.sc_elems = sc_elems;
+  const size_t smem = (size_t)(sc_elems + a.dh + 8 + a.C + 12 * a.dh) * sizeof(float) + (size_t)a.C * (dtype == GM_F32 ? 4 : 2);
+  if (smem > 160 * 1024) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(a.B * a.H, GM_DECODE_KV_SPLITS);
+#define GM_QKV_LAUNCH(T, NG, UM)                                                                                          \
+  do {                                                                                                                    \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attn_rows_kernel<T, NG, UM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    qkv_attn_rows_kernel<T, NG, UM><<<grid, 256, smem, st>>>(k);                                                           \
+    return hipGetLastError() == hipSuccess ? 1 : -1;                                                                      \
+  } while (0)
+  if (dtype == GM_BF16) {
+    if (ng == 6 && um <= 2) GM_QKV_LAUNCH(bf16_raw, 6, 2);
+    if (ng == 6 && um <= 4) GM_QKV_LAUNCH(bf16_raw, 6, 4);
+    if (ng == 12 && um <= 2) GM_QKV_LAUNCH(bf16_raw, 12, 2);
+  } else {
+    if (ng == 6 && um <= 2) GM_QKV_LAUNCH(float, 6, 2);
+    if (ng == 6 && um <= 4) GM_QKV_LAUNCH(float, 6, 4);
+    if (ng == 12 && um <= 2) GM_QKV_LAUNCH(float, 12, 2);
+  }
+#undef GM_QKV_LAUNCH
+  return 0;
+}
+
 
 template <typename T>
 __global__ __launch_bounds__(64) void attn_decode_combine_kernel(GmAttnDesc p, const float* __restrict__ ws) {
