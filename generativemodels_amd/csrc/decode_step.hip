@@ -1,9 +1,12 @@
 // One autoregressive decoding step of the decoder-only transformer, issued from native code.
 //
-// A token step is 62 tiny launches (per block: LayerNorm + stacked q|k|v GEMM writing k, v into the KV caches, 1 x t attention, out_proj +
+// A token step was 62 tiny launches in round 2 (per block: LayerNorm + stacked q|k|v GEMM writing k, v into the KV caches, 1 x t attention, out_proj +
 // residual, LayerNorm + MLP up + GELU, MLP down + residual).  Issued one by one through the Python binding it cost 2.7 ms per token
 // (20 us of interpreter + descriptor work per launch) -- no faster than the reference's recompute-the-prefix loop on this model
-// size.  This entry point walks the block table in C++ and enqueues the same kernels back to back
+// size.  This entry point walks the block table in C++ and enqueues the kernels back to back.  Round 3: 38 launches where the fused kernels of
+// small_ops.hip take the geometry -- per block [LayerNorm + q|k|v + split-KV attention ranges, its prologue assembling the residual stream from
+// the previous block's MLP partials] -> [out_proj + residual, its prologue merging the attention ranges] -> [LayerNorm + MLP up + GELU + MLP down
+// as K-slice partials] -- and the round-2 sequence (or a partly fused one) otherwise
 // (reference semantics: networks/nets/transformer.py:98-106, blocks/transformerblock.py:86-91, blocks/selfattention.py:98-147).
 #include <cstdlib>
 #include "attn_common.h"
