@@ -562,3 +562,49 @@ def test_stride2_phase_tap_tables_reproduce_a_k4_stride2_weight_gradient():
                             g3[t] += gy[o] * ph[i]
                 got[r], got[r + 2] = g3[t0], g3[t1]
             assert np.allclose(got, want), (pad, X)
+
+
+def test_trainable_parameter_derivatives_are_remade_inside_a_training_capture():
+    """ops._cached serves packed panels / fp32 copies per (parameter, version); while a training step is being captured into a HIP graph
+    (graphs.GraphedForwardBackward enters ops.refresh_trainable_derivatives) the derivatives of TRAINABLE parameters must be re-made inside the
+    capture -- a cached panel would be baked into the graph and the replays would keep reading the weights of the capture step -- while frozen
+    parameters (inference graphs, a frozen autoencoder) keep the cache.  Pure host logic."""
+    import torch
+    from generativemodels_amd import ops
+    calls = []
+
+    def make():
+        calls.append(1)
+        return object()
+
+    trainable = torch.nn.Parameter(torch.zeros(4))
+    frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+    a = ops._cached(trainable, "t", make)
+    assert ops._cached(trainable, "t", make) is a and len(calls) == 1
+    with ops.refresh_trainable_derivatives():
+        b = ops._cached(trainable, "t", make)
+        c = ops._cached(trainable, "t", make)
+        assert b is not a and c is not b and len(calls) == 3
+        f1 = ops._cached(frozen, "t", make)
+        assert ops._cached(frozen, "t", make) is f1 and len(calls) == 4
+        with ops.refresh_trainable_derivatives():  # nests
+            pass
+        assert ops._REFRESH_TRAINABLE[0]
+    assert not ops._REFRESH_TRAINABLE[0]
+    assert ops._cached(trainable, "t", make) is a  # the eager cache entry survived the capture
+    with torch.no_grad():
+        trainable.add_(1.0)  # an optimizer step: the version changes, the entry is stale
+    assert ops._cached(trainable, "t", make) is not a
+
+
+def test_graphed_forward_backward_rejects_what_it_cannot_capture():
+    import pytest
+    import torch
+    import generativemodels_amd as gm
+    lin = torch.nn.Linear(4, 4)
+    with pytest.raises(ValueError):  # host tensors cannot be replayed from device memory
+        gm.GraphedForwardBackward(lambda x: lin(x).sum(), (torch.zeros(2, 4),), lin.parameters())
+    for p in lin.parameters():
+        p.requires_grad_(False)
+    with pytest.raises(ValueError):  # nothing to differentiate
+        gm.GraphedForwardBackward(lambda x: lin(x).sum(), (torch.zeros(2, 4),), lin.parameters())
