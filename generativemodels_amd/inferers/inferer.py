@@ -438,8 +438,8 @@ class VQVAETransformerInferer(Inferer):
     def __init__(self, use_hip_graph: bool = False) -> None:
         """use_hip_graph: replay each decode iteration (token step + sampling head + draw + bookkeeping) from one HIP graph with the
         position kept on the device, when the transformer is this package's DecoderOnlyTransformer without cross attention.  Off by
-        default: measured 0.75 ms per token against 0.74 ms for eager launches (tools/bench_c5.py) -- a replayed graph pays the same
-        ~10 us per dependent kernel node as eager dispatch on this stack; it only takes the 62 launches per token off the host."""
+        default: measured the same as eager launches (round 2: 0.75 vs 0.74 ms per token at 62 launches; round 3: 0.32 vs 0.31 at 50) -- the token is
+        bound by the ~4.5 us every dependent launch costs on the GPU side, graph node or not; a replay only takes the launches off the host."""
         self.use_hip_graph = use_hip_graph
 
     @staticmethod

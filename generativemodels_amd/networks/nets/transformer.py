@@ -152,7 +152,7 @@ class DecoderOnlyTransformer(nn.Module):
             raise ValueError("step takes one token per sequence at a position inside the context window")
         with torch.no_grad():
             if not self.with_cross_attention and self.native_step:
-                # the whole token step (~110 launches) is enqueued by one native call: 20 us of interpreter work per launch made
+                # the whole token step (38-62 launches) is enqueued by one native call: 20 us of interpreter work per launch made
                 # the per-op path below as slow as recomputing the prefix (tools/bench_c5.py)
                 d = self._native_table(cache)["desc"]
                 tokens = tokens.contiguous()
