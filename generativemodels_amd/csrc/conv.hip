@@ -373,7 +373,8 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 extern "C" int gm_conv_dma_variant(int cfg);
 // 14: 4 waves x 64 voxels; 15: stride 2; 16: 512 voxels, 16 waves; 17: sub-pixel up-sampling; 18: 512 voxels, 8 waves x 64 voxels; 19: 512 voxels x 128 channels
-static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19); }
+// 21: conv_mw.hip (bf16, 16-channel half-chunks, v_mfma_f32_32x32x16_bf16, three work-groups per CU)
+static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19) || cfg == 21; }
 // HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
 #define CONV_CFG_CIN 12
 #define CONV_CFG_COUT1 13

@@ -656,7 +656,10 @@ SPLITK = os.environ.get("GM_CONV_SPLITK", "1") != "0"
 SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups than this ...
 SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "512"))  # ... into as many slices as it takes to reach about this many (two per CU)
 SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
-DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
+DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 21)
+# cfg 21 (csrc/conv_mw.hip): bf16 3x3x3 stride-1 convolutions without a fused prologue on 16-channel half-chunks + v_mfma_f32_32x32x16_bf16, three
+# work-groups per CU; "1" prefers it over cfg 14 wherever it is eligible and the grid fills the chip, "0" keeps cfg 14
+DMA_MW = os.environ.get("GM_CONV_MW", "1") != "0"
 COUT1_MARCH = os.environ.get("GM_CONV_COUT1_MARCH", "1") != "0"  # C_out == 1 heads: the depth-marching kernel (cfg 20) before the tile kernel (cfg 13)
 DMA_WIDE_WAVES = os.environ.get("GM_CONV_WIDE_WAVES", "1") != "0"  # prefer cfg 14 (4 waves x 64 voxels) for large prologue-free stride-1 convolutions
 DMA_WIDE_WAVES_PRE = os.environ.get("GM_CONV_WIDE_WAVES_PRE", "0") != "0"  # ... also with the fused in-LDS prologue (its cfg 14 instantiation)
@@ -789,7 +792,7 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         # cfg 11 keeps the fused-prologue instantiation (the cfg 14 one spills) and the small grids (its split-K form).
         tiles = desc.N * -(-desc.Do // 4) * -(-desc.Ho // 4) * -(-desc.Wo // 16) * -(-cout // 64)
         wide = (bool(desc.pre_scale is None or not desc.pre_scale) or DMA_WIDE_WAVES_PRE) and tiles >= DMA_WIDE_WAVE_MIN_TILES and DMA_WIDE_WAVES
-        order = ([15] if desc.sd == 2 else ([14, 11] if wide else [11])) + order
+        order = ([15] if desc.sd == 2 else (([21, 14, 11] if DMA_MW and desc.dtype == 1 else [14, 11]) if wide else [11])) + order
         # (512-voxel tiles -- cfg 16 / 18, one work-group per CU, half the weight-panel traffic -- measure within +-5 % of two 256-voxel
         # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,
         # r02_layer_times_cfg16_rule.txt.  They stay available through force_cfg.)
@@ -814,8 +817,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             if COUT1_MARCH_LTD is not None:
                 ltd = int(COUT1_MARCH_LTD)
             bits = [ltd, 3, ltw]
-        if cfg in (11, 14, 15, 16, 18, 19):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
-            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
+        if cfg in (11, 14, 15, 16, 18, 19, 21):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
+            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 21: [2, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy

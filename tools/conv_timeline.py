@@ -61,7 +61,7 @@ def report(name, t, nchunks):
                 groups.append(cur - prev)
                 prev = cur
             g_first8 = np.stack(groups[:8], 1)
-            rows.append((f"chunk {c}: tap groups 0-7 (each 24 MFMAs / wave), median of per-group medians", np.median(g_first8, 1)))
+            rows.append((f"chunk {c}: tap groups 0-7 (3 taps), median of per-group medians", np.median(g_first8, 1)))
             rows.append((f"chunk {c}: tap group 8" + (" + chunk boundary (patch reload)" if c + 1 < nchunks else " (last)"), groups[8]))
         if nchunks <= 5:
             rows.append(("main loop end -> residual requests, shortcut", tt[:, 61] - tt[:, 60]))
@@ -79,4 +79,4 @@ if os.environ.get("GM_TL_SHAPES"):  # e.g. "192,64,128,11;384,128,64,11"
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["GM_TL_SHAPES"].split(";")]
 for cin, cout, size, cfg in SHAPES:
     t, nwg = run(cin, cout, size, cfg)
-    report(f"{cin}->{cout} @ {size}^3 cfg{cfg}", t, cin // 32)
+    report(f"{cin}->{cout} @ {size}^3 cfg{cfg}", t, cin // (16 if cfg == 21 else 32))  # cfg 21 advances K in 16-channel half-chunks
