@@ -33,14 +33,12 @@ def _tup(v, n):
 def _weight_grad(weight: torch.Tensor, shape, run):
     """The weight gradient of one layer: `run(out, accumulate)` launches gm_conv_wgrad (fp32 [Cout, Cin, *k] result).  When the parameter's
     `.grad` is a GradientReducer bucket view (fp32 master parameters: parallel.direct_grad_hook), the kernel's final reduction ADDS INTO IT
-    and the reducer's grad-ready hook is called here -- autograd gets None and launches no `add_` for this parameter; otherwise the fresh
-    tensor goes back to autograd in the parameter's dtype."""
+    and autograd gets None (no `add_` launch for this parameter; the reducer learns of the gradient from the engine's post-accumulate hook, which
+    fires once after every use of the weight); otherwise the fresh tensor goes back to autograd in the parameter's dtype."""
     from .parallel import direct_grad_hook
 
-    hook = direct_grad_hook(weight)
-    if hook is not None:
-        run(weight.grad.view(shape), True)
-        hook(weight)
+    if direct_grad_hook(weight):
+        run(weight.grad.view(shape), True)  # readiness is signalled by the engine's post-accumulate hook, after ALL uses of the weight
         return None
     return run(None, False).reshape(weight.shape).to(weight.dtype)
 

@@ -1524,6 +1524,9 @@ def layernorm_backward(x: torch.Tensor, gy: torch.Tensor, gamma: Optional[torch.
         raise ValueError("layernorm_backward: gy must match x")
     c = x.shape[-1]
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if rows_of(x) == 0:  # nothing is launched over an empty tensor: the partial table would stay uninitialised
+        z = torch.zeros(c, dtype=torch.float32, device=x.device) if want_param_grads else None
+        return dx, z, None if z is None else z.clone()
     slots = int(lib().gm_layernorm_bwd_slots(rows_of(x)))  # one stored partial per block (no atomics, nothing to zero)
     st = torch.empty((slots, c, 2), dtype=torch.float64, device=x.device) if want_param_grads else None
     check(lib().gm_layernorm_bwd(x.data_ptr(), arena_ld(x), gy.data_ptr(), arena_ld(gy), dx.data_ptr(), arena_ld(dx), _ptr(as_f32(gamma)),

@@ -76,21 +76,27 @@ def gather_units(ids: List[int], outs: List[torch.Tensor], n_units: int, group=N
 # Parameters whose weight-gradient kernels may ACCUMULATE STRAIGHT INTO `.grad` (a GradientReducer's persistent bucket view) instead of
 # returning a fresh tensor for autograd's AccumulateGrad node to add in -- one `add_` launch per parameter and step otherwise, which is what
 # a launch-bound backward (the 41.7 M-parameter latent UNet on 32^3 latents: 320 parameters) pays for having its gradients live in buckets.
-# id(param) -> callable(param): the reducer's grad-ready hook, called by the backward function after its kernel has been enqueued.
+# id(param) -> (weakref to the parameter, data_ptr of its bucket view, weakref to the reducer).  Nothing here keeps a reducer (or its flat
+# buckets) alive: entries die with their reducer (`GradientReducer.close`, also run by its finaliser).
 _DIRECT_GRAD: dict = {}
 
 
 def direct_grad_hook(param: torch.Tensor):
-    """The callback to run after a backward kernel has accumulated `param`'s gradient in place into `param.grad`, or None when the parameter's
-    gradient must be returned to autograd as usual (no reducer, `.grad` not an fp32 bucket view, inside `no_sync()` bookkeeping is the same)."""
+    """True when a backward kernel may accumulate `param`'s gradient IN PLACE into `param.grad` and hand autograd None: the parameter belongs
+    to a live GradientReducer that is armed for a `.backward()` pass (`reducer.zero_grad()` arms it, `finish()` disarms it) and `.grad` is its
+    fp32 bucket view.  Otherwise None: the gradient goes back to autograd as a tensor -- in particular for `torch.autograd.grad(loss, params)`
+    outside an armed step (gradient penalties, diagnostics), which must not touch `.grad`.  Readiness is NOT signalled from here: the
+    engine's post-accumulate hook fires once per parameter after ALL of its uses in the graph (also for an undefined gradient), so a weight
+    used twice in one backward is complete before its bucket's exchange starts."""
     ent = _DIRECT_GRAD.get(id(param))
     if ent is None:
         return None
-    ref, view_ptr, hook = ent
+    ref, view_ptr, red = ent
+    reducer = red()
     g = param.grad
-    if ref() is not param or g is None or g.dtype != torch.float32 or g.data_ptr() != view_ptr:
+    if reducer is None or not reducer._armed or ref() is not param or g is None or g.dtype != torch.float32 or g.data_ptr() != view_ptr:
         return None
-    return hook
+    return True
 
 
 class GradientReducer:
@@ -153,6 +159,10 @@ class GradientReducer:
         self._view = {}
         self._side = None
         self._sync = True
+        self._armed = False       # True between zero_grad() and finish(): backward kernels may accumulate fp32 weight gradients in place
+        self._closed = False
+        self._hook_handles: list = []
+        self._direct_ids: list = []
         self.launched_in_backward = 0  # diagnostics: buckets whose exchange started from a hook (overlapped) in the last step
         if self.active:
             for b in self.buckets:
@@ -164,10 +174,19 @@ class GradientReducer:
                     off += p.numel()
             import weakref
 
+            me = weakref.ref(self)
+
+            def hook(p, me=me):  # (holds no strong reference to the reducer: a dropped reducer's hooks become no-ops until close() removes them)
+                r = me()
+                if r is not None and not r._closed:
+                    r._on_grad(p)
+
             for p in self.params:
-                p.register_post_accumulate_grad_hook(self._on_grad)
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(hook))
                 if p.dtype == torch.float32:  # fp32 master parameters (mixed precision): the weight-gradient kernels write fp32
-                    _DIRECT_GRAD[id(p)] = (weakref.ref(p), self._view[id(p)].data_ptr(), self._on_grad_direct)
+                    _DIRECT_GRAD[id(p)] = (weakref.ref(p), self._view[id(p)].data_ptr(), me)
+                    self._direct_ids.append(id(p))
+            weakref.finalize(self, GradientReducer._drop_entries, list(self._direct_ids), me)
         # parameters waited for before a bucket launches: all of them until the first step has shown which ones ever get a gradient
         self._expected = [True] * len(self.params)
         self._learned = False
@@ -181,8 +200,31 @@ class GradientReducer:
         self._work: List[Optional[object]] = [None] * len(self.buckets)
         self._next = 0
         self._late = {}
-        self._direct_done = set()
+        self._armed = False
         self._in_backward_launches = 0
+
+    @staticmethod
+    def _drop_entries(ids, me) -> None:
+        for i in ids:
+            ent = _DIRECT_GRAD.get(i)
+            if ent is not None and ent[2] is me:
+                del _DIRECT_GRAD[i]
+
+    def close(self) -> None:
+        """Detach from the parameters: removes the grad hooks and the in-place-accumulation entries (a later reducer over the same parameters
+        starts clean) and releases the flat buckets.  Gradients that are bucket views stay valid tensors."""
+        if self._closed:
+            return
+        self._closed = True
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        for i in self._direct_ids:
+            ent = _DIRECT_GRAD.get(i)
+            if ent is not None and ent[2]() is self:
+                del _DIRECT_GRAD[i]
+        self._direct_ids = []
+        self._armed = False
 
     def zero_grad(self) -> None:
         """Zero every gradient with one fill per bucket and make `.grad` of every expected parameter its bucket view BEFORE backward: autograd
@@ -197,6 +239,7 @@ class GradientReducer:
         for j, p in enumerate(self.params):
             if self._expected[j] and self._learned:  # (before the first step nobody knows which parameters ever get a gradient: a view installed
                 p.grad = self._view[id(p)]           #  on a never-used one would make the optimizer step it with zeros -- DDP leaves it None)
+        self._armed = True  # a `.backward()` follows: fp32 weight-gradient kernels may add straight into the views (parallel.direct_grad_hook)
 
     def no_sync(self):
         """Context manager for gradient accumulation: backward passes inside it only accumulate locally (like DDP.no_sync)."""
@@ -232,17 +275,10 @@ class GradientReducer:
             view.copy_(g)
         p.grad = view
 
-    def _on_grad_direct(self, p) -> None:
-        """Called by a backward function that accumulated p's gradient in place itself (autograd.py: _weight_grad).  The autograd engine still
-        runs the parameter's AccumulateGrad node with an undefined gradient afterwards and fires its post-accumulate hooks: that second call is
-        swallowed (`_direct_done`)."""
-        self._on_grad(p)
-        self._direct_done.add(id(p))
-
     def _on_grad(self, p) -> None:
-        if id(p) in self._direct_done:  # the engine's own hook call for a gradient the backward kernel already delivered (see above)
-            self._direct_done.discard(id(p))
-            return
+        """The engine's post-accumulate hook: fires once per parameter and backward pass, after every use of the parameter in the graph has
+        delivered its gradient -- also when the backward kernels accumulated in place and handed autograd None (torch >= 2.10 runs the
+        AccumulateGrad node with an undefined gradient)."""
         j = self._index[id(p)]
         if not self._expected[j]:
             # first gradient of a parameter that had none so far: it is not part of its bucket's exchange this step (the bucket may be
@@ -312,7 +348,9 @@ class GradientReducer:
             mwork.wait()
         if self._side is not None:
             torch.cuda.current_stream(dev).wait_stream(self._side)
-        used = [bool(v) for v in mask.cpu().tolist()] if check else [e and s_ for e, s_ in zip(self._expected, self._seen)]
+        # (steps without a mask exchange: every EXPECTED parameter counts as used on every rank -- a local `_seen` would leave `.grad = None` on
+        #  the one rank whose shard produced no gradient for it while the others step it with the averaged view: replicas would diverge)
+        used = [bool(v) for v in mask.cpu().tolist()] if check else list(self._expected)
         if not self._learned:  # first step: from now on only parameters that ever produced a gradient (on any rank) are waited for
             self._expected = list(used)
         for flat in self._flat:

@@ -102,6 +102,38 @@ def main():
                 continue
             assert torch.equal(a.grad, b.grad), f"graphed step {step}: gradient of {name} differs"
             assert b.grad.data_ptr() == red2._view[id(b)].data_ptr()
+    # ---- a weight used TWICE in one backward: with fp32 parameters the weight-gradient kernel of each use adds straight into the
+    #      bucket view; the bucket's exchange may only start after BOTH (readiness comes from the engine's post-accumulate hook, which fires once
+    #      per parameter after all of its uses).  Step 0 learns the used set (gradients arrive as tensors), steps 1-2 take the in-place path ----
+    from generativemodels_amd import autograd as A
+
+    torch.manual_seed(21)
+    w = torch.nn.Parameter(torch.randn(16, 16, 3, 3, 3, device=dev) * 0.05)
+    bb = torch.nn.Parameter(torch.randn(16, device=dev) * 0.1)
+    w0, b0 = w.detach().clone().requires_grad_(), bb.detach().clone().requires_grad_()
+    xs = torch.randn((2, 6, 6, 8, 16), device=dev)
+
+    def twice(wt, bt):
+        h = A.conv(xs, wt, bt, kernel=3, padding=1)
+        return (A.conv(h, wt, bt, kernel=3, padding=1).float() ** 2).mean()
+
+    twice(w0, b0).backward()
+    red3 = GradientReducer([w, bb], bucket_mb=0.001, force=True)
+    for step in range(3):
+        red3.zero_grad()
+        twice(w, bb).backward()
+        red3.finish()
+        torch.cuda.synchronize()
+        assert torch.allclose(w.grad, w0.grad, rtol=1e-5, atol=1e-7) and torch.allclose(bb.grad, b0.grad, rtol=1e-5, atol=1e-7), f"shared weight, step {step}"
+        if step > 0:
+            assert w.grad.data_ptr() == red3._view[id(w)].data_ptr()
+    # torch.autograd.grad outside an armed step returns tensors and leaves .grad alone
+    before = w.grad.clone()
+    gw, = torch.autograd.grad(twice(w, bb), [w])
+    assert gw is not None and torch.allclose(gw, w0.grad, rtol=1e-5, atol=1e-7) and torch.equal(w.grad, before)
+    red3.close()
+    from generativemodels_amd import parallel as P
+    assert id(w) not in P._DIRECT_GRAD
     dist.barrier()
     dist.destroy_process_group()
     print(f"RCCL_WORKER_OK buckets={len(red.buckets)} overlapped_per_step={overlapped} graphed_steps=2")
