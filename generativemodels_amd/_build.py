@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libgmamd.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "conv_fast.hip", "conv_dma.hip", "conv_mw.hip", "conv_edge.hip", "attention.hip", "attention_dma.hip", "attention_bwd.hip", "transformer_ops.hip", "decode_step.hip", "small_ops.hip", "backward.hip", "vq.hip"]
+SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "conv_fast.hip", "conv_dma.hip", "conv_mw.hip", "conv_w8.hip", "conv_edge.hip", "attention.hip", "attention_dma.hip", "attention_bwd.hip", "transformer_ops.hip", "decode_step.hip", "small_ops.hip", "backward.hip", "vq.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 

@@ -782,10 +782,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 extern "C" long long gm_conv_mw_lds_bytes();
 extern "C" int gm_conv_mw_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_mw_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
+// tile configuration 22 (conv_w8.hip: 512-voxel tiles, 64-byte patch rows, 16-channel weight panels from the halves image, 32x32x16 MFMA) likewise
+extern "C" long long gm_conv_w8_lds_bytes();
+extern "C" int gm_conv_w8_eligible(const GmConvDesc* d);
+extern "C" int gm_conv_w8_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 
 extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   const long long addv = 512;
   if (variant == 6) return gm_conv_mw_lds_bytes();
+  if (variant == 7) return gm_conv_w8_lds_bytes();
   if (variant == 4) return 5LL * 96 * DMA_ROWB + 36864 + addv;
   if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB + addv;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
@@ -822,10 +827,11 @@ static unsigned dma_grid(unsigned nwork, long long lds_bytes, int by_waves, bool
 }
 
 // geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)
-extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 21 ? 6 : cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
+extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 22 ? 7 : cfg == 21 ? 6 : cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
 
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   if (d->cfg == 21) return gm_conv_mw_eligible(d);
+  if (d->cfg == 22) return gm_conv_w8_eligible(d);
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const int s = d->cfg == 15 ? 2 : 1;
@@ -892,6 +898,7 @@ static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) 
 
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   if (dp->cfg == 21) return gm_conv_mw_launch(dp, nblocks, stream);
+  if (dp->cfg == 22) return gm_conv_w8_launch(dp, nblocks, stream);
   hipStream_t st = (hipStream_t)stream;
   if (dp->dtype == GM_F32) { dispatch_dma<float>(*dp, nblocks, st); return 0; }
   if (dp->dtype == GM_BF16) { dispatch_dma<bf16_raw>(*dp, nblocks, st); return 0; }

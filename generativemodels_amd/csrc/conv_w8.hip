@@ -1,0 +1,479 @@
+// 3x3x3 stride-1 bf16 convolution on 512-voxel tiles with v_mfma_f32_32x32x16_bf16 (tile configuration 22): the round-4 form of the LDS-DMA
+// kernel for the large prologue-free ResnetBlock convolutions (reference: diffusion_model_unet.py:669-696, autoencoderkl.py:96-122).
+//
+// What the round-4 measurements said (profiles/r04_conv_dma_ablation.txt, r04_conv_timeline_cfg14_cfg21.txt, r04_lds_dma_patterns.txt):
+//   * with every LDS-DMA request removed the 256-voxel tiles run at 1 850 - 2 050 TFLOP/s (cfg 14 / cfg 21 at 192 -> 64), with them at
+//     1 140 / 1 030: a tile waits for operand movement L2 -> LDS, not for the matrix pipe;
+//   * two thirds of those bytes are weight panels, re-fetched for every 256 voxels; removing them alone gives +30-40 %;
+//   * a CU's LDS-DMA path moves <= 64 B/clk and about one request per clock: 64 bytes of a row cost what 32 bytes cost (cfg 21's
+//     16-channel patch rows ran at 20 B/clk), and a patch burst delays every other work-group's weight panels queued behind it.
+// This kernel therefore halves the operand bytes per FLOP and keeps every request at 64 bytes or more:
+//   * 8 x 4 x 16 = 512 output voxels x 64 output channels per work-group, 8 waves (wave = one depth plane = 64 voxels x 64 channels =
+//     2 x 2 blocks of the 32x32x16 MFMA): one weight panel serves 512 voxels, halo 2.11 instead of 2.53 patch rows per voxel;
+//   * the halo patch has 64-byte rows (32 input channels) -- 1080 rows, no padding, bank conflicts removed by a per-column key
+//     (conv_w8_index.h) -- while the weights advance in halves of 16 input channels (the MFMA's K), so a 3-tap panel is 6 KiB and a
+//     two-slot ring 12 KiB: 79.75 KiB per work-group, two work-groups = 16 waves per CU at <= 128 registers;
+//   * the panels are read from the halves image [chunk32][half][tap][Cout_pad][16] (ops.packed_conv_weight_halves): contiguous 2 KiB runs.
+// Index arithmetic lives in conv_w8_index.h and is replayed on the host by tests/emulate_conv_w8.cpp.  bf16 only; stride 1, 3x3x3, direct
+// input (in_mode 0), no fused prologue, no split-K: everything else stays on conv_dma.hip.  Epilogue (bias + timestep row + residual,
+// LDS-transposed 16-byte stores, fused GroupNorm statistics, fused 1x1 shortcut, second input source of the virtual concatenation) as there.
+#include "conv_dma_shared.h"
+#include "conv_w8_index.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __attribute__((aligned(64))) unsigned int gm_w8_zero_row[16] = {0};  // the source of every padding row (this TU's own: no RDC)
+
+__device__ __forceinline__ void w8_mma(const uint4& a, const uint4& b, f32x16_t& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+#ifdef GM_CONV_TIMELINE
+#define W8_STAMP(k)                                                                                                            \
+  do {                                                                                                                         \
+    if ((p.debug_flags & 4096) && threadIdx.x == 0)                                                                            \
+      reinterpret_cast<unsigned long long*>(p.kpartial)[(long long)blockIdx.x * 64 + (k)] = __builtin_readcyclecounter();      \
+  } while (0)
+#else
+#define W8_STAMP(k)
+#endif
+
+// PRE: GroupNorm-apply + activation prologue applied IN LDS to the landed patch (see transform_patch); PIPE2: two operand register sets,
+// software-pipelined over the taps and the group barrier (one set otherwise: 16 registers less, the other three waves of the SIMD cover the reads)
+template <bool PRE, bool PIPE2>
+__global__ __launch_bounds__(512, 4) void conv_w8_kernel(const GmConvDesc p) {
+  using namespace w8;
+  typedef bf16_raw T;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 67.5 KiB][2 weight panels x 6 KiB][addend vector 256 B]
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- the tile of this work-group: XCD x owns a contiguous range of the tile list (neighbouring halo patches meet in one L2) -------------
+  const int ntd = (p.Do + TD - 1) / TD, nth = (p.Ho + TH - 1) / TH, ntw = (p.Wo + TW - 1) / TW;
+  const int ncb = (p.Cout + BN - 1) / BN;
+  W8_STAMP(0);
+  unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+  const int cb = b % ncb; b /= ncb;
+  const int tw_i = b % ntw; b /= ntw;
+  const int th_i = b % nth; b /= nth;
+  const int td_i = b % ntd; b /= ntd;
+  const int n = (int)b;
+  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
+  const int nchunks = p.Cin / BK;                          // host-checked: Cin % 32 == 0
+  const int nchunks0 = p.x2 ? p.cin_split / BK : nchunks;  // chunks of the first source (virtual concatenation: cin_split % 32 == 0)
+  const int cout_pad = (p.Cout + 15) & ~15;
+  const char* zero = reinterpret_cast<const char*>(gm_w8_zero_row) + ((lane & 3) << 4);
+
+  // ---- patch placement: wave w moves pieces w, w + 8, ...; this lane's row advances by 128 = plane + line + 2 columns per piece ------------
+  // Placed ONCE per tile in three registers: pv0 = source voxel of this lane's row of piece 0 (plain arithmetic, also when that row is padding),
+  // pflags = per piece j: bit j = the row is inside the volume (else it is read from the zero page), bit 9 + j / 18 + j = the column / line
+  // carried when the row advanced from piece j - 1, pq = the channel quarter the lane fetches per piece (2 bits each: its LDS slot ^ the row's
+  // bank key).  A chunk's request re-derives piece j's voxel with three adds.
+  constexpr int PPW = (NPIECES + NW - 1) / NW;  // 9
+  int pv0;
+  unsigned pflags = 0, pq = 0;
+  const int plane_vox = p.Hs * p.Ws;
+  const int pstep = plane_vox + p.Ws + 2, pstep_w = p.Ws - LINE, pstep_h = plane_vox - PH * p.Ws;  // + 128 rows; column carry; line carry
+  {
+    KDesc& pk = cold_desc();
+    OPAQUE_LANE(lane_p);
+    PatchRow r = patch_row(PIECE_ROWS * wave + (lane_p >> 2));
+    pv0 = ((n * pk.Ds + (od0 - pk.pd + r.pd)) * pk.Hs + (oh0 - pk.ph + r.ph)) * pk.Ws + (ow0 - pk.pw + r.pw);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int ud = od0 - pk.pd + r.pd, uh = oh0 - pk.ph + r.ph, uw = ow0 - pk.pw + r.pw;
+      const bool ok = wave + NW * j < NPIECES && (wave + NW * j < NPIECES - 1 || lane_p < 32) && ud >= 0 && ud < pk.Ds && uh >= 0 && uh < pk.Hs &&
+                      uw >= 0 && uw < pk.Ws;
+      pflags |= (ok ? 1u : 0u) << j;
+      pq |= (unsigned)patch_lane_quarter(lane_p, r.pw) << (2 * j);
+      const PatchRow nx = patch_row_next(r);
+      if (j + 1 < PPW) {
+        const bool cw = r.pw + 2 >= LINE, ch = r.ph + 1 + (cw ? 1 : 0) >= PH;
+        pflags |= (cw ? 1u : 0u) << (9 + j + 1);
+        pflags |= (ch ? 1u : 0u) << (18 + j + 1);
+      }
+      r = nx;
+    }
+  }
+  auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
+#ifdef GM_CONV_ABLATE
+    if (p.debug_flags & 1024) return;
+#endif
+    const bool second = chunk >= nchunks0;  // wave-uniform
+    const char* cbase = second ? reinterpret_cast<const char*>(p.x2) + (long long)(chunk - nchunks0) * ROWB : reinterpret_cast<const char*>(p.x) + (long long)chunk * ROWB;
+    const long long rowb = (second ? p.x2_ld : p.x_ld) * 2;
+    int pv = pv0;
+    asm volatile("" : "+v"(pv));  // opaque: nothing derived from the placement stays live across the tap loop
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = wave + NW * j;  // wave-uniform
+      if (j > 0) pv += pstep + (((pflags >> (9 + j)) & 1u) ? pstep_w : 0) + (((pflags >> (18 + j)) & 1u) ? pstep_h : 0);
+      if (piece < NPIECES) {
+        const char* src = ((pflags >> j) & 1u) ? cbase + pv * rowb + (((pq >> (2 * j)) & 3u) << 4) : zero;
+        if (piece < NPIECES - 1 || lane < 32) dma16(src, lds0 + (unsigned)patch_piece_dst(piece));  // (the last piece is 8 rows)
+      }
+    }
+  };
+  // ---- fused prologue: GroupNorm-apply (per-sample, per-channel scale / shift) + activation, applied IN LDS to the landed patch ------------------
+  // Lane 4 r + q of a piece transforms channel quarter q of row r -- which sits in the slot the lane itself fetched (q ^ key ^ key) -- so a lane's
+  // scale / shift vector is fixed for the chunk, and every byte it touches came from this wave's own DMA instruction: after the wave's vmcnt(0)
+  // no barrier is needed, and the barrier that follows publishes the transformed rows.  Same arithmetic, in the same order, as gm_gn_apply: the
+  // fused and the two-pass forms are bit-identical.  Rows from the zero page stay zero: the reference pads the ACTIVATED tensor.
+  float sc[8], sh[8];
+  auto load_affine = [&](int chunk) __attribute__((always_inline)) {
+    const int c0 = chunk * BK + (lane & 3) * 8;  // this lane's channels within cat(x, x2)
+    const float* ps = p.pre_scale + (long long)n * p.Cin + c0;
+    const float* ph = p.pre_shift + (long long)n * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < 8; i += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(ps + i), b2 = *reinterpret_cast<const float4*>(ph + i);
+      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+      sh[i] = b2.x; sh[i + 1] = b2.y; sh[i + 2] = b2.z; sh[i + 3] = b2.w;
+    }
+  };
+  auto transform_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (wave + NW * j < NPIECES && ((pflags >> j) & 1u)) {
+        char* a = smem + patch_piece_dst(wave + NW * j) + (lane >> 2) * ROWB + (((pq >> (2 * j)) & 3u) << 4);
+        float v[8];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
+        conv_act_vec(v, p.pre_act, false);
+        *reinterpret_cast<uint4*>(a) = Vec16<T>::pack(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stores are in LDS before the barrier that follows
+  };
+
+  // ---- weight panels: waves 0..5 move one 1 KiB piece each (tap wave >> 1, output channels 32 (wave & 1) ..) ---------------------------------
+  int wsrc;  // byte offset of this lane's 16 bytes from the panel's first row, or -1 beyond cout_pad
+  {
+    const WLane f = wpanel_lane(wave, lane);
+    const int co = cb * BN + f.co;
+    wsrc = (wave < 6 && co < cout_pad) ? (int)whalves_offset(0, 0, f.tap, co, cout_pad, f.slot) : -1;
+  }
+  const char* wbase = reinterpret_cast<const char*>(p.w);
+  auto issue_w = [&](int chunk, int half, int g, int slot) __attribute__((always_inline)) {  // panel (chunk, half, group g) -> ring slot
+#ifdef GM_CONV_ABLATE
+    if (p.debug_flags & 512) return;
+#endif
+    if (wave < 6) {
+      const char* panel = wbase + (((long long)chunk * 2 + half) * 27 + G * g) * cout_pad * WROWB;
+      dma16(wsrc >= 0 ? panel + wsrc : zero, lds0 + (unsigned)wpanel_piece_dst(slot, wave));
+    }
+  };
+
+  // ---- prologue: first patch, first panel, the epilogue addend ----------------------------------------------------------------------------------
+  issue_patch(0);
+  issue_w(0, 0, 0, 0);
+  if (PRE) load_affine(0);
+  W8_STAMP(55);
+  float* addv = reinterpret_cast<float*>(smem + ADDV_OFF);
+  {
+    KDesc& pa = cold_desc();
+    float addend = 0.f;  // bias + shortcut bias + timestep row (this order), fp32
+    if (tid < BN) {
+      const int co = cb * BN + tid;
+      if (co < pa.Cout) {
+        if (pa.bias) addend += pa.bias[co];
+        if (pa.skip_bias) addend += pa.skip_bias[co];
+        if (pa.rowvec) addend += pa.rowvec[(long long)n * pa.rowvec_bstride + co];
+      }
+      addv[tid] = addend;
+    }
+  }
+  // operand read addresses (bytes from smem): lane base per tap column; lines / planes / ring slots are immediates
+  int xa[3];  // (channel half 1 = the same row with bit 5 of the address flipped: the key is XORed onto the slot)
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) xa[kw] = b_lane_base(wave, lane, kw, 0);
+  const int wa0 = a_lane_base(lane);
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
+  W8_STAMP(56);
+  dma_wait<0>();
+  if (PRE) transform_patch();
+  __builtin_amdgcn_s_barrier();
+  W8_STAMP(2);
+
+  // ---- main loop: per 32-channel chunk 2 halves x 9 groups of 3 taps; group gg = 9 half + g reads ring slot gg & 1 (18 groups: compile-time) ---
+  // Every group: request panel gg + 1 into the slot group gg - 1 read (every wave is past the barrier that ended it), three taps of 4 reads +
+  // 4 MFMAs, wait for the panel, barrier.  A chunk ends with: barrier (every wave is done with the patch), patch request, wait, [transform], barrier.
+  constexpr int NRD = 4, NMMA = 4, NGG = 2 * NGROUPS;
+  auto read_ops = [&](int gg, int u, uint4 (&wfr)[2], uint4 (&xfr)[2]) __attribute__((always_inline)) {
+    const int half = gg / NGROUPS, tap = (gg % NGROUPS) * G + u;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) wfr[nb] = *reinterpret_cast<const uint4*>(smem + wa0 + a_offset(gg % RING, u, nb));
+    const int xb = half ? (xa[kw] ^ 32) : xa[kw];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) xfr[mb] = *reinterpret_cast<const uint4*>(smem + xb + b_offset(mb, kd, kh));
+  };
+  auto mma_ops = [&](const uint4 (&wfr)[2], const uint4 (&xfr)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) w8_mma(wfr[nb], xfr[mb], acc[nb][mb]);
+  };
+  auto next_panel = [&](int chunk, int gg, bool last_chunk) __attribute__((always_inline)) {
+    if (gg < NGG - 1) issue_w(chunk, (gg + 1) / NGROUPS, (gg + 1) % NGROUPS, (gg + 1) % RING);
+    else if (!last_chunk) issue_w(chunk + 1, 0, 0, 0);
+  };
+  auto chunk_boundary = [&](int chunk) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
+    issue_patch(chunk + 1);
+    if (PRE) load_affine(chunk + 1);
+    dma_wait<0>();                 // patch + the next chunk's first panel
+    if (PRE) transform_patch();
+    __builtin_amdgcn_s_barrier();
+  };
+  if constexpr (PIPE2) {
+    // two operand sets: tap k+1's four reads are issued under tap k's four MFMAs; the next group's first tap is read right after the barrier
+    // that publishes its panel
+    uint4 xf[2][2], wf[2][2];
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool last_chunk = chunk + 1 == nchunks;
+#pragma unroll
+      for (int half_ = 0; half_ < 2; ++half_)
+#pragma unroll
+      for (int g_ = 0; g_ < NGROUPS; ++g_) {
+        const int gg = half_ * NGROUPS + g_;
+        const int X = (gg * G) & 1, Y = X ^ 1;                                    // operand set of a tap = (tap index within the chunk) & 1
+        const int LASTSET = (gg * G + G - 1) & 1, NEXTSET = ((gg + 1) * G) & 1;   // ... of the group's last tap / the next group's first
+        if (gg == 0) read_ops(0, 0, wf[X], xf[X]);  // (a chunk's first group reads its own tap 0: the patch has just been replaced)
+        read_ops(gg, 1, wf[Y], xf[Y]);
+        mma_ops(wf[X], xf[X]);
+        if (gg == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);     // the operand reads first, then the tap's MFMAs
+        else __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+        next_panel(chunk, gg, last_chunk);
+        read_ops(gg, 2, wf[X], xf[X]);
+        mma_ops(wf[Y], xf[Y]);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+        if (gg == NGG - 1) {
+          mma_ops(wf[LASTSET], xf[LASTSET]);
+          if (!last_chunk) chunk_boundary(chunk);
+        } else {
+          // the panel issued at the top of this group must have landed; the wait also retires every LDS read of the group: the barrier
+          // releases other waves to DMA into the ring slot this group read
+          dma_wait<0>();
+          __builtin_amdgcn_s_barrier();
+          read_ops(gg + 1, 0, wf[NEXTSET], xf[NEXTSET]);
+          mma_ops(wf[LASTSET], xf[LASTSET]);
+          __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NMMA, 0);
+        }
+        if (chunk < 2) W8_STAMP(3 + chunk * 18 + gg);
+      }
+    }
+  } else {
+    uint4 xf[2], wf[2];
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool last_chunk = chunk + 1 == nchunks;
+#pragma unroll
+      for (int half_ = 0; half_ < 2; ++half_)
+#pragma unroll
+      for (int g_ = 0; g_ < NGROUPS; ++g_) {
+        const int gg = half_ * NGROUPS + g_;
+        next_panel(chunk, gg, last_chunk);
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          read_ops(gg, u, wf, xf);
+          mma_ops(wf, xf);
+        }
+        if (gg == NGG - 1) {
+          if (!last_chunk) chunk_boundary(chunk);
+        } else {
+          dma_wait<0>();
+          __builtin_amdgcn_s_barrier();
+        }
+        if (chunk < 2) W8_STAMP(3 + chunk * 18 + gg);
+      }
+    }
+  }
+  W8_STAMP(60);
+
+  const EpTile et = {n, od0, oh0, ow0, cb * BN, 0};
+  EpRows<8> rows0;
+  OPAQUE_LANE(lane_e);
+  dma_epilogue_rows<T, 4, 3, 0>(cold_desc(), et, wave * 4, lane_e, rows0);  // residual rows: requested now, used after the transpose
+
+  // ---- fused 1x1 shortcut convolution: extra 32-channel chunks over the (virtually concatenated) skip sources, centre tap only --------------------
+  // Rounds of up to 2 chunks: each wave DMAs the 64-byte channel slices of ITS OWN 64 output voxels (4 pieces per chunk) and waves 4 j .. 4 j + 3
+  // the 4-piece weight panel of the round's chunk j (rows of the standard packed image); one wait + barrier, then 2 halves x 4 MFMAs per chunk.
+  KDesc& ps = cold_desc();
+  if (ps.skip_x[0]) {
+    const int nsc0 = ps.skip_cin[0] / BK, nsc = nsc0 + (ps.skip_x[1] ? ps.skip_cin[1] / BK : 0);
+    OPAQUE_LANE(lane_k);
+    const char* wsk = reinterpret_cast<const char*>(ps.skip_w);
+    const char* zk = reinterpret_cast<const char*>(gm_w8_zero_row) + ((lane_k & 3) << 4);
+    for (int sc0 = 0; sc0 < nsc; sc0 += SC_ROUND) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // patch buffer and ring are free
+#pragma unroll
+      for (int j = 0; j < SC_ROUND; ++j) {
+        const int sc = sc0 + j;
+        if (sc < nsc) {  // wave-uniform
+          const int part = sc >= nsc0 ? 1 : 0, cip = sc - (part ? nsc0 : 0);
+          const char* xb = reinterpret_cast<const char*>(ps.skip_x[part]) + (long long)cip * ROWB;
+          const long long rowb = ps.skip_ld[part] * 2;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int m = 16 * h + (lane_k >> 2);  // within the wave's plane: line m / 16, column m % 16
+            const int od = od0 + wave, oh = oh0 + (m >> 4), ow = ow0 + (m & 15);
+            const bool ok = od < ps.Do && oh < ps.Ho && ow < ps.Wo;
+            const int vox = ((n * ps.Do + od) * ps.Ho + oh) * ps.Wo + ow;
+            dma16(ok ? xb + vox * rowb + (sc_x_lane_quarter(lane_k, h) << 4) : zk, lds0 + (unsigned)sc_x_piece_dst(j, wave, h));
+          }
+          if ((wave >> 2) == j) {
+            const int h = wave & 3;
+            const int wco = cb * BN + 16 * h + (lane_k >> 2);
+            const char* wpan = wsk + ((long long)sc * cout_pad + wco) * ROWB + (sc_w_lane_quarter(lane_k, h) << 4);
+            dma16(wco < cout_pad ? wpan : zk, lds0 + (unsigned)sc_w_piece_dst(j, h));
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int j = 0; j < SC_ROUND; ++j) {
+        if (sc0 + j < nsc) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            uint4 sx[2], sw[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) sx[mb] = *reinterpret_cast<const uint4*>(smem + sc_b_lane_base(wave, lane_k, half) + sc_b_offset(j, mb));
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) sw[nb] = *reinterpret_cast<const uint4*>(smem + sc_a_lane_base(lane_k, half) + sc_a_offset(j, nb));
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+              for (int mb = 0; mb < 2; ++mb) w8_mma(sw[nb], sx[mb], acc[nb][mb]);
+          }
+        }
+      }
+    }
+  }
+  W8_STAMP(61);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wave is done with the operand buffers: the transpose scratch overlays them
+  W8_STAMP(57);
+
+  // ---- epilogue: accumulators + addend -> wave-private LDS scratch (row = voxel) -> 16-byte row stores, fused GroupNorm statistics ------------
+  KDesc& pe = cold_desc();
+#ifdef GM_CONV_ABLATE
+  if (pe.debug_flags & 256) return;
+#endif
+  float st_s[1][8], st_q[1][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { st_s[0][i] = 0.f; st_q[0][i] = 0.f; }
+  char* scratch = smem + (size_t)wave * SCRATCH_WAVE;
+  {
+    const int hi = lane_e >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const int ch = nb * 32 + 8 * jq + 4 * hi;  // = nb * 32 + acc_channel(lane, 4 jq)
+        const float4 add = *reinterpret_cast<const float4*>(addv + ch);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          char* dst = scratch + acc_row(mb, lane_e) * 144 + ch * 2;
+          const float o0 = acc[nb][mb][4 * jq] + add.x, o1 = acc[nb][mb][4 * jq + 1] + add.y, o2 = acc[nb][mb][4 * jq + 2] + add.z,
+                      o3 = acc[nb][mb][4 * jq + 3] + add.w;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        }
+      }
+    }
+  }
+  dma_epilogue_store<T, 4, 3, 0, 1>(pe, scratch, et, wave * 4, lane_e, rows0, st_s, st_q);
+  W8_STAMP(62);
+  if (pe.stats) {
+    // lane sums over its rows -> sum over the 8 row lanes of a segment (registers) -> one partial per (wave, channel) in the wave's own scratch
+    // block -> fixed-order fp64 sum over the waves: deterministic, one plain store per (tile, channel)
+    OPAQUE_LANE(lane_s);
+    float ra[8], rb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ra[i] = wave_segment_sum(st_s[0][i]); rb[i] = wave_segment_sum(st_q[0][i]); }
+    if (lane_s < 8) {
+      float* part = reinterpret_cast<float*>(scratch);
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) *reinterpret_cast<float4*>(part + 2 * (lane_s * 8 + i)) = make_float4(ra[i], rb[i], ra[i + 1], rb[i + 1]);
+    }
+    __syncthreads();
+    const int ch = wave * 64 + lane_s;
+    if (ch < BN) {
+      double a = 0.0, b2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float2 v = *reinterpret_cast<const float2*>(smem + w * SCRATCH_WAVE + ch * 8);
+        a += (double)v.x;
+        b2 += (double)v.y;
+      }
+      const int co = cb * BN + ch;
+      if (co < pe.Cout) {
+        const long long slot = (long long)(td_i * nth + th_i) * ntw + tw_i;  // the tile within its sample
+        double* dst = pe.stats + ((slot * pe.N + n) * pe.Cout + co) * 2;
+        *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
+      }
+    }
+  }
+  W8_STAMP(63);
+}
+
+extern "C" long long gm_conv_w8_lds_bytes() { return w8::LDS_BYTES; }
+
+// geometry this kernel covers: bf16, 3x3x3, stride 1, direct input, no prologue / split-K / output activation beyond the epilogue's forms.
+// GmConvDesc.w must point at the HALVES image of the weights ([chunk32][half][tap][Cout_pad][16]); the shortcut's skip_w at the standard one.
+extern "C" int gm_conv_w8_eligible(const GmConvDesc* d) {
+  const int vecw = 8;
+  return d->dtype == GM_BF16 && d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->dd == 1 && d->dh == 1 &&
+         d->dw == 1 && d->in_mode == 0 && d->Cin % w8::BK == 0 && d->x_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 &&
+         ((d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_act == 0) ||
+          (d->pre_scale != nullptr && d->pre_shift != nullptr && (reinterpret_cast<uintptr_t>(d->pre_scale) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(d->pre_shift) & 15) == 0)) &&
+         (d->x2 == nullptr || (d->cin_split > 0 && d->cin_split < d->Cin && d->cin_split % w8::BK == 0 && d->x2_ld % vecw == 0 &&
+                               (reinterpret_cast<uintptr_t>(d->x2) & 15) == 0)) &&
+         d->ltd == 3 && d->lth == 2 && d->ltw == 4 && d->Cout % vecw == 0 && d->y_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
+         (!d->res || (d->res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0)) && !(d->ksplit > 1 && d->kpartial) &&
+         (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31) && (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31) &&
+         (!d->skip_x[0] ||
+          (d->skip_w && d->skip_cin[0] > 0 && d->skip_cin[0] % w8::BK == 0 && d->skip_ld[0] % vecw == 0 &&
+           (reinterpret_cast<uintptr_t>(d->skip_x[0]) & 15) == 0 &&
+           (!d->skip_x[1] || (d->skip_cin[1] > 0 && d->skip_cin[1] % w8::BK == 0 && d->skip_ld[1] % vecw == 0 &&
+                              (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
+}
+
+static int g_w8_pipe2 = 0;  // measured (profiles/r04_conv_cfg22_ab.txt): one operand set 14.88 vs two sets 15.54 ms per C2 iteration (the two-set form spills at 128 registers)
+extern "C" void gm_conv_w8_set_pipe2(int on) { g_w8_pipe2 = on; }
+
+template <bool PRE, bool PIPE2>
+static void launch_w8(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_w8_kernel<PRE, PIPE2>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();
+    attr_set = true;
+  }
+  kern<<<dim3(nblocks), 512, (size_t)w8::LDS_BYTES, st>>>(d);
+}
+
+extern "C" int gm_conv_w8_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
+  if (dp->dtype != GM_BF16) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const bool pre = dp->pre_scale != nullptr;
+  if (g_w8_pipe2) { if (pre) launch_w8<true, true>(*dp, nblocks, st); else launch_w8<false, true>(*dp, nblocks, st); }
+  else { if (pre) launch_w8<true, false>(*dp, nblocks, st); else launch_w8<false, false>(*dp, nblocks, st); }
+  return 0;
+}

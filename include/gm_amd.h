@@ -145,7 +145,8 @@ int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const f
  * (:686-690), residual add (:692-696) and the output activation. */
 typedef struct GmConvDesc {
   const void* x; long long x_ld;
-  const void* w;             /* packed by gm_pack_conv_weight */
+  const void* w;             /* packed by gm_pack_conv_weight; cfg 22 alone reads the HALVES image of that panel instead:
+                              * [chunk32][half][tap][Cout_pad][16] (the 16-input-channel weight block of a tap contiguous) */
   const float* bias;         /* [Cout] or NULL */
   const float* pre_scale;    /* [N][Cin] or NULL */
   const float* pre_shift;    /* [N][Cin] or NULL */
@@ -175,7 +176,7 @@ typedef struct GmConvDesc {
                                 must be NULL when gm_conv_stats_slots() returns 0 for the chosen configuration */
   /* optional fused 1x1 shortcut convolution of a ResnetBlock (diffusion_model_unet.py:684-696, autoencoderkl.py:188-193):
    * y += W_skip * cat(skip_x[0], skip_x[1]) + skip_bias with the sources in the output geometry (skip_x[1] may be NULL).
-   * Implemented by the LDS-DMA configurations (cfg 11, 14, 16, 18, 19): gm_conv_lds_bytes() returns -1 for any other when skip_x[0] is set. */
+   * Implemented by the LDS-DMA configurations (cfg 11, 14, 16, 18, 19, 21, 22): gm_conv_lds_bytes() returns -1 for any other when skip_x[0] is set. */
   const void* skip_x[2]; long long skip_ld[2]; int skip_cin[2];
   const void* skip_w;        /* gm_pack_conv_weight image of the [Cout][skip_cin[0]+skip_cin[1]] 1x1 kernel */
   const float* skip_bias;    /* [Cout] or NULL */
@@ -201,6 +202,9 @@ int gm_conv_forward(const GmConvDesc* d, void* stream);
  * patch before the epilogue of the current one (measured 1 % slower on MI355X: DESIGN.md 4.1).  n > 0: at most n work-groups (tests: forces
  * the multi-tile walk on small inputs). */
 void gm_conv_dma_set_persistent(int max_work_groups);
+/* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
+ * software-pipelined over the taps (bench A/B: slower at 128 registers). */
+void gm_conv_w8_set_pipe2(int on);
 long long gm_packed_conv_weight_elems(int Cout, int Cin, int kd, int kh, int kw, int dtype);
 /* src: [Cout][Cin][kd][kh][kw] (transposed = 0) or [Cin][Cout][kd][kh][kw] (transposed = 1, nn.ConvTransposeNd) */
 int gm_pack_conv_weight(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin, int kd, int kh, int kw,

@@ -15,11 +15,13 @@ dev = "cuda"
 def run(cin, cout, size, cfg, with_res=True):
     x = torch.randn((1, size, size, size, cin), device=dev).bfloat16()
     w = (torch.randn((cout, cin, 3, 3, 3), device=dev) / math.sqrt(cin * 27)).bfloat16()
+    if os.environ.get("GM_TL_ZERO"):  # all-zero operands: the same instruction stream at a lower switching power (DVFS check)
+        x.zero_(); w.zero_()
     b = torch.randn((cout,), device=dev)
     res = torch.randn((1, size, size, size, cout), device=dev).bfloat16() if with_res else None
     kw = dict(kernel=3, padding=1, force_cfg=cfg, want_stats=True, res=res, ksplit=1)
     ops.conv(x, w, b, **kw)
-    bm = 512 if cfg in (16, 18, 19) else 256
+    bm = 512 if cfg in (16, 18, 19, 22) else 256
     bn = 128 if cfg == 19 else 64
     nwg = (size ** 3 // bm) * ((cout + bn - 1) // bn)
     buf = torch.zeros((nwg, 64), dtype=torch.int64, device=dev)
@@ -27,8 +29,13 @@ def run(cin, cout, size, cfg, with_res=True):
     ops._CONV_DEBUG_FLAGS = 4096 | int(os.environ.get("GM_TL_FLAGS", "0"))  # + 512: no weight traffic, + 1024: no patch traffic (timeline_ablate build)
     ops._CONV_TIMELINE_BUFFER = buf
     try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         ops.conv(x, w, b, **kw)
+        e1.record()
         torch.cuda.synchronize()
+        global LAST_MS
+        LAST_MS = e0.elapsed_time(e1)
     finally:
         ops._CONV_DEBUG_FLAGS = 0
         ops._CONV_TIMELINE_BUFFER = None
@@ -36,15 +43,19 @@ def run(cin, cout, size, cfg, with_res=True):
     return t, nwg
 
 
-def report(name, t, nchunks):
+LAST_MS = 0.0
+
+
+def report(name, t, nchunks, gpc=9, stride=10):
+    """gpc = tap groups per stamped chunk, stride = stamp slots per chunk (cfg 22: 18 groups = 2 halves x 9, chunks 0-1 stamped)"""
     import numpy as np
-    ok = t[:, 63] > 0
+    ok = (t[:, 63] > 0) & (t[:, 0] > 0)
     t = t[ok]
     order = np.argsort(t[:, 0])
     t = t[order]
     t0 = t[:, 0].min()
     span = t[:, 63].max() - t0
-    print(f"--- {name}: {len(t)} work-groups, kernel span {span} cycles")
+    print(f"--- {name}: {len(t)} work-groups, kernel span {span} cycles in {LAST_MS:.3f} ms = {span / LAST_MS / 1e6:.3f} GHz shader clock (stamped launch)")
     for label, sel in (("all stamped work-groups", slice(0, None)),):
         tt = t[sel]
         if len(tt) == 0:
@@ -54,16 +65,17 @@ def report(name, t, nchunks):
                 ("accumulator init, addend -> LDS", tt[:, 56] - tt[:, 55]),
                 ("wait for the first DMAs (+ barrier)", tt[:, 2] - tt[:, 56])]
         prev = tt[:, 2]
-        for c in range(min(nchunks, 5)):
+        nst = min(nchunks, 5 if gpc == 9 else 2)
+        for c in range(nst):
             groups = []
-            for g in range(9):
-                cur = tt[:, 3 + c * 10 + g]
+            for g in range(gpc):
+                cur = tt[:, 3 + c * stride + g]
                 groups.append(cur - prev)
                 prev = cur
-            g_first8 = np.stack(groups[:8], 1)
-            rows.append((f"chunk {c}: tap groups 0-7 (3 taps), median of per-group medians", np.median(g_first8, 1)))
-            rows.append((f"chunk {c}: tap group 8" + (" + chunk boundary (patch reload)" if c + 1 < nchunks else " (last)"), groups[8]))
-        if nchunks <= 5:
+            g_first = np.stack(groups[:gpc - 1], 1)
+            rows.append((f"chunk {c}: tap groups 0-{gpc - 2} (3 taps), median of per-group medians", np.median(g_first, 1)))
+            rows.append((f"chunk {c}: tap group {gpc - 1}" + (" + chunk boundary (patch reload)" if c + 1 < nchunks else " (last)"), groups[gpc - 1]))
+        if nchunks <= nst:
             rows.append(("main loop end -> residual requests, shortcut", tt[:, 61] - tt[:, 60]))
             rows.append(("barrier, next tile decoded + its patch requested", tt[:, 57] - tt[:, 61]))
             rows.append(("epilogue: LDS transpose, residual, stores", tt[:, 62] - tt[:, 57]))
@@ -79,4 +91,7 @@ if os.environ.get("GM_TL_SHAPES"):  # e.g. "192,64,128,11;384,128,64,11"
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["GM_TL_SHAPES"].split(";")]
 for cin, cout, size, cfg in SHAPES:
     t, nwg = run(cin, cout, size, cfg)
-    report(f"{cin}->{cout} @ {size}^3 cfg{cfg}", t, cin // (16 if cfg == 21 else 32))  # cfg 21 advances K in 16-channel half-chunks
+    if cfg == 22:
+        report(f"{cin}->{cout} @ {size}^3 cfg{cfg}", t, cin // 32, gpc=18, stride=18)
+    else:
+        report(f"{cin}->{cout} @ {size}^3 cfg{cfg}", t, cin // (16 if cfg == 21 else 32))  # cfg 21 advances K in 16-channel half-chunks
