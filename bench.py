@@ -32,6 +32,52 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+# What the chip SUSTAINS on bf16 MFMA at its 1400 W package power cap with random (non-zero) operands -- tools/mfma_power.hip on MI355X,
+# profiles/r04_mfma_power_ceiling.txt: the clock is set by the power budget, and this benchmark runs AT the cap (profiles/r04_power_trace.txt).
+# Reported next to the nominal peak; `roofline.frac` stays achieved / nominal peak.
+MFMA_BF16_SUSTAINED_TFLOPS = {"operands in registers, no memory traffic": 1850.0, "one ds_read_b128 per 32x32x16 MFMA (this kernel's tap loop)": 1490.0,
+                              "0.75 ds_read_b128 per MFMA": 1600.0}
+
+
+class PowerSampler:
+    """Package power of the GPU this rank runs on, read from the amdgpu hwmon node every 50 ms on a host thread while the timed region runs
+    (a file read: no process is spawned, nothing is enqueued on the GPU).  None when the node is not there."""
+
+    def __init__(self, local_rank: int = 0):
+        import glob
+        self.path, self.cap_w = None, None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) or sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+        if cards:
+            self.path = cards[min(local_rank, len(cards) - 1)]
+            try:
+                self.cap_w = int(open(os.path.join(os.path.dirname(self.path), "power1_cap")).read()) / 1e6
+            except Exception:
+                self.cap_w = None
+        self.samples, self._stop, self._thread = [], False, None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.samples.append(int(open(self.path).read()) / 1e6)
+            except Exception:
+                pass
+            time.sleep(0.05)
+
+    def start(self):
+        if self.path is not None:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+        if not self.samples:
+            return None
+        s = sorted(self.samples)
+        return dict(mean_w=round(sum(s) / len(s), 1), median_w=round(s[len(s) // 2], 1), max_w=round(s[-1], 1), cap_w=self.cap_w, samples=len(s),
+                    source=self.path)
 
 C2 = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(64, 128, 256), attention_levels=(False, False, False),
           num_res_blocks=2, num_head_channels=(0, 0, 256), norm_num_groups=32)
@@ -61,7 +107,7 @@ def kernel_source_sha() -> str:
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "generativemodels_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name == "conv_dma.hip" or name.endswith(".h"):  # the roofline kernel's translation unit and every header it can include
+        if name.endswith((".hip", ".h", ".cpp")):  # every translation unit whose kernels the PMC file carries rows for, and every header
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
@@ -126,6 +172,7 @@ def main() -> None:
     from generativemodels_amd.networks.schedulers import DDIMScheduler
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.set_grad_enabled(False)  # sampling only: with gradients enabled a network's forward takes its differentiable (training) path
     torch.manual_seed(0)
     model = DiffusionModelUNet(**C2).eval()
     sd = rerandomize_zero_params({k: v.clone() for k, v in model.state_dict().items()})
@@ -146,11 +193,15 @@ def main() -> None:
     for _ in range(args.warmup):
         out = inferer.sample(noise, model, sched, verbose=False)
     sync()
+    power = PowerSampler(local_rank) if rank == 0 else None
+    if power is not None:
+        power.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = inferer.sample(noise, model, sched, verbose=False)
     sync()
     elapsed = time.perf_counter() - t0
+    power_stats = power.stop() if power is not None else None
     if dist is not None:  # max over ranks
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,6 +245,12 @@ def main() -> None:
 
         if roof is not None:
             roof.update(measured_hbm_traffic(roof["kernel"], dtype))
+            if dtype == torch.bfloat16:
+                key = "one ds_read_b128 per 32x32x16 MFMA (this kernel's tap loop)"
+                roof.update(sustained_peak=MFMA_BF16_SUSTAINED_TFLOPS[key], frac_of_sustained=round(roof["achieved"] / MFMA_BF16_SUSTAINED_TFLOPS[key], 4),
+                            sustained_peak_note="bf16 MFMA rate the chip sustains at its package power cap on random operands (tools/mfma_power.hip, "
+                                                "profiles/r04_mfma_power_ceiling.txt): " + json.dumps(MFMA_BF16_SUSTAINED_TFLOPS) +
+                                                "; this benchmark runs at the cap (package_power_w); `frac` is against the nominal dense peak")
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----------------------------------------------------
     # (1) thread-count sweep at 1/8 of the voxels (oneDNN oversubscribes on many-core hosts: 256 threads measured 2x slower than 8 in
@@ -203,40 +260,53 @@ def main() -> None:
     if rank == 0 and world == 1 and args.cpu_baseline != "off":
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import restatement as R  # test infrastructure: the CPU statement of the reference algorithm (checker / baseline only)
+        import ref_loader          # ... and, where the reference tree exists (the build container), the UNMODIFIED reference itself
 
         cores = os.cpu_count() or 1
+        sd32 = {k: v.float() for k, v in sd.items()}
+        gen = ref_loader.load_reference()
+        if gen is not None:  # kind = "reference": the reference's own modules on the host cores
+            ref_net = gen.networks.nets.DiffusionModelUNet(**C2).eval()
+            ref_net.load_state_dict({k: v.float() for k, v in sd.items()})
+            ref_sched = gen.networks.schedulers.DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+            ref_sched.set_timesteps(args.inference_steps)
+            cpu_forward = lambda xx, tt_: ref_net(xx, tt_)                                         # noqa: E731
+            cpu_step = lambda eps_, t_, xx: ref_sched.step(eps_, t_, xx)                           # noqa: E731
+        else:                # kind = "port": the restatement (the GPU box has no /root/reference)
+            cpu_forward = lambda xx, tt_: R.unet_forward(sd32, C2, xx, tt_)                        # noqa: E731
+            cpu_step = lambda eps_, t_, xx: R.ddim_step(sched.alphas_cumprod, 1000, args.inference_steps, eps_, t_, xx, clip_sample=False)  # noqa: E731
         size = args.size if args.cpu_baseline == "full" else min(args.size, 48)
         x = torch.randn((1, 1, size, size, size), generator=torch.Generator().manual_seed(7))
-        sd32 = {k: v.float() for k, v in sd.items()}
         half = max(size // 2, 8)
         xs = x[..., :half, :half, :half].contiguous()
         sweep = {}
         with torch.no_grad():
             for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256)}):
                 torch.set_num_threads(nt)
-                R.unet_forward(sd32, C2, xs[..., : half // 2, : half // 2, : half // 2].contiguous(), torch.tensor([500.0]))  # spin the pool up
+                cpu_forward(xs[..., : half // 2, : half // 2, : half // 2].contiguous(), torch.tensor([500.0]))  # spin the pool up
                 c0 = time.perf_counter()
-                R.unet_forward(sd32, C2, xs, torch.tensor([500.0]))
+                cpu_forward(xs, torch.tensor([500.0]))
                 sweep[nt] = round(time.perf_counter() - c0, 3)
             best = min(sweep, key=sweep.get)
             torch.set_num_threads(best)
             times, eps500 = [], None
             for tstep in ((980, 500, 20) if args.cpu_baseline == "full" else (500,)):
                 c0 = time.perf_counter()
-                eps = R.unet_forward(sd32, C2, x, torch.tensor([float(tstep)]))
-                R.ddim_step(sched.alphas_cumprod, 1000, args.inference_steps, eps, tstep, x, clip_sample=False)
+                eps = cpu_forward(x, torch.tensor([float(tstep)]))
+                cpu_step(eps, tstep, x)
                 times.append(time.perf_counter() - c0)
                 if tstep == 500:
                     eps500 = eps
         cpu_s = sorted(times)[len(times) // 2]
         scale = (args.size / size) ** 3
-        cpu = dict(value=round(1.0 / (cpu_s * scale * args.inference_steps), 8), unit="volumes/s", cores=best, kind="port",
+        cpu = dict(value=round(1.0 / (cpu_s * scale * args.inference_steps), 8), unit="volumes/s", cores=best, kind="reference" if gen is not None else "port",
                    host_cores=cores, seconds_per_step=round(cpu_s * scale, 3), step_seconds=[round(v, 2) for v in times],
                    thread_sweep_seconds_at_half_edge=sweep,
-                   sample=f"median of {len(times)} DDIM steps (UNet forward + scheduler step, fp32, torch-CPU oracle, t = 980/500/20) at 1x1x{size}^3 on "
+                   sample=f"median of {len(times)} DDIM steps (UNet forward + scheduler step, fp32, " + ("the unmodified reference modules" if gen is not None else "torch-CPU oracle") + f", t = 980/500/20) at 1x1x{size}^3 on "
                           f"{best} threads (best of a sweep over {sorted(sweep)} at 1x1x{half}^3)"
                           + ("" if size == args.size else f", scaled x{scale:.0f} to {args.size}^3 by voxel count") + f", x{args.inference_steps} steps",
-                   port_note="kind=port: oracle/restatement.py, the reference algorithm restated on torch-CPU (the GPU box has no /root/reference); "
+                   port_note="kind=reference: generative.networks.nets.DiffusionModelUNet + DDIMScheduler.step of the unmodified reference tree" if gen is not None else
+                             "kind=port: oracle/restatement.py, the reference algorithm restated on torch-CPU (the GPU box has no /root/reference); "
                              "in the build container (8 cores) it runs the C2 forward at 1x1x64^3 in 1.09x the time of the unmodified reference module, "
                              "bit-equal output (tools/oracle_vs_reference_time.py, profiles/r02_oracle_vs_reference_time.json)")
         if eps500 is not None and size == args.size and eps_gpu is not None and args.dtype == "bf16":
@@ -260,7 +330,7 @@ def main() -> None:
             "unet_forward_ms": None if fwd_ms is None else round(fwd_ms, 3),
             "ms_per_ddim_iteration": round(1e3 * elapsed / args.steps / args.inference_steps, 3),
             "output_finite": finite,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "package_power_w": power_stats, "cpu_baseline": cpu,
             "speedup_vs_cpu": None if cpu is None else round(vol_s / cpu["value"], 1),
             "kernel_breakdown_ms": {k: dict(launches=v["launches"], ms=round(v["ms"], 3),
                                             tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))

@@ -61,11 +61,12 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors[:2]
+        saved = ctx.saved_tensors  # (read ONCE: under torch.utils.checkpoint every access re-triggers the unpack hooks)
+        x, weight = saved[:2]
         kernel, stride, padding, pad_hi = ctx.geom
         gy = gy.contiguous()
         if ctx.post_act != "none":
-            gy = ops.act_backward(ctx.saved_tensors[2], gy, ctx.post_act)
+            gy = ops.act_backward(saved[2], gy, ctx.post_act)
         nsp = x.dim() - 2
         k, s, p = _tup(kernel, nsp), _tup(stride, nsp), _tup(padding, nsp)
         phi = _tup(pad_hi, nsp) if pad_hi is not None else p
@@ -126,11 +127,12 @@ class _ConvTranspose(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors[:2]
+        saved = ctx.saved_tensors  # (read ONCE: under torch.utils.checkpoint every access re-triggers the unpack hooks)
+        x, weight = saved[:2]
         kernel, stride, padding = ctx.geom
         gy = gy.contiguous()
         if ctx.post_act != "none":
-            gy = ops.act_backward(ctx.saved_tensors[2], gy, ctx.post_act)
+            gy = ops.act_backward(saved[2], gy, ctx.post_act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv(gy, weight, None, kernel=kernel, stride=stride, padding=padding)  # [Cin, Cout, *k] read as a Conv weight

@@ -56,6 +56,17 @@ def wants_grad(module: nn.Module, x: torch.Tensor) -> bool:
     return False
 
 
+def run_stage(fn, x: torch.Tensor, checkpointing: bool) -> torch.Tensor:
+    """A training-forward stage, optionally under activation checkpointing exactly as the reference does it
+    (`torch.utils.checkpoint.checkpoint(stage, x, use_reentrant=False)`, autoencoderkl.py:726-729,780-783, vqvae.py:418-431): the stage's
+    autograd.Functions save nothing across the step; its forward is re-run (the same kernels, the same bits) when backward reaches it."""
+    if checkpointing:
+        import torch.utils.checkpoint as cp
+
+        return cp.checkpoint(fn, x, use_reentrant=False)
+    return fn(x)
+
+
 def zero_module(module: nn.Module) -> nn.Module:
     for p in module.parameters():
         p.detach().zero_()

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ._blocks import AttentionBlock, ConvP, ResnetBlock, SPADEResnetBlock, ensure_tuple_rep, gn_prologue, wants_grad
+from ._blocks import AttentionBlock, ConvP, ResnetBlock, SPADEResnetBlock, ensure_tuple_rep, gn_prologue, run_stage, wants_grad
 
 __all__ = ["AutoencoderKL"]
 
@@ -190,7 +190,7 @@ class AutoencoderKL(nn.Module):
         self.quant_conv_log_sigma = ConvP(spatial_dims, latent_channels, latent_channels, 1, 1, 0)
         self.post_quant_conv = ConvP(spatial_dims, latent_channels, latent_channels, 1, 1, 0)
         self.latent_channels = latent_channels
-        self.use_checkpointing = use_checkpointing  # accepted for API parity (the training path below saves what its backward kernels read)
+        self.use_checkpointing = use_checkpointing  # training path: encoder / decoder stages under torch.utils.checkpoint, as the reference (_blocks.run_stage)
 
     def _dtype(self):
         return self.post_quant_conv.conv.weight.dtype
@@ -213,7 +213,7 @@ class AutoencoderKL(nn.Module):
         if wants_grad(self, x):  # a training step: differentiable (z_mu, z_sigma), native kernels in both directions
             from ... import autograd as A
 
-            h = self.encoder.run_train(A.to_arena(x))
+            h = run_stage(self.encoder.run_train, A.to_arena(x), self.use_checkpointing)
             mu_c, ls_c = self.quant_conv_mu.conv, self.quant_conv_log_sigma.conv
             z_mu = A.from_arena(A.conv(h, mu_c.weight, mu_c.bias, kernel=1))
             return z_mu, A.sigma_from_log_var(A.from_arena(A.conv(h, ls_c.weight, ls_c.bias, kernel=1)))
@@ -243,7 +243,7 @@ class AutoencoderKL(nn.Module):
             from ... import autograd as A
 
             pq = self.post_quant_conv.conv
-            return A.from_arena(self.decoder.run_train(A.conv(A.to_arena(z.contiguous()), pq.weight, pq.bias, kernel=1)))
+            return A.from_arena(run_stage(self.decoder.run_train, A.conv(A.to_arena(z.contiguous()), pq.weight, pq.bias, kernel=1), self.use_checkpointing))
         with torch.no_grad():
             h = self.post_quant_conv.run(ops.to_channels_last(z))
             return ops.to_channels_first(self.decoder.run(h))

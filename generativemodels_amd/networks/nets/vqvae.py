@@ -10,9 +10,19 @@ import torch.nn as nn
 
 from ... import ops
 from ..layers.vector_quantizer import EMAQuantizer, VectorQuantizer
-from ._blocks import ConvP, ensure_tuple_rep, wants_grad
+from ._blocks import ConvP, ensure_tuple_rep, run_stage, wants_grad
 
 __all__ = ["VQVAE"]
+
+
+class Act:
+    """The spellings of monai.networks.layers.Act this file's signatures use (MONAI's factory attribute returns the registered NAME;
+    names are matched case-insensitively here, as MONAI's get_act_layer does)."""
+
+    RELU = "relu"
+    LEAKYRELU = "leakyrelu"
+    TANH = "tanh"
+    SIGMOID = "sigmoid"
 
 
 def _act_name(act) -> str:
@@ -145,7 +155,7 @@ class VQVAE(nn.Module):
                  downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1), (2, 4, 1, 1)),
                  upsample_parameters=((2, 4, 1, 1, 0), (2, 4, 1, 1, 0), (2, 4, 1, 1, 0)), num_embeddings: int = 32,
                  embedding_dim: int = 64, embedding_init: str = "normal", commitment_cost: float = 0.25, decay: float = 0.5,
-                 epsilon: float = 1e-5, dropout: float = 0.0, act="RELU", output_act=None, ddp_sync: bool = True,
+                 epsilon: float = 1e-5, dropout: float = 0.0, act: tuple | str | None = Act.RELU, output_act: tuple | str | None = None, ddp_sync: bool = True,
                  use_checkpointing: bool = False):
         super().__init__()
         self.in_channels, self.out_channels, self.spatial_dims = in_channels, out_channels, spatial_dims
@@ -212,7 +222,7 @@ class VQVAE(nn.Module):
         if wants_grad(self, images):
             from ... import autograd as A
 
-            return A.from_arena(self.encoder.run_train(A.to_arena(self._train_entry(images))))
+            return A.from_arena(run_stage(self.encoder.run_train, A.to_arena(self._train_entry(images)), self.use_checkpointing))
         images = self._check(images)
         with torch.no_grad():
             return ops.to_channels_first(self.encoder.run(ops.to_channels_last(images)))
@@ -225,7 +235,7 @@ class VQVAE(nn.Module):
         if wants_grad(self, quantizations):
             from ... import autograd as A
 
-            return A.from_arena(self.decoder.run_train(A.to_arena(self._train_entry(quantizations).contiguous())))
+            return A.from_arena(run_stage(self.decoder.run_train, A.to_arena(self._train_entry(quantizations).contiguous()), self.use_checkpointing))
         quantizations = self._check(quantizations)
         with torch.no_grad():
             return ops.to_channels_first(self.decoder.run(ops.to_channels_last(quantizations)))

@@ -310,7 +310,9 @@ def test_c4_latent_unet_parameter_gradients_at_real_dims_match_the_oracle_autogr
     F.mse_loss(y.float(), target.to(DEV).float()).backward()
     for p in model.parameters():
         assert p.grad is None or p.grad.dtype == p.dtype
-    _grad_check(model, ref_grads, 6e-4 if mode == "fp32" else 0.18, f"C4 latent UNet parameter gradients at real dims ({mode})")
+    # bars: fp32 6e-4 of scale; bf16 / mixed 1e-2 of scale (measured worst 6.6e-4 / 1.4e-3, profiles/r03_fullsize_parity_measured.txt -- round 3's
+    # 0.18 would have passed a broken kernel)
+    _grad_check(model, ref_grads, 6e-4 if mode == "fp32" else 1e-2, f"C4 latent UNet parameter gradients at real dims ({mode})")
 
 
 # ---- C5: the KV-cache decode step over a LONG prefix (split-KV single-query attention, K-split small-row GEMMs) ------------------------

@@ -4,6 +4,8 @@ exactly once, from rank-independent noise, and arrives in global order."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -87,7 +89,33 @@ def test_two_rank_sampling_matches_single_process():
         assert torch.equal(a, b)  # same volumes as a single-process run, in global order
 
 
-def _reducer_worker(rank, world, port, q):
+@_retry_once
+@pytest.mark.parametrize("n_units", [13, 5])
+def test_eight_rank_sampling_with_uneven_unit_counts_matches_single_process(n_units):
+    """world_size 8 (the driver's largest run), unit counts that do not divide: 13 volumes -> shards of 2 and 1; 5 volumes -> three ranks
+    sample nothing and still take part in the gather."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_units, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = sorted(len(ids) for ids, _ in results)
+    assert sizes[-1] - sizes[0] <= 1 and sum(sizes) == n_units
+    assert sorted(i for ids, _ in results for i in ids) == list(range(n_units))
+    gathered = next(v for _, v in results if v is not None)
+    _, ref = parallel.sample_units(_fake_sampler, n_units, (1, 1, 4, 4, 4), base_seed=7, rank=0, world_size=1)
+    assert len(gathered) == n_units
+    for a, b in zip(gathered, ref):
+        assert torch.equal(a, b)
+
+
+def _reducer_worker(rank, world, port, q, nrows=8):
     import torch.distributed as dist
     import torch.nn as nn
     from generativemodels_amd.parallel import GradientReducer, shard_range
@@ -101,9 +129,9 @@ def _reducer_worker(rank, world, port, q):
         params = list(model.parameters()) + list(unused.parameters()) + list(late.parameters()) + list(side.parameters())
         red = GradientReducer(params, bucket_mb=0.0005)  # ~500-byte buckets: several exchanges per step
         assert red.active and len(red.buckets) >= 3
-        data = torch.randn(8, 6, generator=torch.Generator().manual_seed(5))
-        target = torch.randn(8, 3, generator=torch.Generator().manual_seed(6))
-        lo, hi = shard_range(8, rank, world)
+        data = torch.randn(nrows, 6, generator=torch.Generator().manual_seed(5))
+        target = torch.randn(nrows, 3, generator=torch.Generator().manual_seed(6))
+        lo, hi = shard_range(nrows, rank, world)
         overlapped = []
 
         def loss_of(step, rows):
@@ -127,9 +155,10 @@ def _reducer_worker(rank, world, port, q):
         # gradient accumulation: two micro-batches, the first under no_sync, equals one backward over both
         mid = (lo + hi) // 2
         red.zero_grad()
+        wa, wb = (mid - lo) / (hi - lo), (hi - mid) / (hi - lo)  # row-weighted halves: their sum is the shard's mean loss
         with red.no_sync():
-            (0.5 * loss_of(5, slice(lo, mid))).backward()
-        (0.5 * loss_of(5, slice(mid, hi))).backward()
+            (wa * loss_of(5, slice(lo, mid))).backward()
+        (wb * loss_of(5, slice(mid, hi))).backward()
         red.finish()
         acc = [None if p.grad is None else p.grad.detach().numpy().copy() for p in params]
         # a second backward outside no_sync is refused
@@ -191,3 +220,48 @@ def test_two_rank_gradient_all_reduce_matches_the_full_batch():
                     assert g is None
                 else:
                     assert g is not None and torch.allclose(torch.from_numpy(g), w, atol=1e-6), (torch.from_numpy(g) - w).abs().max()
+
+
+@_retry_once
+def test_eight_rank_gradient_all_reduce_with_uneven_shards_matches_the_average_of_the_shard_losses():
+    """GradientReducer over gloo at world_size 8 (the driver's largest run) with 20 rows = shards of 3 and 2: every rank ends with the
+    average over ranks of its shard-mean-loss gradient (what DDP computes for uneven shards), the rank-0-only parameter included; the learned
+    unused set, the late joiner and accumulation under no_sync behave as at world_size 2."""
+    import torch.multiprocessing as mp
+    import torch.nn as nn
+    world, nrows = 8, 20
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q, nrows)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(3)
+    model = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 3))
+    unused, late, side = nn.Linear(4, 4), nn.Linear(3, 3), nn.Linear(3, 3)
+    data = torch.randn(nrows, 6, generator=torch.Generator().manual_seed(5))
+    target = torch.randn(nrows, 3, generator=torch.Generator().manual_seed(6))
+    total = 0.0
+    for r in range(world):
+        lo, hi = parallel.shard_range(nrows, r, world)
+        y = late(model(data[lo:hi]))
+        if r == 0:
+            y = y + 0.5 * side(y.detach())
+        total = total + torch.nn.functional.mse_loss(y, target[lo:hi]) / world
+    total.backward()
+    nmodel = len(list(model.parameters()))
+    want = [p.grad for p in model.parameters()] + [None, None] + [p.grad for p in list(late.parameters()) + list(side.parameters())]
+    for rank in range(world):
+        grads, acc, overlapped, nbuckets, refused = got[rank]
+        assert refused and overlapped[1] == nbuckets and overlapped[3] == nbuckets
+        for got_list in (grads, acc):
+            assert got_list[nmodel] is None and got_list[nmodel + 1] is None
+            for g, w in zip(got_list, want):
+                if w is None:
+                    assert g is None
+                else:
+                    assert g is not None and torch.allclose(torch.from_numpy(g), w, atol=1e-6), (rank, (torch.from_numpy(g) - w).abs().max())
