@@ -69,7 +69,8 @@ def _compile(src: str) -> str:
     deps = [srcp, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     if _stale(obj, deps):
         extra = os.environ.get("GM_EXTRA_HIPCC_FLAGS", "").split() + (VARIANTS[_variant] if _variant else [])
-        cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), *extra, "-x", "hip", "-c", srcp, "-o", obj]
+        flags = [f if not f.startswith("--offload-arch=") or _variant != "asan" else f"--offload-arch={ARCH}:xnack+" for f in FLAGS]
+        cmd = [_hipcc(), *flags, *EXTRA_FLAGS.get(src, []), *extra, "-x", "hip", "-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -93,14 +94,17 @@ def build_native(force: bool = False, verbose: bool = False, variant: str | None
             objs = list(ex.map(_compile, SOURCES))
     finally:
         _variant = None
-    return _link(objs, libpath, force, verbose)
+    return _link(objs, libpath, force, verbose, asan=variant == "asan")
 
 
-def _link(objs, LIBPATH, force, verbose) -> str:
+def _link(objs, LIBPATH, force, verbose, asan=False) -> str:
     if force or _stale(LIBPATH, objs):
         rt = hip_runtime_library()
         linker = shutil.which("g++") or shutil.which("c++") or _hipcc()
         cmd = [linker, "-shared", "-fPIC", *objs, "-o", LIBPATH, rt, f"-Wl,-rpath,{os.path.dirname(rt)}", "-Wl,--enable-new-dtags"]
+        if asan:  # the sanitizer runtime comes from LD_PRELOAD in the process that loads this library: leave its symbols undefined
+            cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", *objs, "-o", LIBPATH, rt,
+                   f"-Wl,-rpath,{os.path.dirname(rt)}", "-Wl,--enable-new-dtags"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -6,5 +6,9 @@ VARIANTS = {
     "timeline_ablate": ["-DGM_CONV_TIMELINE", "-DGM_CONV_ABLATE"],
     "eb": ["-DGM_CONV_EARLY_BARRIER"],                       # round 3 A/B: the tap-group barrier one tap earlier (conv_dma.hip)
     "eb_timeline": ["-DGM_CONV_EARLY_BARRIER", "-DGM_CONV_TIMELINE"],
+    # AddressSanitizer build (tools/gpu_asan.sh): device + host code instrumented, kernels for gfx950:xnack+ (run with HSA_XNACK=1,
+    # LD_PRELOAD of libclang_rt.asan-x86_64.so, PYTORCH_NO_CUDA_MEMORY_CACHING=1 so that every tensor is its own hipMalloc with red zones).
+    # The LDS-DMA requests are inline assembly and are NOT instrumented; every compiler-generated global access is.
+    "asan": ["-fsanitize=address", "-shared-libsan", "-g1", "-DGM_ASAN_BUILD"],
     "ebi": ["-DGM_CONV_EARLY_BARRIER", "-DGM_CONV_DMA_INTERLEAVE"],  # ... plus the panel request's DMA instructions spread over a tap's MFMAs
 }

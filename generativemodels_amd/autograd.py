@@ -289,53 +289,72 @@ class _Attention(torch.autograd.Function):
     def backward(ctx, go):
         q, k, v, o = ctx.saved_tensors
         heads, scale = ctx.cfg
-        b, lq, c = q.shape
-        lk = k.shape[1]
-        dh = c // heads
-        # Measured on MI355X (tools/cmp_attention_backward.py): the fused kernels own 64 rows per work-group, so ONE head of a few
-        # thousand tokens leaves most CUs idle (L = 4096, d = 128: 1.9 ms fused vs 0.86 ms composed), while many (sample, head) pairs
-        # favour them (2 x 4 heads of 1024 tokens: 0.21 vs 2.5 ms) and long sequences leave no choice (the composed path stores L x L).
-        # bf16 operands, one or two (sample, head) pairs of >= 512 tokens (C4: one head x 4096 tokens at 16^3, one x 512 at 8^3): the bf16-MFMA score pass
-        # + the weight-gradient / 1x1 kernels (ops.attention_backward_bf16): every product at the bf16 MFMA rate, where the fused kernels
-        # below run fp32 MFMA on 64 work-groups and the fp32 composed path materialises fp32 L x L matrices
-        if (q.dtype == torch.bfloat16 and dh in ops.ATTENTION_BWD_BF16_HEAD_DIMS and b * heads <= 2 and max(lq, lk) >= ATTENTION_BWD_BF16_MIN_TOKENS
-                and 6 * b * heads * (lq + 63) * (lk + 63) <= ops.ATTENTION_BWD_BF16_MAX_BYTES):
-            dq, dk, dv = ops.attention_backward_bf16(q, k, v, o, go.contiguous(), heads, scale)
-            return dq, dk, dv, None, None
-        composed_ok = max(lq, lk) <= ATTENTION_BWD_MAX_TOKENS
-        prefer_composed = composed_ok and b * heads <= 2 and max(lq, lk) >= 2048
-        if dh in ops.ATTENTION_BWD_HEAD_DIMS and not prefer_composed:
-            # fused flash backward: scores recomputed tile by tile, any sequence length
-            dq, dk, dv = ops.attention_backward(q, k, v, o, go.contiguous(), heads, scale)
-            return dq, dk, dv, None, None
-        # other head dims: per (sample, head) in fp32 on the GEMM / weight-gradient kernels (materialises the L x L scores)
-        if max(lq, lk) > ATTENTION_BWD_MAX_TOKENS:
-            raise NotImplementedError(f"attention backward materialises the {lq} x {lk} score matrix per head: sequences above "
-                                      f"{ATTENTION_BWD_MAX_TOKENS} tokens need the fused flash backward (not built yet)")
-        f32 = torch.float32
+        dh = q.shape[2] // heads
         go = go.contiguous()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        if dh in ops.ATTENTION_BWD_HEAD_DIMS:
+            return (*_attention_backward(q, k, v, o, go, heads, scale), None, None)
+        # any other head dim (<= 256: the forward's bound): zero-pad every head to the next width the kernels are built for.  Zero channels add
+        # nothing to q k^T, and v's zero channels give o / dO zero channels: the products are unchanged, the padded gradient channels are dropped.
+        dhp = min(d for d in ops.ATTENTION_BWD_HEAD_DIMS if d >= dh)
 
-        def head(t, bi, hi, rows):  # fp32 contiguous [1, rows, dh] copy of one (sample, head) slice
-            out = torch.empty((1, rows, dh), dtype=f32, device=t.device)
-            ops.copy_channels(t[bi:bi + 1, :, hi * dh:(hi + 1) * dh], out)
+        def pad(t):
+            out = torch.zeros((t.shape[0], t.shape[1], heads * dhp), dtype=t.dtype, device=t.device)
+            for hi in range(heads):
+                ops.copy_channels(t[:, :, hi * dh:(hi + 1) * dh], out[:, :, hi * dhp:hi * dhp + dh])
             return out
 
-        for bi in range(b):
+        def unpad(t):
+            out = torch.empty((t.shape[0], t.shape[1], heads * dh), dtype=t.dtype, device=t.device)
             for hi in range(heads):
-                qf, kf, vf, gf = head(q, bi, hi, lq), head(k, bi, hi, lk), head(v, bi, hi, lk), head(go, bi, hi, lq)
-                s_ = ops.conv(qf, kf[0], None, kernel=1)                                   # [1, lq, lk] = Q K^T
-                p_ = ops.sample_probs(s_[0], 1.0 / scale, None, -1)                        # softmax(scale * S), fp32
-                dvh = ops.conv_wgrad(gf, p_[None], 1, 1, 0)                                # [lk, dh, 1] = P^T dO
-                dp = ops.conv(gf, vf[0], None, kernel=1)                                   # [1, lq, lk] = dO V^T
-                ds = ops.softmax_bwd(p_, dp[0], scale)                                     # [lq, lk]
-                dqh = ops.conv(ds[None], kf[0], None, kernel=1, transposed=True)           # [1, lq, dh] = dS K
-                dkh = ops.conv_wgrad(qf, ds[None], 1, 1, 0)                                # [lk, dh, 1] = dS^T Q
-                sl = slice(hi * dh, (hi + 1) * dh)
-                ops.copy_channels(dqh, dq[bi:bi + 1, :, sl])
-                ops.copy_channels(dkh.reshape(1, lk, dh), dk[bi:bi + 1, :, sl])
-                ops.copy_channels(dvh.reshape(1, lk, dh), dv[bi:bi + 1, :, sl])
-        return dq, dk, dv, None, None
+                ops.copy_channels(t[:, :, hi * dhp:hi * dhp + dh], out[:, :, hi * dh:(hi + 1) * dh])
+            return out
+
+        dq, dk, dv = _attention_backward(pad(q), pad(k), pad(v), pad(o), pad(go), heads, scale)
+        return unpad(dq), unpad(dk), unpad(dv), None, None
+
+
+def _attention_backward(q, k, v, o, go, heads, scale):
+    """(dq, dk, dv) for a head dim in ops.ATTENTION_BWD_HEAD_DIMS: which kernels, measured on MI355X (tools/cmp_attention_backward.py,
+    profiles/r03_attention_backward_paths.txt).  Every branch handles any sequence length: nothing raises for size."""
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    dh = c // heads
+    long_seq = max(lq, lk) > ATTENTION_BWD_MAX_TOKENS
+    # bf16 operands on the bf16-MFMA score pass + the weight-gradient kernel (ops.attention_backward_bf16: every product at the bf16 MFMA rate;
+    # P, dS, dS^T of the (sample, head) pairs in flight live in HBM, one pair at a time when all of them would not fit): one or two pairs of
+    # >= 512 tokens (C4: one head x 4096 tokens at 16^3, one x 512 at 8^3) -- and ANY number of pairs above 8 192 tokens, where the fused fp32
+    # kernels below run at 45 TFLOP/s (84.6 ms per head at 32 768 x 256 against 16-17 ms here)
+    if (q.dtype == torch.bfloat16 and dh in ops.ATTENTION_BWD_BF16_HEAD_DIMS and max(lq, lk) >= ATTENTION_BWD_BF16_MIN_TOKENS
+            and (b * heads <= 2 or long_seq) and 6 * (lq + 63) * (lk + 63) <= ops.ATTENTION_BWD_BF16_MAX_BYTES):
+        return ops.attention_backward_bf16(q, k, v, o, go, heads, scale)
+    # fp32 (or bf16 below the bounds above): the fused kernels own 64 rows per work-group, so ONE head of a few thousand tokens leaves most CUs
+    # idle (L = 4096, d = 128: 1.9 ms fused vs 0.86 ms composed) while many (sample, head) pairs favour them (2 x 4 heads of 1024 tokens: 0.21 vs
+    # 2.5 ms); the composed path materialises fp32 L x L matrices, so long sequences always take the fused flash kernels
+    if long_seq or not (b * heads <= 2 and max(lq, lk) >= 2048):
+        return ops.attention_backward(q, k, v, o, go, heads, scale)  # fused flash backward: scores recomputed tile by tile, any sequence length
+    f32 = torch.float32
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+
+    def head(t, bi, hi, rows):  # fp32 contiguous [1, rows, dh] copy of one (sample, head) slice
+        out = torch.empty((1, rows, dh), dtype=f32, device=t.device)
+        ops.copy_channels(t[bi:bi + 1, :, hi * dh:(hi + 1) * dh], out)
+        return out
+
+    for bi in range(b):
+        for hi in range(heads):
+            qf, kf, vf, gf = head(q, bi, hi, lq), head(k, bi, hi, lk), head(v, bi, hi, lk), head(go, bi, hi, lq)
+            s_ = ops.conv(qf, kf[0], None, kernel=1)                                   # [1, lq, lk] = Q K^T
+            p_ = ops.sample_probs(s_[0], 1.0 / scale, None, -1)                        # softmax(scale * S), fp32
+            dvh = ops.conv_wgrad(gf, p_[None], 1, 1, 0)                                # [lk, dh, 1] = P^T dO
+            dp = ops.conv(gf, vf[0], None, kernel=1)                                   # [1, lq, lk] = dO V^T
+            ds = ops.softmax_bwd(p_, dp[0], scale)                                     # [lq, lk]
+            dqh = ops.conv(ds[None], kf[0], None, kernel=1, transposed=True)           # [1, lq, dh] = dS K
+            dkh = ops.conv_wgrad(qf, ds[None], 1, 1, 0)                                # [lk, dh, 1] = dS^T Q
+            sl = slice(hi * dh, (hi + 1) * dh)
+            ops.copy_channels(dqh, dq[bi:bi + 1, :, sl])
+            ops.copy_channels(dkh.reshape(1, lk, dh), dk[bi:bi + 1, :, sl])
+            ops.copy_channels(dvh.reshape(1, lk, dh), dv[bi:bi + 1, :, sl])
+    return dq, dk, dv
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> torch.Tensor:

@@ -1527,33 +1527,52 @@ def attention_backward_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o
         raise ValueError("attention_backward operand shapes are inconsistent")
     q, k, v, o, go = (t.contiguous() for t in (q, k, v, o, go))
     lkp, lqp = (lk + 63) // 64 * 64, (lq + 63) // 64 * 64
-    if b * heads * (2 * lq * lkp + lkp * lqp) * 2 > ATTENTION_BWD_BF16_MAX_BYTES:
-        raise ValueError("attention_backward_bf16: the score matrices of this call exceed ATTENTION_BWD_BF16_MAX_BYTES")
-    probs = torch.empty((b * heads, lq, lkp), dtype=torch.bfloat16, device=q.device)
+    pair_bytes = (2 * lq * lkp + lkp * lqp) * 2  # P, dS [Lq][Lk] and dS^T [Lk][Lq] of ONE (sample, head) pair
+    if pair_bytes > ATTENTION_BWD_BF16_MAX_BYTES:
+        raise ValueError("attention_backward_bf16: the score matrices of one (sample, head) pair exceed ATTENTION_BWD_BF16_MAX_BYTES")
+    # (sample, head) pairs per score pass: all of them when their matrices fit the scratch bound, else one at a time through ONE set of buffers
+    # (round 4: any batch x heads at any length -- 8 heads of 32 768 tokens re-use 6.4 GB instead of asking for 51 GB)
+    whole = b * heads * pair_bytes <= ATTENTION_BWD_BF16_MAX_BYTES
+    npairs = b * heads if whole else 1
+    probs = torch.empty((npairs, lq, lkp), dtype=torch.bfloat16, device=q.device)
     dscores = torch.empty_like(probs)
-    dscores_t = torch.empty((b * heads, lkp, lqp), dtype=torch.bfloat16, device=q.device)
-    d = GmAttnBwdDesc()
-    for name, t in (("q", q), ("k", k), ("v", v), ("o", o), ("go", go)):
-        setattr(d, name, t.data_ptr())
-        setattr(d, name + "_ld", _kv_ld(t))
-    d.B, d.H, d.Lq, d.Lk, d.dh = b, heads, lq, lk, dh
-    d.scale, d.dtype = float(scale), dt_code(q.dtype)
-    nbytes = lib().gm_attention_bwd_scores_workspace_bytes(C.byref(d))
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
-    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
-    _timed("attention_bwd_scores<bfloat16>", dict(flops=6.0 * b * heads * lq * lk * dh, bytes=float(6 * b * heads * lq * lkp), shape=f"B{b} H{heads} L{lq}x{lk} d{dh}"),
-           lambda: check(lib().gm_attention_bwd_scores(C.byref(d), probs.data_ptr(), dscores.data_ptr(), lkp, dscores_t.data_ptr(), lqp, _stream()),
-                         "gm_attention_bwd_scores"))
+    dscores_t = torch.empty((npairs, lkp, lqp), dtype=torch.bfloat16, device=q.device)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    for bi in range(b):
-        for hi in range(heads):
-            i, sl = bi * heads + hi, slice(hi * dh, (hi + 1) * dh)
-            dvh = conv_wgrad(go[bi:bi + 1, :, sl], probs[i:i + 1, :, :lk], 1, 1, 0)                # [lk, dh, 1] fp32 = P^T dO
-            dkh = conv_wgrad(q[bi:bi + 1, :, sl], dscores[i:i + 1, :, :lk], 1, 1, 0)               # [lk, dh, 1] fp32 = dS^T Q
-            dqh = conv_wgrad(k[bi:bi + 1, :, sl], dscores_t[i:i + 1, :lk, :lq], 1, 1, 0)           # [lq, dh, 1] fp32 = dS K (rows = keys)
-            copy_channels(dqh.reshape(1, lq, dh), dq[bi:bi + 1, :, sl])
-            copy_channels(dkh.reshape(1, lk, dh), dk[bi:bi + 1, :, sl])
-            copy_channels(dvh.reshape(1, lk, dh), dv[bi:bi + 1, :, sl])
+    es = q.element_size()
+
+    def score_pass(bi0, nb, hi0, nh):
+        d = GmAttnBwdDesc()
+        for name, t in (("q", q), ("k", k), ("v", v), ("o", o), ("go", go)):
+            setattr(d, name, t.data_ptr() + (bi0 * t.shape[1] * t.shape[2] + hi0 * dh) * es)
+            setattr(d, name + "_ld", _kv_ld(t))
+        d.B, d.H, d.Lq, d.Lk, d.dh = nb, nh, lq, lk, dh
+        d.scale, d.dtype = float(scale), dt_code(q.dtype)
+        nbytes = lib().gm_attention_bwd_scores_workspace_bytes(C.byref(d))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+        _timed("attention_bwd_scores<bfloat16>", dict(flops=6.0 * nb * nh * lq * lk * dh, bytes=float(6 * nb * nh * lq * lkp), shape=f"B{nb} H{nh} L{lq}x{lk} d{dh}"),
+               lambda: check(lib().gm_attention_bwd_scores(C.byref(d), probs.data_ptr(), dscores.data_ptr(), lkp, dscores_t.data_ptr(), lqp, _stream()),
+                             "gm_attention_bwd_scores"))
+
+    def contractions(bi, hi, i):
+        sl = slice(hi * dh, (hi + 1) * dh)
+        dvh = conv_wgrad(go[bi:bi + 1, :, sl], probs[i:i + 1, :, :lk], 1, 1, 0)                # [lk, dh, 1] fp32 = P^T dO
+        dkh = conv_wgrad(q[bi:bi + 1, :, sl], dscores[i:i + 1, :, :lk], 1, 1, 0)               # [lk, dh, 1] fp32 = dS^T Q
+        dqh = conv_wgrad(k[bi:bi + 1, :, sl], dscores_t[i:i + 1, :lk, :lq], 1, 1, 0)           # [lq, dh, 1] fp32 = dS K (rows = keys)
+        copy_channels(dqh.reshape(1, lq, dh), dq[bi:bi + 1, :, sl])
+        copy_channels(dkh.reshape(1, lk, dh), dk[bi:bi + 1, :, sl])
+        copy_channels(dvh.reshape(1, lk, dh), dv[bi:bi + 1, :, sl])
+
+    if whole:
+        score_pass(0, b, 0, heads)
+        for bi in range(b):
+            for hi in range(heads):
+                contractions(bi, hi, bi * heads + hi)
+    else:
+        for bi in range(b):
+            for hi in range(heads):
+                score_pass(bi, 1, hi, 1)
+                contractions(bi, hi, 0)
     return dq, dk, dv
 
 

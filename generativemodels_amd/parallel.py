@@ -176,13 +176,19 @@ class GradientReducer:
 
             me = weakref.ref(self)
 
-            def hook(p, me=me):  # (holds no strong reference to the reducer: a dropped reducer's hooks become no-ops until close() removes them)
-                r = me()
-                if r is not None and not r._closed:
-                    r._on_grad(p)
+            def make_hook(j, i, view, me=me):
+                # one closure per parameter with its slots captured (round 4: the hook body is the reducer's whole host cost inside a host-bound
+                # backward -- 320 calls per C4 step; id() / dict lookups and two data_ptr() calls per call were 2/3 of it).  Holds no strong
+                # reference to the reducer: a dropped reducer's hooks become no-ops until close() removes them
+                def hook(p):
+                    r = me()
+                    if r is not None and not r._closed:
+                        r._on_grad(p, j, i, view)
+                return hook
 
-            for p in self.params:
-                self._hook_handles.append(p.register_post_accumulate_grad_hook(hook))
+            self._slots = [(j, p, self._view[id(p)]) for j, p in enumerate(self.params)]
+            for j, p in enumerate(self.params):
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(make_hook(j, self._bucket_of[id(p)], self._view[id(p)])))
                 if p.dtype == torch.float32:  # fp32 master parameters (mixed precision): the weight-gradient kernels write fp32
                     _DIRECT_GRAD[id(p)] = (weakref.ref(p), self._view[id(p)].data_ptr(), me)
                     self._direct_ids.append(id(p))
@@ -265,21 +271,24 @@ class GradientReducer:
         self._side.wait_event(torch.cuda.current_stream(dev).record_event())
         return torch.cuda.stream(self._side)
 
-    def _adopt(self, p) -> None:
+    def _adopt(self, p, view=None) -> None:
         """Make p.grad the bucket view (copying a gradient tensor autograd allocated itself into it first)."""
-        view = self._view[id(p)]
+        if view is None:
+            view = self._view[id(p)]
         g = p.grad
-        if g is None or g.data_ptr() == view.data_ptr():
+        if g is None or g is view or g.data_ptr() == view.data_ptr():  # (`is`: the common case after zero_grad() -- no data_ptr() call)
             return
         with torch.no_grad():
             view.copy_(g)
         p.grad = view
 
-    def _on_grad(self, p) -> None:
+    def _on_grad(self, p, j=None, i=None, view=None) -> None:
         """The engine's post-accumulate hook: fires once per parameter and backward pass, after every use of the parameter in the graph has
         delivered its gradient -- also when the backward kernels accumulated in place and handed autograd None (torch >= 2.10 runs the
         AccumulateGrad node with an undefined gradient)."""
-        j = self._index[id(p)]
+        if j is None:
+            j = self._index[id(p)]
+            i, view = self._bucket_of[id(p)], self._view[id(p)]
         if not self._expected[j]:
             # first gradient of a parameter that had none so far: it is not part of its bucket's exchange this step (the bucket may be
             # in flight already); finish() exchanges it on its own once every rank knows, and it is expected from then on
@@ -288,10 +297,9 @@ class GradientReducer:
             p.grad = None
             self._seen[j] = True
             return
-        self._adopt(p)
+        self._adopt(p, view)
         if not self._sync:
             return
-        i = self._bucket_of[id(p)]
         if self._seen[j] or self._work[i] is not None:
             raise RuntimeError("GradientReducer: a second backward pass reached a parameter before finish(); accumulate gradients under "
                                "`with reducer.no_sync():` and run only the last backward outside it")
@@ -318,15 +326,18 @@ class GradientReducer:
         dist = self._dist
         # gradients that arrived under no_sync (or replaced views) are adopted now; stale regions of expected parameters that produced
         # nothing this step (and whose .grad the optimizer set to None) are cleared so they contribute zeros
-        for j, p in enumerate(self.params):
-            if not self._expected[j]:
+        expected, seen = self._expected, self._seen
+        for j, p, view in self._slots:
+            if not expected[j]:
                 continue
-            if p.grad is None:
-                if not self._seen[j]:
-                    self._view[id(p)].zero_()
+            g = p.grad
+            if g is None:
+                if not seen[j]:
+                    view.zero_()
             else:
-                self._adopt(p)
-                self._seen[j] = True
+                if g is not view:
+                    self._adopt(p, view)
+                seen[j] = True
         while self._next < len(self.buckets):
             self._launch(self._next)
             self._next += 1
@@ -368,9 +379,10 @@ class GradientReducer:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                 view.div_(self.world)
                 self._expected[j] = True
-        for j, p in enumerate(self.params):
-            if self._expected[j] and (used[j] or p.grad is not None):
-                p.grad = self._view[id(p)]  # also where this rank had no gradient: replicas apply the same update
+        expected = self._expected  # (re-read: the first step replaces the list)
+        for j, p, view in self._slots:
+            if expected[j] and p.grad is not view and (used[j] or p.grad is not None):
+                p.grad = view  # also where this rank had no gradient: replicas apply the same update
         self._learned = True
         self.launched_in_backward = self._in_backward_launches
         self.reset()
