@@ -96,6 +96,7 @@ PROTOTYPES = {
     "gm_aekl_sample": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, c_vp]),
     "gm_addcmul": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, C.c_int, c_vp]),
     "gm_scale": (C.c_int, [c_vp, c_vp, C.c_float, C.c_int, c_ll, C.c_int, c_vp]),
+    "gm_activation": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, c_ll, C.c_int, c_vp]),
     "gm_gn_workspace_bytes": (c_ll, [C.c_int, c_ll, C.c_int, C.c_int, C.c_int]),
     "gm_gn_scale_shift": (C.c_int, [c_vp, c_ll, C.c_int, c_ll, C.c_int, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_vp, c_vp, C.c_int, c_vp]),

@@ -273,6 +273,24 @@ def upsample_conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     return _UpsampleConv.apply(x, weight, bias)
 
 
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return ops.activation(x, act)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return ops.activation(x, ctx.act, gy.contiguous()), None
+
+
+def activation(x: torch.Tensor, act: str) -> torch.Tensor:
+    """Stand-alone activation (any of ops.POST_ACT) with its backward from the pre-activation (gm_activation)."""
+    return x if act == "none" else _Activation.apply(x, act)
+
+
 ATTENTION_BWD_MAX_TOKENS = 8192
 ATTENTION_BWD_BF16_MIN_TOKENS = int(__import__("os").environ.get("GM_ATTN_BWD_BF16_MIN_TOKENS", "512"))  # (bench switch: a huge value disables the path)
 

@@ -686,6 +686,55 @@ extern "C" int gm_scale(const void* x, void* out, float s, int mode, long long t
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// A stand-alone activation over a contiguous tensor, and its backward from the PRE-activation: the training forward of layers whose
+// activation cannot ride in a convolution epilogue -- MONAI's Convolution(adn_ordering="DA") puts a dropout BETWEEN the convolution and the
+// activation (VQVAE with dropout > 0: vqvae.py:61-80,127-150), and tanh / sigmoid / SiLU / GELU derivatives need z, which the fused
+// epilogue does not keep.  Codes = the epilogue's (GmConvDesc.post_act): 1 ReLU, 2 tanh, 3 sigmoid, 4 SiLU, 5 LeakyReLU(0.01), 6 GELU (erf).
+//   mode 0: out = act(x);  mode 1: out = g * act'(x)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_fwd_code(float z, int act) {
+  switch (act) {
+    case 1: return fmaxf(z, 0.f);
+    case 2: return tanhf(z);
+    case 3: return 1.0f / (1.0f + expf(-z));
+    case 4: return z / (1.0f + expf(-z));
+    case 5: return z > 0.f ? z : 0.01f * z;
+    case 6: return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));
+    default: return z;
+  }
+}
+__device__ __forceinline__ float act_grad_code(float z, int act) {
+  switch (act) {
+    case 1: return z > 0.f ? 1.f : 0.f;
+    case 2: { const float t = tanhf(z); return 1.0f - t * t; }
+    case 3: { const float s = 1.0f / (1.0f + expf(-z)); return s * (1.0f - s); }
+    case 4: { const float s = 1.0f / (1.0f + expf(-z)); return s * (1.0f + z * (1.0f - s)); }
+    case 5: return z > 0.f ? 1.f : 0.01f;
+    case 6: return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+    default: return 1.f;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void activation_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ out, int act, int mode, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const float z = ElemIO<T>::ld(x + i);
+    ElemIO<T>::st(out + i, mode == 0 ? act_fwd_code(z, act) : ElemIO<T>::ld(g + i) * act_grad_code(z, act));
+  }
+}
+
+extern "C" int gm_activation(const void* x, const void* g, void* out, int act, int mode, long long total, int dtype, void* stream) {
+  GM_REQUIRE(x && out, "null pointer");
+  GM_REQUIRE(mode == 0 || (mode == 1 && g), "mode must be 0 (forward) or 1 (backward: needs the upstream gradient)");
+  GM_REQUIRE(act >= 0 && act <= 6, "unknown activation code");
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GM_F32) activation_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (const float*)g, (float*)out, act, mode, total);
+  else if (dtype == GM_BF16) activation_kernel<bf16_raw><<<ew_grid(total), 256, 0, st>>>((const bf16_raw*)x, (const bf16_raw*)g, (bf16_raw*)out, act, mode, total);
+  else GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // F.interpolate(x, size, mode="nearest") on an arena tensor (N, D, H, W, C): the ControlNet latent inferers resize the conditioning
 // image to the latent grid (reference: inferers/inferer.py:926-927, 989-990, 1096-1097).  Source index = min(floor(dst * (in/out)),
 // in - 1) with the scale evaluated in fp32, exactly torch's nearest_neighbor_compute_source_index.

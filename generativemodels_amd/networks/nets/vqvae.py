@@ -43,9 +43,10 @@ class _ConvAct(nn.Module):
     """MONAI Convolution with adn_ordering="DA" (dropout, activation; the default instance norm is constructed by MONAI but
     never inserted): parameters under `conv.*` (reference vqvae.py:127-163,220-260)."""
 
-    def __init__(self, spatial_dims, cin, cout, kernel, stride, padding, dilation=1, act="none", transposed=False, output_padding=0):
+    def __init__(self, spatial_dims, cin, cout, kernel, stride, padding, dilation=1, act="none", transposed=False, output_padding=0, dropout=0.0):
         super().__init__()
         self.spatial_dims = spatial_dims
+        self.dropout = float(dropout or 0.0)
         self.kernel, self.stride, self.padding, self.dilation = kernel, stride, padding, dilation
         self.transposed, self.output_padding, self.act = transposed, output_padding, act
         holder = ConvP(spatial_dims, cin, cout, kernel, stride, padding, dilation, transposed, output_padding)
@@ -60,18 +61,31 @@ class _ConvAct(nn.Module):
         """The same layer with gradients (generativemodels_amd.autograd): convolution / transposed convolution with the activation in its epilogue."""
         from ... import autograd as A
 
-        _trainable_act(self.act)
         if self.dilation != 1:
             raise NotImplementedError("VQVAE training: dilated down- / up-sampling convolutions have no weight-gradient kernel")
+        fused = _fused_epilogue_trains(self.act, self.dropout, self.training)
+        post = self.act if fused else "none"
         if self.transposed:
-            return A.conv_transpose(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding,
-                                    output_padding=self.output_padding, post_act=self.act)
-        return A.conv(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding, post_act=self.act)
+            z = A.conv_transpose(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding,
+                                 output_padding=self.output_padding, post_act=post)
+        else:
+            z = A.conv(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding, post_act=post)
+        return z if fused else _dropout_act(z, self.dropout, self.training, self.act)
 
 
-def _trainable_act(act: str) -> None:
-    if act not in ("none", "relu"):
-        raise NotImplementedError(f"VQVAE training covers act / output_act in (None, 'RELU'): '{act}' has no backward kernel")
+def _fused_epilogue_trains(act: str, dropout: float, training: bool) -> bool:
+    """The activation can ride in the convolution's epilogue during training when nothing sits between the two (MONAI's ADN ordering "DA" puts
+    the dropout there: vqvae.py:61-80,127-150) and its derivative is a function of the output's sign (the epilogue keeps only the output)."""
+    return act in ("none", "relu") and not (training and dropout > 0.0)
+
+
+def _dropout_act(z, dropout: float, training: bool, act: str):
+    """Dropout (torch's op: the draw must be torch's) then the activation with its backward from the pre-activation (gm_activation)."""
+    from ... import autograd as A
+
+    if training and dropout > 0.0:
+        z = torch.nn.functional.dropout(z, dropout, True)
+    return A.activation(z, act)
 
 
 class VQVAEResidualUnit(nn.Module):
@@ -80,6 +94,7 @@ class VQVAEResidualUnit(nn.Module):
     def __init__(self, spatial_dims, num_channels, num_res_channels, act="relu", dropout=0.0) -> None:
         super().__init__()
         self.act = act
+        self.dropout = float(dropout or 0.0)
         self.conv1 = ConvP(spatial_dims, num_channels, num_res_channels, 3, 1, 1)
         self.conv2 = ConvP(spatial_dims, num_res_channels, num_channels, 3, 1, 1)
 
@@ -89,9 +104,11 @@ class VQVAEResidualUnit(nn.Module):
     def run_train(self, x):
         from ... import autograd as A
 
-        _trainable_act(self.act)
         c1, c2 = self.conv1.conv, self.conv2.conv
-        h = A.conv(x, c1.weight, c1.bias, kernel=3, stride=1, padding=1, post_act=self.act)
+        fused = _fused_epilogue_trains(self.act, self.dropout, self.training)
+        h = A.conv(x, c1.weight, c1.bias, kernel=3, stride=1, padding=1, post_act=self.act if fused else "none")
+        if not fused:
+            h = _dropout_act(h, self.dropout, self.training, self.act)
         return A.conv(h, c2.weight, c2.bias, kernel=3, stride=1, padding=1, res=x, post_act="relu")
 
 
@@ -102,7 +119,7 @@ class Encoder(nn.Module):
         blocks: list[nn.Module] = []
         for i, c in enumerate(num_channels):
             s, k, d, p = downsample_parameters[i]
-            blocks.append(_ConvAct(spatial_dims, in_channels if i == 0 else num_channels[i - 1], c, k, s, p, d, act))
+            blocks.append(_ConvAct(spatial_dims, in_channels if i == 0 else num_channels[i - 1], c, k, s, p, d, act, dropout=0.0 if i == 0 else dropout))
             blocks += [VQVAEResidualUnit(spatial_dims, c, num_res_channels[i], act, dropout) for _ in range(num_res_layers)]
         blocks.append(_ConvAct(spatial_dims, num_channels[-1], out_channels, 3, 1, 1))
         self.blocks = nn.ModuleList(blocks)
@@ -130,7 +147,7 @@ class Decoder(nn.Module):
             s, k, d, p, op = upsample_parameters[i]
             last = i == n - 1
             blocks.append(_ConvAct(spatial_dims, rc[i], out_channels if last else rc[i + 1], k, s, p, d,
-                                   (output_act or "none") if last else act, transposed=True, output_padding=op))
+                                   (output_act or "none") if last else act, transposed=True, output_padding=op, dropout=0.0 if last else dropout))
         self.blocks = nn.ModuleList(blocks)
 
     def run(self, x):
@@ -148,7 +165,8 @@ class VQVAE(nn.Module):
     """Drop-in for generative.networks.nets.VQVAE (same arguments, state_dict keys and methods).  In train() mode with gradients enabled
     `encode` / `decode` / `forward` are differentiable (native kernels in both directions; the quantiser performs the EMA codebook update and
     passes the gradient straight through, vector_quantizer.py:161-188): the VQ-VAE training loop of the reference's tutorials
-    (engines/trainer.py:258-270) runs unchanged.  Covered: act / output_act in (None, "RELU"), dropout = 0, undilated resampling convolutions."""
+    (engines/trainer.py:258-270) runs unchanged -- any activation of the fused epilogue (ReLU, LeakyReLU, tanh, sigmoid, SiLU, GELU) and dropout > 0
+    (torch's dropout op between convolution and activation, MONAI's "DA" ordering); not covered: dilated resampling convolutions."""
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, num_channels: Sequence[int] | int = (96, 96, 192),
                  num_res_layers: int = 3, num_res_channels: Sequence[int] | int = (96, 96, 192),

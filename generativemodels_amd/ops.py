@@ -1885,6 +1885,21 @@ def scale(x: torch.Tensor, s: float, divide: bool = False) -> torch.Tensor:
     return out
 
 
+def activation(x: torch.Tensor, act: str, gy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x) (gy None) or gy * act'(x) element-wise for an activation of POST_ACT: the stand-alone form of a convolution's epilogue activation
+    (training forward of layers with a dropout between convolution and activation; derivatives that need the pre-activation)."""
+    require_device(x, gy)
+    x = x.contiguous()
+    if gy is not None:
+        if gy.shape != x.shape or gy.dtype != x.dtype:
+            raise ValueError("activation: gy must match x")
+        gy = gy.contiguous()
+    out = torch.empty_like(x)
+    check(lib().gm_activation(x.data_ptr(), _ptr(gy), out.data_ptr(), POST_ACT[act], 0 if gy is None else 1, x.numel(), dt_code(x.dtype), _stream()),
+          "gm_activation")
+    return out
+
+
 def concat_dim1(parts: Sequence[torch.Tensor]) -> torch.Tensor:
     """torch.cat(parts, dim=1) for contiguous NC[D]HW tensors (inferers/inferer.py:72,127 "concat" conditioning)."""
     require_device(*parts)

@@ -107,6 +107,11 @@ int gm_addcmul(const void* a, const void* b, const void* c, void* out, long long
 /* out = x*s (mode 0) or x/s (mode 1): latent scale factor of LatentDiffusionInferer (inferers/inferer.py:386,472) */
 int gm_scale(const void* x, void* out, float s, int mode, long long total, int dtype, void* stream);
 
+/* Stand-alone activation over a contiguous tensor (codes = GmConvDesc.post_act) and its backward from the pre-activation: mode 0 out = act(x),
+ * mode 1 out = g * act'(x).  The training forward of MONAI Convolution(adn_ordering="DA") layers with a dropout between convolution and
+ * activation, and of activations whose derivative needs z (vqvae.py:61-80,127-150; monai Convolution / ADN). */
+int gm_activation(const void* x, const void* g, void* out, int act, int mode, long long total, int dtype, void* stream);
+
 /* ---- GroupNorm / LayerNorm (diffusion_model_unet.py:623,643,275,377,1854; autoencoderkl.py:146,156,227,433,579) ------
  * gm_gn_scale_shift reads x once and emits fp32 scale[n][c] = rstd*gamma, shift[n][c] = beta - mean*rstd*gamma that the
  * consumer convolution applies in its prologue (no normalised tensor is ever written). */
