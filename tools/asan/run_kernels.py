@@ -1,0 +1,270 @@
+"""AddressSanitizer pass over the C-ABI kernels WITHOUT torch (tools/gpu_asan.sh): numpy + ctypes + the system HIP runtime.
+
+Why not the pytest suite: the sanitizer's host runtime intercepts hsa_amd_memory_pool_allocate, and with the HIP / HSA runtimes bundled in the
+PyTorch wheel that interceptor fails every device allocation ("AddressSanitizer: out of memory" at `import torch`); with /opt/rocm's runtime it
+works (tools/asan/oob_probe.hip).  So this driver loads lib/libgmamd_asan.so linked against /opt/rocm/lib/libamdhip64.so and calls the kernels
+through the same ctypes prototypes the product uses (generativemodels_amd/_native.py -- importable without torch), on RAGGED shapes: extents
+that are not multiples of any tile, channel counts at the vector width, single rows.  Every device buffer is its own hipMalloc, so the
+sanitizer's red zones sit directly behind each operand; an out-of-bounds access aborts the process with
+"Hostcall: no handler found for service ID 4" (this image's HIP runtime cannot print the report).  Results are also compared with numpy (fp64)
+where that is cheap, so the pass doubles as a torch-free smoke test of the C ABI.  Not covered: the LDS-DMA kernels (inline-assembly requests are
+not instrumented; their translation units are built without -fsanitize)."""
+import ctypes as C
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from generativemodels_amd import _native as nat  # noqa: E402  (structures + prototypes only: lib() is NOT called, torch is not imported)
+
+hip = C.CDLL("/opt/rocm/lib/libamdhip64.so", mode=C.RTLD_GLOBAL)
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+hip.hipFree.argtypes = [C.c_void_p]
+lib = C.CDLL(os.environ.get("GM_NATIVE_LIB") or os.path.join(ROOT, "generativemodels_amd", "lib", "libgmamd_asan.so"))
+for name, (res, args) in nat.PROTOTYPES.items():
+    fn = getattr(lib, name)
+    fn.restype, fn.argtypes = res, args
+lib.gm_last_error.restype = C.c_char_p
+F32, BF16 = 0, 1
+rng = np.random.default_rng(7)
+live = []
+
+
+VERBOSE = bool(os.environ.get("GM_ASAN_VERBOSE"))
+
+
+def ck(rc, what):
+    if VERBOSE:
+        print("  launched:", what, flush=True)
+    if rc != 0:
+        raise RuntimeError(f"{what}: rc {rc}: {lib.gm_last_error()}")
+    assert hip.hipDeviceSynchronize() == 0, what
+
+
+def to_bf16_bits(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+class Dev:
+    """One hipMalloc per array (exact size: the red zone starts at the last byte)."""
+
+    def __init__(self, host=None, nbytes=None):
+        self.nbytes = host.nbytes if host is not None else nbytes
+        self.ptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(self.ptr), max(self.nbytes, 1)) == 0
+        if host is not None:
+            host = np.ascontiguousarray(host)
+            assert hip.hipMemcpy(self.ptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
+        live.append(self)
+
+    def get(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes == self.nbytes, (out.nbytes, self.nbytes)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes, 2) == 0
+        return out
+
+
+def put(a, dt):
+    return Dev(a.astype(np.float32) if dt == F32 else to_bf16_bits(a))
+
+
+def fetch(d, dt, shape):
+    return d.get(np.float32, shape).astype(np.float64) if dt == F32 else from_bf16_bits(d.get(np.uint16, shape)).astype(np.float64)
+
+
+def rounded(a, dt):
+    return a.astype(np.float32).astype(np.float64) if dt == F32 else from_bf16_bits(to_bf16_bits(a)).astype(np.float64)
+
+
+def close(got, want, dt, what, k=1.0):
+    tol = (2e-4 if dt == F32 else 2.5e-2) * k * max(1.0, np.abs(want).max())
+    err = np.abs(got - want).max()
+    assert np.isfinite(got).all() and err <= tol, f"{what}: max|err| {err:.3e} > {tol:.3e}"
+    return err
+
+
+def conv_case(dt, n, cin, cout, sp, k, stride, pad, dil, cfg, pre, res, transposed=False):
+    """gm_conv_forward on an arena tensor against a direct numpy convolution (fp64)."""
+    nsp = 3
+    x = rng.standard_normal((n, *sp, cin))
+    w = rng.standard_normal((cout, cin, k, k, k)) / math.sqrt(cin * k ** 3)
+    b = rng.standard_normal(cout) * 0.1
+    xr, wr = rounded(x, dt), rounded(w, dt)
+    osp = tuple((sp[i] + 2 * pad - dil * (k - 1) - 1) // stride + 1 for i in range(nsp))
+    if pre:
+        sc, sh = rng.uniform(0.5, 1.5, (n, cin)), rng.standard_normal((n, cin)) * 0.1
+        z = xr * sc[:, None, None, None, :] + sh[:, None, None, None, :]
+        xa = rounded(z / (1.0 + np.exp(-z)), dt)  # SiLU prologue, stored operand rounded like the kernel's
+    else:
+        xa = xr
+    xp = np.pad(xa, ((0, 0), (pad, pad), (pad, pad), (pad, pad), (0, 0)))
+    want = np.zeros((n, *osp, cout))
+    for a in range(k):
+        for bb in range(k):
+            for c in range(k):
+                sl = xp[:, a * dil: a * dil + (osp[0] - 1) * stride + 1: stride, bb * dil: bb * dil + (osp[1] - 1) * stride + 1: stride,
+                        c * dil: c * dil + (osp[2] - 1) * stride + 1: stride, :]
+                want += np.einsum("ndhwc,oc->ndhwo", sl, wr[:, :, a, bb, c])
+    want += b
+    r = None
+    if res:
+        r = rng.standard_normal((n, *osp, cout))
+        want += rounded(r, dt)
+    d = nat.GmConvDesc()
+    nelem = lib.gm_packed_conv_weight_elems(cout, cin, k, k, k, dt)
+    wsrc = Dev(w.astype(np.float32))
+    wpk = Dev(nbytes=nelem * (4 if dt == F32 else 2))
+    ck(lib.gm_pack_conv_weight(wsrc.ptr, F32, wpk.ptr, dt, cout, cin, k, k, k, 0, None), "gm_pack_conv_weight")
+    dx, dy, db = put(x, dt), Dev(nbytes=want.size * (4 if dt == F32 else 2)), Dev(b.astype(np.float32))
+    d.x, d.x_ld, d.w, d.bias, d.y, d.y_ld = dx.ptr, cin, wpk.ptr, db.ptr, dy.ptr, cout
+    if pre:
+        dsc, dsh = Dev(sc.astype(np.float32)), Dev(sh.astype(np.float32))
+        d.pre_scale, d.pre_shift, d.pre_act = dsc.ptr, dsh.ptr, 1
+    if res:
+        dr = put(r, dt)
+        d.res, d.res_ld = dr.ptr, cout
+    d.N, d.Cin, d.Cout = n, cin, cout
+    d.Ds, d.Hs, d.Ws = sp
+    d.Do, d.Ho, d.Wo = osp
+    d.kd = d.kh = d.kw = k
+    d.sd = d.sh = d.sw = stride
+    d.pd = d.ph = d.pw = pad
+    d.dd = d.dh = d.dw = dil
+    d.in_mode, d.fd, d.fh, d.fw, d.dtype, d.cfg = 0, 1, 1, 1, dt, cfg
+    bm, bn = C.c_int(), C.c_int()
+    ck(lib.gm_conv_cfg_tile(cfg, C.byref(bm), C.byref(bn)), "gm_conv_cfg_tile")
+    bits, caps = [0, 0, 0], [max(0, (v - 1).bit_length()) for v in osp]
+    if cfg >= 5:
+        bits[2] = min(4, caps[2], bm.value.bit_length() - 1)
+    for _ in range(bm.value.bit_length() - 1 - bits[2]):
+        cand = [i for i in ((1, 0) if cfg >= 5 else (2, 1, 0)) if bits[i] < caps[i]]
+        i = min(cand, key=lambda j: bits[j]) if cand else 2
+        bits[i] += 1
+    d.ltd, d.lth, d.ltw = bits
+    lds = lib.gm_conv_lds_bytes(C.byref(d))
+    if lds <= 0 or lds > 160 * 1024:  # not covered by this configuration / tile too large for it (the host picks another one)
+        return None
+    ck(lib.gm_conv_forward(C.byref(d), None), f"gm_conv_forward cfg {cfg}")
+    return close(fetch(dy, dt, want.shape), want, dt, f"conv cfg{cfg} {cin}->{cout} k{k} s{stride} d{dil} {sp} pre={pre} res={res} dt={dt}", 2.0)
+
+
+def main():
+    done = 0
+    # ---- convolutions: the generic tiles (cfg 0-4) and the register-staged fast kernels (cfg 5-10), ragged everything --------------------
+    for dt in (F32, BF16):
+        vec = 4 if dt == F32 else 8
+        for cfg in (0, 1, 2, 3, 4, 5):  # (the instrumented builds of the larger register-staged tiles, cfg 6+, do not load: HSA_STATUS_ERROR_INVALID_ISA)
+            for (cin, cout, sp, k, stride, pad, dil, pre, res) in [(vec, vec, (3, 5, 7), 3, 1, 1, 1, False, False), (3 * vec, 5 * vec, (5, 6, 9), 3, 1, 1, 1, True, True),
+                                                                     (2 * vec, 3 * vec, (7, 5, 6), 3, 2, 1, 1, False, True), (2 * vec, 2 * vec, (6, 6, 11), 3, 1, 2, 2, True, False),
+                                                                     (5 * vec, 2 * vec, (1, 4, 37), 1, 1, 0, 1, False, False), (2 * vec, 4 * vec, (9, 3, 5), 4, 2, 1, 1, False, False)]:
+                e = conv_case(dt, 2, cin, cout, sp, k, stride, pad, dil, cfg, pre, res)
+                if e is not None:
+                    done += 1
+    print(f"convolutions: {done} (configuration, geometry, dtype) cases ran clean")
+    # ---- GroupNorm statistics / apply, LayerNorm, GEGLU, activation, scale, axpby, timestep embedding -----------------------------------
+    for dt in (F32, BF16):
+        vec = 4 if dt == F32 else 8
+        for (n, v, c, g) in [(1, 1, vec, 1), (2, 37, 4 * vec, 4), (3, 1025, 8 * vec, 8), (1, 7, 64, 32)]:
+            x = rng.standard_normal((n, v, c)) * 2 + 0.5
+            xr = rounded(x, dt)
+            dx = put(x, dt)
+            slots = lib.gm_gn_channel_stats_slots(dx.ptr, c, v, c, dt)  # one partial per block of rows: [slots][N][C][2]
+            assert slots >= 1
+            ch = Dev(nbytes=slots * n * c * 2 * 8)
+            ck(lib.gm_gn_channel_stats(dx.ptr, c, n, v, c, ch.ptr, dt, None), "gm_gn_channel_stats")
+            st = ch.get(np.float64, (slots, n, c, 2)).sum(0)
+            assert np.allclose(st[..., 0], xr.sum(1), rtol=1e-5, atol=1e-3) and np.allclose(st[..., 1], (xr * xr).sum(1), rtol=1e-5, atol=1e-3)
+            gamma, beta = rng.uniform(0.5, 1.5, c), rng.standard_normal(c) * 0.1
+            dg, dbeta = Dev(gamma.astype(np.float32)), Dev(beta.astype(np.float32))
+            dsc, dsh = Dev(nbytes=n * c * 4), Dev(nbytes=n * c * 4)
+            ck(lib.gm_gn_finalize_channels(ch.ptr, slots, c, None, 0, 0, n, v, g, 1e-5, dg.ptr, dbeta.ptr, dsc.ptr, dsh.ptr, None), "gm_gn_finalize_channels")
+            xg = xr.reshape(n, v, g, c // g)
+            mean, var = xg.mean((1, 3), keepdims=True), xg.var((1, 3), keepdims=True)
+            want = ((xg - mean) / np.sqrt(var + 1e-5)).reshape(n, v, c) * gamma + beta
+            dy = Dev(nbytes=dx.nbytes)
+            ck(lib.gm_gn_apply(dx.ptr, c, dy.ptr, c, dsc.ptr, dsh.ptr, c, n, v, c, 1, dt, None), "gm_gn_apply")
+            close(fetch(dy, dt, x.shape), want / (1 + np.exp(-want)), dt, f"GroupNorm + SiLU {n}x{v}x{c}", 2.0)
+            dy2 = Dev(nbytes=dx.nbytes)
+            ck(lib.gm_layernorm(dx.ptr, c, dy2.ptr, c, dg.ptr, dbeta.ptr, n * v, c, 1e-5, dt, None), "gm_layernorm")
+            xl = xr.reshape(n * v, c)
+            close(fetch(dy2, dt, (n * v, c)), (xl - xl.mean(1, keepdims=True)) / np.sqrt(xl.var(1, keepdims=True) + 1e-5) * gamma + beta, dt, f"LayerNorm {n * v}x{c}", 2.0)
+            if c % 2 == 0:
+                dz = Dev(nbytes=dx.nbytes // 2)
+                ck(lib.gm_geglu(dx.ptr, c, dz.ptr, c // 2, n * v, c // 2, dt, None), "gm_geglu")
+                a, gate = xl[:, : c // 2], xl[:, c // 2:]
+                erf = np.vectorize(math.erf)
+                close(fetch(dz, dt, (n * v, c // 2)), a * 0.5 * gate * (1 + erf(gate / math.sqrt(2))), dt, f"GEGLU {n * v}x{c}", 2.0)
+            for act in range(1, 7):
+                da = Dev(nbytes=dx.nbytes)
+                ck(lib.gm_activation(dx.ptr, None, da.ptr, act, 0, x.size, dt, None), "gm_activation fwd")
+                ck(lib.gm_activation(dx.ptr, da.ptr, dy.ptr, act, 1, x.size, dt, None), "gm_activation bwd")
+            # backward kernels of the same tensors (run for bounds, not compared): GroupNorm statistics / apply, LayerNorm, GEGLU
+            gy = put(rng.standard_normal(x.shape), dt)
+            bslots = lib.gm_gn_bwd_stats_slots(n, v)
+            bst = Dev(nbytes=bslots * n * c * 2 * 8)
+            ck(lib.gm_gn_bwd_stats(dx.ptr, c, gy.ptr, c, dsc.ptr, dsh.ptr, c, n, v, c, 1, bst.ptr, dt, None), "gm_gn_bwd_stats")
+            ca, cb, cc = Dev(nbytes=n * c * 4), Dev(nbytes=n * c * 4), Dev(nbytes=n * c * 4)
+            dgam, dbet = Dev(nbytes=c * 4), Dev(nbytes=c * 4)
+            ck(lib.gm_gn_bwd_finalize(ch.ptr, slots, bst.ptr, bslots, n, c, g, v, 1e-5, dg.ptr, ca.ptr, cb.ptr, cc.ptr, dgam.ptr, dbet.ptr, None), "gm_gn_bwd_finalize")
+            ddx = Dev(nbytes=dx.nbytes)
+            ck(lib.gm_gn_bwd_apply(dx.ptr, c, gy.ptr, c, ddx.ptr, c, dsc.ptr, dsh.ptr, c, ca.ptr, cb.ptr, cc.ptr, n, v, c, 1, dt, None), "gm_gn_bwd_apply")
+            lslots = lib.gm_layernorm_bwd_slots(n * v)
+            lst = Dev(nbytes=lslots * c * 2 * 8)
+            ck(lib.gm_layernorm_bwd(dx.ptr, c, gy.ptr, c, ddx.ptr, c, dg.ptr, n * v, c, 1e-5, lst.ptr, dt, None), "gm_layernorm_bwd")
+            if c % 2 == 0:
+                gz = put(rng.standard_normal((n * v, c // 2)), dt)
+                ck(lib.gm_geglu_bwd(dx.ptr, c, gz.ptr, c // 2, ddx.ptr, c, n * v, c // 2, dt, None), "gm_geglu_bwd")
+            ck(lib.gm_scale(dx.ptr, dy.ptr, 0.7, 0, x.size, dt, None), "gm_scale")
+            close(fetch(dy, dt, x.shape), xr * np.float32(0.7), dt, "scale")
+            done += 1
+        for b_, dim in [(1, 2), (3, 64), (5, 33)]:
+            ts = Dev(rng.uniform(0, 999, b_).astype(np.float32))
+            out = Dev(nbytes=b_ * dim * (4 if dt == F32 else 2))
+            ck(lib.gm_timestep_embedding(ts.ptr, out.ptr, b_, dim, 10000.0, dt, None), "gm_timestep_embedding")
+    print("GroupNorm / LayerNorm / GEGLU forward + backward / activation / scale / timestep embedding ran clean")
+    # ---- attention (register-staged kernel: any head dim, ragged lengths, heads as channel slices) ------------------------------------------
+    for dt in (F32, BF16):
+        for (b_, h, lq, lk, dh, causal) in [(1, 1, 1, 1, 8, 0), (2, 3, 37, 53, 24, 0), (1, 2, 130, 130, 64, 1), (1, 1, 65, 200, 256, 0), (2, 1, 16, 300, 40, 0)]:
+            c = h * dh
+            q, k_, v = (rng.standard_normal((b_, l, c)) for l in (lq, lk, lk))
+            dq, dk, dv = put(q, dt), put(k_, dt), put(v, dt)
+            do = Dev(nbytes=dq.nbytes)
+            d = nat.GmAttnDesc()
+            d.q, d.q_ld, d.k, d.k_ld, d.v, d.v_ld, d.o, d.o_ld = dq.ptr, c, dk.ptr, c, dv.ptr, c, do.ptr, c
+            d.B, d.H, d.Lq, d.Lk, d.dh, d.scale, d.dtype, d.causal = b_, h, lq, lk, dh, 1 / math.sqrt(dh), dt, causal
+            ck(lib.gm_attention_forward(C.byref(d), None), "gm_attention_forward")
+            qr, kr, vr = (rounded(t, dt).reshape(b_, -1, h, dh).transpose(0, 2, 1, 3) for t in (q, k_, v))
+            s = qr @ kr.transpose(0, 1, 3, 2) / math.sqrt(dh)
+            if causal:
+                s = np.where(np.arange(lk)[None, :] <= np.arange(lq)[:, None] + (lk - lq), s, -np.inf)
+            p = np.exp(s - s.max(-1, keepdims=True))
+            want = ((p / p.sum(-1, keepdims=True)) @ vr).transpose(0, 2, 1, 3).reshape(b_, lq, c)
+            close(fetch(do, dt, (b_, lq, c)), want, dt, f"attention B{b_} H{h} {lq}x{lk} d{dh} causal={causal}", 2.0)
+            done += 1
+    print("attention ran clean")
+    # ---- layout transposes, row mixes ------------------------------------------------------------------------------------------------------
+    for dt in (F32, BF16):
+        for (n, c, v) in [(1, 1, 7), (2, 5, 33), (1, 64, 129)]:
+            x = rng.standard_normal((n, c, v))
+            dx = Dev(x.astype(np.float32))
+            dy = Dev(nbytes=x.size * (4 if dt == F32 else 2))
+            ck(lib.gm_nchw_to_nhwc(dx.ptr, F32, dy.ptr, dt, n, c, v, c, None), "gm_nchw_to_nhwc")
+            close(fetch(dy, dt, (n, v, c)), x.transpose(0, 2, 1), dt, "nchw -> nhwc")
+            dz = Dev(nbytes=x.size * 4)
+            ck(lib.gm_nhwc_to_nchw(dy.ptr, c, dt, dz.ptr, F32, n, c, v, None), "gm_nhwc_to_nchw")
+            a, b2 = Dev(rng.standard_normal(n).astype(np.float32)), Dev(rng.standard_normal(n).astype(np.float32))
+            ck(lib.gm_axpby_rows(dy.ptr, dy.ptr, a.ptr, b2.ptr, dy.ptr, n, c * v, dt, None), "gm_axpby_rows")
+    print(f"ASAN kernel pass complete: {done} kernel cases + layout / mix kernels, {len(live)} device buffers, no sanitizer abort")
+
+
+if __name__ == "__main__":
+    main()

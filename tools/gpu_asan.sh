@@ -1,22 +1,23 @@
 #!/bin/bash
-# AddressSanitizer pass over the GPU kernel tests: tools/gpu_asan.sh TAG [pytest -k expression] [test files]
-# Needs lib/libgmamd_asan.so (python -m generativemodels_amd._build --variant asan).  Kernels are built for gfx950:xnack+ and instrumented; every
-# tensor is its own hipMalloc (PYTORCH_NO_CUDA_MEMORY_CACHING=1) so that the allocator's red zones sit right behind each operand.  This image's
-# HIP runtime has no handler for the sanitizer's report hostcall: a violation ABORTS the process with "Hostcall: no handler found for service ID 4"
-# (tools/asan/oob_probe.hip shows both outcomes); a clean run ends with pytest's summary.  The LDS-DMA requests are inline assembly: not instrumented.
+# AddressSanitizer pass over the C-ABI kernels: tools/gpu_asan.sh TAG
+# Needs lib/libgmamd_asan.so linked against the SYSTEM HIP runtime:
+#   GM_HIP_RUNTIME=/opt/rocm/lib/libamdhip64.so python -m generativemodels_amd._build --variant asan
+# (kernels for gfx950:xnack+, every translation unit without LDS-DMA inline assembly instrumented).  The driver is tools/asan/run_kernels.py:
+# numpy + ctypes, no torch -- the sanitizer's hsa_amd_memory_pool_allocate interceptor fails every allocation of the HIP runtime bundled with
+# the PyTorch wheel.  This image's HIP runtime has no handler for the sanitizer's report hostcall: a violation ABORTS the process with
+# "Hostcall: no handler found for service ID 4" (tools/asan/oob_probe.hip shows both outcomes); a clean run ends with the driver's summary line.
 set -u
 cd "$(dirname "$0")/.."
-TAG=${1:-asan}; K=${2:-}; shift; shift
-FILES=${@:-tests/test_gpu_kernels.py}
+TAG=${1:-asan}
 CL=$(ls -d /opt/rocm/lib/llvm/lib/clang/*/lib/linux | head -1)
 export LD_PRELOAD=$CL/libclang_rt.asan-x86_64.so
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1
-export HSA_XNACK=1 PYTORCH_NO_CUDA_MEMORY_CACHING=1
+export HSA_XNACK=1
 export GM_NATIVE_LIB=$PWD/generativemodels_amd/lib/libgmamd_asan.so
 mkdir -p gpurun_out
-( cd tools/asan && for n in 0 8; do timeout 60 ./oob_probe.bin $n 2>&1 | grep -c "no handler found for service ID 4" | sed "s/^/probe n=$n violations reported: /"; done ) > gpurun_out/${TAG}_asan.log 2>&1
-if [ -n "$K" ]; then timeout 2400 python -m pytest $FILES -m gpu -q -x -p no:cacheprovider -k "$K" >> gpurun_out/${TAG}_asan.log 2>&1
-else timeout 2400 python -m pytest $FILES -m gpu -q -x -p no:cacheprovider >> gpurun_out/${TAG}_asan.log 2>&1; fi
-echo "pytest rc=$?" >> gpurun_out/${TAG}_asan.log
-grep -c "no handler found for service ID 4" gpurun_out/${TAG}_asan.log | sed 's/^/violation messages in the log: /' >> gpurun_out/${TAG}_asan.log
-tail -15 gpurun_out/${TAG}_asan.log
+LOG=gpurun_out/${TAG}_asan.log
+( cd tools/asan && for n in 0 8; do timeout 60 ./oob_probe.bin $n 2>&1 | grep -c "no handler found for service ID 4" | sed "s/^/probe (oob_probe.bin $n): sanitizer aborts reported: /"; done ) > $LOG 2>&1
+GM_ASAN_VERBOSE=${GM_ASAN_VERBOSE:-} timeout 1500 python tools/asan/run_kernels.py >> $LOG 2>&1
+echo "driver rc=$?" >> $LOG
+grep -c "no handler found for service ID 4" $LOG | sed 's/^/sanitizer abort messages in the log (the probe accounts for 1): /' >> $LOG
+tail -25 $LOG
