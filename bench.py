@@ -330,7 +330,9 @@ def main() -> None:
             "unet_forward_ms": None if fwd_ms is None else round(fwd_ms, 3),
             "ms_per_ddim_iteration": round(1e3 * elapsed / args.steps / args.inference_steps, 3),
             "output_finite": finite,
-            "roofline": roof, "package_power_w": power_stats, "cpu_baseline": cpu,
+            "roofline": roof, "package_power_w": power_stats,
+            "joules_per_volume": None if not power_stats else round(power_stats["mean_w"] * elapsed / args.steps, 1),  # what bounds this loop: it runs at the power cap
+            "cpu_baseline": cpu,
             "speedup_vs_cpu": None if cpu is None else round(vol_s / cpu["value"], 1),
             "kernel_breakdown_ms": {k: dict(launches=v["launches"], ms=round(v["ms"], 3),
                                             tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
