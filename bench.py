@@ -40,31 +40,55 @@ MFMA_BF16_SUSTAINED_TFLOPS = {"operands in registers, no memory traffic": 1850.0
 
 
 class PowerSampler:
-    """Package power of the GPU this rank runs on, read from the amdgpu hwmon node every 50 ms on a host thread while the timed region runs
-    (a file read: no process is spawned, nothing is enqueued on the GPU).  None when the node is not there."""
+    """Socket package power of the GPU this rank runs on, sampled every 50 ms on a host thread while the timed region runs: the same quantity
+    `rocm-smi --showpower` prints (rsmi_dev_current_socket_power_get through librocm_smi64 -- a library call: no process is spawned, nothing is
+    enqueued on the GPU); falls back to the amdgpu hwmon node (a slower moving average) and to None when neither is there."""
 
     def __init__(self, local_rank: int = 0):
+        import ctypes
         import glob
-        self.path, self.cap_w = None, None
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) or sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
-        if cards:
-            self.path = cards[min(local_rank, len(cards) - 1)]
-            try:
-                self.cap_w = int(open(os.path.join(os.path.dirname(self.path), "power1_cap")).read()) / 1e6
-            except Exception:
-                self.cap_w = None
+        self.kind, self.cap_w, self._rsmi, self._idx, self.path = None, None, None, local_rank, None
+        try:
+            lib = ctypes.CDLL("/opt/rocm/lib/librocm_smi64.so")
+            if lib.rsmi_init(ctypes.c_uint64(0)) == 0:
+                v = ctypes.c_uint64(0)
+                if lib.rsmi_dev_current_socket_power_get(ctypes.c_uint32(local_rank), ctypes.byref(v)) == 0 and v.value > 0:
+                    self._rsmi, self.kind = lib, "rsmi_dev_current_socket_power_get (librocm_smi64)"
+                    cap = ctypes.c_uint64(0)
+                    if lib.rsmi_dev_power_cap_get(ctypes.c_uint32(local_rank), ctypes.c_uint32(0), ctypes.byref(cap)) == 0:
+                        self.cap_w = cap.value / 1e6
+        except Exception:
+            self._rsmi = None
+        if self._rsmi is None:
+            cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) or sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+            if cards:
+                self.path = cards[min(local_rank, len(cards) - 1)]
+                self.kind = self.path + " (hwmon: a slow moving average)"
+                try:
+                    self.cap_w = int(open(os.path.join(os.path.dirname(self.path), "power1_cap")).read()) / 1e6
+                except Exception:
+                    self.cap_w = None
         self.samples, self._stop, self._thread = [], False, None
+
+    def _read(self):
+        if self._rsmi is not None:
+            import ctypes
+            v = ctypes.c_uint64(0)
+            return v.value / 1e6 if self._rsmi.rsmi_dev_current_socket_power_get(ctypes.c_uint32(self._idx), ctypes.byref(v)) == 0 else None
+        return int(open(self.path).read()) / 1e6
 
     def _run(self):
         while not self._stop:
             try:
-                self.samples.append(int(open(self.path).read()) / 1e6)
+                w = self._read()
+                if w:
+                    self.samples.append(w)
             except Exception:
                 pass
             time.sleep(0.05)
 
     def start(self):
-        if self.path is not None:
+        if self.kind is not None:
             import threading
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
@@ -77,7 +101,8 @@ class PowerSampler:
             return None
         s = sorted(self.samples)
         return dict(mean_w=round(sum(s) / len(s), 1), median_w=round(s[len(s) // 2], 1), max_w=round(s[-1], 1), cap_w=self.cap_w, samples=len(s),
-                    source=self.path)
+                    source=self.kind)
+
 
 C2 = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(64, 128, 256), attention_levels=(False, False, False),
           num_res_blocks=2, num_head_channels=(0, 0, 256), norm_num_groups=32)

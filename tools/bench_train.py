@@ -61,7 +61,7 @@ unet = unet.to(dev, dt)
 sched = DDPMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205)
 inf = LatentDiffusionInferer(sched, scale_factor=1.0)
 opt = torch.optim.Adam(unet.parameters(), lr=1e-5)
-red = GradientReducer(unet.parameters(), force=force_reducer)
+red = GradientReducer(unet.parameters(), force=force_reducer, usage_check_every=int(os.environ.get("GM_REDUCER_USAGE_EVERY", "1")))
 g = torch.Generator().manual_seed(100 + rank)
 imgs = torch.randn((batch, 1, size, size, size), generator=g).to(dev, dt)
 lat = size // 8
