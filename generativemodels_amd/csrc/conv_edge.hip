@@ -25,11 +25,9 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
   constexpr int TD = 4, TH = 4, TW = 16, PH = TH + 2, PW = TW + 2, PROWS = (TD + 2) * PH * PW;  // 648
   constexpr int MAXK = 128;                    // 27 * C_in <= 108
   constexpr int MAXBLK = MAXK / KB;
-  constexpr int WPITCH = MAXK * (int)sizeof(T) + 16;   // bytes per weight row [co][k], padded against bank conflicts
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* patch = reinterpret_cast<T*>(smem);                            // [PROWS][Cin]
-  char* wlds = smem + ((PROWS * 4 * (int)sizeof(T) + 15) & ~15);    // [BN][WPITCH]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
@@ -47,9 +45,20 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
   const int cout_pad = (p.Cout + 15) & ~15;
   constexpr int BK = ConvTraits<T>::BK;
 
-  // ---- stage the patch (zero padded) and the weight block [co][k = tap * Cin + ci] -------------------------------------------
-  // (round 3: both staging loops request all of a thread's elements before the first wait -- a run-time loop of load -> LDS store waited for
-  //  every element in turn: 3 + 8 dependent round trips per work-group at C_in = 1)
+  // ---- weight fragments: straight from the K-MAJOR image [Cout padded to 64][nblk * KB] (k = tap * C_in + ci, zero padded; ops.packed_cin_weight)
+  // into registers, requested before anything else (round 4: the first form gathered the block element by element from the tap-major panel
+  // into LDS -- 8 scalar loads and ~450 index instructions per thread and tile, most of a work-group's 28 k cycles, for 4 KiB that every tile
+  // of the launch reads identically; 16-byte loads of an L2-resident image need neither LDS nor a barrier)
+  uint4 wfr[nblk][NFR];
+  {
+    const char* wimg = reinterpret_cast<const char*>(p.w) + ((size_t)(cb * BN + l15) * (nblk * KB) + q * VECW) * sizeof(T);
+#pragma unroll
+    for (int blk = 0; blk < nblk; ++blk)
+#pragma unroll
+      for (int nf = 0; nf < NFR; ++nf)
+        wfr[blk][nf] = *reinterpret_cast<const uint4*>(wimg + ((size_t)nf * 16 * (nblk * KB) + blk * KB) * sizeof(T));
+  }
+  // ---- stage the patch (zero padded): all of a thread's elements are requested before the first wait ---------------------------------
   const T* xin = reinterpret_cast<const T*>(p.x);
   {
     constexpr int PMAX = (PROWS * 4 + 255) / 256;  // C_in <= 4
@@ -74,34 +83,6 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
       if (e < PROWS * Cin) patch[e] = pok[it] ? pv[it] : (T)0;
     }
   }
-  const T* wsrc = reinterpret_cast<const T*>(p.w);  // packed [chunk 0][tap][cout_pad][BK]
-  {
-    constexpr int WMAX = BN * MAXK / 256;  // 32
-    const int wtotal = BN * nblk * KB;
-    for (int it0 = 0; it0 < WMAX; it0 += 8) {
-      T wv[8];
-      bool wok[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int e = tid + (it0 + j) * 256;
-        const int ec = e < wtotal ? e : 0;
-        const int col = ec / (nblk * KB), k = ec - col * (nblk * KB);
-        const int co = cb * BN + col;
-        wok[j] = (k < K) & (co < cout_pad);
-        const int tap = wok[j] ? k / Cin : 0, ci = wok[j] ? k - tap * Cin : 0;
-        wv[j] = wsrc[((long long)tap * cout_pad + (wok[j] ? co : 0)) * BK + ci];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int e = tid + (it0 + j) * 256;
-        if (e < wtotal) {
-          const int col = e / (nblk * KB), k = e - col * (nblk * KB);
-          *reinterpret_cast<T*>(wlds + (size_t)col * WPITCH + k * (int)sizeof(T)) = wok[j] ? wv[j] : (T)0;
-        }
-      }
-      if ((it0 + 8) * 256 >= wtotal) break;
-    }
-  }
   __syncthreads();
 
   // ---- this lane's K slots: element offset into the patch of k = blk*KB + q*VECW + i at tap (0,0,0) voxel, -1 beyond K ------------
@@ -116,6 +97,7 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
     const int m = (wave * MF + mf) * 16 + l15;
     vrow[mf] = (((m >> 6) * PH + ((m >> 4) & 3)) * PW + (m & 15)) * Cin;
   }
+#pragma unroll
   for (int blk = 0; blk < nblk; ++blk) {
     int koff[VECW];
 #pragma unroll
@@ -125,10 +107,7 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       koff[i] = k < K ? ((kd * PH + kh) * PW + kw) * Cin + ci : -1;
     }
-    uint4 wf[NFR];
-#pragma unroll
-    for (int nf = 0; nf < NFR; ++nf)
-      wf[nf] = *reinterpret_cast<const uint4*>(wlds + (size_t)(nf * 16 + l15) * WPITCH + (blk * KB + q * VECW) * (int)sizeof(T));
+    const uint4 (&wf)[NFR] = wfr[blk];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       alignas(16) T g[VECW];
@@ -528,7 +507,7 @@ extern "C" int gm_conv_cin_eligible(const GmConvDesc* d) {
 }
 extern "C" long long gm_conv_cin_lds_bytes(const GmConvDesc* d) {
   const long long es = d->dtype == GM_F32 ? 4 : 2;
-  const long long operands = ((648 * 4 * es + 15) & ~15LL) + 64 * (128 * es + 16);
+  const long long operands = (648 * 4 * es + 15) & ~15LL;  // the halo patch (the weight fragments come from the K-major image in registers)
   const long long scratch = 4LL * 64 * 144;
   return operands > scratch ? operands : scratch;
 }

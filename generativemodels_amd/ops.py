@@ -276,6 +276,25 @@ def packed_conv_weight_halves(packed: torch.Tensor, cin: int, taps: int = 27) ->
     return _cached(packed, ("halves", cin, taps), make)
 
 
+def packed_cin_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """The K-MAJOR image of a C_in <= 4 convolution's 3x3x3 weight for tile configuration 12 (csrc/conv_edge.hip conv_cin_kernel):
+    [Cout padded to 64][27 * C_in padded to the MFMA K step] with k = tap * C_in + ci, zero padded -- the taps x inputs ARE the GEMM K, and a
+    lane's weight fragment is one 16-byte load of this image (DiffusionModelUNet.conv_in, AutoencoderKL encoder conv_in)."""
+    require_device(weight)
+
+    def make():
+        w = weight.detach()
+        cout, cin = w.shape[0], w.shape[1]
+        kb = 64 // (4 if dtype == torch.float32 else 2)            # K values per MFMA step: 16 fp32 / 32 bf16
+        k = 27 * cin
+        kp, cp = -(-k // kb) * kb, -(-cout // 64) * 64
+        out = torch.zeros((cp, kp), dtype=dtype, device=w.device)
+        out[:cout, :k] = w.reshape(cout, cin, 27).permute(0, 2, 1).reshape(cout, k).to(dtype)
+        return out
+
+    return _cached(weight, ("cin_rows", dtype), make)
+
+
 SUBPIXEL_UPSAMPLE = True  # nearest-2x + 3x3x3 convolutions run as 8 sub-pixel 2x2x2 convolutions (8/27 of the multiply-adds)
 
 
@@ -1217,7 +1236,13 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                         upsample=upsample, transposed=transposed, output_padding=output_padding, pre=pre, pre_act=pre_act,
                         rowvec=rowvec, res=acc_t, post_act=post_act, out=out, packed=packed, cout=cout, force_cfg=force_cfg,
                         want_stats=want_stats)
-        _choose_conv_cfg(d, nvox, force_cfg, exclude=DMA_CFGS if force_cfg is None else ())
+        no_cin = (12,) if (weight is None or transposed or tuple(weight.shape[2:]) != (3, 3, 3)) else ()  # (cfg 12 derives its image from the weight)
+        _choose_conv_cfg(d, nvox, force_cfg, exclude=(DMA_CFGS + no_cin) if force_cfg is None else ())
+    if d.cfg == 12:  # configuration 12 reads its weight fragments from the K-major image
+        if weight is None or transposed or tuple(weight.shape[2:]) != (3, 3, 3):
+            raise ValueError("configuration 12 needs the original [Cout, Cin, 3, 3, 3] weight (its K-major image is derived from it)")
+        cin_keep = packed_cin_weight(weight, dtype)
+        d.w = cin_keep.data_ptr()
     if dma_ok and d.cfg == 22 and _W8_PIPE2 is not None:
         lib().gm_conv_w8_set_pipe2(int(_W8_PIPE2))
     if dma_ok and d.cfg == 22:  # configuration 22 reads its main weights from the halves image (the fused shortcut keeps the standard one)

@@ -150,8 +150,9 @@ int gm_layernorm(const void* x, long long x_ld, void* y, long long y_ld, const f
  * (:686-690), residual add (:692-696) and the output activation. */
 typedef struct GmConvDesc {
   const void* x; long long x_ld;
-  const void* w;             /* packed by gm_pack_conv_weight; cfg 22 alone reads the HALVES image of that panel instead:
-                              * [chunk32][half][tap][Cout_pad][16] (the 16-input-channel weight block of a tap contiguous) */
+  const void* w;             /* packed by gm_pack_conv_weight; two configurations read their own image instead: cfg 22 the HALVES image of that
+                              * panel, [chunk32][half][tap][Cout_pad][16] (the 16-input-channel weight block of a tap contiguous); cfg 12
+                              * (C_in <= 4) the K-MAJOR image [Cout padded to 64][27 * C_in padded to 32 bf16 / 16 fp32], k = tap * C_in + ci */
   const float* bias;         /* [Cout] or NULL */
   const float* pre_scale;    /* [N][Cin] or NULL */
   const float* pre_shift;    /* [N][Cin] or NULL */
