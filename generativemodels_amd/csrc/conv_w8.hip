@@ -493,6 +493,18 @@ extern "C" int gm_conv_w8_eligible(const GmConvDesc* d) {
 static int g_w8_pipe2 = 0;  // measured (profiles/r04_conv_cfg22_ab.txt): one operand set 14.88 vs two sets 15.54 ms per C2 iteration (the two-set form spills at 128 registers)
 extern "C" void gm_conv_w8_set_pipe2(int on) { g_w8_pipe2 = on; }
 
+// gm_w8_place is a per-device global: filled once per device, stream-ordered ahead of that device's first configuration-22 launch (a first launch
+// inside a graph capture simply replays the fill; the fill is idempotent, so a second stream racing the first one writes the same bytes)
+static void w8_ensure_placement(hipStream_t st) {
+  static unsigned long long placed_devices = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
+  if (!((placed_devices >> dev) & 1ull) || dev == 63) {
+    w8_place_kernel<<<1, w8::NW * 64, 0, st>>>();
+    placed_devices |= 1ull << dev;
+  }
+}
+
 template <bool PRE, bool PIPE2>
 static void launch_w8(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
@@ -502,11 +514,7 @@ static void launch_w8(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  static bool placed = false;  // (stream-ordered ahead of the first convolution; a first launch inside a graph capture just replays it)
-  if (!placed) {
-    w8_place_kernel<<<1, w8::NW * 64, 0, st>>>();
-    placed = true;
-  }
+  w8_ensure_placement(st);
   kern<<<dim3(nblocks), 512, (size_t)w8::LDS_BYTES, st>>>(d);
 }
 
