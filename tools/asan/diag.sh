@@ -1,3 +1,5 @@
+# AddressSanitizer + PyTorch diagnostics (round 4): shows why the pass runs through tools/asan/run_kernels.py -- under LD_PRELOAD of the sanitizer runtime
+# the HIP runtime bundled with the PyTorch wheel fails its first device allocation ("AddressSanitizer: out of memory" at import torch)
 CL=$(ls -d /opt/rocm/lib/llvm/lib/clang/*/lib/linux | head -1)
 export LD_PRELOAD=$CL/libclang_rt.asan-x86_64.so
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1
