@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libgmamd.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "conv_fast.hip", "conv_dma.hip", "conv_mw.hip", "conv_w8.hip", "conv_edge.hip", "attention.hip", "attention_dma.hip", "attention_bwd.hip", "transformer_ops.hip", "decode_step.hip", "small_ops.hip", "backward.hip", "vq.hip"]
+SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "conv_fast.hip", "conv_dma.hip", "conv_mw.hip", "conv_w8.hip", "conv_sk.hip", "conv_edge.hip", "attention.hip", "attention_dma.hip", "attention_bwd.hip", "transformer_ops.hip", "decode_step.hip", "small_ops.hip", "backward.hip", "vq.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
@@ -62,7 +62,7 @@ EXTRA_FLAGS = {"elementwise.hip": ["-ffp-contract=off"]}
 from ._build_variants import VARIANTS  # noqa: E402
 # translation units whose LDS-DMA inline assembly does not survive the sanitizer's instrumentation (its "s" operands stop being provably uniform):
 # compiled WITHOUT -fsanitize in the asan variant; their global accesses are the DMA requests themselves, which no sanitizer sees anyway
-ASAN_PLAIN = {"conv_dma.hip", "conv_mw.hip", "conv_w8.hip", "attention_dma.hip", "conv_edge.hip"}
+ASAN_PLAIN = {"conv_dma.hip", "conv_mw.hip", "conv_w8.hip", "conv_sk.hip", "attention_dma.hip", "conv_edge.hip"}
 _variant = None
 
 

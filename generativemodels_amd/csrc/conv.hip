@@ -466,15 +466,15 @@ extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
 #define SK_THREADS 256
 #define SK_ITERS 8
 template <typename T>
-__global__ __launch_bounds__(SK_THREADS) void conv_splitk_combine_kernel(const GmConvDesc p, long long V) {
+__global__ __launch_bounds__(SK_THREADS) void conv_splitk_combine_kernel(const GmConvDesc p, long long V, int iters) {
   constexpr int VECW = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char sk_smem[];
   const int C = p.Cout, CV = C / VECW, R = SK_THREADS / CV;
   float* part_s = reinterpret_cast<float*>(sk_smem);  // [R][C]
   float* part_q = part_s + (size_t)R * C;
   const int n = blockIdx.y, t = threadIdx.x, cv = t % CV, r0 = t / CV, c = cv * VECW;
-  const long long row_begin = (long long)blockIdx.x * R * SK_ITERS;
-  long long row_end = row_begin + (long long)R * SK_ITERS;
+  const long long row_begin = (long long)blockIdx.x * R * iters;
+  long long row_end = row_begin + (long long)R * iters;
   if (row_end > V) row_end = V;
   const long long nv = (long long)p.N * V;
   // Every load of a row is requested before the first wait (round 3): the per-channel addends come through substitute pointers (a branch per
@@ -568,9 +568,19 @@ static bool conv_splitk_ok(const GmConvDesc& d) {  // configuration 11 (3x3x3, s
          (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 && (!d.res || (d.res_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d.res) & 15) == 0)) &&
          conv_splitk_no_empty_slice(d) && d.in_mode != 3;
 }
+// Rows a combine block owns = (rows in flight R) x (iterations).  Round 3 used SK_ITERS = 8 always: an 8^3 x 256-channel output was 8 blocks walking 8
+// dependent round trips each (12 us per launch, profiles/r03_c3_latent_unet_kernel_stats_v27.csv).  The iteration count now follows the volume: as
+// few as keep the launch at <= gm_stats_compact_slots() = 256 blocks per sample (the statistic table stays small enough to skip the compaction
+// launch), at most SK_ITERS.  The block count is also the S of the statistic partials (gm_conv_stats_slots).
+static int conv_splitk_iters(const GmConvDesc& d) {
+  const int vecw = d.dtype == GM_F32 ? 4 : 8;
+  const long long R = SK_THREADS / (d.Cout / vecw), V = (long long)d.Do * d.Ho * d.Wo;
+  long long it = (V + R * 256 - 1) / (R * 256);
+  return (int)(it < 1 ? 1 : (it > SK_ITERS ? SK_ITERS : it));
+}
 static long long conv_splitk_rows_per_block(const GmConvDesc& d) {
   const int vecw = d.dtype == GM_F32 ? 4 : 8;
-  return (long long)(SK_THREADS / (d.Cout / vecw)) * SK_ITERS;
+  return (long long)(SK_THREADS / (d.Cout / vecw)) * conv_splitk_iters(d);
 }
 extern "C" long long gm_conv_splitk_workspace_bytes(const GmConvDesc* d) {
   if (!d || !conv_splitk_ok(*d)) return 0;
@@ -650,8 +660,8 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
       const int vecw = d.dtype == GM_F32 ? 4 : 8;
       const size_t smem2 = (size_t)(SK_THREADS / (d.Cout / vecw)) * d.Cout * 2 * sizeof(float);
       dim3 grid((unsigned)((V + rpb - 1) / rpb), (unsigned)d.N);
-      if (d.dtype == GM_F32) conv_splitk_combine_kernel<float><<<grid, SK_THREADS, smem2, st>>>(d, V);
-      else conv_splitk_combine_kernel<bf16_raw><<<grid, SK_THREADS, smem2, st>>>(d, V);
+      if (d.dtype == GM_F32) conv_splitk_combine_kernel<float><<<grid, SK_THREADS, smem2, st>>>(d, V, conv_splitk_iters(d));
+      else conv_splitk_combine_kernel<bf16_raw><<<grid, SK_THREADS, smem2, st>>>(d, V, conv_splitk_iters(d));
     }
     GM_LAUNCH_CHECK();
   }

@@ -786,6 +786,9 @@ extern "C" int gm_conv_mw_launch(const GmConvDesc* dp, unsigned nblocks, void* s
 extern "C" long long gm_conv_w8_lds_bytes();
 extern "C" int gm_conv_w8_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_w8_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
+// the K slices of a split-K launch (cfg 11 geometry) run on conv_sk.hip's kernel: one work-group per CU, patch + all nine panels of a chunk resident
+extern "C" int gm_conv_sk_eligible(const GmConvDesc* d);
+extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 
 extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   const long long addv = 512;
@@ -899,6 +902,7 @@ static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) 
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   if (dp->cfg == 21) return gm_conv_mw_launch(dp, nblocks, stream);
   if (dp->cfg == 22) return gm_conv_w8_launch(dp, nblocks, stream);
+  if (gm_conv_sk_eligible(dp)) return gm_conv_sk_launch(dp, nblocks, stream);
   hipStream_t st = (hipStream_t)stream;
   if (dp->dtype == GM_F32) { dispatch_dma<float>(*dp, nblocks, st); return 0; }
   if (dp->dtype == GM_BF16) { dispatch_dma<bf16_raw>(*dp, nblocks, st); return 0; }

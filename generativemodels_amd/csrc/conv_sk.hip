@@ -1,0 +1,349 @@
+// The K slices of a split-K 3x3x3 convolution over a SMALL volume (the 32^3 / 16^3 / 8^3 levels of a latent UNet: fewer 256-voxel x 64-channel
+// tiles than the chip has CUs, so the K chunks of a tile are dealt to `ksplit` work-groups and a combine kernel sums their fp32 partials --
+// GmConvDesc.ksplit / kpartial, conv.hip).  Round 3 ran those slices on the general tile kernel (conv_dma.hip, cfg 11): built for a CU that is
+// shared by two work-groups and streams a long K loop, it keeps three 12 KiB weight panels in a ring and requests a panel two tap groups ahead.
+// A slice is ONE chunk of 27 taps (rarely two or three): 216 MFMAs per wave against nine panel round trips of ~1 us each, plus the set-up of
+// the multi-tile walk and an epilogue it does not need -- 24 us per launch for ~3 us of arithmetic (profiles/r04_c3_layers.txt).
+// Here a work-group owns its CU (1 work-group of 8 waves per CU: the grid is at most one wave of work-groups) and spends the LDS on latency:
+//   * the patch (42 KiB) and ALL NINE weight panels of a chunk (108 KiB) are requested back to back before anything waits: one exposed round
+//     trip per chunk instead of nine; the panels land in request order, so group g starts behind `s_waitcnt vmcnt(16 - 2 g)` + a barrier while
+//     the later panels are still in flight, and from group 4 on nothing waits at all;
+//   * the fused GroupNorm + SiLU prologue takes its scale / shift from a 256-byte LDS copy that every wave requests AHEAD of its patch pieces
+//     (an ordinary global load would make hipcc wait for `vmcnt(0)` -- every panel -- at its first use);
+//   * no tile walk, no epilogue: the partial sums go from the accumulators to kpartial exactly as conv_dma.hip's slices wrote them.
+// Same tile (4x4x16 voxels x 64 channels, 8 waves x 32 voxels), same LDS layouts, same packed weights and the same order of MFMAs per
+// accumulator as cfg 11: the partials are bit-identical to the round-3 path (tests/test_gpu_kernels.py pins that).
+// (reference op: the ResnetBlock / Upsample convolutions of the latent UNet, generative/networks/nets/diffusion_model_unet.py:589-696)
+#include "conv_dma_shared.h"
+
+__device__ __attribute__((aligned(64))) unsigned int gm_sk_zero_row[16] = {0};  // the source of every padding row
+
+namespace sk {
+constexpr int NW = 8, MF = 2, NFR = 4, KS = 3, G = 3, NGROUPS = 9;
+constexpr int TD = 4, TH = 4, TW = 16, BM = 256, BN = 64;
+constexpr int PD = 6, PH = 6, PW = 18, PLANE = 112, PROWS = PD * PLANE, PPIECES = PROWS / 16, PPW = (PPIECES + NW - 1) / NW;
+constexpr int WROWS = G * BN, WPW = 2;
+constexpr int PATCH_BYTES = PROWS * DMA_ROWB, WBUF_BYTES = WROWS * DMA_ROWB;
+constexpr int AFF_OFF = PATCH_BYTES + NGROUPS * WBUF_BYTES, AFF_WAVE = 256;
+constexpr int LDS_BYTES = AFF_OFF + NW * AFF_WAVE;  // 43 008 + 110 592 + 2 048 = 155 648
+constexpr int PANEL_INSTR = NGROUPS * WPW;           // 18 LDS-DMA instructions per wave behind the patch
+constexpr int LAST_BARRIER_GROUP = 4;                // groups 0..3 wait for their own panel, group 4 for everything that is left
+static_assert(LDS_BYTES <= 160 * 1024, "one work-group per CU");
+}  // namespace sk
+
+template <typename T, bool PRE>
+__global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
+  using namespace sk;
+  constexpr int BK = ConvTraits<T>::BK;
+  constexpr int VECW = ConvTraits<T>::VECW;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch][9 weight panels][8 x (scale | shift) of the chunk]
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  // bench-only (tools/sk_timeline.py, debug_flags bit 12): thread 0 stamps the shader clock at the phase boundaries into 16 slots per work-group
+  // BEHIND the partial sums (the tool allocates them); slots 14 / 15 = the 100 MHz wall clock at entry / after the last store was issued
+  unsigned long long* stamps = nullptr;
+  if ((p.debug_flags & 4096) && tid == 0) {
+    stamps = reinterpret_cast<unsigned long long*>(p.kpartial + (long long)p.ksplit * p.N * p.Do * p.Ho * p.Wo * p.Cout) + (long long)blockIdx.x * 16;
+    stamps[14] = __builtin_amdgcn_s_memrealtime();
+    stamps[0] = __builtin_readcyclecounter();
+  }
+#define SK_STAMP(k) do { if (stamps) stamps[k] = __builtin_readcyclecounter(); } while (0)
+
+  // ---- the work item: (K slice, tile, channel block), dealt to the XCDs in contiguous ranges like conv_dma.hip's work list ----------------
+  const int ntd = (p.Do + TD - 1) / TD, nth = (p.Ho + TH - 1) / TH, ntw = (p.Wo + TW - 1) / TW;
+  const int ncb = (p.Cout + BN - 1) / BN;
+  const int ksplit = p.ksplit;
+  const int nchunks = p.Cin / BK, cout_pad = (p.Cout + 15) & ~15;
+  const int cps = (nchunks + ksplit - 1) / ksplit;
+  const unsigned nwork = (unsigned)p.N * ntd * nth * ntw * ncb * (unsigned)ksplit;
+  const unsigned xcd = blockIdx.x & 7;
+  const unsigned q8 = nwork >> 3, r8 = nwork & 7, cx = q8 + (xcd < r8 ? 1u : 0u), sx = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  if ((blockIdx.x >> 3) >= cx) return;  // (never: the grid is nwork work-groups)
+  unsigned b = sx + (blockIdx.x >> 3);
+  const unsigned tiles_all = nwork / (unsigned)ksplit;
+  const int ks = (int)(b / tiles_all);
+  b -= (unsigned)ks * tiles_all;
+  const int cb = b % ncb; b /= ncb;
+  const int tw_i = b % ntw; b /= ntw;
+  const int th_i = b % nth; b /= nth;
+  const int td_i = b % ntd; b /= ntd;
+  const int n = b;
+  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
+  const int c_begin = min(nchunks, ks * cps), c_end = min(nchunks, c_begin + cps);
+
+  // ---- per-lane LDS-DMA sources (layouts of conv_dma.hip: rows of 64 bytes, the bank swizzle applied on the source side) -------------------
+  const char* zero = reinterpret_cast<const char*>(gm_sk_zero_row);
+  int psw = 0, pvox[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int row = 16 * (wave + NW * j) + (lane >> 2);
+    const int pa = row / PLANE, rr = row - pa * PLANE;
+    const int pb = rr / PW, lc = rr - pb * PW;
+    psw |= dma_swz(lc) << (2 * j);
+    const int ud = od0 - p.pd + pa, uh = oh0 - p.ph + pb, uw = ow0 - p.pw + lc;
+    const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < p.Ds) & (uh >= 0) & (uh < p.Hs) & (uw >= 0) & (uw < p.Ws);
+    pvox[j] = ok ? ((n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
+  }
+  const char* xbase = reinterpret_cast<const char*>(p.x);
+  const char* x2base = reinterpret_cast<const char*>(p.x2);
+  const long long xrowb = p.x_ld * (long long)sizeof(T), x2rowb = p.x2_ld * (long long)sizeof(T);
+  const int nchunks0 = p.x2 ? p.cin_split / BK : nchunks;
+  int wsrc[WPW];  // byte offset of this lane's weight row within a (chunk, group) panel image, -1 beyond cout_pad
+#pragma unroll
+  for (int h = 0; h < WPW; ++h) {
+    const int row = h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2);
+    const int u = row / BN, col = row % BN;
+    const int co = cb * BN + col;
+    wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
+  }
+  const char* wbase = reinterpret_cast<const char*>(p.w);
+
+  // everything a chunk needs, requested back to back: [scale | shift] (PRE), the patch pieces, panels 0 .. 8 (in this order: they land in it)
+  auto issue_chunk = [&](int chunk) __attribute__((always_inline)) {
+    if (PRE) {
+      const int nl = BK / 4;  // lanes 0 .. nl - 1 fetch the chunk's scale, nl .. 2 nl - 1 its shift (16 bytes each) into this wave's own copy
+      if (lane < 2 * nl) {
+        const float* src = (lane < nl ? p.pre_scale : p.pre_shift) + (long long)n * p.Cin + chunk * BK + 4 * (lane < nl ? lane : lane - nl);
+        dma16(src, lds0 + AFF_OFF + (unsigned)wave * AFF_WAVE);
+      }
+    }
+    const bool second = chunk >= nchunks0;  // wave-uniform: the chunk comes from x2 (virtual channel concatenation)
+    const char* cbase = second ? x2base + (long long)(chunk - nchunks0) * (BK * (int)sizeof(T)) : xbase + (long long)chunk * (BK * (int)sizeof(T));
+    const long long rowb = second ? x2rowb : xrowb;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (wave + NW * j < PPIECES) {  // wave-uniform
+        // (both addresses computed, then selected: a conditional 64-bit multiply compiles to a branch per piece)
+        const char* in_src = cbase + (long long)(pvox[j] & ~(pvox[j] >> 31)) * rowb + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4);
+        const char* pad_src = zero + ((lane & 3) << 4);
+        dma16(pvox[j] >= 0 ? in_src : pad_src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NGROUPS; ++g) {
+      const char* panel = wbase + (long long)(chunk * NGROUPS + g) * G * cout_pad * DMA_ROWB;
+      const unsigned dst = lds0 + PATCH_BYTES + (unsigned)g * WBUF_BYTES;
+      const char* s0 = wsrc[0] >= 0 ? panel + wsrc[0] : zero + ((lane & 3) << 4);
+      dma16(s0, dst + (unsigned)(16 * wave) * DMA_ROWB);
+      const char* s1 = wsrc[1] >= 0 ? panel + wsrc[1] : zero + ((lane & 3) << 4);
+      if (lane < 32) dma16(s1, dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
+    }
+  };
+  // GroupNorm-apply + activation IN LDS on this wave's own landed pieces (conv_dma.hip: transform_patch; same arithmetic and rounding as gm_gn_apply)
+  auto transform_patch = [&]() __attribute__((always_inline)) {
+    float sc[VECW], sh[VECW];
+    const float* aff = reinterpret_cast<const float*>(smem + AFF_OFF + wave * AFF_WAVE);
+#pragma unroll
+    for (int i = 0; i < VECW; i += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(aff + (lane & 3) * VECW + i), c = *reinterpret_cast<const float4*>(aff + BK + (lane & 3) * VECW + i);
+      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+      sh[i] = c.x; sh[i + 1] = c.y; sh[i + 2] = c.z; sh[i + 3] = c.w;
+    }
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (wave + NW * j < PPIECES && pvox[j] >= 0) {
+        char* a = smem + (16 * (wave + NW * j) + (lane >> 2)) * DMA_ROWB + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4);
+        float v[VECW];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a), v);
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[i] + sh[i];
+        conv_act_vec(v, p.pre_act, sizeof(T) == 4);
+        *reinterpret_cast<uint4*>(a) = Vec16<T>::pack(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  SK_STAMP(1);
+  if (c_begin < c_end) issue_chunk(c_begin);
+  SK_STAMP(2);
+
+  // ---- operand read addresses (conv_dma.hip: XADDR / WADDR) -----------------------------------------------------------------------------------
+  int xa[KS];
+  {
+    const int m0 = wave * MF * 16 + l15;
+    const int a = m0 >> 6, bb0 = (m0 >> 4) & 3, c = m0 & 15;
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) xa[kw] = (a * PLANE + bb0 * PW + c + kw) * DMA_ROWB + ((q ^ dma_swz(c + kw)) << 4);
+  }
+  const int wa0 = PATCH_BYTES + l15 * DMA_ROWB + ((q ^ dma_swz(l15)) << 4);
+#define SK_XADDR(hk, kw) (xa[kw] + (hk) * (PW * DMA_ROWB))
+#define SK_WADDR(nf) (wa0 + (nf) * (16 * DMA_ROWB))
+  f32x4_t acc[NFR][MF];
+#pragma unroll
+  for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  uint4 xf[2][MF], wf[2][4];
+  auto read_tap = [&](int tap, int set) __attribute__((always_inline)) {
+    const int g = tap / G, u = tap % G;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) wf[set][nf] = *reinterpret_cast<const uint4*>(smem + SK_WADDR(nf) + g * WBUF_BYTES + u * (BN * DMA_ROWB));
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) xf[set][mf] = *reinterpret_cast<const uint4*>(smem + SK_XADDR(mf + kh, kw) + kd * (PLANE * DMA_ROWB));
+  };
+  auto mma_tap = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[set][nf], xf[set][mf], acc[nf][mf]);
+  };
+
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    // the patch (and this wave's scale / shift copy) has landed when only the 18 panel instructions are left in flight
+    dma_wait<PANEL_INSTR>();
+    if (chunk == c_begin) SK_STAMP(3);
+    if (PRE) transform_patch();
+    if (chunk == c_begin) SK_STAMP(4);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int g = tap / G, u = tap % G;
+      if (u == 0 && g <= LAST_BARRIER_GROUP) {  // panel g (and, at group 0, everyone's patch pieces) behind this barrier
+        if (g == 0) dma_wait<PANEL_INSTR - WPW>();
+        else if (g == 1) dma_wait<PANEL_INSTR - 2 * WPW>();
+        else if (g == 2) dma_wait<PANEL_INSTR - 3 * WPW>();
+        else if (g == 3) dma_wait<PANEL_INSTR - 4 * WPW>();
+        else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        if (chunk == c_begin && g == 0) SK_STAMP(5);
+        if (chunk == c_begin && g == LAST_BARRIER_GROUP) SK_STAMP(6);
+        read_tap(tap, tap & 1);
+      }
+      // two operand sets: the next tap's six reads are issued, THEN this tap's MFMAs (whose operands were requested a whole tap earlier).  hipcc
+      // merges the sets and reads right in front of each use unless the order is pinned (sched_barrier: nothing moves across)
+      const bool next_behind_barrier = u == G - 1 && g + 1 <= LAST_BARRIER_GROUP;
+      if (tap + 1 < 27 && !next_behind_barrier) read_tap(tap + 1, (tap + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tap(tap & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (chunk == c_begin) SK_STAMP(7);
+    if (chunk + 1 < c_end) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch and panels
+      issue_chunk(chunk + 1);
+    }
+  }
+
+  // ---- fused 1x1 shortcut convolution: its K chunks ride with the last slice (conv_dma.hip, same LDS staging, same order of MFMAs) -----------
+  if (p.skip_x[0] && ks == ksplit - 1) {
+    const int nsc0 = p.skip_cin[0] / BK, nsc = nsc0 + (p.skip_x[1] ? p.skip_cin[1] / BK : 0);
+    const int pswz = ((lane & 3) ^ dma_swz(lane >> 2)) << 4;
+    int svox[MF];
+#pragma unroll
+    for (int h = 0; h < MF; ++h) {
+      const int m = wave * (MF * 16) + h * 16 + (lane >> 2);
+      const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+      svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
+    }
+    const int wpiece = wave & 3, wcol = wpiece * 16 + (lane >> 2), wco = cb * BN + wcol;
+    const int wswz = ((lane & 3) ^ dma_swz(wcol)) << 4;
+    int caddr[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int m = (wave * MF + mf) * 16 + l15;
+      caddr[mf] = m * DMA_ROWB + ((q ^ dma_swz(m)) << 4);
+    }
+    const char* wsk = reinterpret_cast<const char*>(p.skip_w);
+    for (int sc0 = 0; sc0 < nsc; sc0 += 2) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // patch buffer and panel 0 are free
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int sc = sc0 + j;
+        if (sc < nsc) {  // wave-uniform
+          const int part = sc >= nsc0 ? 1 : 0, cip = sc - (part ? nsc0 : 0);
+          const char* xb = reinterpret_cast<const char*>(p.skip_x[part]) + (long long)cip * (BK * (int)sizeof(T)) + pswz;
+          const long long rowb = p.skip_ld[part] * (long long)sizeof(T);
+#pragma unroll
+          for (int h = 0; h < MF; ++h) {
+            const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
+            dma16(src, lds0 + (unsigned)(j * BM + wave * (MF * 16) + h * 16) * DMA_ROWB);
+          }
+          if ((wave >> 2) == j) {  // waves 0-3 move panel 0, waves 4-7 panel 1
+            const char* src = wco < cout_pad ? wsk + ((long long)sc * cout_pad + wco) * DMA_ROWB + wswz : zero + ((lane & 3) << 4);
+            dma16(src, lds0 + PATCH_BYTES + (unsigned)(j * BN + wpiece * 16) * DMA_ROWB);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (sc0 + j < nsc) {
+          uint4 xs[MF], ws[4];
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) xs[mf] = *reinterpret_cast<const uint4*>(smem + caddr[mf] + j * (BM * DMA_ROWB));
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) ws[nf] = *reinterpret_cast<const uint4*>(smem + SK_WADDR(nf) + j * (BN * DMA_ROWB));
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) Mma<T>::run(ws[nf], xs[mf], acc[nf][mf]);
+        }
+      }
+    }
+  }
+
+  SK_STAMP(8);
+  // ---- this slice's fp32 partial sums -> kpartial[ks][n * V + voxel][Cout] (the combine kernel applies the epilogue) ---------------------------
+  const long long nv = (long long)p.N * p.Do * p.Ho * p.Wo;
+  float* part = p.kpartial + (long long)ks * nv * p.Cout;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = (wave * MF + mf) * 16 + l15;
+    const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+    if (od < p.Do && oh < p.Ho && ow < p.Wo) {
+      float* row = part + ((((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout;
+#pragma unroll
+      for (int nf = 0; nf < NFR; ++nf) {
+        const int co = cb * BN + nf * 16 + q * 4;
+        if (co < p.Cout)  // host-checked: Cout % 4 == 0
+          *reinterpret_cast<float4*>(row + co) = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
+      }
+    }
+  }
+  SK_STAMP(9);
+  if (stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (thread 0's own stores have left)
+    stamps[10] = __builtin_readcyclecounter();
+    stamps[15] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+#undef SK_STAMP
+#undef SK_XADDR
+#undef SK_WADDR
+
+// process-wide switch (A/B measurements and the bitwise test against conv_dma.hip's slices); results do not depend on it
+static int g_sk_enabled = 1;
+extern "C" void gm_conv_sk_set_enabled(int on) { g_sk_enabled = on; }
+
+// a split-K launch this kernel takes: cfg 11 geometry (gm_conv_dma_eligible has been checked by the caller), direct input mode
+extern "C" int gm_conv_sk_eligible(const GmConvDesc* d) {
+  return g_sk_enabled && d->cfg == 11 && d->ksplit > 1 && d->kpartial != nullptr && d->in_mode == 0 && d->kd == 3 && d->kh == 3 && d->kw == 3 &&
+         d->sd == 1 && d->sh == 1 && d->sw == 1 && d->ltd == 2 && d->lth == 2 && d->ltw == 4 && (d->dtype == GM_F32 || d->dtype == GM_BF16) &&
+         (d->pre_scale == nullptr || d->pre_shift != nullptr);
+}
+
+template <typename T, bool PRE>
+static void launch_sk(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_sk_kernel<T, PRE>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();
+    attr_set = true;
+  }
+  kern<<<dim3(nblocks), 512, (size_t)sk::LDS_BYTES, st>>>(d);
+}
+
+extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const bool pre = dp->pre_scale != nullptr;
+  if (dp->dtype == GM_F32) { if (pre) launch_sk<float, true>(*dp, nblocks, st); else launch_sk<float, false>(*dp, nblocks, st); return 0; }
+  if (dp->dtype == GM_BF16) { if (pre) launch_sk<bf16_raw, true>(*dp, nblocks, st); else launch_sk<bf16_raw, false>(*dp, nblocks, st); return 0; }
+  return -2;
+}

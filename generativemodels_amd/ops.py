@@ -688,6 +688,7 @@ SPLITK = os.environ.get("GM_CONV_SPLITK", "1") != "0"
 SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups than this ...
 SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "512"))  # ... into as many slices as it takes to reach about this many (two per CU)
 SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
+_SK_KERNEL = os.environ.get("GM_CONV_SK")  # "0": the slices on the general cfg 11 tile kernel (round-3 path) instead of conv_sk.hip -- A/B measurements only
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 21, 22)
 # cfg 21 (csrc/conv_mw.hip): bf16 3x3x3 stride-1 convolutions without a fused prologue on 16-channel half-chunks + v_mfma_f32_32x32x16_bf16, three
 # work-groups per CU; "1" prefers it over cfg 14 wherever it is eligible and the grid fills the chip, "0" keeps cfg 14
@@ -794,6 +795,7 @@ COUT1_MARCH_LTD = os.environ.get("GM_CONV_COUT1_LTD")  # bench only: pin the dep
 
 
 _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
+_SK_STAMPS = None  # tools/sk_timeline.py: the stamp table of the last split-K launch (debug_flags bit 12)
 _CONV_TIMELINE_BUFFER = None  # tools/conv_timeline.py (bench-only -DGM_CONV_TIMELINE build): int64 [work-groups, 64] stamp table
 
 SMALL_LINEAR_ROWS = 64       # 1x1 "convolutions" over at most this many rows take gm_linear_rows
@@ -1256,10 +1258,14 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
         if ks > 1:
             ks = -(-nchunks // -(-nchunks // ks))  # ceil(nchunks / chunks per slice): 12 chunks over "8" slices = 6 slices of 2, none empty
         if ks > 1:
+            if _SK_KERNEL is not None:
+                lib().gm_conv_sk_set_enabled(int(_SK_KERNEL))
             d.ksplit = int(ks)
             nbytes = lib().gm_conv_splitk_workspace_bytes(C.byref(d))
             if nbytes > 0:
-                kpart = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)  # stream-ordered scratch: freed on return
+                stamp_room = (1 << 16) * 4 if (_CONV_DEBUG_FLAGS & 4096) else 0  # tools/sk_timeline.py: 16 int64 stamps per work-group behind the partials
+                kpart = torch.zeros(nbytes // 4 + stamp_room, dtype=torch.float32, device=x.device) if stamp_room else \
+                    torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)  # stream-ordered scratch: freed on return
                 d.kpartial = kpart.data_ptr()
             elif ksplit is not None:
                 raise ValueError(f"split-K by {ks} is not available for this convolution")
@@ -1284,6 +1290,9 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                lambda: check(lib().gm_conv_forward(C.byref(d), _stream()), "gm_conv_forward"))
     if d.stats:
         out._gm_cstats = _compact_stats(out._gm_cstats)
+    if kpart is not None and (_CONV_DEBUG_FLAGS & 4096):
+        global _SK_STAMPS
+        _SK_STAMPS = kpart[kpart.numel() - (1 << 18):].view(torch.int64).reshape(-1, 16).clone()
     return out
 
 

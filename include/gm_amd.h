@@ -211,6 +211,10 @@ void gm_conv_dma_set_persistent(int max_work_groups);
 /* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
  * software-pipelined over the taps (bench A/B: slower at 128 registers). */
 void gm_conv_w8_set_pipe2(int on);
+/* Kernel of the K slices of a split-K launch (process-wide; results do not depend on it: the partial sums are bit-identical): 1 (default) =
+ * conv_sk.hip (one work-group per CU, the patch and all nine weight panels of a K chunk requested up front); 0 = the general cfg 11 tile kernel
+ * (the round-3 path; A/B measurements and the bitwise test). */
+void gm_conv_sk_set_enabled(int on);
 long long gm_packed_conv_weight_elems(int Cout, int Cin, int kd, int kh, int kw, int dtype);
 /* src: [Cout][Cin][kd][kh][kw] (transposed = 0) or [Cin][Cout][kd][kh][kw] (transposed = 1, nn.ConvTransposeNd) */
 int gm_pack_conv_weight(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin, int kd, int kh, int kw,

@@ -497,6 +497,7 @@ def test_conv_split_k_for_small_grids(case, ksplit, dtype):
     """GmConvDesc.ksplit: the K chunks of a small-grid 3x3x3 convolution dealt to several work-groups per tile + the combine kernel (sum of
     the fp32 slices, bias / timestep row / residual or fused shortcut, output statistics) against the unsplit kernel and fp64 -- with the
     in-LDS prologue and a two-part (virtual concat) input as well; also the automatic choice (ops.SPLITK_MAX_TILES)."""
+    from generativemodels_amd._native import lib
     ops = _ops()
     name, cin, cout, split, sp, mode, n = case
     es = 4 if dtype == torch.float32 else 2
@@ -532,8 +533,15 @@ def test_conv_split_k_for_small_grids(case, ksplit, dtype):
         whole = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=11, ksplit=1, **kw)
         sliced = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=11, ksplit=ksplit, **kw)
         auto = ops.conv(operand, w.to(DEV), b.to(DEV), **kw)
+        # the slices run on conv_sk.hip (a chunk's patch + all nine panels requested up front, one work-group per CU); the general tile kernel's
+        # slices (round 3) accumulate in the same order: the two must agree bit for bit, statistics included
+        lib().gm_conv_sk_set_enabled(0)
+        general = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=11, ksplit=ksplit, **kw)
     finally:
+        lib().gm_conv_sk_set_enabled(1)
         ops.DMA_FUSED_PROLOGUE = keep
+    assert torch.equal(sliced, general), f"slice kernels differ: {(sliced.float() - general.float()).abs().max().item():.3e}"
+    assert torch.equal(sliced._gm_cstats, general._gm_cstats)
     _check(_cf(whole), want, dtype, f"unsplit {name}", extra=2.0)
     _check(_cf(sliced), want, dtype, f"split-K {name} x{ksplit}", extra=2.0)
     _check(_cf(auto), want, dtype, f"automatic {name}", extra=2.0)

@@ -32,3 +32,8 @@ tot = sum(v[1] for v in agg.values())
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{v[1]:8.3f} ms  x{v[0]:3d}  avg {1e3 * v[1] / v[0]:7.1f} us  {k}")
 print("sum of profiled launches %.3f ms over %d launches" % (tot, sum(v[0] for v in agg.values())))
+if os.environ.get("GM_C3_PER_LAUNCH", "1") != "0":  # every launch in order, with its shape: which level the latency sits on
+    print("-- per launch")
+    for name, meta, ms in rec:
+        tf = meta.get("flops", 0.0) / max(ms, 1e-9) / 1e9
+        print(f"{1e3 * ms:8.1f} us {tf:8.1f} TF/s  {name:34s} {meta.get('shape', '')}")
