@@ -6,8 +6,10 @@
 // the multi-tile walk and an epilogue it does not need -- 24 us per launch for ~3 us of arithmetic (profiles/r04_c3_layers.txt).
 // Here a work-group owns its CU (1 work-group of 8 waves per CU: the grid is at most one wave of work-groups) and spends the LDS on latency:
 //   * the patch (42 KiB) and ALL NINE weight panels of a chunk (108 KiB) are requested back to back before anything waits: one exposed round
-//     trip per chunk instead of nine; the panels land in request order, so group g starts behind `s_waitcnt vmcnt(16 - 2 g)` + a barrier while
-//     the later panels are still in flight, and from group 4 on nothing waits at all;
+//     trip per chunk instead of nine.  Request order per wave: panels 0-2 (they need the K slice and the channel block of the work item only: the
+//     ~3 k cycles of patch placement arithmetic run under their flight), the patch, panels 3-8; everything lands in request order, so the tap
+//     groups start behind counted `s_waitcnt vmcnt(N)` + a barrier while the later panels are still in flight (barriers in front of groups
+//     0, 3, 4 only), and the panel pieces are requested with a scalar base + 32-bit lane offset (no 64-bit VALU address arithmetic);
 //   * the fused GroupNorm + SiLU prologue takes its scale / shift from a 256-byte LDS copy that every wave requests AHEAD of its patch pieces
 //     (an ordinary global load would make hipcc wait for `vmcnt(0)` -- every panel -- at its first use);
 //   * no tile walk, no epilogue: the partial sums go from the accumulators to kpartial exactly as conv_dma.hip's slices wrote them.
@@ -18,6 +20,19 @@
 
 __device__ __attribute__((aligned(64))) unsigned int gm_sk_zero_row[16] = {0};  // the source of every padding row
 
+// one LDS-DMA piece with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit address arithmetic on the VALU
+// (8 waves x 18 panel pieces of a chunk: the requests, not their addresses, should bound the issue phase)
+__device__ __forceinline__ void dma16_base(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned long long a = (unsigned long long)sbase;  // (made uniform explicitly: an "s" operand the divergence analysis cannot prove uniform is
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));  // handed over in
+  const unsigned long long sb = ((unsigned long long)hi << 32) | lo;  // VGPRs; the builtin returns int: widened unsigned, or bit 31 of the low half smears into the high one)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sb), "s"(lds_dst)
+               : "memory");
+}
+
 namespace sk {
 constexpr int NW = 8, MF = 2, NFR = 4, KS = 3, G = 3, NGROUPS = 9;
 constexpr int TD = 4, TH = 4, TW = 16, BM = 256, BN = 64;
@@ -26,8 +41,11 @@ constexpr int WROWS = G * BN, WPW = 2;
 constexpr int PATCH_BYTES = PROWS * DMA_ROWB, WBUF_BYTES = WROWS * DMA_ROWB;
 constexpr int AFF_OFF = PATCH_BYTES + NGROUPS * WBUF_BYTES, AFF_WAVE = 256;
 constexpr int LDS_BYTES = AFF_OFF + NW * AFF_WAVE;  // 43 008 + 110 592 + 2 048 = 155 648
-constexpr int PANEL_INSTR = NGROUPS * WPW;           // 18 LDS-DMA instructions per wave behind the patch
-constexpr int LAST_BARRIER_GROUP = 4;                // groups 0..3 wait for their own panel, group 4 for everything that is left
+// request order of a chunk, per wave: panels 0 .. FIRST-1 (they need the channel block and the K slice of the work item only), [scale | shift],
+// the patch pieces (they need the whole placement: ~3 k cycles of index arithmetic that now run under the first panels' flight), panels FIRST .. 8
+constexpr int FIRST = 3;
+constexpr int AFTER_PATCH = (NGROUPS - FIRST) * WPW;  // LDS-DMA instructions per wave behind the patch: 12
+constexpr int LAST_BARRIER_GROUP = 4;                // group 0 waits for the patch, groups FIRST .. 3 for their own panel, group 4 for everything that is left
 static_assert(LDS_BYTES <= 160 * 1024, "one work-group per CU");
 }  // namespace sk
 
@@ -62,18 +80,43 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
   if ((blockIdx.x >> 3) >= cx) return;  // (never: the grid is nwork work-groups)
   unsigned b = sx + (blockIdx.x >> 3);
   const unsigned tiles_all = nwork / (unsigned)ksplit;
-  const int ks = (int)(b / tiles_all);
+  // (the digits of a work item are wave-uniform; hipcc does the divisions on the VALU and then treats everything derived from them as divergent --
+  // readfirstlane puts them, and the address arithmetic that follows, back on the scalar unit)
+  const int ks = __builtin_amdgcn_readfirstlane((int)(b / tiles_all));
   b -= (unsigned)ks * tiles_all;
-  const int cb = b % ncb; b /= ncb;
-  const int tw_i = b % ntw; b /= ntw;
-  const int th_i = b % nth; b /= nth;
-  const int td_i = b % ntd; b /= ntd;
-  const int n = b;
-  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
+  const int cb = __builtin_amdgcn_readfirstlane((int)(b % ncb)); b /= ncb;
   const int c_begin = min(nchunks, ks * cps), c_end = min(nchunks, c_begin + cps);
 
-  // ---- per-lane LDS-DMA sources (layouts of conv_dma.hip: rows of 64 bytes, the bank swizzle applied on the source side) -------------------
+  // ---- weight panels: per-lane byte offset within a (chunk, group) panel image; a row beyond cout_pad reads the last row instead (its products
+  // land in accumulator rows that are never stored) ------------------------------------------------------------------------------------------
   const char* zero = reinterpret_cast<const char*>(gm_sk_zero_row);
+  unsigned wsrc[WPW];
+#pragma unroll
+  for (int h = 0; h < WPW; ++h) {
+    const int row = h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2);
+    const int u = row / BN, col = row % BN;
+    const int co = min(cb * BN + col, cout_pad - 1);
+    wsrc[h] = (unsigned)((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4));
+  }
+  const char* wbase = reinterpret_cast<const char*>(p.w);
+  auto issue_panels = [&](int chunk, int g0, int g1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = g0; g < g1; ++g) {
+      const char* panel = wbase + (long long)(chunk * NGROUPS + g) * G * cout_pad * DMA_ROWB;  // wave-uniform
+      const unsigned dst = lds0 + PATCH_BYTES + (unsigned)g * WBUF_BYTES;
+      dma16_base(panel, wsrc[0], dst + (unsigned)(16 * wave) * DMA_ROWB);
+      if (lane < 32) dma16_base(panel, wsrc[1], dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
+    }
+  };
+  if (c_begin < c_end) issue_panels(c_begin, 0, FIRST);
+  SK_STAMP(1);
+
+  // ---- the tile, and the patch rows of this lane (layouts of conv_dma.hip: rows of 64 bytes, the bank swizzle applied on the source side) ------
+  const int tw_i = __builtin_amdgcn_readfirstlane((int)(b % ntw)); b /= ntw;
+  const int th_i = __builtin_amdgcn_readfirstlane((int)(b % nth)); b /= nth;
+  const int td_i = __builtin_amdgcn_readfirstlane((int)(b % ntd)); b /= ntd;
+  const int n = __builtin_amdgcn_readfirstlane((int)b);
+  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
   int psw = 0, pvox[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
@@ -89,18 +132,9 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
   const char* x2base = reinterpret_cast<const char*>(p.x2);
   const long long xrowb = p.x_ld * (long long)sizeof(T), x2rowb = p.x2_ld * (long long)sizeof(T);
   const int nchunks0 = p.x2 ? p.cin_split / BK : nchunks;
-  int wsrc[WPW];  // byte offset of this lane's weight row within a (chunk, group) panel image, -1 beyond cout_pad
-#pragma unroll
-  for (int h = 0; h < WPW; ++h) {
-    const int row = h == 0 ? 16 * wave + (lane >> 2) : 128 + 8 * wave + ((lane & 31) >> 2);
-    const int u = row / BN, col = row % BN;
-    const int co = cb * BN + col;
-    wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane & 3) ^ dma_swz(row)) << 4)) : -1;
-  }
-  const char* wbase = reinterpret_cast<const char*>(p.w);
 
-  // everything a chunk needs, requested back to back: [scale | shift] (PRE), the patch pieces, panels 0 .. 8 (in this order: they land in it)
-  auto issue_chunk = [&](int chunk) __attribute__((always_inline)) {
+  // [scale | shift] (PRE) and the patch pieces of a chunk
+  auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
     if (PRE) {
       const int nl = BK / 4;  // lanes 0 .. nl - 1 fetch the chunk's scale, nl .. 2 nl - 1 its shift (16 bytes each) into this wave's own copy
       if (lane < 2 * nl) {
@@ -119,15 +153,6 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
         const char* pad_src = zero + ((lane & 3) << 4);
         dma16(pvox[j] >= 0 ? in_src : pad_src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
       }
-    }
-#pragma unroll
-    for (int g = 0; g < NGROUPS; ++g) {
-      const char* panel = wbase + (long long)(chunk * NGROUPS + g) * G * cout_pad * DMA_ROWB;
-      const unsigned dst = lds0 + PATCH_BYTES + (unsigned)g * WBUF_BYTES;
-      const char* s0 = wsrc[0] >= 0 ? panel + wsrc[0] : zero + ((lane & 3) << 4);
-      dma16(s0, dst + (unsigned)(16 * wave) * DMA_ROWB);
-      const char* s1 = wsrc[1] >= 0 ? panel + wsrc[1] : zero + ((lane & 3) << 4);
-      if (lane < 32) dma16(s1, dst + (unsigned)(128 + 8 * wave) * DMA_ROWB);
     }
   };
   // GroupNorm-apply + activation IN LDS on this wave's own landed pieces (conv_dma.hip: transform_patch; same arithmetic and rounding as gm_gn_apply)
@@ -155,8 +180,10 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
-  SK_STAMP(1);
-  if (c_begin < c_end) issue_chunk(c_begin);
+  if (c_begin < c_end) {
+    issue_patch(c_begin);
+    issue_panels(c_begin, FIRST, NGROUPS);
+  }
   SK_STAMP(2);
 
   // ---- operand read addresses (conv_dma.hip: XADDR / WADDR) -----------------------------------------------------------------------------------
@@ -193,20 +220,22 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
   };
 
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
-    // the patch (and this wave's scale / shift copy) has landed when only the 18 panel instructions are left in flight
-    dma_wait<PANEL_INSTR>();
+    // the patch, this wave's scale / shift copy and panels 0 .. FIRST-1 have landed when only the AFTER_PATCH later panel instructions are in flight
+    dma_wait<AFTER_PATCH>();
     if (chunk == c_begin) SK_STAMP(3);
     if (PRE) transform_patch();
     if (chunk == c_begin) SK_STAMP(4);
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int g = tap / G, u = tap % G;
-      if (u == 0 && g <= LAST_BARRIER_GROUP) {  // panel g (and, at group 0, everyone's patch pieces) behind this barrier
-        if (g == 0) dma_wait<PANEL_INSTR - WPW>();
-        else if (g == 1) dma_wait<PANEL_INSTR - 2 * WPW>();
-        else if (g == 2) dma_wait<PANEL_INSTR - 3 * WPW>();
-        else if (g == 3) dma_wait<PANEL_INSTR - 4 * WPW>();
+      // a barrier in front of group 0 (everyone's patch pieces and first panels), of groups FIRST .. 3 (their own panel: the later ones stay in
+      // flight) and of group 4 (everything that is left); no other group waits
+      const bool barrier_here = u == 0 && (g == 0 || (g >= FIRST && g <= LAST_BARRIER_GROUP));
+      if (barrier_here) {
+        if (g == 0) dma_wait<AFTER_PATCH>();
+        else if (g == 3) dma_wait<(NGROUPS - 1 - 3) * WPW>();
         else dma_wait<0>();
+        static_assert(FIRST == 3 && LAST_BARRIER_GROUP == 4, "the wait counts above are written for panels 0-2 ahead of the patch");
         __builtin_amdgcn_s_barrier();
         if (chunk == c_begin && g == 0) SK_STAMP(5);
         if (chunk == c_begin && g == LAST_BARRIER_GROUP) SK_STAMP(6);
@@ -214,7 +243,8 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
       }
       // two operand sets: the next tap's six reads are issued, THEN this tap's MFMAs (whose operands were requested a whole tap earlier).  hipcc
       // merges the sets and reads right in front of each use unless the order is pinned (sched_barrier: nothing moves across)
-      const bool next_behind_barrier = u == G - 1 && g + 1 <= LAST_BARRIER_GROUP;
+      const int gn = (tap + 1) / G;
+      const bool next_behind_barrier = u == G - 1 && gn >= FIRST && gn <= LAST_BARRIER_GROUP;
       if (tap + 1 < 27 && !next_behind_barrier) read_tap(tap + 1, (tap + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
       mma_tap(tap & 1);
@@ -224,7 +254,9 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
     if (chunk + 1 < c_end) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch and panels
-      issue_chunk(chunk + 1);
+      issue_panels(chunk + 1, 0, FIRST);
+      issue_patch(chunk + 1);
+      issue_panels(chunk + 1, FIRST, NGROUPS);
     }
   }
 

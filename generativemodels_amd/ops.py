@@ -686,7 +686,9 @@ DMA_FUSED_PROLOGUE_MAX_FLOP = 3.0e10
 # kernel sums the fp32 partials and applies the epilogue.
 SPLITK = os.environ.get("GM_CONV_SPLITK", "1") != "0"
 SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups than this ...
-SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "512"))  # ... into as many slices as it takes to reach about this many (two per CU)
+# ... into as many slices as it takes to reach about this many.  One per CU: a slice work-group of conv_sk.hip owns its CU's LDS, so a second wave of
+# work-groups runs after the first (round 3, two per CU on the general tile kernel: 512; measured on the C3 latent UNet: 1.657 vs 1.678 ms per forward)
+SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "256"))
 SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
 _SK_KERNEL = os.environ.get("GM_CONV_SK")  # "0": the slices on the general cfg 11 tile kernel (round-3 path) instead of conv_sk.hip -- A/B measurements only
 DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 21, 22)

@@ -48,7 +48,8 @@ def _worker(rank, world, port, n_units, q):
         ids, outs = parallel.sample_units(_fake_sampler, n_units, (1, 1, 4, 4, 4), base_seed=7, rank=rank, world_size=world)
         allv = parallel.gather_units(ids, outs, n_units)
         if rank == 0:
-            q.put((ids, [v.clone() for v in allv]))
+            # by value (numpy): a tensor goes through the queue as a shared-memory handle, and this process may be gone before the parent opens it
+            q.put((ids, [v.numpy().copy() for v in allv]))
         else:
             assert allv is None
             q.put((ids, None))
@@ -82,7 +83,7 @@ def test_two_rank_sampling_matches_single_process():
         assert p.exitcode == 0
     all_ids = sorted(i for ids, _ in results for i in ids)
     assert all_ids == list(range(n_units))  # every volume exactly once
-    gathered = next(v for _, v in results if v is not None)
+    gathered = [torch.from_numpy(a) for a in next(v for _, v in results if v is not None)]
     ids1, ref = parallel.sample_units(_fake_sampler, n_units, (1, 1, 4, 4, 4), base_seed=7, rank=0, world_size=1)
     assert ids1 == list(range(n_units))
     for a, b in zip(gathered, ref):
@@ -108,7 +109,7 @@ def test_eight_rank_sampling_with_uneven_unit_counts_matches_single_process(n_un
     sizes = sorted(len(ids) for ids, _ in results)
     assert sizes[-1] - sizes[0] <= 1 and sum(sizes) == n_units
     assert sorted(i for ids, _ in results for i in ids) == list(range(n_units))
-    gathered = next(v for _, v in results if v is not None)
+    gathered = [torch.from_numpy(a) for a in next(v for _, v in results if v is not None)]
     _, ref = parallel.sample_units(_fake_sampler, n_units, (1, 1, 4, 4, 4), base_seed=7, rank=0, world_size=1)
     assert len(gathered) == n_units
     for a, b in zip(gathered, ref):
