@@ -134,9 +134,37 @@ def main():
     red3.close()
     from generativemodels_amd import parallel as P
     assert id(w) not in P._DIRECT_GRAD
+    # ---- static_graph=True: step 1 learns the used set, step 2 records the arrival order, from step 3 on one hook per bucket is left and no
+    #      usage mask is exchanged; gradients stay bitwise those of the plain replica (the in-place fp32 path from step 2 on) ----
+    red.close()
+    stat = build()
+    red4 = GradientReducer(stat.parameters(), bucket_mb=0.25, force=True, static_graph=True)
+    nparam = sum(1 for p_ in stat.parameters() if p_.requires_grad)
+    hooks = []
+    for step in range(4):
+        x = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+        noise = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+        t = torch.randint(0, 1000, (2,), generator=g).to(dev)
+        for p_ in plain.parameters():
+            p_.grad = None
+        red4.zero_grad()
+        for m in (plain, stat):
+            F.mse_loss(inferer(inputs=x, diffusion_model=m, noise=noise, timesteps=t).float(), noise.float()).backward()
+        red4.finish()
+        torch.cuda.synchronize()
+        hooks.append(len(red4._hook_handles))
+        for (name, a), b in zip(plain.named_parameters(), stat.parameters()):
+            if a.grad is None:
+                assert b.grad is None, name
+                continue
+            assert torch.equal(a.grad, b.grad), f"static graph, step {step}: gradient of {name} differs"
+        if step >= 1:
+            assert red4.launched_in_backward == len(red4.buckets), (step, red4.launched_in_backward)
+    assert hooks[0] == nparam and hooks[1] == hooks[2] == hooks[3] <= len(red4.buckets), hooks
+    red4.close()
     dist.barrier()
     dist.destroy_process_group()
-    print(f"RCCL_WORKER_OK buckets={len(red.buckets)} overlapped_per_step={overlapped} graphed_steps=2")
+    print(f"RCCL_WORKER_OK buckets={len(red.buckets)} overlapped_per_step={overlapped} graphed_steps=2 static_graph_hooks={hooks}")
 
 
 if __name__ == "__main__":

@@ -266,3 +266,104 @@ def test_eight_rank_gradient_all_reduce_with_uneven_shards_matches_the_average_o
                     assert g is None
                 else:
                     assert g is not None and torch.allclose(torch.from_numpy(g), w, atol=1e-6), (rank, (torch.from_numpy(g) - w).abs().max())
+
+
+def _static_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import torch.nn as nn
+    from generativemodels_amd.parallel import GradientReducer, shard_range
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        model = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 3))
+        unused = nn.Linear(4, 4)  # never applied
+        params = list(model.parameters()) + list(unused.parameters())
+        red = GradientReducer(params, bucket_mb=0.0005, static_graph=True)
+        nrows = 8
+        data = torch.randn(nrows, 6, generator=torch.Generator().manual_seed(5))
+        target = torch.randn(nrows, 3, generator=torch.Generator().manual_seed(6))
+        lo, hi = shard_range(nrows, rank, world)
+        hooks, overlapped, grads = [], [], []
+        for step in range(5):
+            red.zero_grad()
+            with torch.no_grad():  # the parameters move between steps: a stale bucket would show
+                for p in model.parameters():
+                    p.add_(0.01 * (step + 1))
+            torch.nn.functional.mse_loss(model(data[lo:hi]), target[lo:hi]).backward()
+            red.finish()
+            hooks.append(len(red._hook_handles))
+            overlapped.append(red.launched_in_backward)
+            grads.append([None if p.grad is None else p.grad.detach().numpy().copy() for p in params])
+        # accumulation under no_sync still works with one hook per bucket
+        mid = (lo + hi) // 2
+        red.zero_grad()
+        wa, wb = (mid - lo) / (hi - lo), (hi - mid) / (hi - lo)
+        with red.no_sync():
+            (wa * torch.nn.functional.mse_loss(model(data[lo:mid]), target[lo:mid])).backward()
+        (wb * torch.nn.functional.mse_loss(model(data[mid:hi]), target[mid:hi])).backward()
+        red.finish()
+        acc = [None if p.grad is None else p.grad.detach().numpy().copy() for p in params]
+        # a replaced .grad (set_to_none) is adopted back by the bucket hook
+        for p in params:
+            p.grad = None
+        torch.nn.functional.mse_loss(model(data[lo:hi]), target[lo:hi]).backward()
+        red.finish()
+        none_grads = [None if p.grad is None else p.grad.detach().numpy().copy() for p in params]
+        # the promise broken: the never-used layer suddenly takes part
+        red.zero_grad()
+        (torch.nn.functional.mse_loss(model(data[lo:hi]), target[lo:hi]) + unused(torch.ones(1, 4)).sum()).backward()
+        try:
+            red.finish()
+            raised = False
+        except RuntimeError:
+            raised = True
+        q.put((rank, hooks, overlapped, grads, acc, none_grads, raised, len(red.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+@_retry_once
+def test_two_rank_static_graph_reducer_keeps_one_hook_per_bucket():
+    """GradientReducer(static_graph=True): step 1 learns the used set, step 2 records the arrival order, from step 3 on one hook per bucket
+    is left and no usage mask is exchanged -- the gradients stay the full-batch gradients at every step, accumulation under no_sync and a
+    `.grad = None` reset still work, and a parameter outside the learned set that produces a gradient makes finish() raise."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    import torch.nn as nn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_static_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(3)
+    model = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 3))
+    data = torch.randn(8, 6, generator=torch.Generator().manual_seed(5))
+    target = torch.randn(8, 3, generator=torch.Generator().manual_seed(6))
+    nparams = len(list(model.parameters()))
+    want = []
+    for step in range(5):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.01 * (step + 1))
+        model.zero_grad()
+        torch.nn.functional.mse_loss(model(data), target).backward()
+        want.append([p.grad.numpy().copy() for p in model.parameters()])
+    for rank in (0, 1):
+        hooks, overlapped, grads, acc, none_grads, raised, nbuckets = got[rank]
+        # (counted after finish(): the first step ends with the per-parameter hooks, the second -- the recorded one -- already with one per non-empty bucket)
+        assert hooks[0] == nparams + 2 and hooks[1] == hooks[2] == hooks[3] == hooks[4] < nparams
+        assert hooks[1] <= nbuckets and overlapped[1] == overlapped[2] == overlapped[3] == overlapped[4] == nbuckets
+        for step in range(5):
+            for g, w in zip(grads[step][:nparams], want[step]):
+                assert np.allclose(g, w, rtol=1e-5, atol=1e-6), (rank, step)
+            assert all(g is None for g in grads[step][nparams:])  # the never-used layer keeps grad = None
+        for g, w in zip(acc[:nparams], want[4]):
+            assert np.allclose(g, w, rtol=1e-5, atol=1e-6)
+        for g, w in zip(none_grads[:nparams], want[4]):
+            assert np.allclose(g, w, rtol=1e-5, atol=1e-6)
+        assert raised

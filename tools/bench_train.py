@@ -61,7 +61,13 @@ unet = unet.to(dev, dt)
 sched = DDPMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205)
 inf = LatentDiffusionInferer(sched, scale_factor=1.0)
 opt = torch.optim.Adam(unet.parameters(), lr=1e-5)
-red = GradientReducer(unet.parameters(), force=force_reducer, usage_check_every=int(os.environ.get("GM_REDUCER_USAGE_EVERY", "1")))
+red = GradientReducer(unet.parameters(), force=force_reducer, usage_check_every=int(os.environ.get("GM_REDUCER_USAGE_EVERY", "1")),
+                      static_graph=os.environ.get("GM_REDUCER_STATIC", "0") == "1")
+if os.environ.get("GM_REDUCER_NO_COLLECTIVE", "0") == "1":  # diagnosis only: the bucket / hook machinery without the RCCL launches (what part of the
+    class _Done:                                              # one-rank tax is the collective kernels sharing the GPU with backward)
+        def wait(self):
+            pass
+    red._launch = lambda i: red._work.__setitem__(i, _Done())
 g = torch.Generator().manual_seed(100 + rank)
 imgs = torch.randn((batch, 1, size, size, size), generator=g).to(dev, dt)
 lat = size // 8
