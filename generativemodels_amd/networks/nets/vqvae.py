@@ -226,9 +226,6 @@ class VQVAE(nn.Module):
         from ... import autograd as A
 
         ops.require_device(x)
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("VQVAE training with dropout > 0 is not implemented (the fused convolution epilogues have no dropout mask); "
-                                      "construct the model with dropout=0")
         dt = ops.compute_dtype(self._dtype())
         if x.dtype != dt:
             if ops.autocast_dtype() is None:
