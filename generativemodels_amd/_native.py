@@ -154,7 +154,8 @@ PROTOTYPES = {
     "gm_softmax_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_float, c_vp]),
     "gm_vq_argmin": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_vq_gather_workspace_bytes": (c_ll, []),
-    "gm_vq_ema_stats": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, c_vp, C.c_int, c_vp]),
+    "gm_vq_ema_stats_workspace_elems": (c_ll, [c_ll, C.c_int, C.c_int]),
+    "gm_vq_ema_stats": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, c_vp, c_vp, C.c_int, c_vp]),
     "gm_vq_ema_update": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_float, C.c_float, c_vp]),
     "gm_vq_gather": (C.c_int, [c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, c_vp]),
 }

@@ -121,65 +121,103 @@ extern "C" int gm_vq_gather(const long long* indices, const float* embedding, vo
 // EMA codebook update of EMAQuantizer.forward in training mode (reference: networks/layers/vector_quantizer.py:166-180).
 //   gm_vq_ema_stats : stats[e] = number of tokens assigned to code e, stats[K + e*D + d] = sum of their vectors ("encodings_sum" and
 //                     "dw" of the reference, :168-169) -- ONE flat fp32 buffer, so that data-parallel ranks exchange it with ONE
-//                     all-reduce instead of the reference's two (:155-157).  One work-group per code scans the indices; per-thread
-//                     partial sums are merged in a fixed tree order: deterministic.
+//                     all-reduce instead of the reference's two (:155-157).  Two passes over a workspace of per-range partial tables (below):
+//                     every index and every vector is read once; deterministic (no atomics: exclusive accumulator ownership, fixed orders).
 //   gm_vq_ema_update: ema_cluster_size = decay * ema_cluster_size + (1 - decay) * counts; Laplace-smoothed weights; ema_w likewise;
 //                     embedding = ema_w / weights (:173-180).  One work-group (the codebook is K x D <= a few hundred thousand floats).
 // ---------------------------------------------------------------------------------------------------------------------
 #define VQ_EMA_THREADS 256
-#define VQ_EMA_DCHUNK 32
+#define VQ_EMA_RANGE 1024        // tokens per work-group of the partial pass (fewer, longer ranges above VQ_EMA_MAX_BLOCKS)
+#define VQ_EMA_MAX_BLOCKS 1024
+#define VQ_EMA_LDS_FLOATS 12288  // 48 KiB of per-code accumulators per work-group: codes are dealt to grid.y in chunks of this many / (D + 1)
+// Pass 1 (round 4; rounds 1-3 ran one work-group per CODE that scanned every index 1 + D/32 times: O(K x tokens x D/32) index reads): a work-group
+// owns a RANGE of tokens and a chunk of codes, walks its tokens ONCE in index order and adds each vector into the LDS accumulator row of its code.
+// Ownership makes it deterministic without atomics: thread (g, d0) owns the accumulators (code e, dim d) with e % G == g and d % DT == d0
+// (DT = 64-thread-aligned power of two <= D, G = 256 / DT), so every accumulator is written by exactly one thread, in token order.  The partial
+// tables [block][K x (D + 1)] are summed in block order by pass 2.
 template <typename T>
-__global__ __launch_bounds__(VQ_EMA_THREADS) void vq_ema_stats_kernel(const T* __restrict__ x, long long x_ld, const long long* __restrict__ idx,
-                                                                     long long tokens, int K, int D, float* __restrict__ stats) {
-  __shared__ float red[VQ_EMA_THREADS];
-  const int e = blockIdx.x, t = threadIdx.x;
-  auto block_sum = [&](float v) {  // fixed-order tree over the 256 threads
-    red[t] = v;
-    __syncthreads();
-    for (int s = VQ_EMA_THREADS / 2; s > 0; s >>= 1) {
-      if (t < s) red[t] += red[t + s];
-      __syncthreads();
+__global__ __launch_bounds__(VQ_EMA_THREADS) void vq_ema_partial_kernel(const T* __restrict__ x, long long x_ld, const long long* __restrict__ idx,
+                                                                       long long tokens, long long range, int K, int D, int KC, int DT,
+                                                                       float* __restrict__ part) {
+  extern __shared__ float acc[];  // [KC][D + 1]: vector sums, then the count
+  const int t = threadIdx.x, d0 = t % DT, g = t / DT, G = VQ_EMA_THREADS / DT;
+  const int c0 = blockIdx.y * KC, kc = min(KC, K - c0);
+  const long long r0 = (long long)blockIdx.x * range, r1 = min(tokens, r0 + range);
+  for (int i = t; i < kc * (D + 1); i += VQ_EMA_THREADS) acc[i] = 0.f;
+  __syncthreads();
+  for (long long i = r0; i < r1; ++i) {
+    const int e = (int)idx[i] - c0;  // the same address for every thread: one broadcast load
+    if (e >= 0 && e < kc && (e % G) == g) {
+      float* row = acc + e * (D + 1);
+      const T* xr = x + i * x_ld;
+      for (int d = d0; d < D; d += DT) row[d] += ElemIO<T>::ld(xr + d);
+      if (d0 == 0) row[D] += 1.f;
     }
-    const float r = red[0];
-    __syncthreads();
-    return r;
-  };
-  float cnt = 0.f;
-  for (long long i = t; i < tokens; i += VQ_EMA_THREADS) cnt += idx[i] == e ? 1.f : 0.f;
-  cnt = block_sum(cnt);
-  if (t == 0) stats[e] = cnt;
-  for (int d0 = 0; d0 < D; d0 += VQ_EMA_DCHUNK) {
-    float acc[VQ_EMA_DCHUNK];
-#pragma unroll
-    for (int d = 0; d < VQ_EMA_DCHUNK; ++d) acc[d] = 0.f;
-    if (cnt > 0.f) {  // block-uniform
-      for (long long i = t; i < tokens; i += VQ_EMA_THREADS) {
-        if (idx[i] == e) {
-          const T* row = x + i * x_ld + d0;
-#pragma unroll
-          for (int d = 0; d < VQ_EMA_DCHUNK; ++d)
-            if (d0 + d < D) acc[d] += ElemIO<T>::ld(row + d);
-        }
-      }
+  }
+  __syncthreads();
+  float* out = part + ((long long)blockIdx.x * K + c0) * (D + 1);
+  for (int i = t; i < kc * (D + 1); i += VQ_EMA_THREADS) out[i] = acc[i];
+}
+
+// Pass 2: stats[e] = sum over the blocks of the counts, stats[K + e*D + d] = ... of the vector sums, in block order (one thread per entry)
+__global__ __launch_bounds__(VQ_EMA_THREADS) void vq_ema_fold_kernel(const float* __restrict__ part, int nblk, int K, int D, float* __restrict__ stats) {
+  const long long n = (long long)K * (D + 1);
+  for (long long i = (long long)blockIdx.x * VQ_EMA_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * VQ_EMA_THREADS) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four loads in flight; combined in a fixed order
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+      a0 += part[(long long)b * n + i]; a1 += part[(long long)(b + 1) * n + i]; a2 += part[(long long)(b + 2) * n + i]; a3 += part[(long long)(b + 3) * n + i];
     }
-#pragma unroll
-    for (int d = 0; d < VQ_EMA_DCHUNK; ++d) {
-      if (d0 + d < D) {  // block-uniform
-        const float s = cnt > 0.f ? block_sum(acc[d]) : 0.f;
-        if (t == 0) stats[K + (long long)e * D + d0 + d] = s;
-      }
-    }
+    for (; b < nblk; ++b) a0 += part[(long long)b * n + i];
+    const float s = (a0 + a1) + (a2 + a3);
+    const int e = (int)(i / (D + 1)), d = (int)(i % (D + 1));
+    if (d == D) stats[e] = s; else stats[K + (long long)e * D + d] = s;
   }
 }
 
+static void vq_ema_plan(long long tokens, int K, int D, long long* range, int* nblk, int* KC, int* nchunk, int* DT) {
+  long long r = VQ_EMA_RANGE;
+  while ((tokens + r - 1) / r > VQ_EMA_MAX_BLOCKS) r *= 2;
+  *range = r;
+  *nblk = (int)((tokens + r - 1) / r);
+  if (*nblk < 1) *nblk = 1;
+  int kc = VQ_EMA_LDS_FLOATS / (D + 1);
+  if (kc > K) kc = K;
+  if (kc < 1) kc = 1;
+  *KC = kc;
+  *nchunk = (K + kc - 1) / kc;
+  int dt = 1;
+  while (dt * 2 <= D && dt * 2 <= 64) dt *= 2;
+  *DT = dt;
+}
+
+// fp32 elements of the partial tables gm_vq_ema_stats needs as `workspace`
+extern "C" long long gm_vq_ema_stats_workspace_elems(long long tokens, int num_embeddings, int dim) {
+  if (num_embeddings <= 0 || dim <= 0) return 0;
+  long long range; int nblk, KC, nchunk, DT;
+  vq_ema_plan(tokens, num_embeddings, dim, &range, &nblk, &KC, &nchunk, &DT);
+  return (long long)nblk * num_embeddings * (dim + 1);
+}
+
 extern "C" int gm_vq_ema_stats(const void* x, long long x_ld, const long long* indices, long long tokens, int num_embeddings, int dim,
-                               float* stats, int dtype, void* stream) {
-  GM_REQUIRE(x && indices && stats, "null pointer");
-  GM_REQUIRE(num_embeddings > 0 && dim > 0, "bad codebook shape");
+                               float* stats, float* workspace, int dtype, void* stream) {
+  GM_REQUIRE(stats && workspace && (tokens == 0 || (x && indices)), "null pointer");  // (no tokens: an empty tensor has no storage; zeros are written)
+  GM_REQUIRE(num_embeddings > 0 && dim > 0 && tokens >= 0, "bad codebook shape");
+  GM_REQUIRE((long long)(dim + 1) * 4 <= 48 * 1024, "embedding dim too large for the per-code LDS accumulators");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GM_F32) vq_ema_stats_kernel<float><<<num_embeddings, VQ_EMA_THREADS, 0, st>>>((const float*)x, x_ld, indices, tokens, num_embeddings, dim, stats);
-  else if (dtype == GM_BF16) vq_ema_stats_kernel<bf16_raw><<<num_embeddings, VQ_EMA_THREADS, 0, st>>>((const bf16_raw*)x, x_ld, indices, tokens, num_embeddings, dim, stats);
+  long long range; int nblk, KC, nchunk, DT;
+  vq_ema_plan(tokens, num_embeddings, dim, &range, &nblk, &KC, &nchunk, &DT);
+  const size_t smem = (size_t)KC * (dim + 1) * sizeof(float);
+  dim3 grid((unsigned)nblk, (unsigned)nchunk);
+  if (dtype == GM_F32)
+    vq_ema_partial_kernel<float><<<grid, VQ_EMA_THREADS, smem, st>>>((const float*)x, x_ld, indices, tokens, range, num_embeddings, dim, KC, DT, workspace);
+  else if (dtype == GM_BF16)
+    vq_ema_partial_kernel<bf16_raw><<<grid, VQ_EMA_THREADS, smem, st>>>((const bf16_raw*)x, x_ld, indices, tokens, range, num_embeddings, dim, KC, DT, workspace);
   else GM_FAIL(-2, "unsupported dtype");
+  const long long n = (long long)num_embeddings * (dim + 1);
+  long long g = (n + VQ_EMA_THREADS - 1) / VQ_EMA_THREADS;
+  if (g > 1024) g = 1024;
+  vq_ema_fold_kernel<<<(unsigned)g, VQ_EMA_THREADS, 0, st>>>(workspace, nblk, num_embeddings, dim, stats);
   GM_LAUNCH_CHECK();
 }
 

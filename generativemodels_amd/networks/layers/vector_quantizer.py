@@ -66,8 +66,9 @@ class EMAQuantizer(nn.Module):
         k, d = self.num_embeddings, self.embedding_dim
         stats = torch.empty(k + k * d, dtype=torch.float32, device=z_arena.device)
         idx = indices.reshape(-1).contiguous()
+        work = torch.empty(int(ops.lib().gm_vq_ema_stats_workspace_elems(idx.numel(), k, d)), dtype=torch.float32, device=z_arena.device)
         ops.check(ops.lib().gm_vq_ema_stats(z_arena.data_ptr(), ops.arena_ld(z_arena), idx.data_ptr(), idx.numel(), k, d, stats.data_ptr(),
-                                            ops.dt_code(z_arena.dtype), ops._stream()), "gm_vq_ema_stats")
+                                            work.data_ptr(), ops.dt_code(z_arena.dtype), ops._stream()), "gm_vq_ema_stats")
         if self.ddp_sync and torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)  # counts and vector sums together: one exchange
         # the kernels update fp32 state in place; a module cast to bf16 keeps fp32 master copies of its three tables for the update

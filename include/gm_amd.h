@@ -400,8 +400,11 @@ int gm_vq_argmin(const void* x, long long x_ld, const float* embedding, long lon
  * stats[K + K*D] = (tokens per code | sum of the token vectors per code) -- the reference's `encodings_sum` and `dw`, exchanged between
  * data-parallel ranks by ONE all-reduce instead of two (:155-157); gm_vq_ema_update applies the decayed update, the Laplace smoothing and
  * rewrites the embedding (fp32 buffers, in place). */
+/* workspace: gm_vq_ema_stats_workspace_elems(tokens, K, D) floats (per-token-range partial tables, summed in range order: every index and
+ * every vector is read once, no atomics) */
+long long gm_vq_ema_stats_workspace_elems(long long tokens, int num_embeddings, int dim);
 int gm_vq_ema_stats(const void* x, long long x_ld, const long long* indices, long long tokens, int num_embeddings, int dim, float* stats,
-                    int dtype, void* stream);
+                    float* workspace, int dtype, void* stream);
 int gm_vq_ema_update(const float* stats, float* cluster, float* ema_w, float* embedding, int num_embeddings, int dim, float decay,
                      float epsilon, void* stream);
 long long gm_vq_gather_workspace_bytes(void);

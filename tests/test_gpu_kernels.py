@@ -1119,3 +1119,35 @@ def test_token_gemm_path_of_1x1_convolutions(n, tokens, cin, cout, pre, pre_act,
     tiled = ops.conv(x.to(DEV), wd, b.to(DEV), force_cfg=4, **kw)
     _check(got, tiled, dtype, "token GEMM vs the tiled kernel", extra=2.0)
     assert ops.TOKEN_GEMM and tokens * n <= ops.TOKEN_GEMM_MAX_ROWS  # (the un-forced call above took the new path)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(16, 16, 700), (256, 32, 20000), (1024, 48, 5000), (300, 7, 3000), (8, 64, 0)], ids=lambda c: f"K{c[0]}-D{c[1]}-T{c[2]}")
+def test_vq_ema_stats_single_scan(case, dtype):
+    """gm_vq_ema_stats (EMAQuantizer training update, vector_quantizer.py:166-169: `encodings_sum`, `dw`): per-range partial tables summed in range
+    order -- every index and vector read once -- against a float64 index_add; code chunks over grid.y (K x (D + 1) floats beyond the LDS budget),
+    an embedding dim that is not a power of two, no tokens; two runs are bit-identical (exclusive accumulator ownership, no atomics)."""
+    from generativemodels_amd._native import check, lib
+    ops = _ops()
+    k, d, tokens = case
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((tokens, d), generator=g).to(dtype)
+    idx = torch.randint(0, k, (tokens,), generator=g)
+    if tokens:
+        idx[: min(tokens, 50)] = k - 1  # a busy last code (its chunk is the ragged one)
+    xd, idd = x.to(DEV), idx.to(DEV)
+
+    def run():
+        stats = torch.full((k + k * d,), float("nan"), dtype=torch.float32, device=DEV)
+        work = torch.empty(int(lib().gm_vq_ema_stats_workspace_elems(tokens, k, d)), dtype=torch.float32, device=DEV)
+        check(lib().gm_vq_ema_stats(xd.data_ptr(), d, idd.data_ptr(), tokens, k, d, stats.data_ptr(), work.data_ptr(), ops.dt_code(dtype), ops._stream()),
+              "gm_vq_ema_stats")
+        return stats
+
+    a, b = run(), run()
+    assert torch.equal(a, b)
+    want_cnt = torch.bincount(idx, minlength=k).double()
+    want_sum = torch.zeros((k, d), dtype=torch.float64).index_add_(0, idx, x.double())
+    assert torch.equal(a[:k].cpu().double(), want_cnt)
+    got = a[k:].reshape(k, d).cpu().double()
+    assert (got - want_sum).abs().max().item() <= 1e-5 * max(1.0, want_sum.abs().max().item()) * (1 if dtype == torch.float32 else 1)
