@@ -92,8 +92,9 @@ def close(got, want, dt, what, k=1.0):
     return err
 
 
-def conv_case(dt, n, cin, cout, sp, k, stride, pad, dil, cfg, pre, res, transposed=False):
-    """gm_conv_forward on an arena tensor against a direct numpy convolution (fp64)."""
+def conv_case(dt, n, cin, cout, sp, k, stride, pad, dil, cfg, pre, res, transposed=False, ksplit=0):
+    """gm_conv_forward on an arena tensor against a direct numpy convolution (fp64).  ksplit > 1 (cfg 11): the split-K path -- slice kernel
+    (conv_sk.hip, LDS-DMA inline assembly: not instrumented) + the INSTRUMENTED combine kernel with the fused output statistics."""
     nsp = 3
     x = rng.standard_normal((n, *sp, cin))
     w = rng.standard_normal((cout, cin, k, k, k)) / math.sqrt(cin * k ** 3)
@@ -149,11 +150,27 @@ def conv_case(dt, n, cin, cout, sp, k, stride, pad, dil, cfg, pre, res, transpos
         cand = [i for i in ((1, 0) if cfg >= 5 else (2, 1, 0)) if bits[i] < caps[i]]
         i = min(cand, key=lambda j: bits[j]) if cand else 2
         bits[i] += 1
+    if cfg == 11:
+        bits = [2, 2, 4]  # the LDS-DMA tile is fixed: 4 x 4 x 16 voxels whatever the volume
     d.ltd, d.lth, d.ltw = bits
     lds = lib.gm_conv_lds_bytes(C.byref(d))
     if lds <= 0 or lds > 160 * 1024:  # not covered by this configuration / tile too large for it (the host picks another one)
         return None
+    if ksplit > 1:
+        d.ksplit = ksplit
+        nb = lib.gm_conv_splitk_workspace_bytes(C.byref(d))
+        assert nb > 0, "split-K not available for this case"
+        kp = Dev(nbytes=nb)          # EXACTLY the bytes the library asks for: a slice or combine access past them is a sanitizer abort
+        d.kpartial = kp.ptr
+        slots = lib.gm_conv_stats_slots(C.byref(d))
+        assert slots > 0
+        st = Dev(nbytes=slots * n * cout * 2 * 8)
+        d.stats = st.ptr
     ck(lib.gm_conv_forward(C.byref(d), None), f"gm_conv_forward cfg {cfg}")
+    if ksplit > 1:
+        got_stats = st.get(np.float64, (slots, n, cout, 2)).sum(0)
+        yv = fetch(dy, dt, want.shape).reshape(n, -1, cout)
+        assert np.allclose(got_stats[..., 0], yv.sum(1), rtol=1e-4, atol=1e-2) and np.allclose(got_stats[..., 1], (yv * yv).sum(1), rtol=1e-4, atol=1e-2)
     return close(fetch(dy, dt, want.shape), want, dt, f"conv cfg{cfg} {cin}->{cout} k{k} s{stride} d{dil} {sp} pre={pre} res={res} dt={dt}", 2.0)
 
 
@@ -169,7 +186,33 @@ def main():
                 e = conv_case(dt, 2, cin, cout, sp, k, stride, pad, dil, cfg, pre, res)
                 if e is not None:
                     done += 1
-    print(f"convolutions: {done} (configuration, geometry, dtype) cases ran clean")
+    # ---- split-K over small volumes (cfg 11 geometry): the combine kernel's row blocks follow the volume (ragged last block, 1 .. 8 iterations) --
+    for dt in (F32, BF16):
+        vec = 4 if dt == F32 else 8
+        bk = 64 // (4 if dt == F32 else 2)
+        for (cin, cout, sp, ks, pre, res) in [(2 * bk, 8 * vec, (8, 8, 8), 2, True, True), (4 * bk, 17 * vec, (7, 9, 17), 4, False, True), (3 * bk, 8 * vec, (5, 3, 37), 3, True, False),
+                                              (2 * bk, 2 * vec, (33, 18, 20), 2, False, False)]:
+            e = conv_case(dt, 2, cin, cout, sp, 3, 1, 1, 1, 11, pre, res, ksplit=ks)
+            assert e is not None
+            done += 1
+    print(f"convolutions: {done} (configuration, geometry, dtype) cases ran clean (incl. 8 split-K cases)")
+    # ---- EMA codebook statistics (two-pass single scan; code chunks over grid.y, ragged last chunk, no tokens) ----------------------------------
+    for dt in (F32, BF16):
+        for (k_, d_, tokens) in [(16, 16, 700), (300, 7, 3000), (1024, 48, 2500), (8, 64, 0)]:
+            x = rng.standard_normal((max(tokens, 1), d_))
+            idx = rng.integers(0, k_, max(tokens, 1)).astype(np.int64)
+            dx, di = put(x, dt), Dev(idx)
+            stats = Dev(nbytes=(k_ + k_ * d_) * 4)
+            work = Dev(nbytes=max(1, lib.gm_vq_ema_stats_workspace_elems(tokens, k_, d_)) * 4)
+            ck(lib.gm_vq_ema_stats(dx.ptr, d_, di.ptr, tokens, k_, d_, stats.ptr, work.ptr, dt, None), "gm_vq_ema_stats")
+            got = stats.get(np.float32, (k_ + k_ * d_,))
+            xr = rounded(x, dt)[:tokens]
+            want_cnt = np.bincount(idx[:tokens], minlength=k_)
+            want_sum = np.zeros((k_, d_))
+            np.add.at(want_sum, idx[:tokens], xr)
+            assert np.array_equal(got[:k_], want_cnt) and np.allclose(got[k_:].reshape(k_, d_), want_sum, rtol=1e-4, atol=1e-3), "gm_vq_ema_stats"
+            done += 1
+    print("EMA codebook statistics ran clean")
     # ---- GroupNorm statistics / apply, LayerNorm, GEGLU, activation, scale, axpby, timestep embedding -----------------------------------
     for dt in (F32, BF16):
         vec = 4 if dt == F32 else 8
@@ -268,3 +311,7 @@ def main():
 
 if __name__ == "__main__":
     main()
+    sys.stdout.flush()
+    # (leave without the interpreter's exit handlers: the sanitizer's device allocator checks that the HIP runtime is still loaded when the 800
+    # buffers above are torn down at exit, and it is not -- "CHECK failed: sanitizer_allocator_device.h:125" after a clean pass)
+    os._exit(0)
