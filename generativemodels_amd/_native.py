@@ -59,7 +59,7 @@ class GmAttnDesc(C.Structure):
                 ("res", c_vp), ("res_ld", c_ll), ("o", c_vp), ("o_ld", c_ll),
                 ("B", C.c_int), ("H", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int), ("dh", C.c_int),
                 ("scale", C.c_float), ("dtype", C.c_int), ("workspace", c_vp), ("workspace_bytes", c_ll),
-                ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll)]
+                ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll), ("stats", c_vp)]
 
 
 class GmAttnBwdDesc(C.Structure):
@@ -132,6 +132,7 @@ PROTOTYPES = {
     "gm_sample_index": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, c_vp, c_vp]),
     "gm_token_log_prob": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, C.c_int, c_vp]),
     "gm_attention_workspace_bytes": (c_ll, [C.POINTER(GmAttnDesc)]),
+    "gm_attention_stats_slots": (c_ll, [C.POINTER(GmAttnDesc)]),
     "gm_attention_dma_set_variant": (None, [C.c_int, C.c_int]),
     "gm_attention_forward": (C.c_int, [C.POINTER(GmAttnDesc), c_vp]),
     "gm_conv_wgrad_workspace_bytes": (c_ll, [C.POINTER(GmWgradDesc)]),

@@ -308,15 +308,22 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
 }
 
 // ---- split-KV merge: out[q] = sum_s e^{m_s - M} O_s / sum_s e^{m_s - M} l_s (+ residual); one thread per (query, 8 channels) ----------
+// grid (blocks per sample-head, B * H), grid-stride over the (query, channel vector) items of one (sample, head).  Round 4: optional per-channel
+// (sum, sum of squares) partials of the STORED output for the GroupNorm that follows the attention block (GmAttnDesc.stats, single head): the
+// block's stride is a multiple of the channel vectors per row, so a thread keeps its 8 channels over the walk; threads of a channel vector are
+// added in thread order in fp64 and every (block, channel) entry is stored once -- deterministic, and one gn_stats launch less per block.
+#define ATTN_COMBINE_MAX_BLOCKS 256
 __global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, const float* __restrict__ part, int nsplit) {
+  __shared__ float red[256][17];
   const int dv = p.dh / 8;
-  const long long total = (long long)p.B * p.H * p.Lq * dv;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const long long items = (long long)p.Lq * dv;
+  const long long stride = (long long)p.B * p.H * p.Lq * (p.dh + 4);
+  float ss[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % dv) * 8;
-    const long long qi = i / dv;                       // (b*H + h) * Lq + q
-    const int q = (int)(qi % p.Lq);
-    const int bh = (int)(qi / p.Lq), b = bh / p.H, h = bh % p.H;
-    const long long stride = (long long)p.B * p.H * p.Lq * (p.dh + 4);
+    const int q = (int)(i / dv);
+    const long long qi = (long long)bh * p.Lq + q;
     const float* row = part + qi * (p.dh + 4);
     float M = -INFINITY;
     for (int s = 0; s < nsplit; ++s) M = fmaxf(M, row[s * stride + p.dh]);
@@ -338,8 +345,27 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, c
 #pragma unroll
       for (int k = 0; k < 4; ++k) { o[2 * k] += __uint_as_float(w4[k] << 16); o[2 * k + 1] += __uint_as_float(w4[k] & 0xffff0000u); }
     }
-    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_raw*>(p.o) + ((long long)b * p.Lq + q) * p.o_ld + h * p.dh + c) =
-        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    const uint4 raw = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_raw*>(p.o) + ((long long)b * p.Lq + q) * p.o_ld + h * p.dh + c) = raw;
+    if (p.stats) {  // statistics of the values as stored (rounded to bf16), like a separate pass over the tensor would see them
+      const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = __uint_as_float(w4[k] << 16), hi = __uint_as_float(w4[k] & 0xffff0000u);
+        ss[2 * k] += lo; sq[2 * k] += lo * lo; ss[2 * k + 1] += hi; sq[2 * k + 1] += hi * hi;
+      }
+    }
+  }
+  if (!p.stats) return;  // (uniform)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = ss[k]; red[threadIdx.x][8 + k] = sq[k]; }
+  __syncthreads();
+  const int ch = threadIdx.x;  // single head (host-checked): channel ch = channel vector ch / 8, element ch % 8
+  if (ch < p.dh) {
+    const int cv = ch >> 3, k = ch & 7;
+    double a = 0.0, a2 = 0.0;
+    for (int t = cv; t < 256; t += dv) { a += (double)red[t][k]; a2 += (double)red[t][8 + k]; }  // (thread t walks channel vector t % dv: 256 % dv == 0)
+    *reinterpret_cast<double2*>(p.stats + (((long long)blockIdx.x * p.B + b) * p.dh + ch) * 2) = make_double2(a, a2);
   }
 }
 
@@ -363,6 +389,11 @@ static bool attn_dma_eligible(const GmAttnDesc& d) {
 // every shape, so the automatic choice stays at qf = 1; key slices (powers of two, at least 4 key tiles each) are added until every CU has
 // a work-group: 2.7x at 4096 tokens (32 -> 256 work-groups), nothing at 32768.  (Four waves x 64 queries with a SIMD's 512 registers
 // each -- 0.25 reads per MFMA -- does not survive hipcc: 432 spilled registers.)
+static unsigned attn_combine_blocks(const GmAttnDesc& d) {  // blocks per (sample, head) of the merge kernel = statistic slots per sample
+  const long long items = (long long)d.Lq * (d.dh / 8);
+  long long g = (items + 255) / 256;
+  return (unsigned)(g > ATTN_COMBINE_MAX_BLOCKS ? ATTN_COMBINE_MAX_BLOCKS : (g < 1 ? 1 : g));
+}
 static void attn_dma_plan(const GmAttnDesc& d, int* qf, int* nsplit) {
   const long long tiles = ((long long)d.Lk + 63) / 64;
   const int f = gm_attn_dma_force_qf ? gm_attn_dma_force_qf : 1;
@@ -417,11 +448,15 @@ extern "C" int gm_attention_dma_try(const GmAttnDesc* dp, void* stream) {
   if (d.dh == 64) { if (qf == 2) launch_attn_dma<64, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<64, 1>(d, vt, lk_pad, part, sp, st); }
   else if (d.dh == 128) { if (qf == 2) launch_attn_dma<128, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<128, 1>(d, vt, lk_pad, part, sp, st); }
   else { if (qf == 2) launch_attn_dma<256, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<256, 1>(d, vt, lk_pad, part, sp, st); }
-  if (sp > 1) {
-    const long long items = (long long)d.B * d.H * d.Lq * (d.dh / 8);
-    long long g = (items + 255) / 256;
-    if (g > 256 * 32) g = 256 * 32;
-    attn_combine_kernel<<<(unsigned)g, 256, 0, st>>>(d, part, sp);
-  }
+  if (sp > 1) attn_combine_kernel<<<dim3(attn_combine_blocks(d), (unsigned)(d.B * d.H)), 256, 0, st>>>(d, part, sp);
   return 1;
+}
+
+// Per-channel statistic partials S the LDS-DMA path writes into GmAttnDesc.stats ([S][B][H * dh][2] fp64) for this geometry, 0 = none (the
+// register-staged kernel, an unsplit launch, several heads): the caller leaves `stats` NULL then and runs gm_gn_channel_stats when a norm follows.
+extern "C" long long gm_attention_stats_slots(const GmAttnDesc* d) {
+  if (!d || !attn_dma_eligible(*d) || d->H != 1) return 0;
+  int qf, sp;
+  attn_dma_plan(*d, &qf, &sp);
+  return sp > 1 ? (long long)attn_combine_blocks(*d) : 0;
 }

@@ -18,4 +18,5 @@ struct GmAttnDesc {
   long long workspace_bytes;
   int causal;                  // 1: query i attends keys j <= i + (Lk - Lq) only (SABlock causal mask, blocks/selfattention.py:133-134)
   long long k_bs, v_bs;        // batch strides of k / v in elements; 0 = dense (Lk * ld).  A KV cache is [B][max_len][C] read up to Lk.
+  double* stats;               // optional [gm_attention_stats_slots][B][H * dh][2] per-channel (sum, sum of squares) partials of the stored output
 };

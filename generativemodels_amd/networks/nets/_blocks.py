@@ -154,7 +154,11 @@ class AttentionBlock(nn.Module):
         bq = ops.cat_f32([self.to_q.bias, self.to_k.bias, self.to_v.bias], [c, c, c], x.device)
         qkv = ops.conv(xt, None, bq, kernel=1, pre=pre, packed=wq, cout=3 * c)
         o = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], self.num_heads, self.scale, res=xt)
-        return o.reshape(x.shape)
+        y = o.reshape(x.shape)
+        st = getattr(o, "_gm_cstats", None)
+        if st is not None:  # per-channel statistics of the block's output, written by the attention merge kernel: the next GroupNorm reads them
+            y._gm_cstats = st
+        return y
 
     def run_train(self, x: torch.Tensor) -> torch.Tensor:
         """The same block with gradients (generativemodels_amd.autograd): GroupNorm, three projections, attention, residual."""

@@ -1711,9 +1711,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     if ws_bytes > 0:  # scratch for the transposed V image of the LDS-DMA kernel; stream-ordered, freed on return
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
+    # the split-KV merge kernel can store per-channel (sum, sum of squares) partials of the output it writes: the GroupNorm of the block that
+    # follows an attention block then needs no statistics pass (channel_stats() finds them on the tensor, like a convolution's)
+    d.stats = None
+    st = None
+    slots = lib().gm_attention_stats_slots(C.byref(d)) if ws_bytes > 0 else 0
+    if slots > 0:
+        st = torch.empty((int(slots), b, c, 2), dtype=torch.float64, device=q.device)
+        d.stats = st.data_ptr()
     meta = dict(flops=4.0 * b * lq * lk * c, bytes=float(q.element_size() * b * (2 * lq + 2 * lk) * c), shape=f"B{b} H{heads} Lq{lq} Lk{lk} dh{dh}")
     _timed(f"attention<{str(q.dtype).split('.')[-1]}>", meta,
            lambda: check(lib().gm_attention_forward(C.byref(d), _stream()), "gm_attention_forward"))
+    if st is not None:
+        out._gm_cstats = st
     return out
 
 

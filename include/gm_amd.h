@@ -242,10 +242,16 @@ typedef struct GmAttnDesc {
   long long workspace_bytes;
   int causal;                 /* 1: query i sees keys j <= i + (Lk - Lq) (causal SABlock, blocks/selfattention.py:133-134) */
   long long k_bs, v_bs;       /* batch strides of k / v in elements, 0 = dense (Lk * ld): a KV cache [B][max_len][C] read up to Lk */
+  double* stats;              /* optional [gm_attention_stats_slots(desc)][B][H * dh][2]: per-block partials of the per-channel sum / sum of squares of
+                               * the stored output (+ residual) for the GroupNorm that follows an attention block (plain stores, one per block and
+                               * channel); must be NULL when gm_attention_stats_slots() returns 0 for this geometry */
 } GmAttnDesc;
 int gm_attention_max_head_dim(void);
 /* bytes of scratch the fastest kernel for this geometry wants (0: none; the descriptor's workspace fields are not read) */
 long long gm_attention_workspace_bytes(const GmAttnDesc* d);
+/* partials S the launch writes into GmAttnDesc.stats; 0 = this geometry does not fuse the output statistics (the split-KV form of the LDS-DMA
+ * kernel with one head does: its merge kernel holds every output row anyway) */
+long long gm_attention_stats_slots(const GmAttnDesc* d);
 /* Tests / benchmarks only: pin the LDS-DMA kernel variant -- queries per wave = 16 * qf (qf 1 or 2) and the number of key slices of the
  * split-KV form (1..8) -- instead of the size-based choice; 0 restores the automatic choice for that knob.  Process-wide. */
 void gm_attention_dma_set_variant(int qf, int nsplit);

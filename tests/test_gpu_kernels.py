@@ -1151,3 +1151,25 @@ def test_vq_ema_stats_single_scan(case, dtype):
     assert torch.equal(a[:k].cpu().double(), want_cnt)
     got = a[k:].reshape(k, d).cpu().double()
     assert (got - want_sum).abs().max().item() <= 1e-5 * max(1.0, want_sum.abs().max().item()) * (1 if dtype == torch.float32 else 1)
+
+
+@pytest.mark.parametrize("case", [(1, 512, 256, True), (1, 4096, 128, True), (2, 640, 128, False), (1, 700, 64, True)], ids=lambda c: f"B{c[0]}-L{c[1]}-d{c[2]}")
+def test_attention_merge_kernel_writes_the_output_statistics(case):
+    """The split-KV merge kernel of the LDS-DMA attention stores per-channel (sum, sum of squares) partials of the output it writes
+    (GmAttnDesc.stats, one head): the GroupNorm after an attention block (diffusion_model_unet.py:407-415 -> the next ResnetBlock's norm1) then
+    needs no statistics pass.  The partials must sum to the statistics of the stored tensor, and `channel_stats` must pick them up."""
+    ops = _ops()
+    b, l, dh, with_res = case
+    q, k, v = (_rand((b, l, dh), 900 + i).to(torch.bfloat16).to(DEV) for i in range(3))
+    res = _rand((b, l, dh), 903).to(torch.bfloat16).to(DEV) if with_res else None
+    o = ops.attention(q, k, v, 1, dh ** -0.5, res=res)
+    st = getattr(o, "_gm_cstats", None)
+    assert st is not None and st.shape[1:] == (b, dh, 2) and st.shape[0] <= 256, "the split-KV path did not attach statistics"
+    ov = o.float().cpu().double()
+    got = st.sum(0).cpu()
+    assert torch.allclose(got[..., 0], ov.sum(1), rtol=1e-6, atol=1e-4) and torch.allclose(got[..., 1], (ov * ov).sum(1), rtol=1e-6, atol=1e-4)
+    assert ops.channel_stats(o) is st
+    want = torch.softmax(q.float().cpu().double() @ k.float().cpu().double().transpose(1, 2) * dh ** -0.5, -1) @ v.float().cpu().double()
+    if with_res:
+        want = want + res.float().cpu().double()
+    assert (ov - want).abs().max().item() <= 2.5e-2 * max(1.0, want.abs().max().item())
