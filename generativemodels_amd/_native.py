@@ -59,7 +59,7 @@ class GmAttnDesc(C.Structure):
                 ("res", c_vp), ("res_ld", c_ll), ("o", c_vp), ("o_ld", c_ll),
                 ("B", C.c_int), ("H", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int), ("dh", C.c_int),
                 ("scale", C.c_float), ("dtype", C.c_int), ("workspace", c_vp), ("workspace_bytes", c_ll),
-                ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll), ("stats", c_vp)]
+                ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll), ("stats", c_vp), ("vt_packed", C.c_int)]
 
 
 class GmAttnBwdDesc(C.Structure):
@@ -122,6 +122,8 @@ PROTOTYPES = {
     "gm_pack_subpixel_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_attention_max_head_dim": (C.c_int, []),
     "gm_linear_rows": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "gm_linear_rows_affine_vt": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, C.c_int,
+                                           C.c_int, C.c_int, c_vp]),
     "gm_linear_rows_affine": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, c_vp]),
     "gm_decode_scratch_bytes": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -283,6 +283,7 @@ extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream) {
   if (gm_attention_decode_try(dp, stream)) GM_LAUNCH_CHECK();  // one query per (batch, head): the KV-cache decode kernel (small_ops.hip)
   if (gm_attention_dma_try(dp, stream)) GM_LAUNCH_CHECK();  // bf16, d in {64,128,256}, workspace given: LDS-DMA kernel
   GM_REQUIRE(d.stats == nullptr, "GmAttnDesc.stats is written by the split-KV LDS-DMA path only (see gm_attention_stats_slots)");
+  GM_REQUIRE(!d.vt_packed, "GmAttnDesc.vt_packed needs the LDS-DMA path (a workspace of gm_attention_workspace_bytes() bytes)");
   int rc;
   if (d.dtype == GM_F32) rc = dispatch_attn<float>(d, st);
   else if (d.dtype == GM_BF16) rc = dispatch_attn<bf16_raw>(d, st);

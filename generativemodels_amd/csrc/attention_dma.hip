@@ -444,7 +444,8 @@ extern "C" int gm_attention_dma_try(const GmAttnDesc* dp, void* stream) {
   const long long vt_bytes = (long long)d.B * d.H * d.dh * lk_pad * 2;
   float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(d.workspace) + ((vt_bytes + 255) & ~255LL));
   dim3 pg(lk_pad / 64, d.dh / 64, d.B * d.H);
-  vt_pack_kernel<<<pg, 256, 0, st>>>(reinterpret_cast<const bf16_raw*>(d.v), d.v_ld, vt, d.H, d.Lk, lk_pad, d.dh);
+  if (!d.vt_packed)  // (else: the q | k | v projection stored the image, gm_linear_rows_affine_vt)
+    vt_pack_kernel<<<pg, 256, 0, st>>>(reinterpret_cast<const bf16_raw*>(d.v), d.v_ld, vt, d.H, d.Lk, lk_pad, d.dh);
   if (d.dh == 64) { if (qf == 2) launch_attn_dma<64, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<64, 1>(d, vt, lk_pad, part, sp, st); }
   else if (d.dh == 128) { if (qf == 2) launch_attn_dma<128, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<128, 1>(d, vt, lk_pad, part, sp, st); }
   else { if (qf == 2) launch_attn_dma<256, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<256, 1>(d, vt, lk_pad, part, sp, st); }

@@ -19,4 +19,5 @@ struct GmAttnDesc {
   int causal;                  // 1: query i attends keys j <= i + (Lk - Lq) only (SABlock causal mask, blocks/selfattention.py:133-134)
   long long k_bs, v_bs;        // batch strides of k / v in elements; 0 = dense (Lk * ld).  A KV cache is [B][max_len][C] read up to Lk.
   double* stats;               // optional [gm_attention_stats_slots][B][H * dh][2] per-channel (sum, sum of squares) partials of the stored output
+  int vt_packed;               // 1: the workspace already holds the transposed V image (written by gm_linear_rows_affine_vt): no pack launch
 };

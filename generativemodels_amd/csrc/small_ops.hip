@@ -19,6 +19,10 @@ struct LinearRowsExtra {
   const float* kv_ws; int kv_dh;                       // K-split kernel STAGE 1: x = merge of the split-KV attention partials (head size kv_dh)
   const float* mlp_p; int mlp_nj; const void* mlp_x1; const float* mlp_b2; void* mlp_x0;  // K-split kernel STAGE 2: x = x1 + b2 + sum_j P[j]
   const float* pre_scale; const float* pre_shift; long long ss_ld; int rows_per_sample;   // linear_rows_kernel: x <- x * scale[n][c] + shift[n][c], n = row / rows_per_sample
+  // linear_rows_kernel, stacked q | k | v projection of an attention block: output channels >= vt_c0 (the V columns) are ALSO stored into the
+  // transposed, key-permuted image VT[sample * H + head][channel][position] the LDS-DMA attention kernel consumes (attention_dma.hip:
+  // vt_pack_kernel's layout; rows_per_sample = tokens per sample = the image's row pitch, a multiple of 64): no separate pack launch
+  void* vt; int vt_c0; int vt_dh;
 };
 
 // One channel of the split-KV single-query attention, merged from its GM_DECODE_KV_SPLITS partials in range order.  Workspace =
@@ -169,6 +173,13 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
         ElemIO<T>::st(dst + (long long)row * ex.y12_ld + (co - (co < 2 * ex.split ? ex.split : 2 * ex.split)), v);
       } else {
         ElemIO<T>::st(y + (long long)row * y_ld + co, v);
+        if (ex.vt && co >= ex.vt_c0) {
+          const int cch = co - ex.vt_c0, L = ex.rows_per_sample;
+          const int smp = row / L, key = row - smp * L;
+          const int pos = (key & ~31) + ((key & 15) >> 2) * 8 + ((key >> 4) & 1) * 4 + (key & 3);  // key = blk*32 + half*16 + qq*4 + r -> blk*32 + qq*8 + half*4 + r
+          const int heads = (cout - ex.vt_c0) / ex.vt_dh;
+          ElemIO<T>::st(reinterpret_cast<T*>(ex.vt) + ((long long)(smp * heads + cch / ex.vt_dh) * ex.vt_dh + cch % ex.vt_dh) * L + pos, v);
+        }
       }
     }
   }
@@ -547,6 +558,23 @@ extern "C" int gm_linear_rows_affine(const void* x, long long x_ld, const float*
   LinearRowsExtra ex = {};
   ex.pre_scale = pre_scale; ex.pre_shift = pre_shift; ex.ss_ld = ss_ld; ex.rows_per_sample = rows_per_sample;
   return linear_rows_launch(x, x_ld, w, bias, res, res_ld, y, y_ld, rows, cin, cout, pre_act, post_act, dtype, ex, stream);
+}
+
+// the same GEMM as the stacked q | k | v projection of an attention block whose V columns (output channels >= vt_c0, heads of vt_dh channels) are
+// also written as the transposed key-permuted image of the LDS-DMA attention kernel (GmAttnDesc.vt_packed = 1 then skips its pack launch).
+// rows_per_sample = tokens per sample, a multiple of 64 (the image has no padding keys); bf16.
+extern "C" int gm_linear_rows_affine_vt(const void* x, long long x_ld, const float* pre_scale, const float* pre_shift, long long ss_ld, int rows_per_sample,
+                                        const void* w, const float* bias, void* y, long long y_ld, int rows, int cin, int cout, int pre_act, void* vt,
+                                        int vt_c0, int vt_dh, int dtype, void* stream) {
+  GM_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr), "scale and shift come together");
+  GM_REQUIRE(!pre_scale || (ss_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(pre_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(pre_shift) & 15) == 0),
+             "the affine tables are 16-byte aligned fp32 rows");
+  GM_REQUIRE(vt && dtype == GM_BF16 && rows_per_sample > 0 && rows_per_sample % 64 == 0 && rows % rows_per_sample == 0, "the V^T image needs bf16 and whole 64-key blocks per sample");
+  GM_REQUIRE(vt_dh > 0 && vt_c0 >= 0 && vt_c0 < cout && (cout - vt_c0) % vt_dh == 0, "the V columns are whole heads");
+  LinearRowsExtra ex = {};
+  ex.pre_scale = pre_scale; ex.pre_shift = pre_shift; ex.ss_ld = ss_ld; ex.rows_per_sample = rows_per_sample;
+  ex.vt = vt; ex.vt_c0 = vt_c0; ex.vt_dh = vt_dh;
+  return linear_rows_launch(x, x_ld, w, bias, nullptr, 0, y, y_ld, rows, cin, cout, pre_act, 0, dtype, ex, stream);
 }
 
 // the decode step's fused forms: LayerNorm prologue; q | k | v projection writing k, v rows into the caches (internal to the library)

@@ -152,8 +152,13 @@ class AttentionBlock(nn.Module):
         xt = tokens(x)
         wq = ops.packed_cat_weight([self.to_q.weight, self.to_k.weight, self.to_v.weight], x.dtype)
         bq = ops.cat_f32([self.to_q.bias, self.to_k.bias, self.to_v.bias], [c, c, c], x.device)
-        qkv = ops.conv(xt, None, bq, kernel=1, pre=pre, packed=wq, cout=3 * c)
-        o = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], self.num_heads, self.scale, res=xt)
+        # the projection also stores the transposed V image of the LDS-DMA attention kernel when it runs as the small-row GEMM (one launch less)
+        qkv = torch.empty((*xt.shape[:-1], 3 * c), dtype=xt.dtype, device=xt.device)
+        q, k, v = qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c]
+        ws = ops.attention_workspace(q, k, v, self.num_heads) if (xt.dtype == torch.bfloat16 and xt.shape[1] % 64 == 0) else None
+        qkv = ops.conv(xt, None, bq, kernel=1, pre=pre, packed=wq, cout=3 * c, out=qkv, vt=None if ws is None else (ws, 2 * c, c // self.num_heads))
+        packed = bool(getattr(qkv, "_gm_vt_packed", False))
+        o = ops.attention(q, k, v, self.num_heads, self.scale, res=xt, workspace=ws, vt_packed=packed)
         y = o.reshape(x.shape)
         st = getattr(o, "_gm_cstats", None)
         if st is not None:  # per-channel statistics of the block's output, written by the attention merge kernel: the next GroupNorm reads them

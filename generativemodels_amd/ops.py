@@ -977,7 +977,8 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
          pre: Optional[tuple] = None, pre_act: str = "none", rowvec: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, post_act: str = "none", out: Optional[torch.Tensor] = None,
          packed: Optional[torch.Tensor] = None, cout: Optional[int] = None, force_cfg: Optional[int] = None,
-         want_stats: bool = False, skip: Optional[tuple] = None, allow_subpixel: bool = True, ksplit: Optional[int] = None) -> torch.Tensor:
+         want_stats: bool = False, skip: Optional[tuple] = None, allow_subpixel: bool = True, ksplit: Optional[int] = None,
+         vt: Optional[tuple] = None) -> torch.Tensor:
     """Fused convolution over an arena tensor x = (N, *spatial, Cin) -- or over a VirtualCat of two (their channel concatenation).
 
     kernel/stride/padding/dilation: int or per-axis tuples (len = number of spatial axes). `padding` is the low-side pad,
@@ -1082,6 +1083,18 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             if sc.dtype != torch.float32 or sh.dtype != torch.float32 or sc.shape != (n, cin) or sh.shape != (n, cin) or sc.stride(-1) != 1 or sh.stride(-1) != 1 \
                     or sc.stride(0) != sh.stride(0):
                 raise ValueError("pre = (scale, shift): fp32 [N, Cin] tables with a common row pitch")
+        if (vt is not None and res is None and post_act == "none" and dtype == torch.bfloat16 and (rows // n) % 64 == 0
+                and (sc is None or (sc.stride(0) % 4 == 0 and sc.data_ptr() % 16 == 0 and sh.data_ptr() % 16 == 0))):
+            # vt = (workspace, first V channel, head dim): the stacked q | k | v projection of an attention block also stores the transposed V image
+            # of the LDS-DMA attention kernel (one pack launch less per block); the caller finds `_gm_vt_packed` on the result
+            vws, vt_c0, vt_dh = vt
+            _timed(f"token_gemm<{str(dtype).split('.')[-1]}>", dict(flops=2.0 * rows * cin * cout, bytes=float(x.element_size() * (rows * (cin + cout) + cin * cout)),
+                                                                  shape=f"{rows}x{cin}->{cout} (+V^T image)"),
+                   lambda: check(lib().gm_linear_rows_affine_vt(x.data_ptr(), arena_ld(x), _ptr(sc), _ptr(sh), 0 if sc is None else sc.stride(0), rows // n,
+                                                                panel().data_ptr(), _ptr(b32), out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act],
+                                                                vws.data_ptr(), int(vt_c0), int(vt_dh), dt_code(dtype), _stream()), "gm_linear_rows_affine_vt"))
+            out._gm_vt_packed = True
+            return out
         if sc is None or (sc.stride(0) % 4 == 0 and sc.data_ptr() % 16 == 0 and sh.data_ptr() % 16 == 0):
             _timed(f"token_gemm<{str(dtype).split('.')[-1]}>", dict(flops=2.0 * rows * cin * cout, bytes=float(x.element_size() * (rows * (cin + cout) + cin * cout)),
                                                                   shape=f"{rows}x{cin}->{cout}"),
@@ -1670,10 +1683,28 @@ def _kv_ld(t: torch.Tensor) -> int:
     return t.stride(1) if t.shape[1] > 1 else max(t.stride(1), t.shape[2])
 
 
+def attention_workspace(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> Optional[torch.Tensor]:
+    """The scratch the LDS-DMA attention kernel wants for these operands (its transposed V image comes first), or None when another kernel
+    serves the geometry.  An attention block allocates it BEFORE its q | k | v projection so that the projection can store the V image itself
+    (conv(..., vt=(workspace, first V channel, head dim))) and passes it on: attention(..., workspace=ws, vt_packed=True)."""
+    b, lq, c = q.shape
+    d = GmAttnDesc()
+    d.q, d.q_ld, d.k, d.k_ld, d.v, d.v_ld = q.data_ptr(), arena_ld(q), k.data_ptr(), _kv_ld(k), v.data_ptr(), _kv_ld(v)
+    d.res, d.res_ld, d.o, d.o_ld = None, 0, q.data_ptr(), arena_ld(q)
+    d.B, d.H, d.Lq, d.Lk, d.dh, d.scale, d.dtype = b, heads, lq, k.shape[1], c // heads, 1.0, dt_code(q.dtype)
+    d.causal, d.k_bs, d.v_bs = 0, 0, 0
+    if b > 1 and (k.stride(0) != k.shape[1] * _kv_ld(k) or v.stride(0) != v.shape[1] * _kv_ld(v)):
+        return None
+    nbytes = lib().gm_attention_workspace_bytes(C.byref(d))
+    return torch.empty(nbytes, dtype=torch.uint8, device=q.device) if nbytes > 0 else None
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
-              res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, causal: bool = False) -> torch.Tensor:
+              res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, causal: bool = False,
+              workspace: Optional[torch.Tensor] = None, vt_packed: bool = False) -> torch.Tensor:
     """softmax(scale * Q K^T) V per (batch, head). q: (B, Lq, heads*dh) arena views (channel slices allowed), k/v: (B, Lk, ...);
-    k / v may be the first Lk rows of a longer per-sample buffer (a KV cache). causal: query i sees keys j <= i + (Lk - Lq)."""
+    k / v may be the first Lk rows of a longer per-sample buffer (a KV cache). causal: query i sees keys j <= i + (Lk - Lq).
+    workspace / vt_packed: see attention_workspace."""
     require_device(q, k, v, res, out)
     b, lq, c = q.shape
     lk = k.shape[1]
@@ -1708,9 +1739,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
         raise ValueError("causal attention needs at least as many keys as queries")
     d.workspace, d.workspace_bytes = None, 0
     ws_bytes = lib().gm_attention_workspace_bytes(C.byref(d))
+    d.vt_packed = 0
     if ws_bytes > 0:  # scratch for the transposed V image of the LDS-DMA kernel; stream-ordered, freed on return
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        if workspace is not None and workspace.numel() * workspace.element_size() >= ws_bytes:
+            ws = workspace
+            d.vt_packed = int(bool(vt_packed))
+        else:
+            if vt_packed:
+                raise ValueError("vt_packed needs the workspace the projection wrote the V image into")
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
+    elif vt_packed:
+        raise ValueError("vt_packed: this geometry is not served by the LDS-DMA attention kernel")
     # the split-KV merge kernel can store per-channel (sum, sum of squares) partials of the output it writes: the GroupNorm of the block that
     # follows an attention block then needs no statistics pass (channel_stats() finds them on the tensor, like a convolution's)
     d.stats = None

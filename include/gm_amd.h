@@ -245,6 +245,9 @@ typedef struct GmAttnDesc {
   double* stats;              /* optional [gm_attention_stats_slots(desc)][B][H * dh][2]: per-block partials of the per-channel sum / sum of squares of
                                * the stored output (+ residual) for the GroupNorm that follows an attention block (plain stores, one per block and
                                * channel); must be NULL when gm_attention_stats_slots() returns 0 for this geometry */
+  int vt_packed;              /* 1: `workspace` already holds the transposed, key-permuted V image of the LDS-DMA kernel -- the stacked q | k | v projection
+                               * wrote it (gm_linear_rows_affine_vt; Lk a multiple of 64): the pack launch is skipped.  Only with a workspace of
+                               * gm_attention_workspace_bytes() > 0 bytes */
 } GmAttnDesc;
 int gm_attention_max_head_dim(void);
 /* bytes of scratch the fastest kernel for this geometry wants (0: none; the descriptor's workspace fields are not read) */
@@ -280,6 +283,12 @@ int gm_linear_rows(const void* x, long long x_ld, const void* w, const float* bi
 /* The same over token rows with a per-sample GroupNorm affine in front: y = post_act(pre_act(x * scale[n] + shift[n]) W^T + bias) (+ res),
  * n = row / rows_per_sample, scale / shift fp32 [N][ss_ld] (both null: no affine).  The GroupNorm -> q | k | v projection of the
  * latent-resolution AttentionBlocks (diffusion_model_unet.py:395-405) and the other 1x1 convolutions over a few thousand tokens. */
+/* gm_linear_rows_affine as the stacked q | k | v projection of an attention block (diffusion_model_unet.py:407-415): the V columns (output channels
+ * >= vt_c0, heads of vt_dh channels) are also stored as the V^T image of the LDS-DMA attention kernel at the head of its workspace; bf16,
+ * rows_per_sample (tokens per sample) a multiple of 64 */
+int gm_linear_rows_affine_vt(const void* x, long long x_ld, const float* pre_scale, const float* pre_shift, long long ss_ld, int rows_per_sample,
+                             const void* w, const float* bias, void* y, long long y_ld, int rows, int cin, int cout, int pre_act, void* vt,
+                             int vt_c0, int vt_dh, int dtype, void* stream);
 int gm_linear_rows_affine(const void* x, long long x_ld, const float* pre_scale, const float* pre_shift, long long ss_ld, int rows_per_sample,
                           const void* w, const float* bias, const void* res, long long res_ld, void* y, long long y_ld, int rows, int cin,
                           int cout, int pre_act, int post_act, int dtype, void* stream);

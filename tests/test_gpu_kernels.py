@@ -1173,3 +1173,34 @@ def test_attention_merge_kernel_writes_the_output_statistics(case):
     if with_res:
         want = want + res.float().cpu().double()
     assert (ov - want).abs().max().item() <= 2.5e-2 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 512, 256, 1), (1, 4096, 128, 1), (2, 256, 128, 2), (1, 640, 256, 4)], ids=lambda c: f"B{c[0]}-L{c[1]}-C{c[2]}-H{c[3]}")
+def test_qkv_projection_stores_the_transposed_v_image(case):
+    """The stacked q | k | v projection of an attention block (small-row GEMM, GroupNorm affine as its prologue) can store the transposed,
+    key-permuted V image of the LDS-DMA attention kernel itself (gm_linear_rows_affine_vt -> GmAttnDesc.vt_packed): the attention result must be
+    bit-identical to the path with the separate pack launch, for several heads and batch entries."""
+    ops = _ops()
+    b, l, c, heads = case
+    x = _rand((b, l, c), 950).to(torch.bfloat16).to(DEV)
+    w = (_rand((3 * c, c, 1), 951) / math.sqrt(c)).to(torch.bfloat16).to(DEV)
+    bias = (_rand((3 * c,), 952) * 0.1).to(DEV)
+    scale, shift = (_rand((b, c), 953) * 0.2 + 1.0).to(DEV), (_rand((b, c), 954) * 0.3).to(DEV)
+    packed = ops.packed_conv_weight(w, torch.bfloat16)
+
+    def run(fused):
+        qkv = torch.empty((b, l, 3 * c), dtype=torch.bfloat16, device=DEV)
+        q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+        ws = ops.attention_workspace(q, k, v, heads)
+        assert ws is not None
+        out = ops.conv(x, None, bias, kernel=1, pre=(scale, shift), packed=packed, cout=3 * c, out=qkv, vt=(ws, 2 * c, c // heads) if fused else None)
+        got = bool(getattr(out, "_gm_vt_packed", False))
+        assert got == fused
+        return ops.attention(q, k, v, heads, (c // heads) ** -0.5, res=x, workspace=ws, vt_packed=got), qkv.clone()
+
+    (a, qa), (bb, qb) = run(True), run(False)
+    assert torch.equal(qa, qb) and torch.equal(a, bb), f"{(a.float() - bb.float()).abs().max().item():.3e}"
+    xn = x.float().cpu().double() * scale.cpu().double()[:, None, :] + shift.cpu().double()[:, None, :]
+    xn = xn.to(torch.bfloat16).double() if False else xn
+    qkv_ref = xn @ w[..., 0].float().cpu().double().t() + bias.cpu().double()
+    assert (qa.float().cpu().double() - qkv_ref).abs().max().item() <= 3e-2 * max(1.0, qkv_ref.abs().max().item())
