@@ -535,6 +535,42 @@ def test_native_planners_accept_and_reject_geometries_without_a_gpu():
     assert wgrad_bytes(kd=3, kh=5, kw=5) == -1
     assert wgrad_bytes(stride=3) == -1
 
+    # split-K: the combine kernel's row blocks follow the volume -- as few iterations as keep the launch (= the statistic partials of the output)
+    # at <= 256 blocks per sample, at most 8 (round 4; it was 8 iterations whatever the size: an 8^3 x 256-channel output ran on 8 blocks)
+    def splitk_slots(cout, sp, ks, dtype=1):
+        d = conv_desc(Cin=256, Cout=cout, Ds=sp, Hs=sp, Ws=sp, Do=sp, Ho=sp, Wo=sp, y_ld=cout, dtype=dtype, ksplit=ks)
+        d.kpartial = 0x8000
+        assert lib.gm_conv_splitk_workspace_bytes(C.byref(d)) == ks * sp ** 3 * cout * 4
+        return lib.gm_conv_stats_slots(C.byref(d))
+
+    assert splitk_slots(256, 8, 8) == 512 // 8            # 8 rows in flight x 1 iteration: 64 blocks (was 8)
+    assert splitk_slots(128, 16, 4) == 256                # 16 rows x 1 iteration
+    assert splitk_slots(64, 32, 2) == 256                 # 32 rows x 4 iterations
+    assert splitk_slots(64, 64, 2) == 64 ** 3 // (32 * 8) # large volumes: the 8-iteration cap, the table is compacted afterwards
+    assert splitk_slots(64, 32, 2, dtype=0) == 256        # fp32: 16 rows x 8 iterations
+
+    # EMA codebook statistics: the workspace is one [K x (D + 1)] table per token range of 1024 (fewer, longer ranges beyond 1024 of them)
+    assert lib.gm_vq_ema_stats_workspace_elems(0, 16, 8) == 16 * 9
+    assert lib.gm_vq_ema_stats_workspace_elems(5000, 256, 32) == 5 * 256 * 33
+    assert lib.gm_vq_ema_stats_workspace_elems(1 << 21, 256, 32) == 1024 * 256 * 33
+
+    # attention: the output statistics ride on the split-KV merge kernel (one head, LDS-DMA geometry), the V image may come packed
+    def attn_desc(**kw):
+        d = nat.GmAttnDesc()
+        base = dict(B=1, H=1, Lq=512, Lk=512, dh=256, scale=1.0, dtype=1, q_ld=768, k_ld=768, v_ld=768, o_ld=256, causal=0)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d, k, v)
+        d.q, d.k, d.v, d.o = 0x1000, 0x1200, 0x1400, 0x9000
+        return d
+
+    assert lib.gm_attention_workspace_bytes(C.byref(attn_desc())) > 256 * 512 * 2          # V^T image + the split-KV partial states
+    assert lib.gm_attention_stats_slots(C.byref(attn_desc())) == 512 * (256 // 8) // 256    # one merge block per 256 (query, 8-channel) items
+    assert lib.gm_attention_stats_slots(C.byref(attn_desc(Lq=4096, Lk=4096, dh=128))) == 256  # capped: the consumer reads the table without a compaction
+    assert lib.gm_attention_stats_slots(C.byref(attn_desc(H=2, dh=128))) == 0                # several heads: the statistics pass stays
+    assert lib.gm_attention_stats_slots(C.byref(attn_desc(Lq=32768, Lk=32768))) == 0         # enough query tiles for the chip: no key slices, no merge kernel
+    assert lib.gm_attention_stats_slots(C.byref(attn_desc(dh=80, q_ld=240, k_ld=240, v_ld=240, o_ld=80))) == 0  # not an LDS-DMA head dim
+
 
 def test_training_api_has_no_cpu_fallback_and_checks_its_arguments():
     """generativemodels_amd.autograd / forward_train on CPU tensors raise (no eager fallback); argument checks run before any kernel."""
