@@ -179,6 +179,44 @@ def test_inferer_argument_checks_and_no_cpu_fallback():
         s.add_noise(x, x, torch.tensor([1]))
 
 
+def test_captured_forward_cache_keys_on_shapes_and_parameter_versions(monkeypatch):
+    """DiffusionInferer._cached_graph (host logic, no GPU: the capture itself is replaced by a recorder): one capture per (model, shapes, dtype,
+    conditioning shape) reused across calls; an in-place parameter update (its `_version` moves) or a train() / eval() switch re-captures and
+    drops the stale entry; at most GRAPH_CACHE_SIZE captures are kept."""
+    from generativemodels_amd.inferers import inferer as I
+
+    built = []
+
+    class Recorder:
+        signature = staticmethod(I._GraphedUNet.signature)
+
+        def __init__(self, model, x, t, ctx):
+            built.append((id(model), tuple(x.shape), None if ctx is None else tuple(ctx.shape)))
+
+    monkeypatch.setattr(I, "_GraphedUNet", Recorder)
+    inf = DiffusionInferer(DDIMScheduler(10), use_hip_graph=True)
+    m1, m2 = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    x, t, ctx = torch.zeros(1, 4, 8, 8), torch.zeros(1), torch.zeros(1, 3, 4)
+    g = inf._cached_graph(m1, x, t, None)
+    assert inf._cached_graph(m1, x.clone(), t, None) is g and len(built) == 1          # same shapes: the same capture
+    g_ctx = inf._cached_graph(m1, x, t, ctx)
+    assert g_ctx is not g and len(built) == 2                                          # conditioning changes the graph
+    assert inf._cached_graph(m1, x, t, None) is g and inf._cached_graph(m1, x, t, ctx) is g_ctx
+    with torch.no_grad():
+        m1.weight.mul_(2.0)                                                             # an optimizer step
+    g2 = inf._cached_graph(m1, x, t, None)
+    assert g2 is not g and len(built) == 3
+    assert all(not (e[0]() is m1 and e[3] is g) for e in inf._graph_cache)             # the stale capture is gone
+    m1.train(False)
+    m1.train(True)
+    assert inf._cached_graph(m1, x, t, None) is g2                                      # mode unchanged in the end: still valid
+    m1.eval()
+    assert inf._cached_graph(m1, x, t, None) is not g2                                  # eval() vs train(): another forward
+    inf._cached_graph(m2, x, t, None)
+    inf._cached_graph(m2, torch.zeros(2, 4, 8, 8), t, None)
+    assert len(inf._graph_cache) <= inf.GRAPH_CACHE_SIZE
+
+
 def test_install_as_generative_aliases_the_reference_import_paths():
     import subprocess
     import sys
