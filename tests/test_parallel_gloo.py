@@ -323,7 +323,8 @@ def _static_worker(rank, world, port, q):
 
 
 @_retry_once
-def test_two_rank_static_graph_reducer_keeps_one_hook_per_bucket():
+@pytest.mark.parametrize("world", [2, 8])
+def test_static_graph_reducer_keeps_one_hook_per_bucket(world):
     """GradientReducer(static_graph=True): step 1 learns the used set, step 2 records the arrival order, from step 3 on one hook per bucket
     is left and no usage mask is exchanged -- the gradients stay the full-batch gradients at every step, accumulation under no_sync and a
     `.grad = None` reset still work, and a parameter outside the learned set that produces a gradient makes finish() raise."""
@@ -333,10 +334,10 @@ def test_two_rank_static_graph_reducer_keeps_one_hook_per_bucket():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_static_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_static_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
+    got = {r[0]: r[1:] for r in (q.get(timeout=300) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -353,7 +354,7 @@ def test_two_rank_static_graph_reducer_keeps_one_hook_per_bucket():
         model.zero_grad()
         torch.nn.functional.mse_loss(model(data), target).backward()
         want.append([p.grad.numpy().copy() for p in model.parameters()])
-    for rank in (0, 1):
+    for rank in range(world):
         hooks, overlapped, grads, acc, none_grads, raised, nbuckets = got[rank]
         # (counted after finish(): the first step ends with the per-parameter hooks, the second -- the recorded one -- already with one per non-empty bucket)
         assert hooks[0] == nparams + 2 and hooks[1] == hooks[2] == hooks[3] == hooks[4] < nparams
