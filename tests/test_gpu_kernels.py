@@ -1201,6 +1201,5 @@ def test_qkv_projection_stores_the_transposed_v_image(case):
     (a, qa), (bb, qb) = run(True), run(False)
     assert torch.equal(qa, qb) and torch.equal(a, bb), f"{(a.float() - bb.float()).abs().max().item():.3e}"
     xn = x.float().cpu().double() * scale.cpu().double()[:, None, :] + shift.cpu().double()[:, None, :]
-    xn = xn.to(torch.bfloat16).double() if False else xn
     qkv_ref = xn @ w[..., 0].float().cpu().double().t() + bias.cpu().double()
     assert (qa.float().cpu().double() - qkv_ref).abs().max().item() <= 3e-2 * max(1.0, qkv_ref.abs().max().item())
