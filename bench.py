@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0
 # What the chip SUSTAINS on bf16 MFMA at its 1400 W package power cap with random (non-zero) operands -- tools/mfma_power.hip on MI355X,
 # profiles/r04_mfma_power_ceiling.txt: the clock is set by the power budget, and this benchmark runs AT the cap (profiles/r04_power_trace.txt).
 # Reported next to the nominal peak; `roofline.frac` stays achieved / nominal peak.
-MFMA_BF16_SUSTAINED_TFLOPS = {"operands in registers, no memory traffic": 1850.0, "one ds_read_b128 per 32x32x16 MFMA (this kernel's tap loop)": 1490.0,
-                              "0.75 ds_read_b128 per MFMA": 1600.0}
+MFMA_BF16_SUSTAINED_TFLOPS = {"operands in registers, no memory traffic": 1863.0, "one ds_read_b128 per 32x32x16 MFMA (this kernel's tap loop)": 1490.0,
+                              "0.75 ds_read_b128 per MFMA, 2 work-groups per CU (the best LDS-fed loop measured)": 1621.0}
 
 
 class PowerSampler:
@@ -272,7 +272,9 @@ def main() -> None:
             roof.update(measured_hbm_traffic(roof["kernel"], dtype))
             if dtype == torch.bfloat16:
                 key = "one ds_read_b128 per 32x32x16 MFMA (this kernel's tap loop)"
+                best_lds, regs = MFMA_BF16_SUSTAINED_TFLOPS["0.75 ds_read_b128 per MFMA, 2 work-groups per CU (the best LDS-fed loop measured)"], MFMA_BF16_SUSTAINED_TFLOPS["operands in registers, no memory traffic"]
                 roof.update(sustained_peak=MFMA_BF16_SUSTAINED_TFLOPS[key], frac_of_sustained=round(roof["achieved"] / MFMA_BF16_SUSTAINED_TFLOPS[key], 4),
+                            frac_of_best_lds_fed_ceiling=round(roof["achieved"] / best_lds, 4), frac_of_register_resident_ceiling=round(roof["achieved"] / regs, 4),
                             sustained_peak_note="bf16 MFMA rate the chip sustains at its package power cap on random operands (tools/mfma_power.hip, "
                                                 "profiles/r04_mfma_power_ceiling.txt): " + json.dumps(MFMA_BF16_SUSTAINED_TFLOPS) +
                                                 "; this benchmark runs at the cap (package_power_w); `frac` is against the nominal dense peak")
@@ -306,7 +308,7 @@ def main() -> None:
         xs = x[..., :half, :half, :half].contiguous()
         sweep = {}
         with torch.no_grad():
-            for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256)}):
+            for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):  # (256 threads: 20x off the optimum on the r4 driver box, 46 s for nothing)
                 torch.set_num_threads(nt)
                 cpu_forward(xs[..., : half // 2, : half // 2, : half // 2].contiguous(), torch.tensor([500.0]))  # spin the pool up
                 c0 = time.perf_counter()
