@@ -178,6 +178,11 @@ __global__ __launch_bounds__(VQ_EMA_THREADS) void vq_ema_fold_kernel(const float
 static void vq_ema_plan(long long tokens, int K, int D, long long* range, int* nblk, int* KC, int* nchunk, int* DT) {
   long long r = VQ_EMA_RANGE;
   while ((tokens + r - 1) / r > VQ_EMA_MAX_BLOCKS) r *= 2;
+  // byte budget for the partial tables (nblk x K x (D + 1) floats, written and re-read once per training forward): K = 2048, D = 64 over
+  // >= 1 M tokens would otherwise be ~545 MB of scratch per call; 64 MiB keeps >= 123 blocks there, still a grid that fills the chip
+  // once the K chunks multiply it.  The partition only changes which fixed-order partial sums are formed: results stay deterministic.
+  const long long budget_elems = (64LL << 20) / 4, per_blk = (long long)K * (D + 1);
+  while ((tokens + r - 1) / r > 1 && ((tokens + r - 1) / r) * per_blk > budget_elems) r *= 2;
   *range = r;
   *nblk = (int)((tokens + r - 1) / r);
   if (*nblk < 1) *nblk = 1;

@@ -51,7 +51,7 @@ class _GraphedUNet:
     """HIP-graph replay of `model(x, t, context)` for fixed shapes; falls back to nothing -- errors propagate."""
 
     def __init__(self, model: DiffusionModelUNet, x: torch.Tensor, t: torch.Tensor, context: Optional[torch.Tensor]):
-        self.model = model
+        # (the model is NOT kept: the cache holds it weakly, so a dropped model releases its captured graph and the graph's private memory pool)
         self.x = x.clone()
         self.t = t.clone()
         self.context = None if context is None else context.clone()
@@ -79,9 +79,13 @@ class _GraphedUNet:
 
     @staticmethod
     def signature(model) -> tuple:
-        """What a captured forward depends on besides its inputs: the parameters' identities and versions (the packed MFMA panels a capture baked in
-        are derived per parameter version -- an optimizer step between two sample() calls must re-capture) and the eval / train mode."""
-        return (bool(model.training),) + tuple((id(p), p._version) for p in model.parameters())
+        """What a captured forward depends on besides its inputs: the eval / train mode, the autocast compute dtype, and every parameter's and
+        buffer's identity, version, STORAGE, dtype and device -- the packed MFMA panels a capture baked in are derived per parameter version (an
+        optimizer step between two sample() calls must re-capture), and writes through `.data` (`p.data = ema_p.data`, `module.to()`, `.half()`)
+        change the storage without bumping `_version`: the captured kernels would read the old, possibly freed, storage.  Mirrors the `ver` tuple
+        of `ops._cached`.  (`p.data.copy_()` in place keeps all of these: call `inferer.clear_graph_cache()` after such a write.)"""
+        tensors = list(model.parameters()) + list(model.buffers())
+        return (bool(model.training), ops.autocast_dtype()) + tuple((id(p), p._version, p.data_ptr(), p.dtype, p.device) for p in tensors)
 
 
 class DiffusionInferer(Inferer):
@@ -128,6 +132,11 @@ class DiffusionInferer(Inferer):
         g = _GraphedUNet(model, x, t, ctx)
         cache.append((weakref.ref(model), key, sig, g))
         return g
+
+    def clear_graph_cache(self) -> None:
+        """Drop every captured forward this inferer keeps (and with them the graphs' private memory pools): after an in-place parameter write the
+        signature cannot see (`p.data.copy_(...)`), or to give the activation memory back."""
+        self.__dict__.pop("_graph_cache", None)
 
     @torch.no_grad()
     def sample(self, input_noise: torch.Tensor, diffusion_model: Callable[..., torch.Tensor],

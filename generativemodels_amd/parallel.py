@@ -81,6 +81,43 @@ def gather_units(ids: List[int], outs: List[torch.Tensor], n_units: int, group=N
 _DIRECT_GRAD: dict = {}
 
 
+_UNDEFINED_GRAD_HOOK_PROBE = None
+
+
+def engine_fires_hooks_for_undefined_grads() -> bool:
+    """One-time runtime probe (CPU, microseconds): does this torch run a leaf's post-accumulate-grad hook when the backward Function returned
+    None for it?  torch 2.10 does; an older AccumulateGrad returns before the hook -- there the in-place accumulation path would never signal
+    readiness (in-backward overlap would silently disappear and `static_graph` would never leave its recording stage), so `direct_grad_hook`
+    stays off and every gradient goes back to autograd as a tensor."""
+    global _UNDEFINED_GRAD_HOOK_PROBE
+    if _UNDEFINED_GRAD_HOOK_PROBE is None:
+        class _ReturnsNone(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, w, x):
+                return x * 1.0
+
+            @staticmethod
+            def backward(ctx, g):
+                return None, g
+
+        fired = []
+        with torch.enable_grad():
+            w = torch.zeros(1, requires_grad=True)
+            x = torch.ones(1, requires_grad=True)
+            h = w.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+            try:
+                _ReturnsNone.apply(w, x).sum().backward()
+            finally:
+                h.remove()
+        _UNDEFINED_GRAD_HOOK_PROBE = bool(fired)
+        if not fired:
+            import warnings
+
+            warnings.warn("generativemodels_amd: this torch does not run post-accumulate-grad hooks for undefined gradients; weight gradients are "
+                          "returned to autograd instead of being accumulated in place (one extra add per parameter)")
+    return _UNDEFINED_GRAD_HOOK_PROBE
+
+
 def direct_grad_hook(param: torch.Tensor):
     """True when a backward kernel may accumulate `param`'s gradient IN PLACE into `param.grad` and hand autograd None: the parameter belongs
     to a live GradientReducer that is armed for a `.backward()` pass (`reducer.zero_grad()` arms it, `finish()` disarms it) and `.grad` is its
@@ -89,7 +126,7 @@ def direct_grad_hook(param: torch.Tensor):
     engine's post-accumulate hook fires once per parameter after ALL of its uses in the graph (also for an undefined gradient), so a weight
     used twice in one backward is complete before its bucket's exchange starts."""
     ent = _DIRECT_GRAD.get(id(param))
-    if ent is None:
+    if ent is None or not engine_fires_hooks_for_undefined_grads():
         return None
     ref, view_ptr, red = ent
     reducer = red()
@@ -398,6 +435,12 @@ class GradientReducer:
                     view.zero_()
             else:
                 if g is not view:
+                    if self._static_stage == 2 and self._work[self._bucket_of[id(p)]] is not None:
+                        # the bucket's exchange was launched from its recorded last arrival and this gradient came AFTER it (a changed graph
+                        # order, a conditional branch, a checkpointing toggle): copying it in now would write into a flat buffer whose all-reduce
+                        # is in flight on the side stream and leave the gradient unreduced
+                        raise RuntimeError("GradientReducer(static_graph=True): a gradient arrived after its bucket's exchange had been launched -- "
+                                           "the backward order differs from the recorded step; build the reducer without static_graph for this model")
                     self._adopt(p, view)
                 seen[j] = True
         while self._next < len(self.buckets):

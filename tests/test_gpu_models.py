@@ -222,6 +222,14 @@ def test_captured_forward_is_reused_across_sample_calls_and_refreshed_when_param
     assert graphed._graph_cache[-1][3] is not g1 and len(graphed._graph_cache) == 1  # re-captured, the stale capture dropped
     want3 = eager.sample(noise, m, sched, verbose=False)
     assert torch.equal(got3, want3) and not torch.equal(got3, want)
+    # an EMA-weight swap through .data: no _version moves, the storage does -- the stale capture (old panels, old bias storage) must not be replayed
+    g3 = graphed._graph_cache[-1][3]
+    for p in m.parameters():
+        p.data = (p.data * 0.97).clone()
+    got4 = graphed.sample(noise, m, sched, verbose=False)
+    assert graphed._graph_cache[-1][3] is not g3
+    want4 = eager.sample(noise, m, sched, verbose=False)
+    assert torch.equal(got4, want4) and not torch.equal(got4, want3)
 
 
 def test_ddpm_chain_with_seeded_cpu_noise_matches_reference():

@@ -215,6 +215,35 @@ def test_captured_forward_cache_keys_on_shapes_and_parameter_versions(monkeypatc
     inf._cached_graph(m2, x, t, None)
     inf._cached_graph(m2, torch.zeros(2, 4, 8, 8), t, None)
     assert len(inf._graph_cache) <= inf.GRAPH_CACHE_SIZE
+    # writes through .data do not bump _version (an EMA-weight swap, module.to(), .half()): the storage / dtype are part of the signature
+    inf.clear_graph_cache()
+    m3 = torch.nn.Linear(4, 4).eval()
+    g3 = inf._cached_graph(m3, x, t, None)
+    v0 = m3.weight._version
+    m3.weight.data = torch.ones(4, 4)                                                  # p.data = ema_p.data
+    assert m3.weight._version == v0                                                    # (what ADVICE r4 pointed at)
+    g4 = inf._cached_graph(m3, x, t, None)
+    assert g4 is not g3
+    m3.to(torch.float64)
+    g5 = inf._cached_graph(m3, x, t, None)
+    assert g5 is not g4
+    # the autocast compute dtype is part of the signature too
+    import generativemodels_amd as gm
+    with gm.autocast(torch.bfloat16):
+        g6 = inf._cached_graph(m3, x, t, None)
+    assert g6 is not g5
+    # a dropped model releases its capture (the cached object holds no strong reference to it)
+    inf.clear_graph_cache()
+    import gc
+    import weakref
+    m4 = torch.nn.Linear(4, 4)
+    inf._cached_graph(m4, x, t, None)
+    w = weakref.ref(m4)
+    del m4
+    gc.collect()
+    assert w() is None
+    inf._cached_graph(m2, x, t, None)                                                  # the next insertion prunes the dead entry
+    assert all(e[0]() is not None for e in inf._graph_cache)
 
 
 def test_install_as_generative_aliases_the_reference_import_paths():
@@ -775,4 +804,4 @@ def test_bench_module_imports_and_its_power_sampler_degrades_without_a_gpu():
     ps.start()
     out = ps.stop()
     assert out is None or (out["mean_w"] > 0 and out["samples"] >= 1)
-    assert set(bench.MFMA_BF16_SUSTAINED_TFLOPS.values()) == {1850.0, 1490.0, 1600.0}
+    assert set(bench.MFMA_BF16_SUSTAINED_TFLOPS.values()) == {1863.0, 1490.0, 1621.0}  # profiles/r04_mfma_power_ceiling.txt
