@@ -14,7 +14,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libgmamd.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "conv_fast.hip", "conv_dma.hip", "conv_mw.hip", "conv_w8.hip", "conv_sk.hip", "conv_edge.hip", "attention.hip", "attention_dma.hip", "attention_bwd.hip", "transformer_ops.hip", "decode_step.hip", "small_ops.hip", "backward.hip", "vq.hip"]
+# "file.hip#k": the file compiled with -DGM_DMA_PART=k into its own object (conv_dma.hip: 26 kernel instantiations, 4.5 minutes as one
+# translation unit -- five parts build in parallel)
+SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "conv_fast.hip", "conv_dma.hip#1", "conv_dma.hip#0", "conv_dma.hip#2", "conv_dma.hip#3",
+           "conv_dma.hip#4", "conv_mw.hip", "conv_w8.hip", "conv_sk.hip", "conv_edge.hip", "attention.hip", "attention_dma.hip", "attention_bwd.hip", "transformer_ops.hip", "decode_step.hip", "small_ops.hip", "backward.hip", "vq.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
@@ -67,11 +70,14 @@ _variant = None
 
 
 def _compile(src: str) -> str:
-    obj = os.path.join(OBJDIR if _variant is None else OBJDIR + "_" + _variant, os.path.splitext(src)[0] + ".o")
+    part = None
+    if "#" in src:
+        src, part = src.split("#")
+    obj = os.path.join(OBJDIR if _variant is None else OBJDIR + "_" + _variant, os.path.splitext(src)[0] + ("" if part is None else f"_p{part}") + ".o")
     srcp = os.path.join(CSRC, src)
     deps = [srcp, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     if _stale(obj, deps):
-        extra = os.environ.get("GM_EXTRA_HIPCC_FLAGS", "").split() + (VARIANTS[_variant] if _variant else [])
+        extra = os.environ.get("GM_EXTRA_HIPCC_FLAGS", "").split() + (VARIANTS[_variant] if _variant else []) + ([] if part is None else [f"-DGM_DMA_PART={part}"])
         if _variant == "asan" and src in ASAN_PLAIN:  # (still built for gfx950:xnack+ so that the library loads as one code object family)
             extra = [f for f in extra if not f.startswith("-fsanitize") and f != "-shared-libsan"]
         flags = [f if not f.startswith("--offload-arch=") or _variant != "asan" else f"--offload-arch={ARCH}:xnack+" for f in FLAGS]

@@ -10,5 +10,7 @@ VARIANTS = {
     # LD_PRELOAD of libclang_rt.asan-x86_64.so, PYTORCH_NO_CUDA_MEMORY_CACHING=1 so that every tensor is its own hipMalloc with red zones).
     # The LDS-DMA requests are inline assembly and are NOT instrumented; every compiler-generated global access is.
     "asan": ["-fsanitize=address", "-shared-libsan", "-g1", "-DGM_ASAN_BUILD"],
+    "ldsep": ["-DGM_CONV_LDS_EPILOGUE"],                       # round 5 A/B: the LDS-transposed epilogue on the 64-channel tiles (the pre-round-5 form)
+    "ldsep_timeline": ["-DGM_CONV_LDS_EPILOGUE", "-DGM_CONV_TIMELINE"],
     "ebi": ["-DGM_CONV_EARLY_BARRIER", "-DGM_CONV_DMA_INTERLEAVE"],  # ... plus the panel request's DMA instructions spread over a tap's MFMAs
 }

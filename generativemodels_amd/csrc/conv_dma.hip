@@ -15,6 +15,7 @@
 // Tile: 4x4x16 = 256 voxels x 64 channels, 8 waves (32 voxels x 64 channels each), 78 KiB LDS -> two work-groups per CU, one
 // staging its patch while the other computes.
 #include "conv_dma_shared.h"
+#include <type_traits>
 
 // bench-only build (-DGM_CONV_TIMELINE, tools/conv_timeline.py): thread 0 of every work-group stamps the shader clock at phase boundaries
 // into GmConvDesc.kpartial (64 slots per work-group) when debug_flags bit 12 is set; compiled out of the shipped library
@@ -27,7 +28,14 @@
 #else
 #define TL_STAMP(k)
 #endif
-__device__ __attribute__((aligned(64))) unsigned int gm_zero_row[16] = {0};  // the source of every padding row
+// This file is compiled once per PART (-DGM_DMA_PART=k, _build.py: one object per part, in parallel -- the seven tile configurations x two dtypes x
+// the prologue forms took 4.5 minutes as one translation unit): part 0 = the host entry points + cfg 11, 1 = cfg 14, 2 = cfg 15 + 17,
+// 3 = cfg 16 + 18, 4 = cfg 19.  Without the define everything lands in one translation unit.
+#ifndef GM_DMA_PART
+#define GM_DMA_PART (-1)
+#endif
+#define DMA_PART(k) (GM_DMA_PART == -1 || GM_DMA_PART == (k))
+static __device__ __attribute__((aligned(64))) unsigned int gm_zero_row[16] = {0};  // the source of every padding row (one per part)
 
 // NW waves per work-group, each owning MF voxel fragments (16 voxels) x 64 channels of the 256-voxel tile: <8, 2> = 16 waves / CU,
 // 0.75 LDS operand reads per MFMA; <4, 4> = 8 waves / CU with 256 VGPRs each, 0.5 reads per MFMA (the LDS port is the next limit
@@ -44,8 +52,16 @@ __device__ __attribute__((aligned(64))) unsigned int gm_zero_row[16] = {0};  // 
 // twice the output channels -- half the patch traffic per multiply-add, 0.375 instead of 0.5 LDS operand reads per MFMA at MF = 4).
 // PRE: the instantiation that applies the fused GroupNorm-apply + activation prologue in LDS (a separate instantiation so that the plain
 // kernel's register allocation -- 128 VGPRs = four waves per SIMD for cfg 11 -- is not disturbed by code it never runs).
+// phase_wgs / phase_sleeps: the ONE-TIME phase offset between the work-groups that share a CU (round 5).  The dispatcher starts the co-resident
+// work-groups of a CU together, their tiles take equal time, and every replacement starts when its predecessor ends: the work-groups of a CU
+// run in LOCK STEP for the whole launch -- both in the tap loop (each gets half the MFMA pipe), then both in the epilogue (the pipe idles):
+// tile life = non-loop time + 2 x MFMA time, which is what the cycle stamps show (64 -> 64: 18 k + 2 x 13.8 k = 45.6 k modelled, 44.3 k
+// measured; 192 -> 64: 119 k modelled, 117.9 k measured).  Delaying the work-groups of the FIRST residency round that sit in an odd
+// work-group slot of their CU (HW_ID.TG_ID) by about half a tile puts one work-group's epilogue / chunk boundary under the other's tap
+// loop; every later work-group inherits the phase of the slot it is dispatched into.  (The round-2 skew experiment delayed EVERY tile of the
+// odd slot by <= 3 k cycles -- a permanent handicap of one slot, not a phase.)  Results do not depend on it.
 template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR_ = 4, bool PRE = false>
-__global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p) {
+__global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p, const unsigned phase_wgs, const unsigned phase_sleeps) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * NW;
@@ -71,6 +87,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   static_assert(NFR == 4 || (NFR == 8 && KS == 3 && S == 1 && (WROWS / 16) % NW == 0), "BN = 128: whole pieces per wave");
   static_assert(WROWS == (KS == 3 ? 3 : 2) * BN, "G taps per weight panel");
   static_assert(NGROUPS % RING == 0, "the ring slot of a group is a compile-time constant");
+#ifdef GM_CONV_LDS_EPILOGUE
+  constexpr bool DIRECT_W = false;
+#else
+  constexpr bool DIRECT_W = NFR == 4;  // weight rows in direct_chan() order (the register-direct epilogue below)
+#endif
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB][addend vector 512 B]
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -79,6 +100,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
+  if (blockIdx.x < phase_wgs) {  // (first residency round only; work-group uniform)
+    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);  // HW_REG_HW_ID[19:16] = TG_ID: the work-group's slot on its CU
+    if (tg & 1) {
+      for (unsigned k = phase_sleeps; k > 0; --k) __builtin_amdgcn_s_sleep(16);  // 16 x 64 = 1 024 cycles per iteration
+    }
+  }
 
   // ---- launch constants -------------------------------------------------------------------------------------------------------------------
   // KS = 2: the tiles walk the low-resolution grid (= the input grid); p.Do/Ho/Wo are the full-resolution output extents
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
                               : NW == 8 ? (h == 0 ? 16 * wave + (lane_w >> 2) : 128 + 8 * wave + ((lane_w & 31) >> 2))
                                         : (NW == 4 ? 16 * (wave + NW * h) + (lane_w >> 2) : 16 * (wave < 12 ? wave : 0) + (lane_w >> 2));
       const int u = row / BN, col = row % BN;
-      const int co = t.cb * BN + col;
+      const int co = t.cb * BN + (DIRECT_W ? direct_col_chan<T>(col) : col);  // (the LDS row keeps its place and swizzle: only its SOURCE changes)
       wsrc[h] = co < cout_pad ? ((u * cout_pad + co) * DMA_ROWB + (((lane_w & 3) ^ dma_swz(row)) << 4)) : -1;
     }
   };
@@ -285,6 +312,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   static_assert(EARLY || SCRATCH_BYTES <= PATCH_BYTES + RING_BYTES, "the transpose scratch fits under the addend vector");
   static_assert(BN * 8 <= SCRATCH_WAVE, "a wave's statistic partials fit into its scratch block");
   float* addv = reinterpret_cast<float*>(smem + PATCH_BYTES + RING_BYTES);  // per-channel epilogue addend of this work-group's BN output channels
+  // DIRECT: the register-direct epilogue (conv_dma_shared.h): the weight rows of a panel are DMA'd in direct_chan() order, so that a lane's
+  // accumulators are 16-byte runs of the output row and no LDS transpose is needed (64-channel tiles; bench A/B: -DGM_CONV_LDS_EPILOGUE restores
+  // the transposed form everywhere)
+#ifdef GM_CONV_LDS_EPILOGUE
+  constexpr bool DIRECT = false;
+#else
+  constexpr bool DIRECT = NFR == 4;
+#endif
   constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
   constexpr int CH_PER_PASS = 128 / (int)sizeof(T);
   static_assert(EPASSES <= 4, "at most 4 epilogue passes (128 output channels in fp32)");
@@ -580,7 +615,49 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     const bool partial = KS == 3 && S == 1 && ksplit > 1;
     EpRows<MF * 2> rows0;
     OPAQUE_LANE(lane_e);
-    if (!partial) dma_epilogue_rows<T, MF, KS, 0>(cold_desc(), et, wave * MF, lane_e, rows0);  // residual rows of the first pass: requested now, used after the transpose
+    // ---- register-direct epilogue, part 1: row placement + residual requests (their latency runs under the shortcut / the barrier) ----------------
+    // W line mf of this wave = tile line wave * MF + mf: (depth, height) wave-uniform, the 16 lanes l15 are its 16 voxels.  Address of store st:
+    // scalar row base + lane offset (voxel l15, 16-byte run q) + 64 st.
+    constexpr int NST = 16 / VECW;  // 16-byte stores per voxel and lane: 2 (bf16) / 4 (fp32)
+    // (the residual rows share rows0.rv with the transposed form: a second 32-register array live across the shortcut pushed the patch / shortcut
+    //  source offsets into scratch -- and a scratch reload queued behind an LDS-DMA request returns only after it.  fp32 would need 64: it loads
+    //  the residual at the use, the parity path's latency is not the benchmark's)
+    constexpr bool RES_AHEAD = sizeof(T) == 2;
+    bool d_direct = false, d_lane_ok = false;
+    int d_yoff = 0, d_roff = 0;
+    if constexpr (DIRECT) {
+      KDesc& pd = cold_desc();
+      d_direct = pd.post_act == 0 && !partial;
+      if (d_direct) {
+        const int l15e = lane_e & 15, qe = lane_e >> 4;
+        const int Wl = KS == 2 ? pd.Ws : pd.Wo;
+        const int lw = KS == 2 ? 2 * l15e : l15e;              // this lane's voxel within the OUTPUT's W line
+        d_yoff = lw * (int)(pd.y_ld * (long long)sizeof(T)) + 16 * qe;
+        d_roff = lw * (int)(pd.res_ld * (long long)sizeof(T)) + 16 * qe;
+        d_lane_ok = ow0 + l15e < Wl;
+#pragma unroll
+        for (int it = 0; it < MF * 2; ++it) rows0.rv[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (RES_AHEAD && pd.res) {
+          const int Dl = KS == 2 ? pd.Ds : pd.Do, Hl = KS == 2 ? pd.Hs : pd.Ho;
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            const int line = wave * MF + mf;
+            const int od = od0 + (line >> 2), oh = oh0 + (line & 3);
+            if (od < Dl && oh < Hl) {  // wave-uniform
+              const long long vrow = KS == 2 ? (((long long)cur.n * pd.Do + 2 * od + ((cur.par >> 2) & 1)) * pd.Ho + 2 * oh + ((cur.par >> 1) & 1)) * pd.Wo + 2 * ow0 + (cur.par & 1)
+                                             : (((long long)cur.n * pd.Do + od) * pd.Ho + oh) * pd.Wo + ow0;
+              const char* rrow = reinterpret_cast<const char*>(pd.res) + (vrow * pd.res_ld + cur.cb * BN) * (long long)sizeof(T);
+#pragma unroll
+              for (int st = 0; st < NST; ++st) {
+                const int cfirst = cur.cb * BN + (64 * st + 16 * qe) / (int)sizeof(T);
+                if (d_lane_ok && cfirst < pd.Cout) rows0.rv[(mf * NST + st) % (MF * 2)] = *reinterpret_cast<const uint4*>(rrow + (unsigned)(d_roff + 64 * st));
+              }
+            }
+          }
+        }
+      }
+    }
+    if (!partial && !d_direct) dma_epilogue_rows<T, MF, KS, 0>(cold_desc(), et, wave * MF, lane_e, rows0);  // residual rows of the first pass: requested now, used after the transpose
 
     // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
     // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
@@ -599,7 +676,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       }
       const int wpiece = WGEN ? wave : (wave & 3);        // BN = 64: piece wave&3 of a 4-piece panel; BN = 128 (8 waves): piece wave of 8
       const int wcol = wpiece * 16 + (lane_k >> 2);         // weight row of this lane's panel piece
-      const int wco = cur.cb * BN + wcol;
+      const int wco = cur.cb * BN + (DIRECT_W ? direct_col_chan<T>(wcol) : wcol);
       const int wswz = ((lane_k & 3) ^ dma_swz(wcol)) << 4;
       int caddr[MF];
   #pragma unroll
@@ -654,10 +731,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 
 
     TL_STAMP(61);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave is done with the operand buffers (patch + ring) of this tile
-    // ---- next tile: its first patch is on the way while this tile's epilogue runs ------------------------------------------------------------
     const bool has_next = pos + gx < cx;
+    // The barrier "every wave is done with the operand buffers (patch + ring) of this tile": needed before the next tile's patch request and before
+    // anything is written into the ring.  The register-direct epilogue touches no LDS until its statistic partials: with no next tile the barrier
+    // moves behind the output stores (has_next_early = false), where the waves of the work-group have nothing left to lose by waiting.
+    const bool has_next_early = !DIRECT || has_next || partial;
+    if (has_next_early) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // ---- next tile: its first patch is on the way while this tile's epilogue runs ------------------------------------------------------------
     Tile nxt = cur;
     if (has_next) {
       if (ksplit > 1) {
@@ -688,7 +771,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
           float* row = part + ((((long long)cur.n * pe.Do + od) * pe.Ho + oh) * pe.Wo + ow) * pe.Cout;
   #pragma unroll
           for (int nf = 0; nf < NFR; ++nf) {
-            const int co = cur.cb * BN + nf * 16 + (lane_e >> 4) * 4;
+            const int co = cur.cb * BN + (DIRECT ? direct_chan<T>(nf, lane_e >> 4, 0) : nf * 16 + (lane_e >> 4) * 4);
             if (co < pe.Cout)  // host-checked: Cout % 4 == 0
               *reinterpret_cast<float4*>(row + co) = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
           }
@@ -700,27 +783,199 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #ifdef GM_CONV_ABLATE
     if (!(pe.debug_flags & 256)) {  // bench-only: main loop without the epilogue
 #endif
+    if (DIRECT && d_direct) {
+      // ---- register-direct epilogue, part 2: + addend, round, (+ residual, round), 16-byte stores, statistics of the stored values ----------------
+      // Straight-line code per form (residual yes / no x tile fully inside the volume yes / no): no wave-uniform branch between the eight stores
+      // of a wave, so their dependent chains interleave; a lane outside the volume (or past C_out) is masked at the store and contributes
+      // zeros to the statistics (a select on the packed value -- conditional accumulation costs a copy per accumulator and branch arm).
+      const int qe = lane_e >> 4;
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      f32x2_t ds[NST][VECW / 2], dq[NST][VECW / 2];
+#pragma unroll
+      for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int i = 0; i < VECW / 2; ++i) { ds[st][i] = (f32x2_t){0.f, 0.f}; dq[st][i] = (f32x2_t){0.f, 0.f}; }
+      const int Dl = KS == 2 ? pe.Ds : pe.Do, Hl = KS == 2 ? pe.Hs : pe.Ho, Wl = KS == 2 ? pe.Ws : pe.Wo;
+      const bool has_res = pe.res != nullptr, has_stats = pe.stats != nullptr;
+      const bool full = od0 + TD <= Dl && oh0 + TH <= Hl && ow0 + TW <= Wl && (cur.cb + 1) * BN <= pe.Cout;  // wave-uniform: the common tile
+      bool ok_st[NST];
+#pragma unroll
+      for (int st = 0; st < NST; ++st) ok_st[st] = d_lane_ok && cur.cb * BN + (64 * st + 16 * qe) / (int)sizeof(T) < pe.Cout;
+      f32x2_t addl[NST][VECW / 2];  // this lane's 16 channels of the addend vector
+#pragma unroll
+      for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int i = 0; i < VECW; i += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(addv + (64 * st) / (int)sizeof(T) + qe * VECW + i);
+          addl[st][i / 2] = (f32x2_t){a.x, a.y};
+          addl[st][i / 2 + 1] = (f32x2_t){a.z, a.w};
+        }
+      auto direct_stores = [&](auto RESc, auto FULLc) __attribute__((always_inline)) {
+        constexpr bool RES = decltype(RESc)::value, FULL = decltype(FULLc)::value;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int line = wave * MF + mf;
+          const int od = od0 + (line >> 2), oh = oh0 + (line & 3);
+          const bool row_ok = FULL || (od < Dl && oh < Hl);  // wave-uniform
+          const long long vrow = KS == 2 ? (((long long)cur.n * pe.Do + 2 * od + ((cur.par >> 2) & 1)) * pe.Ho + 2 * oh + ((cur.par >> 1) & 1)) * pe.Wo + 2 * ow0 + (cur.par & 1)
+                                         : (((long long)cur.n * pe.Do + od) * pe.Ho + oh) * pe.Wo + ow0;
+          char* yrow = reinterpret_cast<char*>(pe.y) + (vrow * pe.y_ld + cur.cb * BN) * (long long)sizeof(T);
+          const char* rrow = reinterpret_cast<const char*>(pe.res) + (vrow * pe.res_ld + cur.cb * BN) * (long long)sizeof(T);
+#pragma unroll
+          for (int st = 0; st < NST; ++st) {
+            const bool ok = FULL || (row_ok && ok_st[st]);
+            f32x2_t o[VECW / 2];
+#pragma unroll
+            for (int i = 0; i < VECW / 2; ++i) {
+              const f32x4_t c = acc[st * (VECW / 4) + (i >> 1)][mf];
+              o[i] = (i & 1 ? (f32x2_t){c[2], c[3]} : (f32x2_t){c[0], c[1]}) + addl[st][i];
+            }
+            uint32_t w[4];
+            auto pack4 = [&]() __attribute__((always_inline)) {
+              if (sizeof(T) == 2) {
+#pragma unroll
+                for (int i = 0; i < VECW / 2; ++i) w[i] = pack_bf16x2(o[i][0], o[i][1]);
+              } else {
+                w[0] = __float_as_uint(o[0][0]); w[1] = __float_as_uint(o[0][1]); w[2] = __float_as_uint(o[1][0]); w[3] = __float_as_uint(o[1][1]);
+              }
+            };
+            auto unpack4 = [&](const uint32_t (&u)[4], f32x2_t (&v)[VECW / 2]) __attribute__((always_inline)) {
+              if (sizeof(T) == 2) {
+#pragma unroll
+                for (int i = 0; i < VECW / 2; ++i) v[i] = (f32x2_t){__uint_as_float(u[i] << 16), __uint_as_float(u[i] & 0xffff0000u)};
+              } else {
+                v[0] = (f32x2_t){__uint_as_float(u[0]), __uint_as_float(u[1])};
+                v[1] = (f32x2_t){__uint_as_float(u[2]), __uint_as_float(u[3])};
+              }
+            };
+            pack4();
+            if (RES) {  // the reference adds the residual to the ROUNDED convolution output and rounds again (x + h in the compute dtype)
+              uint4 rv = RES_AHEAD ? rows0.rv[(mf * NST + st) % (MF * 2)] : make_uint4(0u, 0u, 0u, 0u);
+              if (!RES_AHEAD && ok) rv = *reinterpret_cast<const uint4*>(rrow + (unsigned)(d_roff + 64 * st));
+              const uint32_t ru[4] = {rv.x, rv.y, rv.z, rv.w};
+              f32x2_t r[VECW / 2];
+              unpack4(w, o);
+              unpack4(ru, r);
+#pragma unroll
+              for (int i = 0; i < VECW / 2; ++i) o[i] += r[i];
+              pack4();
+            }
+            if (ok) *reinterpret_cast<uint4*>(yrow + (unsigned)(d_yoff + 64 * st)) = make_uint4(w[0], w[1], w[2], w[3]);
+            // statistics of the values as stored (rounded to T), like a separate pass over the tensor would see them
+            if (!FULL) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) w[i] = ok ? w[i] : 0u;
+            }
+            unpack4(w, o);
+#pragma unroll
+            for (int i = 0; i < VECW / 2; ++i) {
+              ds[st][i] += o[i];
+              dq[st][i] = __builtin_elementwise_fma(o[i], o[i], dq[st][i]);
+            }
+          }
+        }
+      };
+      if (has_res) {
+        if (full) direct_stores(std::true_type{}, std::true_type{}); else direct_stores(std::true_type{}, std::false_type{});
+      } else {
+        if (full) direct_stores(std::false_type{}, std::true_type{}); else direct_stores(std::false_type{}, std::false_type{});
+      }
+      TL_STAMP(62);
+      if (has_stats) {
+        // lane sums over its MF voxels -> sum over the 16 voxel lanes of a row: (NW > 4: one / two DPP rotate-adds first, the ring holds 9 KiB
+        // per wave at NW = 4) every lane with l15 < WL stores its 16 (sum, sum of squares) pairs as one 128-byte row of the wave's own scratch
+        // block, lane t then adds the WL rows of ITS channel in a fixed order -> one partial per (wave, channel) -> fixed-order fp64 sum over
+        // the waves: deterministic, one plain store per (tile, channel)
+        constexpr int DSTEPS = NW <= 4 ? 0 : (NW == 8 ? 1 : 2), WL = 16 >> DSTEPS, WSCR = RING_BYTES / NW;
+        static_assert(4 * WL * 144 <= WSCR && BN * 8 <= WSCR, "a wave's statistic rows fit into its share of the weight ring");
+        OPAQUE_LANE(lane_s);
+        if (DSTEPS >= 1) {
+#pragma unroll
+          for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int i = 0; i < VECW; ++i) { ds[st][i / 2][i & 1] += dpp_row_ror8(ds[st][i / 2][i & 1]); dq[st][i / 2][i & 1] += dpp_row_ror8(dq[st][i / 2][i & 1]); }
+        }
+        if (DSTEPS >= 2) {
+#pragma unroll
+          for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int i = 0; i < VECW; ++i) { ds[st][i / 2][i & 1] += dpp_row_ror4(ds[st][i / 2][i & 1]); dq[st][i / 2][i & 1] += dpp_row_ror4(dq[st][i / 2][i & 1]); }
+        }
+        if (!has_next_early) {  // (one tile per work-group: the barrier that frees the ring was not needed until here)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        char* wscr = smem + PATCH_BYTES + (size_t)wave * WSCR;
+        const int l15s = lane_s & 15, qs = lane_s >> 4;
+        if (l15s < WL) {
+          char* rowp = wscr + (qs * WL + l15s) * 144;
+#pragma unroll
+          for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int i = 0; i < VECW; i += 2)
+              *reinterpret_cast<float4*>(rowp + (st * VECW + i) * 8) = make_float4(ds[st][i / 2][0], dq[st][i / 2][0], ds[st][i / 2][1], dq[st][i / 2][1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lane t = channel t of the block: byte b = t * sizeof(T) of the row -> store st = b / 64, lane quarter (b % 64) / 16, element (b % 16) / sizeof(T)
+        const int bch = lane_s * (int)sizeof(T);
+        const char* colp = wscr + (((bch & 63) >> 4) * WL) * 144 + ((bch >> 6) * VECW + (bch & 15) / (int)sizeof(T)) * 8;
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int w = 0; w < WL; ++w) {
+          const float2 v = *reinterpret_cast<const float2*>(colp + w * 144);
+          sa += v.x;
+          sb += v.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        *reinterpret_cast<float2*>(wscr + lane_s * 8) = make_float2(sa, sb);  // (every lane of the wave has read its rows: the block's head is free)
+        __syncthreads();
+        const int ch = wave * 64 + lane_s;  // (= threadIdx.x, from the phase's own lane id)
+        if (ch < BN) {
+          double a = 0.0, b2 = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            const float2 v = *reinterpret_cast<const float2*>(smem + PATCH_BYTES + w * WSCR + ch * 8);
+            a += (double)v.x;
+            b2 += (double)v.y;
+          }
+          const int co = cur.cb * BN + ch;
+          if (co < pe.Cout) {
+            const long long slot = ((long long)(cur.td_i * nth + cur.th_i) * ntw + cur.tw_i) * (KS == 2 ? 8 : 1) + cur.par;  // the tile within its sample
+            double* dst = pe.stats + ((slot * pe.N + cur.n) * pe.Cout + co) * 2;  // fixed-order reduction over the slots by the consumers, no atomics
+            *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
+          }
+        }
+      }
+    } else {
+    if (DIRECT && !has_next_early) {  // (the transposed form needs the operand buffers: the barrier the direct form postpones)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
 #pragma unroll
     for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
       for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
     char* scratch = smem + SCRATCH_OFF + (size_t)wave * SCRATCH_WAVE;
-    dma_epilogue_pass<T, MF, NFR, KS, 0>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows0, st_s, st_q);
+    dma_epilogue_pass<T, MF, NFR, KS, 0, DIRECT>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows0, st_s, st_q);
     if constexpr (EPASSES > 1) {
       EpRows<MF * 2> rows;
       dma_epilogue_rows<T, MF, KS, 1>(pe, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 1>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_pass<T, MF, NFR, KS, 1, DIRECT>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     if constexpr (EPASSES > 2) {
       EpRows<MF * 2> rows;
       dma_epilogue_rows<T, MF, KS, 2>(pe, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 2>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_pass<T, MF, NFR, KS, 2, DIRECT>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     if constexpr (EPASSES > 3) {
       EpRows<MF * 2> rows;
       dma_epilogue_rows<T, MF, KS, 3>(pe, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 3>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_pass<T, MF, NFR, KS, 3, DIRECT>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
     }
     TL_STAMP(62);
     if (pe.stats) {
@@ -758,6 +1013,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         }
       }
     }
+    }  // (the LDS-transposed form)
 #ifdef GM_CONV_ABLATE
     }
 #endif
@@ -790,6 +1046,7 @@ extern "C" int gm_conv_w8_launch(const GmConvDesc* dp, unsigned nblocks, void* s
 extern "C" int gm_conv_sk_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 
+#if DMA_PART(0)
 extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   const long long addv = 512;
   if (variant == 6) return gm_conv_mw_lds_bytes();
@@ -800,6 +1057,7 @@ extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB + addv;
 }
 
+#endif
 // Grid policy: 0 (default) = one work-group per tile; -1 = at most as many work-groups as the device holds at once (CUs x work-groups per CU
 // by LDS and wave count): a work-group then walks several tiles (see the kernel's work list); n > 0 = at most n work-groups (tests).
 // Measured on MI355X (profiles/r02_conv_timeline_grid_policy_ab.txt, C2 bench): the walk hides the first patch's latency (wait 340 vs 1 350-2 450
@@ -807,19 +1065,36 @@ extern "C" long long gm_conv_dma_lds_bytes(int variant) {
 // and the epilogue's stores queue behind the six patch requests of the wave (LDS-DMA requests are consumed at ~16 B/clk per CU): 1.238 vs
 // 1.252 volumes/s -- the hardware dispatcher's own overlap of a finishing and a starting work-group is as good, so one tile per work-group stays
 // the default and the walk is kept as a tested option.
-static int g_dma_grid_cap = 0;
-extern "C" void gm_conv_dma_set_persistent(int max_work_groups) { g_dma_grid_cap = max_work_groups; }
+#if DMA_PART(0)
+int gm_dma_grid_cap = 0;
+extern "C" void gm_conv_dma_set_persistent(int max_work_groups) { gm_dma_grid_cap = max_work_groups; }
+
+// One-time phase offset of the odd work-group slot of every CU (see the kernel): cycles, 0 = off, -1 = automatic (half the modelled tile life of
+// the launch's shape).  Process-wide; results do not depend on it.
+int gm_dma_phase_skew = -1;
+extern "C" void gm_conv_dma_set_phase_skew(int cycles) { gm_dma_phase_skew = cycles; }
+#else
+extern int gm_dma_grid_cap, gm_dma_phase_skew;
+#endif
+#define g_dma_grid_cap gm_dma_grid_cap
+#define g_dma_phase_skew gm_dma_phase_skew
+extern "C" long long gm_conv_dma_lds_bytes(int variant);
+extern "C" int gm_conv_dma_variant(int cfg);
+static int dma_device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  return cus;
+}
 
 static unsigned dma_grid(unsigned nwork, long long lds_bytes, int by_waves, bool splitk) {
   if (splitk || g_dma_grid_cap == 0) return nwork;  // split-K launches are small by construction
   long long cap = g_dma_grid_cap;
   if (cap < 0) {
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-      cus = n;
-    }
+    const int cus = dma_device_cus();
     long long per_cu = (160LL * 1024) / lds_bytes;  // co-resident work-groups per CU: by LDS and by the waves per SIMD the kernel was built for
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
@@ -829,6 +1104,7 @@ static unsigned dma_grid(unsigned nwork, long long lds_bytes, int by_waves, bool
   return nwork < (unsigned)cap ? nwork : (unsigned)cap;
 }
 
+#if DMA_PART(0)
 // geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)
 extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 22 ? 7 : cfg == 21 ? 6 : cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
 
@@ -868,6 +1144,7 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
                               (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
 }
 
+#endif
 template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR = 4, bool PRE = false>
 static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
@@ -880,31 +1157,88 @@ static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   const long long lds = gm_conv_dma_lds_bytes(gm_conv_dma_variant(d.cfg));
   const bool splitk = d.ksplit > 1 && d.kpartial != nullptr;
   constexpr int BY_WAVES = MINW * 4 / NW >= 1 ? MINW * 4 / NW : 1;  // __launch_bounds__(64 * NW, MINW): MINW waves per SIMD = MINW * 4 / NW work-groups per CU
-  kern<<<dim3(dma_grid(nblocks, lds, BY_WAVES, splitk)), 64 * NW, (size_t)lds, st>>>(d);
+  const unsigned grid = dma_grid(nblocks, lds, BY_WAVES, splitk);
+  // ---- one-time phase offset between the co-resident work-groups of a CU (see the kernel) -----------------------------------------------------
+  long long per_cu = (160LL * 1024) / lds;
+  if (per_cu > BY_WAVES) per_cu = BY_WAVES;
+  const unsigned resident = (unsigned)(per_cu * dma_device_cus());
+  unsigned phase_wgs = 0, phase_sleeps = 0;
+  if (per_cu >= 2 && !splitk && g_dma_phase_skew != 0 && nblocks >= 2 * resident) {  // (fewer than two rounds of tiles: the offset would only lengthen the launch)
+    long long cycles = g_dma_phase_skew;
+    if (cycles < 0) {
+      // modelled tile life: MFMA issue cycles of the tile's tap loop for the co-resident waves of a SIMD + the per-tile fixed work (stamps: ~18 k)
+      const long long chunks = d.Cin / (d.dtype == GM_F32 ? 16 : 32), taps = KS * KS * KS;
+      const long long mfma_cycles = chunks * taps * (MF * NFR) * (d.dtype == GM_F32 ? 4 * 8 : 16);  // per wave
+      const long long waves_per_simd = per_cu * NW / 4 > 0 ? per_cu * NW / 4 : 1;
+      cycles = (18000 + waves_per_simd * mfma_cycles) / 2;
+    }
+    phase_wgs = resident;
+    phase_sleeps = (unsigned)((cycles + 512) / 1024);
+    if (phase_sleeps == 0) phase_wgs = 0;
+  }
+  kern<<<dim3(grid), 64 * NW, (size_t)lds, st>>>(d, phase_wgs, phase_sleeps);
 }
 
-template <typename T>
-static void dispatch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
-#ifdef GM_DMA_QUICK  // ISA studies only: one instantiation (bf16 cfg 11) compiles in seconds
-  if (sizeof(T) == 2) launch_dma<bf16_raw, 8, 2, 1, 4>(d, nblocks, st);
-  return;
-#endif
+// ---- the parts: each defines the launcher of its tile configurations ----------------------------------------------------------------------------
+#define DMA_BY_DTYPE(...)                                                                    \
+  do {                                                                                       \
+    if (d.dtype == GM_F32) { using T = float; __VA_ARGS__; return 0; }                       \
+    if (d.dtype == GM_BF16) { using T = bf16_raw; __VA_ARGS__; return 0; }                   \
+    return -2;                                                                               \
+  } while (0)
+extern "C" int gm_conv_dma_launch_part0(const GmConvDesc* dp, unsigned nblocks, void* stream);
+extern "C" int gm_conv_dma_launch_part1(const GmConvDesc* dp, unsigned nblocks, void* stream);
+extern "C" int gm_conv_dma_launch_part2(const GmConvDesc* dp, unsigned nblocks, void* stream);
+extern "C" int gm_conv_dma_launch_part3(const GmConvDesc* dp, unsigned nblocks, void* stream);
+extern "C" int gm_conv_dma_launch_part4(const GmConvDesc* dp, unsigned nblocks, void* stream);
+#if DMA_PART(0)
+extern "C" int gm_conv_dma_launch_part0(const GmConvDesc* dp, unsigned nblocks, void* stream) {  // cfg 11: 8 waves x 32 voxels, two work-groups per CU
+  const GmConvDesc& d = *dp; hipStream_t st = (hipStream_t)stream;
   const bool pre = d.pre_scale != nullptr;  // eligibility (gm_conv_dma_eligible) admits a prologue for the stride-1 3x3x3 variants only
-  if (d.cfg == 19) { if (pre) launch_dma<T, 8, 4, 1, 2, 3, 8, true>(d, nblocks, st); else launch_dma<T, 8, 4, 1, 2, 3, 8>(d, nblocks, st); }  // 512 voxels x 128 channels
-  else if (d.cfg == 18) { if (pre) launch_dma<T, 8, 4, 1, 2, 3, 4, true>(d, nblocks, st); else launch_dma<T, 8, 4, 1, 2>(d, nblocks, st); }  // 512 voxels x 64 channels, 8 waves x 64 voxels
-  else if (d.cfg == 17) launch_dma<T, 8, 2, 1, 4, 2>(d, nblocks, st);  // sub-pixel 2x2x2 kernels of an up-sampling convolution
-  else if (d.cfg == 16) { if (pre) launch_dma<T, 16, 2, 1, 4, 3, 4, true>(d, nblocks, st); else launch_dma<T, 16, 2, 1, 4>(d, nblocks, st); }  // 512 voxels (8x4x16), 16 waves
-  else if (d.cfg == 15) launch_dma<T, 8, 1, 2, 2>(d, nblocks, st);   // stride 2: 8 waves x 16 voxels, one work-group per CU
-  else if (d.cfg == 14) { if (pre) launch_dma<T, 4, 4, 1, 2, 3, 4, true>(d, nblocks, st); else launch_dma<T, 4, 4, 1, 2>(d, nblocks, st); }  // 4 waves x 64 voxels
-  else { if (pre) launch_dma<T, 8, 2, 1, 4, 3, 4, true>(d, nblocks, st); else launch_dma<T, 8, 2, 1, 4>(d, nblocks, st); }  // cfg 11: 8 waves x 32 voxels, two work-groups per CU
+  DMA_BY_DTYPE(if (pre) launch_dma<T, 8, 2, 1, 4, 3, 4, true>(d, nblocks, st); else launch_dma<T, 8, 2, 1, 4>(d, nblocks, st));
 }
+#endif
+#if DMA_PART(1)
+extern "C" int gm_conv_dma_launch_part1(const GmConvDesc* dp, unsigned nblocks, void* stream) {  // cfg 14: 4 waves x 64 voxels
+  const GmConvDesc& d = *dp; hipStream_t st = (hipStream_t)stream;
+  const bool pre = d.pre_scale != nullptr;
+  DMA_BY_DTYPE(if (pre) launch_dma<T, 4, 4, 1, 2, 3, 4, true>(d, nblocks, st); else launch_dma<T, 4, 4, 1, 2>(d, nblocks, st));
+}
+#endif
+#if DMA_PART(2)
+extern "C" int gm_conv_dma_launch_part2(const GmConvDesc* dp, unsigned nblocks, void* stream) {
+  const GmConvDesc& d = *dp; hipStream_t st = (hipStream_t)stream;
+  if (d.cfg == 17) DMA_BY_DTYPE((launch_dma<T, 8, 2, 1, 4, 2>(d, nblocks, st)));  // sub-pixel 2x2x2 kernels of an up-sampling convolution
+  DMA_BY_DTYPE((launch_dma<T, 8, 1, 2, 2>(d, nblocks, st)));                      // cfg 15, stride 2: 8 waves x 16 voxels, one work-group per CU
+}
+#endif
+#if DMA_PART(3)
+extern "C" int gm_conv_dma_launch_part3(const GmConvDesc* dp, unsigned nblocks, void* stream) {
+  const GmConvDesc& d = *dp; hipStream_t st = (hipStream_t)stream;
+  const bool pre = d.pre_scale != nullptr;
+  if (d.cfg == 18) DMA_BY_DTYPE(if (pre) launch_dma<T, 8, 4, 1, 2, 3, 4, true>(d, nblocks, st); else launch_dma<T, 8, 4, 1, 2>(d, nblocks, st));  // 512 voxels x 64 channels, 8 waves x 64 voxels
+  DMA_BY_DTYPE(if (pre) launch_dma<T, 16, 2, 1, 4, 3, 4, true>(d, nblocks, st); else launch_dma<T, 16, 2, 1, 4>(d, nblocks, st));                 // cfg 16: 512 voxels (8x4x16), 16 waves
+}
+#endif
+#if DMA_PART(4)
+extern "C" int gm_conv_dma_launch_part4(const GmConvDesc* dp, unsigned nblocks, void* stream) {  // cfg 19: 512 voxels x 128 channels
+  const GmConvDesc& d = *dp; hipStream_t st = (hipStream_t)stream;
+  const bool pre = d.pre_scale != nullptr;
+  DMA_BY_DTYPE(if (pre) launch_dma<T, 8, 4, 1, 2, 3, 8, true>(d, nblocks, st); else launch_dma<T, 8, 4, 1, 2, 3, 8>(d, nblocks, st));
+}
+#endif
 
+#if DMA_PART(0)
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   if (dp->cfg == 21) return gm_conv_mw_launch(dp, nblocks, stream);
   if (dp->cfg == 22) return gm_conv_w8_launch(dp, nblocks, stream);
   if (gm_conv_sk_eligible(dp)) return gm_conv_sk_launch(dp, nblocks, stream);
-  hipStream_t st = (hipStream_t)stream;
-  if (dp->dtype == GM_F32) { dispatch_dma<float>(*dp, nblocks, st); return 0; }
-  if (dp->dtype == GM_BF16) { dispatch_dma<bf16_raw>(*dp, nblocks, st); return 0; }
-  return -2;
+  switch (dp->cfg) {
+    case 14: return gm_conv_dma_launch_part1(dp, nblocks, stream);
+    case 15: case 17: return gm_conv_dma_launch_part2(dp, nblocks, stream);
+    case 16: case 18: return gm_conv_dma_launch_part3(dp, nblocks, stream);
+    case 19: return gm_conv_dma_launch_part4(dp, nblocks, stream);
+    default: return gm_conv_dma_launch_part0(dp, nblocks, stream);
+  }
 }
+#endif

@@ -105,7 +105,9 @@ __device__ __forceinline__ void dma_epilogue_rows(const D& p, const EpTile& t, i
 
 // first half of an epilogue pass: accumulators of the 16x16x32 / 16x16x4 MFMA layout (lane = voxel l15, 4 channels q * 4 ..) + addend -> the
 // wave's transpose scratch, row = voxel, 144-byte pitch
-template <typename T, int MF, int NFR, int PASS>
+// PERM: the accumulator rows stand for channels in the order of direct_chan() below (the kernels with the register-direct epilogue, whose rare
+// output-activation form still comes through here)
+template <typename T, int MF, int NFR, int PASS, bool PERM = false>
 __device__ __forceinline__ void dma_epilogue_write(f32x4_t (&acc)[NFR][MF], char* lds, const float* addv, int lane) {
   constexpr int ROWB_E = 144;                                   // 128 B of channels + 16 B pad
   constexpr int NF_PER_PASS = 128 / (16 * (int)sizeof(T));      // 4 (bf16) or 2 (fp32) channel fragments per pass
@@ -116,10 +118,13 @@ __device__ __forceinline__ void dma_epilogue_write(f32x4_t (&acc)[NFR][MF], char
     constexpr int NF0 = PASS * NF_PER_PASS;
     if (NF0 + nl < NFR) {
       const int nf = NF0 + nl < NFR ? NF0 + nl : NFR - 1;
-      const float4 add = *reinterpret_cast<const float4*>(addv + nf * 16 + q * 4);
+      // channel of this lane's first row of fragment nf, relative to the work-group's block / to the pass's 128-byte run
+      const int ch = PERM && sizeof(T) == 2 ? 32 * (nf >> 1) + 8 * q + 4 * (nf & 1) : nf * 16 + q * 4;
+      const int chl = PERM && sizeof(T) == 2 ? ch : nl * 16 + q * 4;
+      const float4 add = *reinterpret_cast<const float4*>(addv + ch);
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        char* dst = lds + (mf * 16 + l15) * ROWB_E + (nl * 16 + q * 4) * (int)sizeof(T);
+        char* dst = lds + (mf * 16 + l15) * ROWB_E + chl * (int)sizeof(T);
         const float o0 = acc[nf][mf][0] + add.x, o1 = acc[nf][mf][1] + add.y, o2 = acc[nf][mf][2] + add.z, o3 = acc[nf][mf][3] + add.w;
         if (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = make_float4(o0, o1, o2, o3);
         else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
@@ -205,12 +210,35 @@ __device__ __forceinline__ void dma_epilogue_store(const D& p, char* lds, const 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename T, int MF, int NFR, int KS, int PASS, typename D>
+template <typename T, int MF, int NFR, int KS, int PASS, bool PERM = false, typename D>
 __device__ __forceinline__ void dma_epilogue_pass(const D& p, f32x4_t (&acc)[NFR][MF], char* lds, const float* addv, const EpTile& t, int line0,
                                                   int lane, const EpRows<MF * 2>& R,
                                                   float (&st_s)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)],
                                                   float (&st_q)[(NFR * 16 * (int)sizeof(T) + 127) / 128][16 / (int)sizeof(T)]) {
-  dma_epilogue_write<T, MF, NFR, PASS>(acc, lds, addv, lane);
+  dma_epilogue_write<T, MF, NFR, PASS, PERM>(acc, lds, addv, lane);
   dma_epilogue_store<T, MF, KS, PASS, (NFR * 16 * (int)sizeof(T) + 127) / 128>(p, lds, t, line0, lane, R, st_s, st_q);
 }
 
+
+// ---- register-direct epilogue (round 5) -------------------------------------------------------------------------------------------------------
+// The 16x16 MFMA leaves lane (l15 = voxel column, q = lane / 16) of fragment nf with output rows 4q .. 4q + 3 of that fragment's 16: four
+// channels of one voxel.  WHICH channel an MFMA row stands for is free -- it is decided by the order of the weight rows in the LDS panel, i.e. by
+// the source addresses of the panel's DMA requests.  With the order below a lane's 16 values per voxel are 16-byte runs that the four lanes
+// q = 0..3 of a voxel continue into 64 contiguous bytes: store st of a voxel row covers bytes [64 st + 16 q, + 16) of the work-group's
+// channel block (bf16: 2 stores, fp32: 4), a wave instruction writes sixteen 64-byte segments, and the LDS transpose of the epilogue (16
+// ds_write_b64 + 8 ds_read_b128 + two fences per wave and tile, plus a 64-bit voxel address per row group and lane) is gone: a row's address is
+// a scalar base per W line + one per-lane offset.
+//   bf16: channel(nf, q, j) = 32 (nf / 2) + 8 q + 4 (nf % 2) + j        fp32: channel(nf, q, j) = 16 nf + 4 q + j  (the natural order)
+template <typename T>
+__device__ __forceinline__ constexpr int direct_chan(int nf, int q, int j) {
+  return sizeof(T) == 2 ? 32 * (nf >> 1) + 8 * q + 4 * (nf & 1) + j : 16 * nf + 4 * q + j;
+}
+// the output channel (within the work-group's 64) whose weights LDS panel column `col` holds: column nf * 16 + i is MFMA row i of fragment nf
+template <typename T>
+__device__ __forceinline__ int direct_col_chan(int col) {
+  const int nf = col >> 4, i = col & 15;
+  return direct_chan<T>(nf, i >> 2, i & 3);
+}
+__device__ __forceinline__ float dpp_row_ror4(float v) {  // value of lane (l + 4) mod 16 of the same row of 16 lanes
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xF, 0xF, true));
+}
