@@ -90,7 +90,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #ifdef GM_CONV_LDS_EPILOGUE
   constexpr bool DIRECT_W = false;
 #else
-  constexpr bool DIRECT_W = NFR == 4;  // weight rows in direct_chan() order (the register-direct epilogue below)
+  // weight rows in direct_chan() order (the register-direct epilogue below).  Not for the sub-pixel form: its output voxels are every other
+  // voxel of a row, a store instruction would write sixteen isolated 64-byte halves of 128-byte lines (measured: cfg 17 0.84 -> 1.04 ms)
+  constexpr bool DIRECT_W = NFR == 4 && KS == 3;
 #endif
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch 42 KiB][3 weight panels x 12 KiB][addend vector 512 B]
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #ifdef GM_CONV_LDS_EPILOGUE
   constexpr bool DIRECT = false;
 #else
-  constexpr bool DIRECT = NFR == 4;
+  constexpr bool DIRECT = NFR == 4 && KS == 3;
 #endif
   constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
   constexpr int CH_PER_PASS = 128 / (int)sizeof(T);
@@ -1069,9 +1071,13 @@ extern "C" long long gm_conv_dma_lds_bytes(int variant) {
 int gm_dma_grid_cap = 0;
 extern "C" void gm_conv_dma_set_persistent(int max_work_groups) { gm_dma_grid_cap = max_work_groups; }
 
-// One-time phase offset of the odd work-group slot of every CU (see the kernel): cycles, 0 = off, -1 = automatic (half the modelled tile life of
-// the launch's shape).  Process-wide; results do not depend on it.
-int gm_dma_phase_skew = -1;
+// One-time phase offset of the odd work-group slot of every CU (see the kernel): cycles, 0 = off (default), -1 = automatic (half the modelled tile
+// life of the launch's shape).  Process-wide; results do not depend on it.  MEASURED (profiles/r05_phase_skew_sweep.txt): tools/hwid_probe.hip
+// confirms the lock step (the two work-groups of a CU start 40-620 cycles apart, round after round) and that the offset persists (20.5 k
+// cycles, every round) -- and the convolutions do not care: every C2 shape is within +-1.5 % over offsets 0 ... 64 k cycles under both grid
+// policies.  A wave alone on its SIMD issues a 16x16x32 MFMA every ~36 cycles, two waves every ~26 (tools/mfma_power.hip: 1 082 / 1 374
+// TFLOP/s register-resident at one / two waves per SIMD), so the partner's idle phases were never worth a full-rate tap loop.
+int gm_dma_phase_skew = 0;
 extern "C" void gm_conv_dma_set_phase_skew(int cycles) { gm_dma_phase_skew = cycles; }
 #else
 extern int gm_dma_grid_cap, gm_dma_phase_skew;

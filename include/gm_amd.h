@@ -211,7 +211,8 @@ void gm_conv_dma_set_persistent(int max_work_groups);
 /* One-time phase offset between the work-groups that share a CU in the LDS-DMA configurations (process-wide; results do not depend on it): the
  * co-resident work-groups of a CU are dispatched together and run equal-length tiles, i.e. in lock step -- both in the tap loop, then both in
  * the epilogue with the MFMA pipe idle.  The work-groups of the first residency round that sit in an odd work-group slot of their CU sleep
- * `cycles` once; later work-groups inherit the phase of their slot.  0 = off, -1 (default) = half the modelled tile life of the launch. */
+ * `cycles` once; later work-groups inherit the phase of their slot.  0 = off (default: measured no gain on MI355X, profiles/r05_phase_skew_sweep.txt),
+ * -1 = half the modelled tile life of the launch. */
 void gm_conv_dma_set_phase_skew(int cycles);
 /* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
  * software-pipelined over the taps (bench A/B: slower at 128 registers). */

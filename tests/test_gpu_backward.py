@@ -704,6 +704,8 @@ def test_use_checkpointing_recomputes_the_stage_and_leaves_every_gradient_bitwis
     for ckpt in (False, True):
         m = build(ckpt)
         torch.manual_seed(5)  # the reparameterisation draw of AutoencoderKL.sampling
+        import gc
+        gc.collect()  # (garbage of the previous arm / earlier tests collected DURING the forward would be counted as memory this forward freed)
         torch.cuda.synchronize()
         base = torch.cuda.memory_allocated()
         out = m(x)
@@ -712,6 +714,7 @@ def test_use_checkpointing_recomputes_the_stage_and_leaves_every_gradient_bitwis
         loss = F.mse_loss(rec, target) + (out[1].mean() if net == "vqvae" else 0.1 * out[1].pow(2).mean())
         loss.backward()
         res[ckpt] = (rec.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, held)
+        del m, out, rec, loss
     assert torch.equal(res[False][0], res[True][0])
     assert res[False][1].keys() == res[True][1].keys() and len(res[True][1]) > 20
     for k in res[False][1]:

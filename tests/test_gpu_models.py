@@ -20,6 +20,11 @@ def _nets():
     return nets
 
 
+def _ops():
+    from generativemodels_amd import ops
+    return ops
+
+
 def _fp32_close(got, want, what, factor=1.0):
     got, want = got.double().cpu(), want.double().cpu()
     assert got.shape == want.shape, (what, got.shape, want.shape)
@@ -79,6 +84,38 @@ def test_unet_bf16_close_to_fp32_reference(name):
     err = (y.float().cpu() - fx["outputs"]["y"]).abs()
     assert err.mean().item() <= 1.5 * ref["mean_err"], f"{name}: ours bf16 mean|err| {err.mean().item():.3e} vs reference bf16 {ref['mean_err']:.3e}"
     assert err.max().item() <= 2.0 * ref["max_err"], f"{name}: ours bf16 max|err| {err.max().item():.3e} vs reference bf16 {ref['max_err']:.3e}"
+
+
+@pytest.mark.parametrize("flag,cfg", [("DMA_W8", "cfg22"), ("DMA_MW", "cfg21")])
+def test_selectable_tile_configurations_carry_a_whole_model(flag, cfg):
+    """The two selectable LDS-DMA tile configurations (GM_CONV_W8=1 -> cfg 22, conv_w8.hip; GM_CONV_MW=1 -> cfg 21, conv_mw.hip) end to end: the
+    C2-shaped mini UNet (reference weights of the golden fixture) on a 32 x 32 x 48 volume in bf16 with the switch on -- the launches really are
+    on that configuration -- against the fp32 oracle under the bf16 bar of SURVEY 8(c)(3), and next to the default configuration's output
+    (these kernels were only tested per kernel)."""
+    ops = _ops()
+    fx = load_fixture("unet3d_c2mini")
+    x = torch.randn((1, 1, 32, 32, 48), generator=torch.Generator().manual_seed(11))
+    t = torch.tensor([431.0])
+    with torch.no_grad():
+        want = R.unet_forward(fx["state_dict"], fx["cfg"], x, t)
+    m = _build_unet(fx, torch.bfloat16)
+    base = m(_dev(x.bfloat16()), _dev(t))
+    keep = (getattr(ops, flag), ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES)
+    try:
+        setattr(ops, flag, True)
+        ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES = 1, 1
+        ops.start_profile()
+        y = m(_dev(x.bfloat16()), _dev(t))
+        rec = ops.stop_profile()
+    finally:
+        setattr(ops, flag, keep[0])
+        ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES = keep[1], keep[2]
+    used = sorted({name for name, _, _ in rec if "conv_igemm" in name})
+    assert sum(1 for name, _, _ in rec if cfg in name) >= 4, f"{flag}: expected the model's convolutions on {cfg}, launches were {used}"
+    _bf16_close(y, want, f"c2mini 32x32x48 with {flag}")
+    _bf16_close(base, want, "c2mini 32x32x48 default configuration")
+    sigma = want.std().item()
+    assert (y.float() - base.float()).abs().mean().item() <= 2e-2 * sigma  # same function, another tile structure / summation order
 
 
 def test_unet_forward_errors_match_reference():
