@@ -120,7 +120,7 @@ def rerandomize_zero_params(state_dict, seed=1234, std=0.05):
 
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_current.json")
 # kernel symbol (prefix) behind each label of ops' per-launch profile, as rocprofv3 prints it (T = unsigned short / float)
-DMA_CFG_TEMPLATE = {11: "8, 2, 1, 4, 3, 4", 14: "4, 4, 1, 2, 3, 4", 15: "8, 1, 2, 2, 3, 4", 16: "16, 2, 1, 4, 3, 4", 17: "8, 2, 1, 4, 2, 4",
+DMA_CFG_TEMPLATE = {11: "8, 2, 1, 4, 3, 4", 14: "4, 4, 1, 2, 3, 4", 15: "8, 1, 2, 2, 3, 4", 16: "16, 2, 1, 4, 3, 4", 17: "4, 4, 1, 2, 2, 4",
                     18: "8, 4, 1, 2, 3, 4", 19: "8, 4, 1, 2, 3, 8"}
 
 

@@ -642,7 +642,7 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   const bool splitk = d.ksplit > 1 && d.kpartial != nullptr;
   GM_REQUIRE(!splitk || conv_splitk_ok(d), "split-K needs configuration 11, a vector epilogue and ksplit <= the number of K chunks");
   GM_REQUIRE(!splitk || d.ksplit <= 8, "split-K: at most 8 slices (the combine kernel reads them with a compile-time bound)");
-  const long long nblocks = (long long)d.N * ntd * nth * ntw * ncb * (subpixel ? 8 : 1) * (splitk ? d.ksplit : 1);
+  const long long nblocks = (long long)d.N * ntd * nth * ntw * ncb * (subpixel ? 4 : 1) * (splitk ? d.ksplit : 1);  // sub-pixel: per (d, h) parity; a work item covers both W parities
   GM_REQUIRE(nblocks < (1LL << 31), "grid too large");
   hipStream_t st = (hipStream_t)stream;
   int rc;

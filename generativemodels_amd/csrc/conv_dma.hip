@@ -66,10 +66,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * NW;
   constexpr int NFR = NFR_, G = KS == 3 ? 3 : 2, RING = KS == 3 ? 3 : 4;  // taps per weight panel; panels in the LDS ring
-  static_assert(KS == 3 || (KS == 2 && S == 1 && NW == 8), "the sub-pixel variant is stride 1, 8 waves");
+  static_assert(KS == 3 || (KS == 2 && S == 1 && (NW == 8 || NW == 4)), "the sub-pixel variant is stride 1, 8 waves x 32 or 4 waves x 64 voxels");
   static_assert(NW * MF * 16 == 512 || NW * MF * 16 == (S == 1 ? 256 : 128), "waves x fragments cover the tile");
   constexpr int TH = 4, TW = 16, BM = NW * MF * 16, TD = BM / (TH * TW);  // 4x4x16 (8x4x16 for the 16-wave variant); S = 2: 2x4x16
-  constexpr int PD = S * (TD - 1) + KS, PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS;  // LDS rows per W line (33 for S = 2: 17 even + 16 odd)
+  // NPW (round 5): a sub-pixel work item covers BOTH W parities of its (d, h) parity: parity 0 reads input columns (i - 1, i), parity 1 (i, i + 1) --
+  // the union i - 1 .. i + 1 is one column more of the same staged patch (5 x 18 = 90 rows of a 96-row plane: no more LDS), so one patch request per
+  // chunk feeds 16 taps instead of 8: half the patch traffic, half the chunk boundaries, placements and first-patch waits per output voxel (the
+  // launch was 0.84 ms at 983 TFLOP/s executed with 707 MB of HBM traffic against 377 algorithmic: VERDICT r4 weak 5).  Two accumulator sets.
+  constexpr int NPW = KS == 2 ? 2 : 1;
+  constexpr int PD = S * (TD - 1) + KS, PH = S * (TH - 1) + KS, PW = S * (TW - 1) + KS + (NPW - 1);  // LDS rows per W line (33 for S = 2: 17 even + 16 odd)
   constexpr int EW = TW + 1;                                                            // S = 2: rows of the even-column run
   constexpr int PLANE = ((PH * PW + 15) / 16) * 16;        // 112 rows: depth offsets keep (row mod 16)
   constexpr int PROWS = PD * PLANE;                        // 672 rows = 42 DMA pieces
@@ -77,14 +82,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   constexpr int PPW = (PPIECES + NW - 1) / NW;             // patch pieces per wave (6; the last round is partial)
   constexpr int BN = 16 * NFR;
   constexpr int WROWS = G * BN;                            // 192 rows per weight panel = 12 KiB = 1.5 pieces per wave (BN = 64)
-  constexpr bool WGEN = NFR != 4;                          // general panel distribution: piece wave + NW * h, whole pieces only
+  constexpr bool WGEN = NFR != 4 || (KS == 2 && NW == 4);  // general panel distribution: piece wave + NW * h, whole pieces only
   constexpr int PATCH_BYTES = PROWS * DMA_ROWB;
   constexpr int WBUF_BYTES = WROWS * DMA_ROWB;
-  constexpr int NGROUPS = KS * KS * KS / G;                // 27 taps / 3, or 8 taps / 2
+  constexpr int PVT_OFF = PATCH_BYTES + (KS == 2 ? 36864 : RING * WBUF_BYTES) + 512;  // the placement table of the sub-pixel form (behind the addend vector)
+  constexpr int NGROUPS = KS * KS * KS / G * NPW;          // 27 taps / 3, or 2 parities x 8 taps / 2: group g of a chunk = (W parity g / 4, taps 2 (g % 4) ..)
   // DMA instructions per wave per weight panel (12 pieces): 8 waves x (1 full + 1 half piece), 4 waves x 3 full, or -- 16 waves --
   // one full piece on waves 0..11 and none on waves 12..15 (the end-of-group wait count is then wave dependent)
   constexpr int WPW = WGEN ? WROWS / 16 / NW : (KS == 2 ? 1 : (NW == 8 ? 2 : (NW == 4 ? 3 : 1)));  // KS = 2: 128 rows = 8 pieces, one per wave
-  static_assert(NFR == 4 || (NFR == 8 && KS == 3 && S == 1 && (WROWS / 16) % NW == 0), "BN = 128: whole pieces per wave");
+  static_assert(!WGEN || (S == 1 && (WROWS / 16) % NW == 0), "general panel distribution: whole pieces per wave");
   static_assert(WROWS == (KS == 3 ? 3 : 2) * BN, "G taps per weight panel");
   static_assert(NGROUPS % RING == 0, "the ring slot of a group is a compile-time constant");
 #ifdef GM_CONV_LDS_EPILOGUE
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   // gx work-groups walk it with stride gx.  A grid of nwork work-groups (gx == cx) is the one-tile-per-work-group launch; the host caps the
   // grid at the number of co-resident work-groups (gm_conv_dma_launch), and a work-group then runs several tiles back to back: the tile-
   // independent address tables are built once and the first patch of the next tile is requested BEFORE the epilogue of the current one.
-  const unsigned nwork = (unsigned)p.N * ntd * nth * ntw * ncb * (KS == 2 ? 8u : 1u) * (unsigned)ksplit;
+  const unsigned nwork = (unsigned)p.N * ntd * nth * ntw * ncb * (KS == 2 ? 4u : 1u) * (unsigned)ksplit;  // KS = 2: x the four (d, h) parities
   const unsigned xcd = blockIdx.x & 7, gx = (gridDim.x >> 3) + (xcd < (gridDim.x & 7) ? 1u : 0u);
   const unsigned q8 = nwork >> 3, r8 = nwork & 7, cx = q8 + (xcd < r8 ? 1u : 0u), sx = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   unsigned pos = blockIdx.x >> 3;
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
     t.cb = b % ncb; b /= ncb;
     t.par = 0;
-    if (KS == 2) { t.par = b & 7; b >>= 3; }
+    if (KS == 2) { t.par = b & 3; b >>= 2; }  // (d parity, h parity); the W parity is a loop inside the work item
     t.tw_i = b % ntw; b /= ntw;
     t.th_i = b % nth; b /= nth;
     t.td_i = b % ntd; b /= ntd;
@@ -172,11 +178,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     psw |= dma_swz(rr % PW) << (2 * j);
   }
   int pvox[PPW];  // source voxel of this lane's patch row per piece, or -1 for a padding row (32-bit: host checks N*V < 2^31)
+  // PVOX_LDS: the sub-pixel form carries two accumulator sets (128 registers) and two operand sets through its tap loop; its eight placements per
+  // lane did not fit next to them and went to scratch -- reloaded in front of every patch request, i.e. behind the previous piece's LDS-DMA
+  // (vector memory returns in order).  They live in LDS instead (8 KiB behind the addend vector; a lane reads back only what it wrote).
+  constexpr bool PVOX_LDS = KS == 2 && NW == 4;
+  int* pvt = reinterpret_cast<int*>(smem + PVT_OFF) + threadIdx.x;  // entry j of this thread: pvt[j * NT]; entry PPW: the slot keys psw
+  if (PVOX_LDS) pvt[PPW * NT] = psw;
   auto place_patch = [&](const Tile& t) __attribute__((always_inline)) {
     KDesc& pk = cold_desc();
     // KS = 2: output parity 0 reads inputs (i - 1, i), parity 1 reads (i, i + 1): low-side padding 1 - parity
-    const int ud0 = t.td_i * TD * S - (KS == 2 ? 1 - ((t.par >> 2) & 1) : pk.pd), uh0 = t.th_i * TH * S - (KS == 2 ? 1 - ((t.par >> 1) & 1) : pk.ph),
-              uw0 = t.tw_i * TW * S - (KS == 2 ? 1 - (t.par & 1) : pk.pw);
+    const int ud0 = t.td_i * TD * S - (KS == 2 ? 1 - ((t.par >> 1) & 1) : pk.pd), uh0 = t.th_i * TH * S - (KS == 2 ? 1 - (t.par & 1) : pk.ph),
+              uw0 = t.tw_i * TW * S - (KS == 2 ? 1 : pk.pw);  // KS = 2: the union of both W parities starts at column i - 1
     OPAQUE_LANE(lane_p);
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
@@ -187,7 +199,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       int ud = ud0 + pa, uh = uh0 + pb, uw = uw0 + pc;
       const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv);
       if (pk.in_mode == 1) { ud /= pk.fd; uh /= pk.fh; uw /= pk.fw; }
-      pvox[j] = ok ? ((t.n * pk.Ds + ud) * pk.Hs + uh) * pk.Ws + uw : -1;
+      const int pvj = ok ? ((t.n * pk.Ds + ud) * pk.Hs + uh) * pk.Ws + uw : -1;
+      if (PVOX_LDS) pvt[j * NT] = pvj; else pvox[j] = pvj;
     }
   };
   const long long xrowb = p.x_ld * (long long)sizeof(T);
@@ -206,9 +219,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       if (wave + NW * j < PPIECES) {  // wave-uniform
-        int pv = pvox[j];
+        int pv = PVOX_LDS ? pvt[j * NT] : pvox[j];
         asm volatile("" : "+v"(pv));  // opaque: keeps the 64-bit row offsets pvox[j] * rowb (x and x2: 24 registers) out of the chunk loop's live set
-        const char* src = pv >= 0 ? cbase + pv * rowb + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4) : zero + ((lane & 3) << 4);
+        int ps = PVOX_LDS ? pvt[PPW * NT] : psw;  // (likewise the slot keys: hoisted per piece they went to scratch in the sub-pixel form, and so did the one register they come from)
+        if (PVOX_LDS) asm volatile("" : "+v"(ps));
+        const char* src = pv >= 0 ? cbase + pv * rowb + (((lane & 3) ^ ((ps >> (2 * j)) & 3)) << 4) : zero + ((lane & 3) << 4);
         dma16(src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
       }
     }
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   int wsrc[WPW];                // byte offset within a (chunk, group) panel image, or -1 (channel beyond cout_pad)
   auto place_weights = [&](const Tile& t) __attribute__((always_inline)) {
     KDesc& pk = cold_desc();
-    wbase = reinterpret_cast<const char*>(pk.w) + (long long)t.par * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;
+    wbase = reinterpret_cast<const char*>(pk.w) + (long long)(t.par * NPW) * nchunks * (KS * KS * KS) * cout_pad * DMA_ROWB;  // image of W parity 0; parity 1 follows it
     OPAQUE_LANE(lane_w);
 #pragma unroll
     for (int h = 0; h < WPW; ++h) {
@@ -281,7 +296,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #ifdef GM_CONV_ABLATE
     if (p.debug_flags & 512) return;  // bench-only: no weight traffic (results are garbage)
 #endif
-    const char* panel = wbase + (long long)t * G * cout_pad * DMA_ROWB;  // (chunk*27 + 3*grp) * cout_pad rows
+    // KS = 3: (chunk * 27 + 3 * grp) * cout_pad rows.  KS = 2: t = chunk * 8 + g, W parity g / 4 -> its image, rows (chunk * 8 + 2 (g % 4)) * cout_pad
+    const char* panel = KS == 2 ? wbase + ((long long)((t & 7) >> 2) * nchunks * 8 + (long long)(t >> 3) * 8 + 2 * (t & 3)) * cout_pad * DMA_ROWB
+                                : wbase + (long long)t * G * cout_pad * DMA_ROWB;
     const unsigned dst = lds0 + PATCH_BYTES + (unsigned)buf * WBUF_BYTES;
 #pragma unroll
     for (int h = h0; h < h1; ++h) {
@@ -313,6 +330,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   constexpr int SCRATCH_OFF = EARLY ? PATCH_BYTES : 0;
   static_assert(EARLY || SCRATCH_BYTES <= PATCH_BYTES + RING_BYTES, "the transpose scratch fits under the addend vector");
   static_assert(BN * 8 <= SCRATCH_WAVE, "a wave's statistic partials fit into its scratch block");
+  static_assert(PVT_OFF == PATCH_BYTES + RING_BYTES + 512, "the placement table follows the addend vector");
   float* addv = reinterpret_cast<float*>(smem + PATCH_BYTES + RING_BYTES);  // per-channel epilogue addend of this work-group's BN output channels
   // DIRECT: the register-direct epilogue (conv_dma_shared.h): the weight rows of a panel are DMA'd in direct_chan() order, so that a lane's
   // accumulators are 16-byte runs of the output row and no LDS transpose is needed (64-channel tiles; bench A/B: -DGM_CONV_LDS_EPILOGUE restores
@@ -364,12 +382,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     static_assert(MF <= 4 && (4 % MF) == 0, "a wave's fragments stay inside one 4-row tile plane");
     OPAQUE_LANE(lane_t);  // keeps the two tables out of loop-invariant code motion (= out of the epilogue's live set)
     const int l15t = lane_t & 15, qt = lane_t >> 4;
-    int xa[KS];  // patch row of this lane's voxel column for tap column kw (line 0 of the wave's fragments); lines / planes are immediates
+    constexpr int NXA = KS + NPW - 1;  // tap columns of the staged patch (KS = 2: tap kw of W parity pw reads union column kw + pw)
+    int xa[NXA];  // patch row of this lane's voxel column for tap column kw (line 0 of the wave's fragments); lines / planes are immediates
     {
       const int m0 = wave * MF * 16 + l15t;
       const int a = m0 >> 6, bb0 = (m0 >> 4) & 3, c = m0 & 15;
 #pragma unroll
-      for (int kw = 0; kw < KS; ++kw) {
+      for (int kw = 0; kw < NXA; ++kw) {
         const int col = S == 1 ? c + kw : (kw == 1 ? EW + c : c + (kw >> 1));  // patch column S*c + kw in the split layout
         xa[kw] = (S * a * PLANE + S * bb0 * PW + col) * DMA_ROWB + ((qt ^ dma_swz(col)) << 4);
       }
@@ -378,11 +397,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     const int wa0 = PATCH_BYTES + l15t * DMA_ROWB + ((qt ^ dma_swz(l15t)) << 4);
 #define XADDR(hk, kw) (xa[kw] + (hk) * (PW * DMA_ROWB))
 #define WADDR(nf) (wa0 + (nf) * (16 * DMA_ROWB))
-    f32x4_t acc[NFR][MF];
+    f32x4_t accs[NPW][NFR][MF];
 #pragma unroll
-    for (int nf = 0; nf < NFR; ++nf)
+    for (int pw = 0; pw < NPW; ++pw)
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) accs[pw][nf][mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t (&acc)[NFR][MF] = accs[0];  // (the 3x3x3 forms have one set)
     if (tid_a < BN) addv[tid_a] = addend;
     TL_STAMP(56);
     if (total > 0) {
@@ -419,8 +441,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         // (the patch has just been replaced).
         uint4 xf[2][MF], wf[2][4];
         auto read_tap = [&](int g, int u, int set) __attribute__((always_inline)) {
-          const int tap = g * G + u;
-          const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+          const int tap = (KS == 2 ? g % 4 : g) * G + u;  // KS = 2: groups 4 .. 7 are the taps of W parity 1 ...
+          const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS + (KS == 2 ? g / 4 : 0);  // ... one patch column further
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf)
             wf[set][nf] = *reinterpret_cast<const uint4*>(smem + WADDR(nf) + (g % RING) * WBUF_BYTES + u * (BN * DMA_ROWB));
@@ -428,12 +450,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
           for (int mf = 0; mf < MF; ++mf)
             xf[set][mf] = *reinterpret_cast<const uint4*>(smem + XADDR(S * mf + kh, kw) + kd * (PLANE * DMA_ROWB));
         };
-        auto mma_tap = [&](int set) __attribute__((always_inline)) {
+        auto mma_tap_pw = [&](int set, int pw) __attribute__((always_inline)) {
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[set][nf], xf[set][mf], acc[nf][mf]);
+            for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[set][nf], xf[set][mf], accs[pw][nf][mf]);
         };
+#define mma_tap(set) mma_tap_pw(set, KS == 2 ? g / 4 : 0)  /* every tap multiplied inside iteration g belongs to group g */
         constexpr int NMMA = MF * 4 * (sizeof(T) == 2 ? 1 : 4), NRD = MF + 4;
         static_assert(G == 3 || G == 2, "taps per panel");
 #ifdef GM_CONV_EARLY_BARRIER
@@ -613,9 +636,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
   TL_STAMP(60);
 
-    const EpTile et = {cur.n, od0, oh0, ow0, cur.cb * BN, cur.par};
+    const EpTile et = {cur.n, od0, oh0, ow0, cur.cb * BN, cur.par * NPW};  // (KS = 2: the full parity of W parity 0; parity 1 = + 1)
     const bool partial = KS == 3 && S == 1 && ksplit > 1;
-    EpRows<MF * 2> rows0;
+    EpRows<MF * 2> rowsP[NPW];
+    EpRows<MF * 2>& rows0 = rowsP[0];
     OPAQUE_LANE(lane_e);
     // ---- register-direct epilogue, part 1: row placement + residual requests (their latency runs under the shortcut / the barrier) ----------------
     // W line mf of this wave = tile line wave * MF + mf: (depth, height) wave-uniform, the 16 lanes l15 are its 16 voxels.  Address of store st:
@@ -659,7 +683,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         }
       }
     }
-    if (!partial && !d_direct) dma_epilogue_rows<T, MF, KS, 0>(cold_desc(), et, wave * MF, lane_e, rows0);  // residual rows of the first pass: requested now, used after the transpose
+    if (!partial && !d_direct) {  // residual rows of the first pass: requested now, used after the transpose
+#pragma unroll
+      for (int pw = 0; pw < NPW; ++pw) {
+        const EpTile etp = {et.n, et.od0, et.oh0, et.ow0, et.co_base, et.par + pw};
+        dma_epilogue_rows<T, MF, KS, 0>(cold_desc(), etp, wave * MF, lane_e, rowsP[pw]);
+      }
+    }
 
     // ---- fused 1x1 shortcut convolution: extra K chunks over the (virtually concatenated) skip sources, centre tap only ----------
     // Two chunks per round: each wave DMAs the 64-byte channel chunk of ITS OWN 32 output voxels (4 pieces) into the patch buffer
@@ -750,7 +780,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       } else {  // work item + gx by mixed-radix addition of the stride's digits: a few scalar compares instead of four integer divisions
         int c;
         nxt.cb = cur.cb + stride.cb; c = nxt.cb >= ncb ? 1 : 0; nxt.cb -= c ? ncb : 0;
-        if (KS == 2) { nxt.par = cur.par + stride.par + c; c = nxt.par >> 3; nxt.par &= 7; }
+        if (KS == 2) { nxt.par = cur.par + stride.par + c; c = nxt.par >> 2; nxt.par &= 3; }
         nxt.tw_i = cur.tw_i + stride.tw_i + c; c = nxt.tw_i >= ntw ? 1 : 0; nxt.tw_i -= c ? ntw : 0;
         nxt.th_i = cur.th_i + stride.th_i + c; c = nxt.th_i >= nth ? 1 : 0; nxt.th_i -= c ? nth : 0;
         nxt.td_i = cur.td_i + stride.td_i + c; c = nxt.td_i >= ntd ? 1 : 0; nxt.td_i -= c ? ntd : 0;
@@ -957,27 +987,34 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+#pragma unroll
+    for (int pw = 0; pw < NPW; ++pw) {  // (KS = 2: the two W parities of the work item, one after the other through the same scratch)
+    const EpTile etp = {et.n, et.od0, et.oh0, et.ow0, et.co_base, et.par + pw};
+    if (pw > 0) {  // the cross-wave statistic partials of parity 0 have been read
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
 #pragma unroll
     for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
       for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
     char* scratch = smem + SCRATCH_OFF + (size_t)wave * SCRATCH_WAVE;
-    dma_epilogue_pass<T, MF, NFR, KS, 0, DIRECT>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows0, st_s, st_q);
+    dma_epilogue_pass<T, MF, NFR, KS, 0, DIRECT>(pe, accs[pw], scratch, addv, etp, wave * MF, lane_e, rowsP[pw], st_s, st_q);
     if constexpr (EPASSES > 1) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 1>(pe, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 1, DIRECT>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 1>(pe, etp, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 1, DIRECT>(pe, accs[pw], scratch, addv, etp, wave * MF, lane_e, rows, st_s, st_q);
     }
     if constexpr (EPASSES > 2) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 2>(pe, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 2, DIRECT>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 2>(pe, etp, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 2, DIRECT>(pe, accs[pw], scratch, addv, etp, wave * MF, lane_e, rows, st_s, st_q);
     }
     if constexpr (EPASSES > 3) {
       EpRows<MF * 2> rows;
-      dma_epilogue_rows<T, MF, KS, 3>(pe, et, wave * MF, lane_e, rows);
-      dma_epilogue_pass<T, MF, NFR, KS, 3, DIRECT>(pe, acc, scratch, addv, et, wave * MF, lane_e, rows, st_s, st_q);
+      dma_epilogue_rows<T, MF, KS, 3>(pe, etp, wave * MF, lane_e, rows);
+      dma_epilogue_pass<T, MF, NFR, KS, 3, DIRECT>(pe, accs[pw], scratch, addv, etp, wave * MF, lane_e, rows, st_s, st_q);
     }
     TL_STAMP(62);
     if (pe.stats) {
@@ -1009,12 +1046,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
         }
         const int co = cur.cb * BN + ch;
         if (co < pe.Cout) {
-          const long long slot = ((long long)(cur.td_i * nth + cur.th_i) * ntw + cur.tw_i) * (KS == 2 ? 8 : 1) + cur.par;  // the tile within its sample
+          const long long slot = ((long long)(cur.td_i * nth + cur.th_i) * ntw + cur.tw_i) * (KS == 2 ? 8 : 1) + etp.par;  // the tile (and parity) within its sample
           double* dst = pe.stats + ((slot * pe.N + cur.n) * pe.Cout + co) * 2;  // fixed-order reduction over the slots by the consumers, no atomics
           *reinterpret_cast<double2*>(dst) = make_double2(a, b2);
         }
       }
     }
+    }  // (W parities)
     }  // (the LDS-transposed form)
 #ifdef GM_CONV_ABLATE
     }
@@ -1030,6 +1068,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
   }
 }
 
+#undef mma_tap
 #undef XADDR
 #undef WADDR
 
@@ -1053,7 +1092,7 @@ extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   const long long addv = 512;
   if (variant == 6) return gm_conv_mw_lds_bytes();
   if (variant == 7) return gm_conv_w8_lds_bytes();
-  if (variant == 4) return 5LL * 96 * DMA_ROWB + 36864 + addv;
+  if (variant == 4) return 5LL * 96 * DMA_ROWB + 36864 + addv + 256LL * 9 * 4;  // ... + the placement table (256 threads x (8 pieces + the slot keys))
   if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB + addv;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
   return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB + addv;
@@ -1214,7 +1253,9 @@ extern "C" int gm_conv_dma_launch_part1(const GmConvDesc* dp, unsigned nblocks, 
 #if DMA_PART(2)
 extern "C" int gm_conv_dma_launch_part2(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   const GmConvDesc& d = *dp; hipStream_t st = (hipStream_t)stream;
-  if (d.cfg == 17) DMA_BY_DTYPE((launch_dma<T, 8, 2, 1, 4, 2>(d, nblocks, st)));  // sub-pixel 2x2x2 kernels of an up-sampling convolution
+  // sub-pixel 2x2x2 kernels of an up-sampling convolution: 4 waves x 64 voxels at 256 registers (round 5: both W parities of a work item = two
+  // accumulator sets, 128 registers -- the 8-wave x 32-voxel form at 128 registers spilled 147)
+  if (d.cfg == 17) DMA_BY_DTYPE((launch_dma<T, 4, 4, 1, 2, 2>(d, nblocks, st)));
   DMA_BY_DTYPE((launch_dma<T, 8, 1, 2, 2>(d, nblocks, st)));                      // cfg 15, stride 2: 8 waves x 16 voxels, one work-group per CU
 }
 #endif

@@ -10,7 +10,7 @@
 //                     Z tile in LDS.  No 16x padding of the single output channel, no per-tap re-read of the activations
 //                     (reference: diffusion_model_unet.py:1853-1867, autoencoderkl.py:590-597).
 // The generic implicit-GEMM kernel ran these two at 0.37-0.5 TB/s (0.73 + 0.56 ms of a 26 ms forward).
-#include "conv_epilogue.h"
+#include "conv_dma_shared.h"  // the LDS-DMA kernels' epilogue: addend vector in LDS, residual rows requested ahead, wave-private transpose, lane-swap statistics
 
 // -----------------------------------------------------------------------------------------------------------------------
 // C_in <= 4
@@ -83,6 +83,20 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
       if (e < PROWS * Cin) patch[e] = pok[it] ? pv[it] : (T)0;
     }
   }
+  // per-channel epilogue addend (bias + shortcut bias + timestep row, this order) staged once per work-group behind the scratch region (round 5:
+  // this kernel still ran the first shared epilogue -- 16 x 3 dependent branched loads per lane, a 64-bit voxel address per row group, the residual
+  // of row group i + 1 behind the store of row group i, 48 ds_bpermute round trips for the statistics: most of a work-group's 28 k cycles)
+  float* addv = reinterpret_cast<float*>(smem + 4 * 64 * 144);
+  if (tid < BN) {
+    const int co = cb * BN + tid;
+    float addend = 0.f;
+    if (co < p.Cout) {
+      if (p.bias) addend += p.bias[co];
+      if (p.skip_bias) addend += p.skip_bias[co];
+      if (p.rowvec) addend += p.rowvec[(long long)n * p.rowvec_bstride + co];
+    }
+    addv[tid] = addend;
+  }
   __syncthreads();
 
   // ---- this lane's K slots: element offset into the patch of k = blk*KB + q*VECW + i at tap (0,0,0) voxel, -1 beyond K ------------
@@ -122,8 +136,12 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
     }
   }
 
-  // ---- epilogue: bias / timestep row / residual, 16-byte row stores, fused GroupNorm statistics (as conv_fast) -------------------
-  __syncthreads();
+  // ---- epilogue: the LDS-DMA kernels' (conv_dma_shared.h): residual rows requested first, accumulators + addend through the wave's own
+  // transpose scratch, 16-byte row stores, statistics by lane swaps; fixed-order fp64 sum over the waves ------------------------------------------
+  const EpTile et = {n, od0, oh0, ow0, cb * BN, 0};
+  EpRows<MF * 2> rows0;
+  dma_epilogue_rows<T, MF, 3, 0>(p, et, wave * MF, lane, rows0);
+  __syncthreads();  // every wave has gathered its operands: the scratch overlays the patch
   constexpr int EPASSES = (NFR * 16 * (int)sizeof(T) + 127) / 128;
   constexpr int CH_PER_PASS = 128 / (int)sizeof(T);
   float st_s[EPASSES][VECW], st_q[EPASSES][VECW];
@@ -131,31 +149,35 @@ __global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
   for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
     for (int i = 0; i < VECW; ++i) { st_s[e][i] = 0.f; st_q[e][i] = 0.f; }
-  conv_epilogue_lds<T, MF, NFR>(p, acc, smem + (size_t)wave * MF * 16 * 144, n, wave * MF * 16, cb * BN, od0, oh0, ow0, lane, st_s, st_q);
+  char* scratch = smem + (size_t)wave * MF * 16 * 144;
+  dma_epilogue_pass<T, MF, NFR, 3, 0>(p, acc, scratch, addv, et, wave * MF, lane, rows0, st_s, st_q);
+  if constexpr (EPASSES > 1) {
+    EpRows<MF * 2> rows;
+    dma_epilogue_rows<T, MF, 3, 1>(p, et, wave * MF, lane, rows);
+    dma_epilogue_pass<T, MF, NFR, 3, 1>(p, acc, scratch, addv, et, wave * MF, lane, rows, st_s, st_q);
+  }
   if (p.stats) {
-    float* sst = reinterpret_cast<float*>(smem);  // [NW][64 channels][2]
-    __syncthreads();
+    float ra[EPASSES][VECW], rb[EPASSES][VECW];
 #pragma unroll
     for (int e = 0; e < EPASSES; ++e)
 #pragma unroll
-      for (int i = 0; i < VECW; ++i) {
-        float a = st_s[e][i], b2 = st_q[e][i];
-        a += __shfl_xor(a, 8, 64); b2 += __shfl_xor(b2, 8, 64);
-        a += __shfl_xor(a, 16, 64); b2 += __shfl_xor(b2, 16, 64);
-        a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64);
-        if (lane < 8) {
-          const int ch = e * CH_PER_PASS + lane * VECW + i;
-          sst[(wave * 64 + ch) * 2] = a;
-          sst[(wave * 64 + ch) * 2 + 1] = b2;
-        }
-      }
+      for (int i = 0; i < VECW; ++i) { ra[e][i] = wave_segment_sum(st_s[e][i]); rb[e][i] = wave_segment_sum(st_q[e][i]); }
+    if (lane < 8) {  // lanes 0..7 hold the wave's sums of VECW consecutive channels each: (sum, sum of squares) pairs
+      float* part = reinterpret_cast<float*>(scratch);
+#pragma unroll
+      for (int e = 0; e < EPASSES; ++e)
+#pragma unroll
+        for (int i = 0; i < VECW; i += 2)
+          *reinterpret_cast<float4*>(part + 2 * (e * CH_PER_PASS + lane * VECW + i)) = make_float4(ra[e][i], rb[e][i], ra[e][i + 1], rb[e][i + 1]);
+    }
     __syncthreads();
     if (tid < BN) {
       double a = 0.0, b2 = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        a += (double)sst[(w * 64 + tid) * 2];
-        b2 += (double)sst[(w * 64 + tid) * 2 + 1];
+        const float2 v = *reinterpret_cast<const float2*>(smem + (size_t)w * MF * 16 * 144 + tid * 8);
+        a += (double)v.x;
+        b2 += (double)v.y;
       }
       const int co = cb * BN + tid;
       if (co < p.Cout) {
@@ -317,8 +339,12 @@ __global__ __launch_bounds__(256, 2) void conv_cout1_kernel(const GmConvDesc p) 
 // sized by the host (depth segments of 2^ltd planes) to at least one work-group per CU.  (reference: diffusion_model_unet.py:1853-1867)
 __device__ __attribute__((aligned(64))) unsigned int gm_edge_zero_row[16] = {0};  // the source of every padding row of the marching kernel
 
+// Round 5: 128-byte rows may also walk 8 x 16 columns (LTW = 4): 2 x 24 KiB raw planes + 21 KiB of Z = 69 KiB, TWO work-groups per CU -- the
+// kernel is bound by its 2.1 M SiLUs per plane column on ONE wave per SIMD with two barriers per plane (0.094 ms without the prologue, 0.197
+// with it); a second work-group runs its transcendental chains under the first one's DMA wait, Z stores and 27-point gather.  Halo 1.41 instead of
+// 1.33 rows per output row.
 template <typename T, int KS, int LTW>  // KS = C_in / BK 64-byte channel steps (row = KS x 64 bytes); 8 x 2^LTW outputs per plane
-__global__ __launch_bounds__(256, 1) void conv_cout1_march_kernel(const GmConvDesc p) {
+__global__ __launch_bounds__(256, (KS == 2 && LTW == 4) ? 2 : 1) void conv_cout1_march_kernel(const GmConvDesc p) {
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int TH = 8, TWO = 1 << LTW, PH = TH + 2, PW = TWO + 2, PROWS = PH * PW;
@@ -509,7 +535,7 @@ extern "C" long long gm_conv_cin_lds_bytes(const GmConvDesc* d) {
   const long long es = d->dtype == GM_F32 ? 4 : 2;
   const long long operands = (648 * 4 * es + 15) & ~15LL;  // the halo patch (the weight fragments come from the K-major image in registers)
   const long long scratch = 4LL * 64 * 144;
-  return operands > scratch ? operands : scratch;
+  return (operands > scratch ? operands : scratch) + 256;  // + the epilogue addend vector (64 floats, at byte 4 * 64 * 144)
 }
 extern "C" int gm_conv_cout1_eligible(const GmConvDesc* d) {
   const int bk = d->dtype == GM_F32 ? 16 : 32, vecw = d->dtype == GM_F32 ? 4 : 8;
@@ -526,13 +552,13 @@ extern "C" int gm_conv_cout1m_eligible(const GmConvDesc* d) {
   const long long rowbytes = (long long)d->Cin * es;
   return d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->dd == 1 && d->dh == 1 && d->dw == 1 &&
          d->pd == 1 && d->ph == 1 && d->pw == 1 && d->in_mode == 0 && d->Cout == 1 && d->Do == d->Ds && d->Ho == d->Hs && d->Wo == d->Ws && d->Ds >= 4 &&
-         (rowbytes == 128 || rowbytes == 256) && d->lth == 3 && d->ltw == (rowbytes == 128 ? 5 : 4) && d->ltd >= 2 && d->ltd <= 5 &&
+         (rowbytes == 128 || rowbytes == 256) && d->lth == 3 && (d->ltw == 4 || (rowbytes == 128 && d->ltw == 5)) && d->ltd >= 2 && d->ltd <= 5 &&
          d->x_ld % vecw == 0 && (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && d->stats == nullptr && d->x2 == nullptr && !d->skip_x[0] &&
          ((d->pre_scale == nullptr) == (d->pre_shift == nullptr)) && (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 40);
 }
 extern "C" long long gm_conv_cout1m_lds_bytes(const GmConvDesc* d) {
   const int es = d->dtype == GM_F32 ? 4 : 2;
-  const long long rowb = (long long)d->Cin * es, two = rowb == 128 ? 32 : 16;
+  const long long rowb = (long long)d->Cin * es, two = 1LL << d->ltw;
   const long long prows = 10 * (two + 2), pad = (prows + 15) / 16 * 16;
   return 2 * pad * rowb + 27LL * (pad + 4) * 4;
 }
@@ -592,12 +618,14 @@ extern "C" int gm_conv_cout1m_launch(const GmConvDesc* dp, unsigned nblocks, voi
   const size_t smem = (size_t)gm_conv_cout1m_lds_bytes(dp);
   const long long rowb = (long long)dp->Cin * (dp->dtype == GM_F32 ? 4 : 2);
   if (dp->dtype == GM_F32) {
-    if (rowb == 128) edge_launch(conv_cout1_march_kernel<float, 2, 5>, *dp, nblocks, smem, st);
+    if (rowb == 128 && dp->ltw == 5) edge_launch(conv_cout1_march_kernel<float, 2, 5>, *dp, nblocks, smem, st);
+    else if (rowb == 128) edge_launch(conv_cout1_march_kernel<float, 2, 4>, *dp, nblocks, smem, st);
     else edge_launch(conv_cout1_march_kernel<float, 4, 4>, *dp, nblocks, smem, st);
     return 0;
   }
   if (dp->dtype == GM_BF16) {
-    if (rowb == 128) edge_launch(conv_cout1_march_kernel<bf16_raw, 2, 5>, *dp, nblocks, smem, st);
+    if (rowb == 128 && dp->ltw == 5) edge_launch(conv_cout1_march_kernel<bf16_raw, 2, 5>, *dp, nblocks, smem, st);
+    else if (rowb == 128) edge_launch(conv_cout1_march_kernel<bf16_raw, 2, 4>, *dp, nblocks, smem, st);
     else edge_launch(conv_cout1_march_kernel<bf16_raw, 4, 4>, *dp, nblocks, smem, st);
     return 0;
   }

@@ -794,6 +794,9 @@ def _cfg_tile(cfg: int):
 
 
 COUT1_MARCH_LTD = os.environ.get("GM_CONV_COUT1_LTD")  # bench only: pin the depth-segment length (log2 planes) of configuration 20
+# log2 of the output columns a configuration-20 work-group walks over 128-byte rows: 5 = 8 x 32 (one work-group per CU, halo 1.33), 4 = 8 x 16 (69 KiB of
+# LDS: two work-groups per CU, halo 1.41; round 5 A/B: GM_CONV_COUT1_LTW)
+COUT1_MARCH_LTW_128B = int(os.environ.get("GM_CONV_COUT1_LTW", "5"))
 
 
 _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only
@@ -860,10 +863,11 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         if cfg == 20:
             # rows of 128 bytes walk 8 x 32 output columns, rows of 256 bytes 8 x 16; the depth segment of a work-group (2^ltd planes, halo
             # overhead (2^ltd + 2) / 2^ltd) is the longest that still gives every CU a work-group
-            ltw = 5 if desc.Cin * (4 if desc.dtype == 0 else 2) == 128 else 4
+            ltw = (COUT1_MARCH_LTW_128B if desc.Cin * (4 if desc.dtype == 0 else 2) == 128 else 4)
             cols = desc.N * -(-desc.Ho // 8) * -(-desc.Wo // (1 << ltw))
+            want = 512 if (ltw == 4 and desc.Cin * (4 if desc.dtype == 0 else 2) == 128) else 256  # (8 x 16 columns of 128-byte rows: two work-groups per CU)
             ltd = 5
-            while ltd > 2 and cols * -(-desc.Do // (1 << ltd)) < 256:
+            while ltd > 2 and cols * -(-desc.Do // (1 << ltd)) < want:
                 ltd -= 1
             if COUT1_MARCH_LTD is not None:
                 ltd = int(COUT1_MARCH_LTD)
