@@ -796,7 +796,7 @@ def _cfg_tile(cfg: int):
 COUT1_MARCH_LTD = os.environ.get("GM_CONV_COUT1_LTD")  # bench only: pin the depth-segment length (log2 planes) of configuration 20
 # log2 of the output columns a configuration-20 work-group walks over 128-byte rows: 5 = 8 x 32 (one work-group per CU, halo 1.33), 4 = 8 x 16 (69 KiB of
 # LDS: two work-groups per CU, halo 1.41; round 5 A/B: GM_CONV_COUT1_LTW)
-COUT1_MARCH_LTW_128B = int(os.environ.get("GM_CONV_COUT1_LTW", "5"))
+COUT1_MARCH_LTW_128B = int(os.environ.get("GM_CONV_COUT1_LTW", "4"))  # measured (gpurun r5v2): C2 out head 0.197-0.200 -> 0.139 ms
 
 
 _CONV_DEBUG_FLAGS = 0  # tools/bench_conv.py ablations only

@@ -214,6 +214,10 @@ void gm_conv_dma_set_persistent(int max_work_groups);
  * `cycles` once; later work-groups inherit the phase of their slot.  0 = off (default: measured no gain on MI355X, profiles/r05_phase_skew_sweep.txt),
  * -1 = half the modelled tile life of the launch. */
 void gm_conv_dma_set_phase_skew(int cycles);
+/* Residual prefetch of the LDS-DMA 3x3x3 stride-1 configurations (process-wide; results do not depend on it): at the last K-chunk boundary of a
+ * tile every wave requests the tile's residual rows (GmConvDesc.res) through the LDS-DMA engine into a dump area, so that the epilogue's
+ * loads hit L2 / the memory-side cache instead of HBM.  1 (default) = on, 0 = off. */
+void gm_conv_dma_set_res_prefetch(int on);
 /* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
  * software-pipelined over the taps (bench A/B: slower at 128 registers). */
 void gm_conv_w8_set_pipe2(int on);

@@ -100,16 +100,21 @@ def test_selectable_tile_configurations_carry_a_whole_model(flag, cfg):
         want = R.unet_forward(fx["state_dict"], fx["cfg"], x, t)
     m = _build_unet(fx, torch.bfloat16)
     base = m(_dev(x.bfloat16()), _dev(t))
-    keep = (getattr(ops, flag), ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES)
+    keep = (getattr(ops, flag), ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES, ops.DMA_FUSED_PROLOGUE, ops.SPLITK)
     try:
         setattr(ops, flag, True)
         ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES = 1, 1
+        # at this toy size the policy would fuse the prologue and split K (the cfg 11 forms); the large-volume policy -- two-pass GroupNorm, whole
+        # K per tile -- is what puts the C2 / AutoencoderKL convolutions on these configurations
+        ops.SPLITK = False
+        if flag == "DMA_MW":
+            ops.DMA_FUSED_PROLOGUE = "never"  # (configuration 21 has no in-LDS prologue)
         ops.start_profile()
         y = m(_dev(x.bfloat16()), _dev(t))
         rec = ops.stop_profile()
     finally:
         setattr(ops, flag, keep[0])
-        ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES = keep[1], keep[2]
+        ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES, ops.DMA_FUSED_PROLOGUE, ops.SPLITK = keep[1], keep[2], keep[3], keep[4]
     used = sorted({name for name, _, _ in rec if "conv_igemm" in name})
     assert sum(1 for name, _, _ in rec if cfg in name) >= 4, f"{flag}: expected the model's convolutions on {cfg}, launches were {used}"
     _bf16_close(y, want, f"c2mini 32x32x48 with {flag}")
