@@ -1146,8 +1146,11 @@ extern "C" void gm_conv_dma_set_persistent(int max_work_groups) { gm_dma_grid_ca
 // TFLOP/s register-resident at one / two waves per SIMD), so the partner's idle phases were never worth a full-rate tap loop.
 int gm_dma_phase_skew = 0;
 extern "C" void gm_conv_dma_set_phase_skew(int cycles) { gm_dma_phase_skew = cycles; }
-// Residual prefetch at the last chunk boundary (see the kernel): 1 = on.  Process-wide; results do not depend on it.
-int gm_dma_res_prefetch = 1;
+// Residual prefetch at the last chunk boundary (see the kernel): 1 = on, 0 = off (default).  Process-wide; results do not depend on it.
+// MEASURED (profiles/r05_res_prefetch_ab.txt, off / on alternated four times per shape): -0.7 ... -2.1 % on every C2 shape with a residual, 14.16-14.23
+// vs 14.41-14.51 ms per DDIM iteration: the 0.05 ms a residual costs the 64 -> 64 launches are not HBM latency the prefetch could hide (they are
+// still there), and the extra 32 KiB per tile through the LDS-DMA path is not free at the power cap.
+int gm_dma_res_prefetch = 0;
 extern "C" void gm_conv_dma_set_res_prefetch(int on) { gm_dma_res_prefetch = on; }
 #else
 extern int gm_dma_grid_cap, gm_dma_phase_skew, gm_dma_res_prefetch;

@@ -216,7 +216,7 @@ void gm_conv_dma_set_persistent(int max_work_groups);
 void gm_conv_dma_set_phase_skew(int cycles);
 /* Residual prefetch of the LDS-DMA 3x3x3 stride-1 configurations (process-wide; results do not depend on it): at the last K-chunk boundary of a
  * tile every wave requests the tile's residual rows (GmConvDesc.res) through the LDS-DMA engine into a dump area, so that the epilogue's
- * loads hit L2 / the memory-side cache instead of HBM.  1 (default) = on, 0 = off. */
+ * loads hit L2 / the memory-side cache instead of HBM.  0 (default) = off -- measured 1-2 % SLOWER on MI355X (profiles/r05_res_prefetch_ab.txt) --, 1 = on. */
 void gm_conv_dma_set_res_prefetch(int on);
 /* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
  * software-pipelined over the taps (bench A/B: slower at 128 registers). */

@@ -116,7 +116,8 @@ def test_selectable_tile_configurations_carry_a_whole_model(flag, cfg):
         setattr(ops, flag, keep[0])
         ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES, ops.DMA_FUSED_PROLOGUE, ops.SPLITK = keep[1], keep[2], keep[3], keep[4]
     used = sorted({name for name, _, _ in rec if "conv_igemm" in name})
-    assert sum(1 for name, _, _ in rec if cfg in name) >= 4, f"{flag}: expected the model's convolutions on {cfg}, launches were {used}"
+    # (cfg 22 takes every stride-1 3x3x3 convolution of the model; cfg 21 has no fused shortcut / two-source form, so it gets the plain ones)
+    assert sum(1 for name, _, _ in rec if cfg in name) >= (4 if flag == "DMA_W8" else 2), f"{flag}: expected the model's convolutions on {cfg}, launches were {used}"
     _bf16_close(y, want, f"c2mini 32x32x48 with {flag}")
     _bf16_close(base, want, "c2mini 32x32x48 default configuration")
     sigma = want.std().item()
