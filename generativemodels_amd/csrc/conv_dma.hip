@@ -61,7 +61,7 @@ static __device__ __attribute__((aligned(64))) unsigned int gm_zero_row[16] = {0
 // loop; every later work-group inherits the phase of the slot it is dispatched into.  (The round-2 skew experiment delayed EVERY tile of the
 // odd slot by <= 3 k cycles -- a permanent handicap of one slot, not a phase.)  Results do not depend on it.
 template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR_ = 4, bool PRE = false>
-__global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p, const unsigned phase_wgs, const unsigned phase_sleeps, const unsigned launch_flags) {
+__global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p, const unsigned phase_wgs, const unsigned phase_sleeps) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * NW;
@@ -424,31 +424,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 #endif
     TL_STAMP(2);
 
-    // ---- residual prefetch (round 5): the residual rows of a tile are first touched in its epilogue -- cold in HBM (the tensor was written three
-    // kernels ago), every work-group of the chip reaching its epilogue in the same microsecond -- and the 64 -> 64 launches with a residual take
-    // 0.05 ms (12 %) longer than those without, far more than 268 MB cost in bandwidth or energy.  At the LAST chunk boundary each wave therefore
-    // requests the tile's residual rows with BM / 8 / NW LDS-DMA pieces into a 1 KiB dump area nobody reads (no destination registers; they
-    // complete under the wait for the patch that is outstanding anyway): the epilogue's loads then hit L2 / the memory-side cache.
-    constexpr bool RES_PF = DIRECT && S == 1 && sizeof(T) == 2;
-    auto prefetch_residual = [&]() __attribute__((always_inline)) {
-      if constexpr (RES_PF) {
-        KDesc& pr = cold_desc();
-        if ((launch_flags & 1u) && pr.res && !(KS == 3 && S == 1 && ksplit > 1)) {
-          OPAQUE_LANE(lane_r);
-          const char* rbase = reinterpret_cast<const char*>(pr.res) + ((long long)cur.cb * BN + (lane_r & 7) * 8) * 2;
-          const long long rrowb = pr.res_ld * 2;
-#pragma unroll
-          for (int i = 0; i < BM / 8 / NW; ++i) {
-            const int m = 8 * (wave + NW * i) + (lane_r >> 3);  // voxel of the tile: line m / 16, column m % 16
-            const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
-            const bool ok = od < pr.Do && oh < pr.Ho && ow < pr.Wo && cur.cb * BN + (lane_r & 7) * 8 < pr.Cout;
-            const int vox = ((cur.n * pr.Do + od) * pr.Ho + oh) * pr.Wo + ow;
-            dma16(ok ? rbase + vox * rrowb : zero + ((lane_r & 3) << 4), lds0 + (unsigned)PVT_OFF);
-          }
-        }
-      }
-    };
-
     // ---- main loop ----------------------------------------------------------------------------------------------------------
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
       const bool last_chunk = chunk + 1 == c_end;
@@ -538,7 +513,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
               __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
               issue_patch(chunk + 1);
-              if (chunk + 2 == c_end) prefetch_residual();
               if (pre) load_affine(chunk + 1);
               dma_wait<0>();                 // patch + the panel in flight
               if (pre) transform_patch();
@@ -579,7 +553,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
               __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
               issue_patch(chunk + 1);
-              if (chunk + 2 == c_end) prefetch_residual();
               if (pre) load_affine(chunk + 1);
               dma_wait<0>();                 // patch + the two panels in flight
               if (pre) transform_patch();
@@ -646,7 +619,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
             issue_patch(chunk + 1);
-            if (chunk + 2 == c_end) prefetch_residual();
             if (pre) load_affine(chunk + 1);
             dma_wait<0>();                 // patch + the two panels in flight
             if (pre) transform_patch();
@@ -670,6 +642,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     EpRows<MF * 2>& rows0 = rowsP[0];
     OPAQUE_LANE(lane_e);
     // ---- register-direct epilogue, part 1: row placement + residual requests (their latency runs under the shortcut / the barrier) ----------------
+    // (Round 5, measured and removed: requesting the tile's residual rows a chunk EARLIER through the LDS-DMA engine into a dump area, so that these
+    //  loads hit L2 -- the 64 -> 64 launches with a residual take 0.05 ms longer than those without -- made every C2 shape 0.7-2.1 % slower and the
+    //  forward 14.41-14.51 vs 14.16-14.23 ms: profiles/r05_res_prefetch_ab.txt.  The 0.05 ms are not exposed HBM latency.)
     // W line mf of this wave = tile line wave * MF + mf: (depth, height) wave-uniform, the 16 lanes l15 are its 16 voxels.  Address of store st:
     // scalar row base + lane offset (voxel l15, 16-byte run q) + 64 st.
     constexpr int NST = 16 / VECW;  // 16-byte stores per voxel and lane: 2 (bf16) / 4 (fp32)
@@ -1111,6 +1086,10 @@ extern "C" int gm_conv_mw_launch(const GmConvDesc* dp, unsigned nblocks, void* s
 extern "C" long long gm_conv_w8_lds_bytes();
 extern "C" int gm_conv_w8_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_w8_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
+// tile configuration 23 (conv_w4.hip: configuration 22's LDS image on four waves of 4 x 2 MFMA blocks)
+extern "C" long long gm_conv_w4_lds_bytes();
+extern "C" int gm_conv_w4_eligible(const GmConvDesc* d);
+extern "C" int gm_conv_w4_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 // the K slices of a split-K launch (cfg 11 geometry) run on conv_sk.hip's kernel: one work-group per CU, patch + all nine panels of a chunk resident
 extern "C" int gm_conv_sk_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
@@ -1120,10 +1099,11 @@ extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   const long long addv = 512;
   if (variant == 6) return gm_conv_mw_lds_bytes();
   if (variant == 7) return gm_conv_w8_lds_bytes();
+  if (variant == 8) return gm_conv_w4_lds_bytes();
   if (variant == 4) return 5LL * 96 * DMA_ROWB + 36864 + addv + 256LL * 9 * 4;  // ... + the placement table (256 threads x (8 pieces + the slot keys))
   if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB + addv;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
-  return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB + addv + (variant == 2 ? 0 : 1024);  // stride 1: + the 1 KiB dump area of the residual prefetch
+  return planes * plane * DMA_ROWB + 3LL * 192 * DMA_ROWB + addv;
 }
 
 #endif
@@ -1146,14 +1126,8 @@ extern "C" void gm_conv_dma_set_persistent(int max_work_groups) { gm_dma_grid_ca
 // TFLOP/s register-resident at one / two waves per SIMD), so the partner's idle phases were never worth a full-rate tap loop.
 int gm_dma_phase_skew = 0;
 extern "C" void gm_conv_dma_set_phase_skew(int cycles) { gm_dma_phase_skew = cycles; }
-// Residual prefetch at the last chunk boundary (see the kernel): 1 = on, 0 = off (default).  Process-wide; results do not depend on it.
-// MEASURED (profiles/r05_res_prefetch_ab.txt, off / on alternated four times per shape): -0.7 ... -2.1 % on every C2 shape with a residual, 14.16-14.23
-// vs 14.41-14.51 ms per DDIM iteration: the 0.05 ms a residual costs the 64 -> 64 launches are not HBM latency the prefetch could hide (they are
-// still there), and the extra 32 KiB per tile through the LDS-DMA path is not free at the power cap.
-int gm_dma_res_prefetch = 0;
-extern "C" void gm_conv_dma_set_res_prefetch(int on) { gm_dma_res_prefetch = on; }
 #else
-extern int gm_dma_grid_cap, gm_dma_phase_skew, gm_dma_res_prefetch;
+extern int gm_dma_grid_cap, gm_dma_phase_skew;
 #endif
 #define g_dma_grid_cap gm_dma_grid_cap
 #define g_dma_phase_skew gm_dma_phase_skew
@@ -1185,11 +1159,12 @@ static unsigned dma_grid(unsigned nwork, long long lds_bytes, int by_waves, bool
 
 #if DMA_PART(0)
 // geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)
-extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 22 ? 7 : cfg == 21 ? 6 : cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
+extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 23 ? 8 : cfg == 22 ? 7 : cfg == 21 ? 6 : cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
 
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   if (d->cfg == 21) return gm_conv_mw_eligible(d);
   if (d->cfg == 22) return gm_conv_w8_eligible(d);
+  if (d->cfg == 23) return gm_conv_w4_eligible(d);
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const int s = d->cfg == 15 ? 2 : 1;
@@ -1255,7 +1230,7 @@ static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
     phase_sleeps = (unsigned)((cycles + 512) / 1024);
     if (phase_sleeps == 0) phase_wgs = 0;
   }
-  kern<<<dim3(grid), 64 * NW, (size_t)lds, st>>>(d, phase_wgs, phase_sleeps, gm_dma_res_prefetch ? 1u : 0u);
+  kern<<<dim3(grid), 64 * NW, (size_t)lds, st>>>(d, phase_wgs, phase_sleeps);
 }
 
 // ---- the parts: each defines the launcher of its tile configurations ----------------------------------------------------------------------------
@@ -1313,6 +1288,7 @@ extern "C" int gm_conv_dma_launch_part4(const GmConvDesc* dp, unsigned nblocks, 
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   if (dp->cfg == 21) return gm_conv_mw_launch(dp, nblocks, stream);
   if (dp->cfg == 22) return gm_conv_w8_launch(dp, nblocks, stream);
+  if (dp->cfg == 23) return gm_conv_w4_launch(dp, nblocks, stream);
   if (gm_conv_sk_eligible(dp)) return gm_conv_sk_launch(dp, nblocks, stream);
   switch (dp->cfg) {
     case 14: return gm_conv_dma_launch_part1(dp, nblocks, stream);

@@ -214,13 +214,11 @@ void gm_conv_dma_set_persistent(int max_work_groups);
  * `cycles` once; later work-groups inherit the phase of their slot.  0 = off (default: measured no gain on MI355X, profiles/r05_phase_skew_sweep.txt),
  * -1 = half the modelled tile life of the launch. */
 void gm_conv_dma_set_phase_skew(int cycles);
-/* Residual prefetch of the LDS-DMA 3x3x3 stride-1 configurations (process-wide; results do not depend on it): at the last K-chunk boundary of a
- * tile every wave requests the tile's residual rows (GmConvDesc.res) through the LDS-DMA engine into a dump area, so that the epilogue's
- * loads hit L2 / the memory-side cache instead of HBM.  0 (default) = off -- measured 1-2 % SLOWER on MI355X (profiles/r05_res_prefetch_ab.txt) --, 1 = on. */
-void gm_conv_dma_set_res_prefetch(int on);
 /* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
  * software-pipelined over the taps (bench A/B: slower at 128 registers). */
 void gm_conv_w8_set_pipe2(int on);
+/* Tap-loop form of tile configuration 23 (process-wide; results do not depend on it): 1 (default) = two operand register sets, 0 = one. */
+void gm_conv_w4_set_pipe2(int on);
 /* Kernel of the K slices of a split-K launch (process-wide; results do not depend on it: the partial sums are bit-identical): 1 (default) =
  * conv_sk.hip (one work-group per CU, the patch and all nine weight panels of a K chunk requested up front); 0 = the general cfg 11 tile kernel
  * (the round-3 path; A/B measurements and the bitwise test). */
