@@ -592,7 +592,7 @@ def test_native_planners_accept_and_reject_geometries_without_a_gpu():
     assert lds(cfg=15, sd=2, sh=2, sw=2, Do=8, Ho=8, Wo=8, ltd=1) > 0 # stride-2 variant
     assert lds(cfg=15) == -1                                          # ... which does not take stride 1
     sub = dict(cfg=17, in_mode=3, kd=2, kh=2, kw=2, Do=32, Ho=32, Wo=32, pd=0, ph=0, pw=0)
-    assert lds(**sub) == 5 * 96 * 64 + 36 * 1024 + 512             # sub-pixel up-sampling (2x2x2 kernels): four 8 KiB panels padded to the 36 KiB transpose scratch
+    assert lds(**sub) == 5 * 96 * 64 + 36 * 1024 + 512 + 256 * 9 * 4  # sub-pixel up-sampling (2x2x2 kernels): four 8 KiB panels padded to the 36 KiB transpose scratch, + the placement table (round 5)
     assert lds(**dict(sub, Do=31)) == -1
     assert lds(**dict(sub, in_mode=1)) == -1
     assert lds(in_mode=3, kd=2, kh=2, kw=2, Do=32, Ho=32, Wo=32) == -1  # in_mode 3 exists for configuration 17 only
