@@ -1086,10 +1086,6 @@ extern "C" int gm_conv_mw_launch(const GmConvDesc* dp, unsigned nblocks, void* s
 extern "C" long long gm_conv_w8_lds_bytes();
 extern "C" int gm_conv_w8_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_w8_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
-// tile configuration 23 (conv_w4.hip: configuration 22's LDS image on four waves of 4 x 2 MFMA blocks)
-extern "C" long long gm_conv_w4_lds_bytes();
-extern "C" int gm_conv_w4_eligible(const GmConvDesc* d);
-extern "C" int gm_conv_w4_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 // the K slices of a split-K launch (cfg 11 geometry) run on conv_sk.hip's kernel: one work-group per CU, patch + all nine panels of a chunk resident
 extern "C" int gm_conv_sk_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
@@ -1099,7 +1095,6 @@ extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   const long long addv = 512;
   if (variant == 6) return gm_conv_mw_lds_bytes();
   if (variant == 7) return gm_conv_w8_lds_bytes();
-  if (variant == 8) return gm_conv_w4_lds_bytes();
   if (variant == 4) return 5LL * 96 * DMA_ROWB + 36864 + addv + 256LL * 9 * 4;  // ... + the placement table (256 threads x (8 pieces + the slot keys))
   if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB + addv;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
@@ -1159,12 +1154,11 @@ static unsigned dma_grid(unsigned nwork, long long lds_bytes, int by_waves, bool
 
 #if DMA_PART(0)
 // geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)
-extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 23 ? 8 : cfg == 22 ? 7 : cfg == 21 ? 6 : cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
+extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 22 ? 7 : cfg == 21 ? 6 : cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
 
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   if (d->cfg == 21) return gm_conv_mw_eligible(d);
   if (d->cfg == 22) return gm_conv_w8_eligible(d);
-  if (d->cfg == 23) return gm_conv_w4_eligible(d);
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const int s = d->cfg == 15 ? 2 : 1;
@@ -1288,7 +1282,6 @@ extern "C" int gm_conv_dma_launch_part4(const GmConvDesc* dp, unsigned nblocks, 
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   if (dp->cfg == 21) return gm_conv_mw_launch(dp, nblocks, stream);
   if (dp->cfg == 22) return gm_conv_w8_launch(dp, nblocks, stream);
-  if (dp->cfg == 23) return gm_conv_w4_launch(dp, nblocks, stream);
   if (gm_conv_sk_eligible(dp)) return gm_conv_sk_launch(dp, nblocks, stream);
   switch (dp->cfg) {
     case 14: return gm_conv_dma_launch_part1(dp, nblocks, stream);

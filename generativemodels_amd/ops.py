@@ -691,7 +691,7 @@ SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups t
 SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "256"))
 SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
 _SK_KERNEL = os.environ.get("GM_CONV_SK")  # "0": the slices on the general cfg 11 tile kernel (round-3 path) instead of conv_sk.hip -- A/B measurements only
-DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 21, 22, 23)
+DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 21, 22)
 # cfg 21 (csrc/conv_mw.hip): bf16 3x3x3 stride-1 convolutions without a fused prologue on 16-channel half-chunks + v_mfma_f32_32x32x16_bf16, three
 # work-groups per CU; "1" prefers it over cfg 14 wherever it is eligible and the grid fills the chip, "0" keeps cfg 14
 DMA_MW = os.environ.get("GM_CONV_MW", "0") != "0"
@@ -701,10 +701,9 @@ DMA_MW = os.environ.get("GM_CONV_MW", "0") != "0"
 # iteration) -- the sampling loop runs at the package power cap (1 380 of 1 400 W, profiles/r04_power_trace.txt), where three different tile
 # structures (cfg 14 / 21 / 22) land on the same throughput.  "1" prefers it from DMA_W8_MIN_TILES work-groups on; the default keeps cfg 14.
 DMA_W8 = os.environ.get("GM_CONV_W8", "0") != "0"
-# cfg 23 (csrc/conv_w4.hip, round 5): configuration 22's LDS image on FOUR waves of 4 x 2 blocks of the 32x32x16 MFMA at 256 registers with two operand
-# sets -- 6 operand reads per 8 MFMAs: 0.830 pJ/FLOP at the instruction level against 0.954 for cfg 14's 16x16x32 loop (profiles/r05_mfma_energy.txt),
-# which is what counts at the package power cap.  No fused prologue.  "1" prefers it from DMA_W8_MIN_TILES work-groups on.
-DMA_W4 = os.environ.get("GM_CONV_W4", "0") != "0"
+# (round 5: a FOURTH structure -- this LDS image on four waves of 4 x 2 blocks of the 32x32x16 MFMA at 256 registers with two operand sets, 0.75 operand
+#  reads per MFMA -- was built, verified bit-identical to cfg 22 and measured: -2 ... -8 % on deep K against cfg 14, 14.17 vs 13.97 ms per DDIM
+#  iteration; it lives under experiments/conv_w4/ with its numbers in profiles/r05_conv_cfg23_ab.txt, not in the library)
 DMA_W8_MIN_TILES = int(os.environ.get("GM_CONV_W8_MIN_TILES", "512"))
 # ... also WITH the GroupNorm-apply + activation prologue, applied in LDS to the landed patch (conv_w8.hip transform_patch; halo redundancy 2.11
 # against 2.53 at 256 voxels, four waves per SIMD): bit-identical to the two-pass form, 26 launches and 9 GB of HBM traffic less per C2 forward --
@@ -850,8 +849,6 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         tiles512 = desc.N * -(-desc.Do // 8) * -(-desc.Ho // 4) * -(-desc.Wo // 16) * -(-cout // 64)
         has_pre = bool(desc.pre_scale)
         big = [22] if (DMA_W8 and DMA_WIDE_WAVES and desc.dtype == 1 and tiles512 >= DMA_W8_MIN_TILES and (not has_pre or DMA_W8_PRE)) else []
-        if DMA_W4 and DMA_WIDE_WAVES and desc.dtype == 1 and tiles512 >= DMA_W8_MIN_TILES and not has_pre:
-            big = [23] + big
         order = ([15] if desc.sd == 2 else (big + (([21, 14, 11] if DMA_MW and desc.dtype == 1 else [14, 11]) if wide else [11]))) + order
         # (512-voxel tiles -- cfg 16 / 18, one work-group per CU, half the weight-panel traffic -- measure within +-5 % of two 256-voxel
         # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,
@@ -878,8 +875,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             if COUT1_MARCH_LTD is not None:
                 ltd = int(COUT1_MARCH_LTD)
             bits = [ltd, 3, ltw]
-        if cfg in (11, 14, 15, 16, 18, 19, 21, 22, 23):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
-            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 21: [2, 2, 4], 22: [3, 2, 4], 23: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
+        if cfg in (11, 14, 15, 16, 18, 19, 21, 22):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
+            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 21: [2, 2, 4], 22: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
@@ -1272,7 +1269,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
         d.w = cin_keep.data_ptr()
     if dma_ok and d.cfg == 22 and _W8_PIPE2 is not None:
         lib().gm_conv_w8_set_pipe2(int(_W8_PIPE2))
-    if dma_ok and d.cfg in (22, 23):  # configurations 22 / 23 read their main weights from the halves image (the fused shortcut keeps the standard one)
+    if dma_ok and d.cfg == 22:  # configuration 22 reads its main weights from the halves image (the fused shortcut keeps the standard one)
         halves_keep = packed_conv_weight_halves(packed, cin, math.prod(k))
         d.w = halves_keep.data_ptr()
     kpart = None

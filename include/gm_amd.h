@@ -217,8 +217,6 @@ void gm_conv_dma_set_phase_skew(int cycles);
 /* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
  * software-pipelined over the taps (bench A/B: slower at 128 registers). */
 void gm_conv_w8_set_pipe2(int on);
-/* Tap-loop form of tile configuration 23 (process-wide; results do not depend on it): 1 (default) = two operand register sets, 0 = one. */
-void gm_conv_w4_set_pipe2(int on);
 /* Kernel of the K slices of a split-K launch (process-wide; results do not depend on it: the partial sums are bit-identical): 1 (default) =
  * conv_sk.hip (one work-group per CU, the patch and all nine weight panels of a K chunk requested up front); 0 = the general cfg 11 tile kernel
  * (the round-3 path; A/B measurements and the bitwise test). */

@@ -341,11 +341,9 @@ def test_conv_three_workgroup_kernel(case):
                                   ("cat32", 96, 64, 32, None, (6, 5, 33), "res"), ("skip", 64, 64, None, (32,), (8, 8, 16), "skip"),
                                   ("skip-cat", 32, 40, None, (64, 32), (5, 7, 19), "skip"), ("skip-cat3", 128, 136, 64, (32, 96), (12, 6, 18), "skip"),
                                   ("deep", 256, 64, None, None, (16, 8, 32), "res")], ids=lambda c: c[0])
-@pytest.mark.parametrize("cfg", [22, 23])
+@pytest.mark.parametrize("cfg", [22])
 def test_conv_512_voxel_tile_kernel(case, cfg):
-    """cfg 23 (conv_w4.hip, round 5): the same LDS image on FOUR waves of two depth planes each -- 4 x 2 blocks of the 32x32x16 MFMA per wave, two
-    operand register sets at 256 registers, 17 incrementally placed patch pieces per wave -- held to the same cases.
-    cfg 22 (conv_w8.hip): 8 x 4 x 16 voxel tiles of 8 waves, 64-byte patch rows without padding (per-column bank key), 16-channel weight
+    """cfg 22 (conv_w8.hip): 8 x 4 x 16 voxel tiles of 8 waves, 64-byte patch rows without padding (per-column bank key), 16-channel weight
     panels from the halves image through a two-slot ring, v_mfma_f32_32x32x16_bf16, two work-groups per CU.  Ragged volumes (depths that
     are not multiples of 8), ragged output-channel blocks, the two-source input of a virtual concatenation, bias + timestep row + residual
     into a channel slice of a wider buffer, the fused 1x1 shortcut over one / two sources (more than one round of two chunks), fused
@@ -390,9 +388,6 @@ def test_conv_512_voxel_tile_kernel(case, cfg):
     assert (other.float() - got.float()).abs().max().item() <= 2 ** -6 * max(1.0, want.abs().max().item())
     again = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=cfg, **kw)
     assert torch.equal(again, got.contiguous()) and torch.equal(again._gm_cstats, got._gm_cstats)  # run-to-run bitwise
-    if cfg == 23:  # the two 32x32x16 kernels add the same products in the same order (chunk, half, tap): bit-identical outputs
-        twin = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=22, **kw)
-        assert torch.equal(twin, again)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

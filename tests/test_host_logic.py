@@ -531,27 +531,6 @@ def test_conv_w8_index_arithmetic_replayed_on_the_host():
     assert "bank conflicts: 0" in r.stdout
 
 
-def test_conv_w4_index_arithmetic_replayed_on_the_host():
-    """Tile configuration 23 (csrc/conv_w4.hip, round 5): configuration 22's LDS image owned by four waves of two depth planes each (4 x 2 blocks of
-    the 32x32x16 MFMA): 17 patch pieces per wave advancing by 64 rows, six weight pieces over four waves, four B fragments per tap across two planes,
-    eight shortcut pieces per wave, a 128-row transpose scratch -- replayed by tests/emulate_conv_w4.cpp against a direct convolution, zero bank conflicts."""
-    import os
-    import shutil
-    import subprocess
-    import tempfile
-
-    gxx = shutil.which("g++")
-    if gxx is None:
-        pytest.skip("no host compiler")
-    here = os.path.dirname(os.path.abspath(__file__))
-    with tempfile.TemporaryDirectory() as tmp:
-        exe = os.path.join(tmp, "emu")
-        subprocess.run([gxx, "-O2", "-std=c++17", os.path.join(here, "emulate_conv_w4.cpp"), "-o", exe], check=True)
-        r = subprocess.run([exe], capture_output=True, text=True)
-    assert r.returncode == 0 and "conv_w4 index replay OK" in r.stdout, r.stdout[-2000:]
-    assert "bank conflicts: 0" in r.stdout
-
-
 def test_halves_image_of_a_packed_panel_is_a_permutation():
     """ops.packed_conv_weight_halves: [chunk32][tap][Cout_pad][32] -> [chunk32][half][tap][Cout_pad][16] (pure torch, CPU)."""
     import torch
