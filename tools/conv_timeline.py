@@ -50,12 +50,18 @@ def report(name, t, nchunks, gpc=9, stride=10):
     """gpc = tap groups per stamped chunk, stride = stamp slots per chunk (cfg 22: 18 groups = 2 halves x 9, chunks 0-1 stamped)"""
     import numpy as np
     ok = (t[:, 63] > 0) & (t[:, 0] > 0)
+    # s_memtime counters are PER XCD (work-group b runs on XCD b % 8) and not synchronised with each other: a span is only meaningful inside one XCD.
+    # (Round 4 printed max - min over the whole chip: "6080423.750 GHz".)  The tick is not the shader clock either: 16 tile rounds x 44.3 k ticks in
+    # 0.458 ms = 1.55 G ticks/s while GRBM_GUI_ACTIVE / 8 / duration gives 1.97 GHz for the same launch (profiles/r05_clock_energy.json) -- read the
+    # phase lengths below as RELATIVE shares of a tile's life; the effective clock comes from the counter pass (tools/clock_energy.py).
+    xcd = np.arange(len(t)) % 8
+    spans = [int(t[ok & (xcd == x), 63].max() - t[ok & (xcd == x), 0].min()) for x in range(8) if (ok & (xcd == x)).any()]
     t = t[ok]
     order = np.argsort(t[:, 0])
     t = t[order]
-    t0 = t[:, 0].min()
-    span = t[:, 63].max() - t0
-    print(f"--- {name}: {len(t)} work-groups, kernel span {span} cycles in {LAST_MS:.3f} ms = {span / LAST_MS / 1e6:.3f} GHz shader clock (stamped launch)")
+    span = sorted(spans)[len(spans) // 2] if spans else 0
+    print(f"--- {name}: {len(t)} work-groups, kernel span (median over the XCDs' own counters) {span} s_memtime ticks in {LAST_MS:.3f} ms = "
+          f"{span / max(LAST_MS, 1e-9) / 1e6:.3f} G ticks/s (stamped launch; not the shader clock: see tools/clock_energy.py)")
     for label, sel in (("all stamped work-groups", slice(0, None)),):
         tt = t[sel]
         if len(tt) == 0:
