@@ -115,7 +115,6 @@ PROTOTYPES = {
     "gm_conv_forward": (C.c_int, [C.POINTER(GmConvDesc), c_vp]),
     "gm_conv_dma_set_persistent": (None, [C.c_int]),
     "gm_conv_dma_set_phase_skew": (None, [C.c_int]),
-    "gm_conv_dma_set_walk_back": (None, [C.c_int]),
     "gm_conv_w8_set_pipe2": (None, [C.c_int]),
     "gm_conv_sk_set_enabled": (None, [C.c_int]),
     "gm_packed_conv_weight_elems": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -189,8 +188,6 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         if os.environ.get("GM_CONV_DMA_GRID"):  # A/B of the LDS-DMA grid policy (gm_conv_dma_set_persistent): -1 auto, 0 one tile per work-group
             handle.gm_conv_dma_set_persistent(int(os.environ["GM_CONV_DMA_GRID"]))
-        if os.environ.get("GM_CONV_DMA_WALK_BACK"):  # A/B of the tile order (gm_conv_dma_set_walk_back)
-            handle.gm_conv_dma_set_walk_back(int(os.environ["GM_CONV_DMA_WALK_BACK"]))
         if os.environ.get("GM_CONV_DMA_SKEW"):  # A/B of the one-time phase offset (gm_conv_dma_set_phase_skew): cycles, 0 off, -1 automatic
             handle.gm_conv_dma_set_phase_skew(int(os.environ["GM_CONV_DMA_SKEW"]))
         _lib = handle

@@ -61,7 +61,7 @@ static __device__ __attribute__((aligned(64))) unsigned int gm_zero_row[16] = {0
 // loop; every later work-group inherits the phase of the slot it is dispatched into.  (The round-2 skew experiment delayed EVERY tile of the
 // odd slot by <= 3 k cycles -- a permanent handicap of one slot, not a phase.)  Results do not depend on it.
 template <typename T, int NW, int MF, int S, int MINW, int KS = 3, int NFR_ = 4, bool PRE = false>
-__global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p, const unsigned phase_wgs, const unsigned phase_sleeps, const unsigned walk_back) {
+__global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDesc p, const unsigned phase_wgs, const unsigned phase_sleeps) {
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int NT = 64 * NW;
@@ -229,10 +229,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
     }
   };
 
-  // walk_back (round 5 A/B, one-tile-per-work-group launches): every XCD takes its range from the END -- the tiles whose input the producing pass wrote
-  // last (still in this XCD's L2 / the memory-side cache) come first, and what this launch writes last (the range heads) is what a forward-walking
-  // consumer reads first.  Results do not depend on it.
-  Tile cur = decode(walk_back && gx == cx ? sx + (cx - 1 - pos) : sx + pos);
+  Tile cur = decode(sx + pos);
   const Tile stride = decode(gx);  // the digits of the walk's stride (gx <= cx <= nwork / 8 + 1: a valid work item index, K slice 0)
   place_patch(cur);
   if (min(nchunks, cur.ks * cps) < nchunks) issue_patch(min(nchunks, cur.ks * cps));  // the first patch of the first tile
@@ -1124,10 +1121,8 @@ extern "C" void gm_conv_dma_set_persistent(int max_work_groups) { gm_dma_grid_ca
 // TFLOP/s register-resident at one / two waves per SIMD), so the partner's idle phases were never worth a full-rate tap loop.
 int gm_dma_phase_skew = 0;
 extern "C" void gm_conv_dma_set_phase_skew(int cycles) { gm_dma_phase_skew = cycles; }
-int gm_dma_walk_back = 0;  // bench switch (GM_CONV_DMA_WALK_BACK through gm_conv_dma_set_walk_back): see the kernel
-extern "C" void gm_conv_dma_set_walk_back(int on) { gm_dma_walk_back = on; }
 #else
-extern int gm_dma_grid_cap, gm_dma_phase_skew, gm_dma_walk_back;
+extern int gm_dma_grid_cap, gm_dma_phase_skew;
 #endif
 #define g_dma_grid_cap gm_dma_grid_cap
 #define g_dma_phase_skew gm_dma_phase_skew
@@ -1229,7 +1224,7 @@ static void launch_dma(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
     phase_sleeps = (unsigned)((cycles + 512) / 1024);
     if (phase_sleeps == 0) phase_wgs = 0;
   }
-  kern<<<dim3(grid), 64 * NW, (size_t)lds, st>>>(d, phase_wgs, phase_sleeps, gm_dma_walk_back ? 1u : 0u);
+  kern<<<dim3(grid), 64 * NW, (size_t)lds, st>>>(d, phase_wgs, phase_sleeps);
 }
 
 // ---- the parts: each defines the launcher of its tile configurations ----------------------------------------------------------------------------

@@ -409,10 +409,10 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
   // tail is what the XCD's own L2 and the memory-side cache still hold, and what this pass writes last (the heads) is what the consuming
   // convolution's first tiles read.  Any order is correct; the mapping below is a bijection of the block index.
   unsigned bx = blockIdx.x;
-  if (order != 0) {  // (order 2: the XCD-owned eighths walked forwards -- for a producer that wrote them back to front)
+  if (order == 1) {
     const unsigned nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = bx & 7, idx = bx >> 3;
     const unsigned cx = q8 + (xcd < r8 ? 1u : 0u), sx = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    bx = order == 1 ? sx + (cx - 1 - idx) : sx + idx;
+    bx = sx + (cx - 1 - idx);
   }
   const long long row_begin = (long long)bx * rows_per_block;
   long long row_end = row_begin + rows_per_block;

@@ -214,9 +214,6 @@ void gm_conv_dma_set_persistent(int max_work_groups);
  * `cycles` once; later work-groups inherit the phase of their slot.  0 = off (default: measured no gain on MI355X, profiles/r05_phase_skew_sweep.txt),
  * -1 = half the modelled tile life of the launch. */
 void gm_conv_dma_set_phase_skew(int cycles);
-/* Tile order of the one-tile-per-work-group LDS-DMA launches (process-wide; results do not depend on it): 0 (default) = every XCD walks its tile
- * range front to back, 1 = back to front (the tiles whose input was written last come first; pairs with gm_gn_apply's XCD-owned block order). */
-void gm_conv_dma_set_walk_back(int on);
 /* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
  * software-pipelined over the taps (bench A/B: slower at 128 registers). */
 void gm_conv_w8_set_pipe2(int on);
