@@ -399,22 +399,12 @@ __global__ __launch_bounds__(256) void gn_apply_vec_kernel(const T* __restrict__
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y, long long y_ld,
                                                            const float* __restrict__ scale, const float* __restrict__ shift, long long ss_ld,
-                                                           long long V, int C, int rows_per_block, int act, int order) {
+                                                           long long V, int C, int rows_per_block, int act) {
   const int CV = C / VEC, R = 256 / CV;
   const int n = blockIdx.y, t = threadIdx.x;
   const int cv = t % CV, r0 = t / CV;
   if (r0 >= R) return;
-  // order 1 (round 5): the row blocks are dealt like the convolutions deal their tiles -- XCD x (= blockIdx.x % 8: the dispatcher's round robin)
-  // owns the x-th eighth of the rows -- and every XCD walks its eighth BACKWARDS: the producing convolution wrote each eighth front to back, so its
-  // tail is what the XCD's own L2 and the memory-side cache still hold, and what this pass writes last (the heads) is what the consuming
-  // convolution's first tiles read.  Any order is correct; the mapping below is a bijection of the block index.
-  unsigned bx = blockIdx.x;
-  if (order == 1) {
-    const unsigned nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = bx & 7, idx = bx >> 3;
-    const unsigned cx = q8 + (xcd < r8 ? 1u : 0u), sx = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    bx = sx + (cx - 1 - idx);
-  }
-  const long long row_begin = (long long)bx * rows_per_block;
+  const long long row_begin = (long long)blockIdx.x * rows_per_block;
   long long row_end = row_begin + rows_per_block;
   if (row_end > V) row_end = V;
   float sc[VEC], sh[VEC];
@@ -477,11 +467,10 @@ extern "C" int gm_gn_apply(const void* x, long long x_ld, void* y, long long y_l
     if (iters > 16) iters = 16;
     const int rpb = (int)(R * iters);
     dim3 grid((unsigned)((V + rpb - 1) / rpb), (unsigned)N);
-    static const int order = getenv("GM_GN_APPLY_ORDER") ? atoi(getenv("GM_GN_APPLY_ORDER")) : 0;  // bench switch: 1 = XCD-owned eighths walked backwards
     if (dtype == GM_F32)
-      gn_apply_rows_kernel<float, 4><<<grid, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, ss_ld, V, C, rpb, act, order);
+      gn_apply_rows_kernel<float, 4><<<grid, 256, 0, st>>>((const float*)x, x_ld, (float*)y, y_ld, scale, shift, ss_ld, V, C, rpb, act);
     else
-      gn_apply_rows_kernel<bf16_raw, 8><<<grid, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, ss_ld, V, C, rpb, act, order);
+      gn_apply_rows_kernel<bf16_raw, 8><<<grid, 256, 0, st>>>((const bf16_raw*)x, x_ld, (bf16_raw*)y, y_ld, scale, shift, ss_ld, V, C, rpb, act);
     GM_LAUNCH_CHECK();
   }
   if (vec_ok && (dtype == GM_F32 || dtype == GM_BF16)) {
