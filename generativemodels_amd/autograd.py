@@ -23,7 +23,7 @@ import torch
 
 from . import ops
 
-__all__ = ["cast", "scale", "spade_modulate", "conv", "conv_transpose", "sigma_from_log_var", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
+__all__ = ["cast", "scale", "spade_modulate", "conv", "conv_transpose", "conv_dilated", "conv_transpose_dilated", "sigma_from_log_var", "linear", "group_norm_act", "layer_norm", "geglu", "resample2x", "embedding", "silu", "upsample_conv", "attention", "add", "cat", "to_arena", "from_arena"]
 
 
 def _tup(v, n):
@@ -152,6 +152,117 @@ def conv_transpose(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     """post_act(nn.ConvTransposeNd) over an arena tensor (weight [Cin, Cout, *k]); differentiable in x, weight, bias (kernel 3 at stride 1 or 2,
     kernel 4 at stride 2: the VQ-VAE up-sampling); post_act "none" or "relu"."""
     return _ConvTranspose.apply(x, weight, bias, kernel, stride, padding, output_padding, post_act)
+
+
+def _tap_samples(t: torch.Tensor, out_sp, k, s, p, d):
+    """For every kernel tap the arena tensor `t` ([N, *spatial, C]) sampled at the positions a dilated / strided convolution reads for its output
+    grid `out_sp`: X_tap[n, v, c] = t[n, s v + d tap - p, c], zero outside.  Pure data movement (one zero-padded copy + one strided copy per tap, by
+    torch): the rare dilated layers have no gather kernel of their own -- every multiply-add of their gradients still runs in libgmamd (the 1x1
+    weight-gradient kernel on these samples)."""
+    nsp = len(out_sp)
+    lo = [p[i] for i in range(nsp)]
+    hi = [max(0, s[i] * (out_sp[i] - 1) + d[i] * (k[i] - 1) - p[i] - (t.shape[1 + i] - 1)) for i in range(nsp)]
+    pad = []
+    for i in reversed(range(nsp)):
+        pad += [lo[i], hi[i]]
+    tp = torch.nn.functional.pad(t, [0, 0] + pad)  # (channels last: the first pair pads C by nothing)
+    import itertools
+    for tap in itertools.product(*[range(k[i]) for i in range(nsp)]):
+        idx = [slice(None)] + [slice(d[i] * tap[i], d[i] * tap[i] + s[i] * (out_sp[i] - 1) + 1, s[i]) for i in range(nsp)] + [slice(None)]
+        yield tap, tp[tuple(idx)].contiguous()
+
+
+class _ConvDilated(torch.autograd.Function):
+    """post_act(nn.ConvNd) with dilation > 1 (reference: the VQ-VAE's down-sampling Convolution(dilation=downsample_parameters[i][2]),
+    nets/vqvae.py:127-150).  Forward: the generic kernel.  dx: the transposed convolution with the same weight, stride, padding and dilation.
+    dW: per tap a 1x1 weight gradient (gm_conv_wgrad) of gy against the input sampled where that tap read it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kernel, stride, padding, dilation, post_act="none"):
+        y = ops.conv(x, weight, bias, kernel=kernel, stride=stride, padding=padding, dilation=dilation, post_act=post_act)
+        ctx.post_act = post_act
+        if post_act != "none":
+            ctx.save_for_backward(x, weight, y)
+        else:
+            ctx.save_for_backward(x, weight)
+        ctx.geom = (kernel, stride, padding, dilation)
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        x, weight = saved[:2]
+        kernel, stride, padding, dilation = ctx.geom
+        gy = gy.contiguous()
+        if ctx.post_act != "none":
+            gy = ops.act_backward(saved[2], gy, ctx.post_act)
+        nsp = x.dim() - 2
+        k, s, p, d = _tup(kernel, nsp), _tup(stride, nsp), _tup(padding, nsp), _tup(dilation, nsp)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            opad = tuple(x.shape[1 + i] - ((gy.shape[1 + i] - 1) * s[i] - 2 * p[i] + d[i] * (k[i] - 1) + 1) for i in range(nsp))
+            dx = ops.conv(gy, weight, None, kernel=kernel, stride=stride, padding=padding, dilation=dilation, transposed=True, output_padding=opad)
+        if ctx.needs_input_grad[1]:
+            dw32 = torch.empty((weight.shape[0], weight.shape[1], *k), dtype=torch.float32, device=x.device)
+            for tap, xs in _tap_samples(x, tuple(gy.shape[1:-1]), k, s, p, d):
+                dw32[(slice(None), slice(None)) + tap] = ops.conv_wgrad(xs, gy, 1, 1, 0).reshape(weight.shape[0], weight.shape[1])
+            dw = dw32.to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            db = ops.bias_grad(gy).to(ctx.bias_dtype)
+        return dx, dw, db, None, None, None, None, None
+
+
+class _ConvTransposeDilated(torch.autograd.Function):
+    """post_act(nn.ConvTransposeNd) with dilation > 1 (the VQ-VAE's up-sampling Convolution(is_transposed=True, dilation=...), nets/vqvae.py:244-261): the
+    adjoint of _ConvDilated with the same weight read as [out = Cin, in = Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kernel, stride, padding, output_padding, dilation, post_act="none"):
+        y = ops.conv(x, weight, bias, kernel=kernel, stride=stride, padding=padding, dilation=dilation, transposed=True, output_padding=output_padding,
+                     post_act=post_act)
+        ctx.post_act = post_act
+        if post_act != "none":
+            ctx.save_for_backward(x, weight, y)
+        else:
+            ctx.save_for_backward(x, weight)
+        ctx.geom = (kernel, stride, padding, dilation)
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        x, weight = saved[:2]
+        kernel, stride, padding, dilation = ctx.geom
+        gy = gy.contiguous()
+        if ctx.post_act != "none":
+            gy = ops.act_backward(saved[2], gy, ctx.post_act)
+        nsp = x.dim() - 2
+        k, s, p, d = _tup(kernel, nsp), _tup(stride, nsp), _tup(padding, nsp), _tup(dilation, nsp)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv(gy, weight, None, kernel=kernel, stride=stride, padding=padding, dilation=dilation)  # [Cin, Cout, *k] read as a Conv weight
+            if dx.shape != x.shape:
+                raise ValueError(f"transposed-convolution geometry is not invertible: {tuple(dx.shape)} vs {tuple(x.shape)}")
+        if ctx.needs_input_grad[1]:
+            dw32 = torch.empty((weight.shape[0], weight.shape[1], *k), dtype=torch.float32, device=x.device)
+            for tap, gs in _tap_samples(gy, tuple(x.shape[1:-1]), k, s, p, d):  # gy sampled where the adjoint convolution reads it for every input voxel
+                dw32[(slice(None), slice(None)) + tap] = ops.conv_wgrad(gs, x, 1, 1, 0).reshape(weight.shape[0], weight.shape[1])
+            dw = dw32.to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            db = ops.bias_grad(gy).to(ctx.bias_dtype)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv_dilated(x, weight, bias=None, *, kernel, stride=1, padding=0, dilation=1, post_act: str = "none") -> torch.Tensor:
+    """post_act(conv(x, weight, dilation) + bias) over an arena tensor, differentiable in x, weight, bias; post_act "none" or "relu"."""
+    return _ConvDilated.apply(x, weight, bias, kernel, stride, padding, dilation, post_act)
+
+
+def conv_transpose_dilated(x, weight, bias=None, *, kernel, stride, padding, output_padding=0, dilation=1, post_act: str = "none") -> torch.Tensor:
+    """post_act(nn.ConvTransposeNd with dilation) over an arena tensor (weight [Cin, Cout, *k]), differentiable in x, weight, bias."""
+    return _ConvTransposeDilated.apply(x, weight, bias, kernel, stride, padding, output_padding, dilation, post_act)
 
 
 class _SigmaFromLogVar(torch.autograd.Function):

@@ -61,10 +61,16 @@ class _ConvAct(nn.Module):
         """The same layer with gradients (generativemodels_amd.autograd): convolution / transposed convolution with the activation in its epilogue."""
         from ... import autograd as A
 
-        if self.dilation != 1:
-            raise NotImplementedError("VQVAE training: dilated down- / up-sampling convolutions have no weight-gradient kernel")
         fused = _fused_epilogue_trains(self.act, self.dropout, self.training)
         post = self.act if fused else "none"
+        if self.dilation != 1:  # (round 5) dilated resampling convolutions: gradients composed per tap from the 1x1 weight-gradient kernel
+            if self.transposed:
+                z = A.conv_transpose_dilated(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding,
+                                             output_padding=self.output_padding, dilation=self.dilation, post_act=post)
+            else:
+                z = A.conv_dilated(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding,
+                                   dilation=self.dilation, post_act=post)
+            return z if fused else _dropout_act(z, self.dropout, self.training, self.act)
         if self.transposed:
             z = A.conv_transpose(x, self.conv.weight, self.conv.bias, kernel=self.kernel, stride=self.stride, padding=self.padding,
                                  output_padding=self.output_padding, post_act=post)

@@ -201,6 +201,8 @@ CONV_CASES = [
     ("3d_T_k3s2", 2, 8, 8, (4, 4, 4), dict(k=3, s=2, p=1, T=True, op=1)),
     ("2d_T_k3s1", 1, 8, 4, (8, 8), dict(k=3, s=1, p=1, T=True, op=0)),
     ("2d_T_k3s2op1", 1, 16, 8, (8, 8), dict(k=3, s=2, p=1, T=True, op=1)),
+    ("3d_T_dil", 1, 8, 8, (5, 5, 5), dict(k=3, s=2, p=2, d=2, T=True, op=1)),   # (round 5) the dilated VQ-VAE up-sampling form and its adjoint
+    ("3d_s2_dil", 2, 8, 16, (10, 10, 10), dict(k=3, s=2, p=2, d=2)),
 ]
 
 
