@@ -17,8 +17,11 @@
 // -----------------------------------------------------------------------------------------------------------------------
 // (round 3: C_in is a template constant -- with a run-time C_in the staging loops and the tap tables spent ~2 000 instructions per thread on
 //  integer divisions (element -> row -> (plane, line, column), k -> (tap, channel)), a large part of the 28 k cycles a work-group lives)
+// (round 5: a minimum-occupancy bound.  Without one hipcc kept the 64 accumulators in AGPRs next to 110 VGPRs = 174 registers = TWO waves per SIMD for
+//  a kernel that is a chain of latencies -- patch load, barrier, gather, MFMA, transpose, store -- per tile; bounded, the same code needs 110-154
+//  registers without a spill: four (three) work-groups per CU.  fp32 with 3-4 input channels would spill: left at two.)
 template <typename T, int CIN>
-__global__ __launch_bounds__(256) void conv_cin_kernel(const GmConvDesc p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? (CIN <= 3 ? 4 : 3) : (CIN == 1 ? 4 : (CIN == 2 ? 3 : 2))) void conv_cin_kernel(const GmConvDesc p) {
   constexpr int VECW = ConvTraits<T>::VECW;
   constexpr int KB = 4 * VECW;                 // K values one Mma<T>::run consumes (32 bf16 / 16 fp32)
   constexpr int MF = 4, NFR = 4, NW = 4, BN = 64;
