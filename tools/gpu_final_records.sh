@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 5, final GPU visit (2): the conv_in occupancy change verified, then the records of the final tree: PMC traffic stamp, default bench, rocprofv3 stats, GPU suite
+# One GPU visit that produces the records of a finished tree (round 5's last visit, kept as run): a kernel-test subset, the PMC traffic passes that stamp
+# profiles/pmc_hbm_traffic_current.json, the default bench (CPU leg on), rocprofv3 --kernel-trace --stats of the bench, the 256^3 autoencoder layer times, the GPU suite.
+# (The round's A/B visits were one-off scripts; what each ran is in the header of the profiles/r05_* file it produced.  tools/gpu_visit.sh is the parameterised form.)
 set -u
 cd "$(dirname "$0")/.."
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
