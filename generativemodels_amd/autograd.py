@@ -454,7 +454,7 @@ def _attention_backward(q, k, v, o, go, heads, scale):
     # >= 512 tokens (C4: one head x 4096 tokens at 16^3, one x 512 at 8^3) -- and ANY number of pairs above 8 192 tokens, where the fused fp32
     # kernels below run at 45 TFLOP/s (84.6 ms per head at 32 768 x 256 against 16-17 ms here)
     if (q.dtype == torch.bfloat16 and dh in ops.ATTENTION_BWD_BF16_HEAD_DIMS and max(lq, lk) >= ATTENTION_BWD_BF16_MIN_TOKENS
-            and (b * heads <= 2 or long_seq) and 6 * (lq + 63) * (lk + 63) <= ops.ATTENTION_BWD_BF16_MAX_BYTES):
+            and (b * heads <= 2 or long_seq)):  # (any size: pairs beyond ops.ATTENTION_BWD_BF16_SLAB_BYTES of score matrices go through in query slabs)
         return ops.attention_backward_bf16(q, k, v, o, go, heads, scale)
     # fp32 (or bf16 below the bounds above): the fused kernels own 64 rows per work-group, so ONE head of a few thousand tokens leaves most CUs
     # idle (L = 4096, d = 128: 1.9 ms fused vs 0.86 ms composed) while many (sample, head) pairs favour them (2 x 4 heads of 1024 tokens: 0.21 vs

@@ -1565,6 +1565,10 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: tor
 
 ATTENTION_BWD_BF16_HEAD_DIMS = (32, 64, 128, 256)
 ATTENTION_BWD_BF16_MAX_BYTES = 16 << 30  # the P and dS matrices of one call (2 x B x H x Lq x Lk x 2 bytes): 4.3 GB at 32 768 tokens, one head
+# (round 5) ... and of one QUERY SLAB: a (sample, head) pair whose score matrices exceed this goes through the score pass in slabs of query rows -- every
+# softmax quantity is per query row, dV / dK accumulate over the slabs in fp32 (gm_conv_wgrad's accumulate form), dQ is written slab by slab -- so one
+# head of 32 768 tokens needs 0.4 GB of scratch instead of 6.4 GB, at the same FLOPs
+ATTENTION_BWD_BF16_SLAB_BYTES = 512 << 20
 
 
 def attention_backward_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, go: torch.Tensor, heads: int, scale: float):
@@ -1584,6 +1588,8 @@ def attention_backward_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o
     q, k, v, o, go = (t.contiguous() for t in (q, k, v, o, go))
     lkp, lqp = (lk + 63) // 64 * 64, (lq + 63) // 64 * 64
     pair_bytes = (2 * lq * lkp + lkp * lqp) * 2  # P, dS [Lq][Lk] and dS^T [Lk][Lq] of ONE (sample, head) pair
+    if pair_bytes > ATTENTION_BWD_BF16_SLAB_BYTES and lq > 64:
+        return _attention_backward_bf16_slabs(q, k, v, o, go, heads, scale)
     if pair_bytes > ATTENTION_BWD_BF16_MAX_BYTES:
         raise ValueError("attention_backward_bf16: the score matrices of one (sample, head) pair exceed ATTENTION_BWD_BF16_MAX_BYTES")
     # (sample, head) pairs per score pass: all of them when their matrices fit the scratch bound, else one at a time through ONE set of buffers
@@ -1629,6 +1635,53 @@ def attention_backward_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o
             for hi in range(heads):
                 score_pass(bi, 1, hi, 1)
                 contractions(bi, hi, 0)
+    return dq, dk, dv
+
+
+def _attention_backward_bf16_slabs(q, k, v, o, go, heads: int, scale: float):
+    """attention_backward_bf16 for (sample, head) pairs whose L x L score matrices exceed ATTENTION_BWD_BF16_SLAB_BYTES: the same kernels over slabs
+    of query rows.  The score pass (LSE over all keys, P, dS, dS^T) is row-wise in the queries, so a slab is the call on a row range of q / o / dO;
+    dV = sum over slabs P_s^T dO_s and dK = sum dS_s^T Q_s accumulate in fp32 in a fixed slab order (deterministic), dQ_s = dS_s K lands in its rows."""
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    dh = c // heads
+    lkp = (lk + 63) // 64 * 64
+    bq = max(64, int(ATTENTION_BWD_BF16_SLAB_BYTES // (6 * lkp)) // 64 * 64)  # query rows per slab: 3 matrices x 2 bytes x lkp per row
+    bqp = bq
+    probs = torch.empty((1, bq, lkp), dtype=torch.bfloat16, device=q.device)
+    dscores = torch.empty_like(probs)
+    dscores_t = torch.empty((1, lkp, bqp), dtype=torch.bfloat16, device=q.device)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    es = q.element_size()
+    for bi in range(b):
+        for hi in range(heads):
+            sl = slice(hi * dh, (hi + 1) * dh)
+            dv32 = torch.empty((lk, dh, 1), dtype=torch.float32, device=q.device)
+            dk32 = torch.empty((lk, dh, 1), dtype=torch.float32, device=q.device)
+            for si, i0 in enumerate(range(0, lq, bq)):
+                rows = min(bq, lq - i0)
+                d = GmAttnBwdDesc()
+                for name, t in (("q", q), ("o", o), ("go", go)):
+                    setattr(d, name, t.data_ptr() + ((bi * lq + i0) * c + hi * dh) * es)
+                    setattr(d, name + "_ld", _kv_ld(t))
+                for name, t in (("k", k), ("v", v)):
+                    setattr(d, name, t.data_ptr() + (bi * lk * c + hi * dh) * es)
+                    setattr(d, name + "_ld", _kv_ld(t))
+                d.B, d.H, d.Lq, d.Lk, d.dh = 1, 1, rows, lk, dh
+                d.scale, d.dtype = float(scale), dt_code(q.dtype)
+                nbytes = lib().gm_attention_bwd_scores_workspace_bytes(C.byref(d))
+                ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+                d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+                _timed("attention_bwd_scores<bfloat16>", dict(flops=6.0 * rows * lk * dh, bytes=float(6 * rows * lkp), shape=f"slab {rows}x{lk} d{dh}"),
+                       lambda d=d: check(lib().gm_attention_bwd_scores(C.byref(d), probs.data_ptr(), dscores.data_ptr(), lkp, dscores_t.data_ptr(), bqp, _stream()),
+                                         "gm_attention_bwd_scores"))
+                qs, gs = q[bi:bi + 1, i0:i0 + rows, sl], go[bi:bi + 1, i0:i0 + rows, sl]
+                conv_wgrad(gs, probs[:, :rows, :lk], 1, 1, 0, out=dv32, accumulate=si > 0)              # dV += P_s^T dO_s
+                conv_wgrad(qs, dscores[:, :rows, :lk], 1, 1, 0, out=dk32, accumulate=si > 0)            # dK += dS_s^T Q_s
+                dqh = conv_wgrad(k[bi:bi + 1, :, sl], dscores_t[:, :lk, :rows], 1, 1, 0)               # [rows, dh, 1] = dS_s K
+                copy_channels(dqh.reshape(1, rows, dh), dq[bi:bi + 1, i0:i0 + rows, sl])
+            copy_channels(dk32.reshape(1, lk, dh), dk[bi:bi + 1, :, sl])
+            copy_channels(dv32.reshape(1, lk, dh), dv[bi:bi + 1, :, sl])
     return dq, dk, dv
 
 

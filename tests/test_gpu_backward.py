@@ -1133,6 +1133,67 @@ def test_attention_backward_bf16_one_pair_at_a_time_is_bitwise_the_whole_call(mo
         assert torch.equal(a, b_)
 
 
+@pytest.mark.parametrize("b,lq,lk,heads,dh", [(1, 700, 700, 2, 64), (2, 333, 200, 1, 128), (1, 1100, 520, 1, 32)])
+def test_attention_backward_bf16_in_query_slabs(monkeypatch, b, lq, lk, heads, dh):
+    """(round 5) a (sample, head) pair whose score matrices exceed ops.ATTENTION_BWD_BF16_SLAB_BYTES goes through the score pass in slabs of query
+    rows: dV / dK accumulate over the slabs in fp32, dQ is written per slab.  The scratch of one head of 32 768 tokens drops from 6.4 GB to
+    <= 0.5 GB.  Here with a small budget (slabs of 128 / 64 rows, a ragged last slab, Lq != Lk): against torch autograd in fp64 to the bar of the
+    whole-pair path, and against the whole-pair result itself (same products, another fp32 summation order over the query rows)."""
+    ops = _ops()
+    c, scale = heads * dh, 1 / math.sqrt(dh)
+    q, go = _rand((b, lq, c), 721).bfloat16(), _rand((b, lq, c), 724).bfloat16()
+    k, v = _rand((b, lk, c), 722).bfloat16(), _rand((b, lk, c), 723).bfloat16()
+    ref = [t.double().requires_grad_(True) for t in (q, k, v)]
+    qh = ref[0].reshape(b, lq, heads, dh).transpose(1, 2)
+    kh, vh = (t.reshape(b, lk, heads, dh).transpose(1, 2) for t in ref[1:])
+    o_ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(b, lq, c)
+    (o_ref * go.double()).sum().backward()
+    qd, kd, vd, gd = (t.to(DEV) for t in (q, k, v, go))
+    o = ops.attention(qd, kd, vd, heads, scale)
+    whole = ops.attention_backward_bf16(qd, kd, vd, o, gd, heads, scale)
+    lkp = (lk + 63) // 64 * 64
+    monkeypatch.setattr(ops, "ATTENTION_BWD_BF16_SLAB_BYTES", 6 * lkp * (128 if lq > 400 else 64))
+    calls = []
+    real = ops._attention_backward_bf16_slabs
+    monkeypatch.setattr(ops, "_attention_backward_bf16_slabs", lambda *a: (calls.append(1), real(*a))[1])
+    slabs = ops.attention_backward_bf16(qd, kd, vd, o, gd, heads, scale)
+    assert calls, "the slab path did not run"
+    for name, got, w, r in zip("qkv", slabs, whole, ref):
+        _close(got, r.grad, 1.5e-2, f"slabbed bf16-MFMA attention backward d{name}")
+        _close(got, w.double().cpu(), 1e-2, f"slabbed vs whole-pair d{name}")
+    again = ops.attention_backward_bf16(qd, kd, vd, o, gd, heads, scale)
+    for a, b_ in zip(slabs, again):
+        assert torch.equal(a, b_)  # fixed slab order: deterministic
+
+
+def test_attention_backward_bf16_scratch_is_bounded_at_16k_tokens():
+    """One head of 16 384 tokens: P, dS and dS^T of the whole pair are 1.6 GB; the default slab budget (512 MB) bounds the scratch of the backward
+    -- checked on the allocator's peak -- and the gradients still match the whole-pair call (run under a raised budget)."""
+    import gc
+    ops = _ops()
+    l, dh = 16384, 64
+    scale = 1 / math.sqrt(dh)
+    q, k, v, go = (_rand((1, l, dh), 730 + i).bfloat16().to(DEV) for i in range(4))
+    o = ops.attention(q, k, v, 1, scale)
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    slabs = ops.attention_backward_bf16(q, k, v, o, go, 1, scale)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 700 << 20, f"slabbed attention backward peaked at {peak / 2**20:.0f} MiB of scratch"
+    budget = ops.ATTENTION_BWD_BF16_SLAB_BYTES
+    try:
+        ops.ATTENTION_BWD_BF16_SLAB_BYTES = 4 << 30
+        whole = ops.attention_backward_bf16(q, k, v, o, go, 1, scale)
+    finally:
+        ops.ATTENTION_BWD_BF16_SLAB_BYTES = budget
+    for name, a, w in zip("qkv", slabs, whole):
+        _close(a, w, 1e-2, f"16k-token slabbed vs whole-pair d{name}")
+
+
 def test_transformer_block_training_with_dropout_matches_autograd_under_the_same_masks(monkeypatch):
     """`dropout_cattn` > 0 in train() mode (reference: CrossAttention.to_out = Sequential(Linear, Dropout), MONAI MLPBlock drop1 / drop2;
     diffusion_model_unet.py:155,178-234): the training forward applies a dropout at the reference's three places per block.  With
