@@ -11,22 +11,8 @@
 // means every operand -- K^T, Q^T, dO^T included -- is read from a natural [row][channel] tile with no transposed staging.  That is
 // 1/8 of the bf16 MFMA rate: right for the latent-resolution attention of a training step (C4: 512-4096 tokens), and what makes a
 // 32768-token backward possible at all; a bf16 version needs transposed K / Q / dO images (ds_read_b64_tr_b16) and is the follow-up.
-#include "gm_common.h"
+#include "attn_common.h"
 
-struct GmAttnBwdDesc {
-  const void* q; long long q_ld;
-  const void* k; long long k_ld;
-  const void* v; long long v_ld;
-  const void* o; long long o_ld;       // forward output WITHOUT the residual
-  const void* go; long long go_ld;     // gradient of the forward output
-  void* dq; long long dq_ld;
-  void* dk; long long dk_ld;
-  void* dv; long long dv_ld;
-  int B, H, Lq, Lk, dh;
-  float scale;
-  int dtype;
-  void* workspace; long long workspace_bytes;  // gm_attention_backward_workspace_bytes
-};
 
 template <typename T> __device__ __forceinline__ float4 ab_load4(const T* p);
 template <> __device__ __forceinline__ float4 ab_load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -20,14 +20,6 @@
 
 __device__ __attribute__((aligned(64))) unsigned int gm_attn_zero_row[16] = {0};
 
-__device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
 // ---- V -> VT[b*H + h][c][pos], pos = blk*32 + qq*8 + half*4 + r  <->  key = blk*32 + half*16 + qq*4 + r; keys >= Lk are zero ----
 __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_raw* __restrict__ v, long long v_ld, bf16_raw* __restrict__ vt,
                                                       int H, int Lk, int Lk_pad, int dh) {
@@ -370,6 +362,10 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, c
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
+void gm_attn_pack_transposed(const bf16_raw* rows, long long ld, bf16_raw* image, int B, int H, int L, int L_pad, int dh, hipStream_t st) {
+  vt_pack_kernel<<<dim3(L_pad / 64, dh / 64, B * H), 256, 0, st>>>(rows, ld, image, H, L, L_pad, dh);
+}
+
 static int gm_attn_dma_force_qf = 0, gm_attn_dma_force_split = 0;  // 0 = choose by problem size (tests / benchmarks force a variant)
 extern "C" void gm_attention_dma_set_variant(int qf, int nsplit) {
   gm_attn_dma_force_qf = (qf == 1 || qf == 2) ? qf : 0;

@@ -21,3 +21,33 @@ struct GmAttnDesc {
   double* stats;               // optional [gm_attention_stats_slots][B][H * dh][2] per-channel (sum, sum of squares) partials of the stored output
   int vt_packed;               // 1: the workspace already holds the transposed V image (written by gm_linear_rows_affine_vt): no pack launch
 };
+
+// Attention backward descriptor (attention_bwd.hip: fp32-MFMA fused kernels and the bf16 score pass; attention_bwd_dma.hip: fused bf16 LDS-DMA kernels)
+struct GmAttnBwdDesc {
+  const void* q; long long q_ld;
+  const void* k; long long k_ld;
+  const void* v; long long v_ld;
+  const void* o; long long o_ld;       // forward output WITHOUT the residual
+  const void* go; long long go_ld;     // gradient of the forward output
+  void* dq; long long dq_ld;
+  void* dk; long long dk_ld;
+  void* dv; long long dv_ld;
+  int B, H, Lq, Lk, dh;
+  float scale;
+  int dtype;
+  void* workspace; long long workspace_bytes;  // gm_attention_backward_workspace_bytes / gm_attention_backward_fused_workspace_bytes
+};
+
+#ifdef __HIPCC__
+// one 1 KB LDS-DMA piece: every lane's 16 bytes at gsrc land at lds_dst + 16 * lane (M0 saved and restored around the request)
+__device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+// rows [L][ld] (channels [h * dh, (h + 1) * dh) per head) -> image[b * H + h][channel][position], zero beyond L, position order inside each
+// 32-block = the order a 16x16x32 MFMA consumes two 16-row accumulator fragments (attention_dma.hip: vt_pack_kernel); dh a multiple of 64
+void gm_attn_pack_transposed(const bf16_raw* rows, long long ld, bf16_raw* image, int B, int H, int L, int L_pad, int dh, hipStream_t st);
+#endif

@@ -1563,6 +1563,46 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: tor
     return dq, dk, dv
 
 
+ATTENTION_BWD_FUSED_HEAD_DIMS = (64, 128, 256)
+
+
+def attention_backward_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, go: torch.Tensor, heads: int, scale: float,
+                             lse: Optional[torch.Tensor] = None):
+    """(dq, dk, dv) of o = softmax(scale q k^T) v by the fused bf16 flash backward on the LDS-DMA structure (gm_attention_backward_fused,
+    csrc/attention_bwd_dma.hip): scores recomputed per tile on bf16 MFMA, nothing L x L in HBM, deterministic.  bf16 (B, L, heads * dh) operands,
+    dh in ATTENTION_BWD_FUSED_HEAD_DIMS; lse: optional fp32 (B, heads, Lq) log-sum-exp of the scaled scores (else one more sweep computes it).
+    (reference: torch autograd through diffusion_model_unet.py:407-415)"""
+    require_device(q, k, v, o, go)
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    dh = c // heads
+    if q.dtype != torch.bfloat16 or dh not in ATTENTION_BWD_FUSED_HEAD_DIMS:
+        raise ValueError(f"attention_backward_fused: bf16 operands with a head dim in {ATTENTION_BWD_FUSED_HEAD_DIMS}")
+    if o.shape != q.shape or go.shape != q.shape or k.shape != v.shape or k.shape[2] != c:
+        raise ValueError("attention_backward operand shapes are inconsistent")
+    q, k, v, o, go = (t.contiguous() for t in (q, k, v, o, go))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    d = GmAttnBwdDesc()
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o), ("go", go), ("dq", dq), ("dk", dk), ("dv", dv)):
+        setattr(d, name, t.data_ptr())
+        setattr(d, name + "_ld", _kv_ld(t))
+    d.B, d.H, d.Lq, d.Lk, d.dh = b, heads, lq, lk, dh
+    d.scale, d.dtype = float(scale), dt_code(q.dtype)
+    nbytes = lib().gm_attention_backward_fused_workspace_bytes(C.byref(d))
+    if nbytes <= 0:
+        raise ValueError("attention_backward_fused: operands not served by the fused bf16 kernels (alignment / size)")
+    if lse is not None:
+        if lse.dtype != torch.float32 or lse.numel() != b * heads * lq or not lse.is_contiguous():
+            raise ValueError("attention_backward_fused: lse must be a contiguous fp32 (B, heads, Lq) tensor")
+        require_device(lse)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    _timed("attention_bwd_fused<bfloat16>", dict(flops=(14.0 if lse is not None else 16.0) * b * heads * lq * lk * dh, bytes=float(5 * 2 * q.numel()),
+                                                 shape=f"B{b} H{heads} L{lq}x{lk} d{dh}"),
+           lambda: check(lib().gm_attention_backward_fused(C.byref(d), lse.data_ptr() if lse is not None else None, _stream()), "gm_attention_backward_fused"))
+    return dq, dk, dv
+
+
 ATTENTION_BWD_BF16_HEAD_DIMS = (32, 64, 128, 256)
 ATTENTION_BWD_BF16_MAX_BYTES = 16 << 30  # the P and dS matrices of one call (2 x B x H x Lq x Lk x 2 bytes): 4.3 GB at 32 768 tokens, one head
 # (round 5) ... and of one QUERY SLAB: a (sample, head) pair whose score matrices exceed this goes through the score pass in slabs of query rows -- every

@@ -400,6 +400,12 @@ int gm_attention_backward(const GmAttnBwdDesc* d, void* stream);
  * dK = dS^T Q, dQ = (dS^T)^T K then run on gm_conv_wgrad (generativemodels_amd/ops.py: attention_backward_bf16). */
 long long gm_attention_bwd_scores_workspace_bytes(const GmAttnBwdDesc* d);
 int gm_attention_bwd_scores(const GmAttnBwdDesc* d, void* probs, void* dscores, long long pd_ld, void* dscores_t, long long st_ld, void* stream);
+/* Fused bf16 flash backward of the same autograd node (generativemodels_amd/csrc/attention_bwd_dma.hip; diffusion_model_unet.py:407-415 under
+ * torch autograd): dq / dk / dv written once as bf16, nothing L x L in HBM, deterministic.  bf16 operands, head size 64 / 128 / 256, 16-byte
+ * aligned rows; `lse` = log sum_k exp(scale q.k) per (sample, head, query), fp32 [B*H][Lq], or NULL (one more sweep computes it).
+ * gm_attention_backward_fused_workspace_bytes is 0 for operands this path does not take. */
+long long gm_attention_backward_fused_workspace_bytes(const GmAttnBwdDesc* d);
+int gm_attention_backward_fused(const GmAttnBwdDesc* d, const float* lse, void* stream);
 /* dscores = scale * probs * (dprobs - rowsum(dprobs * probs)): softmax backward of the attention scores scale * Q K^T, fp32 [rows][V]
  * (the softmax of diffusion_model_unet.py:143-153 / 407-415 under torch autograd) */
 int gm_softmax_bwd(const float* probs, const float* dprobs, float* dscores, long long rows, int V, float scale, void* stream);
