@@ -153,6 +153,7 @@ PROTOTYPES = {
     "gm_attention_backward": (C.c_int, [C.POINTER(GmAttnBwdDesc), c_vp]),
     "gm_attention_backward_fused_workspace_bytes": (c_ll, [C.POINTER(GmAttnBwdDesc)]),
     "gm_attention_backward_fused": (C.c_int, [C.POINTER(GmAttnBwdDesc), c_vp, c_vp]),
+    "gm_attention_backward_fused_set_split": (None, [C.c_int]),
     "gm_attention_bwd_scores_workspace_bytes": (c_ll, [C.POINTER(GmAttnBwdDesc)]),
     "gm_attention_bwd_scores": (C.c_int, [C.POINTER(GmAttnBwdDesc), c_vp, c_vp, c_ll, c_vp, c_ll, c_vp]),
     "gm_layernorm_bwd": (C.c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_float, c_vp, C.c_int, c_vp]),

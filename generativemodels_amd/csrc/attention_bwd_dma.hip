@@ -22,8 +22,10 @@ enum { ABD_DQ = 0, ABD_DKV = 1, ABD_LSE = 2 };
 
 // D[q] = dO[q] . O[q] and the (LSE, D) pairs the DKV kernel streams: ld[bh][q] for q < Lq, (+inf, 0) for the padding (a padded query's
 // probability is exp(x - inf) = 0: no masks in the DKV loop).  One thread per (query, 8 channels), 256 threads = 256 * 8 / DH queries.
+// `lse` NULL: the LSE sweep's (max, sum) pairs ms[slice][bh][q] of `nslices` key slices are merged here, slice order.
 template <int DH>
-__global__ __launch_bounds__(256) void abd_prep_kernel(const GmAttnBwdDesc p, const float* __restrict__ lse, float2* __restrict__ ld, int ld_stride) {
+__global__ __launch_bounds__(256) void abd_prep_kernel(const GmAttnBwdDesc p, const float* __restrict__ lse, const float2* __restrict__ ms, int nslices,
+                                                       float2* __restrict__ ld, int ld_stride) {
   constexpr int VPR = DH / 8, QPB = 256 / VPR;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
   const int q = blockIdx.x * QPB + threadIdx.x / VPR, cv = threadIdx.x % VPR;
@@ -39,12 +41,44 @@ __global__ __launch_bounds__(256) void abd_prep_kernel(const GmAttnBwdDesc p, co
   }
 #pragma unroll
   for (int o = 1; o < VPR; o <<= 1) part += __shfl_xor(part, o, 64);  // VPR = 8 / 16 / 32 lanes of one query: a fixed tree (deterministic)
-  if (cv == 0 && q < ld_stride) ld[(long long)bh * ld_stride + q] = q < p.Lq ? make_float2(lse[(long long)bh * p.Lq + q], part) : make_float2(INFINITY, 0.f);
+  if (cv == 0 && q < ld_stride) {
+    float l = INFINITY;
+    if (q < p.Lq) {
+      if (lse) l = lse[(long long)bh * p.Lq + q];
+      else {
+        float M = -INFINITY, tot = 0.f;
+        for (int z = 0; z < nslices; ++z) M = fmaxf(M, ms[((long long)z * gridDim.y + bh) * p.Lq + q].x);
+        for (int z = 0; z < nslices; ++z) {
+          const float2 t = ms[((long long)z * gridDim.y + bh) * p.Lq + q];
+          tot += t.x > -INFINITY ? t.y * __expf(t.x - M) : 0.f;
+        }
+        l = M + __logf(tot);
+      }
+    }
+    ld[(long long)bh * ld_stride + q] = q < p.Lq ? make_float2(l, part) : make_float2(INFINITY, 0.f);
+  }
+}
+
+// out[row][c] (bf16) = sum over the slices, slice order, of part[slice][o][bh][row][c] (fp32): one thread per (row, 4 channels)
+template <int DH>
+__global__ __launch_bounds__(256) void abd_combine_kernel(const float* __restrict__ part, int nslices, int nout, int o, int H, int L, bf16_raw* __restrict__ dst,
+                                                          long long dst_ld) {
+  constexpr int VPR = DH / 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const long long it = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int row = (int)(it / VPR), cv = (int)(it % VPR);
+  if (row >= L) return;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < nslices; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(part + ((((long long)z * nout + o) * gridDim.y + bh) * L + row) * DH + cv * 4);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  }
+  *reinterpret_cast<uint2*>(dst + ((long long)b * L + row) * dst_ld + h * DH + cv * 4) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
 }
 
 template <int DH, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, const bf16_raw* __restrict__ t1, const bf16_raw* __restrict__ t2, int t_ld,
-                                                         const float2* __restrict__ ld, int ld_stride, float* __restrict__ lse_out) {
+                                                         const float2* __restrict__ ld, int ld_stride, float* __restrict__ part) {
   constexpr int TR = DH == 256 ? 32 : 64;         // streamed rows per tile
   constexpr int KF = TR / 16;                     // 16-row fragments per tile
   constexpr int S2N = TR / 32;                    // 32-position blocks per tile (one MFMA k-step of the row contractions each)
@@ -147,15 +181,20 @@ __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, 
   }
   float m_run = -INFINITY, l_run = 0.f;  // LSE mode
 
-  const int ntiles = (Lst + TR - 1) / TR;
-  issue_tile(0, 0);
+  // gridDim.z > 1: work-group z sweeps the z-th slice of the streamed tiles and leaves fp32 partial results in `part` (one head of 4 096 tokens
+  // is only 32 work-groups of 128 own rows); abd_combine_kernel / abd_prep_kernel add the slices in slice order (deterministic)
+  const int ntiles_all = (Lst + TR - 1) / TR;
+  const int tps = (ntiles_all + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int tile0 = (int)blockIdx.z * tps;
+  const int ntiles = min(ntiles_all, tile0 + tps);  // this slice: tiles [tile0, ntiles) (possibly empty)
+  if (tile0 < ntiles) issue_tile(tile0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  for (int tile = 0; tile < ntiles; ++tile) {
+  for (int tile = tile0; tile < ntiles; ++tile) {
     const int r0 = tile * TR;
-    const char* buf = smem + (size_t)(tile & 1) * BUF_BYTES;
-    if (tile + 1 < ntiles) issue_tile(tile + 1, (tile + 1) & 1);  // its buffer was last read two barriers ago
+    const char* buf = smem + (size_t)((tile - tile0) & 1) * BUF_BYTES;
+    if (tile + 1 < ntiles) issue_tile(tile + 1, (tile + 1 - tile0) & 1);  // its buffer was last read two barriers ago
 
     // ---- stage 1: acc1 = N1 X1^T (scores), acc2 = N2 X2^T (dP): D[streamed row 16 kf + 4 qg + r][own row l15] -------------------------
     f32x4_t acc1[KF], acc2[NNAT == 2 ? KF : 1];
@@ -275,10 +314,20 @@ __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, 
     float st = m_run > -INFINITY ? l_run * __expf(m_run - M) : 0.f;
     st += __shfl_xor(st, 16, 64);
     st += __shfl_xor(st, 32, 64);
-    if (qg == 0 && own_ok) lse_out[(long long)bh * p.Lq + own] = M + __logf(st);
+    if (qg == 0 && own_ok)  // (max, sum) of this slice: [slice][bh][q]
+      reinterpret_cast<float2*>(part)[((long long)blockIdx.z * gridDim.y + bh) * p.Lq + own] = make_float2(M, st);
     return;
   }
   if (!own_ok) return;
+  if (part) {  // [slice][output][bh][own row][DH] fp32
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      float* prow = part + ((((long long)blockIdx.z * NOUT + o) * gridDim.y + bh) * Lown + own) * DH;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) *reinterpret_cast<float4*>(prow + d * 16 + qg * 4) = make_float4(out[o][d][0], out[o][d][1], out[o][d][2], out[o][d][3]);
+    }
+    return;
+  }
   // ---- store: out[o][d][r] = channel 16 d + 4 qg + r of this lane's own row (DQ: dq; DKV: 0 -> dk, 1 -> dv) ------------------------------
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
@@ -304,11 +353,29 @@ static bool abd_eligible(const GmAttnBwdDesc& d) {
          ok(d.dv, d.dv_ld);
 }
 
-// workspace: Q^T | dO^T | K^T images, the (LSE, D) pairs (padded by 128 per (sample, head)), an LSE array for callers without one
+// slices of the streamed tiles: until every CU has a work-group, at least 4 tiles per slice (as attention_dma.hip's key slices)
+static int abd_force_split = 0;  // 0 = by problem size (tests / benchmarks force a count)
+extern "C" void gm_attention_backward_fused_set_split(int nsplit) { abd_force_split = (nsplit >= 1 && nsplit <= 16) ? nsplit : 0; }
+static int abd_split(const GmAttnBwdDesc& d, int Lown, int Lst) {
+  if (abd_force_split) return abd_force_split;
+  const long long wgs = (long long)d.B * d.H * ((Lown + 127) / 128), tiles = (Lst + (d.dh == 256 ? 31 : 63)) / (d.dh == 256 ? 32 : 64);
+  int sp = 1;
+  while (wgs * sp < 256 && sp < 16 && tiles / (2 * sp) >= 4) sp *= 2;
+  return sp;
+}
+
+// workspace: Q^T | dO^T | K^T images, the (LSE, D) pairs (padded by 128 per (sample, head)), the LSE sweep's (max, sum) pairs for callers
+// without an LSE, the fp32 partial results of a sliced sweep
+static long long abd_part_bytes(const GmAttnBwdDesc& d) {
+  const long long bh = (long long)d.B * d.H;
+  const int skv = abd_split(d, d.Lk, d.Lq), sq = abd_split(d, d.Lq, d.Lk);
+  const long long a = skv > 1 ? (long long)skv * 2 * bh * d.Lk * d.dh * 4 : 0, b = sq > 1 ? (long long)sq * bh * d.Lq * d.dh * 4 : 0;
+  return a > b ? a : b;
+}
 extern "C" long long gm_attention_backward_fused_workspace_bytes(const GmAttnBwdDesc* d) {
   if (!d || !abd_eligible(*d)) return 0;
   const long long bh = (long long)d->B * d->H, lqp = abd_pad64(d->Lq), lkp = abd_pad64(d->Lk);
-  return 2 * abd_al(bh * d->dh * lqp * 2) + abd_al(bh * d->dh * lkp * 2) + abd_al(bh * (lqp + 128) * 8) + abd_al(bh * d->Lq * 4);
+  return 2 * abd_al(bh * d->dh * lqp * 2) + abd_al(bh * d->dh * lkp * 2) + abd_al(bh * (lqp + 128) * 8) + abd_al(16 * bh * d->Lq * 8) + abd_al(abd_part_bytes(*d));
 }
 
 template <int DH>
@@ -330,7 +397,8 @@ static void abd_launch(const GmAttnBwdDesc& d, const float* lse, hipStream_t st)
   bf16_raw* got = reinterpret_cast<bf16_raw*>(w);  w += abd_al(bh * DH * lqp * 2);
   bf16_raw* kt = reinterpret_cast<bf16_raw*>(w);   w += abd_al(bh * DH * lkp * 2);
   float2* ld = reinterpret_cast<float2*>(w);       w += abd_al(bh * (lqp + 128) * 8);
-  float* own_lse = reinterpret_cast<float*>(w);
+  float2* ms = reinterpret_cast<float2*>(w);       w += abd_al(16 * bh * d.Lq * 8);
+  float* part = reinterpret_cast<float*>(w);
   const int ld_stride = (int)lqp + 128;
   const bf16_raw* Q = reinterpret_cast<const bf16_raw*>(d.q);
   const bf16_raw* K = reinterpret_cast<const bf16_raw*>(d.k);
@@ -338,15 +406,22 @@ static void abd_launch(const GmAttnBwdDesc& d, const float* lse, hipStream_t st)
   gm_attn_pack_transposed(Q, d.q_ld, qt, d.B, d.H, d.Lq, (int)lqp, DH, st);
   gm_attn_pack_transposed(G, d.go_ld, got, d.B, d.H, d.Lq, (int)lqp, DH, st);
   gm_attn_pack_transposed(K, d.k_ld, kt, d.B, d.H, d.Lk, (int)lkp, DH, st);
-  const dim3 gq((d.Lq + NW * 16 - 1) / (NW * 16), (unsigned)bh), gk((d.Lk + NW * 16 - 1) / (NW * 16), (unsigned)bh);
-  if (!lse) {
-    abd_kernel<DH, ABD_LSE, NW><<<gq, 64 * NW, lds_lse, st>>>(d, nullptr, nullptr, 0, nullptr, 0, own_lse);
-    lse = own_lse;
-  }
+  const int skv = abd_split(d, d.Lk, d.Lq), sq = abd_split(d, d.Lq, d.Lk);
+  const unsigned wq = (d.Lq + NW * 16 - 1) / (NW * 16), wk = (d.Lk + NW * 16 - 1) / (NW * 16);
+  if (!lse) abd_kernel<DH, ABD_LSE, NW><<<dim3(wq, (unsigned)bh, sq), 64 * NW, lds_lse, st>>>(d, nullptr, nullptr, 0, nullptr, 0, reinterpret_cast<float*>(ms));
   constexpr int QPB = 256 * 8 / DH;
-  abd_prep_kernel<DH><<<dim3((ld_stride + QPB - 1) / QPB, (unsigned)bh), 256, 0, st>>>(d, lse, ld, ld_stride);
-  abd_kernel<DH, ABD_DKV, NW><<<gk, 64 * NW, lds_dkv, st>>>(d, qt, got, (int)lqp, ld, ld_stride, nullptr);
-  abd_kernel<DH, ABD_DQ, NW><<<gq, 64 * NW, lds_dq, st>>>(d, kt, nullptr, (int)lkp, ld, ld_stride, nullptr);
+  abd_prep_kernel<DH><<<dim3((ld_stride + QPB - 1) / QPB, (unsigned)bh), 256, 0, st>>>(d, lse, ms, sq, ld, ld_stride);
+  abd_kernel<DH, ABD_DKV, NW><<<dim3(wk, (unsigned)bh, skv), 64 * NW, lds_dkv, st>>>(d, qt, got, (int)lqp, ld, ld_stride, skv > 1 ? part : nullptr);
+  if (skv > 1) {
+    const dim3 cg((unsigned)(((long long)d.Lk * (DH / 4) + 255) / 256), (unsigned)bh);
+    abd_combine_kernel<DH><<<cg, 256, 0, st>>>(part, skv, 2, 0, d.H, d.Lk, reinterpret_cast<bf16_raw*>(d.dk), d.dk_ld);
+    abd_combine_kernel<DH><<<cg, 256, 0, st>>>(part, skv, 2, 1, d.H, d.Lk, reinterpret_cast<bf16_raw*>(d.dv), d.dv_ld);
+  }
+  abd_kernel<DH, ABD_DQ, NW><<<dim3(wq, (unsigned)bh, sq), 64 * NW, lds_dq, st>>>(d, kt, nullptr, (int)lkp, ld, ld_stride, sq > 1 ? part : nullptr);
+  if (sq > 1) {
+    const dim3 cg((unsigned)(((long long)d.Lq * (DH / 4) + 255) / 256), (unsigned)bh);
+    abd_combine_kernel<DH><<<cg, 256, 0, st>>>(part, sq, 1, 0, d.H, d.Lq, reinterpret_cast<bf16_raw*>(d.dq), d.dq_ld);
+  }
 }
 
 // dq, dk, dv (bf16, written once; no accumulation into the destinations) of o = softmax(scale q k^T) v.  `lse` = log sum_k exp(scale q.k) per

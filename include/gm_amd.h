@@ -406,6 +406,8 @@ int gm_attention_bwd_scores(const GmAttnBwdDesc* d, void* probs, void* dscores, 
  * gm_attention_backward_fused_workspace_bytes is 0 for operands this path does not take. */
 long long gm_attention_backward_fused_workspace_bytes(const GmAttnBwdDesc* d);
 int gm_attention_backward_fused(const GmAttnBwdDesc* d, const float* lse, void* stream);
+/* slices of the streamed rows per sweep (fp32 partial results added in slice order): 0 = by problem size (until every CU has a work-group), 1..16 forced */
+void gm_attention_backward_fused_set_split(int nsplit);
 /* dscores = scale * probs * (dprobs - rowsum(dprobs * probs)): softmax backward of the attention scores scale * Q K^T, fp32 [rows][V]
  * (the softmax of diffusion_model_unet.py:143-153 / 407-415 under torch autograd) */
 int gm_softmax_bwd(const float* probs, const float* dprobs, float* dscores, long long rows, int V, float scale, void* stream);

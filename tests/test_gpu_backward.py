@@ -1163,6 +1163,15 @@ def test_attention_backward_fused_bf16_lds_dma_kernels(b, lq, lk, heads, dh):
     again = ops.attention_backward_fused(qd, kd, vd, o, gd, heads, scale)
     for a, b_ in zip(own, again):
         assert torch.equal(a, b_)
+    from generativemodels_amd import _native
+    try:  # the streamed rows in 3 slices (fp32 partial results added in slice order; an empty slice when there are fewer tiles), and unsliced
+        for nsplit in (3, 1):
+            _native.lib().gm_attention_backward_fused_set_split(nsplit)
+            sliced = ops.attention_backward_fused(qd, kd, vd, o, gd, heads, scale)
+            for name, a, r in zip("qkv", sliced, ref):
+                _close(a, r.grad, 1.5e-2, f"fused bf16 attention backward d{name} ({nsplit} slices)")
+    finally:
+        _native.lib().gm_attention_backward_fused_set_split(0)
     with pytest.raises(ValueError):
         ops.attention_backward_fused(qd.float(), kd.float(), vd.float(), o.float(), gd.float(), heads, scale)
 
