@@ -59,7 +59,7 @@ class GmAttnDesc(C.Structure):
                 ("res", c_vp), ("res_ld", c_ll), ("o", c_vp), ("o_ld", c_ll),
                 ("B", C.c_int), ("H", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int), ("dh", C.c_int),
                 ("scale", C.c_float), ("dtype", C.c_int), ("workspace", c_vp), ("workspace_bytes", c_ll),
-                ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll), ("stats", c_vp), ("vt_packed", C.c_int)]
+                ("causal", C.c_int), ("k_bs", c_ll), ("v_bs", c_ll), ("stats", c_vp), ("vt_packed", C.c_int), ("lse", c_vp)]
 
 
 class GmAttnBwdDesc(C.Structure):

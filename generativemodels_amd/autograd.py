@@ -406,20 +406,37 @@ ATTENTION_BWD_MAX_TOKENS = 8192
 ATTENTION_BWD_BF16_MIN_TOKENS = int(__import__("os").environ.get("GM_ATTN_BWD_BF16_MIN_TOKENS", "512"))  # (bench switch: a huge value disables the path)
 
 
+# (round 5) bf16 operands, head dim 64 / 128 / 256: the fused LDS-DMA flash backward (ops.attention_backward_fused) from this many tokens on.
+# Measured on MI355X (tools/attn_bwd_fused_ab.py, profiles/r05_attn_bwd_fused_ab.txt): 32 768 x 256 3.97 ms against 17-20 composed, 4 096 x 256 0.14
+# against 0.33, 2 x 8 heads x 256 x 64 0.048 against 0.092 (profiles/r05_attn_bwd_fused_policy.txt: every measured shape from 256 tokens on).  (bench switch: a huge value restores the round-4 policy)
+ATTENTION_BWD_FUSED_MIN_TOKENS = int(__import__("os").environ.get("GM_ATTN_BWD_FUSED_MIN_TOKENS", "256"))
+
+
+def _fused_backward_serves(q, k, heads):
+    dh = q.shape[2] // heads
+    return (q.dtype == torch.bfloat16 and dh in ops.ATTENTION_BWD_FUSED_HEAD_DIMS and q.shape[2] == heads * dh
+            and max(q.shape[1], k.shape[1]) >= ATTENTION_BWD_FUSED_MIN_TOKENS)
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, heads, scale):
-        o = ops.attention(q, k, v, heads, scale)
-        ctx.save_for_backward(q, k, v, o)
+        lse = None
+        if _fused_backward_serves(q, k, heads) and ops.attention_writes_lse(q, k, v, heads):
+            lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device)  # the forward kernel's log-sum-exp: one sweep less in backward
+        o = ops.attention(q, k, v, heads, scale, lse_out=lse)
+        ctx.save_for_backward(q, k, v, o, *(() if lse is None else (lse,)))
         ctx.cfg = (heads, scale)
         return o
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, o = ctx.saved_tensors
+        q, k, v, o, *rest = ctx.saved_tensors
         heads, scale = ctx.cfg
         dh = q.shape[2] // heads
         go = go.contiguous()
+        if _fused_backward_serves(q, k, heads):
+            return (*ops.attention_backward_fused(q, k, v, o, go, heads, scale, lse=rest[0] if rest else None), None, None)
         if dh in ops.ATTENTION_BWD_HEAD_DIMS:
             return (*_attention_backward(q, k, v, o, go, heads, scale), None, None)
         # any other head dim (<= 256: the forward's bound): zero-pad every head to the next width the kernels are built for.  Zero channels add

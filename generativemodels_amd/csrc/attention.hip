@@ -280,9 +280,10 @@ extern "C" int gm_attention_forward(const GmAttnDesc* dp, void* stream) {
   GM_REQUIRE((long long)d.B * d.H <= 65535, "too many (batch, head) pairs for one launch");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (gm_attention_decode_try(dp, stream)) GM_LAUNCH_CHECK();  // one query per (batch, head): the KV-cache decode kernel (small_ops.hip)
+  if (!d.lse && gm_attention_decode_try(dp, stream)) GM_LAUNCH_CHECK();  // one query per (batch, head): the KV-cache decode kernel (small_ops.hip)
   if (gm_attention_dma_try(dp, stream)) GM_LAUNCH_CHECK();  // bf16, d in {64,128,256}, workspace given: LDS-DMA kernel
   GM_REQUIRE(d.stats == nullptr, "GmAttnDesc.stats is written by the split-KV LDS-DMA path only (see gm_attention_stats_slots)");
+  GM_REQUIRE(d.lse == nullptr, "GmAttnDesc.lse is written by the LDS-DMA path only (a workspace of gm_attention_workspace_bytes() > 0 bytes)");
   GM_REQUIRE(!d.vt_packed, "GmAttnDesc.vt_packed needs the LDS-DMA path (a workspace of gm_attention_workspace_bytes() bytes)");
   int rc;
   if (d.dtype == GM_F32) rc = dispatch_attn<float>(d, st);

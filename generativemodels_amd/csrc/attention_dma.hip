@@ -273,6 +273,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
     l_tot += __shfl_xor(l_tot, 32, 64);
     const float inv = 1.0f / l_tot;
     if (!q_ok[f]) continue;
+    if (p.lse && !part && qg == 0) p.lse[(long long)bh * p.Lq + my_q[f]] = m_run[f] + __logf(l_tot);
     if (part) {  // [slice][b*H + h][query][DH + 2]: O (fp32, relative to the slice maximum), maximum, sum
       float* prow = part + (((long long)blockIdx.z * gridDim.y + bh) * p.Lq + my_q[f]) * (DH + 4);
 #pragma unroll
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, c
       o[4] += w * b2.x; o[5] += w * b2.y; o[6] += w * b2.z; o[7] += w * b2.w;
     }
     const float inv = 1.0f / L;
+    if (p.lse && c == 0) p.lse[qi] = M + __logf(L);
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] *= inv;
     if (p.res) {

@@ -20,6 +20,8 @@ struct GmAttnDesc {
   long long k_bs, v_bs;        // batch strides of k / v in elements; 0 = dense (Lk * ld).  A KV cache is [B][max_len][C] read up to Lk.
   double* stats;               // optional [gm_attention_stats_slots][B][H * dh][2] per-channel (sum, sum of squares) partials of the stored output
   int vt_packed;               // 1: the workspace already holds the transposed V image (written by gm_linear_rows_affine_vt): no pack launch
+  float* lse;                  // optional [B*H][Lq] fp32: log sum_k exp(scale q.k), written by the LDS-DMA path only (the training forward keeps it for
+                               // gm_attention_backward_fused)
 };
 
 // Attention backward descriptor (attention_bwd.hip: fp32-MFMA fused kernels and the bf16 score pass; attention_bwd_dma.hip: fused bf16 LDS-DMA kernels)

@@ -1783,7 +1783,7 @@ def _kv_ld(t: torch.Tensor) -> int:
     return t.stride(1) if t.shape[1] > 1 else max(t.stride(1), t.shape[2])
 
 
-def attention_workspace(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> Optional[torch.Tensor]:
+def attention_workspace(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, bytes_only: bool = False):
     """The scratch the LDS-DMA attention kernel wants for these operands (its transposed V image comes first), or None when another kernel
     serves the geometry.  An attention block allocates it BEFORE its q | k | v projection so that the projection can store the V image itself
     (conv(..., vt=(workspace, first V channel, head dim))) and passes it on: attention(..., workspace=ws, vt_packed=True)."""
@@ -1796,15 +1796,23 @@ def attention_workspace(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads
     if b > 1 and (k.stride(0) != k.shape[1] * _kv_ld(k) or v.stride(0) != v.shape[1] * _kv_ld(v)):
         return None
     nbytes = lib().gm_attention_workspace_bytes(C.byref(d))
+    if bytes_only:
+        return int(nbytes)
     return torch.empty(nbytes, dtype=torch.uint8, device=q.device) if nbytes > 0 else None
+
+
+def attention_writes_lse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> bool:
+    """Whether attention(q, k, v, heads, ..., lse_out=...) is served (the LDS-DMA kernel takes these operands)."""
+    return bool(attention_workspace(q, k, v, heads, bytes_only=True))
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
               res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, causal: bool = False,
-              workspace: Optional[torch.Tensor] = None, vt_packed: bool = False) -> torch.Tensor:
+              workspace: Optional[torch.Tensor] = None, vt_packed: bool = False, lse_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(scale * Q K^T) V per (batch, head). q: (B, Lq, heads*dh) arena views (channel slices allowed), k/v: (B, Lk, ...);
     k / v may be the first Lk rows of a longer per-sample buffer (a KV cache). causal: query i sees keys j <= i + (Lk - Lq).
-    workspace / vt_packed: see attention_workspace."""
+    workspace / vt_packed: see attention_workspace.  lse_out: fp32 (B, heads, Lq) tensor that receives log sum_k exp(scale q.k) -- only for
+    geometries the LDS-DMA kernel serves (attention_workspace(...) is not None); the training forward keeps it for attention_backward_fused."""
     require_device(q, k, v, res, out)
     b, lq, c = q.shape
     lk = k.shape[1]
@@ -1851,6 +1859,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
     elif vt_packed:
         raise ValueError("vt_packed: this geometry is not served by the LDS-DMA attention kernel")
+    d.lse = None
+    if lse_out is not None:
+        require_device(lse_out)
+        if ws_bytes <= 0:
+            raise ValueError("lse_out: this geometry is not served by the LDS-DMA attention kernel")
+        if lse_out.dtype != torch.float32 or lse_out.numel() != b * heads * lq or not lse_out.is_contiguous():
+            raise ValueError("lse_out must be a contiguous fp32 (B, heads, Lq) tensor")
+        d.lse = lse_out.data_ptr()
     # the split-KV merge kernel can store per-channel (sum, sum of squares) partials of the output it writes: the GroupNorm of the block that
     # follows an attention block then needs no statistics pass (channel_stats() finds them on the tensor, like a convolution's)
     d.stats = None

@@ -254,6 +254,8 @@ typedef struct GmAttnDesc {
   int vt_packed;              /* 1: `workspace` already holds the transposed, key-permuted V image of the LDS-DMA kernel -- the stacked q | k | v projection
                                * wrote it (gm_linear_rows_affine_vt; Lk a multiple of 64): the pack launch is skipped.  Only with a workspace of
                                * gm_attention_workspace_bytes() > 0 bytes */
+  float* lse;                 /* optional fp32 [B*H][Lq]: log sum_k exp(scale q.k) per query, written by the LDS-DMA path only (must be NULL otherwise);
+                               * the training forward keeps it for gm_attention_backward_fused */
 } GmAttnDesc;
 int gm_attention_max_head_dim(void);
 /* bytes of scratch the fastest kernel for this geometry wants (0: none; the descriptor's workspace fields are not read) */

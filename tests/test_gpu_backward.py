@@ -1085,7 +1085,7 @@ def test_attention_backward_bf16_mfma_path(b, lq, lk, heads, dh):
     dq, dk, dv = ops.attention_backward_bf16(qd, kd, vd, o, gd, heads, scale)
     for name, got, r in zip("qkv", (dq, dk, dv), ref):
         _close(got, r.grad, 1.5e-2, f"bf16-MFMA attention backward d{name}")
-    if b * heads <= 2 and max(lq, lk) >= A.ATTENTION_BWD_BF16_MIN_TOKENS:  # the policy takes this path: same bits through autograd
+    if b * heads <= 2 and max(lq, lk) >= A.ATTENTION_BWD_BF16_MIN_TOKENS and not A._fused_backward_serves(qd, kd, heads):  # the policy takes this path: same bits through autograd
         dev = [t.clone().requires_grad_(True) for t in (qd, kd, vd)]
         A.attention(*dev, heads, scale).backward(gd)
         for got, want in zip(dev, (dq, dk, dv)):
@@ -1163,6 +1163,12 @@ def test_attention_backward_fused_bf16_lds_dma_kernels(b, lq, lk, heads, dh):
     again = ops.attention_backward_fused(qd, kd, vd, o, gd, heads, scale)
     for a, b_ in zip(own, again):
         assert torch.equal(a, b_)
+    from generativemodels_amd import autograd as A
+    if A._fused_backward_serves(qd, kd, heads):  # the policy takes this path, with the forward kernel's LSE when the LDS-DMA forward ran
+        dev = [t.clone().requires_grad_(True) for t in (qd, kd, vd)]
+        A.attention(*dev, heads, scale).backward(gd)
+        for name, got, r in zip("qkv", dev, ref):
+            _close(got.grad, r.grad, 1.5e-2, f"autograd through the fused backward d{name}")
     from generativemodels_amd import _native
     try:  # the streamed rows in 3 slices (fp32 partial results added in slice order; an empty slice when there are fewer tiles), and unsliced
         for nsplit in (3, 1):
