@@ -14,6 +14,12 @@
 //   * 8 waves x 16 queries per work-group share each tile (halves the L2 -> LDS traffic of the 4-wave kernel).
 #include "attn_common.h"
 
+// bench-only build (-DGM_ATTN_ABLATE=mask, tools/attn_ablate.hip): parts of the tile loop removed to price them (results are then wrong):
+// 1 no max / exp / shuffles, 2 no DMA after the first two tiles, 4 no per-tile wait + barrier (with 2), 8 no K fragment reads, 16 no V^T
+// fragment reads, 32 no O rescale.  The product library never defines it.
+#ifndef GM_ATTN_ABLATE
+#define GM_ATTN_ABLATE 0
+#endif
 #ifndef GM_ATTN_PD
 #define GM_ATTN_PD 8  // operand fragments in flight ahead of the MFMAs (256-register kernels); bench-only builds override it
 #endif
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
   for (int tile = tile0; tile < ntiles; ++tile) {
     const int key0 = tile * KT;
     const char* buf = smem + (size_t)((tile - tile0) & 1) * (KBYTES + VBYTES);
-    if (tile + 1 < ntiles) issue_tile(tile + 1, (tile + 1 - tile0) & 1);  // its buffer was last read two barriers ago
+    if (tile + 1 < ntiles && !((GM_ATTN_ABLATE & 2) && tile > tile0)) issue_tile(tile + 1, (tile + 1 - tile0) & 1);  // its buffer was last read two barriers ago
 
     // The 64-key tile is consumed in NH slices of KFH key fragments (QF = 2: two 32-key slices, so that the score / probability
     // registers of 32 queries stay at 24 per lane -- the kernel sits at the 256-register limit of two waves per SIMD); each slice is
@@ -183,9 +189,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
           for (int f = 0; f < QF; ++f)
             sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kq[i % PD]), __builtin_bit_cast(bf16x8_t, qf[f][s]),
                                                                   sacc[f][kf], 0, 0, 0);
-          if (i + PD < NKQ) kq[i % PD] = kread(i + PD);
+          if (i + PD < NKQ && !(GM_ATTN_ABLATE & 8)) kq[i % PD] = kread(i + PD);
           __builtin_amdgcn_sched_group_barrier(0x008, QF, 0);
-          if (i + PD < NKQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i + PD < NKQ && !(GM_ATTN_ABLATE & 8)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }
       // ---- online softmax: this lane's queries, keys key0 + (hf * KFH + kf) * 16 + qg * 4 + r ----------------------------------
@@ -204,9 +210,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
             sacc[f][kf][r] = sv;
             tmax = fmaxf(tmax, sv);
           }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run[f], tmax);
+        if (!(GM_ATTN_ABLATE & 1)) {
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        }
+        const float m_new = (GM_ATTN_ABLATE & 1) ? 0.f : fmaxf(m_run[f], tmax);
         alpha[f] = __expf(m_run[f] - m_new);
         moved |= m_new != m_run[f];
         float psum = 0.f;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
         for (int kf = 0; kf < KFH; ++kf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = __expf(sacc[f][kf][r] - m_new);
+            const float pv = (GM_ATTN_ABLATE & 1) ? sacc[f][kf][r] : __expf(sacc[f][kf][r] - m_new);
             sacc[f][kf][r] = pv;
             psum += pv;
           }
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
       }
       // rescale O only when some lane's running maximum moved (alpha == 1 exactly otherwise: skipping the multiply changes nothing);
       // after the first tiles that is rare, and the 16 x QF x 4 multiplies per step are the largest VALU block of the loop
-      if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+      if (!(GM_ATTN_ABLATE & 32) && __builtin_amdgcn_ballot_w64(moved) != 0) {
 #pragma unroll
         for (int f = 0; f < QF; ++f)
 #pragma unroll
@@ -255,15 +263,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
           for (int f = 0; f < QF; ++f)
             oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vq[i % PD]), __builtin_bit_cast(bf16x8_t, pf[f][s]),
                                                                  oacc[f][d], 0, 0, 0);
-          if (i + PD < NVQ) vq[i % PD] = vread(i + PD);
+          if (i + PD < NVQ && !(GM_ATTN_ABLATE & 16)) vq[i % PD] = vread(i + PD);
           __builtin_amdgcn_sched_group_barrier(0x008, QF, 0);
-          if (i + PD < NVQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i + PD < NVQ && !(GM_ATTN_ABLATE & 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }
     }
     // the next tile has landed (this wave's pieces) and this wave is done reading the current one
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(GM_ATTN_ABLATE & 4)) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
 
   // ---- finish: 1/l, residual, store (or, split-KV: the slice's un-normalised state for attn_combine_kernel) -----------------------

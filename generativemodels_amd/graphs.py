@@ -33,16 +33,22 @@ class GraphedForwardBackward:
     fn:      callable of device tensors returning a scalar loss (run under whatever autocast context it enters itself).
     example_inputs: tensors of the shapes / dtypes / device every later call uses (their values are used by the warm-up steps).
     params:  the parameters whose `.grad` the step produces (e.g. `model.parameters()`); the graph owns their gradient tensors.
-    reducer: optional `parallel.GradientReducer` (data-parallel training).  The captured backward runs under `reducer.no_sync()` with the
-             gradients accumulated straight into the reducer's bucket views and the bucket fills inside the graph; call `reducer.finish()`
-             after each step as usual -- the exchange then starts after the replay instead of overlapping the backward (a ring all-reduce of
-             the 167 MB of C4 gradients is ~2 ms over xGMI, an eager backward costs 13 ms more than the replayed one).
+    reducer: optional `parallel.GradientReducer` (data-parallel training).  The gradients are accumulated straight into the reducer's bucket
+             views and the bucket fills run inside the graph.  With `GradientReducer(static_graph=True)` on an RCCL group (round 5) the EXCHANGE
+             is captured too: once the warm-up steps have recorded the arrival order, the captured backward runs with the reducer's one hook
+             per bucket, each bucket's all-reduce is launched on the reducer's side stream from the hook of its last gradient (a fork of the
+             capture: event -> side stream -> RCCL kernel), and `finish()`'s waits, join and division are the graph's last nodes -- the
+             replayed step overlaps its exchange with the rest of the backward like the eager step does (`exchange_captured` is True; the
+             `reducer.finish()` a training loop calls after the step returns at once).  Otherwise the captured backward runs under
+             `reducer.no_sync()` and `reducer.finish()` after each step starts the exchange after the replay (a ring all-reduce of the 167 MB
+             of C4 gradients is ~2 ms over xGMI, an eager backward costs 13 ms more than the replayed one).
+    capture_exchange: None = whenever the reducer allows it (above), False = never.
     warmup:  eager steps run before the capture (weight packing, kernel attribute set-up, allocator sizing, the reducer's first-step discovery
              of unused parameters).  They accumulate nothing: gradients are cleared before the capture.
     """
 
     def __init__(self, fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor], params: Iterable[torch.nn.Parameter],
-                 reducer=None, warmup: int = 2) -> None:
+                 reducer=None, warmup: int = 2, capture_exchange: Optional[bool] = None) -> None:
         self.fn = fn
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
@@ -52,6 +58,8 @@ class GraphedForwardBackward:
             raise ValueError("GraphedForwardBackward: the inputs must live on the GPU (the step is replayed from device memory)")
         self.reducer = reducer if (reducer is not None and getattr(reducer, "active", False)) else None
         red = self.reducer
+        if capture_exchange and not (red is not None and getattr(red, "static_graph", False)):
+            raise ValueError("GraphedForwardBackward(capture_exchange=True) needs an active GradientReducer(static_graph=True)")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -64,7 +72,15 @@ class GraphedForwardBackward:
         torch.cuda.synchronize()
         self._clear()
         self.graph = torch.cuda.CUDAGraph()
-        sync_off = red.no_sync() if red is not None else contextlib.nullcontext()
+        # the exchange inside the graph: only with the recorded bucket order (stage 2: finish() then has no host synchronisation -- no usage-mask
+        # exchange, no first-gradient admissions) and a backend whose collectives are stream work (RCCL)
+        can = (red is not None and getattr(red, "static_graph", False) and getattr(red, "_static_stage", 0) == 2
+               and str(red._dist.get_backend(red.group)) == "nccl")
+        if capture_exchange and not can:
+            raise ValueError("GraphedForwardBackward(capture_exchange=True) needs GradientReducer(static_graph=True) on an RCCL (\"nccl\") group whose "
+                             "warm-up steps recorded the gradient arrival order (warmup >= 2)")
+        self.exchange_captured = bool(can and capture_exchange is not False)
+        sync_off = red.no_sync() if (red is not None and not self.exchange_captured) else contextlib.nullcontext()
         # thread-local capture mode: HIP calls of other host threads (DataLoader pin-memory, the RCCL watchdog) do not invalidate the capture;
         # the autograd engine issues this backward's kernels on the capturing stream
         from . import ops
@@ -75,6 +91,8 @@ class GraphedForwardBackward:
             with sync_off:
                 self.loss = fn(*self.inputs)
                 self.loss.backward()
+            if self.exchange_captured:
+                red.finish()  # remaining launches, the waits, the join of the side stream, the division: stream work only in stage 2
         # the gradient tensors the captured step writes: graph-pool allocations (or the reducer's bucket views); re-attached after every replay,
         # so an optimizer.zero_grad(set_to_none=True) between steps is harmless
         self.grads = [p.grad for p in self.params]
@@ -98,4 +116,6 @@ class GraphedForwardBackward:
         self.graph.replay()
         for p, g in zip(self.params, self.grads):
             p.grad = g
+        if self.exchange_captured:
+            self.reducer._exchanged_in_graph = True  # the loop's reducer.finish() after this step has nothing left to do
         return self.loss

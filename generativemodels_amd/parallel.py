@@ -176,6 +176,7 @@ class GradientReducer:
         self.usage_check_every = int(usage_check_every)
         self.static_graph = bool(static_graph)
         self._static_stage = 0   # 0: learning the used set; 1: recording the arrival order (full hooks); 2: one hook per bucket
+        self._exchanged_in_graph = False  # set by a replayed step that carries its exchange (graphs.GraphedForwardBackward.exchange_captured)
         self._arrival: List[List[int]] = []
         self._step = 0
 
@@ -419,6 +420,9 @@ class GradientReducer:
         """Launch the buckets that did not complete during backward, wait for every exchange, average, and leave the averaged gradient in
         `.grad` of every parameter that is used on any rank."""
         if not self.active:
+            return
+        if self._exchanged_in_graph:  # the step was a replay of graphs.GraphedForwardBackward with the exchange captured: averaged gradients are in place
+            self._exchanged_in_graph = False
             return
         if not self._sync:
             raise RuntimeError("GradientReducer.finish() inside no_sync()")

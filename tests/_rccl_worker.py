@@ -102,6 +102,37 @@ def main():
                 continue
             assert torch.equal(a.grad, b.grad), f"graphed step {step}: gradient of {name} differs"
             assert b.grad.data_ptr() == red2._view[id(b)].data_ptr()
+    # ---- (round 5) the replayed step CARRIES its exchange: GradientReducer(static_graph=True) records the arrival order in the warm-up steps, the
+    #      capture then contains one RCCL all-reduce per bucket on the reducer's side stream, forked from the hook of the bucket's last gradient and
+    #      joined by finish()'s waits inside the graph; the loop's finish() after a replay returns at once ----
+    replica3 = build()
+    red4 = GradientReducer(replica3.parameters(), bucket_mb=0.25, force=True, static_graph=True)
+    graphed3 = gm.GraphedForwardBackward(loss_fn(replica3), (x0, n0, t0), replica3.parameters(), reducer=red4)
+    assert graphed3.exchange_captured and red4._static_stage == 2 and len(red4.buckets) >= 3
+    for step in range(3):
+        x = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+        noise = torch.randn((2, 1, 8, 8, 8), generator=g).to(dev)
+        t = torch.randint(0, 1000, (2,), generator=g).to(dev)
+        for p_ in plain.parameters():
+            p_.grad = None
+        want = loss_fn(plain)(x, noise, t)
+        want.backward()
+        got = graphed3(x, noise, t)
+        red4.finish()  # nothing left to do: the exchange ran inside the graph
+        assert red4._work == [None] * len(red4.buckets) and not red4._exchanged_in_graph
+        torch.cuda.synchronize()
+        assert torch.equal(got, want.detach()), (step, float(got), float(want))
+        for (name, a), b in zip(plain.named_parameters(), replica3.parameters()):
+            if a.grad is None:
+                assert b.grad is None, name
+                continue
+            assert torch.equal(a.grad, b.grad), f"step {step} (exchange inside the graph): gradient of {name} differs"
+            assert b.grad.data_ptr() == red4._view[id(b)].data_ptr()
+    try:
+        gm.GraphedForwardBackward(loss_fn(replica), (x0, n0, t0), replica.parameters(), reducer=red2, capture_exchange=True)
+        raise AssertionError("capture_exchange=True without static_graph must raise")
+    except ValueError:
+        pass
     # ---- a weight used TWICE in one backward: with fp32 parameters the weight-gradient kernel of each use adds straight into the
     #      bucket view; the bucket's exchange may only start after BOTH (readiness comes from the engine's post-accumulate hook, which fires once
     #      per parameter after all of its uses).  Step 0 learns the used set (gradients arrive as tensors), steps 1-2 take the in-place path ----

@@ -150,6 +150,7 @@ if rank == 0:
                           gradient_bucket_bytes=sum(p.numel() * p.element_size() for p in unet.parameters()), n_gpus=world, step_ms=round(dt_step * 1e3, 2), hip_graph=use_graph,
                           gradient_exchange=(f"RCCL all-reduce, {len(red.buckets)} buckets, {red.launched_in_backward} launched during backward "
                                              f"(world_size {world})" if red.active else "off (one rank)"),
+                          exchange_inside_graph=bool(graphed is not None and graphed.exchange_captured),
                           volumes_per_s=round(world * batch / dt_step, 3), losses=[round(v, 4) for v in losses], phases=phases,
                           unet_fwd_bwd_breakdown={k: dict(launches=v["launches"], ms=round(v["ms"], 3), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1))
                                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]})))
