@@ -309,6 +309,16 @@ def _static_worker(rank, world, port, q):
         torch.nn.functional.mse_loss(model(data[lo:hi]), target[lo:hi]).backward()
         red.finish()
         none_grads = [None if p.grad is None else p.grad.detach().numpy().copy() for p in params]
+        # a replayed step that carried its exchange (graphs.GraphedForwardBackward.exchange_captured marks the reducer): the loop's finish() has
+        # nothing left to do -- no second exchange, gradients untouched, the mark cleared
+        red.zero_grad()
+        torch.nn.functional.mse_loss(model(data[lo:hi]), target[lo:hi]).backward()
+        red.finish()  # (what the graph's last nodes did)
+        before = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        red._exchanged_in_graph = True
+        red.finish()
+        noop = (not red._exchanged_in_graph and red._work == [None] * len(red.buckets)
+                and all((a is None and p.grad is None) or torch.equal(a, p.grad) for a, p in zip(before, params)))
         # the promise broken: the never-used layer suddenly takes part
         red.zero_grad()
         (torch.nn.functional.mse_loss(model(data[lo:hi]), target[lo:hi]) + unused(torch.ones(1, 4)).sum()).backward()
@@ -317,7 +327,7 @@ def _static_worker(rank, world, port, q):
             raised = False
         except RuntimeError:
             raised = True
-        q.put((rank, hooks, overlapped, grads, acc, none_grads, raised, len(red.buckets)))
+        q.put((rank, hooks, overlapped, grads, acc, none_grads, raised, len(red.buckets), noop))
     finally:
         dist.destroy_process_group()
 
@@ -355,7 +365,7 @@ def test_static_graph_reducer_keeps_one_hook_per_bucket(world):
         torch.nn.functional.mse_loss(model(data), target).backward()
         want.append([p.grad.numpy().copy() for p in model.parameters()])
     for rank in range(world):
-        hooks, overlapped, grads, acc, none_grads, raised, nbuckets = got[rank]
+        hooks, overlapped, grads, acc, none_grads, raised, nbuckets, noop = got[rank]
         # (counted after finish(): the first step ends with the per-parameter hooks, the second -- the recorded one -- already with one per non-empty bucket)
         assert hooks[0] == nparams + 2 and hooks[1] == hooks[2] == hooks[3] == hooks[4] < nparams
         assert hooks[1] <= nbuckets and overlapped[1] == overlapped[2] == overlapped[3] == overlapped[4] == nbuckets
@@ -367,4 +377,4 @@ def test_static_graph_reducer_keeps_one_hook_per_bucket(world):
             assert np.allclose(g, w, rtol=1e-5, atol=1e-6)
         for g, w in zip(none_grads[:nparams], want[4]):
             assert np.allclose(g, w, rtol=1e-5, atol=1e-6)
-        assert raised
+        assert raised and noop
