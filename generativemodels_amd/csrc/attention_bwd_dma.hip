@@ -61,9 +61,12 @@ __global__ __launch_bounds__(256) void abd_prep_kernel(const GmAttnBwdDesc p, co
 
 // out[row][c] (bf16) = sum over the slices, slice order, of part[slice][o][bh][row][c] (fp32): one thread per (row, 4 channels)
 template <int DH>
-__global__ __launch_bounds__(256) void abd_combine_kernel(const float* __restrict__ part, int nslices, int nout, int o, int H, int L, bf16_raw* __restrict__ dst,
-                                                          long long dst_ld) {
+__global__ __launch_bounds__(256) void abd_combine_kernel(const float* __restrict__ part, int nslices, int nout, int H, int L, bf16_raw* __restrict__ dst0,
+                                                          long long dst0_ld, bf16_raw* __restrict__ dst1, long long dst1_ld) {
   constexpr int VPR = DH / 4;
+  const int o = blockIdx.z;  // output of the sweep (DKV: 0 = dk, 1 = dv)
+  bf16_raw* dst = o == 0 ? dst0 : dst1;
+  const long long dst_ld = o == 0 ? dst0_ld : dst1_ld;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const long long it = (long long)blockIdx.x * 256 + threadIdx.x;
   const int row = (int)(it / VPR), cv = (int)(it % VPR);
@@ -403,9 +406,17 @@ static void abd_launch(const GmAttnBwdDesc& d, const float* lse, hipStream_t st)
   const bf16_raw* Q = reinterpret_cast<const bf16_raw*>(d.q);
   const bf16_raw* K = reinterpret_cast<const bf16_raw*>(d.k);
   const bf16_raw* G = reinterpret_cast<const bf16_raw*>(d.go);
-  gm_attn_pack_transposed(Q, d.q_ld, qt, d.B, d.H, d.Lq, (int)lqp, DH, st);
-  gm_attn_pack_transposed(G, d.go_ld, got, d.B, d.H, d.Lq, (int)lqp, DH, st);
-  gm_attn_pack_transposed(K, d.k_ld, kt, d.B, d.H, d.Lk, (int)lkp, DH, st);
+  if (3 * bh <= 65535) {
+    const bf16_raw* const rows[3] = {Q, G, K};
+    const long long lds_[3] = {d.q_ld, d.go_ld, d.k_ld};
+    bf16_raw* const images[3] = {qt, got, kt};
+    const int ls[3] = {d.Lq, d.Lq, d.Lk}, lps[3] = {(int)lqp, (int)lqp, (int)lkp};
+    gm_attn_pack_transposed3(rows, lds_, images, ls, lps, d.B, d.H, DH, st);
+  } else {
+    gm_attn_pack_transposed(Q, d.q_ld, qt, d.B, d.H, d.Lq, (int)lqp, DH, st);
+    gm_attn_pack_transposed(G, d.go_ld, got, d.B, d.H, d.Lq, (int)lqp, DH, st);
+    gm_attn_pack_transposed(K, d.k_ld, kt, d.B, d.H, d.Lk, (int)lkp, DH, st);
+  }
   const int skv = abd_split(d, d.Lk, d.Lq), sq = abd_split(d, d.Lq, d.Lk);
   const unsigned wq = (d.Lq + NW * 16 - 1) / (NW * 16), wk = (d.Lk + NW * 16 - 1) / (NW * 16);
   if (!lse) abd_kernel<DH, ABD_LSE, NW><<<dim3(wq, (unsigned)bh, sq), 64 * NW, lds_lse, st>>>(d, nullptr, nullptr, 0, nullptr, 0, reinterpret_cast<float*>(ms));
@@ -413,14 +424,13 @@ static void abd_launch(const GmAttnBwdDesc& d, const float* lse, hipStream_t st)
   abd_prep_kernel<DH><<<dim3((ld_stride + QPB - 1) / QPB, (unsigned)bh), 256, 0, st>>>(d, lse, ms, sq, ld, ld_stride);
   abd_kernel<DH, ABD_DKV, NW><<<dim3(wk, (unsigned)bh, skv), 64 * NW, lds_dkv, st>>>(d, qt, got, (int)lqp, ld, ld_stride, skv > 1 ? part : nullptr);
   if (skv > 1) {
-    const dim3 cg((unsigned)(((long long)d.Lk * (DH / 4) + 255) / 256), (unsigned)bh);
-    abd_combine_kernel<DH><<<cg, 256, 0, st>>>(part, skv, 2, 0, d.H, d.Lk, reinterpret_cast<bf16_raw*>(d.dk), d.dk_ld);
-    abd_combine_kernel<DH><<<cg, 256, 0, st>>>(part, skv, 2, 1, d.H, d.Lk, reinterpret_cast<bf16_raw*>(d.dv), d.dv_ld);
+    const dim3 cg((unsigned)(((long long)d.Lk * (DH / 4) + 255) / 256), (unsigned)bh, 2);
+    abd_combine_kernel<DH><<<cg, 256, 0, st>>>(part, skv, 2, d.H, d.Lk, reinterpret_cast<bf16_raw*>(d.dk), d.dk_ld, reinterpret_cast<bf16_raw*>(d.dv), d.dv_ld);
   }
   abd_kernel<DH, ABD_DQ, NW><<<dim3(wq, (unsigned)bh, sq), 64 * NW, lds_dq, st>>>(d, kt, nullptr, (int)lkp, ld, ld_stride, sq > 1 ? part : nullptr);
   if (sq > 1) {
     const dim3 cg((unsigned)(((long long)d.Lq * (DH / 4) + 255) / 256), (unsigned)bh);
-    abd_combine_kernel<DH><<<cg, 256, 0, st>>>(part, sq, 1, 0, d.H, d.Lq, reinterpret_cast<bf16_raw*>(d.dq), d.dq_ld);
+    abd_combine_kernel<DH><<<cg, 256, 0, st>>>(part, sq, 1, d.H, d.Lq, reinterpret_cast<bf16_raw*>(d.dq), d.dq_ld, nullptr, 0);
   }
 }
 

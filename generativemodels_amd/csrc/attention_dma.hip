@@ -26,11 +26,24 @@
 
 __device__ __attribute__((aligned(64))) unsigned int gm_attn_zero_row[16] = {0};
 
+// up to three tensors per launch (the fused backward packs Q, dO and K at once): blockIdx.z = set * (B * H) + (b * H + h)
+struct GmPackSet { const bf16_raw* rows; long long ld; bf16_raw* image; int L, L_pad; };
+struct GmPackSets { GmPackSet s[3]; };
+
 // ---- V -> VT[b*H + h][c][pos], pos = blk*32 + qq*8 + half*4 + r  <->  key = blk*32 + half*16 + qq*4 + r; keys >= Lk are zero ----
+__device__ __forceinline__ void vt_pack_body(const bf16_raw* __restrict__ v, long long v_ld, bf16_raw* __restrict__ vt, int H, int Lk, int Lk_pad, int dh, int bh);
 __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_raw* __restrict__ v, long long v_ld, bf16_raw* __restrict__ vt,
                                                       int H, int Lk, int Lk_pad, int dh) {
+  vt_pack_body(v, v_ld, vt, H, Lk, Lk_pad, dh, blockIdx.z);
+}
+__global__ __launch_bounds__(256) void vt_pack_sets_kernel(const GmPackSets ps, int BH, int H, int dh) {
+  const GmPackSet& t = ps.s[blockIdx.z / BH];
+  if ((int)blockIdx.x * 64 >= t.L_pad) return;  // (uniform: the grid covers the longest set)
+  vt_pack_body(t.rows, t.ld, t.image, H, t.L, t.L_pad, dh, blockIdx.z % BH);
+}
+__device__ __forceinline__ void vt_pack_body(const bf16_raw* __restrict__ v, long long v_ld, bf16_raw* __restrict__ vt, int H, int Lk, int Lk_pad, int dh, int bh) {
   __shared__ bf16_raw tile[64][64 + 8];
-  const int bh = blockIdx.z, b = bh / H, h = bh % H;
+  const int b = bh / H, h = bh % H;
   const int key0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const bf16_raw* vb = v + (long long)b * Lk * v_ld + h * dh;
   for (int it = threadIdx.x; it < 64 * 8; it += 256) {
@@ -376,6 +389,16 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, c
 // ---- host side -------------------------------------------------------------------------------------------------------------
 void gm_attn_pack_transposed(const bf16_raw* rows, long long ld, bf16_raw* image, int B, int H, int L, int L_pad, int dh, hipStream_t st) {
   vt_pack_kernel<<<dim3(L_pad / 64, dh / 64, B * H), 256, 0, st>>>(rows, ld, image, H, L, L_pad, dh);
+}
+void gm_attn_pack_transposed3(const bf16_raw* const rows[3], const long long ld[3], bf16_raw* const image[3], const int L[3], const int L_pad[3], int B, int H, int dh,
+                              hipStream_t st) {
+  GmPackSets ps;
+  int lmax = 0;
+  for (int i = 0; i < 3; ++i) {
+    ps.s[i] = GmPackSet{rows[i], ld[i], image[i], L[i], L_pad[i]};
+    lmax = L_pad[i] > lmax ? L_pad[i] : lmax;
+  }
+  vt_pack_sets_kernel<<<dim3(lmax / 64, dh / 64, 3 * B * H), 256, 0, st>>>(ps, B * H, H, dh);
 }
 
 static int gm_attn_dma_force_qf = 0, gm_attn_dma_force_split = 0;  // 0 = choose by problem size (tests / benchmarks force a variant)

@@ -52,4 +52,7 @@ __device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
 // rows [L][ld] (channels [h * dh, (h + 1) * dh) per head) -> image[b * H + h][channel][position], zero beyond L, position order inside each
 // 32-block = the order a 16x16x32 MFMA consumes two 16-row accumulator fragments (attention_dma.hip: vt_pack_kernel); dh a multiple of 64
 void gm_attn_pack_transposed(const bf16_raw* rows, long long ld, bf16_raw* image, int B, int H, int L, int L_pad, int dh, hipStream_t st);
+// ... three tensors in one launch (3 * B * H <= 65535)
+void gm_attn_pack_transposed3(const bf16_raw* const rows[3], const long long ld[3], bf16_raw* const image[3], const int L[3], const int L_pad[3], int B, int H, int dh,
+                              hipStream_t st);
 #endif
