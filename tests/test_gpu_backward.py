@@ -1182,6 +1182,27 @@ def test_attention_backward_fused_bf16_lds_dma_kernels(b, lq, lk, heads, dh):
         ops.attention_backward_fused(qd.float(), kd.float(), vd.float(), o.float(), gd.float(), heads, scale)
 
 
+def test_attention_backward_fused_at_c2_size_agrees_with_the_composed_path():
+    """C2's mid-block attention in training (one head x 32 768 tokens x 256 channels; BASELINE.json configs[1], diffusion_model_unet.py:407-415): the
+    fused LDS-DMA backward (4 ms, nothing L x L in HBM) against the composed bf16 path (score pass in query slabs + weight-gradient kernels, 20 ms) --
+    two independent implementations of the same five products, both checked against fp64 autograd at small sizes; here they must agree to bf16
+    rounding of P / dS at the full size, where fp64 autograd on the CPU would need 17 GB and minutes."""
+    ops = _ops()
+    l, dh = 32768, 256
+    scale = 1 / math.sqrt(dh)
+    q, k, v, go = (_rand((1, l, dh), 750 + i).bfloat16().to(DEV) for i in range(4))
+    lse = torch.empty((1, 1, l), dtype=torch.float32, device=DEV)
+    o = ops.attention(q, k, v, 1, scale, lse_out=lse)
+    assert torch.isfinite(lse).all()
+    fused = ops.attention_backward_fused(q, k, v, o, go, 1, scale, lse=lse)
+    own = ops.attention_backward_fused(q, k, v, o, go, 1, scale)  # with its own LSE sweep
+    composed = ops.attention_backward_bf16(q, k, v, o, go, 1, scale)
+    for name, a, b_, c in zip("qkv", fused, own, composed):
+        assert torch.isfinite(a.float()).all()
+        _close(a, c, 1e-2, f"32 768 x 256: fused vs composed d{name}")
+        _close(b_, a, 2e-3, f"32 768 x 256: own LSE sweep vs the forward kernel's LSE d{name}")
+
+
 @pytest.mark.parametrize("b,lq,lk,heads,dh", [(1, 700, 700, 2, 64), (2, 333, 200, 1, 128), (1, 1100, 520, 1, 32)])
 def test_attention_backward_bf16_in_query_slabs(monkeypatch, b, lq, lk, heads, dh):
     """(round 5) a (sample, head) pair whose score matrices exceed ops.ATTENTION_BWD_BF16_SLAB_BYTES goes through the score pass in slabs of query
