@@ -20,6 +20,9 @@
 #ifndef GM_ATTN_ABLATE
 #define GM_ATTN_ABLATE 0
 #endif
+#ifndef GM_ATTN_NH2
+#define GM_ATTN_NH2 0  // bench-only: 1 = two 32-key online-softmax steps per 64-key tile at 16 queries per wave too (measured: see profiles/r05_attn_fwd_ablation.txt)
+#endif
 #ifndef GM_ATTN_PD
 #define GM_ATTN_PD 8  // operand fragments in flight ahead of the MFMAs (256-register kernels); bench-only builds override it
 #endif
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
     // The 64-key tile is consumed in NH slices of KFH key fragments (QF = 2: two 32-key slices, so that the score / probability
     // registers of 32 queries stay at 24 per lane -- the kernel sits at the 256-register limit of two waves per SIMD); each slice is
     // one online-softmax step.
-    constexpr int NH = QF >= 2 ? 2 : 1, KFH = KF / NH;
+    constexpr int NH = (QF >= 2 || GM_ATTN_NH2) ? 2 : 1, KFH = KF / NH;
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
       // ---- S^T = K Q^T: one K fragment read feeds QF MFMAs ------------------------------------------------------------------
