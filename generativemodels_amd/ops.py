@@ -617,7 +617,7 @@ def channel_stats(x: torch.Tensor) -> torch.Tensor:
     return st
 
 
-STATS_COMPACT_ABOVE = 256  # tables with more partials than this are folded to gm_stats_compact_slots() rows right after they are produced
+STATS_COMPACT_ABOVE = int(os.environ.get("GM_STATS_COMPACT_ABOVE", "256"))  # tables with more partials than this are folded to gm_stats_compact_slots() rows right after they are produced
 
 
 def _compact_stats(st: torch.Tensor) -> torch.Tensor:
