@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void abd_combine_kernel(const float* __restric
 template <int DH, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, const bf16_raw* __restrict__ t1, const bf16_raw* __restrict__ t2, int t_ld,
                                                          const float2* __restrict__ ld, int ld_stride, float* __restrict__ part) {
-  constexpr int TR = DH == 256 ? 32 : 64;         // streamed rows per tile
+  constexpr int TR = (DH == 256 && MODE != ABD_LSE) ? 32 : 64;  // streamed rows per tile (LDS: 4 (DKV) / 3 (DQ) / 1 (LSE) images of TR x DH x 2 bytes, twice)
   constexpr int KF = TR / 16;                     // 16-row fragments per tile
   constexpr int S2N = TR / 32;                    // 32-position blocks per tile (one MFMA k-step of the row contractions each)
   constexpr int STEPS = DH / 32, DF = DH / 16;
@@ -361,7 +361,7 @@ static int abd_force_split = 0;  // 0 = by problem size (tests / benchmarks forc
 extern "C" void gm_attention_backward_fused_set_split(int nsplit) { abd_force_split = (nsplit >= 1 && nsplit <= 16) ? nsplit : 0; }
 static int abd_split(const GmAttnBwdDesc& d, int Lown, int Lst) {
   if (abd_force_split) return abd_force_split;
-  const long long wgs = (long long)d.B * d.H * ((Lown + 127) / 128), tiles = (Lst + (d.dh == 256 ? 31 : 63)) / (d.dh == 256 ? 32 : 64);
+  const long long wgs = (long long)d.B * d.H * ((Lown + 127) / 128), tiles = (Lst + (d.dh == 256 ? 31 : 63)) / (d.dh == 256 ? 32 : 64);  // (the LSE sweep's 64-row tiles: >= 2 per slice)
   int sp = 1;
   while (wgs * sp < 256 && sp < 16 && tiles / (2 * sp) >= 4) sp *= 2;
   return sp;
@@ -385,7 +385,7 @@ template <int DH>
 static void abd_launch(const GmAttnBwdDesc& d, const float* lse, hipStream_t st) {
   constexpr int NW = 8;
   constexpr int TR = DH == 256 ? 32 : 64, TB = TR * DH * 2;
-  constexpr size_t lds_lse = 2 * (size_t)TB, lds_dq = 2 * (size_t)(3 * TB), lds_dkv = 2 * (size_t)(4 * TB + 1024);
+  constexpr size_t lds_lse = 2 * (size_t)(64 * DH * 2), lds_dq = 2 * (size_t)(3 * TB), lds_dkv = 2 * (size_t)(4 * TB + 1024);
   static bool attr_set = false;
   if (!attr_set) {
     const void* ks[3] = {reinterpret_cast<const void*>(abd_kernel<DH, ABD_DQ, NW>), reinterpret_cast<const void*>(abd_kernel<DH, ABD_DKV, NW>),
