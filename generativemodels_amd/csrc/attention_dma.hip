@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
   float m_run[QF], l_run[QF];
 #pragma unroll
   for (int f = 0; f < QF; ++f) { m_run[f] = -INFINITY; l_run[f] = 0.f; }
+  const float scale2 = p.scale * 1.4426950408889634f;
 
   const int ntiles_all = (p.Lk + KT - 1) / KT;
   const int tps = (ntiles_all + (int)gridDim.z - 1) / (int)gridDim.z;  // key tiles per slice
@@ -211,34 +212,48 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
         }
       }
       // ---- online softmax: this lane's queries, keys key0 + (hf * KFH + kf) * 16 + qg * 4 + r ----------------------------------
+      // (round 5) scores, running maximum and sums live in the base-2 domain: x = s * (scale log2 e), p = 2^(x - m) -- one multiply per score and a
+      // bare v_exp_f32 (e^y costs the multiply by log2 e again); the key-bound select runs on the last tile only (wave-uniform branch)
       uint4 pf[QF][KFH / 2];
       float alpha[QF];
       bool moved = false;
+      const bool full_tile = key0 + KT <= p.Lk;
 #pragma unroll
       for (int f = 0; f < QF; ++f) {
         float tmax = -INFINITY;
+        if (full_tile) {
 #pragma unroll
-        for (int kf = 0; kf < KFH; ++kf)
+          for (int kf = 0; kf < KFH; ++kf)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = key0 + (hf * KFH + kf) * 16 + qg * 4 + r;
-            const float sv = key < p.Lk ? sacc[f][kf][r] * p.scale : -INFINITY;
-            sacc[f][kf][r] = sv;
-            tmax = fmaxf(tmax, sv);
-          }
+            for (int r = 0; r < 4; ++r) {
+              const float sv = sacc[f][kf][r] * scale2;
+              sacc[f][kf][r] = sv;
+              tmax = fmaxf(tmax, sv);
+            }
+        } else {
+#pragma unroll
+          for (int kf = 0; kf < KFH; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = key0 + (hf * KFH + kf) * 16 + qg * 4 + r;
+              const float sv = key < p.Lk ? sacc[f][kf][r] * scale2 : -INFINITY;
+              sacc[f][kf][r] = sv;
+              tmax = fmaxf(tmax, sv);
+            }
+        }
         if (!(GM_ATTN_ABLATE & 1)) {
           tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
           tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         }
         const float m_new = (GM_ATTN_ABLATE & 1) ? 0.f : fmaxf(m_run[f], tmax);
-        alpha[f] = __expf(m_run[f] - m_new);
+        alpha[f] = __builtin_amdgcn_exp2f(m_run[f] - m_new);
         moved |= m_new != m_run[f];
         float psum = 0.f;
 #pragma unroll
         for (int kf = 0; kf < KFH; ++kf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = (GM_ATTN_ABLATE & 1) ? sacc[f][kf][r] : __expf(sacc[f][kf][r] - m_new);
+            const float pv = (GM_ATTN_ABLATE & 1) ? sacc[f][kf][r] : __builtin_amdgcn_exp2f(sacc[f][kf][r] - m_new);
             sacc[f][kf][r] = pv;
             psum += pv;
           }
@@ -299,13 +314,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
     l_tot += __shfl_xor(l_tot, 32, 64);
     const float inv = 1.0f / l_tot;
     if (!q_ok[f]) continue;
-    if (p.lse && !part && qg == 0) p.lse[(long long)bh * p.Lq + my_q[f]] = m_run[f] + __logf(l_tot);
+    const float m_nat = m_run[f] * 0.6931471805599453f;  // the running maximum in natural-log units (what the merge kernel and the LSE use)
+    if (p.lse && !part && qg == 0) p.lse[(long long)bh * p.Lq + my_q[f]] = m_nat + __logf(l_tot);
     if (part) {  // [slice][b*H + h][query][DH + 2]: O (fp32, relative to the slice maximum), maximum, sum
       float* prow = part + (((long long)blockIdx.z * gridDim.y + bh) * p.Lq + my_q[f]) * (DH + 4);
 #pragma unroll
       for (int d = 0; d < DF; ++d)
         *reinterpret_cast<float4*>(prow + d * 16 + qg * 4) = make_float4(oacc[f][d][0], oacc[f][d][1], oacc[f][d][2], oacc[f][d][3]);
-      if (qg == 0) { prow[DH] = m_run[f]; prow[DH + 1] = l_tot; }
+      if (qg == 0) { prow[DH] = m_nat; prow[DH + 1] = l_tot; }
       continue;
     }
     bf16_raw* orow = reinterpret_cast<bf16_raw*>(p.o) + ((long long)b * p.Lq + my_q[f]) * p.o_ld + h * DH;
