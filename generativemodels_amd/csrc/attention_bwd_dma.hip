@@ -312,11 +312,8 @@ __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, 
   }
 
   if constexpr (MODE == ABD_LSE) {  // the four lanes sharing a query hold disjoint key subsets
-    float M = fmaxf(m_run, __shfl_xor(m_run, 16, 64));
-    M = fmaxf(M, __shfl_xor(M, 32, 64));
-    float st = m_run > -INFINITY ? l_run * __expf(m_run - M) : 0.f;
-    st += __shfl_xor(st, 16, 64);
-    st += __shfl_xor(st, 32, 64);
+    const float M = attn_quad_max(m_run);
+    const float st = attn_quad_sum(m_run > -INFINITY ? l_run * __expf(m_run - M) : 0.f);
     if (qg == 0 && own_ok)  // (max, sum) of this slice: [slice][bh][q]
       reinterpret_cast<float2*>(part)[((long long)blockIdx.z * gridDim.y + bh) * p.Lq + own] = make_float2(M, st);
     return;

@@ -241,10 +241,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
               tmax = fmaxf(tmax, sv);
             }
         }
-        if (!(GM_ATTN_ABLATE & 1)) {
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        }
+        if (!(GM_ATTN_ABLATE & 1)) tmax = attn_quad_max(tmax);
         const float m_new = (GM_ATTN_ABLATE & 1) ? 0.f : fmaxf(m_run[f], tmax);
         alpha[f] = __builtin_amdgcn_exp2f(m_run[f] - m_new);
         moved |= m_new != m_run[f];
@@ -310,8 +307,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
   // ---- finish: 1/l, residual, store (or, split-KV: the slice's un-normalised state for attn_combine_kernel) -----------------------
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
-    float l_tot = l_run[f] + __shfl_xor(l_run[f], 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float l_tot = attn_quad_sum(l_run[f]);
     const float inv = 1.0f / l_tot;
     if (!q_ok[f]) continue;
     const float m_nat = m_run[f] * 0.6931471805599453f;  // the running maximum in natural-log units (what the merge kernel and the LSE use)

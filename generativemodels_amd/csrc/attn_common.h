@@ -41,6 +41,21 @@ struct GmAttnBwdDesc {
 };
 
 #ifdef __HIPCC__
+// The four lanes l15 + 16 * {0, 1, 2, 3} of a wave hold partial results of one MFMA column: max / sum over them by gfx950's lane-swap VALU
+// instructions (v_permlane32_swap exchanges the wave's halves, v_permlane16_swap the odd and even 16-lane rows) instead of two ds_bpermute
+// round trips through the LDS pipeline.  Every lane receives the same value, operands combined in a fixed order.
+__device__ __forceinline__ float attn_quad_max(float x) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float attn_quad_sum(float x) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 // one 1 KB LDS-DMA piece: every lane's 16 bytes at gsrc land at lds_dst + 16 * lane (M0 saved and restored around the request)
 __device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
