@@ -114,10 +114,32 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
   const int vrow0 = wave * PPW * 8 + (lane >> 3), vslot = lane & 7;       // piece j: V^T channel row vrow0 + 8 j
   const long long k_rowb = p.k_ld * 2;
   const int v_rowb = Lk_pad * 2;                                          // host-checked: DH * Lk_pad * 2 < 2^31
+  // (round 5) 16 queries per wave: this lane's byte offsets inside a tile are launch constants (the swizzle of a row does not depend on the tile:
+  // key0 is a multiple of 64), so a whole tile is a wave-uniform base (SGPR pair, advanced on the scalar unit) + PPW + PPW lane offsets -- ~45
+  // VALU instructions per tile less than re-deriving 64-bit addresses; only the last, partial tile takes the general path (rows >= Lk -> zeros)
+  constexpr bool FASTDMA = QF == 1;
+  unsigned koff[FASTDMA ? PPW : 1], voff[FASTDMA ? PPW : 1];
+  if (FASTDMA) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int krow = krow0 + j * KRPP, vrow = vrow0 + 8 * j;
+      koff[j] = (unsigned)krow * (unsigned)k_rowb + (unsigned)((kslot ^ ((krow >> KSH) & (KNB - 1))) * 16);
+      voff[j] = (unsigned)vrow * (unsigned)v_rowb + (unsigned)((vslot ^ ((vrow >> 1) & 7)) * 16);
+    }
+  }
   auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
     const int key0 = tile * KT;
     const unsigned kdst = lds0 + (unsigned)buf * (KBYTES + VBYTES), vdst = kdst + KBYTES;
     const char* vt0 = Vt + (long long)key0 * 2;
+    if (FASTDMA && key0 + KT <= p.Lk) {
+      const char* kt0 = Kb + (long long)key0 * k_rowb;
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        attn_dma16_s(kt0, koff[j], kdst + (unsigned)(wave * PPW + j) * 1024);
+        attn_dma16_s(vt0, voff[j], vdst + (unsigned)(wave * PPW + j) * 1024);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       const int krow = krow0 + j * KRPP;
@@ -203,9 +225,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
         for (int i = 0; i < NKQ; ++i) {
           const int s = i / KFH, kf = i % KFH;
 #pragma unroll
-          for (int f = 0; f < QF; ++f)
+          for (int f = 0; f < QF; ++f)  // (the first k-step takes a literal zero accumulator: no register clears per tile)
             sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kq[i % PD]), __builtin_bit_cast(bf16x8_t, qf[f][s]),
-                                                                  sacc[f][kf], 0, 0, 0);
+                                                                  s == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : sacc[f][kf], 0, 0, 0);
           if (i + PD < NKQ && !(GM_ATTN_ABLATE & 8)) kq[i % PD] = kread(i + PD);
           __builtin_amdgcn_sched_group_barrier(0x008, QF, 0);
           if (i + PD < NKQ && !(GM_ATTN_ABLATE & 8)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -426,6 +448,7 @@ static bool attn_dma_eligible(const GmAttnDesc& d) {
   auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
   return d.dtype == GM_BF16 && !d.causal && d.k_bs == 0 && d.v_bs == 0 && (d.dh == 64 || d.dh == 128 || d.dh == 256) && d.Lq >= 128 && d.Lk >= 128 &&
          (long long)d.dh * (((long long)d.Lk + 63) / 64 * 64) * 2 < (1LL << 31) &&  // 32-bit byte offsets inside one head's V^T image
+         d.k_ld < (1LL << 24) &&                                                    // ... and inside one K tile (64 rows x k_ld x 2 bytes)
          d.q_ld % 8 == 0 && d.k_ld % 8 == 0 && d.v_ld % 8 == 0 && al(d.q, 16) && al(d.k, 16) && al(d.v, 16) &&
          d.o_ld % 8 == 0 && al(d.o, 16) && (!d.res || (d.res_ld % 8 == 0 && al(d.res, 16)));
 }

@@ -64,6 +64,14 @@ __device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
 }
+// ... the same piece from a wave-uniform base (SGPR pair) + this lane's 32-bit byte offset: per-tile address arithmetic on the scalar unit
+__device__ __forceinline__ void attn_dma16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
 // rows [L][ld] (channels [h * dh, (h + 1) * dh) per head) -> image[b * H + h][channel][position], zero beyond L, position order inside each
 // 32-block = the order a 16x16x32 MFMA consumes two 16-row accumulator fragments (attention_dma.hip: vt_pack_kernel); dh a multiple of 64
 void gm_attn_pack_transposed(const bf16_raw* rows, long long ld, bf16_raw* image, int B, int H, int L, int L_pad, int dh, hipStream_t st);
