@@ -20,7 +20,8 @@ static __device__ __attribute__((aligned(64))) unsigned int abd_zero_row[16] = {
 
 enum { ABD_DQ = 0, ABD_DKV = 1, ABD_LSE = 2 };
 
-// D[q] = dO[q] . O[q] and the (LSE, D) pairs the DKV kernel streams: ld[bh][q] for q < Lq, (+inf, 0) for the padding (a padded query's
+// D[q] = dO[q] . O[q] and the (LSE log2 e, D) pairs the gradient kernels read (they evaluate P = 2^(s scale log2 e - LSE log2 e): one FMA and a
+// bare v_exp_f32 per score): ld[bh][q] for q < Lq, (+inf, 0) for the padding (a padded query's
 // probability is exp(x - inf) = 0: no masks in the DKV loop).  One thread per (query, 8 channels), 256 threads = 256 * 8 / DH queries.
 // `lse` NULL: the LSE sweep's (max, sum) pairs ms[slice][bh][q] of `nslices` key slices are merged here, slice order.
 template <int DH>
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void abd_prep_kernel(const GmAttnBwdDesc p, co
         l = M + __logf(tot);
       }
     }
-    ld[(long long)bh * ld_stride + q] = q < p.Lq ? make_float2(l, part) : make_float2(INFINITY, 0.f);
+    ld[(long long)bh * ld_stride + q] = q < p.Lq ? make_float2(l * 1.4426950408889634f, part) : make_float2(INFINITY, 0.f);  // (LSE in base-2 units)
   }
 }
 
@@ -129,9 +130,35 @@ __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, 
   const int trow0 = wave * PPW * TRPP + lane / SPRT, tslot = lane % SPRT;    // piece j: channel row trow0 + j * TRPP
   const int t_rowb = t_ld * 2;                                                // host-checked: DH * t_ld * 2 < 2^31
   auto tkey = [](int row) __attribute__((always_inline)) { return TR == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
+  // full tiles: a wave-uniform base per image (advanced on the scalar unit) + launch-constant lane offsets (attention_dma.hip, round 5); the last,
+  // partial tile takes the general path (rows >= Lst -> zeros)
+  unsigned noff1[PPW], noff2[NNAT == 2 ? PPW : 1], toff[NTR >= 1 ? PPW : 1];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int row = nrow0 + j * NRPP, trow = trow0 + j * TRPP;
+    const unsigned slotb = (unsigned)((nslot ^ ((row >> KSH) & (KNB - 1))) * 16);
+    noff1[j] = (unsigned)row * (unsigned)n1_rowb + slotb;
+    if (NNAT == 2) noff2[NNAT == 2 ? j : 0] = (unsigned)row * (unsigned)n2_rowb + slotb;
+    if (NTR >= 1) toff[NTR >= 1 ? j : 0] = (unsigned)trow * (unsigned)t_rowb + (unsigned)((tslot ^ tkey(trow)) * 16);
+  }
   auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
     const int r0 = tile * TR;
     const unsigned dst = lds0 + (unsigned)buf * BUF_BYTES;
+    if (r0 + TR <= Lst) {
+      const char* b1 = N1 + (long long)r0 * n1_rowb;
+      const char* b2 = N2 + (long long)r0 * n2_rowb;
+      const char* bt1 = T1 + (long long)r0 * 2;
+      const char* bt2 = T2 + (long long)r0 * 2;
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        attn_dma16_s(b1, noff1[j], dst + (unsigned)(wave * PPW + j) * 1024);
+        if (NNAT == 2) attn_dma16_s(b2, noff2[NNAT == 2 ? j : 0], dst + TBYTES + (unsigned)(wave * PPW + j) * 1024);
+        if (NTR >= 1) attn_dma16_s(bt1, toff[NTR >= 1 ? j : 0], dst + NNAT * TBYTES + (unsigned)(wave * PPW + j) * 1024);
+        if (NTR == 2) attn_dma16_s(bt2, toff[NTR >= 1 ? j : 0], dst + (NNAT + 1) * TBYTES + (unsigned)(wave * PPW + j) * 1024);
+      }
+      if (MODE == ABD_DKV && wave == 0) attn_dma16_s(LD + (long long)r0 * 8, (unsigned)lane * 16u, dst + LD_OFF);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       const int row = nrow0 + j * NRPP;
@@ -183,6 +210,7 @@ __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, 
     own_lse = t.x; own_d = t.y;
   }
   float m_run = -INFINITY, l_run = 0.f;  // LSE mode
+  const float scale2 = p.scale * 1.4426950408889634f;
 
   // gridDim.z > 1: work-group z sweeps the z-th slice of the streamed tiles and leaves fp32 partial results in `part` (one head of 4 096 tokens
   // is only 32 work-groups of 128 own rows); abd_combine_kernel / abd_prep_kernel add the slices in slice order (deterministic)
@@ -201,11 +229,6 @@ __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, 
 
     // ---- stage 1: acc1 = N1 X1^T (scores), acc2 = N2 X2^T (dP): D[streamed row 16 kf + 4 qg + r][own row l15] -------------------------
     f32x4_t acc1[KF], acc2[NNAT == 2 ? KF : 1];
-#pragma unroll
-    for (int kf = 0; kf < KF; ++kf) {
-      acc1[kf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      if (NNAT == 2) acc2[kf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
     {
       constexpr int NKQ = NNAT * STEPS * KF, PDW = MODE == ABD_DKV ? 2 : 6, PD = NKQ < PDW ? NKQ : PDW;
       uint4 kq[PD];
@@ -220,11 +243,12 @@ __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, 
 #pragma unroll
       for (int i = 0; i < NKQ; ++i) {
         const int which = i % NNAT, kf = (i / NNAT) % KF, s = i / (NNAT * KF);
+        const f32x4_t zero4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};  // (the first k-step takes a literal zero accumulator: no register clears per tile)
         if (NNAT == 1 || which == 0)
-          acc1[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kq[i % PD]), __builtin_bit_cast(bf16x8_t, x1[s]), acc1[kf], 0, 0, 0);
+          acc1[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kq[i % PD]), __builtin_bit_cast(bf16x8_t, x1[s]), s == 0 ? zero4 : acc1[kf], 0, 0, 0);
         else
           acc2[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kq[i % PD]), __builtin_bit_cast(bf16x8_t, x2[NNAT == 2 ? s : 0]),
-                                                             acc2[NNAT == 2 ? kf : 0], 0, 0, 0);
+                                                             s == 0 ? zero4 : acc2[NNAT == 2 ? kf : 0], 0, 0, 0);
         if (i + PD < NKQ) kq[i % PD] = nread(i + PD);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (i + PD < NKQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -269,11 +293,11 @@ __global__ __launch_bounds__(64 * NW, 2) void abd_kernel(const GmAttnBwdDesc p, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (MODE == ABD_DKV) {
-              pv[hf][r] = __expf(acc1[kf][r] * p.scale - lse_r[r]);
+              pv[hf][r] = __builtin_amdgcn_exp2f(fmaf(acc1[kf][r], scale2, -lse_r[r]));
               dv[hf][r] = pv[hf][r] * (acc2[kf][r] - d_r[r]) * p.scale;
             } else {
               const bool ok = r0 + kf * 16 + qg * 4 + r < Lst;
-              pv[hf][r] = ok ? __expf(acc1[kf][r] * p.scale - own_lse) : 0.f;
+              pv[hf][r] = ok ? __builtin_amdgcn_exp2f(fmaf(acc1[kf][r], scale2, -own_lse)) : 0.f;
               dv[hf][r] = pv[hf][r] * (acc2[kf][r] - own_d) * p.scale;
             }
           }
