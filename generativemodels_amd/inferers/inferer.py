@@ -9,6 +9,8 @@ MI355X-specific execution of `sample`:
     captured once on the first step and replayed for the remaining steps."""
 from __future__ import annotations
 
+import os
+
 import functools
 import math
 from typing import Callable, Optional
@@ -50,25 +52,38 @@ def _check_mode(mode: str) -> None:
 class _GraphedUNet:
     """HIP-graph replay of `model(x, t, context)` for fixed shapes; falls back to nothing -- errors propagate."""
 
-    def __init__(self, model: DiffusionModelUNet, x: torch.Tensor, t: torch.Tensor, context: Optional[torch.Tensor]):
+    def __init__(self, model: DiffusionModelUNet, x: torch.Tensor, t: torch.Tensor, context: Optional[torch.Tensor],
+                 row: Optional[torch.Tensor] = None):
         # (the model is NOT kept: the cache holds it weakly, so a dropped model releases its captured graph and the graph's private memory pool)
+        # row: this step's row of `model.time_rows_table()` -- the captured forward then reads its timestep rows from a static buffer the loop
+        # fills per step (one copy) instead of running the embedding + MLP + stacked projection inside the graph (4 launches)
         self.x = x.clone()
         self.t = t.clone()
+        self.row = None if row is None else row.clone()
         self.context = None if context is None else context.clone()
+
+        def run():
+            if self.row is not None:
+                model._time_rows_row = self.row  # consumed by this forward
+            return model(self.x, self.t, self.context)
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up: packs weights, sets kernel attributes, sizes the allocator
-            model(self.x, self.t, self.context)
+            run()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: HIP calls of OTHER host threads (DataLoader pin-memory, the RCCL watchdog, a GradientReducer side stream
         # during in-training validation sampling) do not invalidate the capture
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = model(self.x, self.t, self.context)
+            self.out = run()
 
-    def __call__(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, row: Optional[torch.Tensor] = None) -> torch.Tensor:
         self.x.copy_(x)
-        self.t.copy_(t)
+        if self.row is not None:
+            self.row.copy_(row)
+        else:
+            self.t.copy_(t)
         self.graph.replay()
         return self.out
 
@@ -116,20 +131,21 @@ class DiffusionInferer(Inferer):
             return diffusion_model.forward_train(noisy, timesteps, context=condition)
         return diffusion_model(x=noisy, timesteps=timesteps, context=condition)
 
+    BATCHED_TIME_ROWS = os.environ.get("GM_BATCHED_TIME_ROWS", "1") != "0"  # (bench switch: "0" = the embedding + MLP + stacked projection once per step)
     GRAPH_CACHE_SIZE = 2  # captured forwards kept per inferer (a capture costs two eager forwards: ~10 ms for the C3 latent UNet, 7 % of a sample)
 
-    def _cached_graph(self, model, x: torch.Tensor, t: torch.Tensor, ctx: Optional[torch.Tensor]) -> "_GraphedUNet":
+    def _cached_graph(self, model, x: torch.Tensor, t: torch.Tensor, ctx: Optional[torch.Tensor], row: Optional[torch.Tensor] = None) -> "_GraphedUNet":
         """The captured forward of `model` for these shapes, reused across sample() calls while the model's parameters are unchanged."""
         import weakref
 
         cache = self.__dict__.setdefault("_graph_cache", [])
-        key = (tuple(x.shape), x.dtype, x.device, tuple(t.shape), None if ctx is None else (tuple(ctx.shape), ctx.dtype))
+        key = (tuple(x.shape), x.dtype, x.device, tuple(t.shape), None if ctx is None else (tuple(ctx.shape), ctx.dtype), row is not None)
         sig = _GraphedUNet.signature(model)
         for ent in cache:
             if ent[0]() is model and ent[1] == key and ent[2] == sig:
                 return ent[3]
         cache[:] = [ent for ent in cache if ent[0]() is not None and not (ent[0]() is model and ent[1] == key)][-(self.GRAPH_CACHE_SIZE - 1):]
-        g = _GraphedUNet(model, x, t, ctx)
+        g = _GraphedUNet(model, x, t, ctx, row)
         cache.append((weakref.ref(model), key, sig, g))
         return g
 
@@ -153,12 +169,25 @@ class DiffusionInferer(Inferer):
         steps = [int(t) for t in torch.as_tensor(scheduler.timesteps).cpu().tolist()]
         t_dev = torch.tensor(steps, dtype=torch.float32).to(input_noise.device)  # whole chain, one upload
         it = tqdm(range(len(steps))) if (verbose and has_tqdm) else range(len(steps))
+        graphable = isinstance(diffusion_model, DiffusionModelUNet) and not isinstance(diffusion_model, SPADEDiffusionModelUNet)
+        # the timestep rows of the whole chain from one batched pass (4 launches per chain instead of 4 per step); row i goes to step i
+        unet = diffusion_model if isinstance(diffusion_model, DiffusionModelUNet) else None
+        table = unet.time_rows_table(t_dev) if (unet is not None and len(steps) > 1 and self.BATCHED_TIME_ROWS) else None
+        diffusion_model = _bind_seg(diffusion_model, seg)
+        try:
+            return self._sample_loop(it, steps, t_dev, table, unet, graphable, image, diffusion_model, scheduler, conditioning, mode,
+                                     save_intermediates, intermediate_steps)
+        finally:
+            if unet is not None:
+                unet.__dict__.pop("_time_rows_row", None)  # (a forward that raised before consuming its row)
+
+    def _sample_loop(self, it, steps, t_dev, table, unet, graphable, image, diffusion_model, scheduler, conditioning, mode, save_intermediates,
+                     intermediate_steps):
         graphed = None
         intermediates = []
-        graphable = isinstance(diffusion_model, DiffusionModelUNet) and not isinstance(diffusion_model, SPADEDiffusionModelUNet)
-        diffusion_model = _bind_seg(diffusion_model, seg)
         for i in it:
             t, tt = steps[i], t_dev[i:i + 1]
+            row = None if table is None else table[i:i + 1]
             if mode == "concat":
                 model_input, ctx = ops.concat_dim1([image, conditioning]), None
             else:
@@ -167,12 +196,14 @@ class DiffusionInferer(Inferer):
                 model_input.numel() <= self.GRAPH_AUTO_MAX_ELEMENTS and len(steps) >= self.GRAPH_AUTO_MIN_STEPS)
             if use_graph and graphable:
                 if graphed is None:
-                    graphed = self._cached_graph(diffusion_model, model_input, tt, ctx)
+                    graphed = self._cached_graph(diffusion_model, model_input, tt, ctx, row)
                     graphed.set_context(ctx)
-                model_output = graphed(model_input, tt)
+                model_output = graphed(model_input, tt, row)
                 if getattr(scheduler, "keeps_model_outputs", False):
                     model_output = model_output.clone()  # the graph's static output buffer is overwritten by the next replay
             else:
+                if row is not None:
+                    unet._time_rows_row = row  # consumed by this forward
                 model_output = diffusion_model(model_input, timesteps=tt, context=ctx)
             image, _ = scheduler.step(model_output, t, image)
             if save_intermediates and t % intermediate_steps == 0:

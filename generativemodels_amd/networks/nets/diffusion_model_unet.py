@@ -259,6 +259,29 @@ class _TimestepPath:
     def _temb_rows(self, timesteps: torch.Tensor, class_labels: Optional[torch.Tensor]):
         """fp32 [B_t, C_out] additive rows for every ResnetBlock from ONE stacked GEMM (reference: one Linear per block,
         diffusion_model_unet.py:686-690).  The whole timestep path runs in fp32 regardless of the model dtype."""
+        return self._temb_split(self._temb_stacked(timesteps, class_labels))
+
+    def time_rows_table(self, timesteps: torch.Tensor) -> Optional[torch.Tensor]:
+        """fp32 [T, sum of the ResnetBlocks' channels]: the stacked timestep rows of EVERY timestep of a sampling chain from one batched pass (the
+        embedding, the two-layer MLP and the stacked `time_emb_proj` GEMM over T rows instead of T x one row: 4 launches per chain instead of 4
+        per step; reference: diffusion_model_unet.py:1895-1905 + :686-690 once per step).  `DiffusionInferer.sample` computes it before its loop
+        and hands row i to step i (`_time_rows_row`, consumed by the next forward).  None for class-conditional models (their rows depend on the
+        labels of the batch)."""
+        if self.num_class_embeds is not None:
+            return None
+        with torch.no_grad():
+            return self._temb_stacked(timesteps, None)
+
+    def _temb_split(self, rows: torch.Tensor):
+        out, off = {}, 0
+        for b in self._resnets_in_order():
+            out[id(b)] = rows[:, off:off + b.out_channels]
+            off += b.out_channels
+        if off != rows.shape[1]:
+            raise ValueError("timestep rows do not match this network's ResnetBlocks")
+        return out
+
+    def _temb_stacked(self, timesteps: torch.Tensor, class_labels: Optional[torch.Tensor]) -> torch.Tensor:
         f32 = torch.float32
         t_emb = ops.timestep_embedding(timesteps, self.block_out_channels[0], dtype=f32)
         l0, l2 = self.time_embed[0], self.time_embed[2]
@@ -275,12 +298,7 @@ class _TimestepPath:
         w = ops.packed_cat_weight([b.time_emb_proj.weight for b in blocks], f32)
         sizes = [b.out_channels for b in blocks]
         bias = ops.cat_f32([b.time_emb_proj.bias for b in blocks], sizes, emb.device)
-        rows = ops.conv(emb.unsqueeze(0), None, bias, kernel=1, pre_act="silu", packed=w, cout=sum(sizes)).squeeze(0)
-        out, off = {}, 0
-        for b, s in zip(blocks, sizes):
-            out[id(b)] = rows[:, off:off + s]
-            off += s
-        return out
+        return ops.conv(emb.unsqueeze(0), None, bias, kernel=1, pre_act="silu", packed=w, cout=sum(sizes)).squeeze(0)
 
 
 
@@ -381,6 +399,7 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
         residuals = list(down_block_additional_residuals or ()) + ([] if mid_block_additional_residual is None else [mid_block_additional_residual])
         if self._wants_grad(x) or (self.supports_training() and torch.is_grad_enabled() and any(r.requires_grad for r in residuals)):
             # (ControlNet residuals that require grad: a ControlNet training against this -- usually frozen -- network)
+            self.__dict__.pop("_time_rows_row", None)  # (a sampling loop's hand-over is for the inference path only)
             return self.forward_train(x, timesteps, context=context, class_labels=class_labels,
                                       down_block_additional_residuals=down_block_additional_residuals,
                                       mid_block_additional_residual=mid_block_additional_residual)
@@ -407,7 +426,8 @@ class DiffusionModelUNet(_TimestepPath, nn.Module):
         if timesteps.shape[0] not in (1, x.shape[0]):
             raise ValueError("timesteps must have one entry, or one per batch element")
         with torch.no_grad():
-            rows = self._temb_rows(timesteps.to(x.device), class_labels)
+            pre = self.__dict__.pop("_time_rows_row", None)  # this step's row of time_rows_table(), handed over by the sampling loop
+            rows = self._temb_rows(timesteps.to(x.device), class_labels) if pre is None else self._temb_split(pre)
             if context is not None:
                 ops.require_device(context)
                 context = ops.cast(context.contiguous(), dtype)

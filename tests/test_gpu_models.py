@@ -275,6 +275,49 @@ def test_captured_forward_is_reused_across_sample_calls_and_refreshed_when_param
     assert torch.equal(got4, want4) and not torch.equal(got4, want3)
 
 
+def test_sampling_loop_takes_its_timestep_rows_from_one_batched_pass():
+    """(round 5) `DiffusionInferer.sample` computes the timestep rows of the whole chain once (`DiffusionModelUNet.time_rows_table`: embedding, two-layer
+    MLP and the stacked `time_emb_proj` GEMM over all T timesteps -- 4 launches per chain instead of 4 per step; reference:
+    diffusion_model_unet.py:1895-1905, :686-690 once per step) and hands row i to step i.  The table equals the per-step rows to fp32 rounding
+    (another GEMM row count = another summation order), a chain through sample() equals the manual chain of single forwards to the same bar, nothing
+    is left on the model afterwards, and a class-conditional model (rows depend on the labels) takes the per-step path."""
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    from generativemodels_amd.networks.schedulers import DDIMScheduler
+    fx = load_fixture("chain_c1a3d")
+    m = _build_unet(fx)
+    sched = DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
+    sched.set_timesteps(5)
+    steps = [int(t) for t in sched.timesteps.tolist()]
+    t_dev = torch.tensor(steps, dtype=torch.float32, device=DEV)
+    table = m.time_rows_table(t_dev)
+    assert table is not None and table.shape[0] == len(steps) and table.dtype == torch.float32
+    for i in range(len(steps)):
+        one = m._temb_stacked(t_dev[i:i + 1], None)
+        scale = max(1.0, one.abs().max().item())
+        assert (table[i:i + 1] - one).abs().max().item() <= 2e-6 * scale, i
+    noise = _dev(fx["noise"])
+    inf = DiffusionInferer(sched, use_hip_graph=False)
+    got = inf.sample(noise, m, sched, verbose=False)
+    assert "_time_rows_row" not in m.__dict__
+    x = noise
+    with torch.no_grad():
+        for i, t in enumerate(steps):
+            x, _ = sched.step(m(x, timesteps=t_dev[i:i + 1]), t, x)
+    _fp32_close(got, x.cpu(), "sample() with the batched timestep rows vs single forwards", factor=1.0)
+    # a row handed over and never consumed must not leak into a later direct call
+    m._time_rows_row = table[0:1]
+    try:
+        inf.sample(noise[:, :, :1], m, sched, verbose=False)  # wrong shape: raises inside the first forward
+    except Exception:
+        pass
+    assert "_time_rows_row" not in m.__dict__
+    torch.manual_seed(3)
+    mc = DiffusionModelUNet(spatial_dims=2, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 32), attention_levels=(False, False),
+                            norm_num_groups=32, num_class_embeds=4).to(DEV).eval()
+    assert mc.time_rows_table(t_dev) is None
+
+
 def test_ddpm_chain_with_seeded_cpu_noise_matches_reference():
     """DDPM draws its noise from the global CPU generator (ddpm.py:244-247): same seed => same chain as the reference."""
     from generativemodels_amd.inferers import DiffusionInferer

@@ -190,7 +190,7 @@ def test_captured_forward_cache_keys_on_shapes_and_parameter_versions(monkeypatc
     class Recorder:
         signature = staticmethod(I._GraphedUNet.signature)
 
-        def __init__(self, model, x, t, ctx):
+        def __init__(self, model, x, t, ctx, row=None):
             built.append((id(model), tuple(x.shape), None if ctx is None else tuple(ctx.shape)))
 
     monkeypatch.setattr(I, "_GraphedUNet", Recorder)
