@@ -1201,6 +1201,16 @@ def test_attention_backward_fused_at_c2_size_agrees_with_the_composed_path():
         assert torch.isfinite(a.float()).all()
         _close(a, c, 1e-2, f"32 768 x 256: fused vs composed d{name}")
         _close(b_, a, 2e-3, f"32 768 x 256: own LSE sweep vs the forward kernel's LSE d{name}")
+    # size-independent identities of the attention backward (no reference needed): with dS = P (dP - D) scale, dQ = dS K and dK = dS^T Q give
+    # <dQ, Q> = <dS, Q K^T> = <dK, K>; and sum_k P (dP - D) = 0 per query gives <dV, V> = sum_q D[q] = <dO, O>
+    dq, dk, dv = (t.double() for t in fused)
+    qd_, kd_, vd_, od_, gd_ = (t.double() for t in (q, k, v, o, go))
+    a, b_ = (dq * qd_).sum().item(), (dk * kd_).sum().item()
+    norm = (dq.norm() * qd_.norm()).item()
+    assert abs(a - b_) <= 2e-3 * norm, f"<dQ, Q> = {a:.6e} vs <dK, K> = {b_:.6e} (|dQ||Q| = {norm:.3e})"
+    c, d_ = (dv * vd_).sum().item(), (gd_ * od_).sum().item()
+    norm = (dv.norm() * vd_.norm()).item()
+    assert abs(c - d_) <= 2e-3 * norm, f"<dV, V> = {c:.6e} vs <dO, O> = {d_:.6e} (|dV||V| = {norm:.3e})"
 
 
 @pytest.mark.parametrize("b,lq,lk,heads,dh", [(1, 700, 700, 2, 64), (2, 333, 200, 1, 128), (1, 1100, 520, 1, 32)])
