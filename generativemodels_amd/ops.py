@@ -1023,7 +1023,7 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             off += c_t
         return conv(xa, weight, bias, kernel=kernel, stride=stride, padding=padding, dilation=dilation, pad_hi=pad_hi, upsample=upsample,
                     transposed=transposed, output_padding=output_padding, rowvec=rowvec, res=res, post_act=post_act, out=out, packed=packed,
-                    cout=cout, force_cfg=force_cfg, want_stats=want_stats, skip=skip, allow_subpixel=allow_subpixel, ksplit=ksplit)
+                    cout=cout, force_cfg=force_cfg, want_stats=want_stats, skip=skip, allow_subpixel=allow_subpixel, ksplit=ksplit, vt=vt)
 
     def tup(v):
         v = tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * nsp
@@ -1243,6 +1243,8 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             raise ValueError(f"configuration {force_cfg} does not cover this convolution")
         if x2 is not None:
             return two_pass()  # only the LDS-DMA kernels read a concatenated input in place
+        # (round 5: NOT the large 1x1 projections -- the q | k | v projection of C2's mid-block attention, 32 768 x 256 -> 768, is 102 us fused against
+        #  62 + 12 two-pass in isolation, and 0.109 against 0.081 + 0.035 inside the forward: nothing, profiles/r05_qkv_projection_c2.txt)
         if pre is not None and force_cfg is None and cout > 16 and math.prod(k) > 1 and not fuse_gn_prologue(x):
             return two_pass()  # a large ResnetBlock convolution: the HBM-bound gm_gn_apply pass + the prologue-free kernel (which still fuses
             # the shortcut) beats both the in-LDS and the register-staged prologue (GN_APPLY_POLICY, DMA_FUSED_PROLOGUE)
