@@ -805,3 +805,39 @@ def test_bench_module_imports_and_its_power_sampler_degrades_without_a_gpu():
     out = ps.stop()
     assert out is None or (out["mean_w"] > 0 and out["samples"] >= 1)
     assert set(bench.MFMA_BF16_SUSTAINED_TFLOPS.values()) == {1863.0, 1490.0, 1621.0}  # profiles/r04_mfma_power_ceiling.txt
+
+
+def test_attention_backward_policy_and_timestep_row_hand_over_host_side():
+    """Round 5 host logic without a GPU: which attention shapes train through the fused LDS-DMA backward (`autograd._fused_backward_serves`: bf16, head
+    dim 64 / 128 / 256, at least ATTENTION_BWD_FUSED_MIN_TOKENS on either side), that the fused entry point has no CPU fallback, and the split of a
+    stacked timestep row (`DiffusionModelUNet.time_rows_table` / `_time_rows_row`) into per-ResnetBlock views -- rejecting a row of the wrong width,
+    None for class-conditional networks."""
+    from generativemodels_amd import autograd as A, ops
+    bf, f32 = torch.bfloat16, torch.float32
+    q = lambda l, c, dt=bf: torch.zeros((1, l, c), dtype=dt)
+    assert A._fused_backward_serves(q(4096, 256), q(4096, 256), 1)
+    assert A._fused_backward_serves(q(4096, 512), q(77, 512), 8)                       # cross-attention: the longer side counts
+    assert A._fused_backward_serves(q(256, 128), q(256, 128), 2)
+    assert not A._fused_backward_serves(q(255, 128), q(128, 128), 2)                   # below the measured bound
+    assert not A._fused_backward_serves(q(4096, 256, f32), q(4096, 256, f32), 1)       # fp32: the fp32-MFMA kernels
+    assert not A._fused_backward_serves(q(4096, 256), q(4096, 256), 8)                 # head dim 32: the composed bf16 path
+    assert not A._fused_backward_serves(q(4096, 192), q(4096, 192), 1)                 # head dim 192: padded to 256 by the caller first
+    with pytest.raises(RuntimeError, match="MI355X"):
+        ops.attention_backward_fused(q(512, 64), q(512, 64), q(512, 64), q(512, 64), q(512, 64), 1, 0.125)  # CPU tensors: no fallback
+    torch.manual_seed(0)
+    m = DiffusionModelUNet(spatial_dims=2, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 64), attention_levels=(False, False),
+                           norm_num_groups=32)
+    blocks = m._resnets_in_order()
+    total = sum(b.out_channels for b in blocks)
+    row = torch.arange(total, dtype=f32).unsqueeze(0)
+    parts = m._temb_split(row)
+    off = 0
+    for b in blocks:
+        assert torch.equal(parts[id(b)], row[:, off:off + b.out_channels]) and parts[id(b)].data_ptr() == row[:, off:].data_ptr()
+        off += b.out_channels
+    with pytest.raises(ValueError):
+        m._temb_split(row[:, :-1])
+    mc = DiffusionModelUNet(spatial_dims=2, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 32), attention_levels=(False, False),
+                            norm_num_groups=32, num_class_embeds=3)
+    assert mc.time_rows_table(torch.zeros(4)) is None
+    assert DiffusionInferer.BATCHED_TIME_ROWS is True
