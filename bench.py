@@ -1,7 +1,8 @@
 """bench.py -- headline benchmark of the MI355X sampling path (BASELINE.json: 3D volumes/sec, DDIM 50-step sample of
 1x128^3 volumes; UNet forward ms/step), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            # N = 1
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N = 1 runs in this process; N > 1 re-executes itself under
+                                                                   # torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (config C2): DiffusionModelUNet(3, 1, 1, num_channels=(64,128,256), 2 res blocks, attention in the
@@ -14,9 +15,11 @@ on the data path (weak scaling, no collective); the barrier / all-reduce below o
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   "roofline":     the dominant kernel (implicit-GEMM convolution) -- algorithmic FLOPs per launch / HIP-event time per launch
                   over one instrumented forward, against the dense bf16 MFMA peak;
-  "cpu_baseline": the CPU oracle (oracle/restatement.py, the reference algorithm restated on torch-CPU fp32) timed on this
-                  box's host cores on a bounded sample (median of three of the 50 steps at full size, at the best thread count of a
-                  sweep), extrapolated to volumes/s -- and its t = 500 prediction compared with the GPU forward of the same volume."""
+  "cpu_baseline": kind "reference" = the UNMODIFIED reference modules (oracle/_ref: /root/reference byte-compiled by oracle/make_ref.py,
+                  a build output that travels to the GPU box like the .so) or, where that is absent, kind "port" = oracle/restatement.py
+                  (the reference algorithm restated on torch-CPU fp32); timed on this box's host cores on a bounded sample (median of
+                  three of the 50 steps at full size, at the best thread count of a sweep), extrapolated to volumes/s -- and its
+                  t = 500 prediction compared with the GPU forward of the same volume."""
 from __future__ import annotations
 
 import argparse
@@ -164,6 +167,42 @@ def measured_hbm_traffic(label: str, dtype) -> dict:
     return dict(traffic=None, traffic_note=f"the committed PMC pass holds no row for {sym}")
 
 
+def needs_self_launch(gpus: int, env) -> bool:
+    """True when this process was started as plain `python bench.py --gpus N` (no launcher environment) and has to become N ranks itself:
+    N > 1, or GM_BENCH_SELF_LAUNCH=1 (the GPU suite forces the path at N = 1, the only size a 1-GPU box can run)."""
+    if "WORLD_SIZE" in env or "RANK" in env:
+        return False
+    return gpus > 1 or env.get("GM_BENCH_SELF_LAUNCH", "0") == "1"
+
+
+def self_launch_command(gpus: int, argv, port: int | None = None):
+    """The command (and environment additions) `python bench.py --gpus N ...` re-executes itself as: one rank per GPU of THIS node under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), the reference's own multi-GPU entry
+    (tutorials/generative/distributed_training/ddpm_training_ddp.py:117-127,199 is launched the same way by torchrun)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *argv]
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),  # dmabuf IPC: the only form the host driver supports
+           "GM_BENCH_SELF_LAUNCHED": "1", "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(gpus, 1))))}
+    return cmd, env
+
+
+def self_launch(gpus: int, argv) -> int:
+    import subprocess
+
+    if torch.cuda.is_available() and torch.cuda.device_count() < gpus:
+        raise SystemExit(f"--gpus {gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
+    cmd, extra = self_launch_command(gpus, argv)
+    env = dict(os.environ)
+    env.pop("GM_BENCH_SELF_LAUNCH", None)
+    env.update(extra)
+    return subprocess.run(cmd, env=env).returncode  # rank 0 of the child job prints the ONE JSON line on this process's stdout
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +215,8 @@ def main() -> None:
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "small", "off"])
     args = ap.parse_args()
 
+    if needs_self_launch(args.gpus, os.environ):  # `python bench.py --gpus N` as the driver calls it: become N ranks under torch.distributed.run
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -353,7 +394,8 @@ def main() -> None:
                                    f"sampling of 1x1x{args.size}^3 volumes, 1 volume per GPU per step",
                        "volumes_per_gpu_per_step": 1, "inference_steps": args.inference_steps,
                        "parallelism": f"{world} independent replicas (batch-sharded, no data-path collective)", "hip_graph": bool(args.graph),
-                       "process_group": None if dist is None else f"nccl (RCCL), world_size {world}"},
+                       "process_group": None if dist is None else f"nccl (RCCL), world_size {world}",
+                       "self_launched": os.environ.get("GM_BENCH_SELF_LAUNCHED") == "1"},
             "unet_forward_ms": None if fwd_ms is None else round(fwd_ms, 3),
             "ms_per_ddim_iteration": round(1e3 * elapsed / args.steps / args.inference_steps, 3),
             "output_finite": finite,

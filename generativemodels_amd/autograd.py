@@ -436,7 +436,9 @@ class _Attention(torch.autograd.Function):
         dh = q.shape[2] // heads
         go = go.contiguous()
         if _fused_backward_serves(q, k, heads):
-            return (*ops.attention_backward_fused(q, k, v, o, go, heads, scale, lse=rest[0] if rest else None), None, None)
+            grads = ops.attention_backward_fused(q, k, v, o, go, heads, scale, lse=rest[0] if rest else None, or_none=True)
+            if grads is not None:  # (None: the library declined -- more than 65 535 (sample, head) pairs, very wide rows: the round-4 path serves those)
+                return (*grads, None, None)
         if dh in ops.ATTENTION_BWD_HEAD_DIMS:
             return (*_attention_backward(q, k, v, o, go, heads, scale), None, None)
         # any other head dim (<= 256: the forward's bound): zero-pad every head to the next width the kernels are built for.  Zero channels add

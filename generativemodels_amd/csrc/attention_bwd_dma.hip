@@ -370,9 +370,11 @@ static long long abd_al(long long x) { return (x + 255) & ~255LL; }
 
 static bool abd_eligible(const GmAttnBwdDesc& d) {
   auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-  auto ok = [&](const void* p, long long ld) { return p && ld % 8 == 0 && al(p, 16); };
+  // (row strides below 2^24 elements: the DMA lane offsets row * ld * 2 are 32-bit, as attn_dma_eligible bounds k_ld for the forward; at most 65 535
+  //  (sample, head) pairs: they are a grid dimension)
+  auto ok = [&](const void* p, long long ld) { return p && ld % 8 == 0 && ld > 0 && ld < (1LL << 24) && al(p, 16); };
   const long long lmax = abd_pad64(d.Lq > d.Lk ? d.Lq : d.Lk);
-  return d.dtype == GM_BF16 && (d.dh == 64 || d.dh == 128 || d.dh == 256) && d.Lq >= 1 && d.Lk >= 1 && (long long)d.dh * lmax * 2 < (1LL << 31) &&
+  return d.dtype == GM_BF16 && (long long)d.B * d.H <= 65535 && (d.dh == 64 || d.dh == 128 || d.dh == 256) && d.Lq >= 1 && d.Lk >= 1 && (long long)d.dh * lmax * 2 < (1LL << 31) &&
          ok(d.q, d.q_ld) && ok(d.k, d.k_ld) && ok(d.v, d.v_ld) && ok(d.o, d.o_ld) && ok(d.go, d.go_ld) && ok(d.dq, d.dq_ld) && ok(d.dk, d.dk_ld) &&
          ok(d.dv, d.dv_ld);
 }

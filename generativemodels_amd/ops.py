@@ -1569,7 +1569,7 @@ ATTENTION_BWD_FUSED_HEAD_DIMS = (64, 128, 256)
 
 
 def attention_backward_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, go: torch.Tensor, heads: int, scale: float,
-                             lse: Optional[torch.Tensor] = None):
+                             lse: Optional[torch.Tensor] = None, or_none: bool = False):
     """(dq, dk, dv) of o = softmax(scale q k^T) v by the fused bf16 flash backward on the LDS-DMA structure (gm_attention_backward_fused,
     csrc/attention_bwd_dma.hip): scores recomputed per tile on bf16 MFMA, nothing L x L in HBM, deterministic.  bf16 (B, L, heads * dh) operands,
     dh in ATTENTION_BWD_FUSED_HEAD_DIMS; lse: optional fp32 (B, heads, Lq) log-sum-exp of the scaled scores (else one more sweep computes it).
@@ -1591,7 +1591,9 @@ def attention_backward_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, 
     d.B, d.H, d.Lq, d.Lk, d.dh = b, heads, lq, lk, dh
     d.scale, d.dtype = float(scale), dt_code(q.dtype)
     nbytes = lib().gm_attention_backward_fused_workspace_bytes(C.byref(d))
-    if nbytes <= 0:
+    if nbytes <= 0:  # the library's own eligibility test (abd_eligible) is the one place the decision is made: callers with another path ask with or_none
+        if or_none:
+            return None
         raise ValueError("attention_backward_fused: operands not served by the fused bf16 kernels (alignment / size)")
     if lse is not None:
         if lse.dtype != torch.float32 or lse.numel() != b * heads * lq or not lse.is_contiguous():

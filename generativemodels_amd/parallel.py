@@ -173,6 +173,8 @@ class GradientReducer:
         (the C4 step: VERDICT r3 item 8).  A parameter outside the learned set that produces a gradient later makes `finish()` raise."""
         import torch.distributed as dist
 
+        engine_fires_hooks_for_undefined_grads()  # the one-time probe runs HERE, outside any backward: `direct_grad_hook` (called from inside a custom
+                                                  # Function.backward on the engine's device thread, possibly under a HIP-graph capture) only reads it (ADVICE r5)
         self.usage_check_every = int(usage_check_every)
         self.static_graph = bool(static_graph)
         self._static_stage = 0   # 0: learning the used set; 1: recording the arrival order (full hooks); 2: one hook per bucket
@@ -288,6 +290,7 @@ class GradientReducer:
         """Zero every gradient with one fill per bucket and make `.grad` of every expected parameter its bucket view BEFORE backward: autograd
         (or, for fp32 parameters, the weight-gradient kernel itself: `direct_grad_hook`) then accumulates in place and no gradient is ever
         copied into a bucket.  An optimizer's zero_grad(set_to_none=True) also works -- the next gradient is then copied into its view on arrival."""
+        self._exchanged_in_graph = False  # a new step begins: a replay whose finish() was skipped must not excuse THIS step's exchange (ADVICE r5)
         if not self.active:
             for p in self.params:
                 p.grad = None
@@ -338,6 +341,7 @@ class GradientReducer:
         """The engine's post-accumulate hook: fires once per parameter and backward pass, after every use of the parameter in the graph has
         delivered its gradient -- also when the backward kernels accumulated in place and handed autograd None (torch >= 2.10 runs the
         AccumulateGrad node with an undefined gradient)."""
+        self._exchanged_in_graph = False  # an eager backward is running: its exchange is finish()'s to join, whatever a replay left behind
         if j is None:
             j = self._index[id(p)]
             i, view = self._bucket_of[id(p)], self._view[id(p)]
@@ -367,6 +371,7 @@ class GradientReducer:
     def _on_bucket(self, i: int) -> None:
         """static_graph, third step on: the hook of bucket i's last-arriving parameter.  Every expected gradient of the bucket is in by now
         (same graph, same order as the recorded step); a `.grad` that is not the bucket view any more is copied back in first."""
+        self._exchanged_in_graph = False
         if not self._sync:
             return
         if self._work[i] is not None:
@@ -423,7 +428,11 @@ class GradientReducer:
             return
         if self._exchanged_in_graph:  # the step was a replay of graphs.GraphedForwardBackward with the exchange captured: averaged gradients are in place
             self._exchanged_in_graph = False
-            return
+            if self._next == 0 and not any(self._seen) and all(w is None for w in self._work):
+                return
+            # (unreachable through the hooks, which clear the flag; kept as the explicit statement of when the early return is legal)
+            raise RuntimeError("GradientReducer.finish(): an eager backward ran after a graph-replayed step whose exchange was captured; its gradients are "
+                               "not reduced yet -- call finish() once per step")
         if not self._sync:
             raise RuntimeError("GradientReducer.finish() inside no_sync()")
         dist = self._dist

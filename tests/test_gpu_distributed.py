@@ -43,3 +43,18 @@ def test_bench_under_torch_distributed_run_with_one_gpu():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["output_finite"] and line["scaling"] == "weak"
     assert line["config"]["process_group"] == "nccl (RCCL), world_size 1"
+
+
+def test_bench_launches_itself_the_way_the_driver_calls_it():
+    """`python bench.py --gpus N` with no launcher environment: the process re-executes itself under torch.distributed.run (forced at N = 1 here by
+    GM_BENCH_SELF_LAUNCH=1 -- at N > 1 it is automatic) and rank 0 of the child job prints the ONE JSON line on the parent's stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GM_BENCH_SELF_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--size", "32", "--inference-steps", "2",
+                        "--cpu-baseline", "off"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["output_finite"]
+    assert line["config"]["process_group"] == "nccl (RCCL), world_size 1" and line["config"]["self_launched"] is True

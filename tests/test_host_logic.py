@@ -807,6 +807,31 @@ def test_bench_module_imports_and_its_power_sampler_degrades_without_a_gpu():
     assert set(bench.MFMA_BF16_SUSTAINED_TFLOPS.values()) == {1863.0, 1490.0, 1621.0}  # profiles/r04_mfma_power_ceiling.txt
 
 
+def test_bench_self_launch_argv_and_environment():
+    """`python bench.py --gpus N` as the driver calls it (no launcher environment): N > 1 -- or GM_BENCH_SELF_LAUNCH=1 at N = 1 -- re-executes
+    itself under torch.distributed.run with one rank per GPU, rendezvous on 127.0.0.1, the original arguments handed on unchanged; a process
+    that already IS a rank (WORLD_SIZE / RANK set by the launcher) never launches again."""
+    import sys
+
+    import bench
+
+    assert not bench.needs_self_launch(1, {})
+    assert bench.needs_self_launch(2, {}) and bench.needs_self_launch(8, {"PATH": "/usr/bin"})
+    assert bench.needs_self_launch(1, {"GM_BENCH_SELF_LAUNCH": "1"})
+    assert not bench.needs_self_launch(8, {"WORLD_SIZE": "8", "RANK": "3"})
+    assert not bench.needs_self_launch(1, {"GM_BENCH_SELF_LAUNCH": "1", "RANK": "0", "WORLD_SIZE": "1"})  # the child of a forced self-launch
+    argv = ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    cmd, env = bench.self_launch_command(8, argv, port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(bench.__file__ if bench.__file__ in cmd else __import__("os").path.abspath(bench.__file__))
+    assert cmd[i + 1:] == argv
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["GM_BENCH_SELF_LAUNCHED"] == "1" and int(env["OMP_NUM_THREADS"]) >= 1
+    cmd2, _ = bench.self_launch_command(2, [])  # a free port is picked when none is given
+    assert 1024 < int(cmd2[cmd2.index("--master-port") + 1]) < 65536
+
+
 def test_attention_backward_policy_and_timestep_row_hand_over_host_side():
     """Round 5 host logic without a GPU: which attention shapes train through the fused LDS-DMA backward (`autograd._fused_backward_serves`: bf16, head
     dim 64 / 128 / 256, at least ATTENTION_BWD_FUSED_MIN_TOKENS on either side), that the fused entry point has no CPU fallback, and the split of a
