@@ -15,11 +15,11 @@ on the data path (weak scaling, no collective); the barrier / all-reduce below o
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   "roofline":     the dominant kernel (implicit-GEMM convolution) -- algorithmic FLOPs per launch / HIP-event time per launch
                   over one instrumented forward, against the dense bf16 MFMA peak;
-  "cpu_baseline": kind "reference" = the UNMODIFIED reference modules (oracle/_ref: /root/reference byte-compiled by oracle/make_ref.py,
-                  a build output that travels to the GPU box like the .so) or, where that is absent, kind "port" = oracle/restatement.py
-                  (the reference algorithm restated on torch-CPU fp32); timed on this box's host cores on a bounded sample (median of
-                  three of the 50 steps at full size, at the best thread count of a sweep), extrapolated to volumes/s -- and its
-                  t = 500 prediction compared with the GPU forward of the same volume."""
+  "cpu_baseline": kind "port" = oracle/restatement.py (the reference algorithm restated on torch-CPU fp32, pinned to outputs of the unmodified
+                  reference by tests/golden/ -- at this size by c2_fullsize_ref.pt; the reference itself is Python and does not travel to the
+                  GPU box), timed on this box's host cores on a bounded sample (median of three of the 50 steps at full size, at the best
+                  thread count of a sweep), extrapolated to volumes/s -- and its t = 500 prediction compared with the GPU forward of the
+                  same volume and with the reference's own output of it."""
 from __future__ import annotations
 
 import argparse
@@ -71,7 +71,23 @@ class PowerSampler:
                     self.cap_w = int(open(os.path.join(os.path.dirname(self.path), "power1_cap")).read()) / 1e6
                 except Exception:
                     self.cap_w = None
-        self.samples, self._stop, self._thread = [], False, None
+        self.samples, self.clocks, self._stop, self._thread = [], [], False, None
+
+    def _read_sclk(self):
+        """current shader clock in MHz (rsmi_dev_gpu_clk_freq_get, RSMI_CLK_TYPE_SYS) or None: what the power management leaves of the clock while the
+        package sits at its cap -- the throttle evidence next to the watts"""
+        if self._rsmi is None:
+            return None
+        import ctypes
+
+        class Freqs(ctypes.Structure):  # rsmi_frequencies_t
+            _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32), ("frequency", ctypes.c_uint64 * 33)]
+
+        f = Freqs()
+        if self._rsmi.rsmi_dev_gpu_clk_freq_get(ctypes.c_uint32(self._idx), ctypes.c_uint32(0), ctypes.byref(f)) != 0 or f.num_supported == 0:
+            return None
+        cur = f.frequency[min(f.current, f.num_supported - 1, 32)]
+        return cur / 1e6 if cur > 0 else None
 
     def _read(self):
         if self._rsmi is not None:
@@ -86,6 +102,10 @@ class PowerSampler:
                 w = self._read()
                 if w:
                     self.samples.append(w)
+                if len(self.samples) % 4 == 1:  # (every 200 ms)
+                    c = self._read_sclk()
+                    if c:
+                        self.clocks.append(c)
             except Exception:
                 pass
             time.sleep(0.05)
@@ -103,8 +123,15 @@ class PowerSampler:
         if not self.samples:
             return None
         s = sorted(self.samples)
-        return dict(mean_w=round(sum(s) / len(s), 1), median_w=round(s[len(s) // 2], 1), max_w=round(s[-1], 1), cap_w=self.cap_w, samples=len(s),
-                    source=self.kind)
+        out = dict(mean_w=round(sum(s) / len(s), 1), median_w=round(s[len(s) // 2], 1), max_w=round(s[-1], 1), cap_w=self.cap_w, samples=len(s),
+                   source=self.kind)
+        if self.cap_w:  # how much of the timed region ran AT the cap: the convolutions do, the bandwidth-bound passes between them do not
+            out["frac_samples_ge_95pct_of_cap"] = round(sum(1 for w in s if w >= 0.95 * self.cap_w) / len(s), 3)
+            out["frac_samples_ge_90pct_of_cap"] = round(sum(1 for w in s if w >= 0.90 * self.cap_w) / len(s), 3)
+        if self.clocks:
+            c = sorted(self.clocks)
+            out["sclk_mhz"] = dict(mean=round(sum(c) / len(c)), min=round(c[0]), max=round(c[-1]), samples=len(c), source="rsmi_dev_gpu_clk_freq_get(RSMI_CLK_TYPE_SYS)")
+        return out
 
 
 C2 = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(64, 128, 256), attention_levels=(False, False, False),
@@ -318,7 +345,9 @@ def main() -> None:
                             frac_of_best_lds_fed_ceiling=round(roof["achieved"] / best_lds, 4), frac_of_register_resident_ceiling=round(roof["achieved"] / regs, 4),
                             sustained_peak_note="bf16 MFMA rate the chip sustains at its package power cap on random operands (tools/mfma_power.hip, "
                                                 "profiles/r04_mfma_power_ceiling.txt): " + json.dumps(MFMA_BF16_SUSTAINED_TFLOPS) +
-                                                "; this benchmark runs at the cap (package_power_w); `frac` is against the nominal dense peak")
+                                                "; the convolutions of this benchmark run at the cap (1 357-1 395 W per launch loop, profiles/r05_clock_energy.json), the "
+                                                "bandwidth-bound passes between them (gn_apply, ~13 % of an iteration) do not: package_power_w.mean_w is the time-weighted mix and "
+                                                "frac_samples_ge_95pct_of_cap the share of 50-ms samples at the cap; `frac` is against the nominal dense peak")
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----------------------------------------------------
     # (1) thread-count sweep at 1/8 of the voxels (oneDNN oversubscribes on many-core hosts: 256 threads measured 2x slower than 8 in
@@ -327,22 +356,14 @@ def main() -> None:
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline != "off":
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import restatement as R  # test infrastructure: the CPU statement of the reference algorithm (checker / baseline only)
-        import ref_loader          # ... and, where the reference tree exists (the build container), the UNMODIFIED reference itself
+        import restatement as R  # test infrastructure: the CPU statement of the reference algorithm (checker / baseline only; never on the product path)
 
         cores = os.cpu_count() or 1
         sd32 = {k: v.float() for k, v in sd.items()}
-        gen = ref_loader.load_reference()
-        if gen is not None:  # kind = "reference": the reference's own modules on the host cores
-            ref_net = gen.networks.nets.DiffusionModelUNet(**C2).eval()
-            ref_net.load_state_dict({k: v.float() for k, v in sd.items()})
-            ref_sched = gen.networks.schedulers.DDIMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0005, beta_end=0.0195, clip_sample=False)
-            ref_sched.set_timesteps(args.inference_steps)
-            cpu_forward = lambda xx, tt_: ref_net(xx, tt_)                                         # noqa: E731
-            cpu_step = lambda eps_, t_, xx: ref_sched.step(eps_, t_, xx)                           # noqa: E731
-        else:                # kind = "port": the restatement (the GPU box has no /root/reference)
-            cpu_forward = lambda xx, tt_: R.unet_forward(sd32, C2, xx, tt_)                        # noqa: E731
-            cpu_step = lambda eps_, t_, xx: R.ddim_step(sched.alphas_cumprod, 1000, args.inference_steps, eps_, t_, xx, clip_sample=False)  # noqa: E731
+        # kind = "port": the reference is Python and does not travel to the GPU box in any form; the restatement is pinned to it by the golden
+        # fixtures (tests/test_oracle_golden.py) -- at THIS size by tests/golden/c2_fullsize_ref.pt, compared again below
+        cpu_forward = lambda xx, tt_: R.unet_forward(sd32, C2, xx, tt_)                        # noqa: E731
+        cpu_step = lambda eps_, t_, xx: R.ddim_step(sched.alphas_cumprod, 1000, args.inference_steps, eps_, t_, xx, clip_sample=False)  # noqa: E731
         size = args.size if args.cpu_baseline == "full" else min(args.size, 48)
         x = torch.randn((1, 1, size, size, size), generator=torch.Generator().manual_seed(7))
         half = max(size // 2, 8)
@@ -367,16 +388,21 @@ def main() -> None:
                     eps500 = eps
         cpu_s = sorted(times)[len(times) // 2]
         scale = (args.size / size) ** 3
-        cpu = dict(value=round(1.0 / (cpu_s * scale * args.inference_steps), 8), unit="volumes/s", cores=best, kind="reference" if gen is not None else "port",
+        cpu = dict(value=round(1.0 / (cpu_s * scale * args.inference_steps), 8), unit="volumes/s", cores=best, kind="port",
                    host_cores=cores, seconds_per_step=round(cpu_s * scale, 3), step_seconds=[round(v, 2) for v in times],
                    thread_sweep_seconds_at_half_edge=sweep,
-                   sample=f"median of {len(times)} DDIM steps (UNet forward + scheduler step, fp32, " + ("the unmodified reference modules" if gen is not None else "torch-CPU oracle") + f", t = 980/500/20) at 1x1x{size}^3 on "
+                   sample=f"median of {len(times)} DDIM steps (UNet forward + scheduler step, fp32, torch-CPU oracle, t = 980/500/20) at 1x1x{size}^3 on "
                           f"{best} threads (best of a sweep over {sorted(sweep)} at 1x1x{half}^3)"
                           + ("" if size == args.size else f", scaled x{scale:.0f} to {args.size}^3 by voxel count") + f", x{args.inference_steps} steps",
-                   port_note="kind=reference: generative.networks.nets.DiffusionModelUNet + DDIMScheduler.step of the unmodified reference tree" if gen is not None else
-                             "kind=port: oracle/restatement.py, the reference algorithm restated on torch-CPU (the GPU box has no /root/reference); "
-                             "in the build container (8 cores) it runs the C2 forward at 1x1x64^3 in 1.09x the time of the unmodified reference module, "
-                             "bit-equal output (tools/oracle_vs_reference_time.py, profiles/r02_oracle_vs_reference_time.json)")
+                   port_note="kind=port: oracle/restatement.py, the reference algorithm restated on torch-CPU (the reference is Python and does not travel to the "
+                             "GPU box); in the build container (8 cores) it runs the C2 forward at 1x1x64^3 in 1.09x the time of the unmodified reference module "
+                             "(tools/oracle_vs_reference_time.py, profiles/r02_oracle_vs_reference_time.json)")
+        fx_path = os.path.join(ROOT, "tests", "golden", "c2_fullsize_ref.pt")  # outputs of the unmodified reference at this very size (oracle/make_golden_c2_fullsize.py)
+        if eps500 is not None and size == args.size == 128 and os.path.exists(fx_path):
+            fx = torch.load(fx_path, weights_only=False)
+            L = fx["lattice"]
+            cpu.update(port_vs_reference_max_abs_diff=round((eps500[..., ::L, ::L, ::L] - fx["fp32"][500]["lattice"]).abs().max().item(), 8),
+                       port_vs_reference_note="this run's t = 500 oracle output against the reference's own (every-4th-voxel lattice of tests/golden/c2_fullsize_ref.pt)")
         if eps500 is not None and size == args.size and eps_gpu is not None and args.dtype == "bf16":
             err = (eps_gpu.reshape(eps500.shape) - eps500).abs()
             sigma = eps500.std().item()
@@ -403,8 +429,11 @@ def main() -> None:
             "joules_per_volume": None if not power_stats else round(power_stats["mean_w"] * elapsed / args.steps, 1),  # what bounds this loop: it runs at the power cap
             "cpu_baseline": cpu,
             "speedup_vs_cpu": None if cpu is None else round(vol_s / cpu["value"], 1),
+            # per kernel label: algorithmic FLOP and HBM rates of one forward; frac_mfma / frac_hbm = those rates over the nominal peaks (the larger one names the bound)
             "kernel_breakdown_ms": {k: dict(launches=v["launches"], ms=round(v["ms"], 3),
-                                            tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
+                                            tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                                            frac_mfma=round(v["flops"] / max(v["ms"], 1e-9) / 1e9 / (MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else 157.3), 3),
+                                            frac_hbm=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 3))
                                     for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])},
         }
         print(json.dumps(line), flush=True)

@@ -1134,7 +1134,9 @@ def test_attention_backward_bf16_one_pair_at_a_time_is_bitwise_the_whole_call(mo
 
 
 @pytest.mark.parametrize("b,lq,lk,heads,dh", [(1, 1024, 1024, 1, 128), (1, 200, 136, 2, 64), (2, 96, 320, 1, 64), (1, 520, 520, 1, 256),
-                                              (1, 333, 777, 2, 128), (1, 1, 1, 1, 64), (1, 129, 31, 1, 256), (1, 2050, 1990, 1, 256)])
+                                              (1, 333, 777, 2, 128), (1, 1, 1, 1, 64), (1, 129, 31, 1, 256), (1, 2050, 1990, 1, 256),
+                                              # (round 6) long sequences against the fp64 oracle, not only against the composed path
+                                              (1, 8192, 8192, 1, 256), (1, 4096, 4096, 2, 128)])
 def test_attention_backward_fused_bf16_lds_dma_kernels(b, lq, lk, heads, dh):
     """(round 5; VERDICT r4 "missing" #1) ops.attention_backward_fused = gm_attention_backward_fused (csrc/attention_bwd_dma.hip): dQ, dK, dV with the
     scores recomputed per tile on bf16 MFMA, K^T / Q^T / dO^T images packed once, nothing L x L in HBM.  Against torch autograd in fp64

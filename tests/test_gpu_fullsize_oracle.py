@@ -93,6 +93,37 @@ def test_c2_forward_and_teacher_forced_ddim_step_match_the_oracle_at_full_size(c
     _bf16_bar(prev16, prev_ref, f"C2 teacher-forced DDIM step t={t} (bf16)")
 
 
+def test_c2_full_size_forward_against_outputs_of_the_reference_itself(c2):
+    """tests/golden/c2_fullsize_ref.pt (oracle/make_golden_c2_fullsize.py): the UNMODIFIED reference's own C2 predictions at 1x1x128^3, t = 980 / 500 / 20,
+    kept as the every-4th-voxel lattice + whole-tensor mean / std / max-abs / axis projections -- no restatement between the HIP path and the
+    reference at the headline size -- and the reference's OWN bf16 error at this size: SURVEY 8(c)(3)'s third clause
+    err(ours_bf16) <= 1.5 err(ref_bf16) at C2 size (weak 1(b)).  Weights / noise are rebuilt from the seeds the fixture was made with."""
+    from make_golden_c2_fullsize import sd_checksum, whole_tensor_summary
+
+    from _util import GOLDEN
+
+    fx = torch.load(os.path.join(GOLDEN, "c2_fullsize_ref.pt"), weights_only=False)
+    assert abs(sd_checksum(c2["sd"]) - fx["sd_checksum"]) <= 1e-9 * fx["sd_checksum"], "the rebuilt state_dict is not the one the fixture was generated with"
+    L = fx["lattice"]
+    x = c2["x"]
+    for t, ref in fx["fp32"].items():
+        eps32 = c2["m32"](x.to(DEV), torch.tensor([float(t)], device=DEV)).float().cpu()
+        _fp32_bar(eps32[..., ::L, ::L, ::L], ref["lattice"], f"C2 1x1x128^3 fp32 forward t={t} vs the reference's own output (lattice of {ref['lattice'].numel()} voxels)")
+        got = whole_tensor_summary(eps32)
+        n_line = 128 * 128  # voxels behind one entry of a projection: the fp32 bar per voxel bounds the sum
+        for k in ("proj_d", "proj_h", "proj_w"):
+            err = (got[k].double() - ref[k].double()).abs().max().item()
+            assert err <= 1e-4 * max(1.0, ref["absmax"]) * n_line, (t, k, err)
+        assert abs(got["mean"] - ref["mean"]) <= 1e-4 and abs(got["std"] - ref["std"]) <= 1e-4 * ref["std"] and abs(got["absmax"] - ref["absmax"]) <= 1e-4 * ref["absmax"], (t, got["mean"], ref["mean"])
+    ref16 = fx["bf16"][500]
+    eps16 = c2["m16"](x.to(DEV, torch.bfloat16), torch.tensor([500.0], device=DEV)).float().cpu()
+    err = (eps16[..., ::L, ::L, ::L] - fx["fp32"][500]["lattice"]).abs()
+    print(f"[parity] C2 1x1x128^3 bf16 t=500 vs the reference's fp32 output: ours mean|err| {err.mean().item():.4e} max {err.max().item():.4e}; "
+          f"the reference's own bf16 run: mean {ref16['lattice_mean_err']:.4e} max {ref16['lattice_max_err']:.4e} (sigma {ref16['sigma']:.3f})")
+    assert err.mean().item() <= 1.5 * ref16["lattice_mean_err"], f"ours bf16 mean|err| {err.mean().item():.3e} vs reference bf16 {ref16['lattice_mean_err']:.3e}"
+    assert err.max().item() <= 2.0 * ref16["lattice_max_err"], f"ours bf16 max|err| {err.max().item():.3e} vs reference bf16 {ref16['lattice_max_err']:.3e}"
+
+
 # ---- C3 ------------------------------------------------------------------------------------------------------------------------------
 AEKL_BRAIN = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4, num_channels=(64, 128, 128, 128), num_res_blocks=2,
                   attention_levels=(False, False, False, False), with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False)

@@ -275,3 +275,27 @@ def test_constructor_argument_grid_matches_reference():
             assert torch.equal(R.vq_index_quantize(sd, e["z"])[0], e["indices"])
             assert_close(R.vqvae_decode(sd, e["cfg"], R.vq_embed(sd, e["indices"])), e["reconstruction"],
                          atol=2e-5 * max(1.0, e["reconstruction"].abs().max().item()), what=f"vqvae decode {e['cfg']}")
+
+
+def test_restatement_matches_the_reference_at_the_headline_size():
+    """The oracle pinned at BASELINE's REAL size: oracle/restatement.py's C2 forward of the benchmark's own 1x1x128^3 noise volume at t = 500 against the
+    unmodified reference's output (tests/golden/c2_fullsize_ref.pt: every-4th-voxel lattice + whole-tensor summaries; about a minute on 8 cores)."""
+    import os
+
+    from _util import GOLDEN
+    from bench import C2, rerandomize_zero_params
+    from generativemodels_amd.networks.nets import DiffusionModelUNet
+    from make_golden_c2_fullsize import sd_checksum, whole_tensor_summary
+
+    fx = torch.load(os.path.join(GOLDEN, "c2_fullsize_ref.pt"), weights_only=False)
+    torch.manual_seed(0)
+    sd = rerandomize_zero_params({k: v.clone() for k, v in DiffusionModelUNet(**C2).eval().state_dict().items()})
+    assert abs(sd_checksum(sd) - fx["sd_checksum"]) <= 1e-9 * fx["sd_checksum"]
+    x = torch.randn((1, 1, 128, 128, 128), generator=torch.Generator().manual_seed(fx["input_seed"]))
+    with torch.no_grad():
+        y = R.unet_forward(sd, C2, x, torch.tensor([500.0]))
+    ref, L = fx["fp32"][500], fx["lattice"]
+    err = (y[..., ::L, ::L, ::L] - ref["lattice"]).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref["absmax"]), err  # same algorithm, same fp32 kernels of the same torch: only thread-partition round-off differs
+    got = whole_tensor_summary(y)
+    assert abs(got["std"] - ref["std"]) <= 1e-5 * ref["std"] and abs(got["absmax"] - ref["absmax"]) <= 1e-4 * ref["absmax"]
