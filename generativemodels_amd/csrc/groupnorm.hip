@@ -290,6 +290,13 @@ __global__ __launch_bounds__(256) void gn_finalize_channels_kernel(const double*
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int C = C0 + C1, cpg = C / G;
+  // gamma / beta of this thread's first output channel: requested BEFORE the table (round 6: behind the reduction they were a second dependent
+  // round trip of every one of the 36-46 finalisations of a forward)
+  float ga0 = 1.f, be0 = 0.f;
+  if (t < cpg) {
+    if (gamma) ga0 = gamma[g * cpg + t];
+    if (beta) be0 = beta[g * cpg + t];
+  }
   double a = 0.0, b = 0.0;
   for (int j = 0; j < cpg; ++j) {  // a group may straddle the two sources: per channel, then per partial
     const int c = g * cpg + j;
@@ -314,8 +321,8 @@ __global__ __launch_bounds__(256) void gn_finalize_channels_kernel(const double*
   const double rstd = 1.0 / sqrt(var + (double)eps);
   for (int j = t; j < cpg; j += 256) {
     const int c = g * cpg + j;
-    const double ga = gamma ? (double)gamma[c] : 1.0;
-    const double be = beta ? (double)beta[c] : 0.0;
+    const double ga = j == t ? (double)ga0 : (gamma ? (double)gamma[c] : 1.0);
+    const double be = j == t ? (double)be0 : (beta ? (double)beta[c] : 0.0);
     scale[(long long)n * C + c] = (float)(rstd * ga);
     shift[(long long)n * C + c] = (float)(be - mean * rstd * ga);
   }
