@@ -115,7 +115,6 @@ PROTOTYPES = {
     "gm_conv_forward": (C.c_int, [C.POINTER(GmConvDesc), c_vp]),
     "gm_conv_dma_set_persistent": (None, [C.c_int]),
     "gm_conv_dma_set_phase_skew": (None, [C.c_int]),
-    "gm_conv_w8_set_pipe2": (None, [C.c_int]),
     "gm_conv_sk_set_enabled": (None, [C.c_int]),
     "gm_packed_conv_weight_elems": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -373,11 +373,9 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 extern "C" int gm_conv_dma_variant(int cfg);
 // 14: 4 waves x 64 voxels; 15: stride 2; 16: 512 voxels, 16 waves; 17: sub-pixel up-sampling; 18: 512 voxels, 8 waves x 64 voxels; 19: 512 voxels x 128 channels
-// 21: conv_mw.hip (bf16, 16-channel half-chunks, v_mfma_f32_32x32x16_bf16, three work-groups per CU)
-// 22: conv_w8.hip (bf16, 512 voxels, 64-byte patch rows + 16-channel weight panels from the halves image, v_mfma_f32_32x32x16_bf16)
-// (23: round 5's four-wave 4 x 2-block form of configuration 22 -- measured equal / slower, kept under experiments/conv_w4/ with its numbers in
-//  profiles/r05_conv_cfg23_ab.txt; not part of the library)
-static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19) || cfg == 21 || cfg == 22; }
+// (21 / 22 / 23: the three tile structures on v_mfma_f32_32x32x16_bf16 of rounds 4-5 -- each verified and measured equal or slower in time, and in round 6
+//  costlier in joules per launch on every C2 shape (profiles/r06_taploop_energy.txt) -- live under experiments/conv_mw, conv_w8, conv_w4; the ids stay retired)
+static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19); }
 // HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
 #define CONV_CFG_CIN 12
 #define CONV_CFG_COUT1 13
@@ -406,7 +404,7 @@ static bool conv_fast_eligible(const GmConvDesc& d) {
 
 extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
   if (cfg == 15) { *bm = 128; *bn = 64; return 0; }
-  if (cfg == 16 || cfg == 18 || cfg == 22) { *bm = 512; *bn = 64; return 0; }
+  if (cfg == 16 || cfg == 18) { *bm = 512; *bn = 64; return 0; }
   if (cfg == 19) { *bm = 512; *bn = 128; return 0; }
   if (conv_is_dma(cfg) || cfg == CONV_CFG_CIN) { *bm = 256; *bn = 64; return 0; }
   if (cfg == CONV_CFG_COUT1) { *bm = 256; *bn = 16; return 0; }

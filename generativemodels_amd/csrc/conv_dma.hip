@@ -1078,14 +1078,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 // variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile; 4 = sub-pixel 2x2x2 (5 planes of 5 x 17 -> 96 rows,
 // four 128-row weight panels, padded to the 36 KiB of the epilogue's transpose scratch); 5 = 8x4x16 tile x 128 output channels (three 384-row
 // weight panels).  Every variant ends with the 512-byte epilogue addend vector.
-// tile configuration 21 (conv_mw.hip: 16-channel half-chunks, 32x32x16 MFMA, three work-groups per CU) shares this file's entry points
-extern "C" long long gm_conv_mw_lds_bytes();
-extern "C" int gm_conv_mw_eligible(const GmConvDesc* d);
-extern "C" int gm_conv_mw_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
-// tile configuration 22 (conv_w8.hip: 512-voxel tiles, 64-byte patch rows, 16-channel weight panels from the halves image, 32x32x16 MFMA) likewise
-extern "C" long long gm_conv_w8_lds_bytes();
-extern "C" int gm_conv_w8_eligible(const GmConvDesc* d);
-extern "C" int gm_conv_w8_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 // the K slices of a split-K launch (cfg 11 geometry) run on conv_sk.hip's kernel: one work-group per CU, patch + all nine panels of a chunk resident
 extern "C" int gm_conv_sk_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
@@ -1093,8 +1085,6 @@ extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* s
 #if DMA_PART(0)
 extern "C" long long gm_conv_dma_lds_bytes(int variant) {
   const long long addv = 512;
-  if (variant == 6) return gm_conv_mw_lds_bytes();
-  if (variant == 7) return gm_conv_w8_lds_bytes();
   if (variant == 4) return 5LL * 96 * DMA_ROWB + 36864 + addv + 256LL * 9 * 4;  // ... + the placement table (256 threads x (8 pieces + the slot keys))
   if (variant == 5) return 10LL * 112 * DMA_ROWB + 3LL * 384 * DMA_ROWB + addv;
   const long long plane = variant == 2 ? 304 : 112, planes = variant == 1 ? 6 : (variant == 2 ? 5 : 10);
@@ -1154,11 +1144,10 @@ static unsigned dma_grid(unsigned nwork, long long lds_bytes, int by_waves, bool
 
 #if DMA_PART(0)
 // geometry this kernel covers (cfg 11 / 14: stride 1, tile 4x4x16; cfg 15: stride 2, tile 2x4x16)
-extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 22 ? 7 : cfg == 21 ? 6 : cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
+extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 17 ? 4 : (cfg == 15 ? 2 : (cfg == 16 || cfg == 18 ? 3 : (cfg == 19 ? 5 : 1))); }
 
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
-  if (d->cfg == 21) return gm_conv_mw_eligible(d);
-  if (d->cfg == 22) return gm_conv_w8_eligible(d);
+  if (d->cfg == 21 || d->cfg == 22) return 0;  // (the 32x32x16 tile structures of rounds 4-5: experiments/conv_mw, conv_w8 -- not in the library)
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const int s = d->cfg == 15 ? 2 : 1;
@@ -1280,8 +1269,6 @@ extern "C" int gm_conv_dma_launch_part4(const GmConvDesc* dp, unsigned nblocks, 
 
 #if DMA_PART(0)
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
-  if (dp->cfg == 21) return gm_conv_mw_launch(dp, nblocks, stream);
-  if (dp->cfg == 22) return gm_conv_w8_launch(dp, nblocks, stream);
   if (gm_conv_sk_eligible(dp)) return gm_conv_sk_launch(dp, nblocks, stream);
   switch (dp->cfg) {
     case 14: return gm_conv_dma_launch_part1(dp, nblocks, stream);

@@ -1,4 +1,4 @@
-// Pieces shared by the LDS-DMA convolution kernels (conv_dma.hip, conv_mw.hip): the LDS-DMA issue / wait primitives, the opaque kernarg
+// Pieces shared by the LDS-DMA convolution kernels (conv_dma.hip, conv_sk.hip): the LDS-DMA issue / wait primitives, the opaque kernarg
 // descriptor access and the LDS-transposed epilogue with fused GroupNorm statistics.
 #pragma once
 #include "conv_epilogue.h"
@@ -134,7 +134,7 @@ __device__ __forceinline__ void dma_epilogue_write(f32x4_t (&acc)[NFR][MF], char
 }
 
 // second half: transpose scratch -> global (lane = row it * 8 + lane / 8, 16-byte segment lane % 8), residual, activation, statistics.  The
-// accumulator layout does not matter here: conv_mw.hip (32x32x16 MFMA) shares it.  EPASSES = epilogue passes of the tile (dims of st_s / st_q).
+// accumulator layout does not matter here.  EPASSES = epilogue passes of the tile (dims of st_s / st_q).
 template <typename T, int MF, int KS, int PASS, int EPASSES, typename D>
 __device__ __forceinline__ void dma_epilogue_store(const D& p, char* lds, const EpTile& t, int line0, int lane, const EpRows<MF * 2>& R,
                                                    float (&st_s)[EPASSES][16 / (int)sizeof(T)], float (&st_q)[EPASSES][16 / (int)sizeof(T)]) {

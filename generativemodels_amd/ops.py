@@ -263,19 +263,6 @@ def packed_conv_weight(weight: torch.Tensor, dtype: torch.dtype, transposed: boo
     return _cached(weight, ("pack", dtype, transposed, cin_range), make)
 
 
-def packed_conv_weight_halves(packed: torch.Tensor, cin: int, taps: int = 27) -> torch.Tensor:
-    """The HALVES image of a packed bf16 3x3x3 panel for tile configuration 22 (csrc/conv_w8.hip): gm_pack_conv_weight's [chunk32][tap][Cout_pad][32]
-    re-ordered to [chunk32][half][tap][Cout_pad][16], so that the 16-input-channel weight panel of a tap (the K of v_mfma_f32_32x32x16_bf16) is a
-    contiguous 32-byte-row block instead of a 32-byte column of 64-byte rows (LDS-DMA requests below 64 contiguous bytes cost what 64 bytes
-    cost: profiles/r04_lds_dma_patterns.txt).  Derived once per packed panel (which is itself cached per parameter version)."""
-    def make():
-        nchunk = -(-cin // 32)
-        cout_pad = packed.numel() // (nchunk * taps * 32)
-        return packed.view(nchunk, taps, cout_pad, 2, 16).permute(0, 3, 1, 2, 4).contiguous().view(-1)
-
-    return _cached(packed, ("halves", cin, taps), make)
-
-
 def packed_cin_weight(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """The K-MAJOR image of a C_in <= 4 convolution's 3x3x3 weight for tile configuration 12 (csrc/conv_edge.hip conv_cin_kernel):
     [Cout padded to 64][27 * C_in padded to the MFMA K step] with k = tap * C_in + ci, zero padded -- the taps x inputs ARE the GEMM K, and a
@@ -691,25 +678,11 @@ SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups t
 SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "256"))
 SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
 _SK_KERNEL = os.environ.get("GM_CONV_SK")  # "0": the slices on the general cfg 11 tile kernel (round-3 path) instead of conv_sk.hip -- A/B measurements only
-DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 21, 22)
-# cfg 21 (csrc/conv_mw.hip): bf16 3x3x3 stride-1 convolutions without a fused prologue on 16-channel half-chunks + v_mfma_f32_32x32x16_bf16, three
-# work-groups per CU; "1" prefers it over cfg 14 wherever it is eligible and the grid fills the chip, "0" keeps cfg 14
-DMA_MW = os.environ.get("GM_CONV_MW", "0") != "0"
-# cfg 22 (csrc/conv_w8.hip): the same convolutions on 512-voxel tiles (8 waves, 64-byte patch rows, 16-channel weight panels from the halves image,
-# v_mfma_f32_32x32x16_bf16, two work-groups per CU): 0.58x the operand bytes per FLOP of the 256-voxel tiles.  Measured on MI355X (round 4,
-# profiles/r04_conv_cfg22_ab.txt): within +-3 % of cfg 14 on every C2 shape and 1.5 % slower on the whole forward (14.88 vs 14.66 ms per DDIM
-# iteration) -- the sampling loop runs at the package power cap (1 380 of 1 400 W, profiles/r04_power_trace.txt), where three different tile
-# structures (cfg 14 / 21 / 22) land on the same throughput.  "1" prefers it from DMA_W8_MIN_TILES work-groups on; the default keeps cfg 14.
-DMA_W8 = os.environ.get("GM_CONV_W8", "0") != "0"
-# (round 5: a FOURTH structure -- this LDS image on four waves of 4 x 2 blocks of the 32x32x16 MFMA at 256 registers with two operand sets, 0.75 operand
-#  reads per MFMA -- was built, verified bit-identical to cfg 22 and measured: -2 ... -8 % on deep K against cfg 14, 14.17 vs 13.97 ms per DDIM
-#  iteration; it lives under experiments/conv_w4/ with its numbers in profiles/r05_conv_cfg23_ab.txt, not in the library)
-DMA_W8_MIN_TILES = int(os.environ.get("GM_CONV_W8_MIN_TILES", "512"))
-# ... also WITH the GroupNorm-apply + activation prologue, applied in LDS to the landed patch (conv_w8.hip transform_patch; halo redundancy 2.11
-# against 2.53 at 256 voxels, four waves per SIMD): bit-identical to the two-pass form, 26 launches and 9 GB of HBM traffic less per C2 forward --
-# and the same time (14.94 vs 14.88 ms per iteration): under the power cap the transform's VALU work costs what the HBM pass costs
-DMA_W8_PRE = os.environ.get("GM_CONV_W8_PRE", "1") != "0"
-_W8_PIPE2 = os.environ.get("GM_CONV_W8_PIPE2")  # bench A/B: "0" = one operand register set in the tap loop
+DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
+# (Rounds 4-5 built three more tile structures on v_mfma_f32_32x32x16_bf16 -- cfg 21: 16-channel half-chunks, three work-groups per CU; cfg 22: 512-voxel
+#  tiles with 16-channel weight panels; cfg 23: cfg 22's image on four waves of 4 x 2 blocks -- each verified bit-level and measured: all tie or lose against
+#  cfg 14 in time, and in round 6 in JOULES per launch on every C2 shape (profiles/r06_taploop_energy.txt: +1 ... +16 %).  They live under experiments/
+#  with their host replays, not in the library.)
 COUT1_MARCH = os.environ.get("GM_CONV_COUT1_MARCH", "1") != "0"  # C_out == 1 heads: the depth-marching kernel (cfg 20) before the tile kernel (cfg 13)
 DMA_WIDE_WAVES = os.environ.get("GM_CONV_WIDE_WAVES", "1") != "0"  # prefer cfg 14 (4 waves x 64 voxels) for large prologue-free stride-1 convolutions
 DMA_WIDE_WAVES_PRE = os.environ.get("GM_CONV_WIDE_WAVES_PRE", "0") != "0"  # ... also with the fused in-LDS prologue (its cfg 14 instantiation)
@@ -846,10 +819,7 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         # cfg 11 keeps the fused-prologue instantiation (the cfg 14 one spills) and the small grids (its split-K form).
         tiles = desc.N * -(-desc.Do // 4) * -(-desc.Ho // 4) * -(-desc.Wo // 16) * -(-cout // 64)
         wide = (bool(desc.pre_scale is None or not desc.pre_scale) or DMA_WIDE_WAVES_PRE) and tiles >= DMA_WIDE_WAVE_MIN_TILES and DMA_WIDE_WAVES
-        tiles512 = desc.N * -(-desc.Do // 8) * -(-desc.Ho // 4) * -(-desc.Wo // 16) * -(-cout // 64)
-        has_pre = bool(desc.pre_scale)
-        big = [22] if (DMA_W8 and DMA_WIDE_WAVES and desc.dtype == 1 and tiles512 >= DMA_W8_MIN_TILES and (not has_pre or DMA_W8_PRE)) else []
-        order = ([15] if desc.sd == 2 else (big + (([21, 14, 11] if DMA_MW and desc.dtype == 1 else [14, 11]) if wide else [11]))) + order
+        order = ([15] if desc.sd == 2 else ([14, 11] if wide else [11])) + order
         # (512-voxel tiles -- cfg 16 / 18, one work-group per CU, half the weight-panel traffic -- measure within +-5 % of two 256-voxel
         # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,
         # r02_layer_times_cfg16_rule.txt.  They stay available through force_cfg.)
@@ -875,8 +845,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             if COUT1_MARCH_LTD is not None:
                 ltd = int(COUT1_MARCH_LTD)
             bits = [ltd, 3, ltw]
-        if cfg in (11, 14, 15, 16, 18, 19, 21, 22):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
-            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 21: [2, 2, 4], 22: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
+        if cfg in (11, 14, 15, 16, 18, 19):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
+            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
@@ -1231,13 +1201,6 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             dma_ok = True
         except ValueError:
             dma_ok = False
-    elif force_cfg is None and pre is not None and DMA_CONV and DMA_W8 and DMA_W8_PRE and cout > 16 and DMA_FUSED_PROLOGUE != "never":
-        # a large convolution with a prologue: fused in LDS only where the 512-voxel kernel (cfg 22) takes it, two-pass otherwise
-        try:
-            _choose_conv_cfg(d, nvox, None, only=(22,))
-            dma_ok = True
-        except ValueError:
-            dma_ok = False
     if not dma_ok:
         if force_cfg is not None and force_cfg in DMA_CFGS:
             raise ValueError(f"configuration {force_cfg} does not cover this convolution")
@@ -1269,11 +1232,6 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             raise ValueError("configuration 12 needs the original [Cout, Cin, 3, 3, 3] weight (its K-major image is derived from it)")
         cin_keep = packed_cin_weight(weight, dtype)
         d.w = cin_keep.data_ptr()
-    if dma_ok and d.cfg == 22 and _W8_PIPE2 is not None:
-        lib().gm_conv_w8_set_pipe2(int(_W8_PIPE2))
-    if dma_ok and d.cfg == 22:  # configuration 22 reads its main weights from the halves image (the fused shortcut keeps the standard one)
-        halves_keep = packed_conv_weight_halves(packed, cin, math.prod(k))
-        d.w = halves_keep.data_ptr()
     kpart = None
     if dma_ok and d.cfg == 11 and (ksplit is not None or SPLITK):
         nchunks = cin // (64 // x.element_size())

@@ -182,7 +182,7 @@ typedef struct GmConvDesc {
                                 must be NULL when gm_conv_stats_slots() returns 0 for the chosen configuration */
   /* optional fused 1x1 shortcut convolution of a ResnetBlock (diffusion_model_unet.py:684-696, autoencoderkl.py:188-193):
    * y += W_skip * cat(skip_x[0], skip_x[1]) + skip_bias with the sources in the output geometry (skip_x[1] may be NULL).
-   * Implemented by the LDS-DMA configurations (cfg 11, 14, 16, 18, 19, 21, 22): gm_conv_lds_bytes() returns -1 for any other when skip_x[0] is set. */
+   * Implemented by the LDS-DMA configurations (cfg 11, 14, 16, 18, 19): gm_conv_lds_bytes() returns -1 for any other when skip_x[0] is set. */
   const void* skip_x[2]; long long skip_ld[2]; int skip_cin[2];
   const void* skip_w;        /* gm_pack_conv_weight image of the [Cout][skip_cin[0]+skip_cin[1]] 1x1 kernel */
   const float* skip_bias;    /* [Cout] or NULL */
@@ -214,9 +214,6 @@ void gm_conv_dma_set_persistent(int max_work_groups);
  * `cycles` once; later work-groups inherit the phase of their slot.  0 = off (default: measured no gain on MI355X, profiles/r05_phase_skew_sweep.txt),
  * -1 = half the modelled tile life of the launch. */
 void gm_conv_dma_set_phase_skew(int cycles);
-/* Tap-loop form of tile configuration 22 (process-wide; results do not depend on it): 0 (default) = one operand register set; 1 = two sets,
- * software-pipelined over the taps (bench A/B: slower at 128 registers). */
-void gm_conv_w8_set_pipe2(int on);
 /* Kernel of the K slices of a split-K launch (process-wide; results do not depend on it: the partial sums are bit-identical): 1 (default) =
  * conv_sk.hip (one work-group per CU, the patch and all nine weight panels of a K chunk requested up front); 0 = the general cfg 11 tile kernel
  * (the round-3 path; A/B measurements and the bitwise test). */

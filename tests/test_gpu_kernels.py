@@ -285,115 +285,8 @@ def test_conv_lds_dma_kernel(case, dtype, cfg):
     assert torch.equal(auto, got.contiguous()) or (auto.float() - got.float()).abs().max() <= 2e-2 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("case", [("plain", 32, 64, None, None, (8, 8, 16), "res"), ("ragged16", 48, 40, None, None, (5, 7, 19), "res"),
-                                  ("wide", 96, 136, None, None, (4, 6, 18), "res"), ("cat", 96, 72, 64, None, (5, 7, 19), "none"),
-                                  ("cat16", 80, 64, 48, None, (6, 5, 33), "res"), ("skip", 64, 64, None, (32,), (8, 8, 16), "skip"),
-                                  ("skip-cat", 32, 40, None, (64, 32), (5, 7, 19), "skip"), ("skip-cat3", 128, 136, 64, (48, 96), (4, 6, 18), "skip"),
-                                  ("deep", 256, 64, None, None, (8, 8, 32), "res")], ids=lambda c: c[0])
-def test_conv_three_workgroup_kernel(case):
-    """cfg 21 (conv_mw.hip): 16-channel half-chunks in 32-byte LDS rows, v_mfma_f32_32x32x16_bf16, three work-groups per CU.  Ragged volumes,
-    channel counts that are 16- but not 32-multiples, ragged output-channel blocks, the two-source input of a virtual concatenation (split on a
-    16-channel boundary), bias + timestep row + residual into a channel slice of a wider buffer, the fused 1x1 shortcut over one / two sources
-    (more than one round of four half-chunks), fused GroupNorm statistics -- against fp64 and against cfg 14 (same function, another
-    summation order).  Reference: ResnetBlock, diffusion_model_unet.py:669-696."""
-    ops = _ops()
-    dtype = torch.bfloat16
-    name, cin, cout, split, pcs, sp, mode = case
-    n = 2
-    x = _rand((n, cin, *sp), 371).to(dtype)
-    w = (_rand((cout, cin, 3, 3, 3), 372) / math.sqrt(cin * 27)).to(dtype)
-    b, temb = _rand((cout,), 373) * 0.1, _rand((n, cout), 374) * 0.5
-    want = F.conv3d(x.double(), w.double(), b.double(), padding=1) + temb.double().reshape(n, cout, 1, 1, 1)
-    wide_in = torch.zeros((n, *sp, cin + 8), dtype=dtype, device=DEV)
-    wide_in[..., 8:] = _cl(x)
-    xa = wide_in[..., 8:]
-    operand = xa if split is None else ops.VirtualCat([xa[..., :split], xa[..., split:].contiguous()])
-    kw = dict(kernel=3, padding=1, rowvec=temb.to(DEV), want_stats=True)
-    if mode == "res":
-        res = _rand((n, cout, *sp), 375).to(dtype)
-        kw["res"] = _cl(res)
-        want = want + res.double()
-    elif mode == "skip":
-        parts = [_rand((n, c, *sp), 380 + i).to(dtype) for i, c in enumerate(pcs)]
-        ws = (_rand((cout, sum(pcs), 1, 1, 1), 376) / math.sqrt(sum(pcs))).to(dtype)
-        bs = _rand((cout,), 377) * 0.1
-        want = want + F.conv3d(torch.cat([p.double() for p in parts], 1), ws.double(), bs.double())
-        dparts = []
-        for p in parts:
-            wide = torch.zeros((n, *sp, p.shape[1] + 8), dtype=dtype, device=DEV)
-            wide[..., 8:] = _cl(p)
-            dparts.append(wide[..., 8:])
-        kw["skip"] = (dparts, ws.to(DEV), bs.to(DEV))
-    wide_out = torch.full((n, *sp, cout + 16), 7.0, dtype=dtype, device=DEV)
-    got = ops.conv(operand, w.to(DEV), b.to(DEV), out=wide_out[..., 16:], force_cfg=21, **kw)
-    _check(_cf(got), want, dtype, f"cfg21 {name}", extra=1.5 if mode == "skip" else 1.0)
-    assert torch.all(wide_out[..., :16] == 7.0)  # nothing written outside the slice
-    st = got._gm_cstats.sum(0).cpu()
-    v = got.float().cpu().double().reshape(n, -1, cout)
-    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1], (v * v).sum(1), rtol=1e-4, atol=1e-2)
-    if cin % 32 == 0 and (split is None or split % 32 == 0) and (pcs is None or all(c % 32 == 0 for c in pcs)):
-        other = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=14, **kw)
-        assert (other.float() - got.float()).abs().max().item() <= 2 ** -6 * max(1.0, want.abs().max().item())
-    again = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=21, **kw)
-    assert torch.equal(again, got.contiguous()) and torch.equal(again._gm_cstats, got._gm_cstats)  # run-to-run bitwise
-
-
-@pytest.mark.parametrize("case", [("plain", 32, 64, None, None, (8, 8, 16), "res"), ("ragged", 64, 40, None, None, (5, 7, 19), "res"),
-                                  ("wide", 96, 136, None, None, (9, 6, 18), "res"), ("cat", 96, 72, 64, None, (11, 7, 19), "none"),
-                                  ("cat32", 96, 64, 32, None, (6, 5, 33), "res"), ("skip", 64, 64, None, (32,), (8, 8, 16), "skip"),
-                                  ("skip-cat", 32, 40, None, (64, 32), (5, 7, 19), "skip"), ("skip-cat3", 128, 136, 64, (32, 96), (12, 6, 18), "skip"),
-                                  ("deep", 256, 64, None, None, (16, 8, 32), "res")], ids=lambda c: c[0])
-@pytest.mark.parametrize("cfg", [22])
-def test_conv_512_voxel_tile_kernel(case, cfg):
-    """cfg 22 (conv_w8.hip): 8 x 4 x 16 voxel tiles of 8 waves, 64-byte patch rows without padding (per-column bank key), 16-channel weight
-    panels from the halves image through a two-slot ring, v_mfma_f32_32x32x16_bf16, two work-groups per CU.  Ragged volumes (depths that
-    are not multiples of 8), ragged output-channel blocks, the two-source input of a virtual concatenation, bias + timestep row + residual
-    into a channel slice of a wider buffer, the fused 1x1 shortcut over one / two sources (more than one round of two chunks), fused
-    GroupNorm statistics -- against fp64 and against cfg 14 (same function, another summation order).  Reference: ResnetBlock,
-    diffusion_model_unet.py:669-696."""
-    ops = _ops()
-    dtype = torch.bfloat16
-    name, cin, cout, split, pcs, sp, mode = case
-    n = 2
-    x = _rand((n, cin, *sp), 471).to(dtype)
-    w = (_rand((cout, cin, 3, 3, 3), 472) / math.sqrt(cin * 27)).to(dtype)
-    b, temb = _rand((cout,), 473) * 0.1, _rand((n, cout), 474) * 0.5
-    want = F.conv3d(x.double(), w.double(), b.double(), padding=1) + temb.double().reshape(n, cout, 1, 1, 1)
-    wide_in = torch.zeros((n, *sp, cin + 8), dtype=dtype, device=DEV)
-    wide_in[..., 8:] = _cl(x)
-    xa = wide_in[..., 8:]
-    operand = xa if split is None else ops.VirtualCat([xa[..., :split], xa[..., split:].contiguous()])
-    kw = dict(kernel=3, padding=1, rowvec=temb.to(DEV), want_stats=True)
-    if mode == "res":
-        res = _rand((n, cout, *sp), 475).to(dtype)
-        kw["res"] = _cl(res)
-        want = want + res.double()
-    elif mode == "skip":
-        parts = [_rand((n, c, *sp), 480 + i).to(dtype) for i, c in enumerate(pcs)]
-        ws = (_rand((cout, sum(pcs), 1, 1, 1), 476) / math.sqrt(sum(pcs))).to(dtype)
-        bs = _rand((cout,), 477) * 0.1
-        want = want + F.conv3d(torch.cat([p.double() for p in parts], 1), ws.double(), bs.double())
-        dparts = []
-        for p in parts:
-            wide = torch.zeros((n, *sp, p.shape[1] + 8), dtype=dtype, device=DEV)
-            wide[..., 8:] = _cl(p)
-            dparts.append(wide[..., 8:])
-        kw["skip"] = (dparts, ws.to(DEV), bs.to(DEV))
-    wide_out = torch.full((n, *sp, cout + 16), 7.0, dtype=dtype, device=DEV)
-    got = ops.conv(operand, w.to(DEV), b.to(DEV), out=wide_out[..., 16:], force_cfg=cfg, **kw)
-    _check(_cf(got), want, dtype, f"cfg{cfg} {name}", extra=1.5 if mode == "skip" else 1.0)
-    assert torch.all(wide_out[..., :16] == 7.0)  # nothing written outside the slice
-    st = got._gm_cstats.sum(0).cpu()
-    v = got.float().cpu().double().reshape(n, -1, cout)
-    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1], (v * v).sum(1), rtol=1e-4, atol=1e-2)
-    other = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=14, **kw)
-    assert (other.float() - got.float()).abs().max().item() <= 2 ** -6 * max(1.0, want.abs().max().item())
-    again = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=cfg, **kw)
-    assert torch.equal(again, got.contiguous()) and torch.equal(again._gm_cstats, got._gm_cstats)  # run-to-run bitwise
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [11, 14, 16, 18, 19, 22])
+@pytest.mark.parametrize("cfg", [11, 14, 16, 18, 19])
 @pytest.mark.parametrize("case", [("one", 64, 72, None, (6, 9, 19), 2), ("cat", 96, 40, 64, (5, 7, 19), 2), ("cat-wide", 160, 136, 32, (9, 6, 18), 1),
                                   ("relu", 32, 64, None, (4, 4, 16), 3)], ids=lambda c: c[0] if isinstance(c, tuple) else str(c))
 def test_conv_lds_dma_in_lds_prologue_matches_the_two_pass_form_bitwise(case, cfg, dtype):
@@ -402,8 +295,6 @@ def test_conv_lds_dma_in_lds_prologue_matches_the_two_pass_form_bitwise(case, cf
     (GmConvDesc.x2) against (a) the two-pass form -- gm_gn_apply per part, then the plain convolution -- which must agree BIT FOR BIT
     (same arithmetic, same rounding), output statistics included, and (b) F.conv3d(act(x * scale + shift)) in fp64.
     Reference: conv(silu(norm(x))) of ResnetBlock, diffusion_model_unet.py:671-684, over torch.cat([h, skip]) in the decoder (:1232)."""
-    if cfg == 22 and dtype != torch.bfloat16:
-        pytest.skip("configuration 22 is bf16 only")
     ops = _ops()
     name, cin, cout, split, sp, n = case
     act = "relu" if name == "relu" else "silu"

@@ -86,44 +86,6 @@ def test_unet_bf16_close_to_fp32_reference(name):
     assert err.max().item() <= 2.0 * ref["max_err"], f"{name}: ours bf16 max|err| {err.max().item():.3e} vs reference bf16 {ref['max_err']:.3e}"
 
 
-@pytest.mark.parametrize("flag,cfg", [("DMA_W8", "cfg22"), ("DMA_MW", "cfg21")])
-def test_selectable_tile_configurations_carry_a_whole_model(flag, cfg):
-    """The two selectable LDS-DMA tile configurations (GM_CONV_W8=1 -> cfg 22, conv_w8.hip; GM_CONV_MW=1 -> cfg 21, conv_mw.hip) end to end: the
-    C2-shaped mini UNet (reference weights of the golden fixture) on a 32 x 32 x 48 volume in bf16 with the switch on -- the launches really are
-    on that configuration -- against the fp32 oracle under the bf16 bar of SURVEY 8(c)(3), and next to the default configuration's output
-    (these kernels were only tested per kernel)."""
-    ops = _ops()
-    fx = load_fixture("unet3d_c2mini")
-    x = torch.randn((1, 1, 32, 32, 48), generator=torch.Generator().manual_seed(11))
-    t = torch.tensor([431.0])
-    with torch.no_grad():
-        want = R.unet_forward(fx["state_dict"], fx["cfg"], x, t)
-    m = _build_unet(fx, torch.bfloat16)
-    base = m(_dev(x.bfloat16()), _dev(t))
-    keep = (getattr(ops, flag), ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES, ops.DMA_FUSED_PROLOGUE, ops.SPLITK)
-    try:
-        setattr(ops, flag, True)
-        ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES = 1, 1
-        # at this toy size the policy would fuse the prologue and split K (the cfg 11 forms); the large-volume policy -- two-pass GroupNorm, whole
-        # K per tile -- is what puts the C2 / AutoencoderKL convolutions on these configurations
-        ops.SPLITK = False
-        if flag == "DMA_MW":
-            ops.DMA_FUSED_PROLOGUE = "never"  # (configuration 21 has no in-LDS prologue)
-        ops.start_profile()
-        y = m(_dev(x.bfloat16()), _dev(t))
-        rec = ops.stop_profile()
-    finally:
-        setattr(ops, flag, keep[0])
-        ops.DMA_W8_MIN_TILES, ops.DMA_WIDE_WAVE_MIN_TILES, ops.DMA_FUSED_PROLOGUE, ops.SPLITK = keep[1], keep[2], keep[3], keep[4]
-    used = sorted({name for name, _, _ in rec if "conv_igemm" in name})
-    # (cfg 22 takes every stride-1 3x3x3 convolution of the model; cfg 21 has no fused shortcut / two-source form, so it gets the plain ones)
-    assert sum(1 for name, _, _ in rec if cfg in name) >= (4 if flag == "DMA_W8" else 2), f"{flag}: expected the model's convolutions on {cfg}, launches were {used}"
-    _bf16_close(y, want, f"c2mini 32x32x48 with {flag}")
-    _bf16_close(base, want, "c2mini 32x32x48 default configuration")
-    sigma = want.std().item()
-    assert (y.float() - base.float()).abs().mean().item() <= 2e-2 * sigma  # same function, another tile structure / summation order
-
-
 def test_unet_forward_errors_match_reference():
     fx = load_fixture("unet2d_c1a")
     m = _build_unet(fx)

@@ -457,89 +457,23 @@ def test_tile_configuration_policy_of_the_lds_dma_convolutions():
         ops._choose_conv_cfg(d, (size // kw.get("stride", 1)) ** 3, only=ops.DMA_CFGS)
         return d.cfg
 
-    keep, keep_mw, keep_w8 = ops.DMA_WIDE_WAVES, ops.DMA_MW, ops.DMA_W8
+    keep = ops.DMA_WIDE_WAVES
     try:
-        ops.DMA_MW = False
-        # round 4: 512-voxel tiles (cfg 22: bf16, halves weight image) from one full wave of 512-voxel work-groups on; smaller grids stay on cfg 14
-        ops.DMA_W8 = True
-        assert chosen(128, 64, 64) == 22 and chosen(64, 384, 128) == 22 and chosen(32, 256, 256) == 14
-        assert chosen(128, 64, 64, pre=True) == 22 and chosen(128, 64, 64, stride=2) == 15   # the fused in-LDS prologue is cfg 22's too
-        keep_pre, ops.DMA_W8_PRE = ops.DMA_W8_PRE, False
-        assert chosen(128, 64, 64, pre=True) == 11
-        ops.DMA_W8_PRE = keep_pre
-        ops.DMA_W8 = False
         assert chosen(128, 64, 64) == 14 and chosen(64, 384, 128) == 14 and chosen(32, 256, 256) == 14   # >= 512 tiles x channel blocks
         assert chosen(32, 64, 64) == 11 and chosen(16, 512, 512) == 11                                     # small grids: cfg 11 (+ split-K)
         assert chosen(128, 64, 64, pre=True) == 11                                                         # fused prologue
         assert chosen(128, 64, 64, stride=2) == 15
-        # round 4: the three-work-groups-per-CU kernel (cfg 21: bf16, 16-channel half-chunks) takes the large prologue-free bf16 convolutions
-        ops.DMA_MW = True
-        assert chosen(128, 64, 64) == 21 and chosen(64, 384, 128) == 21 and chosen(32, 256, 256) == 21
-        assert chosen(32, 64, 64) == 11 and chosen(128, 64, 64, pre=True) == 11 and chosen(128, 64, 64, stride=2) == 15
         d32 = desc(128, 64, 64)
         d32.dtype = 0
         ops._choose_conv_cfg(d32, 128 ** 3, only=ops.DMA_CFGS)
-        assert d32.cfg == 14                                                                               # fp32 stays on conv_dma.hip
+        assert d32.cfg == 14                                                                               # fp32 too
+        for gone in (21, 22):  # (round 6) the two 32x32x16 tile configurations left the library after the energy-metered no-go (experiments/conv_mw, conv_w8)
+            with pytest.raises(ValueError):
+                ops._choose_conv_cfg(desc(128, 64, 64), 128 ** 3, force_cfg=gone, only=ops.DMA_CFGS)
         ops.DMA_WIDE_WAVES = False
         assert chosen(128, 64, 64) == 11
     finally:
-        ops.DMA_WIDE_WAVES, ops.DMA_MW, ops.DMA_W8 = keep, keep_mw, keep_w8
-
-
-def test_conv_mw_index_arithmetic_replayed_on_the_host():
-    """csrc/conv_mw_index.h -- the LDS-DMA piece placement, ds_read_b128 fragment addresses and v_mfma_f32_32x32x16_bf16 lane maps of tile
-    configuration 21 -- replayed by tests/emulate_conv_mw.cpp (plain g++, no GPU) over whole tiles of ragged problems incl. the two-source
-    input and the fused shortcut: exact agreement with a direct convolution, every byte read was written by a DMA piece of the same
-    half-chunk, zero LDS bank conflicts in any ds_read_b128 lane group."""
-    import os
-    import shutil
-    import subprocess
-    import tempfile
-
-    gxx = shutil.which("g++")
-    if gxx is None:
-        pytest.skip("no host compiler")
-    here = os.path.dirname(os.path.abspath(__file__))
-    with tempfile.TemporaryDirectory() as tmp:
-        exe = os.path.join(tmp, "emu")
-        subprocess.run([gxx, "-O2", "-std=c++17", os.path.join(here, "emulate_conv_mw.cpp"), "-o", exe], check=True)
-        r = subprocess.run([exe], capture_output=True, text=True)
-    assert r.returncode == 0 and "conv_mw index replay OK" in r.stdout, r.stdout[-2000:]
-    assert "bank conflicts: 0" in r.stdout
-
-
-def test_conv_w8_index_arithmetic_replayed_on_the_host():
-    """Tile configuration 22 (csrc/conv_w8.hip): LDS-DMA pieces of the unpadded 1080-row patch (incremental row placement, the half piece at the
-    end), the halves weight image and its two-slot panel ring, ds_read_b128 fragments under the per-column bank key, the 32x32x16 MFMA lane maps,
-    the 64-byte-row fused shortcut and the transposing epilogue -- replayed by tests/emulate_conv_w8.cpp (plain g++, no GPU) over whole tiles of
-    ragged problems: exact agreement with a direct convolution, every byte read was written by a DMA piece of the same chunk / panel, zero LDS
-    bank conflicts in any ds_read_b128 lane group."""
-    import os
-    import shutil
-    import subprocess
-    import tempfile
-
-    gxx = shutil.which("g++")
-    if gxx is None:
-        pytest.skip("no host compiler")
-    here = os.path.dirname(os.path.abspath(__file__))
-    with tempfile.TemporaryDirectory() as tmp:
-        exe = os.path.join(tmp, "emu")
-        subprocess.run([gxx, "-O2", "-std=c++17", os.path.join(here, "emulate_conv_w8.cpp"), "-o", exe], check=True)
-        r = subprocess.run([exe], capture_output=True, text=True)
-    assert r.returncode == 0 and "conv_w8 index replay OK" in r.stdout, r.stdout[-2000:]
-    assert "bank conflicts: 0" in r.stdout
-
-
-def test_halves_image_of_a_packed_panel_is_a_permutation():
-    """ops.packed_conv_weight_halves: [chunk32][tap][Cout_pad][32] -> [chunk32][half][tap][Cout_pad][16] (pure torch, CPU)."""
-    import torch
-
-    nchunk, taps, cout_pad = 3, 27, 48
-    packed = torch.arange(nchunk * taps * cout_pad * 32, dtype=torch.float32)
-    v = packed.view(nchunk, taps, cout_pad, 2, 16).permute(0, 3, 1, 2, 4).contiguous()
-    c, h, t, co, e = 2, 1, 13, 40, 5
-    assert v[c, h, t, co, e] == packed.view(nchunk, taps, cout_pad, 32)[c, t, co, 16 * h + e]
+        ops.DMA_WIDE_WAVES = keep
 
 
 def test_native_planners_accept_and_reject_geometries_without_a_gpu():
@@ -575,14 +509,7 @@ def test_native_planners_accept_and_reject_geometries_without_a_gpu():
     assert lds(**dict(sub, Do=31)) == -1
     assert lds(**dict(sub, in_mode=1)) == -1
     assert lds(in_mode=3, kd=2, kh=2, kw=2, Do=32, Ho=32, Wo=32) == -1  # in_mode 3 exists for configuration 17 only
-    mw = 6 * 128 * 32 + 3 * 192 * 32 + 256                            # cfg 21 (conv_mw.hip): 32-byte rows, 24 KiB patch + 3 x 6 KiB panels + addend
-    assert lds(cfg=21) == mw and 3 * mw <= 160 * 1024                 # three work-groups per CU
-    assert lds(cfg=21, Cin=48) == mw                                  # 16-channel half-chunks
-    assert lds(cfg=21, Cin=40) == -1 and lds(cfg=21, dtype=0) == -1   # bf16 only
-    assert lds(cfg=21, in_mode=1, fd=2, fh=2, fw=2) == -1             # no folded up-sampling ...
-    d = conv_desc(cfg=21)
-    d.pre_scale, d.pre_shift, d.pre_act = 0x4000, 0x5000, 1
-    assert lib.gm_conv_lds_bytes(C.byref(d)) == -1                    # ... and no fused prologue: those stay on conv_dma.hip
+    assert lds(cfg=21) == -1 and lds(cfg=22) == -1                    # (round 6) no longer in the library
 
     def wgrad_bytes(**kw):
         d = nat.GmWgradDesc()

@@ -3,7 +3,8 @@ LDS-DMA kernels -- its real LDS image, DMA ring and barriers -- looped for >= 1.
 ms / launch, mean W, J / launch, pJ / FLOP.  All A/Bs quote joules, not milliseconds: the convolutions run at the package power cap, where
 time = joules / cap and the same launch reads +-15 % in ms minutes apart.
 
-  part A  the MFMA body, with the whole operand movement around it (python tools/taploop_energy.py bodies; the product library):
+  part A  the MFMA body, with the whole operand movement around it (python tools/taploop_energy.py bodies; the product library AS OF COMMIT 7c80f60: cfg 21 / 22
+          left it with this measurement -- experiments/conv_mw, conv_w8 -- and now print an error row):
           (i)  cfg 14: v_mfma_f32_16x16x32_bf16, 256-voxel tile, 64-byte rows, 4 waves x 64 voxels, two work-groups per CU  (today's default)
           (ii) cfg 21: v_mfma_f32_32x32x16_bf16 on the SAME 256-voxel tile in 16-channel half-chunks (32-byte rows), three work-groups per CU
                cfg 22: v_mfma_f32_32x32x16_bf16 on a 512-voxel tile, 64-byte patch rows, 16-channel weight panels, two work-groups per CU
