@@ -17,7 +17,7 @@ OBJDIR = os.path.join(HERE, "build")
 # "file.hip#k": the file compiled with -DGM_DMA_PART=k into its own object (conv_dma.hip: 26 kernel instantiations, 4.5 minutes as one
 # translation unit -- five parts build in parallel)
 SOURCES = ["capi.cpp", "elementwise.hip", "groupnorm.hip", "conv.hip", "conv_fast.hip", "conv_dma.hip#1", "conv_dma.hip#0", "conv_dma.hip#2", "conv_dma.hip#3",
-           "conv_dma.hip#4", "conv_sk.hip", "conv_edge.hip", "attention.hip", "attention_dma.hip", "attention_bwd.hip", "attention_bwd_dma.hip", "transformer_ops.hip", "decode_step.hip", "small_ops.hip", "backward.hip", "vq.hip"]
+           "conv_dma.hip#4", "conv_sk.hip", "conv_sn.hip", "conv_edge.hip", "attention.hip", "attention_dma.hip", "attention_bwd.hip", "attention_bwd_dma.hip", "transformer_ops.hip", "decode_step.hip", "small_ops.hip", "backward.hip", "vq.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
@@ -65,7 +65,7 @@ EXTRA_FLAGS = {"elementwise.hip": ["-ffp-contract=off"]}
 from ._build_variants import VARIANTS  # noqa: E402
 # translation units whose LDS-DMA inline assembly does not survive the sanitizer's instrumentation (its "s" operands stop being provably uniform):
 # compiled WITHOUT -fsanitize in the asan variant; their global accesses are the DMA requests themselves, which no sanitizer sees anyway
-ASAN_PLAIN = {"conv_dma.hip", "conv_sk.hip", "attention_dma.hip", "attention_bwd_dma.hip", "conv_edge.hip"}
+ASAN_PLAIN = {"conv_dma.hip", "conv_sk.hip", "conv_sn.hip", "attention_dma.hip", "attention_bwd_dma.hip", "conv_edge.hip"}
 _variant = None
 
 

@@ -375,7 +375,11 @@ extern "C" int gm_conv_dma_variant(int cfg);
 // 14: 4 waves x 64 voxels; 15: stride 2; 16: 512 voxels, 16 waves; 17: sub-pixel up-sampling; 18: 512 voxels, 8 waves x 64 voxels; 19: 512 voxels x 128 channels
 // (21 / 22 / 23: the three tile structures on v_mfma_f32_32x32x16_bf16 of rounds 4-5 -- each verified and measured equal or slower in time, and in round 6
 //  costlier in joules per launch on every C2 shape (profiles/r06_taploop_energy.txt) -- live under experiments/conv_mw, conv_w8, conv_w4; the ids stay retired)
-static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19); }
+// 24: conv_sn.hip -- small volumes, K-complete on 16-channel output blocks (256 voxels x 16 channels per work-group, no split-K, epilogue + statistics in the kernel)
+#define CONV_CFG_SN 24
+extern "C" int gm_conv_sn_eligible(const GmConvDesc* d);
+extern "C" long long gm_conv_sn_lds_bytes();
+static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19) || cfg == CONV_CFG_SN; }
 // HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
 #define CONV_CFG_CIN 12
 #define CONV_CFG_COUT1 13
@@ -406,6 +410,7 @@ extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
   if (cfg == 15) { *bm = 128; *bn = 64; return 0; }
   if (cfg == 16 || cfg == 18) { *bm = 512; *bn = 64; return 0; }
   if (cfg == 19) { *bm = 512; *bn = 128; return 0; }
+  if (cfg == CONV_CFG_SN) { *bm = 256; *bn = 16; return 0; }
   if (conv_is_dma(cfg) || cfg == CONV_CFG_CIN) { *bm = 256; *bn = 64; return 0; }
   if (cfg == CONV_CFG_COUT1) { *bm = 256; *bn = 16; return 0; }
   if (cfg == CONV_CFG_COUT1M) { *bm = 256; *bn = 16; return 0; }  // (per plane; the depth extent of a work-group is GmConvDesc.ltd)
@@ -444,6 +449,7 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   if (d && (d->skip_x[0] || d->x2) && !conv_is_dma(d->cfg)) return -1;  // the fused 1x1 shortcut / second source exist in the LDS-DMA kernels only
+  if (d && d->cfg == CONV_CFG_SN) return gm_conv_sn_eligible(d) ? gm_conv_sn_lds_bytes() : -1;
   if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes(gm_conv_dma_variant(d->cfg)) : -1;
   if (d && d->cfg == CONV_CFG_CIN) return gm_conv_cin_eligible(d) ? gm_conv_cin_lds_bytes(d) : -1;
   if (d && d->cfg == CONV_CFG_COUT1) return gm_conv_cout1_eligible(d) ? gm_conv_cout1_lds_bytes() : -1;
@@ -594,6 +600,8 @@ extern "C" long long gm_conv_stats_slots(const GmConvDesc* d) {
   if (!d) return 0;
   const bool fused = conv_is_fast(d->cfg) || conv_is_dma(d->cfg) || d->cfg == CONV_CFG_CIN;
   if (!fused) return 0;
+  if (d->cfg == CONV_CFG_SN)  // four channels per lane straight from the accumulators: whatever the kernel takes, it also counts
+    return gm_conv_sn_eligible(d) ? (long long)((d->Do + 3) >> 2) * ((d->Ho + 3) >> 2) * ((d->Wo + 15) >> 4) : 0;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const bool lds_epilogue = (d->Cout % vecw == 0) && (d->y_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0) &&
                             (!d->res || ((d->res_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->res) & 15) == 0)));

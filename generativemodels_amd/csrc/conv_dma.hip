@@ -1078,6 +1078,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv_dma_kernel(const GmConvDes
 // variant: 1 = stride 1, 4x4x16 tile; 2 = stride 2, 2x4x16 tile; 3 = stride 1, 8x4x16 tile; 4 = sub-pixel 2x2x2 (5 planes of 5 x 17 -> 96 rows,
 // four 128-row weight panels, padded to the 36 KiB of the epilogue's transpose scratch); 5 = 8x4x16 tile x 128 output channels (three 384-row
 // weight panels).  Every variant ends with the 512-byte epilogue addend vector.
+// tile configuration 24 (conv_sn.hip: small volumes, K-complete on 16-channel output blocks) shares this file's entry points
+extern "C" int gm_conv_sn_eligible(const GmConvDesc* d);
+extern "C" int gm_conv_sn_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
 // the K slices of a split-K launch (cfg 11 geometry) run on conv_sk.hip's kernel: one work-group per CU, patch + all nine panels of a chunk resident
 extern "C" int gm_conv_sk_eligible(const GmConvDesc* d);
 extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* stream);
@@ -1148,6 +1151,7 @@ extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 17 ? 4 : (cfg == 15 
 
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   if (d->cfg == 21 || d->cfg == 22) return 0;  // (the 32x32x16 tile structures of rounds 4-5: experiments/conv_mw, conv_w8 -- not in the library)
+  if (d->cfg == 24) return gm_conv_sn_eligible(d);
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const int s = d->cfg == 15 ? 2 : 1;
@@ -1269,6 +1273,7 @@ extern "C" int gm_conv_dma_launch_part4(const GmConvDesc* dp, unsigned nblocks, 
 
 #if DMA_PART(0)
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
+  if (dp->cfg == 24) return gm_conv_sn_launch(dp, nblocks, stream);
   if (gm_conv_sk_eligible(dp)) return gm_conv_sk_launch(dp, nblocks, stream);
   switch (dp->cfg) {
     case 14: return gm_conv_dma_launch_part1(dp, nblocks, stream);

@@ -1,0 +1,376 @@
+// 3x3x3 stride-1 convolution over a SMALL volume, K-COMPLETE on NARROW output-channel blocks (tile configuration 24, round 6): the ResnetBlock convolutions
+// of the 32^3 / 16^3 / 8^3 levels of a latent UNet (reference: generative/networks/nets/diffusion_model_unet.py:589-696).
+//
+// Until round 5 these launches were split-K: too few 256-voxel x 64-channel tiles for 256 CUs, so the K chunks of a tile were dealt to `ksplit` work-groups
+// (conv_sk.hip) that wrote fp32 partial sums, and a second launch (conv_splitk_combine_kernel) summed the slices and applied the epilogue: 17.3 + 7.7 us of
+// kernel time per convolution, 34 convolutions per latent step = 0.85 of the step's 1.67 ms (rocprofv3, profiles/r06_c3_unet_kernel_stats_before.csv).
+// The other way to make more work-groups out of a small volume is the OUTPUT-CHANNEL axis: a work-group owns a 256-voxel tile x 16 output channels and the
+// WHOLE contraction.  What that buys: no partial sums in HBM, no second launch, the epilogue (bias + timestep row + residual + activation + GroupNorm
+// statistics) in the kernel that produced the accumulators.  What it costs: the halo patch of a tile is staged once per 16-channel block instead of once per
+// 64 (L2 hits: the blocks of a tile are neighbours in the XCD's work range) and one MFMA column per operand read.  Per K chunk a work-group stages 42 KiB of
+// patch + 27 KiB of weights (ALL 27 taps of its 16 channels: one request burst, one wait, one barrier per chunk -- conv_sk.hip's latency recipe) = 73 KiB of
+// LDS with the scale / shift copies: TWO work-groups per CU, one staging while the other multiplies.
+// Same 4x4x16 tile, patch layout, source-side bank swizzle and packed weight image ([chunk][tap][Cout_pad][BK]) as conv_dma.hip / conv_sk.hip; also their
+// fused GroupNorm-apply + activation prologue in LDS (bit-identical arithmetic to gm_gn_apply), the second input source of a virtual concatenation and the
+// fused 1x1 shortcut.  bf16 and fp32.  Deterministic: fixed summation orders, statistics stored once per (tile, channel).
+#include "conv_dma_shared.h"
+
+__device__ __attribute__((aligned(64))) unsigned int gm_sn_zero_row[16] = {0};  // the source of every padding row
+
+namespace sn {
+constexpr int KS = 3, NTAP = 27;
+constexpr int TD = 4, TH = 4, TW = 16, BM = 256, BN = 16;
+constexpr int PD = 6, PH = 6, PW = 18, PLANE = 112, PROWS = PD * PLANE, PPIECES = PROWS / 16;
+constexpr int PATCH_BYTES = PROWS * DMA_ROWB, W_BYTES = NTAP * BN * DMA_ROWB;  // 43 008 + 27 648
+constexpr int MAXW = 8;                                         // the LDS layout is sized for the 8-wave form
+constexpr int AFF_OFF = PATCH_BYTES + W_BYTES, AFF_WAVE = 256;  // per wave: [scale | shift] of the chunk being staged (PRE)
+constexpr int STAT_OFF = AFF_OFF + MAXW * AFF_WAVE;             // [wave][16 channels][sum, sum of squares] fp32
+constexpr int LDS_BYTES = STAT_OFF + MAXW * BN * 8;             // 73 728: two work-groups per CU
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two work-groups per CU");
+static_assert(2 * BM * DMA_ROWB <= PATCH_BYTES && 2 * BN * DMA_ROWB <= W_BYTES, "the shortcut's two chunks per round fit into the operand buffers");
+}  // namespace sn
+
+__device__ __forceinline__ float sn_row16_sum(float v) {  // sum over the 16 lanes of a DPP row, every lane ends with it; fixed order
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x122, 0xF, 0xF, true));  // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x121, 0xF, 0xF, true));  // row_ror:1
+  return v;
+}
+
+// NW waves x MF 16-voxel fragments cover the 256-voxel tile: <8, 2> (the fragments of a tap are 3 LDS reads for 2 MFMAs) or <4, 4> (5 reads for 4 MFMAs:
+// the kernel is bound by its LDS operand reads -- one MFMA column per weight fragment -- so fewer, fatter waves read less)
+template <typename T, bool PRE, int NW, int MF>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const GmConvDesc p) {
+  using namespace sn;
+  static_assert(NW * MF * 16 == BM && NW <= MAXW && MF <= 4, "waves x fragments cover the tile; a wave's fragments are lines of one plane");
+  constexpr int PPW = (PPIECES + NW - 1) / NW, WPW = (NTAP + NW - 1) / NW;  // patch / weight pieces per wave and chunk (tap = wave + NW h: one 1 KiB piece per tap)
+  constexpr int BK = ConvTraits<T>::BK;
+  constexpr int VECW = ConvTraits<T>::VECW;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch][27 taps x 16 weight rows][8 x (scale | shift)][8 x 16 statistic partials]
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+
+  // ---- the work item: (tile, 16-channel block); XCD x owns a contiguous range, the blocks of a tile are neighbours in it (their patches meet in one L2) ----
+  const int ntd = (p.Do + TD - 1) / TD, nth = (p.Ho + TH - 1) / TH, ntw = (p.Wo + TW - 1) / TW;
+  const int ncb = (p.Cout + BN - 1) / BN;
+  const int nchunks = p.Cin / BK, cout_pad = (p.Cout + 15) & ~15;
+  const unsigned nwork = (unsigned)p.N * ntd * nth * ntw * ncb;
+  const unsigned xcd = blockIdx.x & 7;
+  const unsigned q8 = nwork >> 3, r8 = nwork & 7, cx = q8 + (xcd < r8 ? 1u : 0u), sx = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  if ((blockIdx.x >> 3) >= cx) return;  // (never: the grid is nwork work-groups)
+  unsigned b = sx + (blockIdx.x >> 3);
+  const int cb = __builtin_amdgcn_readfirstlane((int)(b % ncb)); b /= ncb;
+  const int tw_i = __builtin_amdgcn_readfirstlane((int)(b % ntw)); b /= ntw;
+  const int th_i = __builtin_amdgcn_readfirstlane((int)(b % nth)); b /= nth;
+  const int td_i = __builtin_amdgcn_readfirstlane((int)(b % ntd)); b /= ntd;
+  const int n = __builtin_amdgcn_readfirstlane((int)b);
+  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
+
+  // ---- weights: tap t of this block = rows cb*16 .. +15 of the (chunk, tap) panel = one contiguous 1 KiB piece; LDS row t*16 + r, slot s <- source slot
+  // s ^ swz(r) (rows 16 apart share the key: period 8) -----------------------------------------------------------------------------------------------
+  const char* zero = reinterpret_cast<const char*>(gm_sn_zero_row);
+  const char* wbase = reinterpret_cast<const char*>(p.w) + ((long long)cb * BN + (lane >> 2)) * DMA_ROWB + (((lane & 3) ^ dma_swz(lane >> 2)) << 4);
+  auto issue_weights = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < WPW; ++h) {
+      const int tap = wave + NW * h;  // wave-uniform
+      if (tap < NTAP) dma16(wbase + (long long)(chunk * NTAP + tap) * cout_pad * DMA_ROWB, lds0 + PATCH_BYTES + (unsigned)tap * (BN * DMA_ROWB));
+    }
+  };
+
+  issue_weights(0);  // (they need the channel block only: the patch placement arithmetic below runs under their flight)
+
+  // ---- patch rows of this lane (conv_dma.hip's layout: 64-byte rows, swizzle keyed on the row's column within its W line, applied on the source side) ----
+  int psw = 0, pvox[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int row = 16 * (wave + NW * j) + (lane >> 2);
+    const int pa = row / PLANE, rr = row - pa * PLANE;
+    const int pb = rr / PW, lc = rr - pb * PW;
+    psw |= dma_swz(lc) << (2 * j);
+    const int ud = od0 - p.pd + pa, uh = oh0 - p.ph + pb, uw = ow0 - p.pw + lc;
+    const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < p.Ds) & (uh >= 0) & (uh < p.Hs) & (uw >= 0) & (uw < p.Ws);
+    pvox[j] = ok ? ((n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
+  }
+  const char* xbase = reinterpret_cast<const char*>(p.x);
+  const char* x2base = reinterpret_cast<const char*>(p.x2);
+  const long long xrowb = p.x_ld * (long long)sizeof(T), x2rowb = p.x2_ld * (long long)sizeof(T);
+  const int nchunks0 = p.x2 ? p.cin_split / BK : nchunks;
+  auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
+    if (PRE) {
+      const int nl = BK / 4;  // lanes 0 .. nl - 1 fetch the chunk's scale, nl .. 2 nl - 1 its shift (16 bytes each) into this wave's own copy
+      if (lane < 2 * nl) {
+        const float* src = (lane < nl ? p.pre_scale : p.pre_shift) + (long long)n * p.Cin + chunk * BK + 4 * (lane < nl ? lane : lane - nl);
+        dma16(src, lds0 + AFF_OFF + (unsigned)wave * AFF_WAVE);
+      }
+    }
+    const bool second = chunk >= nchunks0;  // wave-uniform: the chunk comes from x2 (virtual channel concatenation)
+    const char* cbase = second ? x2base + (long long)(chunk - nchunks0) * (BK * (int)sizeof(T)) : xbase + (long long)chunk * (BK * (int)sizeof(T));
+    const long long rowb = second ? x2rowb : xrowb;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (wave + NW * j < PPIECES) {  // wave-uniform
+        const char* in_src = cbase + (long long)(pvox[j] & ~(pvox[j] >> 31)) * rowb + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4);
+        const char* pad_src = zero + ((lane & 3) << 4);
+        dma16(pvox[j] >= 0 ? in_src : pad_src, lds0 + (unsigned)(16 * (wave + NW * j)) * DMA_ROWB);
+      }
+    }
+  };
+  // GroupNorm-apply + activation IN LDS on this wave's own landed pieces (conv_dma.hip: transform_patch; same arithmetic and rounding as gm_gn_apply;
+  // rows that came from the zero page stay zero: the reference pads the ACTIVATED tensor)
+  auto transform_patch = [&]() __attribute__((always_inline)) {
+    float sc[VECW], sh[VECW];
+    const float* aff = reinterpret_cast<const float*>(smem + AFF_OFF + wave * AFF_WAVE);
+#pragma unroll
+    for (int i = 0; i < VECW; i += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(aff + (lane & 3) * VECW + i), c = *reinterpret_cast<const float4*>(aff + BK + (lane & 3) * VECW + i);
+      sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
+      sh[i] = c.x; sh[i + 1] = c.y; sh[i + 2] = c.z; sh[i + 3] = c.w;
+    }
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (wave + NW * j < PPIECES && pvox[j] >= 0) {
+        char* a = smem + (16 * (wave + NW * j) + (lane >> 2)) * DMA_ROWB + (((lane & 3) ^ ((psw >> (2 * j)) & 3)) << 4);
+        float v[VECW];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(a), v);
+#pragma unroll
+        for (int i = 0; i < VECW; ++i) v[i] = v[i] * sc[i] + sh[i];
+        conv_act_vec(v, p.pre_act, sizeof(T) == 4);
+        *reinterpret_cast<uint4*>(a) = Vec16<T>::pack(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  issue_patch(0);
+
+  // ---- the epilogue's per-channel addend (bias + shortcut bias + timestep row, this order, fp32) and this lane's output rows: under the first flight ----
+  const int co4 = cb * BN + q * 4;  // this lane's four output channels (accumulator rows 4q .. 4q + 3 of the 16x16 MFMA)
+  float add[4] = {0.f, 0.f, 0.f, 0.f};
+  if (co4 < p.Cout) {  // host-checked: Cout % 4 == 0
+    if (p.bias) { const float4 v = *reinterpret_cast<const float4*>(p.bias + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
+    if (p.skip_bias) { const float4 v = *reinterpret_cast<const float4*>(p.skip_bias + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
+    if (p.rowvec) { const float4 v = *reinterpret_cast<const float4*>(p.rowvec + (long long)n * p.rowvec_bstride + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
+  }
+
+  // ---- operand read addresses (conv_dma.hip: XADDR / WADDR) ---------------------------------------------------------------------------------------
+  int xa[KS];
+  {
+    const int m0 = wave * MF * 16 + l15;
+    const int a = m0 >> 6, bb0 = (m0 >> 4) & 3, c = m0 & 15;
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) xa[kw] = (a * PLANE + bb0 * PW + c + kw) * DMA_ROWB + ((q ^ dma_swz(c + kw)) << 4);
+  }
+  const int wa0 = PATCH_BYTES + l15 * DMA_ROWB + ((q ^ dma_swz(l15)) << 4);
+  f32x4_t acc[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) acc[mf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  uint4 xf[2][MF], wf[2];
+  auto read_tap = [&](int tap, int set) __attribute__((always_inline)) {
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    wf[set] = *reinterpret_cast<const uint4*>(smem + wa0 + tap * (BN * DMA_ROWB));
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) xf[set][mf] = *reinterpret_cast<const uint4*>(smem + xa[kw] + (mf + kh) * (PW * DMA_ROWB) + kd * (PLANE * DMA_ROWB));
+  };
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    dma_wait<0>();                    // this wave's pieces of the chunk (and, PRE, its scale / shift copy) have landed
+    if (PRE) transform_patch();
+    __builtin_amdgcn_s_barrier();     // ... everyone's
+    read_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      // two operand sets: the next tap's three reads are issued, THEN this tap's MFMAs (sched_barrier: hipcc would merge the sets otherwise)
+      if (tap + 1 < NTAP) read_tap(tap + 1, (tap + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) Mma<T>::run(wf[tap & 1], xf[tap & 1][mf], acc[mf]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (chunk + 1 < nchunks) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // every wave is done with this chunk's patch and weights
+      issue_weights(chunk + 1);
+      issue_patch(chunk + 1);
+    }
+  }
+
+  // ---- fused 1x1 shortcut convolution (conv_dma.hip: extra K chunks over the skip sources, centre tap only): two chunks per round -- every wave stages the
+  // 64-byte chunk of ITS OWN 32 output voxels into the patch buffer, waves 0 / 1 the 16-row weight piece of chunk 0 / 1 ------------------------------------
+  if (p.skip_x[0]) {
+    const int nsc0 = p.skip_cin[0] / BK, nsc = nsc0 + (p.skip_x[1] ? p.skip_cin[1] / BK : 0);
+    const int pswz = ((lane & 3) ^ dma_swz(lane >> 2)) << 4;
+    int svox[MF];
+#pragma unroll
+    for (int h = 0; h < MF; ++h) {
+      const int m = wave * (MF * 16) + h * 16 + (lane >> 2);
+      const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+      svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
+    }
+    int caddr[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int m = (wave * MF + mf) * 16 + l15;
+      caddr[mf] = m * DMA_ROWB + ((q ^ dma_swz(m)) << 4);
+    }
+    const char* wsk = reinterpret_cast<const char*>(p.skip_w) + ((long long)cb * BN + (lane >> 2)) * DMA_ROWB + pswz;
+    for (int sc0 = 0; sc0 < nsc; sc0 += 2) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // the operand buffers are free
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int sc = sc0 + j;
+        if (sc < nsc) {  // wave-uniform
+          const int part = sc >= nsc0 ? 1 : 0, cip = sc - (part ? nsc0 : 0);
+          const char* xb = reinterpret_cast<const char*>(p.skip_x[part]) + (long long)cip * (BK * (int)sizeof(T)) + pswz;
+          const long long rowb = p.skip_ld[part] * (long long)sizeof(T);
+#pragma unroll
+          for (int h = 0; h < MF; ++h) {
+            const char* src = svox[h] >= 0 ? xb + svox[h] * rowb : zero + ((lane & 3) << 4);
+            dma16(src, lds0 + (unsigned)(j * BM + wave * (MF * 16) + h * 16) * DMA_ROWB);
+          }
+          if (wave == j) dma16(wsk + (long long)sc * cout_pad * DMA_ROWB, lds0 + PATCH_BYTES + (unsigned)(j * BN) * DMA_ROWB);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (sc0 + j < nsc) {
+          const uint4 ws = *reinterpret_cast<const uint4*>(smem + wa0 + j * (BN * DMA_ROWB));
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            const uint4 xs = *reinterpret_cast<const uint4*>(smem + caddr[mf] + j * (BM * DMA_ROWB));
+            Mma<T>::run(ws, xs, acc[mf]);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue from the accumulators: lane (l15, q) holds channels co4 .. co4 + 3 of voxels (wave * 2 + mf) * 16 + l15 -- y = act(acc + addend + residual),
+  // rounded once; statistics of the values as stored ---------------------------------------------------------------------------------------------------
+  float ss[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+  T* yout = reinterpret_cast<T*>(p.y);
+  const T* res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = (wave * MF + mf) * 16 + l15;
+    const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+    if (od < p.Do && oh < p.Ho && ow < p.Wo && co4 < p.Cout) {
+      const long long vox = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = acc[mf][r] + add[r];
+      if (res) {
+        const T* rp = res + vox * p.res_ld + co4;
+        if (sizeof(T) == 4) {
+          const float4 rv = *reinterpret_cast<const float4*>(rp);
+          o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+        } else {
+          const uint2 rv = *reinterpret_cast<const uint2*>(rp);
+          o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+          o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+        }
+      }
+      if (p.post_act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = conv_post_act(o[r], p.post_act);
+      }
+      T* yp = yout + vox * p.y_ld + co4;
+      if (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        const uint2 raw = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(yp) = raw;
+        o[0] = __uint_as_float(raw.x << 16); o[1] = __uint_as_float(raw.x & 0xffff0000u);
+        o[2] = __uint_as_float(raw.y << 16); o[3] = __uint_as_float(raw.y & 0xffff0000u);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ss[r] += o[r]; sq[r] += o[r] * o[r]; }
+    }
+  }
+  if (p.stats) {
+    // lane sums over its two voxels -> sum over the 16 lanes of its DPP row (the 16 voxels of a W line) -> one partial per (wave, channel) in LDS ->
+    // fixed-order fp64 sum over the 8 waves: one plain store per (tile, channel), no atomics
+    float* part = reinterpret_cast<float*>(smem + STAT_OFF) + wave * (BN * 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = sn_row16_sum(ss[r]), b2 = sn_row16_sum(sq[r]);
+      if (l15 == 0) { part[(q * 4 + r) * 2] = a; part[(q * 4 + r) * 2 + 1] = b2; }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      double a = 0.0, b2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float2 v = *reinterpret_cast<const float2*>(smem + STAT_OFF + (w * BN + tid) * 8);
+        a += (double)v.x;
+        b2 += (double)v.y;
+      }
+      const int co = cb * BN + tid;
+      if (co < p.Cout) {
+        const long long slot = ((long long)td_i * nth + th_i) * ntw + tw_i;  // the tile within its sample
+        *reinterpret_cast<double2*>(p.stats + ((slot * p.N + n) * p.Cout + co) * 2) = make_double2(a, b2);
+      }
+    }
+  }
+}
+
+// geometry this kernel takes: cfg 24, 3x3x3 stride 1, direct input, the vector-aligned operands of the other LDS-DMA configurations
+extern "C" int gm_conv_sn_eligible(const GmConvDesc* d) {
+  const int bk = d->dtype == GM_F32 ? 16 : 32;
+  const int vecw = d->dtype == GM_F32 ? 4 : 8;
+  return d->cfg == 24 && (d->dtype == GM_F32 || d->dtype == GM_BF16) && d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
+         d->dd == 1 && d->dh == 1 && d->dw == 1 && d->in_mode == 0 && d->ltd == 2 && d->lth == 2 && d->ltw == 4 && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
+         (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && !(d->ksplit > 1 && d->kpartial) &&
+         ((d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_act == 0) ||
+          (d->pre_scale != nullptr && d->pre_shift != nullptr && (reinterpret_cast<uintptr_t>(d->pre_scale) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(d->pre_shift) & 15) == 0 && (d->Cin % 4) == 0)) &&
+         (d->x2 == nullptr || (d->cin_split > 0 && d->cin_split < d->Cin && d->cin_split % bk == 0 && d->x2_ld % vecw == 0 &&
+                               (reinterpret_cast<uintptr_t>(d->x2) & 15) == 0)) &&
+         // four channels per lane: 8-byte (bf16) / 16-byte (fp32) stores and residual loads; fp32 addend vectors
+         d->Cout % 4 == 0 && d->y_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->y) & (4 * (d->dtype == GM_F32 ? 4 : 2) - 1)) == 0 &&
+         (!d->res || (d->res_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->res) & (4 * (d->dtype == GM_F32 ? 4 : 2) - 1)) == 0)) &&
+         (!d->bias || (reinterpret_cast<uintptr_t>(d->bias) & 15) == 0) && (!d->skip_bias || (reinterpret_cast<uintptr_t>(d->skip_bias) & 15) == 0) &&
+         (!d->rowvec || ((reinterpret_cast<uintptr_t>(d->rowvec) & 15) == 0 && d->rowvec_bstride % 4 == 0)) &&
+         (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31) && (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31) &&
+         (!d->skip_x[0] ||
+          (d->skip_w && d->skip_cin[0] > 0 && d->skip_cin[0] % bk == 0 && d->skip_ld[0] % vecw == 0 && (reinterpret_cast<uintptr_t>(d->skip_x[0]) & 15) == 0 &&
+           (!d->skip_x[1] || (d->skip_cin[1] > 0 && d->skip_cin[1] % bk == 0 && d->skip_ld[1] % vecw == 0 &&
+                              (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
+}
+
+extern "C" long long gm_conv_sn_lds_bytes() { return sn::LDS_BYTES; }
+
+static int g_sn_waves = 8;  // process-wide (A/B measurements; results do not depend on it up to the summation order of the statistics): 8 x 2 or 4 x 4
+extern "C" void gm_conv_sn_set_waves(int waves) { g_sn_waves = waves == 4 ? 4 : 8; }
+
+template <typename T, bool PRE, int NW, int MF>
+static void launch_sn(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_sn_kernel<T, PRE, NW, MF>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();
+    attr_set = true;
+  }
+  kern<<<dim3(nblocks), 64 * NW, (size_t)sn::LDS_BYTES, st>>>(d);
+}
+
+template <typename T>
+static void launch_sn_dt(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
+  const bool pre = d.pre_scale != nullptr;
+  if (g_sn_waves == 4) { if (pre) launch_sn<T, true, 4, 4>(d, nblocks, st); else launch_sn<T, false, 4, 4>(d, nblocks, st); }
+  else { if (pre) launch_sn<T, true, 8, 2>(d, nblocks, st); else launch_sn<T, false, 8, 2>(d, nblocks, st); }
+}
+
+extern "C" int gm_conv_sn_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dp->dtype == GM_F32) { launch_sn_dt<float>(*dp, nblocks, st); return 0; }
+  if (dp->dtype == GM_BF16) { launch_sn_dt<bf16_raw>(*dp, nblocks, st); return 0; }
+  return -2;
+}

@@ -678,7 +678,14 @@ SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups t
 SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "256"))
 SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
 _SK_KERNEL = os.environ.get("GM_CONV_SK")  # "0": the slices on the general cfg 11 tile kernel (round-3 path) instead of conv_sk.hip -- A/B measurements only
-DMA_CFGS = (11, 14, 15, 16, 17, 18, 19)
+DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 24)
+# cfg 24 (csrc/conv_sn.hip, round 6): a small volume's 3x3x3 convolution K-COMPLETE on 16-channel output blocks -- 256 voxels x 16 channels per work-group, the
+# epilogue and the GroupNorm statistics in the kernel -- instead of split-K slices + a combine launch.  Taken where the launch would have been split (fewer
+# 64-channel tiles than SPLITK_MAX_TILES) and the contraction is at most NARROW_N_MAX_CHUNKS K chunks deep (a work-group walks them one after the other; deeper
+# contractions keep the K slices), and for the C_out <= 16 heads the tile kernels do not cover (the latent UNet's 64 -> 4 output convolution).
+NARROW_N = os.environ.get("GM_CONV_SN", "1") != "0"
+NARROW_N_MAX_CHUNKS = int(os.environ.get("GM_CONV_SN_MAX_CHUNKS", "6"))
+_SN_WAVES = os.environ.get("GM_CONV_SN_WAVES")  # bench A/B: "4" = 4 waves x 64 voxels
 # (Rounds 4-5 built three more tile structures on v_mfma_f32_32x32x16_bf16 -- cfg 21: 16-channel half-chunks, three work-groups per CU; cfg 22: 512-voxel
 #  tiles with 16-channel weight panels; cfg 23: cfg 22's image on four waves of 4 x 2 blocks -- each verified bit-level and measured: all tie or lose against
 #  cfg 14 in time, and in round 6 in JOULES per launch on every C2 shape (profiles/r06_taploop_energy.txt: +1 ... +16 %).  They live under experiments/
@@ -845,8 +852,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             if COUT1_MARCH_LTD is not None:
                 ltd = int(COUT1_MARCH_LTD)
             bits = [ltd, 3, ltw]
-        if cfg in (11, 14, 15, 16, 18, 19):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
-            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
+        if cfg in (11, 14, 15, 16, 18, 19, 24):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
+            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 24: [2, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
@@ -1201,6 +1208,22 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             dma_ok = True
         except ValueError:
             dma_ok = False
+    if NARROW_N and force_cfg is None and ksplit is None and DMA_CONV and fuse_in_lds and nvox * n >= DMA_CONV_MIN_VOXELS:
+        bk = 64 // x.element_size()
+        if dma_ok and d.cfg == 11 and SPLITK:
+            tiles = n * ((out_sp[0] + 3) // 4) * ((out_sp[1] + 3) // 4) * ((out_sp[2] + 15) // 16) * ((cout + 63) // 64)
+            deep = cin // bk + (0 if skip is None else sum(t.shape[-1] for t in skip[0]) // bk)
+            if tiles < SPLITK_MAX_TILES and min(cin // bk, SPLITK_MAX, SPLITK_TARGET_WGS // tiles) > 1 and deep <= NARROW_N_MAX_CHUNKS:
+                try:  # the launch would be split over K: K-complete on 16-channel blocks instead (cfg 24)
+                    _choose_conv_cfg(d, nvox, 24, only=DMA_CFGS)
+                except ValueError:
+                    _choose_conv_cfg(d, nvox, 11, only=DMA_CFGS)
+        elif not dma_ok and cout <= 16:  # a narrow output head (64 -> 4): the generic tile kernel otherwise (42 us at 32^3)
+            try:
+                _choose_conv_cfg(d, nvox, 24, only=DMA_CFGS)
+                dma_ok = True
+            except ValueError:
+                pass
     if not dma_ok:
         if force_cfg is not None and force_cfg in DMA_CFGS:
             raise ValueError(f"configuration {force_cfg} does not cover this convolution")
@@ -1232,6 +1255,8 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             raise ValueError("configuration 12 needs the original [Cout, Cin, 3, 3, 3] weight (its K-major image is derived from it)")
         cin_keep = packed_cin_weight(weight, dtype)
         d.w = cin_keep.data_ptr()
+    if dma_ok and d.cfg == 24 and _SN_WAVES is not None:
+        lib().gm_conv_sn_set_waves(int(_SN_WAVES))
     kpart = None
     if dma_ok and d.cfg == 11 and (ksplit is not None or SPLITK):
         nchunks = cin // (64 // x.element_size())

@@ -285,8 +285,65 @@ def test_conv_lds_dma_kernel(case, dtype, cfg):
     assert torch.equal(auto, got.contiguous()) or (auto.float() - got.float()).abs().max() <= 2e-2 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", [("plain", 32, 64, None, None, (8, 8, 16), "res"), ("ragged", 64, 40, None, None, (5, 7, 19), "res"),
+                                  ("head4", 64, 4, None, None, (6, 9, 17), "none"), ("wide", 96, 136, None, None, (4, 6, 18), "res"),
+                                  ("cat", 96, 72, 64, None, (5, 7, 19), "none"), ("skip", 64, 64, None, (32,), (8, 8, 16), "skip"),
+                                  ("skip-cat", 32, 40, None, (64, 32), (5, 7, 19), "skip"), ("skip-cat3", 128, 136, 64, (32, 96), (4, 6, 18), "skip"),
+                                  ("deep", 256, 64, None, None, (8, 8, 8), "res"), ("tanh", 32, 24, None, None, (4, 4, 16), "tanh")], ids=lambda c: c[0])
+def test_conv_small_volume_narrow_output_block_kernel(case, dtype):
+    """cfg 24 (conv_sn.hip, round 6): a small volume's 3x3x3 convolution K-complete on 16-channel output blocks -- no split-K slices, no combine launch, the
+    epilogue and the GroupNorm statistics in the kernel.  Ragged volumes, output-channel counts that are not multiples of 16 (40, 136, a 4-channel head), the
+    two-source input of a virtual concatenation, bias + timestep row + residual into a channel slice of a wider buffer, the fused 1x1 shortcut over one / two
+    sources (more than one round of two chunks), an output activation, fused statistics -- against fp64 and against the split-K path it replaces (cfg 11:
+    same function, another summation order); run-to-run bitwise.  Reference: ResnetBlock, diffusion_model_unet.py:669-696."""
+    ops = _ops()
+    name, cin, cout, split, pcs, sp, mode = case
+    n = 2
+    x = _rand((n, cin, *sp), 571).to(dtype)
+    w = (_rand((cout, cin, 3, 3, 3), 572) / math.sqrt(cin * 27)).to(dtype)
+    b, temb = _rand((cout,), 573) * 0.1, _rand((n, cout), 574) * 0.5
+    want = F.conv3d(x.double(), w.double(), b.double(), padding=1) + temb.double().reshape(n, cout, 1, 1, 1)
+    wide_in = torch.zeros((n, *sp, cin + 8), dtype=dtype, device=DEV)
+    wide_in[..., 8:] = _cl(x)
+    xa = wide_in[..., 8:]
+    operand = xa if split is None else ops.VirtualCat([xa[..., :split], xa[..., split:].contiguous()])
+    kw = dict(kernel=3, padding=1, rowvec=temb.to(DEV), want_stats=True)
+    if mode == "res":
+        res = _rand((n, cout, *sp), 575).to(dtype)
+        kw["res"] = _cl(res)
+        want = want + res.double()
+    elif mode == "tanh":
+        kw["post_act"] = "tanh"
+        want = torch.tanh(want)
+    elif mode == "skip":
+        parts = [_rand((n, c, *sp), 580 + i).to(dtype) for i, c in enumerate(pcs)]
+        ws = (_rand((cout, sum(pcs), 1, 1, 1), 576) / math.sqrt(sum(pcs))).to(dtype)
+        bs = _rand((cout,), 577) * 0.1
+        want = want + F.conv3d(torch.cat([p.double() for p in parts], 1), ws.double(), bs.double())
+        dparts = []
+        for p in parts:
+            wide = torch.zeros((n, *sp, p.shape[1] + 8), dtype=dtype, device=DEV)
+            wide[..., 8:] = _cl(p)
+            dparts.append(wide[..., 8:])
+        kw["skip"] = (dparts, ws.to(DEV), bs.to(DEV))
+    wide_out = torch.full((n, *sp, cout + 16), 7.0, dtype=dtype, device=DEV)
+    got = ops.conv(operand, w.to(DEV), b.to(DEV), out=wide_out[..., 16:], force_cfg=24, **kw)
+    _check(_cf(got), want, dtype, f"cfg24 {name}", extra=1.5 if mode == "skip" else 1.0)
+    assert torch.all(wide_out[..., :16] == 7.0)  # nothing written outside the slice
+    st = got._gm_cstats.sum(0).cpu()
+    v = got.float().cpu().double().reshape(n, -1, cout)
+    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1], (v * v).sum(1), rtol=1e-4, atol=1e-2)
+    if cout % 8 == 0 and mode != "tanh":  # the split-K slices + combine launch this configuration replaces
+        other = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=11, ksplit=2 if cin >= 64 else None, **kw)
+        tol = (2 ** -6 if dtype == torch.bfloat16 else 1e-4) * max(1.0, want.abs().max().item())
+        assert (other.float() - got.float()).abs().max().item() <= tol
+    again = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=24, **kw)
+    assert torch.equal(again, got.contiguous()) and torch.equal(again._gm_cstats, got._gm_cstats)  # run-to-run bitwise
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [11, 14, 16, 18, 19])
+@pytest.mark.parametrize("cfg", [11, 14, 16, 18, 19, 24])
 @pytest.mark.parametrize("case", [("one", 64, 72, None, (6, 9, 19), 2), ("cat", 96, 40, 64, (5, 7, 19), 2), ("cat-wide", 160, 136, 32, (9, 6, 18), 1),
                                   ("relu", 32, 64, None, (4, 4, 16), 3)], ids=lambda c: c[0] if isinstance(c, tuple) else str(c))
 def test_conv_lds_dma_in_lds_prologue_matches_the_two_pass_form_bitwise(case, cfg, dtype):
