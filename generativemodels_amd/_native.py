@@ -116,7 +116,6 @@ PROTOTYPES = {
     "gm_conv_dma_set_persistent": (None, [C.c_int]),
     "gm_conv_dma_set_phase_skew": (None, [C.c_int]),
     "gm_conv_sk_set_enabled": (None, [C.c_int]),
-    "gm_conv_sn_set_waves": (None, [C.c_int]),
     "gm_packed_conv_weight_elems": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gm_pack_conv_weight": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       c_vp]),

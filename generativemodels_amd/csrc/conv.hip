@@ -376,10 +376,13 @@ extern "C" int gm_conv_dma_variant(int cfg);
 // (21 / 22 / 23: the three tile structures on v_mfma_f32_32x32x16_bf16 of rounds 4-5 -- each verified and measured equal or slower in time, and in round 6
 //  costlier in joules per launch on every C2 shape (profiles/r06_taploop_energy.txt) -- live under experiments/conv_mw, conv_w8, conv_w4; the ids stay retired)
 // 24: conv_sn.hip -- small volumes, K-complete on 16-channel output blocks (256 voxels x 16 channels per work-group, no split-K, epilogue + statistics in the kernel)
+// 25: the same kernel over images (3x3 convolutions carried as depth-1 volumes): 16 x 16 pixels x 16 channels per work-group
 #define CONV_CFG_SN 24
+#define CONV_CFG_SN2D 25
 extern "C" int gm_conv_sn_eligible(const GmConvDesc* d);
-extern "C" long long gm_conv_sn_lds_bytes();
-static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19) || cfg == CONV_CFG_SN; }
+extern "C" long long gm_conv_sn_lds_bytes(int cfg);
+static inline bool conv_is_sn(int cfg) { return cfg == CONV_CFG_SN || cfg == CONV_CFG_SN2D; }
+static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19) || conv_is_sn(cfg); }
 // HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
 #define CONV_CFG_CIN 12
 #define CONV_CFG_COUT1 13
@@ -410,7 +413,7 @@ extern "C" int gm_conv_cfg_tile(int cfg, int* bm, int* bn) {
   if (cfg == 15) { *bm = 128; *bn = 64; return 0; }
   if (cfg == 16 || cfg == 18) { *bm = 512; *bn = 64; return 0; }
   if (cfg == 19) { *bm = 512; *bn = 128; return 0; }
-  if (cfg == CONV_CFG_SN) { *bm = 256; *bn = 16; return 0; }
+  if (conv_is_sn(cfg)) { *bm = 256; *bn = 16; return 0; }
   if (conv_is_dma(cfg) || cfg == CONV_CFG_CIN) { *bm = 256; *bn = 64; return 0; }
   if (cfg == CONV_CFG_COUT1) { *bm = 256; *bn = 16; return 0; }
   if (cfg == CONV_CFG_COUT1M) { *bm = 256; *bn = 16; return 0; }  // (per plane; the depth extent of a work-group is GmConvDesc.ltd)
@@ -449,7 +452,7 @@ static int dispatch_conv(const GmConvDesc& d, size_t smem, long long nblocks, hi
 // LDS bytes a launch with this descriptor needs (-1: invalid descriptor)
 extern "C" long long gm_conv_lds_bytes(const GmConvDesc* d) {
   if (d && (d->skip_x[0] || d->x2) && !conv_is_dma(d->cfg)) return -1;  // the fused 1x1 shortcut / second source exist in the LDS-DMA kernels only
-  if (d && d->cfg == CONV_CFG_SN) return gm_conv_sn_eligible(d) ? gm_conv_sn_lds_bytes() : -1;
+  if (d && conv_is_sn(d->cfg)) return gm_conv_sn_eligible(d) ? gm_conv_sn_lds_bytes(d->cfg) : -1;
   if (d && conv_is_dma(d->cfg)) return gm_conv_dma_eligible(d) ? gm_conv_dma_lds_bytes(gm_conv_dma_variant(d->cfg)) : -1;
   if (d && d->cfg == CONV_CFG_CIN) return gm_conv_cin_eligible(d) ? gm_conv_cin_lds_bytes(d) : -1;
   if (d && d->cfg == CONV_CFG_COUT1) return gm_conv_cout1_eligible(d) ? gm_conv_cout1_lds_bytes() : -1;
@@ -600,8 +603,8 @@ extern "C" long long gm_conv_stats_slots(const GmConvDesc* d) {
   if (!d) return 0;
   const bool fused = conv_is_fast(d->cfg) || conv_is_dma(d->cfg) || d->cfg == CONV_CFG_CIN;
   if (!fused) return 0;
-  if (d->cfg == CONV_CFG_SN)  // four channels per lane straight from the accumulators: whatever the kernel takes, it also counts
-    return gm_conv_sn_eligible(d) ? (long long)((d->Do + 3) >> 2) * ((d->Ho + 3) >> 2) * ((d->Wo + 15) >> 4) : 0;
+  if (conv_is_sn(d->cfg))  // four channels per lane straight from the accumulators: whatever the kernel takes, it also counts
+    return gm_conv_sn_eligible(d) ? (long long)((d->Do + (1 << d->ltd) - 1) >> d->ltd) * ((d->Ho + (1 << d->lth) - 1) >> d->lth) * ((d->Wo + 15) >> 4) : 0;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const bool lds_epilogue = (d->Cout % vecw == 0) && (d->y_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0) &&
                             (!d->res || ((d->res_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->res) & 15) == 0)));

@@ -1151,7 +1151,7 @@ extern "C" int gm_conv_dma_variant(int cfg) { return cfg == 17 ? 4 : (cfg == 15 
 
 extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
   if (d->cfg == 21 || d->cfg == 22) return 0;  // (the 32x32x16 tile structures of rounds 4-5: experiments/conv_mw, conv_w8 -- not in the library)
-  if (d->cfg == 24) return gm_conv_sn_eligible(d);
+  if (d->cfg == 24 || d->cfg == 25) return gm_conv_sn_eligible(d);
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const int s = d->cfg == 15 ? 2 : 1;
@@ -1273,7 +1273,7 @@ extern "C" int gm_conv_dma_launch_part4(const GmConvDesc* dp, unsigned nblocks, 
 
 #if DMA_PART(0)
 extern "C" int gm_conv_dma_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
-  if (dp->cfg == 24) return gm_conv_sn_launch(dp, nblocks, stream);
+  if (dp->cfg == 24 || dp->cfg == 25) return gm_conv_sn_launch(dp, nblocks, stream);
   if (gm_conv_sk_eligible(dp)) return gm_conv_sk_launch(dp, nblocks, stream);
   switch (dp->cfg) {
     case 14: return gm_conv_dma_launch_part1(dp, nblocks, stream);

@@ -18,16 +18,24 @@
 __device__ __attribute__((aligned(64))) unsigned int gm_sn_zero_row[16] = {0};  // the source of every padding row
 
 namespace sn {
-constexpr int KS = 3, NTAP = 27;
-constexpr int TD = 4, TH = 4, TW = 16, BM = 256, BN = 16;
-constexpr int PD = 6, PH = 6, PW = 18, PLANE = 112, PROWS = PD * PLANE, PPIECES = PROWS / 16;
-constexpr int PATCH_BYTES = PROWS * DMA_ROWB, W_BYTES = NTAP * BN * DMA_ROWB;  // 43 008 + 27 648
-constexpr int MAXW = 8;                                         // the LDS layout is sized for the 8-wave form
-constexpr int AFF_OFF = PATCH_BYTES + W_BYTES, AFF_WAVE = 256;  // per wave: [scale | shift] of the chunk being staged (PRE)
-constexpr int STAT_OFF = AFF_OFF + MAXW * AFF_WAVE;             // [wave][16 channels][sum, sum of squares] fp32
-constexpr int LDS_BYTES = STAT_OFF + MAXW * BN * 8;             // 73 728: two work-groups per CU
-static_assert(2 * LDS_BYTES <= 160 * 1024, "two work-groups per CU");
-static_assert(2 * BM * DMA_ROWB <= PATCH_BYTES && 2 * BN * DMA_ROWB <= W_BYTES, "the shortcut's two chunks per round fit into the operand buffers");
+constexpr int KS = 3, BM = 256, BN = 16, TW = 16, PW = 18;
+constexpr int MAXW = 8;  // the LDS layout is sized for the 8-wave form
+// ND = 3: 4 x 4 x 16 voxel tile, 6 planes of 6 x 18 patch rows (plane pitch padded to 112: depth offsets keep row mod 16), 27 taps.
+// ND = 2 (tile configuration 25): the same kernel over IMAGES -- 16 x 16 pixel tile, one "plane" of 18 x 18 patch rows, 9 taps; the descriptor carries a
+// 2-D convolution as depth 1 / kd 1 (ops.py), so every depth index below is 0.
+template <int ND> struct Geom {
+  static constexpr int NTAP = ND == 3 ? 27 : 9;
+  static constexpr int TD = ND == 3 ? 4 : 1, TH = ND == 3 ? 4 : 16;
+  static constexpr int PH = ND == 3 ? 6 : 18, PLANE = ND == 3 ? 112 : 336, PROWS = (ND == 3 ? 6 : 1) * PLANE, PPIECES = PROWS / 16;
+  static constexpr int PATCH_BYTES = PROWS * DMA_ROWB, W_BYTES = NTAP * BN * DMA_ROWB;  // 43 008 + 27 648 (3-D), 21 504 + 9 216 (2-D)
+  static constexpr int AFF_OFF = PATCH_BYTES + W_BYTES, AFF_WAVE = 256;  // per wave: [scale | shift] of the chunk being staged (PRE)
+  static constexpr int STAT_OFF = AFF_OFF + MAXW * AFF_WAVE;             // [wave][16 channels][sum, sum of squares] fp32
+  static constexpr int LDS_BYTES = STAT_OFF + MAXW * BN * 8;             // 73 728 (3-D): two work-groups per CU; 33 792 (2-D)
+  static constexpr int SKIP_ROUND = 2 * BM * DMA_ROWB <= PATCH_BYTES ? 2 : 1;  // shortcut chunks staged per round (their voxel rows go into the patch buffer)
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two work-groups per CU");
+  static_assert(SKIP_ROUND * BM * DMA_ROWB <= PATCH_BYTES && SKIP_ROUND * BN * DMA_ROWB <= W_BYTES, "the shortcut's chunks of a round fit into the operand buffers");
+  static_assert(PLANE % 16 == 0 && PH * PW <= PLANE, "whole DMA pieces per plane");
+};
 }  // namespace sn
 
 __device__ __forceinline__ float sn_row16_sum(float v) {  // sum over the 16 lanes of a DPP row, every lane ends with it; fixed order
@@ -38,13 +46,20 @@ __device__ __forceinline__ float sn_row16_sum(float v) {  // sum over the 16 lan
   return v;
 }
 
-// NW waves x MF 16-voxel fragments cover the 256-voxel tile: <8, 2> (the fragments of a tap are 3 LDS reads for 2 MFMAs) or <4, 4> (5 reads for 4 MFMAs:
-// the kernel is bound by its LDS operand reads -- one MFMA column per weight fragment -- so fewer, fatter waves read less)
-template <typename T, bool PRE, int NW, int MF>
+// NW waves x MF 16-voxel fragments cover the 256-voxel tile.  <8, 2> is what the library instantiates (a tap = 3 LDS reads for 2 MFMAs per wave); <4, 4> (5
+// reads for 4 MFMAs: fewer LDS operand bytes) was measured and is SLOWER on the C3 latent UNet (1.562 vs 1.518 ms per forward, profiles/r06_c3_cfg24_policy_sweep.txt):
+// sixteen waves per CU hide the request / barrier chain of a chunk better than eight.
+template <typename T, bool PRE, int NW, int MF, int ND>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const GmConvDesc p) {
   using namespace sn;
-  static_assert(NW * MF * 16 == BM && NW <= MAXW && MF <= 4, "waves x fragments cover the tile; a wave's fragments are lines of one plane");
+  typedef Geom<ND> GE;
+  constexpr int NTAP = GE::NTAP, TD = GE::TD, TH = GE::TH, PH = GE::PH, PLANE = GE::PLANE, PROWS = GE::PROWS, PPIECES = GE::PPIECES;
+  constexpr int PATCH_BYTES = GE::PATCH_BYTES, AFF_OFF = GE::AFF_OFF, AFF_WAVE = GE::AFF_WAVE, STAT_OFF = GE::STAT_OFF, SKIP_ROUND = GE::SKIP_ROUND;
+  static_assert(NW * MF * 16 == BM && NW <= MAXW && MF <= 4 && (ND == 2 || 4 % MF == 0), "waves x fragments cover the tile; a wave's fragments are lines of one plane");
   constexpr int PPW = (PPIECES + NW - 1) / NW, WPW = (NTAP + NW - 1) / NW;  // patch / weight pieces per wave and chunk (tap = wave + NW h: one 1 KiB piece per tap)
+  // voxel m of the tile -> (plane, line, column): 3-D (m >> 6, (m >> 4) & 3, m & 15); 2-D (0, m >> 4, m & 15)
+  auto m_plane = [](int m) { return ND == 3 ? m >> 6 : 0; };
+  auto m_line = [](int m) { return ND == 3 ? (m >> 4) & 3 : m >> 4; };
   constexpr int BK = ConvTraits<T>::BK;
   constexpr int VECW = ConvTraits<T>::VECW;
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [patch][27 taps x 16 weight rows][8 x (scale | shift)][8 x 16 statistic partials]
@@ -90,8 +105,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
     const int pa = row / PLANE, rr = row - pa * PLANE;
     const int pb = rr / PW, lc = rr - pb * PW;
     psw |= dma_swz(lc) << (2 * j);
-    const int ud = od0 - p.pd + pa, uh = oh0 - p.ph + pb, uw = ow0 - p.pw + lc;
-    const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < p.Ds) & (uh >= 0) & (uh < p.Hs) & (uw >= 0) & (uw < p.Ws);
+    // in_mode 1: the input is the nearest-neighbour up-sampling by (fd, fh, fw) of the stored tensor, never materialised (reference Upsample,
+    // diffusion_model_unet.py:572-585): bounds on the virtual grid, source voxel = virtual / factor
+    int ud = od0 - p.pd + pa, uh = oh0 - p.ph + pb, uw = ow0 - p.pw + lc;
+    const int Dv = p.in_mode == 1 ? p.Ds * p.fd : p.Ds, Hv = p.in_mode == 1 ? p.Hs * p.fh : p.Hs, Wv = p.in_mode == 1 ? p.Ws * p.fw : p.Ws;
+    const bool ok = (row < PROWS) & (rr < PH * PW) & (ud >= 0) & (ud < Dv) & (uh >= 0) & (uh < Hv) & (uw >= 0) & (uw < Wv);
+    if (p.in_mode == 1) { ud /= p.fd; uh /= p.fh; uw /= p.fw; }
     pvox[j] = ok ? ((n * p.Ds + ud) * p.Hs + uh) * p.Ws + uw : -1;
   }
   const char* xbase = reinterpret_cast<const char*>(p.x);
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
   int xa[KS];
   {
     const int m0 = wave * MF * 16 + l15;
-    const int a = m0 >> 6, bb0 = (m0 >> 4) & 3, c = m0 & 15;
+    const int a = m_plane(m0), bb0 = m_line(m0), c = m0 & 15;
 #pragma unroll
     for (int kw = 0; kw < KS; ++kw) xa[kw] = (a * PLANE + bb0 * PW + c + kw) * DMA_ROWB + ((q ^ dma_swz(c + kw)) << 4);
   }
@@ -170,7 +189,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
 
   uint4 xf[2][MF], wf[2];
   auto read_tap = [&](int tap, int set) __attribute__((always_inline)) {
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;  // (2-D: nine taps, kd = 0)
     wf[set] = *reinterpret_cast<const uint4*>(smem + wa0 + tap * (BN * DMA_ROWB));
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) xf[set][mf] = *reinterpret_cast<const uint4*>(smem + xa[kw] + (mf + kh) * (PW * DMA_ROWB) + kd * (PLANE * DMA_ROWB));
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
 #pragma unroll
     for (int h = 0; h < MF; ++h) {
       const int m = wave * (MF * 16) + h * 16 + (lane >> 2);
-      const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+      const int od = od0 + m_plane(m), oh = oh0 + m_line(m), ow = ow0 + (m & 15);
       svox[h] = (od < p.Do && oh < p.Ho && ow < p.Wo) ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
     }
     int caddr[MF];
@@ -217,11 +236,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
       caddr[mf] = m * DMA_ROWB + ((q ^ dma_swz(m)) << 4);
     }
     const char* wsk = reinterpret_cast<const char*>(p.skip_w) + ((long long)cb * BN + (lane >> 2)) * DMA_ROWB + pswz;
-    for (int sc0 = 0; sc0 < nsc; sc0 += 2) {
+    for (int sc0 = 0; sc0 < nsc; sc0 += SKIP_ROUND) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // the operand buffers are free
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < SKIP_ROUND; ++j) {
         const int sc = sc0 + j;
         if (sc < nsc) {  // wave-uniform
           const int part = sc >= nsc0 ? 1 : 0, cip = sc - (part ? nsc0 : 0);
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < SKIP_ROUND; ++j) {
         if (sc0 + j < nsc) {
           const uint4 ws = *reinterpret_cast<const uint4*>(smem + wa0 + j * (BN * DMA_ROWB));
 #pragma unroll
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int m = (wave * MF + mf) * 16 + l15;
-    const int od = od0 + (m >> 6), oh = oh0 + ((m >> 4) & 3), ow = ow0 + (m & 15);
+    const int od = od0 + m_plane(m), oh = oh0 + m_line(m), ow = ow0 + (m & 15);
     if (od < p.Do && oh < p.Ho && ow < p.Wo && co4 < p.Cout) {
       const long long vox = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
       float o[4];
@@ -320,12 +339,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
   }
 }
 
-// geometry this kernel takes: cfg 24, 3x3x3 stride 1, direct input, the vector-aligned operands of the other LDS-DMA configurations
+// geometry this kernel takes: cfg 24 = 3x3x3 over volumes (tile 4 x 4 x 16), cfg 25 = 3x3 over images carried as depth-1 volumes (tile 1 x 16 x 16); stride 1,
+// direct input, the vector-aligned operands of the other LDS-DMA configurations
 extern "C" int gm_conv_sn_eligible(const GmConvDesc* d) {
   const int bk = d->dtype == GM_F32 ? 16 : 32;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
-  return d->cfg == 24 && (d->dtype == GM_F32 || d->dtype == GM_BF16) && d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
-         d->dd == 1 && d->dh == 1 && d->dw == 1 && d->in_mode == 0 && d->ltd == 2 && d->lth == 2 && d->ltw == 4 && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
+  const bool geom3 = d->cfg == 24 && d->kd == 3 && d->ltd == 2 && d->lth == 2 && d->ltw == 4;
+  const bool geom2 = d->cfg == 25 && d->kd == 1 && d->Ds == 1 && d->Do == 1 && d->pd == 0 && d->ltd == 0 && d->lth == 4 && d->ltw == 4 &&
+                     (d->in_mode == 0 || d->fd == 1);
+  return (geom3 || geom2) && (d->dtype == GM_F32 || d->dtype == GM_BF16) && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
+         d->dd == 1 && d->dh == 1 && d->dw == 1 && (d->in_mode == 0 || (d->in_mode == 1 && d->fd >= 1 && d->fh >= 1 && d->fw >= 1)) && d->Cin % bk == 0 &&
+         d->x_ld % vecw == 0 &&
          (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && !(d->ksplit > 1 && d->kpartial) &&
          ((d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_act == 0) ||
           (d->pre_scale != nullptr && d->pre_shift != nullptr && (reinterpret_cast<uintptr_t>(d->pre_scale) & 15) == 0 &&
@@ -344,28 +368,25 @@ extern "C" int gm_conv_sn_eligible(const GmConvDesc* d) {
                               (reinterpret_cast<uintptr_t>(d->skip_x[1]) & 15) == 0))));
 }
 
-extern "C" long long gm_conv_sn_lds_bytes() { return sn::LDS_BYTES; }
+extern "C" long long gm_conv_sn_lds_bytes(int cfg) { return cfg == 25 ? sn::Geom<2>::LDS_BYTES : sn::Geom<3>::LDS_BYTES; }
 
-static int g_sn_waves = 8;  // process-wide (A/B measurements; results do not depend on it up to the summation order of the statistics): 8 x 2 or 4 x 4
-extern "C" void gm_conv_sn_set_waves(int waves) { g_sn_waves = waves == 4 ? 4 : 8; }
-
-template <typename T, bool PRE, int NW, int MF>
+template <typename T, bool PRE, int NW, int MF, int ND>
 static void launch_sn(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_sn_kernel<T, PRE, NW, MF>;
+  auto kern = conv_sn_kernel<T, PRE, NW, MF, ND>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
-  kern<<<dim3(nblocks), 64 * NW, (size_t)sn::LDS_BYTES, st>>>(d);
+  kern<<<dim3(nblocks), 64 * NW, (size_t)sn::Geom<ND>::LDS_BYTES, st>>>(d);
 }
 
 template <typename T>
 static void launch_sn_dt(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
   const bool pre = d.pre_scale != nullptr;
-  if (g_sn_waves == 4) { if (pre) launch_sn<T, true, 4, 4>(d, nblocks, st); else launch_sn<T, false, 4, 4>(d, nblocks, st); }
-  else { if (pre) launch_sn<T, true, 8, 2>(d, nblocks, st); else launch_sn<T, false, 8, 2>(d, nblocks, st); }
+  if (d.cfg == 25) { if (pre) launch_sn<T, true, 8, 2, 2>(d, nblocks, st); else launch_sn<T, false, 8, 2, 2>(d, nblocks, st); }
+  else { if (pre) launch_sn<T, true, 8, 2, 3>(d, nblocks, st); else launch_sn<T, false, 8, 2, 3>(d, nblocks, st); }
 }
 
 extern "C" int gm_conv_sn_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {

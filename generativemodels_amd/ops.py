@@ -678,14 +678,18 @@ SPLITK_MAX_TILES = 256   # split when the unsplit launch has fewer work-groups t
 SPLITK_TARGET_WGS = int(os.environ.get("GM_CONV_SPLITK_WGS", "256"))
 SPLITK_MAX = int(os.environ.get("GM_CONV_SPLITK_MAX", "8"))
 _SK_KERNEL = os.environ.get("GM_CONV_SK")  # "0": the slices on the general cfg 11 tile kernel (round-3 path) instead of conv_sk.hip -- A/B measurements only
-DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 24)
+DMA_CFGS = (11, 14, 15, 16, 17, 18, 19, 24, 25)
 # cfg 24 (csrc/conv_sn.hip, round 6): a small volume's 3x3x3 convolution K-COMPLETE on 16-channel output blocks -- 256 voxels x 16 channels per work-group, the
 # epilogue and the GroupNorm statistics in the kernel -- instead of split-K slices + a combine launch.  Taken where the launch would have been split (fewer
 # 64-channel tiles than SPLITK_MAX_TILES) and the contraction is at most NARROW_N_MAX_CHUNKS K chunks deep (a work-group walks them one after the other; deeper
 # contractions keep the K slices), and for the C_out <= 16 heads the tile kernels do not cover (the latent UNet's 64 -> 4 output convolution).
 NARROW_N = os.environ.get("GM_CONV_SN", "1") != "0"
 NARROW_N_MAX_CHUNKS = int(os.environ.get("GM_CONV_SN_MAX_CHUNKS", "6"))
-_SN_WAVES = os.environ.get("GM_CONV_SN_WAVES")  # bench A/B: "4" = 4 waves x 64 voxels
+# cfg 25: the same kernel over IMAGES (2-D 3x3 stride-1 convolutions, also over a nearest-2x up-sampled input): 16 x 16 pixels x 16 channels per work-group with the
+# in-LDS GroupNorm + SiLU prologue, the two-source input, the fused 1x1 shortcut and the statistics -- where the register-staged 2-D kernels took a separate
+# gn_stats / gn_apply / shortcut launch each (BASELINE configs[0], the 2-D DDPM UNet).  Up to NARROW_N_2D_MAX_FLOP per convolution (what was measured).
+NARROW_N_2D = os.environ.get("GM_CONV_SN2D", "1") != "0"
+NARROW_N_2D_MAX_FLOP = float(os.environ.get("GM_CONV_SN2D_MAX_FLOP", "3e10"))
 # (Rounds 4-5 built three more tile structures on v_mfma_f32_32x32x16_bf16 -- cfg 21: 16-channel half-chunks, three work-groups per CU; cfg 22: 512-voxel
 #  tiles with 16-channel weight panels; cfg 23: cfg 22's image on four waves of 4 x 2 blocks -- each verified bit-level and measured: all tie or lose against
 #  cfg 14 in time, and in round 6 in JOULES per launch on every C2 shape (profiles/r06_taploop_energy.txt: +1 ... +16 %).  They live under experiments/
@@ -830,6 +834,9 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         # (512-voxel tiles -- cfg 16 / 18, one work-group per CU, half the weight-panel traffic -- measure within +-5 % of two 256-voxel
         # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,
         # r02_layer_times_cfg16_rule.txt.  They stay available through force_cfg.)
+    if (force_cfg is None and NARROW_N_2D and DMA_CONV and desc.kd == 1 and desc.Ds == 1 and desc.kh == 3 and desc.kw == 3 and desc.sh == 1 and desc.sw == 1
+            and cout % 4 == 0 and 2.0 * n_vox_out * desc.N * cout * desc.Cin * 9 <= NARROW_N_2D_MAX_FLOP):
+        order = [25] + order  # images: the K-complete 16-channel-block kernel (the C side rejects what it does not cover)
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups (the LDS-DMA kernels stay first)
         dma_first = [c for c in order if c in (11, 15, 18, 19)]
         rest = [c for c in order if c not in (11, 15, 18, 19)]
@@ -852,8 +859,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             if COUT1_MARCH_LTD is not None:
                 ltd = int(COUT1_MARCH_LTD)
             bits = [ltd, 3, ltw]
-        if cfg in (11, 14, 15, 16, 18, 19, 24):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
-            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 24: [2, 2, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
+        if cfg in (11, 14, 15, 16, 18, 19, 24, 25):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
+            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 24: [2, 2, 4], 25: [0, 4, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
@@ -1218,9 +1225,9 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                     _choose_conv_cfg(d, nvox, 24, only=DMA_CFGS)
                 except ValueError:
                     _choose_conv_cfg(d, nvox, 11, only=DMA_CFGS)
-        elif not dma_ok and cout <= 16:  # a narrow output head (64 -> 4): the generic tile kernel otherwise (42 us at 32^3)
+        elif not dma_ok and cout <= 16 and (d.kd == 3 or NARROW_N_2D):  # a narrow output head (64 -> 4): the generic tile kernel otherwise (42 us at 32^3)
             try:
-                _choose_conv_cfg(d, nvox, 24, only=DMA_CFGS)
+                _choose_conv_cfg(d, nvox, 24 if d.kd == 3 else 25, only=DMA_CFGS)
                 dma_ok = True
             except ValueError:
                 pass
@@ -1255,8 +1262,6 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
             raise ValueError("configuration 12 needs the original [Cout, Cin, 3, 3, 3] weight (its K-major image is derived from it)")
         cin_keep = packed_cin_weight(weight, dtype)
         d.w = cin_keep.data_ptr()
-    if dma_ok and d.cfg == 24 and _SN_WAVES is not None:
-        lib().gm_conv_sn_set_waves(int(_SN_WAVES))
     kpart = None
     if dma_ok and d.cfg == 11 and (ksplit is not None or SPLITK):
         nchunks = cin // (64 // x.element_size())

@@ -218,9 +218,6 @@ void gm_conv_dma_set_phase_skew(int cycles);
  * conv_sk.hip (one work-group per CU, the patch and all nine weight panels of a K chunk requested up front); 0 = the general cfg 11 tile kernel
  * (the round-3 path; A/B measurements and the bitwise test). */
 void gm_conv_sk_set_enabled(int on);
-/* Wave shape of tile configuration 24 (conv_sn.hip: a small volume's 3x3x3 convolution K-complete on 16-channel output blocks; reference
- * diffusion_model_unet.py:589-696): 8 (default) = 8 waves x 32 voxels, 4 = 4 waves x 64 voxels.  Process-wide; outputs do not depend on it. */
-void gm_conv_sn_set_waves(int waves);
 long long gm_packed_conv_weight_elems(int Cout, int Cin, int kd, int kh, int kw, int dtype);
 /* src: [Cout][Cin][kd][kh][kw] (transposed = 0) or [Cin][Cout][kd][kh][kw] (transposed = 1, nn.ConvTransposeNd) */
 int gm_pack_conv_weight(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin, int kd, int kh, int kw,

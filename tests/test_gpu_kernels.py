@@ -342,6 +342,87 @@ def test_conv_small_volume_narrow_output_block_kernel(case, dtype):
     assert torch.equal(again, got.contiguous()) and torch.equal(again._gm_cstats, got._gm_cstats)  # run-to-run bitwise
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", [("plain", 32, 32, None, None, (64, 64), "res"), ("ragged", 64, 40, None, None, (21, 37), "res"),
+                                  ("head4", 64, 4, None, None, (17, 19), "none"), ("cat", 96, 64, 64, None, (33, 30), "none"),
+                                  ("skip", 64, 64, None, (32,), (32, 32), "skip"), ("skip-cat", 32, 40, None, (64, 32), (18, 35), "skip"),
+                                  ("skip3", 128, 72, 64, (32, 32), (16, 16), "skip"), ("up", 64, 64, None, None, (16, 19), "up"),
+                                  ("pre-cat", 96, 32, 64, None, (32, 40), "pre"), ("pre", 64, 64, None, None, (16, 48), "pre")], ids=lambda c: c[0])
+def test_conv_2d_narrow_output_block_kernel(case, dtype):
+    """cfg 25 (conv_sn.hip over images, round 6): 3x3 stride-1 convolutions of a 2-D UNet (BASELINE configs[0]) K-complete on 16 x 16 pixels x 16 output
+    channels per work-group -- ragged images, output-channel counts that are not multiples of 16, the two-source input of a virtual concatenation, bias +
+    timestep row + residual into a channel slice of a wider buffer, the fused 1x1 shortcut (one chunk per round here), a nearest-2x up-sampled input, the in-LDS
+    GroupNorm-apply + SiLU prologue (bit-identical to gm_gn_apply + the plain kernel), fused statistics -- against fp64 and against the kernel the automatic
+    choice took before (same function, another summation order); run-to-run bitwise.  Reference: ResnetBlock / Upsample, diffusion_model_unet.py:572-696."""
+    ops = _ops()
+    name, cin, cout, split, pcs, sp, mode = case
+    n = 3
+    x = _rand((n, cin, *sp), 671).to(dtype)
+    w = (_rand((cout, cin, 3, 3), 672) / math.sqrt(cin * 9)).to(dtype)
+    b, temb = _rand((cout,), 673) * 0.1, _rand((n, cout), 674) * 0.5
+    xin = x.double()
+    kw = dict(kernel=3, padding=1, rowvec=temb.to(DEV), want_stats=True)
+    if mode == "up":
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+        kw["upsample"] = True
+    scale = shift = None
+    if mode == "pre":
+        scale, shift = (_rand((n, cin), 675) * 0.2 + 1.0), (_rand((n, cin), 676) * 0.3)
+        xin = F.silu(xin * scale.double().reshape(n, cin, 1, 1) + shift.double().reshape(n, cin, 1, 1))
+        kw.update(pre=(scale.to(DEV), shift.to(DEV)), pre_act="silu")
+    want = F.conv2d(xin, w.double(), b.double(), padding=1) + temb.double().reshape(n, cout, 1, 1)
+    osp = tuple(want.shape[2:])
+    wide_in = torch.zeros((n, *sp, cin + 8), dtype=dtype, device=DEV)
+    wide_in[..., 8:] = _cl(x)
+    xa = wide_in[..., 8:]
+    operand = xa if split is None else ops.VirtualCat([xa[..., :split], xa[..., split:].contiguous()])
+    if mode == "res":
+        res = _rand((n, cout, *osp), 677).to(dtype)
+        kw["res"] = _cl(res)
+        want = want + res.double()
+    elif mode == "skip":
+        parts = [_rand((n, c, *osp), 680 + i).to(dtype) for i, c in enumerate(pcs)]
+        ws = (_rand((cout, sum(pcs), 1, 1), 678) / math.sqrt(sum(pcs))).to(dtype)
+        bs = _rand((cout,), 679) * 0.1
+        want = want + F.conv2d(torch.cat([p.double() for p in parts], 1), ws.double(), bs.double())
+        dparts = []
+        for p in parts:
+            wide = torch.zeros((n, *osp, p.shape[1] + 8), dtype=dtype, device=DEV)
+            wide[..., 8:] = _cl(p)
+            dparts.append(wide[..., 8:])
+        kw["skip"] = (dparts, ws.to(DEV), bs.to(DEV))
+    wide_out = torch.full((n, *osp, cout + 16), 7.0, dtype=dtype, device=DEV)
+    got = ops.conv(operand, w.to(DEV), b.to(DEV), out=wide_out[..., 16:], force_cfg=25, **kw)
+    _check(_cf(got), want, dtype, f"cfg25 {name}", extra=1.5 if mode in ("skip", "pre") else 1.0)
+    assert torch.all(wide_out[..., :16] == 7.0)  # nothing written outside the slice
+    st = got._gm_cstats.sum(0).cpu()
+    v = got.float().cpu().double().reshape(n, -1, cout)
+    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1], (v * v).sum(1), rtol=1e-4, atol=1e-2)
+    keep = ops.NARROW_N_2D
+    try:  # what the automatic choice took before this configuration existed (register-staged / generic 2-D kernels, shortcut and prologue as their own launches)
+        ops.NARROW_N_2D = False
+        other = ops.conv(operand, w.to(DEV), b.to(DEV), **kw)
+    finally:
+        ops.NARROW_N_2D = keep
+    tol = (2 ** -5 if dtype == torch.bfloat16 else 1e-4) * max(1.0, want.abs().max().item())
+    assert (other.float() - got.float()).abs().max().item() <= tol
+    auto = ops.conv(operand, w.to(DEV), b.to(DEV), **kw)  # ... and takes now
+    assert torch.equal(auto, got.contiguous())
+    if mode == "pre":  # the in-LDS prologue against gm_gn_apply per part + the plain kernel: bit for bit
+        parts_in = [xa] if split is None else operand.parts
+        act_t = torch.empty((n, *sp, cin), dtype=dtype, device=DEV)
+        off = 0
+        for t in parts_in:
+            c_t = t.shape[-1]
+            ops.gn_apply(t, kw["pre"][0][:, off:off + c_t], kw["pre"][1][:, off:off + c_t], "silu", out=act_t[..., off:off + c_t])
+            off += c_t
+        kw2 = {k_: v_ for k_, v_ in kw.items() if k_ not in ("pre", "pre_act")}
+        two = ops.conv(act_t, w.to(DEV), b.to(DEV), force_cfg=25, **kw2)
+        assert torch.equal(two, got.contiguous()) and torch.equal(two._gm_cstats, got._gm_cstats)
+    again = ops.conv(operand, w.to(DEV), b.to(DEV), force_cfg=25, **kw)
+    assert torch.equal(again, got.contiguous()) and torch.equal(again._gm_cstats, got._gm_cstats)  # run-to-run bitwise
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [11, 14, 16, 18, 19, 24])
 @pytest.mark.parametrize("case", [("one", 64, 72, None, (6, 9, 19), 2), ("cat", 96, 40, 64, (5, 7, 19), 2), ("cat-wide", 160, 136, 32, (9, 6, 18), 1),

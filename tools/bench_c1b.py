@@ -29,7 +29,10 @@ for dt, name in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
     sched = DDPMScheduler(1000)
     sched.set_timesteps(steps)
     noise = torch.randn((batch, 1, 64, 64), generator=torch.Generator().manual_seed(7)).to(dev, dt)
-    for graph in (False, True):
+    for graph, fast_noise in ((False, False), (True, False)) + (((True, True),) if dt == torch.bfloat16 else ()):
+        # (third bf16 row: DDPMScheduler.fp32_noise_draw -- the CPU generator's noise drawn as fp32 and rounded on the device; the reference's own bf16 draw is
+        #  torch's serial fill, 0.9 ms per step on this host)
+        sched.fp32_noise_draw = fast_noise
         inf = DiffusionInferer(sched, use_hip_graph=graph)
         torch.manual_seed(1)
         inf.sample(noise, model, sched, verbose=False) if steps <= 50 else None
@@ -39,6 +42,6 @@ for dt, name in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
         img = inf.sample(noise, model, sched, verbose=False)
         torch.cuda.synchronize()
         dtm = time.perf_counter() - t0
-        out["results"][f"{name}{'_graph' if graph else ''}"] = dict(seconds=round(dtm, 3), images_per_s=round(batch / dtm, 2),
+        out["results"][f"{name}{'_graph' if graph else ''}{'_fp32_noise_draw' if fast_noise else ''}"] = dict(seconds=round(dtm, 3), images_per_s=round(batch / dtm, 2),
                                                                  ms_per_step=round(dtm * 1e3 / steps, 4), finite=bool(torch.isfinite(img.float()).all()))
 print(json.dumps(out))
