@@ -39,7 +39,9 @@ class GmConvDesc(C.Structure):
                 ("pre_act", C.c_int), ("post_act", C.c_int), ("dtype", C.c_int),
                 ("ltd", C.c_int), ("lth", C.c_int), ("ltw", C.c_int), ("cfg", C.c_int), ("debug_flags", C.c_int), ("stats", c_vp),
                 ("skip_x", c_vp * 2), ("skip_ld", c_ll * 2), ("skip_cin", C.c_int * 2), ("skip_w", c_vp), ("skip_bias", c_vp),
-                ("x2", c_vp), ("x2_ld", c_ll), ("cin_split", C.c_int), ("ksplit", C.c_int), ("kpartial", c_vp)]
+                ("x2", c_vp), ("x2_ld", c_ll), ("cin_split", C.c_int), ("ksplit", C.c_int), ("kpartial", c_vp),
+                ("pre_stats", c_vp * 2), ("pre_S", C.c_int * 2), ("pre_C", C.c_int * 2), ("pre_gamma", c_vp), ("pre_beta", c_vp), ("pre_eps", C.c_float),
+                ("pre_groups", C.c_int)]
 
 
 class GmDecodeBlock(C.Structure):

@@ -42,6 +42,13 @@ struct GmConvDesc {
   // writing its fp32 partial accumulators to kpartial[ks][n * V + voxel][Cout]; gm_conv_forward then runs the combine kernel (sum of the
   // slices + bias / timestep row / residual / activation / output statistics).  ksplit <= 1: off.
   int ksplit; float* kpartial;
+  // optional GroupNorm prologue given as STATISTICS instead of (pre_scale, pre_shift) -- tile configurations 24 / 25 (conv_sn.hip) only: the consumer folds the
+  // per-tile partials of its input (up to two channel-concatenated sources, S_i <= 64 rows of [N][C_i][2] fp64 each, as gm_gn_finalize_channels takes them) and
+  // forms scale = rstd * gamma, shift = beta - mean * rstd * gamma itself, in its prologue: bit-identical to gm_gn_finalize_channels, one launch less per norm.
+  // pre_stats[0] == NULL: off (pre_scale / pre_shift as before).  pre_act applies as usual.
+  const double* pre_stats[2]; int pre_S[2]; int pre_C[2];
+  const float* pre_gamma; const float* pre_beta;   // [Cin] fp32 or NULL (1 / 0)
+  float pre_eps; int pre_groups;
 };
 
 // slot count of the zero-initialised, atomically accumulated statistic tables the BACKWARD kernels still use ([GM_STAT_SLOTS][N][C][2];

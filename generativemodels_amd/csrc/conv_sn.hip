@@ -28,9 +28,12 @@ template <int ND> struct Geom {
   static constexpr int TD = ND == 3 ? 4 : 1, TH = ND == 3 ? 4 : 16;
   static constexpr int PH = ND == 3 ? 6 : 18, PLANE = ND == 3 ? 112 : 336, PROWS = (ND == 3 ? 6 : 1) * PLANE, PPIECES = PROWS / 16;
   static constexpr int PATCH_BYTES = PROWS * DMA_ROWB, W_BYTES = NTAP * BN * DMA_ROWB;  // 43 008 + 27 648 (3-D), 21 504 + 9 216 (2-D)
-  static constexpr int AFF_OFF = PATCH_BYTES + W_BYTES, AFF_WAVE = 256;  // per wave: [scale | shift] of the chunk being staged (PRE)
-  static constexpr int STAT_OFF = AFF_OFF + MAXW * AFF_WAVE;             // [wave][16 channels][sum, sum of squares] fp32
-  static constexpr int LDS_BYTES = STAT_OFF + MAXW * BN * 8;             // 73 728 (3-D): two work-groups per CU; 33 792 (2-D)
+  static constexpr int AFF_OFF = PATCH_BYTES + W_BYTES, AFF_WAVE = 256;  // per wave: [scale | shift] of the chunk being staged (PRE, scale / shift arrays given)
+  static constexpr int MAX_CIN_TAB = 384;                                // ... or ONE table [scale[Cin] | shift[Cin]] built from the input's statistics (PRE, pre_stats),
+  static constexpr int AFF_BYTES = 2 * MAX_CIN_TAB * 4 + MAX_CIN_TAB * 16;  //     behind it the per-channel fp64 (sum, sum of squares) the table is built from: 9 KiB
+  static constexpr int STAT_OFF = AFF_OFF + AFF_BYTES;                   // [wave][16 channels][sum, sum of squares] fp32
+  static constexpr int LDS_BYTES = STAT_OFF + MAXW * BN * 8;             // 80 896 (3-D): two work-groups per CU; 40 960 (2-D)
+  static_assert(AFF_BYTES >= MAXW * AFF_WAVE, "the per-wave scale / shift copies fit too");
   static constexpr int SKIP_ROUND = 2 * BM * DMA_ROWB <= PATCH_BYTES ? 2 : 1;  // shortcut chunks staged per round (their voxel rows go into the patch buffer)
   static_assert(2 * LDS_BYTES <= 160 * 1024, "two work-groups per CU");
   static_assert(SKIP_ROUND * BM * DMA_ROWB <= PATCH_BYTES && SKIP_ROUND * BN * DMA_ROWB <= W_BYTES, "the shortcut's chunks of a round fit into the operand buffers");
@@ -117,8 +120,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
   const char* x2base = reinterpret_cast<const char*>(p.x2);
   const long long xrowb = p.x_ld * (long long)sizeof(T), x2rowb = p.x2_ld * (long long)sizeof(T);
   const int nchunks0 = p.x2 ? p.cin_split / BK : nchunks;
+  const bool from_stats = PRE && p.pre_stats[0] != nullptr;  // (work-group uniform)
   auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
-    if (PRE) {
+    if (PRE && !from_stats) {
       const int nl = BK / 4;  // lanes 0 .. nl - 1 fetch the chunk's scale, nl .. 2 nl - 1 its shift (16 bytes each) into this wave's own copy
       if (lane < 2 * nl) {
         const float* src = (lane < nl ? p.pre_scale : p.pre_shift) + (long long)n * p.Cin + chunk * BK + 4 * (lane < nl ? lane : lane - nl);
@@ -139,12 +143,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
   };
   // GroupNorm-apply + activation IN LDS on this wave's own landed pieces (conv_dma.hip: transform_patch; same arithmetic and rounding as gm_gn_apply;
   // rows that came from the zero page stay zero: the reference pads the ACTIVATED tensor)
-  auto transform_patch = [&]() __attribute__((always_inline)) {
+  auto transform_patch = [&](int chunk) __attribute__((always_inline)) {
     float sc[VECW], sh[VECW];
-    const float* aff = reinterpret_cast<const float*>(smem + AFF_OFF + wave * AFF_WAVE);
+    // scale / shift of this lane's channel slot: the wave's own per-chunk copy, or the table over all input channels built from the statistics
+    const float* aff = reinterpret_cast<const float*>(smem + AFF_OFF) + (from_stats ? chunk * BK : wave * (AFF_WAVE / 4));
+    const int shoff = from_stats ? p.Cin : BK;
 #pragma unroll
     for (int i = 0; i < VECW; i += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(aff + (lane & 3) * VECW + i), c = *reinterpret_cast<const float4*>(aff + BK + (lane & 3) * VECW + i);
+      const float4 a = *reinterpret_cast<const float4*>(aff + (lane & 3) * VECW + i), c = *reinterpret_cast<const float4*>(aff + shoff + (lane & 3) * VECW + i);
       sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
       sh[i] = c.x; sh[i + 1] = c.y; sh[i + 2] = c.z; sh[i + 3] = c.w;
     }
@@ -164,6 +170,32 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
   };
 
   issue_patch(0);
+
+  // ---- PRE from statistics: scale[c] = rstd_g * gamma[c], shift[c] = beta[c] - mean_g * rstd_g * gamma[c] for every input channel, from the per-tile partials of
+  // the input's producer(s), under the flight of the first requests.  The SHORT-TABLE order of gm_gn_finalize_channels (groupnorm.hip: gn_short_* -- shared
+  // helpers, so the two are bit-identical): a thread owns a channel and adds its S <= 64 rows in row order (fp64, eight loads in flight); a group is the sum of its
+  // channels in channel order.  A group may straddle the two sources of a virtual concatenation.
+  if (PRE && from_stats) {
+    float* tab = reinterpret_cast<float*>(smem + AFF_OFF);                                   // [scale[Cin] | shift[Cin]]
+    double* csum = reinterpret_cast<double*>(smem + AFF_OFF + 2 * GE::MAX_CIN_TAB * 4);      // [Cin][sum, sum of squares]
+    const int G = p.pre_groups, cpg = p.Cin / G;
+    const long long V = (long long)p.Ds * p.Hs * p.Ws;  // voxels of the NORMALISED tensor
+    for (int c = tid; c < p.Cin; c += 64 * NW) {
+      const double2 v = gn_short_channel_sum(p.pre_stats[0], p.pre_S[0], p.pre_C[0], p.pre_stats[1], p.pre_S[1], p.pre_C[1], p.N, n, c);
+      csum[2 * c] = v.x; csum[2 * c + 1] = v.y;
+    }
+    __syncthreads();
+    for (int c = tid; c < p.Cin; c += 64 * NW) {
+      const int g = c / cpg;
+      double a = 0.0, b2 = 0.0;
+      for (int j = 0; j < cpg; ++j) { a += csum[2 * (g * cpg + j)]; b2 += csum[2 * (g * cpg + j) + 1]; }
+      float sc1, sh1;
+      gn_short_scale_shift(a, b2, cpg, V, p.pre_eps, p.pre_gamma ? p.pre_gamma[c] : 1.f, p.pre_beta ? p.pre_beta[c] : 0.f, sc1, sh1);
+      tab[c] = sc1;
+      tab[p.Cin + c] = sh1;
+    }
+    __syncthreads();  // (transform_patch of chunk 0 runs in front of the first tap-loop barrier: the table needs its own)
+  }
 
   // ---- the epilogue's per-channel addend (bias + shortcut bias + timestep row, this order, fp32) and this lane's output rows: under the first flight ----
   const int co4 = cb * BN + q * 4;  // this lane's four output channels (accumulator rows 4q .. 4q + 3 of the 16x16 MFMA)
@@ -197,7 +229,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     dma_wait<0>();                    // this wave's pieces of the chunk (and, PRE, its scale / shift copy) have landed
-    if (PRE) transform_patch();
+    if (PRE) transform_patch(chunk);
     __builtin_amdgcn_s_barrier();     // ... everyone's
     read_tap(0, 0);
 #pragma unroll
@@ -351,9 +383,15 @@ extern "C" int gm_conv_sn_eligible(const GmConvDesc* d) {
          d->dd == 1 && d->dh == 1 && d->dw == 1 && (d->in_mode == 0 || (d->in_mode == 1 && d->fd >= 1 && d->fh >= 1 && d->fw >= 1)) && d->Cin % bk == 0 &&
          d->x_ld % vecw == 0 &&
          (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && !(d->ksplit > 1 && d->kpartial) &&
-         ((d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_act == 0) ||
-          (d->pre_scale != nullptr && d->pre_shift != nullptr && (reinterpret_cast<uintptr_t>(d->pre_scale) & 15) == 0 &&
-           (reinterpret_cast<uintptr_t>(d->pre_shift) & 15) == 0 && (d->Cin % 4) == 0)) &&
+         ((d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_stats[0] == nullptr && d->pre_act == 0) ||
+          (d->pre_stats[0] == nullptr && d->pre_scale != nullptr && d->pre_shift != nullptr && (reinterpret_cast<uintptr_t>(d->pre_scale) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(d->pre_shift) & 15) == 0 && (d->Cin % 4) == 0) ||
+          // the statistics form: short tables (their rows all sit in one wave of the fold), whole groups, the table over all input channels in LDS
+          (d->pre_stats[0] != nullptr && d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_groups > 0 && d->Cin % d->pre_groups == 0 &&
+           d->Cin <= sn::Geom<3>::MAX_CIN_TAB && d->pre_S[0] >= 1 && d->pre_S[0] <= 64 && d->pre_C[0] > 0 &&
+           ((d->pre_stats[1] == nullptr && d->pre_C[1] == 0 && d->pre_C[0] == d->Cin) ||
+            (d->pre_stats[1] != nullptr && d->pre_S[1] >= 1 && d->pre_S[1] <= 64 && d->pre_C[1] > 0 && d->pre_C[0] + d->pre_C[1] == d->Cin)) &&
+           (reinterpret_cast<uintptr_t>(d->pre_stats[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->pre_stats[1]) & 15) == 0 && d->in_mode == 0)) &&
          (d->x2 == nullptr || (d->cin_split > 0 && d->cin_split < d->Cin && d->cin_split % bk == 0 && d->x2_ld % vecw == 0 &&
                                (reinterpret_cast<uintptr_t>(d->x2) & 15) == 0)) &&
          // four channels per lane: 8-byte (bf16) / 16-byte (fp32) stores and residual loads; fp32 addend vectors
@@ -384,7 +422,7 @@ static void launch_sn(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
 
 template <typename T>
 static void launch_sn_dt(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
-  const bool pre = d.pre_scale != nullptr;
+  const bool pre = d.pre_scale != nullptr || d.pre_stats[0] != nullptr;
   if (d.cfg == 25) { if (pre) launch_sn<T, true, 8, 2, 2>(d, nblocks, st); else launch_sn<T, false, 8, 2, 2>(d, nblocks, st); }
   else { if (pre) launch_sn<T, true, 8, 2, 3>(d, nblocks, st); else launch_sn<T, false, 8, 2, 3>(d, nblocks, st); }
 }

@@ -70,4 +70,38 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// ---- GroupNorm finalisation over SHORT statistic tables (every source S <= 64 rows of [N][C_i][2] fp64 partials) -- shared by gm_gn_finalize_channels
+// (groupnorm.hip) and the consumer-side prologue of conv_sn.hip, which must agree bit for bit: a channel's partials are added in ROW order, a group is the sum
+// of its channels in CHANNEL order, everything in fp64.  Channel c of the concatenation (C0 + C1 channels) lives in source 0 when c < C0.
+__device__ __forceinline__ double2 gn_short_channel_sum(const double* s0, int S0, int C0, const double* s1, int S1, int C1, int N, int n, int c) {
+  const bool first = c < C0;
+  const double* src = first ? s0 + ((long long)n * C0 + c) * 2 : s1 + ((long long)n * C1 + (c - C0)) * 2;
+  const long long pitch = (long long)N * (first ? C0 : C1) * 2;
+  const int S = first ? S0 : S1;
+  double a = 0.0, b = 0.0;
+  int sl = 0;
+  for (; sl + 8 <= S; sl += 8) {  // eight rows in flight, added in row order
+    double2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double2*>(src + (long long)(sl + k) * pitch);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a += v[k].x; b += v[k].y; }
+  }
+  for (; sl < S; ++sl) {
+    const double2 v = *reinterpret_cast<const double2*>(src + (long long)sl * pitch);
+    a += v.x; b += v.y;
+  }
+  return make_double2(a, b);
+}
+// (a, b) = the group's (sum, sum of squares) over cpg channels x V voxels -> this channel's scale = rstd * gamma, shift = beta - mean * rstd * gamma
+__device__ __forceinline__ void gn_short_scale_shift(double a, double b, int cpg, long long V, float eps, float gamma, float beta, float& scale, float& shift) {
+  const double cnt = (double)cpg * (double)V;
+  const double mean = a / cnt;
+  double var = b / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  scale = (float)(rstd * (double)gamma);
+  shift = (float)((double)beta - mean * rstd * (double)gamma);
+}
+
 static inline int gm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -328,6 +328,35 @@ __global__ __launch_bounds__(256) void gn_finalize_channels_kernel(const double*
   }
 }
 
+// SHORT tables (every source S <= 64): a thread owns a channel of the group and adds its rows in row order; thread 0 adds the channels in channel order -- the
+// order conv_sn.hip's consumer-side prologue reproduces (gm_common.h: gn_short_*), so that a norm finalised there and one finalised here agree bit for bit.
+__global__ __launch_bounds__(256) void gn_finalize_channels_short_kernel(const double* __restrict__ s0, int S0, int C0, const double* __restrict__ s1, int S1, int C1,
+                                                                        int N, int G, long long V, float eps, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+  extern __shared__ double gn_short_sums[];  // [cpg][2], then the group's pair
+  const int n = blockIdx.x / G, g = blockIdx.x % G, t = threadIdx.x;
+  const int C = C0 + C1, cpg = C / G;
+  for (int j = t; j < cpg; j += 256) {
+    const double2 v = gn_short_channel_sum(s0, S0, C0, s1, S1, C1, N, n, g * cpg + j);
+    gn_short_sums[2 * j] = v.x; gn_short_sums[2 * j + 1] = v.y;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < cpg; ++j) { a += gn_short_sums[2 * j]; b += gn_short_sums[2 * j + 1]; }
+    gn_short_sums[2 * cpg] = a; gn_short_sums[2 * cpg + 1] = b;
+  }
+  __syncthreads();
+  const double a = gn_short_sums[2 * cpg], b = gn_short_sums[2 * cpg + 1];
+  for (int j = t; j < cpg; j += 256) {
+    const int c = g * cpg + j;
+    float sc, sh;
+    gn_short_scale_shift(a, b, cpg, V, eps, gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f, sc, sh);
+    scale[(long long)n * C + c] = sc;
+    shift[(long long)n * C + c] = sh;
+  }
+}
+
 extern "C" int gm_gn_finalize_channels(const double* stats0, int S0, int C0, const double* stats1, int S1, int C1, int N, long long V, int G,
                                        float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
   GM_REQUIRE(stats0 && scale && shift, "null pointer");
@@ -335,7 +364,12 @@ extern "C" int gm_gn_finalize_channels(const double* stats0, int S0, int C0, con
   GM_REQUIRE(S0 > 0 && (C1 == 0 || S1 > 0), "statistic tables need at least one partial");
   GM_REQUIRE(G > 0 && (C0 + C1) % G == 0, "channels must be divisible by groups");
   if (N == 0) return 0;
-  gn_finalize_channels_kernel<<<N * G, 256, 0, (hipStream_t)stream>>>(stats0, S0, C0, stats1, S1, C1, N, G, V, eps, gamma, beta, scale, shift);
+  const int cpg = (C0 + C1) / G;
+  if (S0 <= 64 && (C1 == 0 || S1 <= 64) && cpg <= 4096)  // short tables: the order the consumer-side finalisation shares (ops.GnRecipe)
+    gn_finalize_channels_short_kernel<<<N * G, 256, (size_t)(2 * cpg + 2) * sizeof(double), (hipStream_t)stream>>>(stats0, S0, C0, stats1, S1, C1, N, G, V, eps, gamma, beta,
+                                                                                                               scale, shift);
+  else
+    gn_finalize_channels_kernel<<<N * G, 256, 0, (hipStream_t)stream>>>(stats0, S0, C0, stats1, S1, C1, N, G, V, eps, gamma, beta, scale, shift);
   GM_LAUNCH_CHECK();
 }
 

@@ -195,6 +195,13 @@ typedef struct GmConvDesc {
    * `ksplit` work-groups per tile that write fp32 partial sums to `kpartial` (gm_conv_splitk_workspace_bytes) and a combine kernel
    * applies the epilogue (bias, timestep row, residual, activation, output statistics).  ksplit <= 1 or kpartial NULL: off. */
   int ksplit; float* kpartial;
+  /* optional GroupNorm prologue given as STATISTICS instead of (pre_scale, pre_shift) -- tile configurations 24 / 25 only (conv_sn.hip): the consumer folds the
+   * per-tile partials of its input (up to two channel-concatenated sources, S_i <= 64 rows of [N][C_i][2] fp64 each, exactly what gm_gn_finalize_channels takes)
+   * and forms scale = rstd * gamma, shift = beta - mean * rstd * gamma in its prologue: bit-identical to gm_gn_finalize_channels (reference nn.GroupNorm,
+   * diffusion_model_unet.py:671-684), one launch less per norm.  pre_stats[0] == NULL: off. */
+  const double* pre_stats[2]; int pre_S[2]; int pre_C[2];
+  const float* pre_gamma; const float* pre_beta;
+  float pre_eps; int pre_groups;
 } GmConvDesc;
 int gm_conv_cfg_tile(int cfg, int* voxels, int* channels);
 long long gm_conv_lds_bytes(const GmConvDesc* d);

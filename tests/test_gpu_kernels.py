@@ -423,6 +423,45 @@ def test_conv_2d_narrow_output_block_kernel(case, dtype):
     assert torch.equal(again, got.contiguous()) and torch.equal(again._gm_cstats, got._gm_cstats)  # run-to-run bitwise
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", [("2d", (40, 56), 64, 64, None, 32), ("2d-cat-straddle", (33, 30), 96, 32, 64, 32), ("2d-groups8", (16, 16), 32, 40, None, 8),
+                                  ("3d", (8, 8, 16), 64, 64, None, 32), ("3d-cat", (4, 8, 16), 96, 64, 32, 32)], ids=lambda c: c[0])
+def test_groupnorm_finalised_in_the_consumer_prologue_is_the_finalisation_launch_bit_for_bit(case, dtype):
+    """(round 6) `ops.gn_scale_shift_composed` hands out a GnRecipe when the producer's statistic tables are short; a consumer on tile configuration 24 / 25 folds
+    them and forms (scale, shift) in its own prologue (GmConvDesc.pre_stats) -- the gm_gn_finalize_channels launch of that norm does not happen.  Output and output
+    statistics must equal, BIT FOR BIT, the convolution fed with the launch's (scale, shift): one source and the two sources of a virtual concatenation whose
+    groups straddle the seam, 2-D and 3-D, against fp64 GroupNorm + SiLU + convolution as well.  Reference: conv(silu(norm(x))), diffusion_model_unet.py:671-684."""
+    ops = _ops()
+    name, sp, cin, cout, split, groups = case
+    n, nd = 2, len(sp)
+    conv_nd = F.conv2d if nd == 2 else F.conv3d
+    x = _rand((n, cin, *sp), 771).to(dtype)
+    gamma, beta = (_rand((cin,), 772) * 0.2 + 1.0), _rand((cin,), 773) * 0.3
+    w = (_rand((cout, cin) + (3,) * nd, 774) / math.sqrt(cin * 3 ** nd)).to(dtype)
+    b = _rand((cout,), 775) * 0.1
+    xa = _cl(x)
+    parts = [xa] if split is None else [xa[..., :split].contiguous(), xa[..., split:].contiguous()]
+    with torch.no_grad():
+        for t in parts:  # short tables, as a producing convolution of these sizes leaves them: one partial per 256-voxel tile
+            st = ops._fresh_channel_stats(t)
+            rows = min(int(st.shape[0]), 7)
+            fold = torch.zeros((rows, *st.shape[1:]), dtype=st.dtype, device=st.device)
+            for i in range(int(st.shape[0])):
+                fold[i % rows] += st[i]
+            t._gm_cstats = fold
+        operand = parts[0] if split is None else ops.VirtualCat(parts)
+        recipe = ops.gn_scale_shift_composed(operand, groups, 1e-5, gamma.to(DEV), beta.to(DEV))
+        assert isinstance(recipe, ops.GnRecipe) and recipe._done is None
+        kw = dict(kernel=3, padding=1, pre_act="silu", want_stats=True)
+        fused = ops.conv(operand, w.to(DEV), b.to(DEV), pre=recipe, **kw)
+        assert recipe._done is None, "the consumer should have finalised the norm itself"
+        scale, shift = ops.gn_scale_shift_composed(operand, groups, 1e-5, gamma.to(DEV), beta.to(DEV)).materialise()
+        launched = ops.conv(operand, w.to(DEV), b.to(DEV), pre=(scale, shift), **kw)
+    assert torch.equal(fused, launched) and torch.equal(fused._gm_cstats, launched._gm_cstats)
+    want = conv_nd(F.silu(F.group_norm(x.double(), groups, gamma.double(), beta.double(), 1e-5)), w.double(), b.double(), padding=1)
+    _check(_cf(fused), want, dtype, f"GroupNorm finalised in the prologue, {name}", extra=2.0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [11, 14, 16, 18, 19, 24])
 @pytest.mark.parametrize("case", [("one", 64, 72, None, (6, 9, 19), 2), ("cat", 96, 40, 64, (5, 7, 19), 2), ("cat-wide", 160, 136, 32, (9, 6, 18), 1),
