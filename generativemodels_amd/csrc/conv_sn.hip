@@ -199,11 +199,29 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
 
   // ---- the epilogue's per-channel addend (bias + shortcut bias + timestep row, this order, fp32) and this lane's output rows: under the first flight ----
   const int co4 = cb * BN + q * 4;  // this lane's four output channels (accumulator rows 4q .. 4q + 3 of the 16x16 MFMA)
+  // vec4: the lane's four channels as ONE vector access (C_out, the row pitches and the base addresses allow it: host-checked per operand below); else element-wise with a
+  // per-channel bound -- output heads of 1-3 channels, ragged channel counts
+  const int elt = (int)sizeof(T);
+  const bool vec4 = (p.Cout & 3) == 0 && (p.y_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & (4 * elt - 1)) == 0 &&
+                    (!p.res || ((p.res_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & (4 * elt - 1)) == 0)) &&
+                    (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) && (!p.skip_bias || (reinterpret_cast<uintptr_t>(p.skip_bias) & 15) == 0) &&
+                    (!p.rowvec || ((reinterpret_cast<uintptr_t>(p.rowvec) & 15) == 0 && (p.rowvec_bstride & 3) == 0));
   float add[4] = {0.f, 0.f, 0.f, 0.f};
-  if (co4 < p.Cout) {  // host-checked: Cout % 4 == 0
-    if (p.bias) { const float4 v = *reinterpret_cast<const float4*>(p.bias + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
-    if (p.skip_bias) { const float4 v = *reinterpret_cast<const float4*>(p.skip_bias + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
-    if (p.rowvec) { const float4 v = *reinterpret_cast<const float4*>(p.rowvec + (long long)n * p.rowvec_bstride + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
+  if (vec4) {
+    if (co4 < p.Cout) {
+      if (p.bias) { const float4 v = *reinterpret_cast<const float4*>(p.bias + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
+      if (p.skip_bias) { const float4 v = *reinterpret_cast<const float4*>(p.skip_bias + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
+      if (p.rowvec) { const float4 v = *reinterpret_cast<const float4*>(p.rowvec + (long long)n * p.rowvec_bstride + co4); add[0] += v.x; add[1] += v.y; add[2] += v.z; add[3] += v.w; }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (co4 + r < p.Cout) {
+        if (p.bias) add[r] += p.bias[co4 + r];
+        if (p.skip_bias) add[r] += p.skip_bias[co4 + r];
+        if (p.rowvec) add[r] += p.rowvec[(long long)n * p.rowvec_bstride + co4 + r];
+      }
+    }
   }
 
   // ---- operand read addresses (conv_dma.hip: XADDR / WADDR) ---------------------------------------------------------------------------------------
@@ -316,29 +334,43 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
       float o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = acc[mf][r] + add[r];
-      if (res) {
-        const T* rp = res + vox * p.res_ld + co4;
-        if (sizeof(T) == 4) {
-          const float4 rv = *reinterpret_cast<const float4*>(rp);
-          o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
-        } else {
-          const uint2 rv = *reinterpret_cast<const uint2*>(rp);
-          o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
-          o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
-        }
-      }
-      if (p.post_act) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = conv_post_act(o[r], p.post_act);
-      }
       T* yp = yout + vox * p.y_ld + co4;
-      if (sizeof(T) == 4) {
-        *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+      if (vec4) {
+        if (res) {
+          const T* rp = res + vox * p.res_ld + co4;
+          if (sizeof(T) == 4) {
+            const float4 rv = *reinterpret_cast<const float4*>(rp);
+            o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+          } else {
+            const uint2 rv = *reinterpret_cast<const uint2*>(rp);
+            o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+            o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+          }
+        }
+        if (p.post_act) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = conv_post_act(o[r], p.post_act);
+        }
+        if (sizeof(T) == 4) {
+          *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          const uint2 raw = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+          *reinterpret_cast<uint2*>(yp) = raw;
+          o[0] = __uint_as_float(raw.x << 16); o[1] = __uint_as_float(raw.x & 0xffff0000u);
+          o[2] = __uint_as_float(raw.y << 16); o[3] = __uint_as_float(raw.y & 0xffff0000u);
+        }
       } else {
-        const uint2 raw = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-        *reinterpret_cast<uint2*>(yp) = raw;
-        o[0] = __uint_as_float(raw.x << 16); o[1] = __uint_as_float(raw.x & 0xffff0000u);
-        o[2] = __uint_as_float(raw.y << 16); o[3] = __uint_as_float(raw.y & 0xffff0000u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (co4 + r < p.Cout) {
+            if (res) o[r] += ElemIO<T>::ld(res + vox * p.res_ld + co4 + r);
+            if (p.post_act) o[r] = conv_post_act(o[r], p.post_act);
+            ElemIO<T>::st(yp + r, o[r]);
+            if (sizeof(T) == 2) o[r] = __uint_as_float(pack_bf16x2(o[r], 0.f) << 16);  // (the value as stored: rounded to T)
+          } else {
+            o[r] = 0.f;
+          }
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ss[r] += o[r]; sq[r] += o[r] * o[r]; }
@@ -394,11 +426,7 @@ extern "C" int gm_conv_sn_eligible(const GmConvDesc* d) {
            (reinterpret_cast<uintptr_t>(d->pre_stats[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->pre_stats[1]) & 15) == 0 && d->in_mode == 0)) &&
          (d->x2 == nullptr || (d->cin_split > 0 && d->cin_split < d->Cin && d->cin_split % bk == 0 && d->x2_ld % vecw == 0 &&
                                (reinterpret_cast<uintptr_t>(d->x2) & 15) == 0)) &&
-         // four channels per lane: 8-byte (bf16) / 16-byte (fp32) stores and residual loads; fp32 addend vectors
-         d->Cout % 4 == 0 && d->y_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->y) & (4 * (d->dtype == GM_F32 ? 4 : 2) - 1)) == 0 &&
-         (!d->res || (d->res_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->res) & (4 * (d->dtype == GM_F32 ? 4 : 2) - 1)) == 0)) &&
-         (!d->bias || (reinterpret_cast<uintptr_t>(d->bias) & 15) == 0) && (!d->skip_bias || (reinterpret_cast<uintptr_t>(d->skip_bias) & 15) == 0) &&
-         (!d->rowvec || ((reinterpret_cast<uintptr_t>(d->rowvec) & 15) == 0 && d->rowvec_bstride % 4 == 0)) &&
+         // (any C_out / row pitch / alignment of y, res, bias, rowvec: four channels per lane go out as one vector where all of them allow it, element-wise otherwise)
          (long long)d->N * d->Ds * d->Hs * d->Ws < (1LL << 31) && (long long)d->N * d->Do * d->Ho * d->Wo < (1LL << 31) &&
          (!d->skip_x[0] ||
           (d->skip_w && d->skip_cin[0] > 0 && d->skip_cin[0] % bk == 0 && d->skip_ld[0] % vecw == 0 && (reinterpret_cast<uintptr_t>(d->skip_x[0]) & 15) == 0 &&

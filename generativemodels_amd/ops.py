@@ -725,6 +725,7 @@ NARROW_N_MAX_CHUNKS = int(os.environ.get("GM_CONV_SN_MAX_CHUNKS", "6"))
 # gn_stats / gn_apply / shortcut launch each (BASELINE configs[0], the 2-D DDPM UNet).  Up to NARROW_N_2D_MAX_FLOP per convolution (what was measured).
 NARROW_N_2D = os.environ.get("GM_CONV_SN2D", "1") != "0"
 NARROW_N_2D_MAX_FLOP = float(os.environ.get("GM_CONV_SN2D_MAX_FLOP", "3e10"))
+NARROW_HEAD_MAX_FLOP = 1.0e9
 # (Rounds 4-5 built three more tile structures on v_mfma_f32_32x32x16_bf16 -- cfg 21: 16-channel half-chunks, three work-groups per CU; cfg 22: 512-voxel
 #  tiles with 16-channel weight panels; cfg 23: cfg 22's image on four waves of 4 x 2 blocks -- each verified bit-level and measured: all tie or lose against
 #  cfg 14 in time, and in round 6 in JOULES per launch on every C2 shape (profiles/r06_taploop_energy.txt: +1 ... +16 %).  They live under experiments/
@@ -870,7 +871,7 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,
         # r02_layer_times_cfg16_rule.txt.  They stay available through force_cfg.)
     if (force_cfg is None and NARROW_N_2D and DMA_CONV and desc.kd == 1 and desc.Ds == 1 and desc.kh == 3 and desc.kw == 3 and desc.sh == 1 and desc.sw == 1
-            and cout % 4 == 0 and 2.0 * n_vox_out * desc.N * cout * desc.Cin * 9 <= NARROW_N_2D_MAX_FLOP):
+            and 2.0 * n_vox_out * desc.N * cout * desc.Cin * 9 <= NARROW_N_2D_MAX_FLOP):
         order = [25] + order  # images: the K-complete 16-channel-block kernel (the C side rejects what it does not cover)
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups (the LDS-DMA kernels stay first)
         dma_first = [c for c in order if c in (11, 15, 18, 19)]
@@ -1267,7 +1268,9 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                     _choose_conv_cfg(d, nvox, 24, only=DMA_CFGS)
                 except ValueError:
                     _choose_conv_cfg(d, nvox, 11, only=DMA_CFGS)
-        elif not dma_ok and cout <= 16 and (d.kd == 3 or NARROW_N_2D):  # a narrow output head (64 -> 4): the generic tile kernel otherwise (42 us at 32^3)
+        elif not dma_ok and cout <= 16 and (d.kd == 3 or NARROW_N_2D) and 2.0 * n * nvox * cout * cin * math.prod(k) <= NARROW_HEAD_MAX_FLOP:
+            # a narrow output head of a SMALL problem (the latent UNet's 64 -> 4, the 2-D UNet's 32 -> 1): the generic tile kernel otherwise (42 us at 32^3); the
+            # C_out = 1 head of a large volume keeps its depth-marching kernel (cfg 20)
             try:
                 _choose_conv_cfg(d, nvox, 24 if d.kd == 3 else 25, only=DMA_CFGS)
                 dma_ok = True

@@ -290,7 +290,8 @@ def test_conv_lds_dma_kernel(case, dtype, cfg):
                                   ("head4", 64, 4, None, None, (6, 9, 17), "none"), ("wide", 96, 136, None, None, (4, 6, 18), "res"),
                                   ("cat", 96, 72, 64, None, (5, 7, 19), "none"), ("skip", 64, 64, None, (32,), (8, 8, 16), "skip"),
                                   ("skip-cat", 32, 40, None, (64, 32), (5, 7, 19), "skip"), ("skip-cat3", 128, 136, 64, (32, 96), (4, 6, 18), "skip"),
-                                  ("deep", 256, 64, None, None, (8, 8, 8), "res"), ("tanh", 32, 24, None, None, (4, 4, 16), "tanh")], ids=lambda c: c[0])
+                                  ("deep", 256, 64, None, None, (8, 8, 8), "res"), ("tanh", 32, 24, None, None, (4, 4, 16), "tanh"),
+                                  ("head1", 64, 1, None, None, (5, 6, 17), "res"), ("ragged6", 32, 6, None, None, (4, 5, 18), "skip1")], ids=lambda c: c[0])
 def test_conv_small_volume_narrow_output_block_kernel(case, dtype):
     """cfg 24 (conv_sn.hip, round 6): a small volume's 3x3x3 convolution K-complete on 16-channel output blocks -- no split-K slices, no combine launch, the
     epilogue and the GroupNorm statistics in the kernel.  Ragged volumes, output-channel counts that are not multiples of 16 (40, 136, a 4-channel head), the
@@ -316,7 +317,8 @@ def test_conv_small_volume_narrow_output_block_kernel(case, dtype):
     elif mode == "tanh":
         kw["post_act"] = "tanh"
         want = torch.tanh(want)
-    elif mode == "skip":
+    elif mode in ("skip", "skip1"):
+        pcs = pcs or (32,)
         parts = [_rand((n, c, *sp), 580 + i).to(dtype) for i, c in enumerate(pcs)]
         ws = (_rand((cout, sum(pcs), 1, 1, 1), 576) / math.sqrt(sum(pcs))).to(dtype)
         bs = _rand((cout,), 577) * 0.1
@@ -329,7 +331,7 @@ def test_conv_small_volume_narrow_output_block_kernel(case, dtype):
         kw["skip"] = (dparts, ws.to(DEV), bs.to(DEV))
     wide_out = torch.full((n, *sp, cout + 16), 7.0, dtype=dtype, device=DEV)
     got = ops.conv(operand, w.to(DEV), b.to(DEV), out=wide_out[..., 16:], force_cfg=24, **kw)
-    _check(_cf(got), want, dtype, f"cfg24 {name}", extra=1.5 if mode == "skip" else 1.0)
+    _check(_cf(got), want, dtype, f"cfg24 {name}", extra=1.5 if mode in ("skip", "skip1") else 1.0)
     assert torch.all(wide_out[..., :16] == 7.0)  # nothing written outside the slice
     st = got._gm_cstats.sum(0).cpu()
     v = got.float().cpu().double().reshape(n, -1, cout)
@@ -347,7 +349,8 @@ def test_conv_small_volume_narrow_output_block_kernel(case, dtype):
                                   ("head4", 64, 4, None, None, (17, 19), "none"), ("cat", 96, 64, 64, None, (33, 30), "none"),
                                   ("skip", 64, 64, None, (32,), (32, 32), "skip"), ("skip-cat", 32, 40, None, (64, 32), (18, 35), "skip"),
                                   ("skip3", 128, 72, 64, (32, 32), (16, 16), "skip"), ("up", 64, 64, None, None, (16, 19), "up"),
-                                  ("pre-cat", 96, 32, 64, None, (32, 40), "pre"), ("pre", 64, 64, None, None, (16, 48), "pre")], ids=lambda c: c[0])
+                                  ("pre-cat", 96, 32, 64, None, (32, 40), "pre"), ("pre", 64, 64, None, None, (16, 48), "pre"),
+                                  ("head1", 32, 1, None, None, (64, 64), "pre"), ("ragged3", 64, 3, None, None, (19, 23), "res")], ids=lambda c: c[0])
 def test_conv_2d_narrow_output_block_kernel(case, dtype):
     """cfg 25 (conv_sn.hip over images, round 6): 3x3 stride-1 convolutions of a 2-D UNet (BASELINE configs[0]) K-complete on 16 x 16 pixels x 16 output
     channels per work-group -- ragged images, output-channel counts that are not multiples of 16, the two-source input of a virtual concatenation, bias +
