@@ -88,6 +88,7 @@ PROTOTYPES = {
     "gm_likelihood_term": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, C.c_int, C.POINTER(GmKlParams), c_vp]),
     "gm_lincomb": (C.c_int, [C.POINTER(c_vp), C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, c_vp, c_ll, C.c_int, c_vp]),
     "gm_copy_channels": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp]),
+    "gm_normal_bf16_from_bits": (C.c_int, [c_vp, c_vp, c_vp, c_ll, c_vp]),
     "gm_nchw_to_nhwc": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_ll, c_vp]),
     "gm_nhwc_to_nchw": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_vp]),
     "gm_resample2x": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

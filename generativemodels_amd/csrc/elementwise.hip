@@ -114,6 +114,28 @@ extern "C" int gm_sched_step(const void* sample, const void* model_output, const
   GM_LAUNCH_CHECK();
 }
 
+// ---- Gaussian noise of a bf16 ancestral sampling chain from the host generator's BYTES (host_noise.py) ------------------------------------------------------
+// torch.randn(n, dtype=bfloat16) on the CPU generator (what the reference's DDPMScheduler.step draws: ddpm.py:244-248) is, block of 16 by block of 16, a pure
+// function of byte pairs: out[16 b + j] = cos branch, out[16 b + 8 + j] = sin branch of (bits[16 b + j], bits[16 b + 8 + j]), j < 8.  table[b1 * 256 + b2] holds
+// the two bf16 results (low half: cos branch).  One thread per pair; the 256 KiB table lives in L2.
+__global__ __launch_bounds__(256) void normal_bf16_from_bits_kernel(const unsigned char* __restrict__ bits, const unsigned int* __restrict__ table,
+                                                                   unsigned short* __restrict__ out, long long npairs) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (long long)gridDim.x * blockDim.x) {
+    const long long base = (p >> 3) * 16 + (p & 7);
+    const unsigned e = table[(unsigned)bits[base] * 256u + bits[base + 8]];
+    out[base] = (unsigned short)(e & 0xFFFFu);
+    out[base + 8] = (unsigned short)(e >> 16);
+  }
+}
+
+extern "C" int gm_normal_bf16_from_bits(const unsigned char* bits, const unsigned int* table, void* out, long long n, void* stream) {
+  GM_REQUIRE(bits && table && out, "null pointer");
+  GM_REQUIRE(n >= 0 && n % 16 == 0, "whole blocks of 16 values");
+  if (n == 0) return 0;
+  normal_bf16_from_bits_kernel<<<ew_grid(n / 2), 256, 0, (hipStream_t)stream>>>(bits, table, (unsigned short*)out, n / 2);
+  GM_LAUNCH_CHECK();
+}
+
 // out = post_mul * (((c0*x0 + c1*x1) + c2*x2) + c3*x3) / post_div, left to right, every op rounded (no contraction): the
 // linear multi-step / Runge-Kutta combinations of PNDMScheduler (pndm.py:186-195,241-250).  post_mul / post_div of 1 are skipped
 // (x*1 and x/1 are exact anyway).  x0 may be null (the reference's integer-0 accumulator: 0 + t == t exactly).

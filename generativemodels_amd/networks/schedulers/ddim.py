@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch
 
-from ... import ops
+from ... import host_noise, ops
 from ..._native import GmStepParams
 from .scheduler import Scheduler, inference_timesteps, x0_prediction_code
 
@@ -76,8 +76,8 @@ class DDIMScheduler(Scheduler):
         noise = None
         p.noise_mode = 0
         if eta > 0:
-            # CPU-generator draw + H2D copy, like the reference (ddim.py:229-235): identical random stream
-            noise = torch.randn(model_output.shape, dtype=model_output.dtype, generator=generator).to(model_output.device)
+            # CPU-generator draw + H2D copy, like the reference (ddim.py:229-235): identical random stream (bf16: from the generator's byte draws, host_noise.py)
+            noise = host_noise.randn(model_output.shape, model_output.dtype, generator, model_output.device)
             p.noise_mode, p.c_noise = 1, self._f(variance**0.5 * eta)
         return ops.sched_step(sample, model_output, p, noise=noise)
 

@@ -6,7 +6,7 @@ import os
 
 import torch
 
-from ... import ops
+from ... import host_noise, ops
 from ..._native import GmStepParams
 from .scheduler import Scheduler, inference_timesteps, x0_prediction_code
 
@@ -30,11 +30,12 @@ class DDPMScheduler(Scheduler):
     """Ho et al. 2020 ancestral sampler. Arguments as the reference (ddpm.py:84-94).
 
     `fp32_noise_draw` (class / instance attribute, not in the reference; default False): how the noise of a REDUCED-PRECISION chain is drawn.  The reference
-    calls `torch.randn(shape, dtype=model_output.dtype)` on the CPU generator (ddpm.py:244-248); for bf16 that is torch's serial double-precision fill --
+    calls `torch.randn(shape, dtype=model_output.dtype)` on the CPU generator (ddpm.py:244-248); for bf16 that is torch's serial scalar bf16 fill --
     0.9 ms per 16 x 1 x 64 x 64 draw on the MI355X box's host, more than the whole replayed bf16 forward of the BASELINE configs[0] UNet (0.48 ms,
-    profiles/r06_c1b_2d_ddpm.json): the chain is then bound by the host's random number generator.  True: a bf16 / fp16 chain draws fp32 values from the same
-    generator (0.15 ms; torch's vectorised fill) and rounds them on the device -- the same distribution and seed dependence, NOT the reference's bf16 values
-    (its bf16 fill is another algorithm over the same generator state).  fp32 chains are untouched: same seed, same chain as the reference."""
+    profiles/r06_c1b_2d_ddpm.json).  The DEFAULT (False) now reproduces exactly those bf16 values from the generator's byte draws and a device-side table
+    (host_noise.py: 0.2 ms of host time, same stream, same bits).  True: a bf16 / fp16 chain draws fp32 values from the same generator (torch's vectorised fill)
+    and rounds them on the device -- the same distribution and seed dependence, NOT the reference's bf16 values (its bf16 fill is another algorithm over the
+    same generator state); kept for fp16 chains and as the A/B of round 6.  fp32 chains are untouched: same seed, same chain as the reference."""
 
     fp32_noise_draw = os.environ.get("GM_DDPM_FP32_NOISE_DRAW", "0") == "1"
 
@@ -122,9 +123,8 @@ class DDPMScheduler(Scheduler):
             if self.fp32_noise_draw and model_output.dtype in (torch.bfloat16, torch.float16):
                 noise = ops.cast(torch.randn(shape, dtype=torch.float32, layout=model_output.layout, generator=generator).to(model_output.device),
                                  model_output.dtype)
-            else:
-                noise = torch.randn(shape, dtype=model_output.dtype, layout=model_output.layout, generator=generator).to(
-                    model_output.device)
+            else:  # (bf16: the same values from the generator's byte draws + a device table lookup, host_noise.py)
+                noise = host_noise.randn(shape, model_output.dtype, generator, model_output.device)
             variance = (1 - a_prev) / (1 - a_t) * beta_t
             if self.variance_type == DDPMVarianceType.FIXED_SMALL:
                 p.noise_mode, p.c_noise = 1, self._f(torch.clamp(variance, min=1e-20) ** 0.5)

@@ -446,6 +446,20 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+def normal_bf16_from_bits(bits: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """torch.randn(n, dtype=bfloat16) of the CPU generator from that generator's byte draws (host_noise.py; reference ddpm.py:244-248): bits uint8 [n] and the
+    [256][256] int32 pair table, both on the device; n % 16 == 0."""
+    require_device(bits, table)
+    if bits.dtype != torch.uint8 or table.dtype != torch.int32 or table.numel() != 65536 or not bits.is_contiguous() or not table.is_contiguous():
+        raise ValueError("bits: contiguous uint8, table: contiguous int32 [256][256]")
+    n = bits.numel()
+    if n % 16 != 0:
+        raise ValueError("whole blocks of 16 values")
+    out = torch.empty(n, dtype=torch.bfloat16, device=bits.device)
+    check(lib().gm_normal_bf16_from_bits(bits.data_ptr(), table.data_ptr(), out.data_ptr(), n, _stream()), "gm_normal_bf16_from_bits")
+    return out
+
+
 def resample2x(x: torch.Tensor, mode: str) -> torch.Tensor:
     """mode 'up': nearest x2; 'down': 2x average pool, on every spatial axis of an arena tensor."""
     require_device(x)

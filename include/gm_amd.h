@@ -45,6 +45,10 @@ typedef struct GmStepParams {
  * x0 and noise may be NULL. */
 int gm_sched_step(const void* sample, const void* model_output, const void* noise, void* prev, void* x0,
                   long long batch, long long inner, long long mo_bstride, int dtype, const GmStepParams* p, void* stream);
+/* out[0..n) = torch.randn(n, dtype=torch.bfloat16) of the CPU generator -- the noise DDPMScheduler.step / DDIMScheduler.step (eta > 0) draw for a bf16 chain
+ * (networks/schedulers/ddpm.py:244-248, ddim.py:231-234) -- from that generator's n byte draws: torch's bf16 fill is a function of byte pairs within blocks of 16
+ * (generativemodels_amd/host_noise.py).  bits: n bytes (device); table: [256 * 256] (cos branch | sin branch << 16) bf16 pairs (device); n % 16 == 0. */
+int gm_normal_bf16_from_bits(const unsigned char* bits, const unsigned int* table, void* out, long long n, void* stream);
 /* out = post_mul * (((c0*x0 + c1*x1) + c2*x2) + c3*x3) / post_div over n elements, k = 1..4 terms, left to right with every
  * operation rounded: the Runge-Kutta / linear multi-step combinations of PNDMScheduler.step_prk / step_plms
  * (networks/schedulers/pndm.py:186-195, 241-250).  A NULL x[j] is skipped (the reference's integer-0 accumulator). */

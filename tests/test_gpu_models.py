@@ -328,6 +328,44 @@ def test_ddpm_fp32_noise_draw_for_reduced_precision_chains():
     assert torch.equal(state_fast, torch.get_rng_state())                # ... and the generator ends where one fp32 draw leaves it
 
 
+def test_bf16_noise_of_an_ancestral_step_is_torch_randn_bit_for_bit(monkeypatch):
+    """(round 6) A bf16 DDPM / DDIM(eta > 0) step draws its noise through host_noise.randn: the CPU generator's BYTE draws, copied to the device and expanded by
+    gm_normal_bf16_from_bits -- against `torch.randn(shape, dtype=bfloat16, generator=g).to(device)`, the reference's draw (ddpm.py:244-248, ddim.py:231-234): the
+    same bits, the generator left in the same state, for whole and ragged sizes (the latter take the plain draw); the steps with the table switched off are
+    bit-identical."""
+    from generativemodels_amd import host_noise as H
+    from generativemodels_amd.networks.schedulers import DDIMScheduler, DDPMScheduler
+    assert H.ENABLED and H.table_matches_torch()
+    for seed, shape in ((3, (16, 1, 64, 64)), (4, (2, 4, 8, 8, 8)), (5, (3, 5, 7)), (6, (1, 16))):
+        g1, g2 = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed)
+        want = torch.randn(shape, dtype=torch.bfloat16, generator=g1).to(DEV)
+        got = H.randn(shape, torch.bfloat16, g2, DEV)
+        assert got.shape == want.shape and torch.equal(got.view(torch.int16), want.view(torch.int16)) and torch.equal(g1.get_state(), g2.get_state()), shape
+    # the device kernel against the host-side lookup on every byte pair
+    pairs = torch.arange(65536, dtype=torch.int64)
+    bits = torch.stack([pairs // 256, pairs % 256], 1).reshape(-1, 8, 2).permute(0, 2, 1).reshape(-1).to(torch.uint8)  # blocks of 16: 8 first bytes, 8 second bytes
+    dev_out = _ops().normal_bf16_from_bits(bits.to(DEV), H.bf16_normal_table().to(DEV))
+    assert torch.equal(dev_out.cpu().view(torch.int16), H.normal_bf16_from_bits_host(bits).view(torch.int16))
+    eps = torch.randn((4, 1, 16, 16), generator=torch.Generator().manual_seed(1)).bfloat16()
+    x = torch.randn((4, 1, 16, 16), generator=torch.Generator().manual_seed(2)).bfloat16()
+    ddpm, ddim = DDPMScheduler(num_train_timesteps=100), DDIMScheduler(num_train_timesteps=100)
+    ddpm.set_timesteps(100)
+    ddim.set_timesteps(50)
+
+    def steps():
+        torch.manual_seed(9)
+        a, _ = ddpm.step(_dev(eps), 50, _dev(x))
+        b, _ = ddpm.step(_dev(eps), 49, a, generator=torch.Generator().manual_seed(11))
+        c, _ = ddim.step(_dev(eps), 50, _dev(x), eta=0.7, generator=torch.Generator().manual_seed(12))
+        return a, b, c, torch.get_rng_state()
+
+    fast = steps()
+    monkeypatch.setattr(H, "ENABLED", False)
+    plain = steps()
+    for f, p in zip(fast, plain):
+        assert torch.equal(f, p)
+
+
 def test_inferer_concat_mode_and_errors():
     from generativemodels_amd.inferers import DiffusionInferer
     from generativemodels_amd.networks.schedulers import DDIMScheduler

@@ -734,6 +734,34 @@ def test_bench_module_imports_and_its_power_sampler_degrades_without_a_gpu():
     assert set(bench.MFMA_BF16_SUSTAINED_TFLOPS.values()) == {1863.0, 1490.0, 1621.0}  # profiles/r04_mfma_power_ceiling.txt
 
 
+def test_bf16_noise_table_reproduces_torch_randn_from_the_generator_bytes():
+    """host_noise.py: torch's CPU bf16 `randn` (what the reference's DDPMScheduler.step draws for a bf16 chain, ddpm.py:244-248) is a function of byte pairs of the
+    generator's draws inside blocks of 16.  The table (built with torch's own bf16 operators) and the host-side lookup -- the checker of the device kernel --
+    against torch.randn itself: several seeds and shapes, the default generator, signed zeros (u1 = 1), and the generator must end in the same state.  Without a GPU
+    (or for other dtypes / ragged sizes) `host_noise.randn` IS torch.randn."""
+    from generativemodels_amd import host_noise as H
+    assert H.table_matches_torch()
+    assert H.bf16_normal_table().shape == (256, 256) and H.bf16_normal_table().dtype == torch.int32
+    for seed in (0, 1, 77):
+        for shape in ((16, 1, 64, 64), (2, 3, 8), (1, 16), (5, 4, 32, 32)):
+            g1, g2 = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed)
+            want = torch.randn(shape, dtype=torch.bfloat16, generator=g1)
+            bits = torch.empty(want.numel(), dtype=torch.uint8).random_(generator=g2)
+            got = H.normal_bf16_from_bits_host(bits).reshape(shape)
+            assert torch.equal(want.view(torch.int16), got.view(torch.int16)) and torch.equal(g1.get_state(), g2.get_state()), (seed, shape)
+    torch.manual_seed(9)
+    want = torch.randn(64, dtype=torch.bfloat16)
+    torch.manual_seed(9)
+    assert torch.equal(want.view(torch.int16), H.normal_bf16_from_bits_host(torch.empty(64, dtype=torch.uint8).random_()).view(torch.int16))
+    zero_pairs = torch.zeros(16, dtype=torch.uint8)  # u1 = 1: r = sqrt(-0); `* std + mean` makes every result +0
+    assert torch.equal(H.normal_bf16_from_bits_host(zero_pairs).view(torch.int16), torch.zeros(16, dtype=torch.int16))
+    with pytest.raises(ValueError):
+        H.normal_bf16_from_bits_host(torch.zeros(24, dtype=torch.uint8))
+    for dtype, shape in ((torch.bfloat16, (4, 16)), (torch.bfloat16, (3, 5)), (torch.float32, (4, 16))):  # no device: the plain draw, same stream
+        g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+        assert torch.equal(H.randn(shape, dtype, g1, "cpu"), torch.randn(shape, dtype=dtype, generator=g2)) and torch.equal(g1.get_state(), g2.get_state())
+
+
 def test_bench_self_launch_argv_and_environment():
     """`python bench.py --gpus N` as the driver calls it (no launcher environment): N > 1 -- or GM_BENCH_SELF_LAUNCH=1 at N = 1 -- re-executes
     itself under torch.distributed.run with one rank per GPU, rendezvous on 127.0.0.1, the original arguments handed on unchanged; a process
