@@ -72,18 +72,53 @@ def table_matches_torch() -> bool:
     return _verified
 
 
+# Page-locked staging, so that the host never waits for the device inside a sampling loop: `tensor.to(device)` from pageable memory returns only when the copy
+# has run, i.e. after everything queued in front of it -- the forward of the step -- which serialises the host's work of the NEXT step behind the device's of this
+# one.  A draw goes into the next slot of a small ring of pinned buffers (per size and dtype), is copied with non_blocking=True, and an event guards the slot's
+# reuse RING steps later.
+RING = 4
+_ring: dict = {}
+
+
+def _staged_copy(draw, n: int, dtype: torch.dtype, dev: torch.device) -> torch.Tensor:
+    """draw(buffer) fills a pinned [n] buffer of `dtype` on the host; returns its device copy (stream-ordered, the host does not wait)."""
+    key = (n, dtype, dev.index)
+    ent = _ring.get(key)
+    if ent is None:
+        ent = _ring[key] = dict(slots=[torch.empty(n, dtype=dtype).pin_memory() for _ in range(RING)], events=[None] * RING, i=0)
+        if len(_ring) > 16:  # (a few sizes per process: chains of one shape)
+            _ring.pop(next(iter(_ring)))
+    i = ent["i"]
+    ent["i"] = (i + 1) % RING
+    if ent["events"][i] is not None:
+        ent["events"][i].synchronize()  # the copy that read this slot RING draws ago
+    buf = ent["slots"][i]
+    draw(buf)
+    out = torch.empty(n, dtype=dtype, device=dev)
+    out.copy_(buf, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    ent["events"][i] = ev
+    return out
+
+
 def randn(shape, dtype: torch.dtype, generator: Optional[torch.Generator], device) -> torch.Tensor:
     """`torch.randn(shape, dtype=dtype, generator=generator).to(device)`, bit for bit, the generator left in the same state."""
     shape = tuple(int(s) for s in shape)
     n = math.prod(shape)
     dev = torch.device(device)
-    if ENABLED and dtype == torch.bfloat16 and dev.type == "cuda" and n >= 16 and n % 16 == 0 and table_matches_torch():
+    if dev.type != "cuda" or n == 0:
+        return torch.randn(shape, dtype=dtype, generator=generator).to(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if ENABLED and dtype == torch.bfloat16 and n >= 16 and n % 16 == 0 and table_matches_torch():
         from . import ops
 
-        bits = torch.empty(n, dtype=torch.uint8).random_(generator=generator)
-        key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-        tab = _table_dev.get(key)
+        bits = _staged_copy(lambda buf: buf.random_(generator=generator), n, torch.uint8, dev)
+        tab = _table_dev.get(dev.index)
         if tab is None:
-            tab = _table_dev[key] = bf16_normal_table().to(dev)
-        return ops.normal_bf16_from_bits(bits.to(dev), tab).reshape(shape)
-    return torch.randn(shape, dtype=dtype, generator=generator).to(dev)
+            tab = _table_dev[dev.index] = bf16_normal_table().to(dev)
+        return ops.normal_bf16_from_bits(bits, tab).reshape(shape)
+    if not ENABLED or torch.cuda.is_current_stream_capturing():
+        return torch.randn(shape, dtype=dtype, generator=generator).to(dev)
+    return _staged_copy(lambda buf: torch.randn((n,), dtype=dtype, generator=generator, out=buf), n, dtype, dev).reshape(shape)

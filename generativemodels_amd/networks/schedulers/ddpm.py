@@ -121,8 +121,7 @@ class DDPMScheduler(Scheduler):
             if learned:
                 shape[1] //= 2
             if self.fp32_noise_draw and model_output.dtype in (torch.bfloat16, torch.float16):
-                noise = ops.cast(torch.randn(shape, dtype=torch.float32, layout=model_output.layout, generator=generator).to(model_output.device),
-                                 model_output.dtype)
+                noise = ops.cast(host_noise.randn(shape, torch.float32, generator, model_output.device), model_output.dtype)
             else:  # (bf16: the same values from the generator's byte draws + a device table lookup, host_noise.py)
                 noise = host_noise.randn(shape, model_output.dtype, generator, model_output.device)
             variance = (1 - a_prev) / (1 - a_t) * beta_t

@@ -738,6 +738,9 @@ NARROW_N_MAX_CHUNKS = int(os.environ.get("GM_CONV_SN_MAX_CHUNKS", "6"))
 # in-LDS GroupNorm + SiLU prologue, the two-source input, the fused 1x1 shortcut and the statistics -- where the register-staged 2-D kernels took a separate
 # gn_stats / gn_apply / shortcut launch each (BASELINE configs[0], the 2-D DDPM UNet).  Up to NARROW_N_2D_MAX_FLOP per convolution (what was measured).
 NARROW_N_2D = os.environ.get("GM_CONV_SN2D", "1") != "0"
+# conv_in of a 2-D network (C_in <= 4, 3x3, stride 1) on the C_in <= 4 edge kernel (cfg 12) as a depth-1 volume: BASELINE configs[0]'s 1 -> 32 at 16 x 64 x 64 ran
+# on the generic tile kernel (27 us, the longest launch of that forward, and a stand-alone statistics pass behind it)
+EDGE_2D_AS_3D = os.environ.get("GM_CONV_EDGE2D", "1") != "0"
 NARROW_N_2D_MAX_FLOP = float(os.environ.get("GM_CONV_SN2D_MAX_FLOP", "3e10"))
 NARROW_HEAD_MAX_FLOP = 1.0e9
 # (Rounds 4-5 built three more tile structures on v_mfma_f32_32x32x16_bf16 -- cfg 21: 16-channel half-chunks, three work-groups per CU; cfg 22: 512-voxel
@@ -888,8 +891,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             and 2.0 * n_vox_out * desc.N * cout * desc.Cin * 9 <= NARROW_N_2D_MAX_FLOP):
         order = [25] + order  # images: the K-complete 16-channel-block kernel (the C side rejects what it does not cover)
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups (the LDS-DMA kernels stay first)
-        dma_first = [c for c in order if c in (11, 15, 18, 19)]
-        rest = [c for c in order if c not in (11, 15, 18, 19)]
+        dma_first = [c for c in order if c in (11, 12, 15, 18, 19)]  # (12: the C_in <= 4 edge kernel -- its cost is the output store, whatever the tile)
+        rest = [c for c in order if c not in (11, 12, 15, 18, 19)]
         order = dma_first + [c for c in rest if _cfg_tile(c)[0] <= 64] + [c for c in rest if _cfg_tile(c)[0] > 64]
     order = [c for c in order if (only is None or c in only) and c not in exclude]
     best = None
@@ -909,8 +912,8 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
             if COUT1_MARCH_LTD is not None:
                 ltd = int(COUT1_MARCH_LTD)
             bits = [ltd, 3, ltw]
-        if cfg in (11, 14, 15, 16, 18, 19, 24, 25):  # the LDS-DMA kernels are built for fixed tiles; extents below the tile are masked (W = 8 at the
-            bits = {11: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 24: [2, 2, 4], 25: [0, 4, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
+        if cfg in (11, 12, 14, 15, 16, 18, 19, 24, 25):  # the LDS-DMA kernels (and the C_in <= 4 edge kernel) are built for fixed tiles; extents below the tile are masked (W = 8 at the
+            bits = {11: [2, 2, 4], 12: [2, 2, 4], 14: [2, 2, 4], 15: [1, 2, 4], 16: [3, 2, 4], 18: [3, 2, 4], 19: [3, 2, 4], 24: [2, 2, 4], 25: [0, 4, 4]}[cfg]  # 8^3 level: half the tile idles, still 2x faster than cfg 4)
         desc.cfg, desc.ltd, desc.lth, desc.ltw = cfg, bits[0], bits[1], bits[2]
         lds = lib().gm_conv_lds_bytes(C.byref(desc))  # -1: configuration not applicable to this geometry
         soft = LDS_HARD_LIMIT if cfg >= 5 else LDS_SOFT_LIMIT  # the fast kernels are sized for their own occupancy
@@ -1106,6 +1109,22 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                                                   out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act], POST_ACT[post_act], dt_code(dtype),
                                                   _stream()), "gm_linear_rows"))
         return out
+    if (EDGE_2D_AS_3D and nsp == 2 and x2 is None and packed is None and weight is not None and weight.dim() == 4 and not transposed and not upsample
+            and cin <= 4 and k == (1, 3, 3) and s == (1, 1, 1) and dil == (1, 1, 1) and plo == (0, 1, 1) and phi == (0, 1, 1) and pre is None
+            and pre_act == "none" and skip is None and force_cfg is None and ksplit is None and cout % vecw == 0 and rows >= DMA_CONV_MIN_VOXELS):
+        # conv_in of a 2-D network (C_in <= 4): the taps x inputs ARE the GEMM K of the edge kernel (cfg 12, conv_edge.hip) -- handed over as the depth-1 volume
+        # it is, the 3x3 kernel as the centre plane of a 3x3x3 one (zero planes in front of and behind it meet the padding planes only)
+        def embed():
+            w5 = torch.zeros((weight.shape[0], weight.shape[1], 3, 3, 3), dtype=weight.dtype, device=weight.device)
+            w5[:, :, 1] = weight.detach()
+            return w5
+        got = conv(x.unsqueeze(1), _cached(weight, ("centre_plane_3d",), embed), bias, kernel=3, padding=1, rowvec=rowvec,
+                   res=None if res is None else res.unsqueeze(1), post_act=post_act, out=None if out is None else out.unsqueeze(1), want_stats=want_stats)
+        y = out if out is not None else got.squeeze(1)
+        st = getattr(got, "_gm_cstats", None)
+        if st is not None:
+            y._gm_cstats = st
+        return y
     if (TOKEN_GEMM and SMALL_LINEAR_ROWS < rows <= TOKEN_GEMM_MAX_ROWS and cin <= TOKEN_GEMM_MAX_CIN and 2.0 * rows * cin * cout <= TOKEN_GEMM_MAX_FLOP
             and x2 is None and k == (1, 1, 1) and s == (1, 1, 1) and not upsample and rowvec is None and not want_stats and skip is None
             and force_cfg is None and ksplit is None and cin % vecw == 0 and arena_ld(x) % vecw == 0 and x.data_ptr() % 16 == 0

@@ -345,6 +345,45 @@ def test_conv_small_volume_narrow_output_block_kernel(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", [(1, 32, (64, 64), 4), (3, 64, (33, 21), 2), (4, 40, (16, 50), 1), (2, 8, (7, 9), 3)], ids=lambda c: f"cin{c[0]}-cout{c[1]}")
+def test_conv_in_of_a_2d_network_on_the_edge_kernel(case, dtype):
+    """(round 6) conv_in of a 2-D DiffusionModelUNet (C_in <= 4, 3x3, stride 1; BASELINE configs[0]: 1 -> 32 at 16 x 64 x 64) runs on the C_in <= 4 edge kernel
+    (cfg 12: taps x inputs are the GEMM K) as a depth-1 volume with the 3x3 kernel in the centre plane of a 3x3x3 one, output statistics fused -- against fp64
+    F.conv2d, against the generic tile kernel it replaces (same function, another summation order), ragged images, a residual, writes into a channel slice.
+    Reference: diffusion_model_unet.py:1748-1756."""
+    ops = _ops()
+    cin, cout, sp, n = case
+    x = _rand((n, cin, *sp), 881).to(dtype)
+    w = (_rand((cout, cin, 3, 3), 882) / math.sqrt(cin * 9)).to(dtype)
+    b, temb = _rand((cout,), 883) * 0.1, _rand((n, cout), 884) * 0.5
+    res = _rand((n, cout, *sp), 885).to(dtype)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1) + temb.double().reshape(n, cout, 1, 1) + res.double()
+    kw = dict(kernel=3, padding=1, rowvec=temb.to(DEV), res=_cl(res), want_stats=True)
+    wide = torch.full((n, *sp, cout + 16), 7.0, dtype=dtype, device=DEV)
+    wd = w.to(DEV)
+    ops.start_profile()
+    got = ops.conv(_cl(x), wd, b.to(DEV), out=wide[..., 16:], **kw)
+    took = any("cfg12" in nm for nm, _, _ in ops.stop_profile())
+    assert took == (n * sp[0] * sp[1] >= ops.DMA_CONV_MIN_VOXELS), "the edge kernel takes every such convolution of at least 256 pixels"
+    _check(_cf(got), want, dtype, f"2-D conv_in on cfg 12, {case}")
+    assert torch.all(wide[..., :16] == 7.0)
+    assert took == hasattr(got, "_gm_cstats")  # (fused into the edge kernel's epilogue; a stand-alone pass otherwise)
+    st = ops.channel_stats(got).sum(0).cpu()
+    v = got.float().cpu().double().reshape(n, -1, cout)
+    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1], (v * v).sum(1), rtol=1e-4, atol=1e-2)
+    keep = ops.EDGE_2D_AS_3D
+    try:
+        ops.EDGE_2D_AS_3D = False
+        other = ops.conv(_cl(x), wd, b.to(DEV), **kw)
+    finally:
+        ops.EDGE_2D_AS_3D = keep
+    tol = (2 ** -6 if dtype == torch.bfloat16 else 1e-4) * max(1.0, want.abs().max().item())
+    assert (other.float() - got.float()).abs().max().item() <= tol
+    again = ops.conv(_cl(x), wd, b.to(DEV), **kw)
+    assert torch.equal(again, got.contiguous()) and torch.equal(ops.channel_stats(again), ops.channel_stats(got))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("case", [("plain", 32, 32, None, None, (64, 64), "res"), ("ragged", 64, 40, None, None, (21, 37), "res"),
                                   ("head4", 64, 4, None, None, (17, 19), "none"), ("cat", 96, 64, 64, None, (33, 30), "none"),
                                   ("skip", 64, 64, None, (32,), (32, 32), "skip"), ("skip-cat", 32, 40, None, (64, 32), (18, 35), "skip"),

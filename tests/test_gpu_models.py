@@ -341,6 +341,13 @@ def test_bf16_noise_of_an_ancestral_step_is_torch_randn_bit_for_bit(monkeypatch)
         want = torch.randn(shape, dtype=torch.bfloat16, generator=g1).to(DEV)
         got = H.randn(shape, torch.bfloat16, g2, DEV)
         assert got.shape == want.shape and torch.equal(got.view(torch.int16), want.view(torch.int16)) and torch.equal(g1.get_state(), g2.get_state()), shape
+    g1, g2 = torch.Generator().manual_seed(21), torch.Generator().manual_seed(21)
+    for i in range(2 * H.RING + 1):  # the pinned staging ring wraps: every draw still is torch.randn's, fp32 and bf16 alike
+        for dt in (torch.float32, torch.bfloat16):
+            want = torch.randn((2, 1, 32, 32), dtype=dt, generator=g1).to(DEV)
+            got = H.randn((2, 1, 32, 32), dt, g2, DEV)
+            assert torch.equal(got, want), (i, dt)
+    assert torch.equal(g1.get_state(), g2.get_state())
     # the device kernel against the host-side lookup on every byte pair
     pairs = torch.arange(65536, dtype=torch.int64)
     bits = torch.stack([pairs // 256, pairs % 256], 1).reshape(-1, 8, 2).permute(0, 2, 1).reshape(-1).to(torch.uint8)  # blocks of 16: 8 first bytes, 8 second bytes
