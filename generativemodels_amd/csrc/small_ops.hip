@@ -185,6 +185,150 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
   }
 }
 
+// The same GEMM for MANY token rows (round 6): y = post_act(act(x * scale[n] + shift[n]) W^T + b) (+ res) with a wave owning 16 rows x NB * 16 output channels.
+// linear_rows_kernel gives every 16-channel block of a row group its own wave: each re-reads the group's x rows (and re-applies the GroupNorm affine) and
+// stores its results two bytes at a time.  At 16 384 rows (the q | k | v projections of BASELINE configs[0]'s attention blocks: 16 x 32 x 32 tokens, 64 -> 192)
+// that is 12 passes over x and 3 072 work-groups for 0.4 GFLOP.  Here the x fragment of a K chunk is loaded and transformed ONCE per NB blocks, the four waves
+// of a work-group take four consecutive row groups (the weight fragments they share meet in the CU's L1), and a lane stores its four consecutive channels as
+// one vector.  Same accumulation order per output (K chunks in order, one MFMA each) as linear_rows_kernel: bit-identical results.  C_in a multiple of the MFMA
+// K step; affine prologue, pre-/post-activation, residual and the V^T image as there.
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void token_gemm_wide_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ w, const float* __restrict__ bias,
+                                                             const T* __restrict__ res, long long res_ld, T* __restrict__ y, long long y_ld, int rows, int cin,
+                                                             int cout, int pre_act, int post_act, LinearRowsExtra ex) {
+  constexpr int BK = ConvTraits<T>::BK, VECW = ConvTraits<T>::VECW;
+  constexpr bool PRECISE = sizeof(T) == 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int cout_pad = (cout + 15) & ~15;
+  const int co0 = blockIdx.x * (16 * NB);
+  const int r0 = (blockIdx.y * 4 + wave) * 16;
+  if (r0 >= rows) return;  // wave-uniform
+  const int row = r0 + l15;
+  const bool row_ok = row < rows;
+  const int rowc = row_ok ? row : rows - 1;
+  const int nchunks = cin / BK;  // host: cin % BK == 0
+  const T* xrow = x + (long long)rowc * x_ld + q * VECW;
+  // block nb of this wave: channels co0 + 16 nb .. + 15; blocks beyond the padded panel re-read the last one and are dropped at the store
+  int wblk[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wblk[nb] = co0 + 16 * nb < cout_pad ? co0 + 16 * nb : cout_pad - 16;
+  const T* wrow = w + (long long)l15 * BK + q * VECW;  // + (chunk * cout_pad + block channel) * BK
+  const long long aoff = ex.pre_scale ? (long long)(rowc / ex.rows_per_sample) * ex.ss_ld + q * VECW : 0;
+  // bias / residual of this lane's outputs, requested up front at clamped addresses
+  float bia[NB][4];
+  uint2 rsd[NB];
+  const bool vec4 = (cout & 3) == 0 && (y_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & (4 * sizeof(T) - 1)) == 0 &&
+                    (!res || ((res_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & (4 * sizeof(T) - 1)) == 0));
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = wblk[nb] + 4 * q + i;
+      bia[nb][i] = bias ? bias[co < cout ? co : cout - 1] : 0.f;
+    }
+    rsd[nb] = make_uint2(0u, 0u);
+    if (sizeof(T) == 2 && res && vec4) {
+      const int co = wblk[nb] + 4 * q;
+      rsd[nb] = *reinterpret_cast<const uint2*>(res + (long long)rowc * res_ld + (co + 3 < cout ? co : 0));
+    }
+  }
+  f32x4_t acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 2;
+  for (int c0 = 0; c0 < nchunks; c0 += U) {
+    uint4 wf[U][NB], xf[U];
+    float asc[U][VECW], ash[U][VECW];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;  // clamped: the duplicate is discarded below
+      xf[u] = *reinterpret_cast<const uint4*>(xrow + c * BK);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wf[u][nb] = *reinterpret_cast<const uint4*>(wrow + ((long long)c * cout_pad + wblk[nb]) * BK);
+      if (ex.pre_scale) {  // (uniform)
+#pragma unroll
+        for (int i = 0; i < VECW; i += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(ex.pre_scale + aoff + c * BK + i), b2 = *reinterpret_cast<const float4*>(ex.pre_shift + aoff + c * BK + i);
+          asc[u][i] = a.x; asc[u][i + 1] = a.y; asc[u][i + 2] = a.z; asc[u][i + 3] = a.w;
+          ash[u][i] = b2.x; ash[u][i + 1] = b2.y; ash[u][i + 2] = b2.z; ash[u][i + 3] = b2.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (c0 + u >= nchunks) break;
+      uint4 b = row_ok ? xf[u] : make_uint4(0u, 0u, 0u, 0u);
+      if (pre_act || ex.pre_scale) {
+        float v[VECW];
+        Vec16<T>::unpack(b, v);
+        if (ex.pre_scale) {
+#pragma unroll
+          for (int i = 0; i < VECW; ++i) v[i] = row_ok ? v[i] * asc[u][i] + ash[u][i] : 0.f;
+        }
+        if (pre_act) conv_act_vec(v, pre_act, PRECISE);
+        b = Vec16<T>::pack(v);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) Mma<T>::run(wf[u][nb], b, acc[nb]);
+    }
+  }
+  if (!row_ok) return;
+  // D layout: column = row l15, rows = output channels block + 4q + i
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    if (co0 + 16 * nb >= cout_pad) break;  // (uniform)
+    const int cob = co0 + 16 * nb + 4 * q;
+    float o[4];
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (res) {
+      if (sizeof(T) == 2 && vec4) {
+        rs[0] = __uint_as_float(rsd[nb].x << 16); rs[1] = __uint_as_float(rsd[nb].x & 0xffff0000u);
+        rs[2] = __uint_as_float(rsd[nb].y << 16); rs[3] = __uint_as_float(rsd[nb].y & 0xffff0000u);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[i] = cob + i < cout ? ElemIO<T>::ld(res + (long long)row * res_ld + cob + i) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = acc[nb][i] + (bias ? bia[nb][i] : 0.f);
+      v = conv_post_act(v, post_act);
+      if (res) v += rs[i];
+      o[i] = v;
+    }
+    if (vec4) {
+      if (cob < cout) {
+        if (sizeof(T) == 2) *reinterpret_cast<uint2*>(y + (long long)row * y_ld + cob) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        else *reinterpret_cast<float4*>(y + (long long)row * y_ld + cob) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (cob + i < cout) ElemIO<T>::st(y + (long long)row * y_ld + cob + i, o[i]);
+    }
+    if (ex.vt && cob + 3 >= ex.vt_c0) {
+      const int L = ex.rows_per_sample, smp = row / L, key = row - smp * L;
+      const int pos = (key & ~31) + ((key & 15) >> 2) * 8 + ((key >> 4) & 1) * 4 + (key & 3);  // key = blk*32 + half*16 + qq*4 + r -> blk*32 + qq*8 + half*4 + r
+      const int heads = (cout - ex.vt_c0) / ex.vt_dh;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cch = cob + i - ex.vt_c0;
+        if (cch >= 0 && cob + i < cout)
+          ElemIO<T>::st(reinterpret_cast<T*>(ex.vt) + ((long long)(smp * heads + cch / ex.vt_dh) * ex.vt_dh + cch % ex.vt_dh) * L + pos, o[i]);
+      }
+    }
+  }
+}
+
+// rows from which the wide form takes the affine token GEMMs (0 = never), and its blocks per wave: tools / tests pin them, the defaults are the measured ones
+// (nb 0 = by row count: 4 blocks per wave from 8 192 rows, 2 below -- MI355X, profiles/r06_token_gemm_wide_ab.txt: 16 384 x 64 -> 192 runs best at 3-4, 4 096 x 128 -> 384 at 2)
+static int gm_token_gemm_wide_rows = 2048, gm_token_gemm_wide_nb = 0;
+extern "C" void gm_token_gemm_set_wide(int min_rows, int nb) {
+  gm_token_gemm_wide_rows = min_rows < 0 ? 2048 : min_rows;
+  gm_token_gemm_wide_nb = (nb == 2 || nb == 3 || nb == 4) ? nb : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Round 3: the decode step's GEMMs re-built around ONE rule -- every global load of a launch is issued before the first wait.  A launch of
 // these kernels is a handful of work-groups on an idle chip; its duration is the ~4.3 us every launch costs on this stack plus one L2 round
@@ -525,6 +669,19 @@ static int linear_rows_launch(const void* x, long long x_ld, const void* w, cons
     else GM_FAIL(-2, "unsupported dtype");
 #undef GM_KSPLIT_DISPATCH
 #undef GM_KSPLIT_LAUNCH
+    GM_LAUNCH_CHECK();
+  }
+  const int bk = dtype == GM_F32 ? 16 : 32;
+  if (gm_token_gemm_wide_rows > 0 && rows >= gm_token_gemm_wide_rows && cin % bk == 0 && cout_pad >= 32 && !ex.ln_g && !ex.kv_ws && !ex.mlp_p && ex.split == 0 &&
+      !ex.off_dev && (!ex.pre_scale || ex.rows_per_sample > 0) && (dtype == GM_F32 || dtype == GM_BF16)) {
+    const int nb = gm_token_gemm_wide_nb ? gm_token_gemm_wide_nb : (rows >= 8192 ? 4 : 2);
+    dim3 gw((cout_pad + 16 * nb - 1) / (16 * nb), (rows + 63) / 64);
+#define GM_WIDE_LAUNCH(T, NBV)                                                                                                              \
+  token_gemm_wide_kernel<T, NBV><<<gw, 256, 0, st>>>((const T*)x, x_ld, (const T*)w, bias, (const T*)res, res_ld, (T*)y, y_ld, rows, cin, cout, \
+                                                     pre_act, post_act, ex)
+    if (dtype == GM_F32) { if (nb == 2) GM_WIDE_LAUNCH(float, 2); else if (nb == 3) GM_WIDE_LAUNCH(float, 3); else GM_WIDE_LAUNCH(float, 4); }
+    else { if (nb == 2) GM_WIDE_LAUNCH(bf16_raw, 2); else if (nb == 3) GM_WIDE_LAUNCH(bf16_raw, 3); else GM_WIDE_LAUNCH(bf16_raw, 4); }
+#undef GM_WIDE_LAUNCH
     GM_LAUNCH_CHECK();
   }
   dim3 grid((cout_pad / 16 + 3) / 4, (rows + 15) / 16);

@@ -848,7 +848,7 @@ SMALL_LINEAR_ROWS = 64       # 1x1 "convolutions" over at most this many rows ta
 # kernels cost ~20 us per launch there whatever the size (a stage -> barrier -> tap -> barrier chain per K chunk); gm_linear_rows_affine requests
 # all K chunks of a 16 x 16 output block straight from L2.  Bounds: what was measured (tools/bench_conv1x1.py)
 TOKEN_GEMM = os.environ.get("GM_TOKEN_GEMM", "1") != "0"
-TOKEN_GEMM_MAX_ROWS = 8192
+TOKEN_GEMM_MAX_ROWS = int(os.environ.get("GM_TOKEN_GEMM_MAX_ROWS", "32768"))  # (8192 until the wide form of round 6: small_ops.hip token_gemm_wide_kernel)
 TOKEN_GEMM_MAX_CIN = 512
 TOKEN_GEMM_MAX_FLOP = 2.0e9
 DMA_CONV = True              # route eligible 3x3x3 convolutions through conv_dma.hip (cfg 11)

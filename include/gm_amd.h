@@ -45,6 +45,10 @@ typedef struct GmStepParams {
  * x0 and noise may be NULL. */
 int gm_sched_step(const void* sample, const void* model_output, const void* noise, void* prev, void* x0,
                   long long batch, long long inner, long long mo_bstride, int dtype, const GmStepParams* p, void* stream);
+/* The affine token GEMMs (gm_linear_rows_affine / _vt, gm_linear_rows) over at least `min_rows` rows run with a wave owning 16 rows x nb * 16 output channels
+ * (nb = 2, 3 or 4, anything else = chosen by the row count; small_ops.hip: token_gemm_wide_kernel) instead of one 16-channel block per wave.  min_rows 0 = never,
+ * < 0 = the default (2048): a process-wide switch for measurements and tests; results are bit-identical either way. */
+void gm_token_gemm_set_wide(int min_rows, int nb);
 /* out[0..n) = torch.randn(n, dtype=torch.bfloat16) of the CPU generator -- the noise DDPMScheduler.step / DDIMScheduler.step (eta > 0) draw for a bf16 chain
  * (networks/schedulers/ddpm.py:244-248, ddim.py:231-234) -- from that generator's n byte draws: torch's bf16 fill is a function of byte pairs within blocks of 16
  * (generativemodels_amd/host_noise.py).  bits: n bytes (device); table: [256 * 256] (cos branch | sin branch << 16) bf16 pairs (device); n % 16 == 0. */

@@ -1235,6 +1235,56 @@ def test_token_gemm_path_of_1x1_convolutions(n, tokens, cin, cout, pre, pre_act,
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nb", [2, 3, 4])
+@pytest.mark.parametrize("case", [(16, 1024, 64, 192, 64, True, False), (1, 4096, 128, 384, 128, True, False), (3, 1000, 96, 72, 0, False, True),
+                                  (2, 2050, 64, 50, 0, True, True), (1, 512, 256, 768, 256, True, False)], ids=lambda c: f"N{c[0]}-L{c[1]}-{c[2]}to{c[3]}")
+def test_token_gemm_wide_form_is_bit_identical(case, nb, dtype):
+    """(round 6) token_gemm_wide_kernel -- a wave owns 16 rows x nb * 16 output channels, four row groups per work-group, vector stores -- against the
+    one-block-per-wave kernel it replaces from 2 048 rows on: the same accumulation order per output, so BIT FOR BIT: GroupNorm affine prologue, residual,
+    ragged row and channel counts (the element-wise store path), several samples, and the V^T image of the attention kernel (byte-identical; bf16, whole 64-key
+    blocks).  BASELINE configs[0]'s q | k | v projection (16 x 1024 tokens, 64 -> 192) is the first case.  fp64 reference as well.
+    Reference: AttentionBlock.forward, diffusion_model_unet.py:424-441."""
+    from generativemodels_amd._native import lib
+    ops = _ops()
+    n, tokens, cin, cout, dh, pre, res = case
+    x = _rand((n, tokens, cin), 811).to(dtype).to(DEV)
+    w = (_rand((cout, cin, 1), 812) / math.sqrt(cin)).to(dtype).to(DEV)
+    b = _rand((cout,), 813).to(DEV)
+    sc = (torch.rand((n, cin), generator=torch.Generator().manual_seed(814)) + 0.5).to(DEV) if pre else None
+    sh = _rand((n, cin), 815, scale=0.2).to(DEV) if pre else None
+    r = _rand((n, tokens, cout), 816).to(dtype).to(DEV) if res else None
+    with_vt = dtype == torch.bfloat16 and dh > 0 and tokens % 64 == 0
+
+    def run():
+        out = torch.empty((n, tokens, cout), dtype=dtype, device=DEV)
+        ws = None
+        if with_vt:
+            c = cout // 3
+            ws = ops.attention_workspace(out[..., :c], out[..., c:2 * c], out[..., 2 * c:], c // dh)
+        y = ops.conv(x, w, b, kernel=1, pre=None if not pre else (sc, sh), res=r, out=out, vt=None if ws is None else (ws, 2 * (cout // 3), dh))
+        assert bool(getattr(y, "_gm_vt_packed", False)) == (ws is not None)
+        return y.clone(), (None if ws is None else ws[: n * (cout // 3) * tokens * 2].clone())
+
+    try:
+        lib().gm_token_gemm_set_wide(0, 4)
+        narrow, vt_narrow = run()
+        lib().gm_token_gemm_set_wide(1, nb)
+        wide, vt_wide = run()
+    finally:
+        lib().gm_token_gemm_set_wide(-1, 0)
+    assert torch.equal(wide, narrow)
+    if vt_narrow is not None:
+        assert torch.equal(vt_wide, vt_narrow)
+    xa = x.float().cpu().double()
+    if pre:
+        xa = xa * sc.cpu().double()[:, None, :] + sh.cpu().double()[:, None, :]
+    want = xa @ w[..., 0].float().cpu().double().t() + b.cpu().double()
+    if res:
+        want = want + r.float().cpu().double()
+    _check(wide, want, dtype, "wide token GEMM", extra=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(16, 16, 700), (256, 32, 20000), (1024, 48, 5000), (300, 7, 3000), (8, 64, 0)], ids=lambda c: f"K{c[0]}-D{c[1]}-T{c[2]}")
 def test_vq_ema_stats_single_scan(case, dtype):
     """gm_vq_ema_stats (EMAQuantizer training update, vector_quantizer.py:166-169: `encodings_sum`, `dw`): per-range partial tables summed in range
