@@ -90,6 +90,7 @@ PROTOTYPES = {
     "gm_copy_channels": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp]),
     "gm_normal_bf16_from_bits": (C.c_int, [c_vp, c_vp, c_vp, c_ll, c_vp]),
     "gm_token_gemm_set_wide": (None, [C.c_int, C.c_int]),
+    "gm_attention_set_wave_groups": (None, [C.c_int]),
     "gm_nchw_to_nhwc": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_ll, c_vp]),
     "gm_nhwc_to_nchw": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_vp]),
     "gm_resample2x": (C.c_int, [c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -196,6 +197,8 @@ def lib() -> C.CDLL:
             handle.gm_conv_dma_set_persistent(int(os.environ["GM_CONV_DMA_GRID"]))
         if os.environ.get("GM_CONV_DMA_SKEW"):  # A/B of the one-time phase offset (gm_conv_dma_set_phase_skew): cycles, 0 off, -1 automatic
             handle.gm_conv_dma_set_phase_skew(int(os.environ["GM_CONV_DMA_SKEW"]))
+        if os.environ.get("GM_ATTN_WAVE_GROUPS"):  # A/B of the register-staged attention kernel's wave groups (gm_attention_set_wave_groups)
+            handle.gm_attention_set_wave_groups(int(os.environ["GM_ATTN_WAVE_GROUPS"]))
         if os.environ.get("GM_TOKEN_GEMM_WIDE") or os.environ.get("GM_TOKEN_GEMM_WIDE_NB"):  # A/B of the wide token GEMM: "0" off, else the row threshold; blocks per wave
             rows = int(os.environ.get("GM_TOKEN_GEMM_WIDE", "-1"))
             handle.gm_token_gemm_set_wide(rows, int(os.environ.get("GM_TOKEN_GEMM_WIDE_NB", "0")))

@@ -40,8 +40,11 @@ __device__ __forceinline__ uint4 load_row16(const T* base, long long ld, long lo
   return *reinterpret_cast<uint4*>(tmp);
 }
 
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
+// G = 2 (round 6): TWO groups of four waves per work-group share the 64 queries and deal the key tiles between them (group g takes tiles g, g + 2, ...), each with
+// its own K / V buffers; their softmax states meet in LDS at the end.  Eight waves per CU instead of four: one group's softmax and staging run under the other's
+// MFMAs (a 256-work-group grid -- 16 x 1024 queries -- has one work-group per CU), without the second launch a split over work-groups needs.
+template <typename T, int DH, int G>
+__global__ __launch_bounds__(256 * G) void attn_kernel(const GmAttnDesc p) {
   constexpr int VECW = AttnTraits<T>::VECW;
   constexpr int KT = AttnTraits<T>::KT;
   constexpr int KF = KT / 16;                      // key fragments per tile
@@ -52,10 +55,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
   constexpr int ROWB_V = IS_BF16 ? (KT * 2 + 16) : (DH * 4 + 16);  // bf16: V^T rows of KT keys; fp32: V rows of DH
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ldsK = smem;                              // [KT][ROWB_K]
-  char* ldsV = smem + (size_t)KT * ROWB_K;        // bf16: [DH][ROWB_V] (transposed), fp32: [KT][ROWB_V]
+  constexpr int GROUP_BYTES = KT * ROWB_K + (IS_BF16 ? DH * ROWB_V : KT * ROWB_V);
+  const int grp = G == 1 ? 0 : (int)(threadIdx.x >> 8);  // wave group (wave-uniform)
+  char* ldsK = smem + (size_t)grp * GROUP_BYTES;  // [KT][ROWB_K]
+  char* ldsV = ldsK + (size_t)KT * ROWB_K;        // bf16: [DH][ROWB_V] (transposed), fp32: [KT][ROWB_V]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // (within the group)
   const int l15 = lane & 15, qg = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
   const int q0 = blockIdx.x * 64 + wave * 16;
@@ -86,54 +91,91 @@ __global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
     const int last = min(p.Lk - 1, (int)blockIdx.x * 64 + 63 + (p.Lk - p.Lq));
     ntiles = max(1, min(ntiles, last / KT + 1));
   }
-  for (int tile = 0; tile < ntiles; ++tile) {
+  // ---- K / V staging, software-pipelined (round 6): tile t + 1 is REQUESTED into registers right after tile t has been committed to LDS, so its global-memory
+  // latency runs under tile t's MFMAs and softmax instead of in front of them (the loop used to be load -> wait -> barrier -> compute per 32 / 64 keys: 3.4 us per
+  // tile at 16 x 1024 x 1024 x 64 fp32, 110 us per attention block of BASELINE configs[0]).  Per thread: (KT * row chunks) / 256 16-byte vectors of K and as many
+  // of V (bf16: one 8 x 8 block of V, transposed at the commit).
+  constexpr int CHK = DH * (int)sizeof(T) / 16;            // 16-byte chunks per K row (fp32: and per V row)
+  constexpr int NKI = (KT * CHK + 255) / 256;              // K items per thread
+  constexpr int PB = KT / 8, DB = DH / 8;                  // bf16 V: 8-key x 8-channel blocks
+  constexpr int NVI = IS_BF16 ? (PB * DB + 255) / 256 : NKI;
+  uint4 kreg[NKI];
+  uint4 vreg[NVI][IS_BF16 ? 8 : 1];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int key0 = tile * KT;
-    __syncthreads();  // the previous tile's LDS reads are complete
-    // ---- stage K: [KT][DH] row-major --------------------------------------------------------------------------------
-    {
-      constexpr int CH = DH * (int)sizeof(T) / 16;  // 16-byte chunks per row
-      for (int item = tid; item < KT * CH; item += 256) {
-        const int row = item / CH, ch = item % CH;
-        const uint4 v = load_row16<T>(Kb, p.k_ld, key0 + row, key0 + row < p.Lk, ch * VECW, p.dh, kvec);
-        *reinterpret_cast<uint4*>(ldsK + (size_t)row * ROWB_K + ch * 16) = v;
-      }
+#pragma unroll
+    for (int it = 0; it < NKI; ++it) {
+      const int item = tid + it * 256;
+      const int row = item / CHK, ch = item % CHK;
+      kreg[it] = (KT * CHK % 256 == 0 || item < KT * CHK) ? load_row16<T>(Kb, p.k_ld, key0 + row, key0 + row < p.Lk, ch * VECW, p.dh, kvec) : make_uint4(0, 0, 0, 0);
     }
-    // ---- stage V ----------------------------------------------------------------------------------------------------
     if constexpr (IS_BF16) {
-      // 8 keys x 8 channels per item, transposed in registers.  Key order inside a V^T row: position
+      // 8 keys x 8 channels per item, transposed in registers at the commit.  Key order inside a V^T row: position
       // pos = s*32 + qq*8 + half*4 + r  <->  key = (2s+half)*16 + qq*4 + r, i.e. exactly the 8 keys lane-group qq
       // feeds into k-step s of the PV MFMA are contiguous (one ds_read_b128).
-      constexpr int PB = KT / 8, DB = DH / 8;
-      for (int item = tid; item < PB * DB; item += 256) {
+#pragma unroll
+      for (int it = 0; it < NVI; ++it) {
+        const int item = tid + it * 256;
         const int pb = item % PB, db = item / PB;
-        const int s = pb >> 2, qq = pb & 3;
-        uint4 rows[8];
+        const int sq = pb >> 2, qq = pb & 3;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int key = key0 + (2 * s + (j >> 2)) * 16 + qq * 4 + (j & 3);
-          rows[j] = load_row16<T>(Vb, p.v_ld, key, key < p.Lk, db * 8, p.dh, vvec);
-        }
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          uint32_t w[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const uint32_t a = reinterpret_cast<const uint32_t*>(&rows[2 * c])[d >> 1];
-            const uint32_t bq = reinterpret_cast<const uint32_t*>(&rows[2 * c + 1])[d >> 1];
-            w[c] = (d & 1) ? ((a >> 16) | (bq & 0xffff0000u)) : ((a & 0xffffu) | (bq << 16));
-          }
-          *reinterpret_cast<uint4*>(ldsV + (size_t)(db * 8 + d) * ROWB_V + pb * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+          const int key = key0 + (2 * sq + (j >> 2)) * 16 + qq * 4 + (j & 3);
+          vreg[it][j] = item < PB * DB ? load_row16<T>(Vb, p.v_ld, key, key < p.Lk, db * 8, p.dh, vvec) : make_uint4(0, 0, 0, 0);
         }
       }
     } else {
-      constexpr int CH = DH * 4 / 16;
-      for (int item = tid; item < KT * CH; item += 256) {
-        const int row = item / CH, ch = item % CH;
-        const uint4 v = load_row16<T>(Vb, p.v_ld, key0 + row, key0 + row < p.Lk, ch * VECW, p.dh, vvec);
-        *reinterpret_cast<uint4*>(ldsV + (size_t)row * ROWB_V + ch * 16) = v;
+#pragma unroll
+      for (int it = 0; it < NVI; ++it) {
+        const int item = tid + it * 256;
+        const int row = item / CHK, ch = item % CHK;
+        vreg[it][0] = (KT * CHK % 256 == 0 || item < KT * CHK) ? load_row16<T>(Vb, p.v_ld, key0 + row, key0 + row < p.Lk, ch * VECW, p.dh, vvec) : make_uint4(0, 0, 0, 0);
       }
     }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NKI; ++it) {
+      const int item = tid + it * 256;
+      if (KT * CHK % 256 == 0 || item < KT * CHK) *reinterpret_cast<uint4*>(ldsK + (size_t)(item / CHK) * ROWB_K + (item % CHK) * 16) = kreg[it];
+    }
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int it = 0; it < NVI; ++it) {
+        const int item = tid + it * 256;
+        if (item < PB * DB) {
+          const int pb = item % PB, db = item / PB;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            uint32_t w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const uint32_t a = reinterpret_cast<const uint32_t*>(&vreg[it][2 * c])[d >> 1];
+              const uint32_t bq = reinterpret_cast<const uint32_t*>(&vreg[it][2 * c + 1])[d >> 1];
+              w[c] = (d & 1) ? ((a >> 16) | (bq & 0xffff0000u)) : ((a & 0xffffu) | (bq << 16));
+            }
+            *reinterpret_cast<uint4*>(ldsV + (size_t)(db * 8 + d) * ROWB_V + pb * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NVI; ++it) {
+        const int item = tid + it * 256;
+        if (KT * CHK % 256 == 0 || item < KT * CHK) *reinterpret_cast<uint4*>(ldsV + (size_t)(item / CHK) * ROWB_V + (item % CHK) * 16) = vreg[it][0];
+      }
+    }
+  };
+  if (grp < ntiles) fetch(grp);
+  for (int round = 0; round * G < ntiles; ++round) {
+    const int tile = round * G + grp;  // this group's tile of the round; the last round may have none for group 1 (it still meets the barriers)
+    const bool live = tile < ntiles;   // (group-uniform)
+    const int key0 = tile * KT;
+    __syncthreads();  // the previous tile's LDS reads are complete
+    if (live) commit();
     __syncthreads();
+    if (!live) continue;
+    if (tile + G < ntiles) fetch(tile + G);  // (group-uniform) in flight under this tile's arithmetic
 
     // ---- S^T = K Q^T ------------------------------------------------------------------------------------------------
     f32x4_t sacc[KF];
@@ -169,13 +211,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = IS_BF16 ? __expf(m_run - m_new) : expf(m_run - m_new);
+    // (a group whose first tile is entirely masked for this query -- causal, G = 2 -- has no maximum yet: exponents against 0 then, every weight e^(-inf) = 0)
+    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = IS_BF16 ? __expf(m_run - m_ref) : expf(m_run - m_ref);
     float psum = 0.f;
 #pragma unroll
     for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = IS_BF16 ? __expf(sacc[kf][r] - m_new) : expf(sacc[kf][r] - m_new);
+        const float pv = IS_BF16 ? __expf(sacc[kf][r] - m_ref) : expf(sacc[kf][r] - m_ref);
         sacc[kf][r] = pv;
         psum += pv;
       }
@@ -219,6 +263,29 @@ __global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
     }
   }
 
+  // ---- G = 2: group 1 hands its state (running maximum, this lane's partial sum, un-normalised output) to the same lane of group 0 through LDS ----------------
+  if constexpr (G == 2) {
+    __syncthreads();  // every tile has been read: the operand buffers are free
+    float* xch = reinterpret_cast<float*>(smem) + (size_t)tid * (2 + DF * 4);
+    if (grp == 1) {
+      xch[0] = m_run; xch[1] = l_run;
+#pragma unroll
+      for (int d = 0; d < DF; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[2 + d * 4 + r] = oacc[d][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float m1 = xch[0], l1 = xch[1];
+    const float M = fmaxf(m_run, m1);  // (group 0 always has a tile: finite)
+    const float a0 = IS_BF16 ? __expf(m_run - M) : expf(m_run - M), a1 = IS_BF16 ? __expf(m1 - M) : expf(m1 - M);  // a group without a tile: e^(-inf) = 0
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int d = 0; d < DF; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[d][r] = oacc[d][r] * a0 + xch[2 + d * 4 + r] * a1;
+  }
+
   // ---- finish: 1/l, residual, store ------------------------------------------------------------------------------------
   float l_tot = l_run + __shfl_xor(l_run, 16, 64);
   l_tot += __shfl_xor(l_tot, 32, 64);
@@ -240,21 +307,35 @@ __global__ __launch_bounds__(256) void attn_kernel(const GmAttnDesc p) {
   }
 }
 
-template <typename T, int DH>
-static int launch_attn(const GmAttnDesc& d, hipStream_t st) {
+template <typename T, int DH, int G>
+static int launch_attn_g(const GmAttnDesc& d, hipStream_t st) {
   constexpr int KT = AttnTraits<T>::KT;
   constexpr bool IS_BF16 = sizeof(T) == 2;
-  constexpr size_t smem = (size_t)KT * (DH * sizeof(T) + 16) + (IS_BF16 ? (size_t)DH * (KT * 2 + 16) : (size_t)KT * (DH * 4 + 16));
+  constexpr size_t group = (size_t)KT * (DH * sizeof(T) + 16) + (IS_BF16 ? (size_t)DH * (KT * 2 + 16) : (size_t)KT * (DH * 4 + 16));
+  constexpr size_t xch = G == 2 ? (size_t)256 * (2 + DH / 16 * 4) * 4 : 0;  // the hand-over of group 1's state overlays the operand buffers
+  constexpr size_t smem = G * group > xch ? G * group : xch;
+  static_assert(smem <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = attn_kernel<T, DH>;
+  auto kern = attn_kernel<T, DH, G>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) (void)hipGetLastError();
     attr_set = true;
   }
   dim3 grid((d.Lq + 63) / 64, d.B * d.H);
-  kern<<<grid, 256, smem, st>>>(d);
+  kern<<<grid, 256 * G, smem, st>>>(d);
   return 0;
+}
+
+// two wave groups once a work-group has at least four key tiles to deal (process-wide override for measurements: gm_attention_set_wave_groups)
+static int gm_attn_wave_groups = 0;  // 0 = by key count
+extern "C" void gm_attention_set_wave_groups(int g) { gm_attn_wave_groups = (g == 1 || g == 2) ? g : 0; }
+template <typename T, int DH>
+static int launch_attn(const GmAttnDesc& d, hipStream_t st) {
+  constexpr int KT = AttnTraits<T>::KT;
+  const int g = gm_attn_wave_groups ? gm_attn_wave_groups : ((d.Lk + KT - 1) / KT >= 4 ? 2 : 1);
+  if constexpr (sizeof(T) == 4 && DH == 256) return launch_attn_g<T, DH, 1>(d, st);  // (two groups = 256 registers per wave: the fp32 kernel at head dim 256 would spill 81)
+  else return g == 2 ? launch_attn_g<T, DH, 2>(d, st) : launch_attn_g<T, DH, 1>(d, st);
 }
 
 template <typename T>

@@ -45,6 +45,9 @@ typedef struct GmStepParams {
  * x0 and noise may be NULL. */
 int gm_sched_step(const void* sample, const void* model_output, const void* noise, void* prev, void* x0,
                   long long batch, long long inner, long long mo_bstride, int dtype, const GmStepParams* p, void* stream);
+/* The register-staged attention kernel (fp32; bf16 outside the LDS-DMA kernel's geometries: causal, few keys, head dim 32) deals the key tiles of a work-group to
+ * g = 1 or 2 groups of four waves; anything else = two groups from four key tiles on (the default).  Process-wide, for measurements and tests. */
+void gm_attention_set_wave_groups(int g);
 /* The affine token GEMMs (gm_linear_rows_affine / _vt, gm_linear_rows) over at least `min_rows` rows run with a wave owning 16 rows x nb * 16 output channels
  * (nb = 2, 3 or 4, anything else = chosen by the row count; small_ops.hip: token_gemm_wide_kernel) instead of one 16-channel block per wave.  min_rows 0 = never,
  * < 0 = the default (2048): a process-wide switch for measurements and tests; results are bit-identical either way. */
