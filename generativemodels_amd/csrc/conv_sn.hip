@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
 
   // ---- PRE from statistics: scale[c] = rstd_g * gamma[c], shift[c] = beta[c] - mean_g * rstd_g * gamma[c] for every input channel, from the per-tile partials of
   // the input's producer(s), under the flight of the first requests.  The SHORT-TABLE order of gm_gn_finalize_channels (groupnorm.hip: gn_short_* -- shared
-  // helpers, so the two are bit-identical): a thread owns a channel and adds its S <= 64 rows in row order (fp64, eight loads in flight); a group is the sum of its
+  // helpers, so the two are bit-identical): a thread owns a channel and adds its S <= GN_SHORT_MAX_ROWS rows in row order (fp64, eight loads in flight); a group is the sum of its
   // channels in channel order.  A group may straddle the two sources of a virtual concatenation.
   if (PRE && from_stats) {
     float* tab = reinterpret_cast<float*>(smem + AFF_OFF);                                   // [scale[Cin] | shift[Cin]]
@@ -420,9 +420,9 @@ extern "C" int gm_conv_sn_eligible(const GmConvDesc* d) {
            (reinterpret_cast<uintptr_t>(d->pre_shift) & 15) == 0 && (d->Cin % 4) == 0) ||
           // the statistics form: short tables (their rows all sit in one wave of the fold), whole groups, the table over all input channels in LDS
           (d->pre_stats[0] != nullptr && d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_groups > 0 && d->Cin % d->pre_groups == 0 &&
-           d->Cin <= sn::Geom<3>::MAX_CIN_TAB && d->pre_S[0] >= 1 && d->pre_S[0] <= 64 && d->pre_C[0] > 0 &&
+           d->Cin <= sn::Geom<3>::MAX_CIN_TAB && d->pre_S[0] >= 1 && d->pre_S[0] <= GN_SHORT_MAX_ROWS && d->pre_C[0] > 0 &&
            ((d->pre_stats[1] == nullptr && d->pre_C[1] == 0 && d->pre_C[0] == d->Cin) ||
-            (d->pre_stats[1] != nullptr && d->pre_S[1] >= 1 && d->pre_S[1] <= 64 && d->pre_C[1] > 0 && d->pre_C[0] + d->pre_C[1] == d->Cin)) &&
+            (d->pre_stats[1] != nullptr && d->pre_S[1] >= 1 && d->pre_S[1] <= GN_SHORT_MAX_ROWS && d->pre_C[1] > 0 && d->pre_C[0] + d->pre_C[1] == d->Cin)) &&
            (reinterpret_cast<uintptr_t>(d->pre_stats[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->pre_stats[1]) & 15) == 0 && d->in_mode == 0)) &&
          (d->x2 == nullptr || (d->cin_split > 0 && d->cin_split < d->Cin && d->cin_split % bk == 0 && d->x2_ld % vecw == 0 &&
                                (reinterpret_cast<uintptr_t>(d->x2) & 15) == 0)) &&

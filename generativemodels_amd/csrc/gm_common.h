@@ -70,9 +70,10 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// ---- GroupNorm finalisation over SHORT statistic tables (every source S <= 64 rows of [N][C_i][2] fp64 partials) -- shared by gm_gn_finalize_channels
+// ---- GroupNorm finalisation over SHORT statistic tables (every source S <= GN_SHORT_MAX_ROWS rows of [N][C_i][2] fp64 partials) -- shared by gm_gn_finalize_channels
 // (groupnorm.hip) and the consumer-side prologue of conv_sn.hip, which must agree bit for bit: a channel's partials are added in ROW order, a group is the sum
 // of its channels in CHANNEL order, everything in fp64.  Channel c of the concatenation (C0 + C1 channels) lives in source 0 when c < C0.
+#define GN_SHORT_MAX_ROWS 128  // (64 until the second half of round 6: the 32^3 level of a latent UNet leaves 128-row tables -- one partial per 256-voxel tile)
 __device__ __forceinline__ double2 gn_short_channel_sum(const double* s0, int S0, int C0, const double* s1, int S1, int C1, int N, int n, int c) {
   const bool first = c < C0;
   const double* src = first ? s0 + ((long long)n * C0 + c) * 2 : s1 + ((long long)n * C1 + (c - C0)) * 2;

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void gn_finalize_channels_kernel(const double*
   }
 }
 
-// SHORT tables (every source S <= 64): a thread owns a channel of the group and adds its rows in row order; thread 0 adds the channels in channel order -- the
+// SHORT tables (every source S <= GN_SHORT_MAX_ROWS): a thread owns a channel of the group and adds its rows in row order; thread 0 adds the channels in channel order -- the
 // order conv_sn.hip's consumer-side prologue reproduces (gm_common.h: gn_short_*), so that a norm finalised there and one finalised here agree bit for bit.
 __global__ __launch_bounds__(256) void gn_finalize_channels_short_kernel(const double* __restrict__ s0, int S0, int C0, const double* __restrict__ s1, int S1, int C1,
                                                                         int N, int G, long long V, float eps, const float* __restrict__ gamma,
@@ -365,7 +365,7 @@ extern "C" int gm_gn_finalize_channels(const double* stats0, int S0, int C0, con
   GM_REQUIRE(G > 0 && (C0 + C1) % G == 0, "channels must be divisible by groups");
   if (N == 0) return 0;
   const int cpg = (C0 + C1) / G;
-  if (S0 <= 64 && (C1 == 0 || S1 <= 64) && cpg <= 4096)  // short tables: the order the consumer-side finalisation shares (ops.GnRecipe)
+  if (S0 <= GN_SHORT_MAX_ROWS && (C1 == 0 || S1 <= GN_SHORT_MAX_ROWS) && cpg <= 4096)  // short tables: the order the consumer-side finalisation shares (ops.GnRecipe)
     gn_finalize_channels_short_kernel<<<N * G, 256, (size_t)(2 * cpg + 2) * sizeof(double), (hipStream_t)stream>>>(stats0, S0, C0, stats1, S1, C1, N, G, V, eps, gamma, beta,
                                                                                                                scale, shift);
   else

@@ -648,7 +648,7 @@ def _fresh_channel_stats(x: torch.Tensor) -> torch.Tensor:
 
 
 GN_IN_CONSUMER = os.environ.get("GM_GN_IN_CONSUMER", "1") != "0"  # short statistic tables: the fold + finalisation in the consumer convolution's prologue (cfg 24 / 25)
-GN_IN_CONSUMER_MAX_ROWS = 64
+GN_IN_CONSUMER_MAX_ROWS = int(os.environ.get("GM_GN_IN_CONSUMER_MAX_ROWS", "128"))  # = GN_SHORT_MAX_ROWS of csrc/gm_common.h (64 until the 32^3 level's 128-row tables were measured)
 
 
 class GnRecipe:
