@@ -22,6 +22,11 @@ class GmStepParams(C.Structure):
                 ("min_log", C.c_float), ("max_log", C.c_float)]
 
 
+class GmGnTables(C.Structure):
+    _fields_ = [("stats", C.c_void_p * 2), ("S", C.c_int * 2), ("C", C.c_int * 2), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+                ("groups", C.c_int)]
+
+
 class GmKlParams(C.Structure):
     _fields_ = [("pred_type", C.c_int), ("c_sa", C.c_float), ("c_sb", C.c_float), ("clip", C.c_int), ("k0", C.c_float),
                 ("k1", C.c_float), ("m0", C.c_float), ("m1", C.c_float), ("t0", C.c_int), ("s", C.c_float), ("e", C.c_float),
@@ -129,6 +134,8 @@ PROTOTYPES = {
     "gm_linear_rows": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_linear_rows_affine_vt": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_vp, c_vp, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, C.c_int,
                                            C.c_int, C.c_int, c_vp]),
+    "gm_linear_rows_gn": (C.c_int, [c_vp, c_ll, C.POINTER(GmGnTables), C.c_int, C.c_int, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "gm_linear_rows_affine": (C.c_int, [c_vp, c_ll, c_vp, c_vp, c_ll, C.c_int, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, c_vp]),
     "gm_decode_scratch_bytes": (c_ll, [C.c_int, C.c_int, C.c_int, C.c_int]),

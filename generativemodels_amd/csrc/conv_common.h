@@ -2,6 +2,12 @@
 #pragma once
 #include "gm_common.h"
 
+// include/gm_amd.h: GmGnTables (the GroupNorm of a token GEMM's input as the statistic tables of its producers, gm_linear_rows_gn)
+struct GmGnTables {
+  const double* stats[2]; int S[2]; int C[2];
+  const float* gamma; const float* beta; float eps; int groups;
+};
+
 struct GmConvDesc {
   const void* x; long long x_ld;
   const void* w;                  // packed by gm_pack_conv_weight: [chunk][tap][Cout_pad][BK]

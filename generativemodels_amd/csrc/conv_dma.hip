@@ -1168,9 +1168,12 @@ extern "C" int gm_conv_dma_eligible(const GmConvDesc* d) {
          (d->in_mode == 0 || (d->in_mode == 1 && s == 1)) && d->Cin % bk == 0 && d->x_ld % vecw == 0 &&
          (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 &&
          // fused GroupNorm-apply + SiLU / ReLU prologue: applied in LDS by the stride-1 variants (scale and shift together, fp32 [N][Cin])
-         ((d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_act == 0) ||
-          (s == 1 && d->pre_scale != nullptr && d->pre_shift != nullptr && (reinterpret_cast<uintptr_t>(d->pre_scale) & 15) == 0 &&
-           (reinterpret_cast<uintptr_t>(d->pre_shift) & 15) == 0 && (d->Cin % 4) == 0)) &&
+         ((d->pre_stats[0] == nullptr &&
+           ((d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_act == 0) ||
+            (s == 1 && d->pre_scale != nullptr && d->pre_shift != nullptr && (reinterpret_cast<uintptr_t>(d->pre_scale) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(d->pre_shift) & 15) == 0 && (d->Cin % 4) == 0))) ||
+          // ... or from the input's statistic tables (GmConvDesc.pre_stats): the K slices of a split launch only (conv_sk.hip finalises the norm in its prologue)
+          (d->pre_stats[0] != nullptr && d->cfg == 11 && gm_conv_sk_eligible(d))) &&
          // second input source (virtual channel concatenation): same geometry, chunk-aligned split
          (d->x2 == nullptr || (d->cin_split > 0 && d->cin_split < d->Cin && d->cin_split % bk == 0 && d->x2_ld % vecw == 0 &&
                                (reinterpret_cast<uintptr_t>(d->x2) & 15) == 0)) &&

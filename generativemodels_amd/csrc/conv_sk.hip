@@ -40,7 +40,11 @@ constexpr int PD = 6, PH = 6, PW = 18, PLANE = 112, PROWS = PD * PLANE, PPIECES 
 constexpr int WROWS = G * BN, WPW = 2;
 constexpr int PATCH_BYTES = PROWS * DMA_ROWB, WBUF_BYTES = WROWS * DMA_ROWB;
 constexpr int AFF_OFF = PATCH_BYTES + NGROUPS * WBUF_BYTES, AFF_WAVE = 256;
-constexpr int LDS_BYTES = AFF_OFF + NW * AFF_WAVE;  // 43 008 + 110 592 + 2 048 = 155 648
+// PRE from the input's statistic tables (GmConvDesc.pre_stats: the GroupNorm finalised HERE, conv_sn.hip's recipe, round 6): behind the per-wave copies, the (scale |
+// shift) of THIS SLICE's channels (<= TAB_CH) and the fp64 channel sums of the groups they belong to (<= COVER_CH channels: the slice + the rest of its first and last group)
+constexpr int TAB_CH = 128, COVER_CH = 256;
+constexpr int TAB_OFF = AFF_OFF + NW * AFF_WAVE, CSUM_OFF = TAB_OFF + 2 * TAB_CH * 4;
+constexpr int LDS_BYTES = CSUM_OFF + COVER_CH * 16;  // 43 008 + 110 592 + 2 048 + 1 024 + 4 096 = 160 768
 // request order of a chunk, per wave: panels 0 .. FIRST-1 (they need the channel block and the K slice of the work item only), [scale | shift],
 // the patch pieces (they need the whole placement: ~3 k cycles of index arithmetic that now run under the first panels' flight), panels FIRST .. 8
 constexpr int FIRST = 3;
@@ -133,9 +137,10 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
   const long long xrowb = p.x_ld * (long long)sizeof(T), x2rowb = p.x2_ld * (long long)sizeof(T);
   const int nchunks0 = p.x2 ? p.cin_split / BK : nchunks;
 
+  const bool from_stats = PRE && p.pre_stats[0] != nullptr;  // (work-group uniform)
   // [scale | shift] (PRE) and the patch pieces of a chunk
   auto issue_patch = [&](int chunk) __attribute__((always_inline)) {
-    if (PRE) {
+    if (PRE && !from_stats) {
       const int nl = BK / 4;  // lanes 0 .. nl - 1 fetch the chunk's scale, nl .. 2 nl - 1 its shift (16 bytes each) into this wave's own copy
       if (lane < 2 * nl) {
         const float* src = (lane < nl ? p.pre_scale : p.pre_shift) + (long long)n * p.Cin + chunk * BK + 4 * (lane < nl ? lane : lane - nl);
@@ -156,12 +161,14 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
     }
   };
   // GroupNorm-apply + activation IN LDS on this wave's own landed pieces (conv_dma.hip: transform_patch; same arithmetic and rounding as gm_gn_apply)
-  auto transform_patch = [&]() __attribute__((always_inline)) {
+  auto transform_patch = [&](int chunk) __attribute__((always_inline)) {
     float sc[VECW], sh[VECW];
-    const float* aff = reinterpret_cast<const float*>(smem + AFF_OFF + wave * AFF_WAVE);
+    // the wave's own copy of the chunk's (scale | shift), or the slice's table built from the statistics
+    const float* aff = from_stats ? reinterpret_cast<const float*>(smem + TAB_OFF) + (chunk - c_begin) * BK : reinterpret_cast<const float*>(smem + AFF_OFF + wave * AFF_WAVE);
+    const int shoff = from_stats ? TAB_CH : BK;
 #pragma unroll
     for (int i = 0; i < VECW; i += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(aff + (lane & 3) * VECW + i), c = *reinterpret_cast<const float4*>(aff + BK + (lane & 3) * VECW + i);
+      const float4 a = *reinterpret_cast<const float4*>(aff + (lane & 3) * VECW + i), c = *reinterpret_cast<const float4*>(aff + shoff + (lane & 3) * VECW + i);
       sc[i] = a.x; sc[i + 1] = a.y; sc[i + 2] = a.z; sc[i + 3] = a.w;
       sh[i] = c.x; sh[i + 1] = c.y; sh[i + 2] = c.z; sh[i + 3] = c.w;
     }
@@ -185,6 +192,32 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
     issue_panels(c_begin, FIRST, NGROUPS);
   }
   SK_STAMP(2);
+
+  // ---- PRE from statistics (conv_sn.hip's recipe, the shared gn_short_* order: bit-identical to gm_gn_finalize_channels' short form): the channel sums of the groups
+  // this slice's channels belong to, then (scale, shift) of the slice's channels -- under the flight of the chunk's requests ------------------------------------------
+  if (PRE && from_stats && c_begin < c_end) {
+    float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
+    double* csum = reinterpret_cast<double*>(smem + CSUM_OFF);
+    const int cpg = p.Cin / p.pre_groups;
+    const int ch0 = c_begin * BK, ch1 = c_end * BK;
+    const int cov0 = (ch0 / cpg) * cpg, cov1 = min(p.Cin, ((ch1 - 1) / cpg + 1) * cpg);  // whole groups (host-checked: cov1 - cov0 <= COVER_CH)
+    const long long V = (long long)p.Ds * p.Hs * p.Ws;
+    for (int c = cov0 + tid; c < cov1; c += 64 * NW) {
+      const double2 v = gn_short_channel_sum(p.pre_stats[0], p.pre_S[0], p.pre_C[0], p.pre_stats[1], p.pre_S[1], p.pre_C[1], p.N, n, c);
+      csum[2 * (c - cov0)] = v.x; csum[2 * (c - cov0) + 1] = v.y;
+    }
+    __syncthreads();
+    for (int c = ch0 + tid; c < ch1; c += 64 * NW) {
+      const int g = c / cpg;
+      double a = 0.0, b2 = 0.0;
+      for (int j = 0; j < cpg; ++j) { a += csum[2 * (g * cpg + j - cov0)]; b2 += csum[2 * (g * cpg + j - cov0) + 1]; }
+      float sc1, sh1;
+      gn_short_scale_shift(a, b2, cpg, V, p.pre_eps, p.pre_gamma ? p.pre_gamma[c] : 1.f, p.pre_beta ? p.pre_beta[c] : 0.f, sc1, sh1);
+      tab[c - ch0] = sc1;
+      tab[TAB_CH + (c - ch0)] = sh1;
+    }
+    __syncthreads();
+  }
 
   // ---- operand read addresses (conv_dma.hip: XADDR / WADDR) -----------------------------------------------------------------------------------
   int xa[KS];
@@ -223,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
     // the patch, this wave's scale / shift copy and panels 0 .. FIRST-1 have landed when only the AFTER_PATCH later panel instructions are in flight
     dma_wait<AFTER_PATCH>();
     if (chunk == c_begin) SK_STAMP(3);
-    if (PRE) transform_patch();
+    if (PRE) transform_patch(chunk);
     if (chunk == c_begin) SK_STAMP(4);
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
@@ -349,6 +382,11 @@ __global__ __launch_bounds__(512, 2) void conv_sk_kernel(const GmConvDesc p) {
 #undef SK_XADDR
 #undef SK_WADDR
 
+static int sk_slice_channels(const GmConvDesc* d) {  // channels of the longest K slice
+  const int bk = d->dtype == GM_F32 ? 16 : 32, nchunks = d->Cin / bk;
+  return ((nchunks + d->ksplit - 1) / d->ksplit) * bk;
+}
+
 // process-wide switch (A/B measurements and the bitwise test against conv_dma.hip's slices); results do not depend on it
 static int g_sk_enabled = 1;
 extern "C" void gm_conv_sk_set_enabled(int on) { g_sk_enabled = on; }
@@ -357,7 +395,14 @@ extern "C" void gm_conv_sk_set_enabled(int on) { g_sk_enabled = on; }
 extern "C" int gm_conv_sk_eligible(const GmConvDesc* d) {
   return g_sk_enabled && d->cfg == 11 && d->ksplit > 1 && d->kpartial != nullptr && d->in_mode == 0 && d->kd == 3 && d->kh == 3 && d->kw == 3 &&
          d->sd == 1 && d->sh == 1 && d->sw == 1 && d->ltd == 2 && d->lth == 2 && d->ltw == 4 && (d->dtype == GM_F32 || d->dtype == GM_BF16) &&
-         (d->pre_scale == nullptr || d->pre_shift != nullptr);
+         ((d->pre_stats[0] == nullptr && (d->pre_scale == nullptr || d->pre_shift != nullptr)) ||
+          // the statistics form: short tables, whole groups, a slice's channels and their groups within the LDS tables
+          (d->pre_stats[0] != nullptr && d->pre_scale == nullptr && d->pre_shift == nullptr && d->pre_groups > 0 && d->Cin % d->pre_groups == 0 &&
+           d->pre_S[0] >= 1 && d->pre_S[0] <= GN_SHORT_MAX_ROWS && d->pre_C[0] > 0 &&
+           ((d->pre_stats[1] == nullptr && d->pre_C[1] == 0 && d->pre_C[0] == d->Cin) ||
+            (d->pre_stats[1] != nullptr && d->pre_S[1] >= 1 && d->pre_S[1] <= GN_SHORT_MAX_ROWS && d->pre_C[1] > 0 && d->pre_C[0] + d->pre_C[1] == d->Cin)) &&
+           (reinterpret_cast<uintptr_t>(d->pre_stats[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->pre_stats[1]) & 15) == 0 &&
+           sk_slice_channels(d) <= sk::TAB_CH && sk_slice_channels(d) + 2 * (d->Cin / d->pre_groups) <= sk::COVER_CH));
 }
 
 template <typename T, bool PRE>
@@ -374,7 +419,7 @@ static void launch_sk(const GmConvDesc& d, unsigned nblocks, hipStream_t st) {
 
 extern "C" int gm_conv_sk_launch(const GmConvDesc* dp, unsigned nblocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const bool pre = dp->pre_scale != nullptr;
+  const bool pre = dp->pre_scale != nullptr || dp->pre_stats[0] != nullptr;
   if (dp->dtype == GM_F32) { if (pre) launch_sk<float, true>(*dp, nblocks, st); else launch_sk<float, false>(*dp, nblocks, st); return 0; }
   if (dp->dtype == GM_BF16) { if (pre) launch_sk<bf16_raw, true>(*dp, nblocks, st); else launch_sk<bf16_raw, false>(*dp, nblocks, st); return 0; }
   return -2;

@@ -23,6 +23,9 @@ struct LinearRowsExtra {
   // transposed, key-permuted image VT[sample * H + head][channel][position] the LDS-DMA attention kernel consumes (attention_dma.hip:
   // vt_pack_kernel's layout; rows_per_sample = tokens per sample = the image's row pitch, a multiple of 64): no separate pack launch
   void* vt; int vt_c0; int vt_dh;
+  // token_gemm_wide_kernel<.., GN = true>: the per-sample GroupNorm of x given as the statistic tables of its producer(s) -- finalised in the kernel's prologue
+  // (gm_linear_rows_gn; the shared short-table order of gm_common.h: bit-identical to gm_gn_finalize_channels + the (scale, shift) form)
+  const double* gn_stats[2]; int gn_S[2]; int gn_C[2]; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_groups; int gn_N;
 };
 
 // One channel of the split-KV single-query attention, merged from its GM_DECODE_KV_SPLITS partials in range order.  Workspace =
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const T* __restrict__ 
 // of a work-group take four consecutive row groups (the weight fragments they share meet in the CU's L1), and a lane stores its four consecutive channels as
 // one vector.  Same accumulation order per output (K chunks in order, one MFMA each) as linear_rows_kernel: bit-identical results.  C_in a multiple of the MFMA
 // K step; affine prologue, pre-/post-activation, residual and the V^T image as there.
-template <typename T, int NB>
+template <typename T, int NB, bool GN>
 __global__ __launch_bounds__(256) void token_gemm_wide_kernel(const T* __restrict__ x, long long x_ld, const T* __restrict__ w, const float* __restrict__ bias,
                                                              const T* __restrict__ res, long long res_ld, T* __restrict__ y, long long y_ld, int rows, int cin,
                                                              int cout, int pre_act, int post_act, LinearRowsExtra ex) {
@@ -203,6 +206,29 @@ __global__ __launch_bounds__(256) void token_gemm_wide_kernel(const T* __restric
   const int cout_pad = (cout + 15) & ~15;
   const int co0 = blockIdx.x * (16 * NB);
   const int r0 = (blockIdx.y * 4 + wave) * 16;
+  // ---- GN: (scale | shift) of the work-group's sample over all input channels, from the statistic tables (every thread takes part: before any wave leaves) -----
+  extern __shared__ __attribute__((aligned(16))) char gn_smem[];  // [scale[cin] | shift[cin]] fp32, [cin] fp64 (sum, sum of squares)
+  if constexpr (GN) {
+    float* tab = reinterpret_cast<float*>(gn_smem);
+    double* csum = reinterpret_cast<double*>(gn_smem + 2 * (size_t)cin * 4);
+    const int n = (blockIdx.y * 64) / ex.rows_per_sample;  // host: rows_per_sample % 64 == 0 -- one sample per work-group
+    const int cpg = cin / ex.gn_groups;
+    for (int c = threadIdx.x; c < cin; c += 256) {
+      const double2 v = gn_short_channel_sum(ex.gn_stats[0], ex.gn_S[0], ex.gn_C[0], ex.gn_stats[1], ex.gn_S[1], ex.gn_C[1], ex.gn_N, n, c);
+      csum[2 * c] = v.x; csum[2 * c + 1] = v.y;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cin; c += 256) {
+      const int g = c / cpg;
+      double a = 0.0, b2 = 0.0;
+      for (int j = 0; j < cpg; ++j) { a += csum[2 * (g * cpg + j)]; b2 += csum[2 * (g * cpg + j) + 1]; }
+      float sc1, sh1;
+      gn_short_scale_shift(a, b2, cpg, (long long)ex.rows_per_sample, ex.gn_eps, ex.gn_gamma ? ex.gn_gamma[c] : 1.f, ex.gn_beta ? ex.gn_beta[c] : 0.f, sc1, sh1);
+      tab[c] = sc1;
+      tab[cin + c] = sh1;
+    }
+    __syncthreads();
+  }
   if (r0 >= rows) return;  // wave-uniform
   const int row = r0 + l15;
   const bool row_ok = row < rows;
@@ -246,7 +272,15 @@ __global__ __launch_bounds__(256) void token_gemm_wide_kernel(const T* __restric
       xf[u] = *reinterpret_cast<const uint4*>(xrow + c * BK);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) wf[u][nb] = *reinterpret_cast<const uint4*>(wrow + ((long long)c * cout_pad + wblk[nb]) * BK);
-      if (ex.pre_scale) {  // (uniform)
+      if (GN) {
+        const float* tab = reinterpret_cast<const float*>(gn_smem) + c * BK + q * VECW;
+#pragma unroll
+        for (int i = 0; i < VECW; i += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(tab + i), b2 = *reinterpret_cast<const float4*>(tab + cin + i);
+          asc[u][i] = a.x; asc[u][i + 1] = a.y; asc[u][i + 2] = a.z; asc[u][i + 3] = a.w;
+          ash[u][i] = b2.x; ash[u][i + 1] = b2.y; ash[u][i + 2] = b2.z; ash[u][i + 3] = b2.w;
+        }
+      } else if (ex.pre_scale) {  // (uniform)
 #pragma unroll
         for (int i = 0; i < VECW; i += 4) {
           const float4 a = *reinterpret_cast<const float4*>(ex.pre_scale + aoff + c * BK + i), b2 = *reinterpret_cast<const float4*>(ex.pre_shift + aoff + c * BK + i);
@@ -259,10 +293,10 @@ __global__ __launch_bounds__(256) void token_gemm_wide_kernel(const T* __restric
     for (int u = 0; u < U; ++u) {
       if (c0 + u >= nchunks) break;
       uint4 b = row_ok ? xf[u] : make_uint4(0u, 0u, 0u, 0u);
-      if (pre_act || ex.pre_scale) {
+      if (pre_act || ex.pre_scale || GN) {
         float v[VECW];
         Vec16<T>::unpack(b, v);
-        if (ex.pre_scale) {
+        if (ex.pre_scale || GN) {
 #pragma unroll
           for (int i = 0; i < VECW; ++i) v[i] = row_ok ? v[i] * asc[u][i] + ash[u][i] : 0.f;
         }
@@ -672,18 +706,25 @@ static int linear_rows_launch(const void* x, long long x_ld, const void* w, cons
     GM_LAUNCH_CHECK();
   }
   const int bk = dtype == GM_F32 ? 16 : 32;
-  if (gm_token_gemm_wide_rows > 0 && rows >= gm_token_gemm_wide_rows && cin % bk == 0 && cout_pad >= 32 && !ex.ln_g && !ex.kv_ws && !ex.mlp_p && ex.split == 0 &&
+  const bool gn = ex.gn_stats[0] != nullptr;  // (gm_linear_rows_gn: the wide form whatever the row count)
+  if ((gn || (gm_token_gemm_wide_rows > 0 && rows >= gm_token_gemm_wide_rows)) && cin % bk == 0 && cout_pad >= 32 && !ex.ln_g && !ex.kv_ws && !ex.mlp_p && ex.split == 0 &&
       !ex.off_dev && (!ex.pre_scale || ex.rows_per_sample > 0) && (dtype == GM_F32 || dtype == GM_BF16)) {
     const int nb = gm_token_gemm_wide_nb ? gm_token_gemm_wide_nb : (rows >= 8192 ? 4 : 2);
     dim3 gw((cout_pad + 16 * nb - 1) / (16 * nb), (rows + 63) / 64);
-#define GM_WIDE_LAUNCH(T, NBV)                                                                                                              \
-  token_gemm_wide_kernel<T, NBV><<<gw, 256, 0, st>>>((const T*)x, x_ld, (const T*)w, bias, (const T*)res, res_ld, (T*)y, y_ld, rows, cin, cout, \
-                                                     pre_act, post_act, ex)
+    const size_t gsm = gn ? (size_t)cin * (2 * 4 + 16) : 0;
+#define GM_WIDE_LAUNCH(T, NBV)                                                                                                                                    \
+  do {                                                                                                                                                            \
+    if (gn) token_gemm_wide_kernel<T, NBV, true><<<gw, 256, gsm, st>>>((const T*)x, x_ld, (const T*)w, bias, (const T*)res, res_ld, (T*)y, y_ld, rows, cin, cout, \
+                                                                       pre_act, post_act, ex);                                                                    \
+    else token_gemm_wide_kernel<T, NBV, false><<<gw, 256, 0, st>>>((const T*)x, x_ld, (const T*)w, bias, (const T*)res, res_ld, (T*)y, y_ld, rows, cin, cout,     \
+                                                                   pre_act, post_act, ex);                                                                        \
+  } while (0)
     if (dtype == GM_F32) { if (nb == 2) GM_WIDE_LAUNCH(float, 2); else if (nb == 3) GM_WIDE_LAUNCH(float, 3); else GM_WIDE_LAUNCH(float, 4); }
     else { if (nb == 2) GM_WIDE_LAUNCH(bf16_raw, 2); else if (nb == 3) GM_WIDE_LAUNCH(bf16_raw, 3); else GM_WIDE_LAUNCH(bf16_raw, 4); }
 #undef GM_WIDE_LAUNCH
     GM_LAUNCH_CHECK();
   }
+  GM_REQUIRE(!gn, "the statistics form of the token GEMM's GroupNorm needs the wide kernel's geometry (cin a multiple of the MFMA K step, cout >= 32)");
   dim3 grid((cout_pad / 16 + 3) / 4, (rows + 15) / 16);
   if (dtype == GM_F32)
     linear_rows_kernel<float><<<grid, 256, 0, st>>>((const float*)x, x_ld, (const float*)w, bias, (const float*)res, res_ld, (float*)y, y_ld,
@@ -732,6 +773,26 @@ extern "C" int gm_linear_rows_affine_vt(const void* x, long long x_ld, const flo
   ex.pre_scale = pre_scale; ex.pre_shift = pre_shift; ex.ss_ld = ss_ld; ex.rows_per_sample = rows_per_sample;
   ex.vt = vt; ex.vt_c0 = vt_c0; ex.vt_dh = vt_dh;
   return linear_rows_launch(x, x_ld, w, bias, nullptr, 0, y, y_ld, rows, cin, cout, pre_act, 0, dtype, ex, stream);
+}
+
+// gm_linear_rows_affine(_vt) with the GroupNorm given as the statistic tables of x's producer(s): finalised in the GEMM's prologue, one launch less per attention block
+extern "C" int gm_linear_rows_gn(const void* x, long long x_ld, const GmGnTables* gn, int n_samples, int rows_per_sample, const void* w, const float* bias,
+                                 const void* res, long long res_ld, void* y, long long y_ld, int rows, int cin, int cout, int pre_act, int post_act, void* vt,
+                                 int vt_c0, int vt_dh, int dtype, void* stream) {
+  GM_REQUIRE(gn && gn->stats[0] && gn->groups > 0 && cin % gn->groups == 0 && cin <= 384, "GroupNorm tables: whole groups, at most 384 channels");
+  GM_REQUIRE(gn->S[0] >= 1 && gn->S[0] <= GN_SHORT_MAX_ROWS && gn->C[0] > 0 &&
+             ((gn->stats[1] == nullptr && gn->C[0] == cin) || (gn->stats[1] != nullptr && gn->S[1] >= 1 && gn->S[1] <= GN_SHORT_MAX_ROWS && gn->C[1] > 0 && gn->C[0] + gn->C[1] == cin)),
+             "short statistic tables covering the input channels");
+  GM_REQUIRE((reinterpret_cast<uintptr_t>(gn->stats[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(gn->stats[1]) & 15) == 0, "16-byte aligned tables");
+  GM_REQUIRE(n_samples > 0 && rows_per_sample > 0 && rows_per_sample % 64 == 0 && rows == n_samples * rows_per_sample, "whole 64-row groups per sample");
+  GM_REQUIRE(!vt || (dtype == GM_BF16 && vt_dh > 0 && vt_c0 >= 0 && vt_c0 < cout && (cout - vt_c0) % vt_dh == 0 && !res && post_act == 0), "the V^T image: bf16, whole heads, no residual");
+  LinearRowsExtra ex = {};
+  ex.rows_per_sample = rows_per_sample;
+  ex.gn_stats[0] = gn->stats[0]; ex.gn_stats[1] = gn->stats[1]; ex.gn_S[0] = gn->S[0]; ex.gn_S[1] = gn->stats[1] ? gn->S[1] : 0;
+  ex.gn_C[0] = gn->C[0]; ex.gn_C[1] = gn->stats[1] ? gn->C[1] : 0;
+  ex.gn_gamma = gn->gamma; ex.gn_beta = gn->beta; ex.gn_eps = gn->eps; ex.gn_groups = gn->groups; ex.gn_N = n_samples;
+  ex.vt = vt; ex.vt_c0 = vt_c0; ex.vt_dh = vt_dh;
+  return linear_rows_launch(x, x_ld, w, bias, res, res_ld, y, y_ld, rows, cin, cout, pre_act, post_act, dtype, ex, stream);
 }
 
 // the decode step's fused forms: LayerNorm prologue; q | k | v projection writing k, v rows into the caches (internal to the library)

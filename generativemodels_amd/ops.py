@@ -16,7 +16,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _native as nat
-from ._native import GmAttnBwdDesc, GmAttnDesc, GmConvDesc, GmKlParams, GmStepParams, GmWgradDesc, check, lib
+from ._native import GmAttnBwdDesc, GmAttnDesc, GmConvDesc, GmGnTables, GmKlParams, GmStepParams, GmWgradDesc, check, lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 ACT = {"none": 0, "silu": 1, "relu": 2}
@@ -648,6 +648,8 @@ def _fresh_channel_stats(x: torch.Tensor) -> torch.Tensor:
 
 
 GN_IN_CONSUMER = os.environ.get("GM_GN_IN_CONSUMER", "1") != "0"  # short statistic tables: the fold + finalisation in the consumer convolution's prologue (cfg 24 / 25)
+GN_IN_TOKEN_GEMM = os.environ.get("GM_GN_IN_TOKEN_GEMM", "1") != "0"    # ... and in the wide token GEMM (the q | k | v projection of an attention block)
+GN_IN_SPLIT_SLICES = os.environ.get("GM_GN_IN_SPLIT_SLICES", "1") != "0"  # ... also in the K slices of a split launch (conv_sk.hip, second half of round 6)
 GN_IN_CONSUMER_MAX_ROWS = int(os.environ.get("GM_GN_IN_CONSUMER_MAX_ROWS", "128"))  # = GN_SHORT_MAX_ROWS of csrc/gm_common.h (64 until the 32^3 level's 128-row tables were measured)
 
 
@@ -1137,6 +1139,26 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
         if res is not None and (tuple(res.shape) != out_shape or res.dtype != dtype):
             raise ValueError(f"residual has shape {tuple(res.shape)} / {res.dtype}, expected {out_shape} / {dtype}")
         b32 = as_f32(bias) if bias is not None else None
+        if GN_IN_TOKEN_GEMM and isinstance(pre, GnRecipe) and pre._done is None and not transposed:
+            # the GroupNorm is still a recipe (short statistic tables): the wide token GEMM finalises it in its prologue -- no launch for the norm
+            l_tok = rows // n
+            want_vt = (vt is not None and res is None and post_act == "none" and dtype == torch.bfloat16 and l_tok % 64 == 0)
+            if (pre.n == n and sum(pre.cs) == cin and cin <= 384 and cin % (64 // x.element_size()) == 0 and cout >= 32 and l_tok % 64 == 0
+                    and cin % pre.groups == 0 and all(st.shape[0] <= GN_IN_CONSUMER_MAX_ROWS for st in pre.stats) and (vt is None or want_vt)):
+                g = GmGnTables()
+                for i, st in enumerate(pre.stats):
+                    g.stats[i], g.S[i], g.C[i] = st.data_ptr(), st.shape[0], pre.cs[i]
+                g.gamma, g.beta, g.eps, g.groups = _ptr(pre.gamma), _ptr(pre.beta), pre.eps, pre.groups
+                vws, vt_c0, vt_dh = vt if want_vt else (None, 0, 0)
+                _timed(f"token_gemm<{str(dtype).split('.')[-1]}>", dict(flops=2.0 * rows * cin * cout, bytes=float(x.element_size() * (rows * (cin + cout) + cin * cout)),
+                                                                      shape=f"{rows}x{cin}->{cout} (GroupNorm from statistics{' +V^T image' if want_vt else ''})"),
+                       lambda: check(lib().gm_linear_rows_gn(x.data_ptr(), arena_ld(x), C.byref(g), n, l_tok, panel().data_ptr(), _ptr(b32), _ptr(res),
+                                                             0 if res is None else arena_ld(res), out.data_ptr(), arena_ld(out), rows, cin, cout, ACT[pre_act],
+                                                             POST_ACT[post_act], None if vws is None else vws.data_ptr(), int(vt_c0), int(vt_dh), dt_code(dtype),
+                                                             _stream()), "gm_linear_rows_gn"))
+                if want_vt:
+                    out._gm_vt_packed = True
+                return out
         sc = sh = None
         if pre is not None:
             sc, sh = pre
@@ -1309,16 +1331,27 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                 dma_ok = True
             except ValueError:
                 pass
+    def recipe_into_descriptor():
+        """The pending GroupNorm as statistic tables in the descriptor; False (descriptor restored) when the kernel does not take that form after all."""
+        keep = (d.pre_scale, d.pre_shift)
+        d.pre_scale = d.pre_shift = None
+        for i, st in enumerate(recipe.stats):
+            d.pre_stats[i], d.pre_S[i], d.pre_C[i] = st.data_ptr(), st.shape[0], recipe.cs[i]
+        d.pre_gamma, d.pre_beta, d.pre_eps, d.pre_groups = _ptr(recipe.gamma), _ptr(recipe.beta), recipe.eps, recipe.groups
+        if lib().gm_conv_lds_bytes(C.byref(d)) > 0:
+            return True
+        d.pre_stats[0] = d.pre_stats[1] = None  # (a table longer than the short form's bound, more channels than the LDS tables hold)
+        d.pre_S[0] = d.pre_S[1] = d.pre_C[0] = d.pre_C[1] = 0
+        d.pre_scale, d.pre_shift = keep
+        return False
+
+    recipe_pending_split = False
     if recipe is not None:
         if dma_ok and d.cfg in (24, 25):
-            d.pre_scale = d.pre_shift = None
-            for i, st in enumerate(recipe.stats):
-                d.pre_stats[i], d.pre_S[i], d.pre_C[i] = st.data_ptr(), st.shape[0], recipe.cs[i]
-            d.pre_gamma, d.pre_beta, d.pre_eps, d.pre_groups = _ptr(recipe.gamma), _ptr(recipe.beta), recipe.eps, recipe.groups
-            if lib().gm_conv_lds_bytes(C.byref(d)) <= 0:  # (the statistics form is not taken after all: a table longer than the fold's one wave, > 512 channels)
-                d.pre_stats[0] = d.pre_stats[1] = None
-                d.pre_S[0] = d.pre_S[1] = d.pre_C[0] = d.pre_C[1] = 0
+            if not recipe_into_descriptor():
                 recipe = None
+        elif dma_ok and d.cfg == 11 and GN_IN_SPLIT_SLICES and (ksplit is not None or SPLITK):
+            recipe_pending_split = True  # decided with the split (below): the K slices of conv_sk.hip finalise the norm themselves
         else:
             recipe = None
         if recipe is None:
@@ -1376,6 +1409,10 @@ def conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
                 raise ValueError(f"split-K by {ks} is not available for this convolution")
             else:
                 d.ksplit = 0
+    if recipe_pending_split:
+        if not (d.ksplit > 1 and kpart is not None and recipe_into_descriptor()):
+            sc, sh = pre.materialise()
+            d.pre_scale, d.pre_shift = sc.data_ptr(), sh.data_ptr()
     if _CONV_TIMELINE_BUFFER is not None and kpart is None:
         d.kpartial = _CONV_TIMELINE_BUFFER.data_ptr()  # ksplit stays 0: the kernel only stamps into it (debug_flags bit 12)
     d.stats = None

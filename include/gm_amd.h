@@ -315,6 +315,18 @@ int gm_linear_rows_affine_vt(const void* x, long long x_ld, const float* pre_sca
 int gm_linear_rows_affine(const void* x, long long x_ld, const float* pre_scale, const float* pre_shift, long long ss_ld, int rows_per_sample,
                           const void* w, const float* bias, const void* res, long long res_ld, void* y, long long y_ld, int rows, int cin,
                           int cout, int pre_act, int post_act, int dtype, void* stream);
+/* The same GEMM with the GroupNorm given as the per-tile statistic tables of x's producer(s) instead of (scale, shift): finalised in the GEMM's prologue (the
+ * short-table order of gm_gn_finalize_channels: bit-identical to that launch + gm_linear_rows_affine), so an attention block's norm costs no launch of its own
+ * (diffusion_model_unet.py:424-441).  stats[i]: [S_i][N][C_i][2] fp64 (sum, sum of squares), S_i <= 128, stats[1] NULL for one source; gamma / beta fp32 over
+ * the C0 + C1 = cin <= 384 channels (nullable); rows = n_samples * rows_per_sample, rows_per_sample a multiple of 64; cin a multiple of the MFMA K step (32 bf16 /
+ * 16 fp32).  vt != NULL: the V^T image as gm_linear_rows_affine_vt (bf16, no residual). */
+typedef struct GmGnTables {
+  const double* stats[2]; int S[2]; int C[2];
+  const float* gamma; const float* beta; float eps; int groups;
+} GmGnTables;
+int gm_linear_rows_gn(const void* x, long long x_ld, const GmGnTables* gn, int n_samples, int rows_per_sample, const void* w, const float* bias,
+                      const void* res, long long res_ld, void* y, long long y_ld, int rows, int cin, int cout, int pre_act, int post_act, void* vt,
+                      int vt_c0, int vt_dh, int dtype, void* stream);
 
 /* One KV-cache decoding step of the decoder-only transformer issued natively (38-62 launches back to back, by how many of the fused kernels of small_ops.hip take the geometry): embed the fed token at
  * `pos`, per block LayerNorm -> q|k|v -> append k, v to the caches -> 1 x (pos+1) attention -> out_proj + x -> LayerNorm -> MLP(GELU) + x,

@@ -33,7 +33,8 @@ def test_ctypes_prototypes_cover_the_header():
 
 def test_struct_layouts_match_the_header_field_order():
     src = open(os.path.join(ROOT, "include", "gm_amd.h")).read()
-    for cname, cls in (("GmStepParams", _native.GmStepParams), ("GmConvDesc", _native.GmConvDesc), ("GmAttnDesc", _native.GmAttnDesc)):
+    for cname, cls in (("GmStepParams", _native.GmStepParams), ("GmConvDesc", _native.GmConvDesc), ("GmAttnDesc", _native.GmAttnDesc),
+                       ("GmGnTables", _native.GmGnTables)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

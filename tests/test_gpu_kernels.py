@@ -468,10 +468,13 @@ def test_conv_2d_narrow_output_block_kernel(case, dtype):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("case", [("2d", (40, 56), 64, 64, None, 32), ("2d-cat-straddle", (33, 30), 96, 32, 64, 32), ("2d-groups8", (16, 16), 32, 40, None, 8),
                                   ("3d", (8, 8, 16), 64, 64, None, 32), ("3d-cat", (4, 8, 16), 96, 64, 32, 32),
-                                  ("3d-long-tables", (8, 8, 32), 64, 48, None, 32), ("3d-cat-long-tables", (8, 4, 32), 96, 64, 32, 32)], ids=lambda c: c[0])
+                                  ("3d-long-tables", (8, 8, 32), 64, 48, None, 32), ("3d-cat-long-tables", (8, 4, 32), 96, 64, 32, 32),
+                                  ("split-slices", (8, 8, 16), 256, 64, None, 32), ("split-slices-cat", (8, 8, 8), 384, 128, 256, 32),
+                                  ("split-slices-groups-straddle", (4, 8, 16), 288, 64, None, 4)], ids=lambda c: c[0])
 def test_groupnorm_finalised_in_the_consumer_prologue_is_the_finalisation_launch_bit_for_bit(case, dtype):
-    """(round 6) `ops.gn_scale_shift_composed` hands out a GnRecipe when the producer's statistic tables are short; a consumer on tile configuration 24 / 25 folds
-    them and forms (scale, shift) in its own prologue (GmConvDesc.pre_stats) -- the gm_gn_finalize_channels launch of that norm does not happen.  Output and output
+    """(round 6) `ops.gn_scale_shift_composed` hands out a GnRecipe when the producer's statistic tables are short; a consumer on tile configuration 24 / 25 -- or the
+    K slices of a split launch (conv_sk.hip) -- folds them and forms (scale, shift) in its own prologue (GmConvDesc.pre_stats) -- the gm_gn_finalize_channels launch
+    of that norm does not happen.  Output and output
     statistics must equal, BIT FOR BIT, the convolution fed with the launch's (scale, shift): one source and the two sources of a virtual concatenation whose
     groups straddle the seam, 2-D and 3-D, against fp64 GroupNorm + SiLU + convolution as well.  Reference: conv(silu(norm(x))), diffusion_model_unet.py:671-684."""
     ops = _ops()
@@ -497,8 +500,12 @@ def test_groupnorm_finalised_in_the_consumer_prologue_is_the_finalisation_launch
         recipe = ops.gn_scale_shift_composed(operand, groups, 1e-5, gamma.to(DEV), beta.to(DEV))
         assert isinstance(recipe, ops.GnRecipe) and recipe._done is None
         kw = dict(kernel=3, padding=1, pre_act="silu", want_stats=True)
+        ops.start_profile()
         fused = ops.conv(operand, w.to(DEV), b.to(DEV), pre=recipe, **kw)
+        names = [nm for nm, _, _ in ops.stop_profile()]
         assert recipe._done is None, "the consumer should have finalised the norm itself"
+        if name.startswith("split-slices"):  # deep contractions keep the K slices (conv_sk.hip): each slice finalises the groups of ITS channels
+            assert any("cfg11k" in nm for nm in names), names
         scale, shift = ops.gn_scale_shift_composed(operand, groups, 1e-5, gamma.to(DEV), beta.to(DEV)).materialise()
         launched = ops.conv(operand, w.to(DEV), b.to(DEV), pre=(scale, shift), **kw)
     assert torch.equal(fused, launched) and torch.equal(fused._gm_cstats, launched._gm_cstats)
@@ -1338,6 +1345,57 @@ def test_attention_merge_kernel_writes_the_output_statistics(case):
     if with_res:
         want = want + res.float().cpu().double()
     assert (ov - want).abs().max().item() <= 2.5e-2 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", [(16, 1024, 64, 1, 32, 5), (1, 4096, 128, 1, 32, 16), (2, 512, 256, 4, 32, 128), (3, 320, 96, 1, 8, 3), (1, 192, 384, 8, 32, 100)],
+                         ids=lambda c: f"B{c[0]}-L{c[1]}-C{c[2]}-H{c[3]}-S{c[5]}")
+def test_qkv_projection_finalises_its_groupnorm_from_the_statistic_tables(case, dtype):
+    """(round 6) gm_linear_rows_gn: the stacked q | k | v projection of an attention block takes the block's GroupNorm as a GnRecipe -- the statistic tables of the
+    producer -- and finalises it in the wide token GEMM's prologue (no finalisation launch), storing the V^T image of the attention kernel from its epilogue.
+    Against the SAME kernel fed with the finalisation launch's (scale, shift): BIT FOR BIT, V^T bytes and attention result included; against fp64 GroupNorm + Linear;
+    tables of 3 ... 128 rows, several samples and heads, token counts that are multiples of 64 only.  Reference: AttentionBlock.forward, diffusion_model_unet.py:424-458."""
+    ops = _ops()
+    b, l, c, heads, groups, srows = case
+    x = _rand((b, l, c), 970).to(dtype).to(DEV)
+    w = (_rand((3 * c, c, 1), 971) / math.sqrt(c)).to(dtype).to(DEV)
+    bias = (_rand((3 * c,), 972) * 0.1).to(DEV)
+    gamma, beta = (_rand((c,), 973) * 0.2 + 1.0).to(DEV), (_rand((c,), 974) * 0.3).to(DEV)
+    packed = ops.packed_conv_weight(w, dtype)
+
+    def recipe():
+        st = ops._fresh_channel_stats(x)
+        fold = torch.zeros((srows, *st.shape[1:]), dtype=st.dtype, device=st.device)
+        for i in range(int(st.shape[0])):
+            fold[i % srows] += st[i]
+        x._gm_cstats = fold
+        return ops.gn_scale_shift_composed(x, groups, 1e-6, gamma, beta)
+
+    def run(pre):
+        qkv = torch.empty((b, l, 3 * c), dtype=dtype, device=DEV)
+        q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+        ws = ops.attention_workspace(q, k, v, heads) if dtype == torch.bfloat16 else None
+        ops.start_profile()
+        out = ops.conv(x, None, bias, kernel=1, pre=pre, packed=packed, cout=3 * c, out=qkv, vt=None if ws is None else (ws, 2 * c, c // heads))
+        names = [nm for nm, _, _ in ops.stop_profile()]
+        got = bool(getattr(out, "_gm_vt_packed", False))
+        assert got == (ws is not None)
+        att = ops.attention(q, k, v, heads, (c // heads) ** -0.5, res=x, workspace=ws, vt_packed=got) if ws is not None else None
+        return qkv.clone(), att, (None if ws is None else ws[: b * c * l * 2].clone()), names
+
+    with torch.no_grad():
+        r = recipe()
+        assert isinstance(r, ops.GnRecipe) and r._done is None
+        q_fused, a_fused, vt_fused, names = run(r)
+        assert r._done is None and not any("gn_finalize" in nm for nm in names), "the projection should have finalised the norm itself"
+        q_launch, a_launch, vt_launch, _ = run(recipe().materialise())
+    assert torch.equal(q_fused, q_launch)
+    if vt_fused is not None:
+        assert torch.equal(vt_fused, vt_launch) and torch.equal(a_fused, a_launch)
+    xn = F.group_norm(x.float().cpu().double().transpose(1, 2), groups, gamma.cpu().double(), beta.cpu().double(), 1e-6).transpose(1, 2)
+    want = xn @ w[..., 0].float().cpu().double().t() + bias.cpu().double()
+    tol = (3e-2 if dtype == torch.bfloat16 else 2e-4) * max(1.0, want.abs().max().item())
+    assert (q_fused.float().cpu().double() - want).abs().max().item() <= tol
 
 
 @pytest.mark.parametrize("case", [(1, 512, 256, 1), (1, 4096, 128, 1), (2, 256, 128, 2), (1, 640, 256, 4)], ids=lambda c: f"B{c[0]}-L{c[1]}-C{c[2]}-H{c[3]}")
