@@ -94,6 +94,7 @@ PROTOTYPES = {
     "gm_lincomb": (C.c_int, [C.POINTER(c_vp), C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, c_vp, c_ll, C.c_int, c_vp]),
     "gm_copy_channels": (C.c_int, [c_vp, c_ll, C.c_int, c_vp, c_ll, C.c_int, c_ll, C.c_int, c_vp]),
     "gm_normal_bf16_from_bits": (C.c_int, [c_vp, c_vp, c_vp, c_ll, c_vp]),
+    "gm_sched_step_noise_bits": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, C.POINTER(GmStepParams), c_vp]),
     "gm_token_gemm_set_wide": (None, [C.c_int, C.c_int]),
     "gm_attention_set_wave_groups": (None, [C.c_int]),
     "gm_nchw_to_nhwc": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_ll, c_ll, c_vp]),

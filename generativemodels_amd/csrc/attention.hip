@@ -40,8 +40,8 @@ __device__ __forceinline__ uint4 load_row16(const T* base, long long ld, long lo
   return *reinterpret_cast<uint4*>(tmp);
 }
 
-// G = 2 (round 6): TWO groups of four waves per work-group share the 64 queries and deal the key tiles between them (group g takes tiles g, g + 2, ...), each with
-// its own K / V buffers; their softmax states meet in LDS at the end.  Eight waves per CU instead of four: one group's softmax and staging run under the other's
+// G = 2 / 4 (round 6): G groups of four waves per work-group share the 64 queries and deal the key tiles between them (group g takes tiles g, g + G, ...), each with
+// its own K / V buffers; their softmax states meet in LDS at the end (merged into group 0 in group order).  Eight waves per CU instead of four: one group's softmax and staging run under the other's
 // MFMAs (a 256-work-group grid -- 16 x 1024 queries -- has one work-group per CU), without the second launch a split over work-groups needs.
 template <typename T, int DH, int G>
 __global__ __launch_bounds__(256 * G) void attn_kernel(const GmAttnDesc p) {
@@ -264,10 +264,11 @@ __global__ __launch_bounds__(256 * G) void attn_kernel(const GmAttnDesc p) {
   }
 
   // ---- G = 2: group 1 hands its state (running maximum, this lane's partial sum, un-normalised output) to the same lane of group 0 through LDS ----------------
-  if constexpr (G == 2) {
+  if constexpr (G > 1) {
     __syncthreads();  // every tile has been read: the operand buffers are free
-    float* xch = reinterpret_cast<float*>(smem) + (size_t)tid * (2 + DF * 4);
-    if (grp == 1) {
+    constexpr int XW = 2 + DF * 4;  // floats per lane: running maximum, partial sum, un-normalised output
+    float* xch = reinterpret_cast<float*>(smem) + ((size_t)(grp > 0 ? grp - 1 : 0) * 256 + tid) * XW;
+    if (grp > 0) {
       xch[0] = m_run; xch[1] = l_run;
 #pragma unroll
       for (int d = 0; d < DF; ++d)
@@ -275,15 +276,20 @@ __global__ __launch_bounds__(256 * G) void attn_kernel(const GmAttnDesc p) {
         for (int r = 0; r < 4; ++r) xch[2 + d * 4 + r] = oacc[d][r];
     }
     __syncthreads();
-    if (grp == 1) return;
-    const float m1 = xch[0], l1 = xch[1];
-    const float M = fmaxf(m_run, m1);  // (group 0 always has a tile: finite)
-    const float a0 = IS_BF16 ? __expf(m_run - M) : expf(m_run - M), a1 = IS_BF16 ? __expf(m1 - M) : expf(m1 - M);  // a group without a tile: e^(-inf) = 0
-    l_run = l_run * a0 + l1 * a1;
+    if (grp > 0) return;
 #pragma unroll
-    for (int d = 0; d < DF; ++d)
+    for (int g = 1; g < G; ++g) {  // group order: a fixed summation order
+      const float* xg = reinterpret_cast<const float*>(smem) + ((size_t)(g - 1) * 256 + tid) * XW;
+      const float m1 = xg[0], l1 = xg[1];
+      const float M = fmaxf(m_run, m1);  // (group 0 always has a tile: finite)
+      const float a0 = IS_BF16 ? __expf(m_run - M) : expf(m_run - M), a1 = IS_BF16 ? __expf(m1 - M) : expf(m1 - M);  // a group without a tile: e^(-inf) = 0
+      l_run = l_run * a0 + l1 * a1;
+      m_run = M;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[d][r] = oacc[d][r] * a0 + xch[2 + d * 4 + r] * a1;
+      for (int d = 0; d < DF; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[d][r] = oacc[d][r] * a0 + xg[2 + d * 4 + r] * a1;
+    }
   }
 
   // ---- finish: 1/l, residual, store ------------------------------------------------------------------------------------
@@ -312,7 +318,7 @@ static int launch_attn_g(const GmAttnDesc& d, hipStream_t st) {
   constexpr int KT = AttnTraits<T>::KT;
   constexpr bool IS_BF16 = sizeof(T) == 2;
   constexpr size_t group = (size_t)KT * (DH * sizeof(T) + 16) + (IS_BF16 ? (size_t)DH * (KT * 2 + 16) : (size_t)KT * (DH * 4 + 16));
-  constexpr size_t xch = G == 2 ? (size_t)256 * (2 + DH / 16 * 4) * 4 : 0;  // the hand-over of group 1's state overlays the operand buffers
+  constexpr size_t xch = G > 1 ? (size_t)(G - 1) * 256 * (2 + DH / 16 * 4) * 4 : 0;  // the hand-over of the other groups' states overlays the operand buffers
   constexpr size_t smem = G * group > xch ? G * group : xch;
   static_assert(smem <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
@@ -327,15 +333,20 @@ static int launch_attn_g(const GmAttnDesc& d, hipStream_t st) {
   return 0;
 }
 
-// two wave groups once a work-group has at least four key tiles to deal (process-wide override for measurements: gm_attention_set_wave_groups)
+// two wave groups once a work-group has at least four key tiles to deal, four from eight tiles on where 128 registers per wave suffice (fp32, head dim <= 64: BASELINE
+// configs[0]'s 16 x 1024-token blocks: 0.970 -> 0.919 ms per fp32 forward); process-wide override for measurements: gm_attention_set_wave_groups
 static int gm_attn_wave_groups = 0;  // 0 = by key count
-extern "C" void gm_attention_set_wave_groups(int g) { gm_attn_wave_groups = (g == 1 || g == 2) ? g : 0; }
+extern "C" void gm_attention_set_wave_groups(int g) { gm_attn_wave_groups = (g == 1 || g == 2 || g == 4) ? g : 0; }
 template <typename T, int DH>
 static int launch_attn(const GmAttnDesc& d, hipStream_t st) {
   constexpr int KT = AttnTraits<T>::KT;
-  const int g = gm_attn_wave_groups ? gm_attn_wave_groups : ((d.Lk + KT - 1) / KT >= 4 ? 2 : 1);
+  const int tiles = (d.Lk + KT - 1) / KT;
+  const int g = gm_attn_wave_groups ? gm_attn_wave_groups : (tiles >= 8 ? 4 : (tiles >= 4 ? 2 : 1));  // (four: the fp32 kernel at head dim <= 64 only, see below)
   if constexpr (sizeof(T) == 4 && DH == 256) return launch_attn_g<T, DH, 1>(d, st);  // (two groups = 256 registers per wave: the fp32 kernel at head dim 256 would spill 81)
-  else return g == 2 ? launch_attn_g<T, DH, 2>(d, st) : launch_attn_g<T, DH, 1>(d, st);
+  else if constexpr (sizeof(T) == 4 && DH <= 64) {  // four groups = 128 registers per wave: the small fp32 head dims only
+    if (g == 4) return launch_attn_g<T, DH, 4>(d, st);
+    return g == 2 ? launch_attn_g<T, DH, 2>(d, st) : launch_attn_g<T, DH, 1>(d, st);
+  } else return g >= 2 ? launch_attn_g<T, DH, 2>(d, st) : launch_attn_g<T, DH, 1>(d, st);
 }
 
 template <typename T>

@@ -29,11 +29,14 @@ struct GmStepParams {
   float min_log, max_log;  // learned_range
 };
 
-template <typename T>
+// BITS: the Gaussian noise of a bf16 chain comes as the CPU generator's byte draws + the pair table of host_noise.py (gm_normal_bf16_from_bits' lookup, here in the
+// step's own kernel: element i of block b = i / 16 is the cos branch (i % 16 < 8) or the sin branch of the byte pair (bits[16 b + i % 8], bits[16 b + 8 + i % 8]))
+template <typename T, bool BITS>
 __global__ __launch_bounds__(256) void sched_step_kernel(const T* __restrict__ sample, const T* __restrict__ mo,
                                                         const T* __restrict__ noise, T* __restrict__ prev,
                                                         T* __restrict__ x0out, long long inner, long long mo_bstride,
-                                                        long long total, GmStepParams p) {
+                                                        long long total, GmStepParams p, const unsigned char* __restrict__ bits,
+                                                        const unsigned int* __restrict__ table) {
   // every operation is an explicitly rounded, never-contracted IEEE fp32 op (__f*_rn) in the reference's order
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / inner, r = i - n * inner;
@@ -64,7 +67,14 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const T* __restrict__ s
       out = __fadd_rn(__fmul_rn(p.k0, x0), __fmul_rn(p.k1, s));
     }
     if (p.noise_mode != 0) {
-      const float z = ElemIO<T>::ld(noise + i);
+      float z;
+      if constexpr (BITS) {
+        const long long base = (i >> 4) * 16 + (i & 7);
+        const unsigned e = table[(unsigned)bits[base] * 256u + bits[base + 8]];
+        z = __uint_as_float((i & 8) ? (e & 0xffff0000u) : (e << 16));  // (bf16 bits -> fp32)
+      } else {
+        z = ElemIO<T>::ld(noise + i);
+      }
       float v;
       if (p.noise_mode == 1) {
         v = __fmul_rn(p.c_noise, z);
@@ -102,15 +112,28 @@ extern "C" int gm_sched_step(const void* sample, const void* model_output, const
   if (total == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == GM_F32)
-    sched_step_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)sample, (const float*)model_output,
-                                                             (const float*)noise, (float*)prev, (float*)x0, inner,
-                                                             mo_bstride, total, *p);
+    sched_step_kernel<float, false><<<ew_grid(total), 256, 0, st>>>((const float*)sample, (const float*)model_output,
+                                                                    (const float*)noise, (float*)prev, (float*)x0, inner,
+                                                                    mo_bstride, total, *p, nullptr, nullptr);
   else if (dtype == GM_BF16)
-    sched_step_kernel<bf16_raw><<<ew_grid(total), 256, 0, st>>>((const bf16_raw*)sample, (const bf16_raw*)model_output,
-                                                                (const bf16_raw*)noise, (bf16_raw*)prev, (bf16_raw*)x0,
-                                                                inner, mo_bstride, total, *p);
+    sched_step_kernel<bf16_raw, false><<<ew_grid(total), 256, 0, st>>>((const bf16_raw*)sample, (const bf16_raw*)model_output,
+                                                                       (const bf16_raw*)noise, (bf16_raw*)prev, (bf16_raw*)x0,
+                                                                       inner, mo_bstride, total, *p, nullptr, nullptr);
   else
     GM_FAIL(-2, "unsupported dtype");
+  GM_LAUNCH_CHECK();
+}
+
+// gm_sched_step for a bf16 chain whose noise arrives as the CPU generator's byte draws (see gm_normal_bf16_from_bits): the lookup runs inside the step's kernel
+extern "C" int gm_sched_step_noise_bits(const void* sample, const void* model_output, const unsigned char* bits, const unsigned int* table, void* prev, void* x0,
+                                        long long batch, long long inner, long long mo_bstride, const GmStepParams* p, void* stream) {
+  GM_REQUIRE(sample && model_output && prev && p && bits && table, "null pointer");
+  GM_REQUIRE(p->noise_mode != 0, "a step without noise takes gm_sched_step");
+  const long long total = batch * inner;
+  GM_REQUIRE(total % 16 == 0, "whole blocks of 16 values");
+  if (total == 0) return 0;
+  sched_step_kernel<bf16_raw, true><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const bf16_raw*)sample, (const bf16_raw*)model_output, nullptr, (bf16_raw*)prev,
+                                                                                    (bf16_raw*)x0, inner, mo_bstride, total, *p, bits, table);
   GM_LAUNCH_CHECK();
 }
 

@@ -102,8 +102,9 @@ def _staged_copy(draw, n: int, dtype: torch.dtype, dev: torch.device) -> torch.T
     return out
 
 
-def randn(shape, dtype: torch.dtype, generator: Optional[torch.Generator], device) -> torch.Tensor:
-    """`torch.randn(shape, dtype=dtype, generator=generator).to(device)`, bit for bit, the generator left in the same state."""
+def randn(shape, dtype: torch.dtype, generator: Optional[torch.Generator], device, as_bits: bool = False):
+    """`torch.randn(shape, dtype=dtype, generator=generator).to(device)`, bit for bit, the generator left in the same state.  as_bits: a bf16 draw may come back as
+    ops.NoiseBits (the bytes + the table) for ops.sched_step, which then does the lookup in the step's kernel: one launch less per step."""
     shape = tuple(int(s) for s in shape)
     n = math.prod(shape)
     dev = torch.device(device)
@@ -118,6 +119,8 @@ def randn(shape, dtype: torch.dtype, generator: Optional[torch.Generator], devic
         tab = _table_dev.get(dev.index)
         if tab is None:
             tab = _table_dev[dev.index] = bf16_normal_table().to(dev)
+        if as_bits:  # (a scheduler step: ops.sched_step expands the bytes inside its own kernel)
+            return ops.NoiseBits(bits, tab, shape)
         return ops.normal_bf16_from_bits(bits, tab).reshape(shape)
     if not ENABLED or torch.cuda.is_current_stream_capturing():
         return torch.randn(shape, dtype=dtype, generator=generator).to(dev)

@@ -77,7 +77,7 @@ class DDIMScheduler(Scheduler):
         p.noise_mode = 0
         if eta > 0:
             # CPU-generator draw + H2D copy, like the reference (ddim.py:229-235): identical random stream (bf16: from the generator's byte draws, host_noise.py)
-            noise = host_noise.randn(model_output.shape, model_output.dtype, generator, model_output.device)
+            noise = host_noise.randn(model_output.shape, model_output.dtype, generator, model_output.device, as_bits=True)
             p.noise_mode, p.c_noise = 1, self._f(variance**0.5 * eta)
         return ops.sched_step(sample, model_output, p, noise=noise)
 

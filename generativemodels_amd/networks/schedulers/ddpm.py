@@ -123,7 +123,7 @@ class DDPMScheduler(Scheduler):
             if self.fp32_noise_draw and model_output.dtype in (torch.bfloat16, torch.float16):
                 noise = ops.cast(host_noise.randn(shape, torch.float32, generator, model_output.device), model_output.dtype)
             else:  # (bf16: the same values from the generator's byte draws + a device table lookup, host_noise.py)
-                noise = host_noise.randn(shape, model_output.dtype, generator, model_output.device)
+                noise = host_noise.randn(shape, model_output.dtype, generator, model_output.device, as_bits=True)
             variance = (1 - a_prev) / (1 - a_t) * beta_t
             if self.variance_type == DDPMVarianceType.FIXED_SMALL:
                 p.noise_mode, p.c_noise = 1, self._f(torch.clamp(variance, min=1e-20) ** 0.5)

@@ -852,7 +852,7 @@ SMALL_LINEAR_ROWS = 64       # 1x1 "convolutions" over at most this many rows ta
 TOKEN_GEMM = os.environ.get("GM_TOKEN_GEMM", "1") != "0"
 TOKEN_GEMM_MAX_ROWS = int(os.environ.get("GM_TOKEN_GEMM_MAX_ROWS", "32768"))  # (8192 until the wide form of round 6: small_ops.hip token_gemm_wide_kernel)
 TOKEN_GEMM_MAX_CIN = 512
-TOKEN_GEMM_MAX_FLOP = 2.0e9
+TOKEN_GEMM_MAX_FLOP = float(os.environ.get("GM_TOKEN_GEMM_MAX_FLOP", "2.0e9"))
 DMA_CONV = True              # route eligible 3x3x3 convolutions through conv_dma.hip (cfg 11)
 DMA_CONV_MIN_VOXELS = 1 << 8
 LDS_SOFT_LIMIT = 80 * 1024   # two workgroups per CU
@@ -2078,9 +2078,38 @@ def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10
     return out
 
 
-def sched_step(sample: torch.Tensor, model_output: torch.Tensor, params: GmStepParams, noise: Optional[torch.Tensor] = None,
-               want_x0: bool = True):
-    """Fused DDIM / DDPM step on logical NC[D]HW tensors (all contiguous, same dtype)."""
+class NoiseBits:
+    """The Gaussian noise of a bf16 step as the CPU generator's byte draws (device uint8 [n]) + the pair table (host_noise.py): sched_step expands them itself."""
+
+    def __init__(self, bits: torch.Tensor, table: torch.Tensor, shape) -> None:
+        self.bits, self.table, self.shape = bits, table, tuple(shape)
+
+    def materialise(self) -> torch.Tensor:
+        return normal_bf16_from_bits(self.bits, self.table).reshape(self.shape)
+
+
+def sched_step(sample: torch.Tensor, model_output: torch.Tensor, params: GmStepParams, noise=None, want_x0: bool = True):
+    """Fused DDIM / DDPM step on logical NC[D]HW tensors (all contiguous, same dtype).  noise: a tensor, or NoiseBits (bf16 chains)."""
+    if isinstance(noise, NoiseBits):
+        if sample.dtype != torch.bfloat16 or noise.bits.numel() != sample.numel() or sample.numel() % 16 != 0 or params.noise_mode == 0:
+            noise = noise.materialise()
+        else:
+            require_device(sample, model_output, noise.bits, noise.table)
+            if sample.dtype != model_output.dtype:
+                raise TypeError("sample and model_output must share a dtype")
+            sample, model_output = sample.contiguous(), model_output.contiguous()
+            batch = sample.shape[0]
+            inner = sample.numel() // max(batch, 1)
+            mo_bs = model_output.numel() // max(batch, 1)
+            if mo_bs not in (inner, 2 * inner) or (params.noise_mode in (2, 3) and mo_bs != 2 * inner):
+                raise ValueError("model_output shape does not match the sample / the variance type")
+            prev = torch.empty_like(sample)
+            x0 = torch.empty_like(sample) if want_x0 else None
+            nb = sample.element_size() * sample.numel()
+            _timed("sched_step", dict(flops=0.0, bytes=float(nb * (3 + (x0 is not None)) + sample.numel()), shape=str(tuple(sample.shape))),
+                   lambda: check(lib().gm_sched_step_noise_bits(sample.data_ptr(), model_output.data_ptr(), noise.bits.data_ptr(), noise.table.data_ptr(), prev.data_ptr(),
+                                                                _ptr(x0), batch, inner, mo_bs, C.byref(params), _stream()), "gm_sched_step_noise_bits"))
+            return prev, x0
     require_device(sample, model_output, noise)
     if sample.dtype != model_output.dtype:
         raise TypeError("sample and model_output must share a dtype")

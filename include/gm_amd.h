@@ -46,7 +46,7 @@ typedef struct GmStepParams {
 int gm_sched_step(const void* sample, const void* model_output, const void* noise, void* prev, void* x0,
                   long long batch, long long inner, long long mo_bstride, int dtype, const GmStepParams* p, void* stream);
 /* The register-staged attention kernel (fp32; bf16 outside the LDS-DMA kernel's geometries: causal, few keys, head dim 32) deals the key tiles of a work-group to
- * g = 1 or 2 groups of four waves; anything else = two groups from four key tiles on (the default).  Process-wide, for measurements and tests. */
+ * g = 1, 2 or 4 groups of four waves (4: fp32 at head dim <= 64 only, else 2); anything else = by key-tile count (the default: 2 from four tiles, 4 from eight).  Process-wide, for measurements and tests. */
 void gm_attention_set_wave_groups(int g);
 /* The affine token GEMMs (gm_linear_rows_affine / _vt, gm_linear_rows) over at least `min_rows` rows run with a wave owning 16 rows x nb * 16 output channels
  * (nb = 2, 3 or 4, anything else = chosen by the row count; small_ops.hip: token_gemm_wide_kernel) instead of one 16-channel block per wave.  min_rows 0 = never,
@@ -56,6 +56,10 @@ void gm_token_gemm_set_wide(int min_rows, int nb);
  * (networks/schedulers/ddpm.py:244-248, ddim.py:231-234) -- from that generator's n byte draws: torch's bf16 fill is a function of byte pairs within blocks of 16
  * (generativemodels_amd/host_noise.py).  bits: n bytes (device); table: [256 * 256] (cos branch | sin branch << 16) bf16 pairs (device); n % 16 == 0. */
 int gm_normal_bf16_from_bits(const unsigned char* bits, const unsigned int* table, void* out, long long n, void* stream);
+/* gm_sched_step (noise_mode != 0) of a bf16 chain with the table lookup of gm_normal_bf16_from_bits inside the step's kernel: `bits` = the batch * inner byte draws
+ * of the CPU generator (device), `table` as there; batch * inner a multiple of 16. */
+int gm_sched_step_noise_bits(const void* sample, const void* model_output, const unsigned char* bits, const unsigned int* table, void* prev, void* x0,
+                             long long batch, long long inner, long long mo_bstride, const GmStepParams* p, void* stream);
 /* out = post_mul * (((c0*x0 + c1*x1) + c2*x2) + c3*x3) / post_div over n elements, k = 1..4 terms, left to right with every
  * operation rounded: the Runge-Kutta / linear multi-step combinations of PNDMScheduler.step_prk / step_plms
  * (networks/schedulers/pndm.py:186-195, 241-250).  A NULL x[j] is skipped (the reference's integer-0 accumulator). */
