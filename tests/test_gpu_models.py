@@ -673,6 +673,48 @@ def test_unet3d_ragged_volume_matches_oracle(shape):
     _bf16_close(yb, want, f"ragged unet bf16 {shape}")
 
 
+SWEEP = [
+    # (name, cfg, input shape, context shape): geometries on either side of the round-6 kernel policies -- token rows below / above 2 048 and 8 192 (wide token GEMM, 2 / 4
+    # blocks per wave), statistic tables of 1 ... 128 rows (GroupNorm finalised in the consumer), C_in <= 4 image inputs (edge kernel), narrow output heads, ragged extents
+    ("2d-configs0-batch16", dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(32, 64), attention_levels=(False, True), num_res_blocks=1,
+                                 num_head_channels=64), (16, 1, 64, 64), None),
+    ("2d-ragged-3levels", dict(spatial_dims=2, in_channels=3, out_channels=2, num_channels=(64, 128, 128), attention_levels=(False, True, True), num_res_blocks=2,
+                               num_head_channels=(0, 64, 32)), (3, 3, 40, 56), None),
+    ("2d-attention-everywhere", dict(spatial_dims=2, in_channels=2, out_channels=4, num_channels=(32, 32, 64), attention_levels=(True, True, True), num_res_blocks=1,
+                                     num_head_channels=32), (9, 2, 32, 32), None),
+    ("3d-latent-like", dict(spatial_dims=3, in_channels=4, out_channels=4, num_channels=(32, 64), attention_levels=(False, True), num_res_blocks=1,
+                            num_head_channels=32), (2, 4, 16, 16, 16), None),
+    ("3d-ragged", dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(32, 64, 128), attention_levels=(False, False, True), num_res_blocks=(1, 1, 2),
+                       num_head_channels=(0, 0, 64)), (1, 1, 24, 20, 36), None),
+    ("2d-cross-attention", dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(32, 64), attention_levels=(False, True), num_res_blocks=1,
+                                num_head_channels=(0, 32), with_conditioning=True, cross_attention_dim=24, transformer_num_layers=1), (2, 1, 32, 32), (2, 5, 24)),
+]
+
+
+@pytest.mark.parametrize("case", SWEEP, ids=lambda c: c[0])
+def test_unet_configuration_sweep_against_the_oracle(case):
+    """(round 6) DiffusionModelUNet.forward under no_grad -- the path DiffusionInferer.sample takes -- over configurations chosen to sit on either side of the kernel
+    policies this round added (SWEEP above), fp32 and bf16, against the CPU oracle's restatement of the reference forward (diffusion_model_unet.py:1869-1943)."""
+    name, cfg, shape, ctx_shape = case
+    torch.manual_seed(11)
+    m = _nets().DiffusionModelUNet(**cfg).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    R.derandomize_zeros(sd)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g)
+    t = torch.randint(0, 1000, (shape[0],), generator=g)
+    ctx = None if ctx_shape is None else torch.randn(ctx_shape, generator=g)
+    with torch.no_grad():
+        want = R.unet_forward(sd, cfg, x, t, ctx)
+        got = m.to(DEV)(_dev(x), _dev(t), context=_dev(ctx))
+        _fp32_close(got, want, f"sweep {name} fp32", factor=2.0)
+        yb = m.to(DEV, torch.bfloat16)(_dev(x.bfloat16()), _dev(t), context=None if ctx is None else _dev(ctx.bfloat16()))
+        _bf16_close(yb, want, f"sweep {name} bf16")
+        again = m(_dev(x.bfloat16()), _dev(t), context=None if ctx is None else _dev(ctx.bfloat16()))
+    assert torch.equal(again, yb)  # run-to-run bitwise
+
+
 def test_spade_networks_match_reference():
     """SPADE block, SPADEDiffusionModelUNet (2-D with attention and a coarser segmentation; 3-D with cross-attention + resblock_updown),
     SPADEAutoencoderKL encode / decode and the seg-conditioned latent DDIM chain against the reference's outputs (fp32), plus bf16
