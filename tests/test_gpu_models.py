@@ -237,6 +237,37 @@ def test_captured_forward_is_reused_across_sample_calls_and_refreshed_when_param
     assert torch.equal(got4, want4) and not torch.equal(got4, want3)
 
 
+def test_bf16_ddpm_chain_is_the_same_eager_graphed_and_through_torchs_own_noise_draw(monkeypatch):
+    """(round 6) A seeded bf16 DDPM chain of BASELINE configs[0]'s UNet (2-D, attention at level 1): eager launches, the HIP-graph replay of the forward, and the
+    chain whose noise goes through torch's own bf16 `randn` (host_noise.ENABLED = False: no byte draws, no table, no pinned staging, no lookup inside the step's
+    kernel) must produce the SAME images bit for bit and leave the CPU generator in the same state (reference: inferer.py:83-143 + ddpm.py:191-252)."""
+    from generativemodels_amd import host_noise as H
+    from generativemodels_amd.inferers import DiffusionInferer
+    from generativemodels_amd.networks.schedulers import DDPMScheduler
+    cfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(32, 64), attention_levels=(False, True), num_res_blocks=1, num_head_channels=64)
+    torch.manual_seed(0)
+    m = _nets().DiffusionModelUNet(**cfg).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    R.derandomize_zeros(sd)
+    m.load_state_dict(sd)
+    m = m.to(DEV, torch.bfloat16)
+    sched = DDPMScheduler(1000)
+    sched.set_timesteps(8)
+    noise = torch.randn((4, 1, 64, 64), generator=torch.Generator().manual_seed(7)).to(DEV, torch.bfloat16)
+
+    def chain(graph):
+        torch.manual_seed(3)
+        out = DiffusionInferer(sched, use_hip_graph=graph).sample(noise, m, sched, verbose=False)
+        return out, torch.get_rng_state()
+
+    (a, sa), (b, sb) = chain(False), chain(True)
+    monkeypatch.setattr(H, "ENABLED", False)
+    (c, sc), (d, sd_) = chain(False), chain(True)
+    assert torch.isfinite(a.float()).all()
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    assert torch.equal(sa, sb) and torch.equal(sa, sc) and torch.equal(sa, sd_)
+
+
 def test_sampling_loop_takes_its_timestep_rows_from_one_batched_pass():
     """(round 5) `DiffusionInferer.sample` computes the timestep rows of the whole chain once (`DiffusionModelUNet.time_rows_table`: embedding, two-layer
     MLP and the stacked `time_emb_proj` GEMM over all T timesteps -- 4 launches per chain instead of 4 per step; reference:
