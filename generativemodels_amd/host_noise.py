@@ -112,6 +112,9 @@ def randn(shape, dtype: torch.dtype, generator: Optional[torch.Generator], devic
         return torch.randn(shape, dtype=dtype, generator=generator).to(dev)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
+    if torch.cuda.is_current_stream_capturing():
+        # the draw is HOST work (the reference's CPU generator): a capture would bake one draw's staging buffer into the graph and replay stale bytes
+        raise RuntimeError("a noise draw from the CPU generator cannot be captured into a HIP graph: capture the model forward, run the scheduler step outside")
     if ENABLED and dtype == torch.bfloat16 and n >= 16 and n % 16 == 0 and table_matches_torch():
         from . import ops
 
@@ -122,6 +125,6 @@ def randn(shape, dtype: torch.dtype, generator: Optional[torch.Generator], devic
         if as_bits:  # (a scheduler step: ops.sched_step expands the bytes inside its own kernel)
             return ops.NoiseBits(bits, tab, shape)
         return ops.normal_bf16_from_bits(bits, tab).reshape(shape)
-    if not ENABLED or torch.cuda.is_current_stream_capturing():
+    if not ENABLED:
         return torch.randn(shape, dtype=dtype, generator=generator).to(dev)
     return _staged_copy(lambda buf: torch.randn((n,), dtype=dtype, generator=generator, out=buf), n, dtype, dev).reshape(shape)
