@@ -382,6 +382,8 @@ extern "C" int gm_conv_dma_variant(int cfg);
 extern "C" int gm_conv_sn_eligible(const GmConvDesc* d);
 extern "C" long long gm_conv_sn_lds_bytes(int cfg);
 static inline bool conv_is_sn(int cfg) { return cfg == CONV_CFG_SN || cfg == CONV_CFG_SN2D; }
+// cfg 25 with stride 2 walks the stride-1 grid (2 n - 1 positions per axis) and stores its even positions (conv_sn.hip)
+static inline long long conv_sn_walk(const GmConvDesc* d, long long n) { return (d->cfg == CONV_CFG_SN2D && d->sh == 2) ? 2 * n - 1 : n; }
 static inline bool conv_is_dma(int cfg) { return cfg == CONV_CFG_DMA || (cfg >= 14 && cfg <= 19) || conv_is_sn(cfg); }
 // HBM-bound end convolutions (conv_edge.hip): cfg 12 = C_in <= 4, cfg 13 = C_out == 1; 4x4x16 tiles
 #define CONV_CFG_CIN 12
@@ -604,7 +606,7 @@ extern "C" long long gm_conv_stats_slots(const GmConvDesc* d) {
   const bool fused = conv_is_fast(d->cfg) || conv_is_dma(d->cfg) || d->cfg == CONV_CFG_CIN;
   if (!fused) return 0;
   if (conv_is_sn(d->cfg))  // four channels per lane straight from the accumulators: whatever the kernel takes, it also counts
-    return gm_conv_sn_eligible(d) ? (long long)((d->Do + (1 << d->ltd) - 1) >> d->ltd) * ((d->Ho + (1 << d->lth) - 1) >> d->lth) * ((d->Wo + 15) >> 4) : 0;
+    return gm_conv_sn_eligible(d) ? (long long)((d->Do + (1 << d->ltd) - 1) >> d->ltd) * ((conv_sn_walk(d, d->Ho) + (1 << d->lth) - 1) >> d->lth) * ((conv_sn_walk(d, d->Wo) + 15) >> 4) : 0;
   const int vecw = d->dtype == GM_F32 ? 4 : 8;
   const bool lds_epilogue = (d->Cout % vecw == 0) && (d->y_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0) &&
                             (!d->res || ((d->res_ld % vecw == 0) && ((reinterpret_cast<uintptr_t>(d->res) & 15) == 0)));
@@ -647,7 +649,7 @@ extern "C" int gm_conv_forward(const GmConvDesc* dp, void* stream) {
   GM_REQUIRE(d.stats == nullptr || gm_conv_stats_slots(dp) > 0, "this tile configuration does not fuse the output statistics");
   // cfg 17 (sub-pixel up-sampling): the tiles walk the low-resolution grid, once per output parity
   const bool subpixel = d.cfg == 17;
-  const long long De = subpixel ? d.Ds : d.Do, He = subpixel ? d.Hs : d.Ho, We = subpixel ? d.Ws : d.Wo;
+  const long long De = subpixel ? d.Ds : d.Do, He = subpixel ? d.Hs : conv_sn_walk(dp, d.Ho), We = subpixel ? d.Ws : conv_sn_walk(dp, d.Wo);
   const long long ntd = (De + (1 << d.ltd) - 1) >> d.ltd, nth = (He + (1 << d.lth) - 1) >> d.lth, ntw = (We + (1 << d.ltw) - 1) >> d.ltw;
   const long long ncb = (d.Cout + bn - 1) / bn;
   const bool splitk = d.ksplit > 1 && d.kpartial != nullptr;

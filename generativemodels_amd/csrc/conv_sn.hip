@@ -71,7 +71,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
   const int l15 = lane & 15, q = lane >> 4;
 
   // ---- the work item: (tile, 16-channel block); XCD x owns a contiguous range, the blocks of a tile are neighbours in it (their patches meet in one L2) ----
-  const int ntd = (p.Do + TD - 1) / TD, nth = (p.Ho + TH - 1) / TH, ntw = (p.Wo + TW - 1) / TW;
+  // images, stride 2 (the Downsample convolution of a 2-D UNet, diffusion_model_unet.py:510-518): out(i, j) = the stride-1 result at (2 i, 2 j) -- the tiles walk
+  // the STRIDE-1 grid of (2 Ho - 1) x (2 Wo - 1) positions and the epilogue stores the even ones (4x the MFMAs of a launch whose cost is its latency chain; the
+  // generic kernel it replaces took 13 us and left the statistics to a stand-alone pass)
+  const bool s2 = ND == 2 && p.sh == 2;  // (work-group uniform; host: sh == sw)
+  const int H1 = s2 ? 2 * p.Ho - 1 : p.Ho, W1 = s2 ? 2 * p.Wo - 1 : p.Wo;
+  const int ntd = (p.Do + TD - 1) / TD, nth = (H1 + TH - 1) / TH, ntw = (W1 + TW - 1) / TW;
   const int ncb = (p.Cout + BN - 1) / BN;
   const int nchunks = p.Cin / BK, cout_pad = (p.Cout + 15) & ~15;
   const unsigned nwork = (unsigned)p.N * ntd * nth * ntw * ncb;
@@ -328,8 +333,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv_sn_kernel(const
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int m = (wave * MF + mf) * 16 + l15;
-    const int od = od0 + m_plane(m), oh = oh0 + m_line(m), ow = ow0 + (m & 15);
-    if (od < p.Do && oh < p.Ho && ow < p.Wo && co4 < p.Cout) {
+    const int od = od0 + m_plane(m);
+    int oh = oh0 + m_line(m), ow = ow0 + (m & 15);
+    bool keep = true;
+    if (s2) { keep = ((oh | ow) & 1) == 0; oh >>= 1; ow >>= 1; }  // the even positions of the stride-1 grid are the strided outputs
+    if (keep && od < p.Do && oh < p.Ho && ow < p.Wo && co4 < p.Cout) {
       const long long vox = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
       float o[4];
 #pragma unroll
@@ -411,7 +419,9 @@ extern "C" int gm_conv_sn_eligible(const GmConvDesc* d) {
   const bool geom3 = d->cfg == 24 && d->kd == 3 && d->ltd == 2 && d->lth == 2 && d->ltw == 4;
   const bool geom2 = d->cfg == 25 && d->kd == 1 && d->Ds == 1 && d->Do == 1 && d->pd == 0 && d->ltd == 0 && d->lth == 4 && d->ltw == 4 &&
                      (d->in_mode == 0 || d->fd == 1);
-  return (geom3 || geom2) && (d->dtype == GM_F32 || d->dtype == GM_BF16) && d->kh == 3 && d->kw == 3 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
+  const bool stride1 = d->sd == 1 && d->sh == 1 && d->sw == 1;
+  const bool stride2_image = geom2 && d->sd == 1 && d->sh == 2 && d->sw == 2 && d->in_mode == 0 && !d->skip_x[0];  // (stride-1 result, even positions stored)
+  return (geom3 || geom2) && (d->dtype == GM_F32 || d->dtype == GM_BF16) && d->kh == 3 && d->kw == 3 && (stride1 || stride2_image) &&
          d->dd == 1 && d->dh == 1 && d->dw == 1 && (d->in_mode == 0 || (d->in_mode == 1 && d->fd >= 1 && d->fh >= 1 && d->fw >= 1)) && d->Cin % bk == 0 &&
          d->x_ld % vecw == 0 &&
          (reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && !(d->ksplit > 1 && d->kpartial) &&

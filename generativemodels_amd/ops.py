@@ -744,6 +744,8 @@ NARROW_N_2D = os.environ.get("GM_CONV_SN2D", "1") != "0"
 # on the generic tile kernel (27 us, the longest launch of that forward, and a stand-alone statistics pass behind it)
 EDGE_2D_AS_3D = os.environ.get("GM_CONV_EDGE2D", "1") != "0"
 NARROW_N_2D_MAX_FLOP = float(os.environ.get("GM_CONV_SN2D_MAX_FLOP", "3e10"))
+# ... and the stride-2 Downsample convolution of a 2-D UNet on the same kernel (the stride-1 result's even positions: conv_sn.hip), statistics fused
+NARROW_N_2D_STRIDE2 = os.environ.get("GM_CONV_SN2D_STRIDE2", "1") != "0"
 NARROW_HEAD_MAX_FLOP = 1.0e9
 # (Rounds 4-5 built three more tile structures on v_mfma_f32_32x32x16_bf16 -- cfg 21: 16-channel half-chunks, three work-groups per CU; cfg 22: 512-voxel
 #  tiles with 16-channel weight panels; cfg 23: cfg 22's image on four waves of 4 x 2 blocks -- each verified bit-level and measured: all tie or lose against
@@ -889,8 +891,9 @@ def _choose_conv_cfg(desc: GmConvDesc, n_vox_out: int, force_cfg: Optional[int] 
         # (512-voxel tiles -- cfg 16 / 18, one work-group per CU, half the weight-panel traffic -- measure within +-5 % of two 256-voxel
         # work-groups in isolation and 5-15 % slower on the 64 -> 64 layers inside the forward: profiles/r02_conv_tile_configs.txt,
         # r02_layer_times_cfg16_rule.txt.  They stay available through force_cfg.)
-    if (force_cfg is None and NARROW_N_2D and DMA_CONV and desc.kd == 1 and desc.Ds == 1 and desc.kh == 3 and desc.kw == 3 and desc.sh == 1 and desc.sw == 1
-            and 2.0 * n_vox_out * desc.N * cout * desc.Cin * 9 <= NARROW_N_2D_MAX_FLOP):
+    if (force_cfg is None and NARROW_N_2D and DMA_CONV and desc.kd == 1 and desc.Ds == 1 and desc.kh == 3 and desc.kw == 3
+            and ((desc.sh == 1 and desc.sw == 1) or (NARROW_N_2D_STRIDE2 and desc.sh == 2 and desc.sw == 2))
+            and 2.0 * n_vox_out * desc.N * cout * desc.Cin * 9 * desc.sh * desc.sw <= NARROW_N_2D_MAX_FLOP):
         order = [25] + order  # images: the K-complete 16-channel-block kernel (the C side rejects what it does not cover)
     if force_cfg is None and n_vox_out * desc.N <= 256 * 64:  # small problem: favour more, smaller workgroups (the LDS-DMA kernels stay first)
         dma_first = [c for c in order if c in (11, 12, 15, 18, 19)]  # (12: the C_in <= 4 edge kernel -- its cost is the output store, whatever the tile)

@@ -345,6 +345,43 @@ def test_conv_small_volume_narrow_output_block_kernel(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", [("unet", 32, 32, (64, 64), 1, 1, 16), ("unet-ragged", 64, 48, (33, 21), 1, 1, 3), ("aekl-high-pad", 32, 32, (32, 40), 0, 1, 2),
+                                  ("odd", 96, 24, (17, 19), 1, 1, 2), ("tiny", 32, 32, (4, 6), 1, 1, 5)], ids=lambda c: c[0])
+def test_conv_2d_stride2_on_the_narrow_output_block_kernel(case, dtype):
+    """(round 6) The stride-2 3x3 Downsample convolution of a 2-D UNet (diffusion_model_unet.py:510-518; AutoencoderKL's asymmetric high-side pad,
+    autoencoderkl.py:107-121) on cfg 25: the kernel walks the stride-1 grid and stores its even positions, output statistics (of the STORED values only) fused --
+    against fp64 F.conv2d(stride=2), against the generic tile kernel it replaces, ragged / odd extents, images smaller than a tile; run-to-run bitwise."""
+    ops = _ops()
+    name, cin, cout, sp, plo, phi, n = case
+    x = _rand((n, cin, *sp), 891).to(dtype)
+    w = (_rand((cout, cin, 3, 3), 892) / math.sqrt(cin * 9)).to(dtype)
+    b = _rand((cout,), 893) * 0.1
+    want = F.conv2d(F.pad(x.double(), (plo, phi, plo, phi)), w.double(), b.double(), stride=2)
+    kw = dict(kernel=3, stride=2, padding=plo, pad_hi=phi, want_stats=True)
+    wd = w.to(DEV)
+    ops.start_profile()
+    got = ops.conv(_cl(x), wd, b.to(DEV), **kw)
+    took = any("cfg25" in nm for nm, _, _ in ops.stop_profile())
+    assert took == (n * want.shape[2] * want.shape[3] >= ops.DMA_CONV_MIN_VOXELS), "cfg 25 takes every such convolution of at least 256 output pixels"
+    assert tuple(got.shape) == (n, want.shape[2], want.shape[3], cout)
+    _check(_cf(got), want, dtype, f"stride-2 image convolution, {name}")
+    assert took == hasattr(got, "_gm_cstats")
+    st = ops.channel_stats(got).sum(0).cpu()
+    v = got.float().cpu().double().reshape(n, -1, cout)
+    assert torch.allclose(st[..., 0], v.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1], (v * v).sum(1), rtol=1e-4, atol=1e-2)
+    keep = ops.NARROW_N_2D_STRIDE2
+    try:
+        ops.NARROW_N_2D_STRIDE2 = False
+        other = ops.conv(_cl(x), wd, b.to(DEV), **kw)
+    finally:
+        ops.NARROW_N_2D_STRIDE2 = keep
+    tol = (2 ** -6 if dtype == torch.bfloat16 else 1e-4) * max(1.0, want.abs().max().item())
+    assert (other.float() - got.float()).abs().max().item() <= tol
+    again = ops.conv(_cl(x), wd, b.to(DEV), **kw)
+    assert torch.equal(again, got) and torch.equal(ops.channel_stats(again), ops.channel_stats(got))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("case", [(1, 32, (64, 64), 4), (3, 64, (33, 21), 2), (4, 40, (16, 50), 1), (2, 8, (7, 9), 3)], ids=lambda c: f"cin{c[0]}-cout{c[1]}")
 def test_conv_in_of_a_2d_network_on_the_edge_kernel(case, dtype):
     """(round 6) conv_in of a 2-D DiffusionModelUNet (C_in <= 4, 3x3, stride 1; BASELINE configs[0]: 1 -> 32 at 16 x 64 x 64) runs on the C_in <= 4 edge kernel
