@@ -332,13 +332,44 @@ __global__ __launch_bounds__(256) void gn_finalize_channels_kernel(const double*
 // order conv_sn.hip's consumer-side prologue reproduces (gm_common.h: gn_short_*), so that a norm finalised there and one finalised here agree bit for bit.
 __global__ __launch_bounds__(256) void gn_finalize_channels_short_kernel(const double* __restrict__ s0, int S0, int C0, const double* __restrict__ s1, int S1, int C1,
                                                                         int N, int G, long long V, float eps, const float* __restrict__ gamma,
-                                                                        const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
-  extern __shared__ double gn_short_sums[];  // [cpg][2], then the group's pair
+                                                                        const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                                                        int staged_rows) {
+  extern __shared__ double gn_short_sums[];  // [cpg][2], then the group's pair; staged form: behind them [rows][cpg][2]
   const int n = blockIdx.x / G, g = blockIdx.x % G, t = threadIdx.x;
   const int C = C0 + C1, cpg = C / G;
-  for (int j = t; j < cpg; j += 256) {
-    const double2 v = gn_short_channel_sum(s0, S0, C0, s1, S1, C1, N, n, g * cpg + j);
-    gn_short_sums[2 * j] = v.x; gn_short_sums[2 * j + 1] = v.y;
+  if (staged_rows > 0) {
+    // every (row, channel) partial of the group is requested at once by the whole block -- ONE round trip instead of S / 8 per channel thread -- and a thread then adds its
+    // channel's rows from LDS in the same row order (fp64): the same sums, bit for bit, as gn_short_channel_sum (8-row batches walked by one thread: 9 us at 128 rows)
+    double* rows = gn_short_sums + 2 * cpg + 2;
+    for (int it0 = 0; it0 < staged_rows * cpg; it0 += 256 * 8) {  // eight requests per thread before the first wait
+      double2 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = it0 + k * 256 + t;
+        const int j = it % cpg, r = it / cpg, c = g * cpg + j;
+        const bool first = c < C0;
+        const bool ok = it < staged_rows * cpg && r < (first ? S0 : S1);
+        const double* src = first ? s0 + ((long long)n * C0 + c) * 2 : s1 + ((long long)n * C1 + (c - C0)) * 2;
+        v[k] = ok ? *reinterpret_cast<const double2*>(src + (long long)r * ((long long)N * (first ? C0 : C1) * 2)) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = it0 + k * 256 + t;
+        if (it < staged_rows * cpg) { rows[2 * it] = v[k].x; rows[2 * it + 1] = v[k].y; }
+      }
+    }
+    __syncthreads();
+    for (int j = t; j < cpg; j += 256) {
+      const int S = (g * cpg + j) < C0 ? S0 : S1;
+      double a = 0.0, b = 0.0;
+      for (int r = 0; r < S; ++r) { a += rows[2 * (r * cpg + j)]; b += rows[2 * (r * cpg + j) + 1]; }
+      gn_short_sums[2 * j] = a; gn_short_sums[2 * j + 1] = b;
+    }
+  } else {
+    for (int j = t; j < cpg; j += 256) {
+      const double2 v = gn_short_channel_sum(s0, S0, C0, s1, S1, C1, N, n, g * cpg + j);
+      gn_short_sums[2 * j] = v.x; gn_short_sums[2 * j + 1] = v.y;
+    }
   }
   __syncthreads();
   if (t == 0) {
@@ -365,9 +396,13 @@ extern "C" int gm_gn_finalize_channels(const double* stats0, int S0, int C0, con
   GM_REQUIRE(G > 0 && (C0 + C1) % G == 0, "channels must be divisible by groups");
   if (N == 0) return 0;
   const int cpg = (C0 + C1) / G;
-  if (S0 <= GN_SHORT_MAX_ROWS && (C1 == 0 || S1 <= GN_SHORT_MAX_ROWS) && cpg <= 4096)  // short tables: the order the consumer-side finalisation shares (ops.GnRecipe)
-    gn_finalize_channels_short_kernel<<<N * G, 256, (size_t)(2 * cpg + 2) * sizeof(double), (hipStream_t)stream>>>(stats0, S0, C0, stats1, S1, C1, N, G, V, eps, gamma, beta,
-                                                                                                               scale, shift);
+  if (S0 <= GN_SHORT_MAX_ROWS && (C1 == 0 || S1 <= GN_SHORT_MAX_ROWS) && cpg <= 4096) {  // short tables: the order the consumer-side finalisation shares (ops.GnRecipe)
+    const int smax = C1 && S1 > S0 ? S1 : S0;
+    const size_t staged = (size_t)smax * cpg * 2 * sizeof(double);
+    const int staged_rows = staged <= 48 * 1024 ? smax : 0;  // (else: a thread walks its channel's rows itself -- the same sums)
+    gn_finalize_channels_short_kernel<<<N * G, 256, (size_t)(2 * cpg + 2) * sizeof(double) + (staged_rows ? staged : 0), (hipStream_t)stream>>>(
+        stats0, S0, C0, stats1, S1, C1, N, G, V, eps, gamma, beta, scale, shift, staged_rows);
+  }
   else
     gn_finalize_channels_kernel<<<N * G, 256, 0, (hipStream_t)stream>>>(stats0, S0, C0, stats1, S1, C1, N, G, V, eps, gamma, beta, scale, shift);
   GM_LAUNCH_CHECK();
