@@ -366,7 +366,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_dma_kernel(const GmAttnDes
 // block's stride is a multiple of the channel vectors per row, so a thread keeps its 8 channels over the walk; threads of a channel vector are
 // added in thread order in fp64 and every (block, channel) entry is stored once -- deterministic, and one gn_stats launch less per block.
 #define ATTN_COMBINE_MAX_BLOCKS 256
-__global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, const float* __restrict__ part, int nsplit) {
+// NS: the slice count as a compile-time constant (2 / 4 / 8; 0 = run-time): with a run-time bound hipcc walks the slices one dependent load at a time (two loops: the maxima,
+// then the weighted sums); unrolled, every slice's loads are in flight before the first wait (the same finding as kv_merge_one, small_ops.hip).  Same arithmetic, same order.
+template <int NS>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, const float* __restrict__ part, int nsplit_rt) {
+  const int nsplit = NS ? NS : nsplit_rt;
   __shared__ float red[256][17];
   const int dv = p.dh / 8;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
@@ -379,15 +383,35 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const GmAttnDesc p, c
     const long long qi = (long long)bh * p.Lq + q;
     const float* row = part + qi * (p.dh + 4);
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, row[s * stride + p.dh]);
     float L = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nsplit; ++s) {
-      const float* r = row + s * stride;
-      const float w = __expf(r[p.dh] - M);             // an empty slice has maximum -inf: weight 0
-      L += w * r[p.dh + 1];
-      const float4 a = *reinterpret_cast<const float4*>(r + c), b2 = *reinterpret_cast<const float4*>(r + c + 4);
-      o[0] += w * a.x; o[1] += w * a.y; o[2] += w * a.z; o[3] += w * a.w;
-      o[4] += w * b2.x; o[5] += w * b2.y; o[6] += w * b2.z; o[7] += w * b2.w;
+    if constexpr (NS > 0) {
+      float ms[NS], ls[NS];
+      float4 av[NS], bv[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {  // every slice's state and output vectors requested before the first use
+        const float* r = row + s * stride;
+        ms[s] = r[p.dh]; ls[s] = r[p.dh + 1];
+        av[s] = *reinterpret_cast<const float4*>(r + c); bv[s] = *reinterpret_cast<const float4*>(r + c + 4);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) M = fmaxf(M, ms[s]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float w = __expf(ms[s] - M);             // an empty slice has maximum -inf: weight 0
+        L += w * ls[s];
+        o[0] += w * av[s].x; o[1] += w * av[s].y; o[2] += w * av[s].z; o[3] += w * av[s].w;
+        o[4] += w * bv[s].x; o[5] += w * bv[s].y; o[6] += w * bv[s].z; o[7] += w * bv[s].w;
+      }
+    } else {
+      for (int s = 0; s < nsplit; ++s) M = fmaxf(M, row[s * stride + p.dh]);
+      for (int s = 0; s < nsplit; ++s) {
+        const float* r = row + s * stride;
+        const float w = __expf(r[p.dh] - M);             // an empty slice has maximum -inf: weight 0
+        L += w * r[p.dh + 1];
+        const float4 a = *reinterpret_cast<const float4*>(r + c), b2 = *reinterpret_cast<const float4*>(r + c + 4);
+        o[0] += w * a.x; o[1] += w * a.y; o[2] += w * a.z; o[3] += w * a.w;
+        o[4] += w * b2.x; o[5] += w * b2.y; o[6] += w * b2.z; o[7] += w * b2.w;
+      }
     }
     const float inv = 1.0f / L;
     if (p.lse && c == 0) p.lse[qi] = M + __logf(L);
@@ -518,7 +542,13 @@ extern "C" int gm_attention_dma_try(const GmAttnDesc* dp, void* stream) {
   if (d.dh == 64) { if (qf == 2) launch_attn_dma<64, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<64, 1>(d, vt, lk_pad, part, sp, st); }
   else if (d.dh == 128) { if (qf == 2) launch_attn_dma<128, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<128, 1>(d, vt, lk_pad, part, sp, st); }
   else { if (qf == 2) launch_attn_dma<256, 2>(d, vt, lk_pad, part, sp, st); else launch_attn_dma<256, 1>(d, vt, lk_pad, part, sp, st); }
-  if (sp > 1) attn_combine_kernel<<<dim3(attn_combine_blocks(d), (unsigned)(d.B * d.H)), 256, 0, st>>>(d, part, sp);
+  if (sp > 1) {
+    const dim3 cg(attn_combine_blocks(d), (unsigned)(d.B * d.H));
+    if (sp == 2) attn_combine_kernel<2><<<cg, 256, 0, st>>>(d, part, sp);
+    else if (sp == 4) attn_combine_kernel<4><<<cg, 256, 0, st>>>(d, part, sp);
+    else if (sp == 8) attn_combine_kernel<8><<<cg, 256, 0, st>>>(d, part, sp);
+    else attn_combine_kernel<0><<<cg, 256, 0, st>>>(d, part, sp);
+  }
   return 1;
 }
 
